@@ -1,0 +1,177 @@
+"""ctypes bindings for the TEST-ONLY checkers under oracle/ (the C restatement and, on a GPU box,
+the driver for the reference's own kernels).  Never imported by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class Scoring(C.Structure):
+    _fields_ = [("match", C.c_int), ("mismatch", C.c_int), ("gap_read", C.c_int), ("gap_ref", C.c_int)]
+
+
+class Trace(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("valid", "best_read_index", "best_ref_index", "ref_position",
+                                       "qstart", "qend", "alignment_offset", "best_score")]
+
+
+class AlignRes(C.Structure):
+    _fields_ = [("ok", C.c_int), ("position_offset", C.c_int), ("qstart", C.c_int), ("qend", C.c_int),
+                ("nm", C.c_int), ("identity", C.c_float), ("score_token", C.c_float)]
+
+
+ALIGN_DTYPE = np.dtype([("ok", "i4"), ("position_offset", "i4"), ("qstart", "i4"), ("qend", "i4"),
+                        ("nm", "i4"), ("identity", "f4"), ("score_token", "f4")])
+
+DEFAULT_SCORING = dict(match=10, mismatch=-15, gap_read=-20, gap_ref=-20)
+
+
+def _build(target):
+    subprocess.check_call(["make", "-C", ORACLE_DIR, target], stdout=subprocess.DEVNULL)
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ORACLE_DIR, "libngm_oracle.so")
+        if not os.path.exists(path):
+            _build("libngm_oracle.so")
+        lib = C.CDLL(path)
+        lib.ngm_oracle_batch_score.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                               C.c_int, C.c_int, C.POINTER(Scoring), C.c_int, C.c_void_p, C.c_int]
+        lib.ngm_oracle_batch_align.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                               C.c_int, C.c_int, C.POINTER(Scoring), C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+        lib.ngm_oracle_align_trace.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                               C.POINTER(Scoring), C.c_int, C.POINTER(Trace), C.c_void_p]
+        _oracle = lib
+    return _oracle
+
+
+def _sc(scoring):
+    s = dict(DEFAULT_SCORING)
+    if scoring:
+        s.update(scoring)
+    return Scoring(**s)
+
+
+def oracle_score(mode, ref, qry, c, scoring=None, variant=0, nthreads=1):
+    """ref [n, q+c] uint8, qry [n, q] uint8 -> float32[n]"""
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    n, q = qry.shape
+    assert ref.shape == (n, q + c)
+    out = np.empty(n, dtype=np.float32)
+    sc = _sc(scoring)
+    oracle().ngm_oracle_batch_score(mode, n, ref.ctypes.data, ref.strides[0], qry.ctypes.data, qry.strides[0],
+                                    q, c, C.byref(sc), variant, out.ctypes.data, nthreads)
+    return out
+
+
+def oracle_align(mode, ref, qry, c, scoring=None, variant=0, hard_clip=0, silent_clip=0, nthreads=1):
+    """-> (structured array ALIGN_DTYPE [n], cigars list[bytes], mds list[bytes])"""
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    n, q = qry.shape
+    stride = 4 * max(1, q)
+    res = np.zeros(n, dtype=ALIGN_DTYPE)
+    cig = np.zeros((n, stride), dtype=np.uint8)
+    md = np.zeros((n, stride), dtype=np.uint8)
+    sc = _sc(scoring)
+    oracle().ngm_oracle_batch_align(mode, n, ref.ctypes.data, ref.strides[0], qry.ctypes.data, qry.strides[0],
+                                    q, c, C.byref(sc), variant, hard_clip, silent_clip, res.ctypes.data,
+                                    cig.ctypes.data, md.ctypes.data, stride, nthreads)
+    cigs = [bytes(r).split(b"\0", 1)[0] for r in cig]
+    mds = [bytes(r).split(b"\0", 1)[0] for r in md]
+    return res, cigs, mds
+
+
+def oracle_trace(mode, ref, qry, c, scoring=None, variant=0):
+    """Raw kernel-level outputs: (results4 int16 [n,4] as the reference leaves them, rle int16 [n, 2*AL],
+    valid bool[n], best_score int32[n])."""
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    n, q = qry.shape
+    al = 2 * q + c + 1
+    res = np.zeros((n, 4), dtype=np.int16)
+    rle = np.zeros((n, 2 * al), dtype=np.int16)
+    valid = np.zeros(n, dtype=bool)
+    best = np.zeros(n, dtype=np.int32)
+    sc = _sc(scoring)
+    tr = Trace()
+    lib = oracle()
+    for i in range(n):
+        lib.ngm_oracle_align_trace(mode, ref[i].ctypes.data, qry[i].ctypes.data, q, c, C.byref(sc), variant,
+                                   C.byref(tr), rle[i].ctypes.data)
+        valid[i] = bool(tr.valid)
+        best[i] = tr.best_score
+        if tr.valid:
+            res[i] = (tr.ref_position, tr.qstart, tr.qend, tr.alignment_offset)
+        else:
+            res[i] = (tr.best_read_index, tr.best_ref_index, tr.qend, 0)
+    return res, rle, valid, best
+
+
+# ---------------------------------------------------------------------------------------------
+# reference kernels on the GPU (oracle/_ref/*.co via oracle/libngm_ref_runner.so)
+# ---------------------------------------------------------------------------------------------
+def ref_co_path(variant, q, c, scoring=None):
+    s = dict(DEFAULT_SCORING)
+    if scoring:
+        s.update(scoring)
+    name = "ngm_ocl_%s_q%d_c%d_m%d_x%d_gr%d_gf%d.co" % (("gpu", "cpu", "gpu1")[variant], q, c, s["match"],
+                                                         -s["mismatch"], -s["gap_read"], -s["gap_ref"])
+    return os.path.join(ORACLE_DIR, "_ref", name)
+
+
+_runner = None
+
+
+def ref_runner():
+    global _runner
+    if _runner is None:
+        path = os.path.join(ORACLE_DIR, "libngm_ref_runner.so")
+        lib = C.CDLL(path)
+        lib.ngm_ref_run_score.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        lib.ngm_ref_run_align.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        _runner = lib
+    return _runner
+
+
+def ref_score(variant, mode, ref, qry, c, scoring=None):
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    n, q = qry.shape
+    out = np.empty(n, dtype=np.float32)
+    ms = C.c_float(0)
+    co = ref_co_path(variant, q, c, scoring)
+    r = ref_runner().ngm_ref_run_score(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c,
+                                       out.ctypes.data, C.byref(ms))
+    if r != n:
+        raise RuntimeError("reference kernel run failed (%s)" % co)
+    return out, ms.value
+
+
+def ref_align(variant, mode, ref, qry, c, scoring=None):
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    n, q = qry.shape
+    al = 2 * q + c + 1
+    res = np.zeros((n, 4), dtype=np.int16)
+    rle = np.zeros((n, 2 * al), dtype=np.int16)
+    ms = C.c_float(0)
+    co = ref_co_path(variant, q, c, scoring)
+    r = ref_runner().ngm_ref_run_align(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c,
+                                       res.ctypes.data, rle.ctypes.data, C.byref(ms))
+    if r != n:
+        raise RuntimeError("reference kernel run failed (%s)" % co)
+    return res, rle, ms.value
