@@ -144,7 +144,8 @@ void ngm_oracle_align_trace(int mode, const char *ref, const char *qry, int q, i
 	if (!local) {
 		/* argmax over the last row, first strict maximum, sentinel slot included (:308-315 / :135-140) */
 		for (int d = 0; d <= c; ++d) if (H[d] > best) { best = H[d]; bri = L - 1; bci = d; }
-		if (L == 0) bri = -1; /* CPU build stores read_index-1; GPU build leaves garbage */
+		/* empty read: CPU build stores read_index-1 = -1 (:144); GPU build zeroes it (:319-321) */
+		if (L == 0) bri = (variant == NGM_ORACLE_VARIANT_CPU) ? -1 : 0;
 	}
 	out->best_read_index = bri;
 	out->best_ref_index = bci;

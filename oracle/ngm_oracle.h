@@ -8,7 +8,7 @@
  * Every function cites the reference file:line it restates (paths relative to
  * /root/reference).  Pinning: see oracle/README.md -- the restatement is checked
  * against the reference's own OpenCL kernels compiled (unmodified, by the ROCm
- * OpenCL toolchain) for gfx950 and run on the MI355X (oracle/_ref/*.co), and
+ * OpenCL toolchain) for gfx950 and run on the MI355X (code objects under oracle/_ref), and
  * against golden vectors captured from those runs (tests/golden/).
  */
 #ifndef NGM_ORACLE_H
