@@ -1,0 +1,39 @@
+"""Build recipe for the HIP library (gfx950 only).  `python -m nextgenmap_amd.build`"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+LIB = os.path.join(HERE, "libngm_hip.so")
+SOURCES = ["ngm_hip.cpp", "ialignment_adapter.cpp"]
+HEADERS = ["sw_device.h", "align_device.h", "cigar_md.h", os.path.join("..", "..", "include", "ngm_hip.h"),
+           os.path.join("..", "..", "include", "ngm_ialignment.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + srcs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

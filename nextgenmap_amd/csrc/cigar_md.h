@@ -1,0 +1,116 @@
+// cigar_md.h -- host post-processing of a traceback record into SAM CIGAR / MD / NM / identity.
+// Produces what NextGenMap's SWOclCigar::computeCigarMD produces
+// (lib/mason/opencl/SWOclCigar.cpp:430-615, bisulfite / SLAM-seq branches excluded), but from the
+// compact device runs of align_device.h instead of the reference's (len<<4|op) short array: the
+// '=' / 'X' split of a diagonal run is re-derived here from the two sequences.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/ngm_hip.h"
+
+namespace ngm {
+
+struct CigarParams {
+	int match;     // > 0
+	int mismatch;  // < 0
+	int variant;   // NGM_VARIANT_*
+	int hard_clip;
+	int silent_clip;
+};
+
+// symbol classes of the reference's kernels (oclDefines.cl:64-80)
+inline int host_sym_class(unsigned char ch) {
+	switch (ch) {
+	case 'A': case 'a': return 0;
+	case 'C': case 'c': return 1;
+	case 'G': case 'g': return 2;
+	case 'T': case 't': return 3;
+	case 'N': case 'n': return 5;
+	case 0: return 6;
+	default: return 4;
+	}
+}
+
+// Is a diagonal column labelled '=' ?  The __GPU__ build compares the characters
+// (oclSwScore.cl:275), the __CPU__ build tests score == match (oclSwScore.cl:64).
+inline bool column_is_eq(const CigarParams &p, unsigned char r, unsigned char f) {
+	if (p.variant == NGM_VARIANT_OCL_GPU) return r == f;
+	const int rc = host_sym_class(r), fc = host_sym_class(f);
+	return rc <= 3 && rc == fc;
+}
+
+inline int put_num(char *dst, int v) { return sprintf(dst, "%d", v); }
+
+// rec: the 8-int record, runs: rec[4] entries in traceback order.
+inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint16_t *runs, const char *ref,
+		const char *qry, ngm_hip_align_out *out) {
+	out->position_offset = 0;
+	out->qstart = 0;
+	out->qend = 0;
+	out->identity = 0.f;
+	out->nm = 0;
+	if (!rec[0]) {  // no alignment could be built: the reference reports Score = -1 (SWOclCigar.cpp:322-327)
+		out->score_token = -1.0f;
+		return;
+	}
+	char *cigar = out->cigar, *md = out->md;
+	int co = 0, mo = 0;
+	const int lead = rec[2], trail = rec[3], nruns = rec[4];
+	const char *refseq = ref + rec[1];
+	if (lead > 0) {
+		if (p.hard_clip == 1) co += sprintf(cigar + co, "%dH", lead);
+		else if (p.silent_clip != 1) co += sprintf(cigar + co, "%dS", lead);
+		out->qstart = lead;
+	}
+	int match = 0, mismatch = 0, total = 0, m_len = 0, md_eq = 0, ref_i = 0, read_i = out->qstart;
+	bool in_x_run = false;  // the reference merges adjacent X columns into one element (one MD prefix)
+	for (int j = nruns - 1; j >= 0; --j) {
+		const int op = runs[j] & 3, len = runs[j] >> 2;
+		total += len;
+		if (op == 1 || op == 0) {
+			for (int k = 0; k < len; ++k) {
+				const bool eq = (op == 1) && column_is_eq(p, (unsigned char) qry[read_i], (unsigned char) refseq[ref_i]);
+				if (eq) {
+					match += 1; md_eq += 1; in_x_run = false;
+				} else {
+					mismatch += 1;
+					if (!in_x_run) { mo += put_num(md + mo, md_eq); md_eq = 0; in_x_run = true; }
+					md[mo++] = refseq[ref_i];
+				}
+				m_len += 1; ref_i += 1; read_i += 1;
+			}
+		} else if (op == 3) {  // deletion: reference bases only
+			in_x_run = false;
+			if (m_len > 0) { co += sprintf(cigar + co, "%dM", m_len); m_len = 0; }
+			co += sprintf(cigar + co, "%dD", len);
+			mo += put_num(md + mo, md_eq);
+			md_eq = 0;
+			md[mo++] = '^';
+			for (int k = 0; k < len; ++k) md[mo++] = refseq[ref_i++];
+			mismatch += len;
+		} else {  // insertion: read bases only
+			in_x_run = false;
+			if (m_len > 0) { co += sprintf(cigar + co, "%dM", m_len); m_len = 0; }
+			co += sprintf(cigar + co, "%dI", len);
+			read_i += len;
+			mismatch += len;
+		}
+	}
+	mo += put_num(md + mo, md_eq);
+	if (m_len > 0) co += sprintf(cigar + co, "%dM", m_len);
+	if (trail > 0) {
+		if (p.hard_clip == 1) co += sprintf(cigar + co, "%dH", trail);
+		else if (p.silent_clip != 1) co += sprintf(cigar + co, "%dS", trail);
+		out->qend = trail;
+	}
+	cigar[co] = 0;
+	md[mo] = 0;
+	out->identity = match * 1.0f / total;
+	out->nm = mismatch;
+	out->score_token = (float) read_i;
+	out->position_offset = rec[1];
+}
+
+}  // namespace ngm

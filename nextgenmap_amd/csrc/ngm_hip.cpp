@@ -1,0 +1,360 @@
+// ngm_hip.cpp -- host side of the flat C ABI (include/ngm_hip.h): context, HBM workspace, kernel
+// dispatch.  Compiled by hipcc for gfx950 only.  There is deliberately no CPU fallback: without a
+// HIP device every entry point fails loudly.
+#include "../../include/ngm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sw_device.h"
+#include "align_device.h"
+#include "cigar_md.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_error(ngm_hip_ctx *ctx, const char *fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                         \
+	do {                                                                                           \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess) {                                                                    \
+			set_error(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return -5;                                                                             \
+		}                                                                                          \
+	} while (0)
+
+template <typename T>
+struct DevBuf {
+	T *p = nullptr;
+	size_t cap = 0;  // elements
+	int reserve(size_t n) {
+		if (n <= cap) return 0;
+		if (p) (void) hipFree(p);
+		p = nullptr;
+		cap = 0;
+		if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return -1;
+		cap = n;
+		return 0;
+	}
+	void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <typename T>
+struct PinnedBuf {
+	T *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t n) {
+		if (n <= cap) return 0;
+		if (p) (void) hipHostFree(p);
+		p = nullptr;
+		cap = 0;
+		if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) return -1;
+		cap = n;
+		return 0;
+	}
+	void release() { if (p) (void) hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct ngm_hip_ctx {
+	int device = 0;
+	ngm_hip_params prm{};
+	ngm::SwConst K{};
+	int q = 0, c = 0, rl = 0, RW = 0, FW = 0;
+	int max_batch = 0;
+	hipStream_t stream = nullptr;
+	// HBM workspace
+	DevBuf<uint32_t> packed;
+	DevBuf<uint16_t> lens, blk_rows;
+	DevBuf<uint8_t> d_ref, d_qry;
+	DevBuf<float> d_scores;
+	DevBuf<uint32_t> dirs;
+	DevBuf<int32_t> d_records;
+	DevBuf<uint16_t> d_runs;
+	// pinned staging for the host-pointer entry points
+	PinnedBuf<uint8_t> h_ref, h_qry;
+	PinnedBuf<float> h_scores;
+	PinnedBuf<int32_t> h_records;
+	PinnedBuf<uint16_t> h_runs;
+	// profiling
+	bool profiling = false;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	bool ev_valid[3] = {false, false, false};
+	std::string error;
+};
+
+namespace {
+
+void set_error(ngm_hip_ctx *ctx, const char *fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	if (ctx) ctx->error = buf;
+}
+
+// ---- kernel dispatch over the compiled corridor widths ------------------------------------------
+// The band width is a compile-time shape exactly as in the reference (its kernels are JIT-compiled
+// with -D corridor_length, lib/mason/opencl/SWOcl.cpp:206-217).  These are the shapes built ahead
+// of time; NGM derives corridor = int(5 + 0.15 * avg_read_len) (src/ReadProvider.cpp:301-305) or
+// 2 * max-consec-indels (src/config/Config.cpp:540-557).
+#define NGM_CORRIDORS(X) X(8) X(12) X(19) X(20) X(27) X(42) X(80)
+
+typedef void (*score_kernel_t)(const uint32_t *, const uint16_t *, const uint16_t *, float *, int, int, int, ngm::SwConst);
+typedef void (*align_kernel_t)(const uint32_t *, const uint16_t *, const uint16_t *, uint32_t *, int32_t *, int, int, int, int, ngm::SwConst);
+
+score_kernel_t find_score_kernel(int c, bool endfree) {
+#define X(C) if (c == C) return endfree ? ngm::sw_score_kernel<C, true> : ngm::sw_score_kernel<C, false>;
+	NGM_CORRIDORS(X)
+#undef X
+	return nullptr;
+}
+align_kernel_t find_align_kernel(int c, bool endfree) {
+#define X(C) if (c == C) return endfree ? ngm::sw_align_kernel<C, true> : ngm::sw_align_kernel<C, false>;
+	NGM_CORRIDORS(X)
+#undef X
+	return nullptr;
+}
+
+int n_blocks_of(int n) { return (n + ngm::kSlots - 1) / ngm::kSlots; }
+
+int reserve_workspace(ngm_hip_ctx *ctx, int n) {
+	const size_t nb = (size_t) n_blocks_of(n);
+	if (ctx->packed.reserve(nb * (size_t) (ctx->RW + ctx->FW) * ngm::kSlots) || ctx->lens.reserve(nb * ngm::kSlots) ||
+			ctx->blk_rows.reserve(nb)) {
+		set_error(ctx, "out of device memory reserving the packed workspace for %d pairs", n);
+		return -12;
+	}
+	return 0;
+}
+
+struct ScopedDevice {
+	int prev = -1;
+	explicit ScopedDevice(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void) hipSetDevice(dev); else prev = -1; }
+	~ScopedDevice() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+int launch_pack(ngm_hip_ctx *ctx, int n, const void *d_ref, const void *d_qry, hipStream_t st) {
+	const int nb = n_blocks_of(n);
+	const size_t lds = (size_t) ngm::kSlots * (ctx->rl + ctx->q);
+	hipLaunchKernelGGL(ngm::pack_pairs_kernel, dim3(nb), dim3(256), lds, st, (const uint8_t *) d_ref,
+			(const uint8_t *) d_qry, n, ctx->q, ctx->rl, ctx->RW, ctx->FW, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p);
+	HIP_TRY(ctx, hipGetLastError());
+	return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ngm_hip_last_error(const ngm_hip_ctx *ctx) { return ctx ? ctx->error.c_str() : g_last_error.c_str(); }
+
+int ngm_hip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
+	if (!p || p->abi_version != NGM_HIP_ABI_VERSION) { set_error(nullptr, "ngm_hip_create: bad params / ABI version"); return nullptr; }
+	if (p->qry_max_len < 2 || p->qry_max_len > 4096 || p->corridor < 2) { set_error(nullptr, "ngm_hip_create: qry_max_len=%d corridor=%d out of range", p->qry_max_len, p->corridor); return nullptr; }
+	if (p->match_bonus <= 0 || p->mismatch_penalty <= 0 || p->gap_read_penalty <= 0 || p->gap_ref_penalty <= 0) {
+		set_error(nullptr, "ngm_hip_create: scores must be positive integers (match %d mismatch %d gap_read %d gap_ref %d)", p->match_bonus, p->mismatch_penalty, p->gap_read_penalty, p->gap_ref_penalty);
+		return nullptr;
+	}
+	if (p->match_bonus + p->mismatch_penalty > 255) { set_error(nullptr, "ngm_hip_create: match_bonus + mismatch_penalty must be <= 255"); return nullptr; }
+	if (!find_score_kernel(p->corridor, false)) {
+		set_error(nullptr, "ngm_hip_create: no kernel compiled for corridor %d (built: 8 12 19 20 27 42 80)", p->corridor);
+		return nullptr;
+	}
+	int ndev = ngm_hip_device_count();
+	if (ndev <= 0) { set_error(nullptr, "ngm_hip_create: no HIP device available (this library has no CPU fallback)"); return nullptr; }
+	if (device < 0 || device >= ndev) { set_error(nullptr, "ngm_hip_create: device %d out of range (%d devices)", device, ndev); return nullptr; }
+	ScopedDevice sd(device);
+	ngm_hip_ctx *ctx = new ngm_hip_ctx();
+	ctx->device = device;
+	ctx->prm = *p;
+	ctx->q = p->qry_max_len;
+	ctx->c = p->corridor;
+	ctx->rl = ctx->q + ctx->c;
+	ctx->RW = ngm::read_words(ctx->q);
+	ctx->FW = ngm::ref_words(ctx->q, ctx->c);
+	ctx->max_batch = p->max_batch > 0 ? p->max_batch : (1 << 20);
+	const int match = p->match_bonus, mismatch = -p->mismatch_penalty, gap_read = -p->gap_read_penalty, gap_ref = -p->gap_ref_penalty;
+	ctx->K.tM = match - mismatch;
+	ctx->K.tZ = -mismatch;
+	ctx->K.gl = gap_ref;
+	ctx->K.gu = gap_read - mismatch;
+	ctx->K.gap_read = gap_read;
+	ctx->K.variant = p->variant;
+	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "ngm_hip_create: hipStreamCreate failed"); delete ctx; return nullptr; }
+	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { set_error(nullptr, "ngm_hip_create: hipEventCreate failed"); ngm_hip_destroy(ctx); return nullptr; }
+	// the pack kernel stages 64 raw pairs in LDS
+	const size_t lds = (size_t) ngm::kSlots * (ctx->rl + ctx->q);
+	if (lds > 160 * 1024 - 2048) { set_error(nullptr, "ngm_hip_create: qry_max_len too large for the LDS staging tile"); ngm_hip_destroy(ctx); return nullptr; }
+	if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) ngm::pack_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+	return ctx;
+}
+
+void ngm_hip_destroy(ngm_hip_ctx *ctx) {
+	if (!ctx) return;
+	ScopedDevice sd(ctx->device);
+	if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+	ctx->packed.release(); ctx->lens.release(); ctx->blk_rows.release(); ctx->d_ref.release(); ctx->d_qry.release();
+	ctx->d_scores.release(); ctx->dirs.release(); ctx->d_records.release(); ctx->d_runs.release();
+	ctx->h_ref.release(); ctx->h_qry.release(); ctx->h_scores.release(); ctx->h_records.release(); ctx->h_runs.release();
+	for (auto &e : ctx->ev) if (e) (void) hipEventDestroy(e);
+	if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+// The reference sizes its batches from the device (CUs * block_multiplier * ..., SWOcl.cpp:558-590);
+// callers allocate their buffers from these once (ScoreBuffer.h:92, AlignmentBuffer.h:63).
+int ngm_hip_score_batch_size(const ngm_hip_ctx *ctx) { return ctx ? ctx->max_batch : 0; }
+int ngm_hip_align_batch_size(const ngm_hip_ctx *ctx) { return ctx ? ctx->max_batch : 0; }
+
+void ngm_hip_set_profiling(ngm_hip_ctx *ctx, int enabled) { if (ctx) ctx->profiling = enabled != 0; }
+
+int ngm_hip_last_kernel_ms(ngm_hip_ctx *ctx, float ms[3]) {
+	if (!ctx) return -22;
+	ScopedDevice sd(ctx->device);
+	for (int i = 0; i < 3; ++i) {
+		ms[i] = 0.f;
+		if (ctx->ev_valid[i]) {
+			HIP_TRY(ctx, hipEventSynchronize(ctx->ev[i + 1]));
+			HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+		}
+	}
+	return 0;
+}
+
+int ngm_hip_score_device(ngm_hip_ctx *ctx, int mode, int n, const void *d_ref, const void *d_qry,
+		float *d_scores, void *stream) {
+	if (!ctx) return -22;
+	if (n <= 0) return 0;
+	const int am = mode & NGM_MODE_ALIGN_MASK;
+	if (am != NGM_MODE_LOCAL && am != NGM_MODE_END_TO_END) { set_error(ctx, "unsupported alignment mode %d", am); return -22; }
+	ScopedDevice sd(ctx->device);
+	hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+	if (int r = reserve_workspace(ctx, n)) return r;
+	const int nb = n_blocks_of(n);
+	ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = false;
+	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+	if (int r = launch_pack(ctx, n, d_ref, d_qry, st)) return r;
+	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+	score_kernel_t k = find_score_kernel(ctx->c, am == NGM_MODE_END_TO_END);
+	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, d_scores, n, nb,
+			ctx->RW, ctx->K);
+	HIP_TRY(ctx, hipGetLastError());
+	if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st)); ctx->ev_valid[0] = ctx->ev_valid[1] = true; }
+	return n;
+}
+
+int ngm_hip_batch_score(ngm_hip_ctx *ctx, int mode, int n, const char *const *ref, const char *const *qry,
+		float *scores, const char *dir) {
+	if (!ctx) return -22;
+	if (n <= 0) return 0;  // SWOcl.cpp:39-42
+	if (dir) { set_error(ctx, "bisulfite / SLAM-seq strand-specific scoring is not implemented"); return -38; }
+	ScopedDevice sd(ctx->device);
+	const size_t rl = ctx->rl, q = ctx->q;
+	if (ctx->h_ref.reserve((size_t) n * rl) || ctx->h_qry.reserve((size_t) n * q) || ctx->h_scores.reserve(n) ||
+			ctx->d_ref.reserve((size_t) n * rl) || ctx->d_qry.reserve((size_t) n * q) || ctx->d_scores.reserve(n)) {
+		set_error(ctx, "out of memory staging %d pairs", n);
+		return -12;
+	}
+	// flatten exactly the bytes the reference copies (SWOcl.cpp:545-548): q+c of the window, q of the read
+	for (int i = 0; i < n; ++i) {
+		memcpy(ctx->h_ref.p + (size_t) i * rl, ref[i], rl);
+		memcpy(ctx->h_qry.p + (size_t) i * q, qry[i], q);
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ref.p, ctx->h_ref.p, (size_t) n * rl, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qry.p, ctx->h_qry.p, (size_t) n * q, hipMemcpyHostToDevice, ctx->stream));
+	int r = ngm_hip_score_device(ctx, mode, n, ctx->d_ref.p, ctx->d_qry.p, ctx->d_scores.p, ctx->stream);
+	if (r < 0) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_scores.p, ctx->d_scores.p, sizeof(float) * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	memcpy(scores, ctx->h_scores.p, sizeof(float) * (size_t) n);
+	return n;
+}
+
+int ngm_hip_align_run_stride(const ngm_hip_ctx *ctx) { return ctx ? ngm::run_stride(ctx->q, ctx->c) : 0; }
+
+int ngm_hip_align_device(ngm_hip_ctx *ctx, int mode, int n, const void *d_ref, const void *d_qry,
+		int32_t *d_records, uint16_t *d_runs, int run_stride, void *stream) {
+	if (!ctx) return -22;
+	if (n <= 0) return 0;
+	const int am = mode & NGM_MODE_ALIGN_MASK;
+	if (am != NGM_MODE_LOCAL && am != NGM_MODE_END_TO_END) { set_error(ctx, "unsupported alignment mode %d", am); return -22; }
+	if (run_stride < ngm::run_stride(ctx->q, ctx->c)) { set_error(ctx, "run_stride %d too small", run_stride); return -22; }
+	ScopedDevice sd(ctx->device);
+	hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+	if (int r = reserve_workspace(ctx, n)) return r;
+	const int nb = n_blocks_of(n);
+	const int DW = ngm::dir_words(ctx->c);
+	if (ctx->dirs.reserve((size_t) nb * ctx->q * DW * ngm::kSlots)) { set_error(ctx, "out of device memory for the direction matrix"); return -12; }
+	ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = false;
+	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+	if (int r = launch_pack(ctx, n, d_ref, d_qry, st)) return r;
+	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+	align_kernel_t k = find_align_kernel(ctx->c, am == NGM_MODE_END_TO_END);
+	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, ctx->dirs.p,
+			d_records, n, nb, ctx->RW, ctx->q, ctx->K);
+	HIP_TRY(ctx, hipGetLastError());
+	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+	hipLaunchKernelGGL(ngm::sw_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, ctx->lens.p, d_records,
+			d_runs, n, ctx->q, ctx->c, run_stride, am == NGM_MODE_END_TO_END ? 1 : 0);
+	HIP_TRY(ctx, hipGetLastError());
+	if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st)); ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = true; }
+	return n;
+}
+
+int ngm_hip_batch_align(ngm_hip_ctx *ctx, int mode, int n, const char *const *ref, const char *const *qry,
+		ngm_hip_align_out *out, const char *dir) {
+	if (!ctx) return -22;
+	if (n <= 0) return 0;  // SWOclCigar.cpp:109-112
+	if (dir) { set_error(ctx, "bisulfite / SLAM-seq strand-specific scoring is not implemented"); return -38; }
+	ScopedDevice sd(ctx->device);
+	const size_t rl = ctx->rl, q = ctx->q;
+	const int rs = ngm::run_stride(ctx->q, ctx->c);
+	if (ctx->h_ref.reserve((size_t) n * rl) || ctx->h_qry.reserve((size_t) n * q) || ctx->d_ref.reserve((size_t) n * rl) ||
+			ctx->d_qry.reserve((size_t) n * q) || ctx->d_records.reserve((size_t) n * 8) || ctx->d_runs.reserve((size_t) n * rs) ||
+			ctx->h_records.reserve((size_t) n * 8) || ctx->h_runs.reserve((size_t) n * rs)) {
+		set_error(ctx, "out of memory staging %d pairs", n);
+		return -12;
+	}
+	for (int i = 0; i < n; ++i) {
+		memcpy(ctx->h_ref.p + (size_t) i * rl, ref[i], rl);
+		memcpy(ctx->h_qry.p + (size_t) i * q, qry[i], q);
+	}
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ref.p, ctx->h_ref.p, (size_t) n * rl, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_qry.p, ctx->h_qry.p, (size_t) n * q, hipMemcpyHostToDevice, ctx->stream));
+	int r = ngm_hip_align_device(ctx, mode, n, ctx->d_ref.p, ctx->d_qry.p, ctx->d_records.p, ctx->d_runs.p, rs, ctx->stream);
+	if (r < 0) return r;
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_records.p, ctx->d_records.p, sizeof(int32_t) * 8 * (size_t) n, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->h_runs.p, ctx->d_runs.p, sizeof(uint16_t) * (size_t) rs * n, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ngm::CigarParams cp;
+	cp.match = ctx->prm.match_bonus;
+	cp.mismatch = -ctx->prm.mismatch_penalty;
+	cp.variant = ctx->prm.variant;
+	cp.hard_clip = ctx->prm.hard_clip;
+	cp.silent_clip = ctx->prm.silent_clip;
+	for (int i = 0; i < n; ++i) {
+		ngm::build_cigar_md(cp, ctx->h_records.p + (size_t) i * 8, ctx->h_runs.p + (size_t) i * rs, ref[i], qry[i], &out[i]);
+	}
+	return n;
+}
+
+}  // extern "C"

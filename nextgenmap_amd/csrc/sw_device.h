@@ -1,0 +1,282 @@
+// sw_device.h -- gfx950 device code of the banded Smith-Waterman score path.
+//
+// Replaces NextGenMap's OpenCL kernels interleaveSeq + oclSW / oclSW_Global
+// (lib/mason/opencl/opencl/oclSwScore.cl:194-213, :332-377, oclEndFreeScore.cl:153-203) with a
+// different decomposition, written for CDNA4:
+//
+//   pack kernel   ASCII pairs (the buffers IAlignment::BatchScore receives, flattened) are loaded
+//                 with 16-byte coalesced reads, staged through LDS, translated to the 7 symbol
+//                 classes of the reference (oclDefines.cl:64-80) and written as 4-bit codes,
+//                 64-way interleaved: dword m of pair slot s of a block sits at [m][s], so the DP
+//                 kernel's per-lane streams are perfectly coalesced (one 256-byte line per wave load).
+//   score kernel  one pair per lane, the whole band row H[0..C) lives in VGPRs (C is a template
+//                 parameter, like the reference's -D corridor_length), integer DP, no LDS traffic
+//                 in the inner loop except one 8-byte per-row lookup.  The substitution score is a
+//                 v_perm_b32 byte-table lookup: per read row an 8-byte table indexed by the reference
+//                 symbol class gives the score of 4 band cells per instruction, which is what makes
+//                 the 7-class alphabet (N, NUL padding, 'x' filler) free.
+//
+// Arithmetic is the reference's, re-based per row so that the table holds non-negative bytes:
+//   H'(i,d) = H(i,d) - (i+1)*mismatch         (mismatch < 0, so H' >= H)
+//   diag' = H'(i-1,d) + t,  t = s - mismatch in {0, -mismatch, match-mismatch}
+//   up'   = H'(i-1,d+1) + (gap_read - mismatch),  left' = H'(i,d-1) + gap_ref,  floor' = -(i+1)*mismatch
+// All values are exact integers (int32); results are bit-identical to the reference's short / float
+// arithmetic inside its own overflow-free domain.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ngm {
+
+constexpr int kSlots = 64;          // pairs per packed block == lanes per wave
+constexpr int kShortMin = -16000;   // oclDefines.cl:28
+
+// number of 4-byte selector registers that cover the C + 7 window bytes one 8-row group touches,
+// rounded up to even (one packed dword = 8 bases = 2 registers)
+__host__ __device__ constexpr int sel_regs(int C) { return (((C + 7 + 3) / 4) + 1) & ~1; }
+__host__ __device__ constexpr int read_words(int q) { return (q + 7) / 8; }
+__host__ __device__ constexpr int ref_words(int q, int C) { return read_words(q) + sel_regs(C) / 2; }
+
+struct SwConst {
+	int tM;        // match - mismatch : table byte of a match
+	int tZ;        // -mismatch        : table byte of a zero score; also the per-row floor step
+	int gl;        // gap_ref
+	int gu;        // gap_read - mismatch
+	int gap_read;  // raw
+	int variant;   // NGM_VARIANT_*
+};
+
+// Symbol class of a byte. oclDefines.cl:64-80: A/a 0, C/c 1, G/g 2, T/t 3, N/n 5, NUL 6, other 4.
+__device__ __forceinline__ uint32_t sym_class(uint32_t ch) {
+	const uint32_t u = ch & 0xDFu;  // fold case
+	uint32_t k = 4;
+	k = (u == 'A') ? 0u : k;
+	k = (u == 'C') ? 1u : k;
+	k = (u == 'G') ? 2u : k;
+	k = (u == 'T') ? 3u : k;
+	k = (u == 'N') ? 5u : k;
+	k = (ch == 0) ? 6u : k;
+	return k;
+}
+
+// Row table for read class rc: byte fc = t(rc, fc) = score(rc, fc) - mismatch. oclDefines.cl:85-91.
+__device__ __forceinline__ uint2 make_row_table(int rc, const SwConst &K) {
+	uint32_t b[8];
+	for (int fc = 0; fc < 8; ++fc) {
+		uint32_t t;
+		if (rc >= 6) t = K.tZ;                                  // read NUL (and the unused code 7): 0
+		else if (rc == 5) t = (fc <= 3) ? K.tZ : 0;              // read N: 0 vs ACGT, mismatch otherwise
+		else if (fc == 6) t = K.tZ;                              // ref NUL: 0
+		else if (rc == 4) t = 0;                                 // read "other": mismatch
+		else t = (fc == rc) ? K.tM : 0;                          // read ACGT
+		b[fc] = t & 0xFF;
+	}
+	uint2 r;
+	r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+	r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+	return r;
+}
+
+// 8 class codes -> one packed dword, nibble 2k = base k, nibble 2k+1 = base k+4, so that
+// (x & 0x0F0F0F0F) and ((x >> 4) & 0x0F0F0F0F) are the byte-selector registers of bases 0-3 / 4-7.
+__device__ __forceinline__ uint32_t pack8(const uint32_t k[8]) {
+	return k[0] | (k[4] << 4) | (k[1] << 8) | (k[5] << 12) | (k[2] << 16) | (k[6] << 20) | (k[3] << 24) | (k[7] << 28);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack kernel: one workgroup (256 threads) per block of 64 pairs.
+//   ref  : n rows of rl = q + c bytes (flat), qry : n rows of q bytes (flat)
+//   out  : block b at b * (RW + FW) * 64 dwords; read dword m at [m][slot], ref dword m at [RW + m][slot]
+//   lens : per pair, number of read chars before the first NUL (what the align kernels loop over)
+//   blk_rows : per block, max over its pairs of (index of last non-NUL read byte + 1)
+// dynamic LDS: 64 * (rl + q) bytes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restrict__ ref,
+		const uint8_t *__restrict__ qry, int n, int q, int rl, int RW, int FW,
+		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows) {
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	__shared__ int s_first_nul[kSlots];
+	__shared__ int s_rows[kSlots];
+	__shared__ int s_blk_rows;
+	__shared__ uint8_t s_trans[256];
+	uint8_t *lref = lds;
+	uint8_t *lqry = lds + (size_t) kSlots * rl;
+	const int tid = threadIdx.x;
+	const int blk = blockIdx.x;
+	const int p0 = blk * kSlots;
+	const int np = min(kSlots, n - p0);
+	if (tid < kSlots) { s_first_nul[tid] = q; s_rows[tid] = 0; }
+	if (tid == 0) s_blk_rows = 0;
+	s_trans[tid] = (uint8_t) sym_class((uint32_t) tid);
+
+	// phase 1: coalesced copy of the block's rows into LDS (same linear layout), zero fill the tail
+	{
+		const size_t gref = (size_t) p0 * rl, gqry = (size_t) p0 * q;
+		const int nref = np * rl, nqry = np * q;
+		const int tref = kSlots * rl, tqry = kSlots * q;
+		const bool al16 = (((uintptr_t) (ref + gref) | (uintptr_t) (qry + gqry)) & 15) == 0;
+		if (al16) {
+			for (int o = tid * 16; o < tref; o += 256 * 16) {
+				uint4 v = make_uint4(0, 0, 0, 0);
+				if (o + 16 <= nref) v = *reinterpret_cast<const uint4 *>(ref + gref + o);
+				*reinterpret_cast<uint4 *>(lref + o) = v;
+				if (o < nref && o + 16 > nref) for (int k = 0; o + k < nref; ++k) lref[o + k] = ref[gref + o + k];
+			}
+			for (int o = tid * 16; o < tqry; o += 256 * 16) {
+				uint4 v = make_uint4(0, 0, 0, 0);
+				if (o + 16 <= nqry) v = *reinterpret_cast<const uint4 *>(qry + gqry + o);
+				*reinterpret_cast<uint4 *>(lqry + o) = v;
+				if (o < nqry && o + 16 > nqry) for (int k = 0; o + k < nqry; ++k) lqry[o + k] = qry[gqry + o + k];
+			}
+		} else {
+			for (int o = tid; o < tref; o += 256) lref[o] = (o < nref) ? ref[gref + o] : 0;
+			for (int o = tid; o < tqry; o += 256) lqry[o] = (o < nqry) ? qry[gqry + o] : 0;
+		}
+	}
+	__syncthreads();
+
+	// phase 2: lane = pair slot, four waves split the dwords; stores are 256-byte coalesced
+	const int slot = tid & 63, part = tid >> 6;
+	uint32_t *ob = out + (size_t) blk * (RW + FW) * kSlots + slot;
+	{
+		const uint8_t *row = lqry + slot * q;
+		int first_nul = q, rows = 0;
+		for (int m = part; m < RW; m += 4) {
+			uint32_t k[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const int i = m * 8 + j;
+				const uint32_t ch = (i < q) ? row[i] : 0u;
+				k[j] = s_trans[ch];
+				if (ch == 0) first_nul = min(first_nul, i); else rows = max(rows, i + 1);
+			}
+			ob[(size_t) m * kSlots] = pack8(k);
+		}
+		first_nul = min(first_nul, q);
+		atomicMin(&s_first_nul[slot], first_nul);
+		atomicMax(&s_rows[slot], rows);
+	}
+	{
+		const uint8_t *row = lref + slot * rl;
+		for (int m = part; m < FW; m += 4) {
+			uint32_t k[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const int i = m * 8 + j;
+				k[j] = s_trans[(i < rl) ? row[i] : 0u];
+			}
+			ob[(size_t) (RW + m) * kSlots] = pack8(k);
+		}
+	}
+	__syncthreads();
+	if (tid < kSlots) {
+		atomicMax(&s_blk_rows, s_rows[tid]);
+		if (p0 + tid < n) lens[p0 + tid] = (uint16_t) s_first_nul[tid];
+	}
+	__syncthreads();
+	if (tid == 0) blk_rows[blk] = (uint16_t) s_blk_rows;
+}
+
+// ---------------------------------------------------------------------------------------------
+// score kernel: BatchScore.  One pair per lane, one packed block per wave, 4 waves per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <int C, bool ENDFREE>
+__global__ __launch_bounds__(256) void sw_score_kernel(const uint32_t *__restrict__ packed,
+		const uint16_t *__restrict__ lens, const uint16_t *__restrict__ blk_rows,
+		float *__restrict__ scores, int n, int n_blocks, int RW, SwConst K) {
+	__shared__ uint2 s_tab[8];
+	if (threadIdx.x < 8) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (blk >= n_blocks) return;
+	constexpr int NRG = sel_regs(C);
+	const int FW = RW + NRG / 2;
+	const uint32_t *rd = packed + (size_t) blk * (RW + FW) * kSlots + lane;
+	const uint32_t *fd = rd + (size_t) RW * kSlots;
+	const int rows = __builtin_amdgcn_readfirstlane((int) blk_rows[blk]);
+	const int ngroups = (rows + 7) >> 3;
+
+	int H[C];
+#pragma unroll
+	for (int d = 0; d < C; ++d) H[d] = 0;
+	uint32_t RG[NRG];
+#pragma unroll
+	for (int r = 0; r < NRG / 2; ++r) {
+		const uint32_t x = fd[(size_t) r * kSlots];
+		RG[2 * r] = x & 0x0F0F0F0Fu;
+		RG[2 * r + 1] = (x >> 4) & 0x0F0F0F0Fu;
+	}
+	int fl = K.tZ;       // floor' of row 0
+	int best = 0;        // virtual NUL rows contribute 0 (the reference starts at -1: see epilogue)
+	uint32_t rnext = (ngroups > 0) ? rd[0] : 0x66666666u;
+
+	for (int g = 0; g < ngroups; ++g) {
+		const uint32_t rx = rnext;
+		// prefetch next group's read and reference dwords (coalesced 256 B per wave)
+		rnext = (g + 1 < ngroups) ? rd[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		const uint32_t fx = fd[(size_t) (g + NRG / 2) * kSlots];
+		const uint32_t rsel[2] = {rx & 0x0F0F0F0Fu, (rx >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {
+			const uint32_t rc = (rsel[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+			const uint2 T = s_tab[rc];
+			// scores of 4 band cells per perm: selector bytes are reference classes 0..6
+			constexpr int R0 = 0;
+			uint32_t P[NRG];
+#pragma unroll
+			for (int r = R0; r < NRG; ++r) P[r] = ((s + C - 1) / 4 >= r && s / 4 <= r) ? __builtin_amdgcn_perm(T.y, T.x, RG[r]) : 0u;
+			int left = ENDFREE ? (fl + kShortMin) : fl;
+			int rowmax = fl;
+#pragma unroll
+			for (int d = 0; d < C; ++d) {
+				const int bi = s + d;
+				const int t = (int) ((P[bi >> 2] >> (8 * (bi & 3))) & 0xFFu);
+				const int dg = H[d] + t;
+				const int a = left + K.gl;
+				int h;
+				if (d < C - 1) {
+					const int b = H[d + 1] + K.gu;
+					h = max(max(a, b), dg);
+				} else if (ENDFREE) {
+					const int b = fl + kShortMin + K.gap_read;  // sentinel column, oclEndFreeScore.cl:170
+					h = max(max(a, b), dg);
+				} else {
+					h = max(a, dg);  // the 0 sentinel + gap_read never beats the floor
+				}
+				if (!ENDFREE) { h = max(h, fl); rowmax = max(rowmax, h); }
+				H[d] = h;
+				left = h;
+			}
+			if (!ENDFREE) best = max(best, rowmax - fl);
+			fl += K.tZ;
+		}
+		// slide the selector window by 8 bytes
+#pragma unroll
+		for (int r = 0; r + 2 < NRG; ++r) RG[r] = RG[r + 2];
+		RG[NRG - 2] = fx & 0x0F0F0F0Fu;
+		RG[NRG - 1] = (fx >> 4) & 0x0F0F0F0Fu;
+	}
+
+	const int pair = blk * kSlots + lane;
+	if (pair < n) {
+		int result;
+		if (ENDFREE) {
+			// max over the last row and the sentinel slot (oclEndFreeScore.cl:197-201); H = H' + K_last
+			const int klast = -(fl - K.tZ);
+			int m = kShortMin;
+#pragma unroll
+			for (int d = 0; d < C; ++d) m = max(m, H[d] + klast);
+			result = m;
+		} else {
+			result = best;
+		}
+		// the float4 (__CPU__) build never enters the DP for an empty read (oclSwScore.cl:124,
+		// oclEndFreeScore.cl:20); the __GPU__ build does and reports 0
+		if (K.variant == 1 && lens[pair] == 0) result = ENDFREE ? kShortMin : -1;
+		scores[pair] = (float) result;
+	}
+}
+
+}  // namespace ngm
