@@ -166,13 +166,18 @@ def main():
         score_cells = NS * READ_LEN * C
         align_cells = R * READ_LEN * C
         achieved = NS * B_SCORE / (k_score * 1e-3) / 1e9
+        # HBM bytes per launch of the same kernel at the same grid, from the PMC passes committed under
+        # profiles/ (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 read correction applied there)
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("sw_score_kernel_bytes_per_launch")
-            except Exception:
-                traffic = None
+        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if fn.endswith("_pmc_traffic.json"):
+                try:
+                    tr = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    traffic = tr.get("ngm::sw_score_kernel<%d, false>|grid=%d" % (C, ((NS + 255) // 256) * 256))
+                except Exception:
+                    traffic = None
+                if traffic is not None:
+                    break
         line = {
             "metric": "mapped reads/sec + SW Gcells/sec, 150bp vs GRCh38, at 1/2/4/8 MI355X",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
