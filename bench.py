@@ -157,7 +157,7 @@ def main():
                          d_rec[:, 5].to(torch.int64).sum(), torch.zeros((), device=dev, dtype=torch.int64),
                          torch.zeros((), device=dev, dtype=torch.int64)])
     if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # the ONE collective of the path (RCCL over xGMI)
     stats = [int(x) for x in stats.tolist()]
 
     if rank == 0:
