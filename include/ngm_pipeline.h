@@ -1,0 +1,113 @@
+/*
+ * ngm_pipeline.h -- flat C ABI of the device-resident mapping path that sits ABOVE IAlignment in
+ * NextGenMap: encoded reference + k-mer index in HBM, candidate search, window gather, score,
+ * candidate selection / MAPQ, alignment.  Rows a1-a5, a7, a8 of SURVEY.md section 8.
+ *
+ * Reference interfaces replaced (paths relative to the NextGenMap tree):
+ *   ngm_ref_*        <- _SequenceProvider (src/SequenceProvider.cpp:228-441: 4-bit concatenated genome with
+ *                       1000-N spacers, DecodeRefSequence, convert) and CompactPrefixTable
+ *                       (src/PrefixTable.cpp:328-498, :641-817: k-mer index, GetRefEntry, stats/max_kfreq)
+ *   ngm_mapper_cs    <- CS::RunBatch / PrefixSearch / AddLocationStd / CollectResultsStd (src/CS.cpp:114-313)
+ *   ngm_mapper_map   <- ScoreBuffer::DoRun + top1SE + computeMQ (src/ScoreBuffer.cpp:34-49, :80-277) and
+ *                       AlignmentBuffer::DoRun (src/AlignmentBuffer.cpp:64-147) around BatchScore / BatchAlign
+ * Plain pointers and sizes only.  All functions return >= 0 on success, a negative errno-style value on
+ * failure (ngm_pipeline_last_error() describes it).  No CPU fallback: a HIP device is required.
+ */
+#ifndef NGM_PIPELINE_H
+#define NGM_PIPELINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ngm_ref ngm_ref;
+typedef struct ngm_mapper ngm_mapper;
+
+typedef struct ngm_ref_params {
+	int kmer;        /* Config "kmer", default 13 (src/config/Config.cpp:383); 4..15 supported here */
+	int kmer_skip;   /* Config "kmer_skip", default 2: every (skip+1)-th reference k-mer is indexed */
+	int bin_size;    /* Config "bin_size", default 2: candidate bins are 2^bin_size bases wide */
+} ngm_ref_params;
+
+const char *ngm_pipeline_last_error(void);
+
+/* Encode a reference (contigs in order; names NUL-terminated; sequences ASCII, any case, non-ACGT -> N;
+ * contigs of length <= 10 are skipped like the reference does, SequenceProvider.h:71) and build its
+ * k-mer index on `device`. */
+ngm_ref *ngm_ref_create(int device, const ngm_ref_params *p, int n_contigs, const char *const *names,
+		const uint8_t *const *seqs, const uint64_t *lens);
+/* Same, reading a (optionally gzip-compressed) FASTA file. */
+ngm_ref *ngm_ref_create_from_fasta(int device, const ngm_ref_params *p, const char *path);
+void ngm_ref_destroy(ngm_ref *r);
+
+int ngm_ref_contig_count(const ngm_ref *r);
+const char *ngm_ref_contig_name(const ngm_ref *r, int i);
+uint64_t ngm_ref_contig_start(const ngm_ref *r, int i); /* position in concatenated coordinates */
+uint64_t ngm_ref_contig_len(const ngm_ref *r, int i);
+uint64_t ngm_ref_concat_len(const ngm_ref *r);          /* _SequenceProvider::GetConcatRefLen */
+int ngm_ref_auto_max_kfreq(const ngm_ref *r);           /* ceil(max(100, avg + 5 sigma)), PrefixTable.cpp:150-194 */
+uint64_t ngm_ref_index_entries(const ngm_ref *r);       /* number of stored k-mer positions */
+/* copy the index out (tests): counts[4^k] = list length per k-mer as a lookup sees it (0 for k-mers
+ * disabled by the 9900-occurrence rule, PrefixTable.cpp:468-478), raw_counts[4^k] = before that rule,
+ * positions[index_entries] grouped by k-mer in k-mer order, ascending inside a group. NULL = skip. */
+int ngm_ref_index_copy(const ngm_ref *r, uint32_t *counts, uint32_t *raw_counts, uint32_t *positions);
+/* _SequenceProvider::DecodeRefSequence(buffer, 0, offset, buffer_len) executed from the HBM copy. */
+int ngm_ref_decode(const ngm_ref *r, uint64_t offset, int buffer_len, char *out);
+/* _SequenceProvider::convert: concatenated position -> (contig, 0-based position); returns 0 when the
+ * position lies in a spacer (reported unmapped), 1 otherwise. */
+int ngm_ref_convert(const ngm_ref *r, uint64_t pos, int *contig, uint64_t *contig_pos);
+
+typedef struct ngm_mapper_params {
+	int qry_max_len;       /* bytes per read row */
+	int corridor;
+	int match_bonus, mismatch_penalty, gap_read_penalty, gap_ref_penalty;
+	int mode;              /* 0 local, 1 end-to-end */
+	int variant;           /* NGM_VARIANT_* of ngm_hip.h */
+	float sensitivity;     /* Config "sensitivity" (-s) */
+	float kmer_min;        /* Config "kmer_min" */
+	int max_cmrs;          /* Config "max_cmrs" (INT_MAX = unlimited) */
+	int max_kfreq;         /* <= 0: use ngm_ref_auto_max_kfreq */
+	int hard_clip, silent_clip;
+} ngm_mapper_params;
+
+ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p);
+void ngm_mapper_destroy(ngm_mapper *m);
+
+/* Candidate search for n reads (reads: n rows of qry_max_len bytes, upper-case ACGTN, NUL padded, host
+ * memory).  Outputs: cand_offsets[n+1] (prefix sums), max_votes[n] (read->s, SAM XE:i); the candidates
+ * themselves are fetched with ngm_mapper_cs_fetch: loc = bin centre in concatenated coordinates
+ * (ResolveBin), strand 0/1, votes.  Candidate order inside a read is (loc, strand) ascending -- the
+ * reference's order is first-threshold-crossing order, which only matters for exact score ties. */
+int ngm_mapper_cs(ngm_mapper *m, int n, const char *reads, uint32_t *cand_offsets, float *max_votes);
+int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *votes);
+
+/* Per-read mapping result (single-end, topn = 1). */
+typedef struct ngm_hit {
+	int mapped;            /* 0: no candidate / no alignment */
+	int contig;            /* index into the reference contigs */
+	uint64_t pos;          /* 0-based leftmost position on the contig */
+	int reverse;           /* 1: read aligned as reverse complement */
+	int mapq;
+	float score;           /* AS:i (from the score stage, like the reference: SAMWriter.cpp:169) */
+	float identity;        /* XI:f */
+	int nm;
+	int qstart, qend;
+	int n_candidates;      /* CMRs scored for this read */
+	int n_best;            /* NH:i / X0:i : candidates sharing the best score */
+	float max_votes;       /* XE:i */
+} ngm_hit;
+
+/* Full single-end path for n reads; cigars/mds: n rows of 4*qry_max_len bytes (NUL-terminated strings). */
+int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds);
+
+/* kernel wall-clock of the last ngm_mapper_* call, HIP events on the launch stream, ms:
+ * [0] candidate search  [1] gather+pack  [2] score  [3] select  [4] gather+pack (align)  [5] align DP  [6] traceback */
+int ngm_mapper_last_kernel_ms(ngm_mapper *m, float ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

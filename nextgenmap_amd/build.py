@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LIB = os.path.join(HERE, "libngm_hip.so")
-SOURCES = ["ngm_hip.cpp", "ialignment_adapter.cpp"]
-HEADERS = ["sw_device.h", "align_device.h", "cigar_md.h", os.path.join("..", "..", "include", "ngm_hip.h"),
+SOURCES = ["ngm_hip.cpp", "ialignment_adapter.cpp", "refindex.cpp", "mapper.cpp"]
+HEADERS = ["sw_device.h", "align_device.h", "cigar_md.h", "refindex.h", "cs_device.h", "gather_device.h", os.path.join("..", "..", "include", "ngm_pipeline.h"), os.path.join("..", "..", "include", "ngm_hip.h"),
            os.path.join("..", "..", "include", "ngm_ialignment.h")]
 
 
@@ -28,7 +28,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + srcs + ["-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + srcs + ["-lz", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

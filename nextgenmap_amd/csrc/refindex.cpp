@@ -1,0 +1,362 @@
+// refindex.cpp -- reference encoding and k-mer index construction (host walk + GPU sort).
+// See refindex.h for what it replaces and for the HBM layout.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string.h>
+
+#include "refindex.h"
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <zlib.h>
+
+namespace {
+thread_local std::string g_pipeline_error;
+
+#define REF_HIP_TRY(expr)                                                                      \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                \
+		if (e_ != hipSuccess) {                                                                \
+			ngm::pipeline_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return -5;                                                                         \
+		}                                                                                      \
+	} while (0)
+
+inline uint8_t class_of_base(uint8_t c) {  // enc4 semantics (SequenceProvider.cpp:72-85): non-ACGT -> N
+	switch (c & 0xDF) {
+	case 'A': return 0;
+	case 'C': return 1;
+	case 'G': return 2;
+	case 'T': return 3;
+	default: return 5;
+	}
+}
+
+// ---- the reference's k-mer enumeration, restated ---------------------------------------------------
+// CS::PrefixIteration (src/CSstatic.cpp:26-76) with prefixskip = kmer_skip over one contig, feeding
+// CompactPrefixTable::CountKmer / BuildPrefixTable (src/PrefixTable.cpp:641-709): emits the (k-mer,
+// position) pairs that end up in the index, in genome order.
+struct KmerWalker {
+	int k, skip, bin_shift;
+	uint32_t mask;
+	uint32_t last_prefix;
+	int64_t last_bin;
+	std::vector<uint32_t> *keys, *vals;
+
+	void fire(uint32_t prefix, uint64_t pos) {
+		// same k-mer as the previous indexed one AND same bin as the previous same-k-mer hit -> dropped
+		if (prefix == last_prefix) {
+			const int64_t bin = (int64_t) (pos >> bin_shift);
+			if (bin != last_bin || last_bin == -1) { keys->push_back(prefix); vals->push_back((uint32_t) pos); }
+			last_bin = bin;
+		} else {
+			last_bin = -1;
+			keys->push_back(prefix);
+			vals->push_back((uint32_t) pos);
+		}
+		last_prefix = prefix;
+	}
+
+	// seq: class per base, the reference's quirks already applied (see walk_contig); N = class 5
+	void iterate(const uint8_t *seq, uint64_t length, uint64_t offset) {
+		for (;;) {  // the reference recurses after every 'N'; this loop is that recursion
+			if (length < (uint64_t) k) return;
+			if (seq[0] == 5) {
+				uint64_t n_skip = 1;
+				while (n_skip < length && seq[n_skip] == 5) ++n_skip;
+				seq += n_skip;
+				if (n_skip >= (length - k)) return;  // CSstatic.cpp:37 (drops a tail of exactly k bases too)
+				length -= n_skip;
+				offset += n_skip;
+			}
+			uint32_t prefix = 0;
+			bool restart = false;
+			for (uint64_t i = 0; i < (uint64_t) k - 1; ++i) {
+				if (seq[i] == 5) { seq += i + 1; length -= i + 1; offset += i + 1; restart = true; break; }
+				prefix = (prefix << 2) | ngm::kmer_code_of_class(seq[i]);
+			}
+			if (restart) continue;
+			int skipcount = skip;
+			for (uint64_t i = k - 1; i < length; ++i) {
+				if (seq[i] == 5) { seq += i + 1; length -= i + 1; offset += i + 1; restart = true; break; }
+				prefix = ((prefix << 2) | ngm::kmer_code_of_class(seq[i])) & mask;
+				if (skipcount == skip) { fire(prefix, offset + i + 1 - k); skipcount = 0; }
+				else ++skipcount;
+			}
+			if (!restart) return;
+		}
+	}
+};
+
+__global__ void mark_runs_kernel(const uint32_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ starts, uint32_t *__restrict__ raw) {
+	const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n) return;
+	const uint32_t kj = keys[j];
+	if (j == 0 || keys[j - 1] != kj) starts[kj] = (uint32_t) j;
+	if (j + 1 == n || keys[j + 1] != kj) raw[kj] = (uint32_t) (j + 1);  // end; turned into a length below
+}
+
+__global__ void finish_index_kernel(uint32_t n_kmers, int k, const uint32_t *__restrict__ starts, uint32_t *__restrict__ raw,
+		uint2 *__restrict__ index) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_kmers) return;
+	const uint32_t end = raw[p];
+	const uint32_t cnt = end ? end - starts[p] : 0u;  // raw[] holds end+0 only for present k-mers
+	raw[p] = cnt;
+	index[p] = make_uint2(starts[p], cnt);
+}
+
+__device__ __forceinline__ uint32_t d_revcomp(uint32_t prefix, int k) {
+	const int shift = 32 - 2 * k;
+	uint32_t c = (prefix ^ 0xAAAAAAAAu) << shift;
+	c = (c & 0xFFFF0000u) >> 16 | (c & 0x0000FFFFu) << 16;
+	c = (c & 0xFF00FF00u) >> 8 | (c & 0x00FF00FFu) << 8;
+	c = (c & 0xF0F0F0F0u) >> 4 | (c & 0x0F0F0F0Fu) << 4;
+	c = (c & 0xCCCCCCCCu) >> 2 | (c & 0x33333333u) << 2;
+	return c;
+}
+
+// the reference marks a k-mer unused when (10000 - min(total,10000)) * 100 / 10000 truncates to 0, i.e.
+// total = own + reverse-complement occurrences >= 9901 (PrefixTable.cpp:468-478); lookups then see an empty list
+__global__ void apply_usage_rule_kernel(uint32_t n_kmers, int k, const uint32_t *__restrict__ raw, uint2 *__restrict__ index) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n_kmers) return;
+	const uint32_t total = raw[p] + raw[d_revcomp(p, k)];
+	if (total > 9900u) index[p].y = 0;
+}
+
+int build_index(ngm_ref *r) {
+	const int k = r->prm.kmer;
+	const uint32_t n_kmers = 1u << (2 * k);
+	std::vector<uint32_t> keys, vals;
+	keys.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
+	vals.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
+	KmerWalker w{k, r->prm.kmer_skip, r->prm.bin_size, (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u), 111111u, -1, &keys, &vals};
+	std::vector<uint8_t> tmp;
+	for (const NgmContig &c : r->contigs) {
+		w.last_prefix = 111111u;  // PrefixTable.cpp:335-336
+		w.last_bin = -1;
+		// CountKmerFreq decodes the contig with bufferLength = len, and DecodeRefSequence emits bufferLength-2
+		// bases ('x' / NUL after that, SequenceProvider.cpp:384, :424-439); PrefixIteration then still walks
+		// all len characters and encode() maps both fillers to 0: the last two bases act as 'A'.
+		tmp.assign(r->host_cls.begin() + c.start, r->host_cls.begin() + c.start + c.len);
+		if (c.len >= 2) { tmp[c.len - 2] = 0; tmp[c.len - 1] = 0; }
+		w.iterate(tmp.data(), c.len, c.start);
+	}
+	const uint64_t n = keys.size();
+	r->n_entries = n;
+
+	uint32_t *d_keys = nullptr, *d_vals = nullptr, *d_keys2 = nullptr, *d_starts = nullptr;
+	REF_HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(n, 1) * 4));
+	REF_HIP_TRY(hipMalloc(&d_vals, std::max<uint64_t>(n, 1) * 4));
+	REF_HIP_TRY(hipMalloc(&d_keys2, std::max<uint64_t>(n, 1) * 4));
+	REF_HIP_TRY(hipMalloc(&r->d_positions, std::max<uint64_t>(n, 1) * 4));
+	REF_HIP_TRY(hipMalloc(&d_starts, (size_t) n_kmers * 4));
+	REF_HIP_TRY(hipMalloc(&r->d_raw_counts, (size_t) n_kmers * 4));
+	REF_HIP_TRY(hipMalloc(&r->d_index, (size_t) n_kmers * sizeof(uint2)));
+	REF_HIP_TRY(hipMemcpy(d_keys, keys.data(), n * 4, hipMemcpyHostToDevice));
+	REF_HIP_TRY(hipMemcpy(d_vals, vals.data(), n * 4, hipMemcpyHostToDevice));
+	REF_HIP_TRY(hipMemset(d_starts, 0, (size_t) n_kmers * 4));
+	REF_HIP_TRY(hipMemset(r->d_raw_counts, 0, (size_t) n_kmers * 4));
+	if (n > 0) {
+		// stable LSD radix sort on the 2k key bits: positions stay ascending inside each k-mer group,
+		// which is the order BuildPrefixTable appends them in (PrefixTable.cpp:729-748)
+		size_t tmp_bytes = 0;
+		REF_HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_vals, r->d_positions, n, 0, 2 * k));
+		void *d_tmp = nullptr;
+		REF_HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
+		REF_HIP_TRY(rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, r->d_positions, n, 0, 2 * k));
+		hipLaunchKernelGGL(mark_runs_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, d_keys2, n, d_starts, r->d_raw_counts);
+		REF_HIP_TRY(hipGetLastError());
+		REF_HIP_TRY(hipDeviceSynchronize());
+		(void) hipFree(d_tmp);
+	}
+	hipLaunchKernelGGL(finish_index_kernel, dim3((n_kmers + 255) / 256), dim3(256), 0, 0, n_kmers, k, d_starts, r->d_raw_counts, r->d_index);
+	hipLaunchKernelGGL(apply_usage_rule_kernel, dim3((n_kmers + 255) / 256), dim3(256), 0, 0, n_kmers, k, r->d_raw_counts, r->d_index);
+	REF_HIP_TRY(hipGetLastError());
+	REF_HIP_TRY(hipDeviceSynchronize());
+	(void) hipFree(d_keys); (void) hipFree(d_vals); (void) hipFree(d_keys2); (void) hipFree(d_starts);
+
+	// CompactPrefixTable::stats (PrefixTable.cpp:150-194): integer sums are exact in double, order-free
+	std::vector<uint32_t> raw(n_kmers);
+	REF_HIP_TRY(hipMemcpy(raw.data(), r->d_raw_counts, (size_t) n_kmers * 4, hipMemcpyDeviceToHost));
+	double sum = 0.0, sum2 = 0.0;
+	for (uint32_t j = 0; j < n_kmers; ++j) { sum += raw[j]; sum2 += (double) raw[j] * (double) raw[j]; }
+	const double len = (double) n_kmers;
+	const double avg = sum / len;
+	const double stdev = sqrt(sum2 / (len - 1) - 2.0 * avg * (sum / (len - 1)) + ((len * avg * avg) / (len - 1)));
+	r->auto_max_kfreq = (int) ceil(std::max(100.0, avg + 5 * stdev));
+	return 0;
+}
+
+int finish_ref(ngm_ref *r) {
+	// artificial upper bound for positions on the last contig (SequenceProvider.cpp:378)
+	r->start_pos.clear();
+	for (const NgmContig &c : r->contigs) r->start_pos.push_back(c.start);
+	if (!r->contigs.empty()) r->start_pos.push_back(r->contigs.back().start + r->contigs.back().len + 1000);
+	// upload the genome as packed nibbles (+ one guard word so window reads never run off the end)
+	r->genome_words = (r->n_bases + 7) / 8 + 64;
+	std::vector<uint32_t> packed(r->genome_words, 0x66666666u);  // NUL class beyond the end
+	for (uint64_t i = 0; i < r->n_bases; ++i) {
+		uint32_t &w = packed[i >> 3];
+		const int sh = 4 * (int) (i & 7);
+		w = (w & ~(0xFu << sh)) | ((uint32_t) r->host_cls[i] << sh);
+	}
+	REF_HIP_TRY(hipMalloc(&r->d_genome, r->genome_words * 4));
+	REF_HIP_TRY(hipMemcpy(r->d_genome, packed.data(), r->genome_words * 4, hipMemcpyHostToDevice));
+	return build_index(r);
+}
+
+void append_spacer(std::vector<uint8_t> &g) { g.insert(g.end(), 1000, (uint8_t) 5); }
+
+void append_contig(ngm_ref *r, const std::string &name, const uint8_t *seq, uint64_t len) {
+	if (len <= 10) return;  // minRefSeqLen, SequenceProvider.h:71 / .cpp:300
+	NgmContig c;
+	c.name = name.substr(0, 100);
+	c.start = r->host_cls.size();
+	c.len = len;
+	r->host_cls.reserve(r->host_cls.size() + len + 1002);
+	for (uint64_t i = 0; i < len; ++i) r->host_cls.push_back(class_of_base(seq[i]));
+	if (len & 1) r->host_cls.push_back(5);  // odd contig: the second nibble of the last byte is an N
+	append_spacer(r->host_cls);
+	r->contigs.push_back(c);
+}
+
+ngm_ref *new_ref(int device, const ngm_ref_params *p) {
+	if (!p || p->kmer < 4 || p->kmer > 15 || p->kmer_skip < 0 || p->bin_size < 0 || p->bin_size > 8) {
+		ngm::pipeline_set_error("ngm_ref_create: bad parameters (kmer 4..15, kmer_skip >= 0, bin_size 0..8)");
+		return nullptr;
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		ngm::pipeline_set_error("ngm_ref_create: no HIP device available (this library has no CPU fallback)");
+		return nullptr;
+	}
+	if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
+		ngm::pipeline_set_error("ngm_ref_create: cannot select device %d", device);
+		return nullptr;
+	}
+	ngm_ref *r = new ngm_ref();
+	r->device = device;
+	r->prm = *p;
+	append_spacer(r->host_cls);  // padding so that windows never start at a negative position
+	return r;
+}
+
+ngm_ref *seal(ngm_ref *r) {
+	r->n_bases = r->host_cls.size();
+	if (r->contigs.empty()) { ngm::pipeline_set_error("ngm_ref_create: no usable contig"); ngm_ref_destroy(r); return nullptr; }
+	if (r->n_bases >= 0xFFFFFFFFull) { ngm::pipeline_set_error("ngm_ref_create: references >= 4 Gbp (multi-unit index) are not supported yet"); ngm_ref_destroy(r); return nullptr; }
+	if (finish_ref(r) != 0) { ngm_ref_destroy(r); return nullptr; }
+	return r;
+}
+}  // namespace
+
+namespace ngm {
+void pipeline_set_error(const char *fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_pipeline_error = buf;
+}
+}  // namespace ngm
+
+extern "C" {
+
+const char *ngm_pipeline_last_error(void) { return g_pipeline_error.c_str(); }
+
+ngm_ref *ngm_ref_create(int device, const ngm_ref_params *p, int n_contigs, const char *const *names,
+		const uint8_t *const *seqs, const uint64_t *lens) {
+	ngm_ref *r = new_ref(device, p);
+	if (!r) return nullptr;
+	for (int i = 0; i < n_contigs; ++i) append_contig(r, names[i], seqs[i], lens[i]);
+	return seal(r);
+}
+
+ngm_ref *ngm_ref_create_from_fasta(int device, const ngm_ref_params *p, const char *path) {
+	gzFile f = gzopen(path, "rb");
+	if (!f) { ngm::pipeline_set_error("cannot open reference %s", path); return nullptr; }
+	ngm_ref *r = new_ref(device, p);
+	if (!r) { gzclose(f); return nullptr; }
+	std::string name, seq, line;
+	bool have = false;
+	std::vector<char> buf(1 << 20);
+	std::string carry;
+	auto flush = [&]() { if (have) append_contig(r, name, (const uint8_t *) seq.data(), seq.size()); seq.clear(); };
+	auto handle_line = [&](const char *s, size_t n) {
+		while (n && (s[n - 1] == '\r' || s[n - 1] == '\n')) --n;
+		if (n && s[0] == '>') {
+			flush();
+			size_t e = 1;
+			while (e < n && s[e] != ' ' && s[e] != '\t') ++e;  // kseq: name = up to the first whitespace
+			name.assign(s + 1, e - 1);
+			have = true;
+		} else if (have) {
+			for (size_t i = 0; i < n; ++i) if (s[i] != ' ' && s[i] != '\t') seq.push_back(s[i]);
+		}
+	};
+	int got;
+	while ((got = gzread(f, buf.data(), (unsigned) buf.size())) > 0) {
+		size_t b = 0;
+		for (size_t i = 0; i < (size_t) got; ++i) {
+			if (buf[i] == '\n') {
+				if (!carry.empty()) { carry.append(buf.data() + b, i - b); handle_line(carry.data(), carry.size()); carry.clear(); }
+				else handle_line(buf.data() + b, i - b);
+				b = i + 1;
+			}
+		}
+		carry.append(buf.data() + b, (size_t) got - b);
+	}
+	if (!carry.empty()) handle_line(carry.data(), carry.size());
+	flush();
+	gzclose(f);
+	return seal(r);
+}
+
+void ngm_ref_destroy(ngm_ref *r) {
+	if (!r) return;
+	(void) hipSetDevice(r->device);
+	if (r->d_genome) (void) hipFree(r->d_genome);
+	if (r->d_index) (void) hipFree(r->d_index);
+	if (r->d_raw_counts) (void) hipFree(r->d_raw_counts);
+	if (r->d_positions) (void) hipFree(r->d_positions);
+	delete r;
+}
+
+int ngm_ref_contig_count(const ngm_ref *r) { return (int) r->contigs.size(); }
+const char *ngm_ref_contig_name(const ngm_ref *r, int i) { return r->contigs[i].name.c_str(); }
+uint64_t ngm_ref_contig_start(const ngm_ref *r, int i) { return r->contigs[i].start; }
+uint64_t ngm_ref_contig_len(const ngm_ref *r, int i) { return r->contigs[i].len; }
+uint64_t ngm_ref_concat_len(const ngm_ref *r) { return r->n_bases - 1; }  // SequenceProvider.cpp:454-456
+int ngm_ref_auto_max_kfreq(const ngm_ref *r) { return r->auto_max_kfreq; }
+uint64_t ngm_ref_index_entries(const ngm_ref *r) { return r->n_entries; }
+
+int ngm_ref_index_copy(const ngm_ref *r, uint32_t *counts, uint32_t *raw_counts, uint32_t *positions) {
+	(void) hipSetDevice(r->device);
+	const uint32_t n_kmers = 1u << (2 * r->prm.kmer);
+	if (counts) {
+		std::vector<uint2> idx(n_kmers);
+		REF_HIP_TRY(hipMemcpy(idx.data(), r->d_index, (size_t) n_kmers * sizeof(uint2), hipMemcpyDeviceToHost));
+		for (uint32_t i = 0; i < n_kmers; ++i) counts[i] = idx[i].y;
+	}
+	if (raw_counts) REF_HIP_TRY(hipMemcpy(raw_counts, r->d_raw_counts, (size_t) n_kmers * 4, hipMemcpyDeviceToHost));
+	if (positions && r->n_entries) REF_HIP_TRY(hipMemcpy(positions, r->d_positions, r->n_entries * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// _SequenceProvider::convert (SequenceProvider.cpp:111-141)
+int ngm_ref_convert(const ngm_ref *r, uint64_t pos, int *contig, uint64_t *contig_pos) {
+	auto upper = std::upper_bound(r->start_pos.begin(), r->start_pos.end(), pos);
+	if (upper == r->start_pos.end() || upper == r->start_pos.begin()) return 0;
+	if ((*upper - pos) < 1000) return 0;  // inside the spacer in front of the next contig
+	*contig = (int) ((upper - 1) - r->start_pos.begin());
+	*contig_pos = pos - *(upper - 1);
+	return 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// refindex.h -- encoded reference + k-mer index, host description shared by the pipeline TUs.
+//
+// Replaces NextGenMap's _SequenceProvider (src/SequenceProvider.cpp) and CompactPrefixTable
+// (src/PrefixTable.cpp).  Coordinates are the reference's: all contigs concatenated, 1000 'N' before the
+// first, between and after contigs, every contig starting at an even position (SequenceProvider.cpp:289-326).
+//
+// HBM layout (MI355X: everything replicated per GPU, 288 GB is plenty for GRCh38):
+//   d_genome    : 4-bit symbol classes (A0 C1 G2 T3 N5, the DP kernels' alphabet), 8 bases per dword,
+//                 base i in bits 4*(i%8)                                   -- 1.55 GB for GRCh38
+//   d_index     : 4^k entries {start, count}: one 8-byte random read per k-mer lookup (the reference reads two
+//                 5-byte packed entries, PrefixTable.h:27-61); count is already 0 for k-mers that the reference
+//                 treats as unused (>= 9901 occurrences fwd+revcomp, PrefixTable.cpp:468-478)  -- 537 MB
+//   d_positions : one uint32 per indexed k-mer occurrence, grouped by k-mer, ascending        -- ~4.1 GB
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ngm_pipeline.h"
+
+struct NgmContig {
+	std::string name;
+	uint64_t start;  // concatenated coordinate of base 0
+	uint64_t len;
+};
+
+struct ngm_ref {
+	int device = 0;
+	ngm_ref_params prm{};
+	std::vector<NgmContig> contigs;
+	std::vector<uint64_t> start_pos;  // contig starts + one artificial upper bound (SequenceProvider.cpp:370-378)
+	uint64_t n_bases = 0;             // nibbles in the encoded genome (binRefIndex after doubling)
+	std::vector<uint8_t> host_cls;    // one class per base (kept for the host-side helpers)
+	uint64_t n_entries = 0;
+	int auto_max_kfreq = 100;
+	// device
+	uint32_t *d_genome = nullptr;
+	uint64_t genome_words = 0;
+	uint2 *d_index = nullptr;
+	uint32_t *d_raw_counts = nullptr;
+	uint32_t *d_positions = nullptr;
+};
+
+namespace ngm {
+void pipeline_set_error(const char *fmt, ...);
+// k-mer integer as the reference builds it: 2 bits per base, A0 C1 T2 G3 ((c >> 1) & 3, CSstatic.cpp:20-22)
+inline uint32_t kmer_code_of_class(uint32_t cls) { return cls == 2 ? 3u : (cls == 3 ? 2u : cls); }
+// reverse complement of a k-mer integer (PrefixTable.cpp:94-108), valid for 2k <= 32
+inline uint32_t kmer_revcomp(uint32_t prefix, int k) {
+	const int shift = 32 - 2 * k;
+	uint32_t c = (prefix ^ 0xAAAAAAAAu) << shift;
+	c = (c & 0xFFFF0000u) >> 16 | (c & 0x0000FFFFu) << 16;
+	c = (c & 0xFF00FF00u) >> 8 | (c & 0x00FF00FFu) << 8;
+	c = (c & 0xF0F0F0F0u) >> 4 | (c & 0x0F0F0F0Fu) << 4;
+	c = (c & 0xCCCCCCCCu) >> 2 | (c & 0x33333333u) << 2;
+	return c;
+}
+}  // namespace ngm
