@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void sw_align_kernel(const uint32_t *__restric
 	}
 }
 
+#ifdef NGM_ENGINE_KERNELS
 // One lane per pair walks the direction bits back from the argmax (oclSwCigar.cl:13-54).
 __global__ __launch_bounds__(256) void sw_traceback_kernel(const uint32_t *__restrict__ dirs,
 		const uint16_t *__restrict__ lens, int32_t *__restrict__ records, uint16_t *__restrict__ runs, int n,
@@ -192,5 +193,7 @@ __global__ __launch_bounds__(256) void sw_traceback_kernel(const uint32_t *__res
 	rec[kRecQStart] = row + 1;
 	rec[kRecRuns] = nruns;
 }
+
+#endif  // NGM_ENGINE_KERNELS
 
 }  // namespace ngm

@@ -1,0 +1,253 @@
+// cs_device.h -- candidate search on the GPU: k-mer lookups into the HBM-resident index and binned
+// diagonal votes.  Replaces NextGenMap's CS::PrefixIteration (read side, src/CSstatic.cpp:26-76),
+// CompactPrefixTable::GetRefEntry (src/PrefixTable.cpp:750-817), CS::PrefixSearch / AddLocationStd
+// (src/CS.cpp:114-213) and CS::CollectResultsStd (src/CS.cpp:263-313).
+//
+// Decomposition (one 64-lane wave per read):
+//   1. lanes own k-mer start positions; each valid k-mer costs two 8-byte index reads (forward k-mer,
+//      reverse-complement k-mer) -> up to 2*(L-k+1) position lists, skipped when fwd+rev >= max_kfreq;
+//   2. the lists are flattened: hit h of the read is found by a binary search over the prefix sums kept in
+//      LDS, so consecutive lanes read consecutive positions of a list (coalesced gather);
+//   3. every hit votes for bin((position - read offset) >> bin_size) in an open-addressing table in LDS
+//      (key = bin, value = forward votes | reverse votes << 16), atomicCAS + atomicAdd;
+//   4. max votes -> threshold max(kmer_min, max * sensitivity) in float exactly as the reference computes it;
+//      table entries at or above it are the candidate mapping regions.
+// The reference walks hits sequentially and remembers the order in which bins first crossed the running
+// threshold; the SET of candidates does not depend on that order (the running threshold never exceeds the
+// final one), only ties between equally scoring loci do.  Here the order is left to the table and the
+// selection stage breaks ties by position.
+// Reads whose hit count does not fit the LDS table are queued and re-run by the same kernel with a table in
+// global memory (template GLOBAL_TABLE).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ngm {
+
+struct CsArgs {
+	const uint8_t *reads;   // n rows of q bytes
+	int n;
+	int q;
+	int k;
+	int bin_shift;
+	int max_kfreq;
+	float sensitivity;
+	float kmer_min;
+	int max_cmrs;
+	const uint2 *index;
+	const uint32_t *positions;
+	int lists_cap;          // LDS capacity for lists (>= 2*(q-k+1))
+	int log2_slots;         // LDS table slots (GLOBAL_TABLE: unused)
+	uint32_t lds_hit_cap;   // reads with more hits go to the overflow queue
+	// outputs
+	uint16_t *read_len;     // [n]
+	uint32_t *cand_base;    // [n]
+	uint32_t *cand_count;   // [n]
+	float *max_votes;       // [n]
+	uint32_t *out_loc;      // candidate bin centres (concatenated coordinates)
+	uint32_t *out_sv;       // votes << 1 | strand
+	unsigned long long *out_total;  // allocation cursor
+	unsigned long long out_capacity;
+	uint32_t *status;       // [0] output overflow flag, [1] number of queued overflow reads
+	// overflow queue (written by the LDS pass, consumed by the GLOBAL_TABLE pass)
+	uint32_t *ovf_read;     // [n]
+	uint32_t *ovf_hits;     // [n]
+	// GLOBAL_TABLE pass
+	const uint64_t *ovf_table_off;  // per queued read: offset (in slots) into gtable_*
+	const uint32_t *ovf_log2;       // per queued read: log2 slots
+	uint32_t *gtable_keys;
+	uint32_t *gtable_votes;
+};
+
+__device__ __forceinline__ uint32_t cs_revcomp(uint32_t prefix, int k) {  // PrefixTable.cpp:94-108
+	const int shift = 32 - 2 * k;
+	uint32_t c = (prefix ^ 0xAAAAAAAAu) << shift;
+	c = (c & 0xFFFF0000u) >> 16 | (c & 0x0000FFFFu) << 16;
+	c = (c & 0xFF00FF00u) >> 8 | (c & 0x00FF00FFu) << 8;
+	c = (c & 0xF0F0F0F0u) >> 4 | (c & 0x0F0F0F0Fu) << 4;
+	c = (c & 0xCCCCCCCCu) >> 2 | (c & 0x33333333u) << 2;
+	return c;
+}
+
+__device__ __forceinline__ int wave_reduce_max(int v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+	return v;
+}
+__device__ __forceinline__ int wave_reduce_min(int v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t t = __shfl_up(v, o);
+		if (lane >= o) v += t;
+	}
+	return v;
+}
+
+// table reads after the voting phase: the global-memory table was updated by L2 atomics, so bypass L1
+template <bool GLOBAL_TABLE>
+__device__ __forceinline__ uint32_t cs_tload(const uint32_t *p) {
+	if (GLOBAL_TABLE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return *p;
+}
+
+template <bool GLOBAL_TABLE>
+__global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+	const int lane = threadIdx.x;
+	const int item = blockIdx.x;
+	const int read = GLOBAL_TABLE ? (int) A.ovf_read[item] : item;
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;                        // [lists_cap]
+	uint32_t *l_pref = cs_lds + A.lists_cap;           // [lists_cap + 1]
+	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);  // [q rounded up to 4]
+	const int code_words = (A.q + 3) / 4;
+	uint32_t *t_keys, *t_votes;
+	int log2_slots;
+	if (GLOBAL_TABLE) {
+		log2_slots = (int) A.ovf_log2[item];
+		t_keys = A.gtable_keys + A.ovf_table_off[item];
+		t_votes = A.gtable_votes + A.ovf_table_off[item];
+	} else {
+		log2_slots = A.log2_slots;
+		t_keys = (uint32_t *) l_code + code_words;
+		t_votes = t_keys + (1u << log2_slots);
+	}
+	const uint32_t n_slots = 1u << log2_slots;
+
+	// ---- 1. read -> 2-bit codes (A0 C1 T2 G3, CSstatic.cpp:20-22), N = 4, past the end = 255 ----------------
+	const uint8_t *rp = A.reads + (size_t) read * A.q;
+	int first_nul = A.q;
+	for (int i = lane; i < A.q; i += 64) {
+		const uint32_t ch = rp[i];
+		uint8_t code;
+		if (ch == 0) { code = 255; first_nul = min(first_nul, i); }
+		else if (ch == 'N') code = 4;
+		else code = (uint8_t) ((ch >> 1) & 3u);
+		l_code[i] = code;
+	}
+	const int L = wave_reduce_min(first_nul);  // MappedRead::length
+	__syncthreads();
+
+	// ---- 2. k-mers and their two position lists ---------------------------------------------------------
+	const int n_kmers = L - k + 1;
+	const int n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
+	uint32_t carry = 0;
+	for (int base = 0; base < n_lists; base += 64) {
+		const int li = base + lane;
+		uint32_t cnt = 0, start = 0;
+		if (li < n_lists) {
+			const int p = li >> 1;
+			bool valid = true;
+			uint32_t kmer = 0;
+			for (int j = 0; j < k; ++j) {
+				const uint32_t c = l_code[p + j];
+				valid = valid && (c < 4);
+				kmer = (kmer << 2) | (c & 3u);
+			}
+			// CSstatic.cpp:30-41: a k-mer that starts right after a restart-position N run and ends exactly at
+			// the read end is never visited
+			if (valid && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) valid = false;
+			if (valid) {
+				const uint2 ef = A.index[kmer];
+				const uint2 er = A.index[cs_revcomp(kmer, k)];
+				if ((int) (ef.y + er.y) < A.max_kfreq) {  // CS.cpp:122
+					const uint2 e = (li & 1) ? er : ef;
+					cnt = e.y;
+					start = e.x;
+				}
+			}
+		}
+		const uint32_t incl = wave_inclusive_scan(cnt, lane);
+		if (li < n_lists) { l_start[li] = start; l_pref[li] = carry + incl - cnt; }
+		carry += __shfl(incl, 63);
+	}
+	if (lane == 0) l_pref[n_lists] = carry;
+	const uint32_t H = carry;
+
+	if (!GLOBAL_TABLE && H > A.lds_hit_cap) {  // does not fit the LDS table: queue for the global-table pass
+		if (lane == 0) {
+			const uint32_t slot = atomicAdd(&A.status[1], 1u);
+			A.ovf_read[slot] = (uint32_t) read;
+			A.ovf_hits[slot] = H;
+			A.read_len[read] = (uint16_t) L;
+		}
+		return;
+	}
+
+	// ---- 3. votes ---------------------------------------------------------------------------------------
+	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+	__syncthreads();
+	if (GLOBAL_TABLE) __threadfence_block();
+	for (uint32_t h = lane; h < H; h += 64) {
+		int lo = 0, hi = n_lists;  // largest li with pref[li] <= h
+		while (hi - lo > 1) {
+			const int mid = (lo + hi) >> 1;
+			if (l_pref[mid] <= h) lo = mid; else hi = mid;
+		}
+		const uint32_t pos = A.positions[l_start[lo] + (h - l_pref[lo])];
+		const int p = lo >> 1;
+		const bool rev = lo & 1;
+		const uint32_t correction = rev ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
+		const uint32_t bin = (pos - correction) >> A.bin_shift;
+		uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
+		for (;;) {
+			const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+			if (prev == 0xFFFFFFFFu || prev == bin) break;
+			slot = (slot + 1) & (n_slots - 1);
+		}
+		atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
+	}
+	__syncthreads();
+	if (GLOBAL_TABLE) __threadfence_block();
+
+	// ---- 4. threshold and candidates (CS.cpp:201-205, :263-313) -------------------------------------------
+	int mx = 0;
+	for (uint32_t s = lane; s < n_slots; s += 64) {
+		const uint32_t v = cs_tload<GLOBAL_TABLE>(&t_votes[s]);
+		mx = max(mx, (int) max(v & 0xFFFFu, v >> 16));
+	}
+	mx = wave_reduce_max(mx);
+	const float max_hit = (float) mx;
+	const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
+	uint32_t count = 0;
+	for (uint32_t s = lane; s < n_slots; s += 64) {
+		if (cs_tload<GLOBAL_TABLE>(&t_keys[s]) != 0xFFFFFFFFu) {
+			const uint32_t v = cs_tload<GLOBAL_TABLE>(&t_votes[s]);
+			count += ((float) (v & 0xFFFFu) >= thresh) + ((float) (v >> 16) >= thresh);
+		}
+	}
+	const uint32_t incl = wave_inclusive_scan(count, lane);
+	uint32_t total = __shfl(incl, 63);
+	if ((int64_t) total >= (int64_t) A.max_cmrs) total = 0;  // "if (index < maxScores) AllocScores" (CS.cpp:308-310)
+	unsigned long long base = 0;
+	if (lane == 0) {
+		base = total ? atomicAdd(A.out_total, (unsigned long long) total) : 0ull;
+		if (base + total > A.out_capacity) { atomicExch(&A.status[0], 1u); }
+		A.cand_base[read] = (uint32_t) base;
+		A.cand_count[read] = total;
+		A.max_votes[read] = max_hit;
+		A.read_len[read] = (uint16_t) L;
+	}
+	base = __shfl((uint32_t) base, 0) | ((unsigned long long) __shfl((uint32_t) (base >> 32), 0) << 32);
+	if (total == 0 || base + total > A.out_capacity) return;
+	uint32_t w = (uint32_t) base + (incl - count);
+	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
+	for (uint32_t s = lane; s < n_slots; s += 64) {
+		const uint32_t key = cs_tload<GLOBAL_TABLE>(&t_keys[s]);
+		if (key != 0xFFFFFFFFu) {
+			const uint32_t v = cs_tload<GLOBAL_TABLE>(&t_votes[s]);
+			const uint32_t f = v & 0xFFFFu, r = v >> 16;
+			const uint32_t loc = (key << A.bin_shift) + centre;
+			if ((float) f >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = f << 1; ++w; }
+			if ((float) r >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = (r << 1) | 1u; ++w; }
+		}
+	}
+}
+
+}  // namespace ngm

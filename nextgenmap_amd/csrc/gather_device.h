@@ -1,0 +1,161 @@
+// gather_device.h -- device-side gather of (read, reference window) pairs into the packed layout the DP
+// kernels consume, straight from the HBM-resident genome and read batch.  Replaces the host loops of
+// ScoreBuffer::DoRun / AlignmentBuffer::DoRun (src/ScoreBuffer.cpp:87-122, src/AlignmentBuffer.cpp:73-111):
+// MappedRead::computeReverseSeq (src/MappedRead.cpp:53-68) and _SequenceProvider::DecodeRefSequence
+// (src/SequenceProvider.cpp:382-441), including its window-geometry quirks (odd offsets yield one extra base,
+// an odd decode length turns the last base into 'x', 'x' fill past the genome end, NUL tail).
+// Also holds the top-1 selection / MAPQ kernel (ScoreBuffer::top1SE + computeMQ, src/ScoreBuffer.cpp:34-49, :228-277).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_device.h"
+
+namespace ngm {
+
+struct WindowGeom {
+	uint64_t concat_len;   // _SequenceProvider::GetConcatRefLen
+	int buffer_len;        // refMaxLen the host would allocate: ((q+c)|1)+1 for scores, (q+c)|2 for alignments
+	int half_corridor;     // corridor >> 1
+};
+
+// class (A0 C1 G2 T3 x4 N5 NUL6) of window byte j for a window starting at genome position `offset`
+__device__ __forceinline__ uint32_t window_class(const uint32_t *__restrict__ genome, const WindowGeom &G, uint64_t offset, int j) {
+	uint64_t len = (uint64_t) G.buffer_len - 2;
+	if (offset >= G.concat_len) return 5u;            // decode failed: the caller fills the row with 'N' (ScoreBuffer.cpp:113-118)
+	uint64_t end = 0;
+	if (offset + len > G.concat_len) { end = offset + len - G.concat_len; len -= end; }
+	const uint64_t emitted = ((offset & 1) ? 1 : 0) + 2 * ((len + 1) / 2);
+	const uint64_t jj = (uint64_t) j;
+	if (jj < emitted) {
+		if ((len & 1) && jj == emitted - 1) return 4u;  // "buffer[codedIndex - 1] = 'x'"
+		const uint64_t pos = offset + jj;
+		return (genome[pos >> 3] >> (4 * (pos & 7))) & 15u;
+	}
+	if (jj < emitted + end) return 4u;                 // 'x' fill past the genome end
+	return 6u;                                         // zero fill
+}
+
+__device__ __forceinline__ uint32_t read_class_fwd(uint32_t ch) {
+	uint32_t k = 5;  // reads only hold A C G T N (IParser.h:59-121); anything else is treated as N
+	k = (ch == 'A') ? 0u : k;
+	k = (ch == 'C') ? 1u : k;
+	k = (ch == 'G') ? 2u : k;
+	k = (ch == 'T') ? 3u : k;
+	k = (ch == 0) ? 6u : k;
+	return k;
+}
+
+// One workgroup (256 threads) per block of 64 pairs; pair p = (pair_read[p], pair_loc[p], pair_strand[p]).
+__global__ __launch_bounds__(256) void gather_pairs_kernel(const uint8_t *__restrict__ reads, const uint16_t *__restrict__ read_len,
+		int q, const uint32_t *__restrict__ genome, WindowGeom G, const uint32_t *__restrict__ pair_read,
+		const uint32_t *__restrict__ pair_loc, const uint32_t *__restrict__ pair_sv, int n_pairs, int RW, int FW,
+		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows) {
+	__shared__ int s_rows;
+	const int tid = threadIdx.x;
+	const int blk = blockIdx.x;
+	const int slot = tid & 63, part = tid >> 6;
+	const int pair = blk * kSlots + slot;
+	if (tid == 0) s_rows = 0;
+	__syncthreads();
+	uint32_t *ob = out + (size_t) blk * (RW + FW) * kSlots + slot;
+	const bool live = pair < n_pairs;
+	const uint32_t ridx = live ? pair_read[pair] : 0u;
+	const bool rev = live ? (pair_sv[pair] & 1u) : false;
+	const int L = live ? (int) read_len[ridx] : 0;
+	const uint8_t *rp = reads + (size_t) ridx * q;
+	for (int m = part; m < RW; m += 4) {
+		uint32_t k[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int i = m * 8 + j;
+			uint32_t c = 6u;
+			if (live && i < L) {
+				if (!rev) c = read_class_fwd(rp[i]);
+				else {  // reverse complement: A<->T, C<->G, N stays (MappedRead.cpp:32-43, :53-68)
+					c = read_class_fwd(rp[L - 1 - i]);
+					c = (c <= 3u) ? 3u - c : c;
+				}
+			}
+			k[j] = c;
+		}
+		ob[(size_t) m * kSlots] = pack8(k);
+	}
+	const uint64_t offset = live ? (uint64_t) pair_loc[pair] - (uint64_t) G.half_corridor : 0;
+	for (int m = part; m < FW; m += 4) {
+		uint32_t k[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) k[j] = live ? window_class(genome, G, offset, m * 8 + j) : 6u;
+		ob[(size_t) (RW + m) * kSlots] = pack8(k);
+	}
+	if (part == 0) {
+		if (live) lens[pair] = (uint16_t) L;
+		atomicMax(&s_rows, L);
+	}
+	__syncthreads();
+	if (tid == 0) blk_rows[blk] = (uint16_t) s_rows;
+}
+
+// ScoreBuffer::top1SE + computeMQ for every read; one thread per read.
+// winner: pair index of the best candidate (ties: smallest location, forward strand first), or 0xFFFFFFFF.
+__global__ void select_top1_kernel(int n_reads, const uint32_t *__restrict__ cand_base, const uint32_t *__restrict__ cand_count,
+		const float *__restrict__ scores, const uint32_t *__restrict__ pair_loc, const uint32_t *__restrict__ pair_sv,
+		uint32_t *__restrict__ winner, int32_t *__restrict__ mapq, int32_t *__restrict__ n_best, float *__restrict__ best_score) {
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const uint32_t b = cand_base[r], n = cand_count[r];
+	if (n == 0) { winner[r] = 0xFFFFFFFFu; mapq[r] = 0; n_best[r] = 0; best_score[r] = 0.f; return; }
+	float best = 0.0f, second = 0.0f;
+	int num = 0;
+	uint32_t bi = b;
+	uint64_t bkey = ~0ull;
+	for (uint32_t j = b; j < b + n; ++j) {
+		const float s = scores[j];
+		const uint64_t key = ((uint64_t) pair_loc[j] << 1) | (pair_sv[j] & 1u);
+		if (s > second) {
+			if (s > best) { second = best; best = s; num = 1; bi = j; bkey = key; }
+			else if (s == best) { ++num; second = best; if (key < bkey) { bkey = key; bi = j; } }
+			else second = s;
+		} else if (s == best) {
+			++num;
+			if (key < bkey) { bkey = key; bi = j; }
+		}
+	}
+	if (num == 0) {  // no positive score: the reference still submits a candidate (its first); ties -> smallest location
+		for (uint32_t j = b; j < b + n; ++j) {
+			const uint64_t key = ((uint64_t) pair_loc[j] << 1) | (pair_sv[j] & 1u);
+			if (key < bkey) { bkey = key; bi = j; }
+		}
+	}
+	int mq = 0;
+	if (best > 0 && second >= 0) mq = (int) ceilf(60.0f * (best - second) / best);  // ScoreBuffer.cpp:34-40
+	winner[r] = bi;
+	mapq[r] = mq;
+	n_best[r] = num;
+	best_score[r] = best > 0 ? best : scores[bi];
+}
+
+// expands per-read candidate lists into pair arrays: pair j of read r gets pair_read[j] = r
+__global__ void expand_pairs_kernel(int n_reads, const uint32_t *__restrict__ cand_base, const uint32_t *__restrict__ cand_count,
+		uint32_t *__restrict__ pair_read) {
+	const int r = blockIdx.x;
+	const uint32_t b = cand_base[r], n = cand_count[r];
+	for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) pair_read[b + j] = (uint32_t) r;
+}
+
+// winners -> compact alignment batch
+__global__ void collect_winners_kernel(int n_reads, const uint32_t *__restrict__ winner, const uint32_t *__restrict__ pair_loc,
+		const uint32_t *__restrict__ pair_sv, const uint32_t *__restrict__ slot_of_read, uint32_t *__restrict__ a_read,
+		uint32_t *__restrict__ a_loc, uint32_t *__restrict__ a_sv) {
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const uint32_t w = winner[r];
+	if (w == 0xFFFFFFFFu) return;
+	const uint32_t s = slot_of_read[r];
+	a_read[s] = (uint32_t) r;
+	a_loc[s] = pair_loc[w];
+	a_sv[s] = pair_sv[w];
+}
+
+}  // namespace ngm

@@ -1,10 +1,415 @@
-#include "../../include/ngm_pipeline.h"
-extern "C" {
-int ngm_ref_decode(const ngm_ref *, uint64_t, int, char *) { return -38; }
-ngm_mapper *ngm_mapper_create(const ngm_ref *, const ngm_mapper_params *) { return 0; }
-void ngm_mapper_destroy(ngm_mapper *) {}
-int ngm_mapper_cs(ngm_mapper *, int, const char *, uint32_t *, float *) { return -38; }
-int ngm_mapper_cs_fetch(ngm_mapper *, uint64_t *, uint8_t *, float *) { return -38; }
-int ngm_mapper_map_se(ngm_mapper *, int, const char *, ngm_hit *, char *, char *) { return -38; }
-int ngm_mapper_last_kernel_ms(ngm_mapper *, float *) { return -38; }
+// mapper.cpp -- the device-resident mapping path above IAlignment (include/ngm_pipeline.h):
+//   candidate search -> window gather -> BatchScore -> top-1 selection / MAPQ -> window gather -> BatchAlign.
+// One ngm_mapper is what one NextGenMap CS thread owns (CS + ScoreBuffer + AlignmentBuffer + IAlignment,
+// src/CS.cpp:455-461); everything between the read upload and the traceback download stays in HBM.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "refindex.h"
+#include "engine_internal.h"
+#include "align_device.h"
+#include "cigar_md.h"
+#include "cs_device.h"
+#include "gather_device.h"
+
+#define MAP_HIP_TRY(expr)                                                                      \
+	do {                                                                                       \
+		hipError_t e_ = (expr);                                                                \
+		if (e_ != hipSuccess) {                                                                \
+			ngm::pipeline_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return -5;                                                                         \
+		}                                                                                      \
+	} while (0)
+
+struct ngm_mapper {
+	const ngm_ref *ref = nullptr;
+	ngm_mapper_params prm{};
+	ngm_hip_ctx *eng = nullptr;
+	hipStream_t st = nullptr;
+	int max_kfreq = 0;
+	int cs_log2_slots = 13;
+	// batch state in HBM
+	ngm::DevBuf<uint8_t> d_reads;
+	ngm::DevBuf<uint16_t> d_read_len;
+	ngm::DevBuf<uint32_t> d_cand_base, d_cand_count, d_out_loc, d_out_sv, d_status, d_ovf_read, d_ovf_hits, d_ovf_log2;
+	ngm::DevBuf<uint64_t> d_ovf_off;
+	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes;
+	ngm::DevBuf<float> d_max_votes, d_scores, d_best;
+	ngm::DevBuf<unsigned long long> d_total;
+	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
+	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records;
+	ngm::DevBuf<uint16_t> d_runs;
+	// last CS result on the host
+	int n_reads = 0;
+	std::vector<uint32_t> h_base, h_count;
+	std::vector<float> h_maxv;
+	uint64_t n_cand = 0;
+	hipEvent_t ev[10] = {};
+	float ms[8] = {};
+};
+
+namespace {
+
+struct DevGuard {
+	int prev = -1;
+	explicit DevGuard(int d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != d) (void) hipSetDevice(d); else prev = -1; }
+	~DevGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+size_t cs_lds_bytes(const ngm::CsArgs &A, bool global_table) {
+	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
+	if (!global_table) w += (size_t) 2 << A.log2_slots;
+	return w * 4;
 }
+
+// candidate search for the reads already in m->d_reads; leaves per-read base/count/max votes and the
+// candidate arrays in HBM (and base/count/max votes on the host)
+int run_cs(ngm_mapper *m, int n) {
+	const ngm_ref *r = m->ref;
+	const int q = m->prm.qry_max_len;
+	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) ||
+			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_ovf_read.reserve(n) || m->d_ovf_hits.reserve(n)) {
+		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
+		return -12;
+	}
+	size_t cap = std::max<size_t>(m->d_out_loc.cap, (size_t) n * 8 + 1024);
+	for (int attempt = 0; attempt < 8; ++attempt) {
+		if (m->d_out_loc.reserve(cap) || m->d_out_sv.reserve(cap)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
+		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, 8, m->st));
+		ngm::CsArgs A{};
+		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
+		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
+		A.index = r->d_index; A.positions = r->d_positions;
+		A.lists_cap = 2 * std::max(1, q - r->prm.kmer + 1);
+		A.log2_slots = m->cs_log2_slots;
+		A.lds_hit_cap = (uint32_t) ((1u << m->cs_log2_slots) * 0.66f);
+		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p;
+		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap;
+		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p;
+		const size_t lds = cs_lds_bytes(A, false);
+		hipLaunchKernelGGL(ngm::cs_kernel<false>, dim3(n), dim3(64), lds, m->st, A);
+		MAP_HIP_TRY(hipGetLastError());
+		uint32_t status[4];
+		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		if (status[1] > 0) {  // reads whose hits do not fit the LDS table: second pass with tables in global memory
+			const uint32_t no = status[1];
+			std::vector<uint32_t> hits(no), lg(no);
+			std::vector<uint64_t> off(no);
+			MAP_HIP_TRY(hipMemcpy(hits.data(), m->d_ovf_hits.p, no * 4, hipMemcpyDeviceToHost));
+			uint64_t total_slots = 0;
+			for (uint32_t i = 0; i < no; ++i) {
+				uint32_t l = 4;
+				while ((1ull << l) < 2ull * hits[i]) ++l;
+				lg[i] = l;
+				off[i] = total_slots;
+				total_slots += 1ull << l;
+			}
+			if (m->d_gt_keys.reserve(total_slots) || m->d_gt_votes.reserve(total_slots) || m->d_ovf_off.reserve(no) || m->d_ovf_log2.reserve(no)) {
+				ngm::pipeline_set_error("out of device memory (overflow vote tables, %llu slots)", (unsigned long long) total_slots);
+				return -12;
+			}
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data(), no * 8, hipMemcpyHostToDevice, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data(), no * 4, hipMemcpyHostToDevice, m->st));
+			A.ovf_table_off = m->d_ovf_off.p; A.ovf_log2 = m->d_ovf_log2.p; A.gtable_keys = m->d_gt_keys.p; A.gtable_votes = m->d_gt_votes.p;
+			hipLaunchKernelGGL(ngm::cs_kernel<true>, dim3(no), dim3(64), cs_lds_bytes(A, true), m->st, A);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		}
+		if (status[0] == 0) {
+			unsigned long long total = 0;
+			MAP_HIP_TRY(hipMemcpy(&total, m->d_total.p, 8, hipMemcpyDeviceToHost));
+			m->n_cand = total;
+			m->n_reads = n;
+			m->h_base.resize(n); m->h_count.resize(n); m->h_maxv.resize(n);
+			MAP_HIP_TRY(hipMemcpy(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+			MAP_HIP_TRY(hipMemcpy(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+			MAP_HIP_TRY(hipMemcpy(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+			return 0;
+		}
+		cap *= 4;  // candidate buffer too small: grow and redo the batch
+	}
+	ngm::pipeline_set_error("candidate buffer overflow persists");
+	return -75;
+}
+
+int upload_reads(ngm_mapper *m, int n, const char *reads) {
+	const size_t bytes = (size_t) n * m->prm.qry_max_len;
+	if (m->d_reads.reserve(bytes)) { ngm::pipeline_set_error("out of device memory (reads)"); return -12; }
+	MAP_HIP_TRY(hipMemcpyAsync(m->d_reads.p, reads, bytes, hipMemcpyHostToDevice, m->st));
+	return 0;
+}
+
+char class_char(uint8_t c) {
+	static const char t[8] = {'A', 'C', 'G', 'T', 'x', 'N', 0, 0};
+	return t[c & 7];
+}
+
+// host twin of window_class (gather_device.h) for the CIGAR/MD pass: DecodeRefSequence into ASCII
+void host_window(const ngm_ref *r, uint64_t offset, int buffer_len, int want, char *out) {
+	const uint64_t concat_len = r->n_bases - 1;
+	uint64_t len = (uint64_t) buffer_len - 2;
+	if (offset >= concat_len) { memset(out, 'N', want); return; }
+	uint64_t end = 0;
+	if (offset + len > concat_len) { end = offset + len - concat_len; len -= end; }
+	const uint64_t emitted = ((offset & 1) ? 1 : 0) + 2 * ((len + 1) / 2);
+	for (int j = 0; j < want; ++j) {
+		const uint64_t jj = (uint64_t) j;
+		char ch;
+		if (jj < emitted) ch = ((len & 1) && jj == emitted - 1) ? 'x' : class_char(r->host_cls[offset + jj]);
+		else if (jj < emitted + end) ch = 'x';
+		else ch = 0;
+		out[j] = ch;
+	}
+}
+
+}  // namespace
+
+extern "C" {
+
+int ngm_ref_decode(const ngm_ref *r, uint64_t offset, int buffer_len, char *out) {
+	// runs the device window function over one window so that tests exercise the HBM copy
+	DevGuard g(r->device);
+	if (buffer_len < 2) return -22;
+	const uint64_t concat_len = r->n_bases - 1;
+	if (offset >= concat_len) { memset(out, 0, buffer_len); return 0; }  // DecodeRefSequence returns false
+	// reuse the gather kernel: one pair, read of length 0, corridor 0, q = buffer_len rounded up
+	const int q = 8, c = buffer_len;  // window = q + c >= buffer_len bytes
+	const int RW = ngm::read_words(q), FW = (q + c + 7) / 8 + 1;
+	uint32_t *d_out; uint16_t *d_lens, *d_rows, *d_rl; uint8_t *d_reads; uint32_t *d_pr, *d_pl, *d_ps;
+	MAP_HIP_TRY(hipMalloc(&d_out, (size_t) (RW + FW) * 64 * 4)); MAP_HIP_TRY(hipMalloc(&d_lens, 128)); MAP_HIP_TRY(hipMalloc(&d_rows, 8));
+	MAP_HIP_TRY(hipMalloc(&d_rl, 8)); MAP_HIP_TRY(hipMalloc(&d_reads, q)); MAP_HIP_TRY(hipMalloc(&d_pr, 4)); MAP_HIP_TRY(hipMalloc(&d_pl, 4)); MAP_HIP_TRY(hipMalloc(&d_ps, 4));
+	MAP_HIP_TRY(hipMemset(d_rl, 0, 8)); MAP_HIP_TRY(hipMemset(d_reads, 0, q)); MAP_HIP_TRY(hipMemset(d_pr, 0, 4)); MAP_HIP_TRY(hipMemset(d_ps, 0, 4));
+	const uint32_t loc = (uint32_t) offset;
+	MAP_HIP_TRY(hipMemcpy(d_pl, &loc, 4, hipMemcpyHostToDevice));
+	ngm::WindowGeom G{concat_len, buffer_len, 0};
+	hipLaunchKernelGGL(ngm::gather_pairs_kernel, dim3(1), dim3(256), 0, 0, d_reads, d_rl, q, r->d_genome, G, d_pr, d_pl, d_ps, 1, RW, FW, d_out, d_lens, d_rows);
+	MAP_HIP_TRY(hipGetLastError());
+	std::vector<uint32_t> h((size_t) (RW + FW) * 64);
+	MAP_HIP_TRY(hipMemcpy(h.data(), d_out, h.size() * 4, hipMemcpyDeviceToHost));
+	for (int j = 0; j < buffer_len; ++j) {
+		const uint32_t w = h[(size_t) (RW + j / 8) * 64];
+		const int b = j & 7;
+		const uint32_t cls = (b < 4) ? (w >> (8 * b)) & 15u : (w >> (8 * (b - 4) + 4)) & 15u;
+		out[j] = class_char((uint8_t) cls);
+	}
+	(void) hipFree(d_out); (void) hipFree(d_lens); (void) hipFree(d_rows); (void) hipFree(d_rl); (void) hipFree(d_reads); (void) hipFree(d_pr); (void) hipFree(d_pl); (void) hipFree(d_ps);
+	return 1;
+}
+
+ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
+	if (!ref || !p) { ngm::pipeline_set_error("ngm_mapper_create: null argument"); return nullptr; }
+	DevGuard g(ref->device);
+	if (p->qry_max_len < ref->prm.kmer + 1 || p->qry_max_len > 1024) { ngm::pipeline_set_error("ngm_mapper_create: qry_max_len %d out of range", p->qry_max_len); return nullptr; }
+	ngm_hip_params ep{};
+	ep.abi_version = NGM_HIP_ABI_VERSION;
+	ep.qry_max_len = p->qry_max_len; ep.corridor = p->corridor;
+	ep.match_bonus = p->match_bonus; ep.mismatch_penalty = p->mismatch_penalty; ep.gap_read_penalty = p->gap_read_penalty; ep.gap_ref_penalty = p->gap_ref_penalty;
+	ep.variant = p->variant; ep.hard_clip = p->hard_clip; ep.silent_clip = p->silent_clip; ep.max_batch = 0;
+	ngm_hip_ctx *eng = ngm_hip_create(ref->device, &ep);
+	if (!eng) { ngm::pipeline_set_error("%s", ngm_hip_last_error(nullptr)); return nullptr; }
+	ngm_mapper *m = new ngm_mapper();
+	m->ref = ref; m->prm = *p; m->eng = eng; m->st = eng->stream;
+	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
+	for (auto &e : m->ev) (void) hipEventCreate(&e);
+	// LDS budget of the vote table: 2^13 slots * 8 B = 64 KB (+ lists and the read)
+	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len; A.log2_slots = m->cs_log2_slots;
+	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, false));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, true));
+	return m;
+}
+
+void ngm_mapper_destroy(ngm_mapper *m) {
+	if (!m) return;
+	DevGuard g(m->ref->device);
+	(void) hipStreamSynchronize(m->st);
+	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
+	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
+	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
+	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
+	m->d_records.release(); m->d_runs.release();
+	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
+	ngm_hip_destroy(m->eng);
+	delete m;
+}
+
+int ngm_mapper_cs(ngm_mapper *m, int n, const char *reads, uint32_t *cand_offsets, float *max_votes) {
+	if (!m || n < 0) return -22;
+	DevGuard g(m->ref->device);
+	if (n == 0) { cand_offsets[0] = 0; m->n_reads = 0; m->n_cand = 0; return 0; }
+	if (int r = upload_reads(m, n, reads)) return r;
+	if (int r = run_cs(m, n)) return r;
+	uint32_t acc = 0;
+	for (int i = 0; i < n; ++i) { cand_offsets[i] = acc; acc += m->h_count[i]; max_votes[i] = m->h_maxv[i]; }
+	cand_offsets[n] = acc;
+	return 0;
+}
+
+int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *votes) {
+	if (!m) return -22;
+	DevGuard g(m->ref->device);
+	if (m->n_cand == 0) return 0;
+	std::vector<uint32_t> hl(m->n_cand), hs(m->n_cand);
+	MAP_HIP_TRY(hipMemcpy(hl.data(), m->d_out_loc.p, m->n_cand * 4, hipMemcpyDeviceToHost));
+	MAP_HIP_TRY(hipMemcpy(hs.data(), m->d_out_sv.p, m->n_cand * 4, hipMemcpyDeviceToHost));
+	size_t w = 0;
+	std::vector<uint32_t> order;
+	for (int i = 0; i < m->n_reads; ++i) {
+		const uint32_t b = m->h_base[i], c = m->h_count[i];
+		order.resize(c);
+		std::iota(order.begin(), order.end(), b);
+		std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+			const uint64_t kx = ((uint64_t) hl[x] << 1) | (hs[x] & 1), ky = ((uint64_t) hl[y] << 1) | (hs[y] & 1);
+			return kx < ky;
+		});
+		for (uint32_t j : order) { loc[w] = hl[j]; strand[w] = (uint8_t) (hs[j] & 1); votes[w] = (float) (hs[j] >> 1); ++w; }
+	}
+	return 0;
+}
+
+int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds) {
+	if (!m || n < 0) return -22;
+	if (n == 0) return 0;
+	const ngm_ref *r = m->ref;
+	DevGuard g(r->device);
+	ngm_hip_ctx *eng = m->eng;
+	const int q = m->prm.qry_max_len, c = m->prm.corridor, mode = m->prm.mode;
+	const size_t str_stride = (size_t) 4 * std::max(1, q);
+	for (auto &x : m->ms) x = 0.f;
+
+	MAP_HIP_TRY(hipEventRecord(m->ev[0], m->st));
+	if (int rc = upload_reads(m, n, reads)) return rc;
+	if (int rc = run_cs(m, n)) return rc;
+	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
+	const uint64_t np = m->n_cand;
+
+	std::vector<uint32_t> h_winner(n, 0xFFFFFFFFu);
+	std::vector<int32_t> h_mapq(n, 0), h_nbest(n, 0);
+	std::vector<float> h_best(n, 0.f);
+	std::vector<uint32_t> h_loc, h_sv;
+	if (np > 0) {
+		// ---- score stage: all candidates of the batch in one BatchScore -------------------------------------
+		if (m->d_pair_read.reserve(np) || m->d_scores.reserve(np) || m->d_winner.reserve(n) || m->d_mapq.reserve(n) || m->d_nbest.reserve(n) ||
+				m->d_best.reserve(n)) { ngm::pipeline_set_error("out of device memory (score stage)"); return -12; }
+		if (int rc = ngm::engine_reserve(eng, (int) np)) { ngm::pipeline_set_error("%s", ngm_hip_last_error(eng)); return rc; }
+		hipLaunchKernelGGL(ngm::expand_pairs_kernel, dim3(n), dim3(64), 0, m->st, n, m->d_cand_base.p, m->d_cand_count.p, m->d_pair_read.p);
+		const int nb = (int) ((np + ngm::kSlots - 1) / ngm::kSlots);
+		ngm::WindowGeom Gs{r->n_bases - 1, ((q + c) | 1) + 1, c >> 1};  // refMaxLen of ScoreBuffer.h:112
+		hipLaunchKernelGGL(ngm::gather_pairs_kernel, dim3(nb), dim3(256), 0, m->st, m->d_reads.p, m->d_read_len.p, q, r->d_genome, Gs,
+				m->d_pair_read.p, m->d_out_loc.p, m->d_out_sv.p, (int) np, eng->RW, eng->FW, eng->packed.p, eng->lens.p, eng->blk_rows.p);
+		MAP_HIP_TRY(hipGetLastError());
+		MAP_HIP_TRY(hipEventRecord(m->ev[2], m->st));
+		if (int rc = ngm::engine_score_packed(eng, mode, (int) np, m->d_scores.p, m->st)) { ngm::pipeline_set_error("%s", ngm_hip_last_error(eng)); return rc; }
+		MAP_HIP_TRY(hipEventRecord(m->ev[3], m->st));
+		hipLaunchKernelGGL(ngm::select_top1_kernel, dim3((n + 255) / 256), dim3(256), 0, m->st, n, m->d_cand_base.p, m->d_cand_count.p,
+				m->d_scores.p, m->d_out_loc.p, m->d_out_sv.p, m->d_winner.p, m->d_mapq.p, m->d_nbest.p, m->d_best.p);
+		MAP_HIP_TRY(hipGetLastError());
+		MAP_HIP_TRY(hipEventRecord(m->ev[4], m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_winner.data(), m->d_winner.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_mapq.data(), m->d_mapq.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_nbest.data(), m->d_nbest.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_best.data(), m->d_best.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		h_loc.resize(np); h_sv.resize(np);
+		MAP_HIP_TRY(hipMemcpyAsync(h_loc.data(), m->d_out_loc.p, np * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_sv.data(), m->d_out_sv.p, np * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+	}
+
+	// ---- alignment stage: one pair per read that has a winner (AlignmentBuffer::DoRun) --------------------
+	std::vector<uint32_t> a_read, a_loc, a_sv;
+	for (int i = 0; i < n; ++i) if (h_winner[i] != 0xFFFFFFFFu) { a_read.push_back(i); a_loc.push_back(h_loc[h_winner[i]]); a_sv.push_back(h_sv[h_winner[i]]); }
+	const int na = (int) a_read.size();
+	const int rs = ngm::run_stride(q, c);
+	std::vector<int32_t> h_rec((size_t) na * 8);
+	std::vector<uint16_t> h_runs((size_t) na * rs);
+	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
+	if (na > 0) {
+		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
+				m->d_runs.reserve((size_t) na * rs)) { ngm::pipeline_set_error("out of device memory (align stage)"); return -12; }
+		if (int rc = ngm::engine_reserve(eng, na)) { ngm::pipeline_set_error("%s", ngm_hip_last_error(eng)); return rc; }
+		MAP_HIP_TRY(hipMemcpyAsync(m->d_a_read.p, a_read.data(), (size_t) na * 4, hipMemcpyHostToDevice, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(m->d_a_loc.p, a_loc.data(), (size_t) na * 4, hipMemcpyHostToDevice, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(m->d_a_sv.p, a_sv.data(), (size_t) na * 4, hipMemcpyHostToDevice, m->st));
+		MAP_HIP_TRY(hipEventRecord(m->ev[5], m->st));
+		ngm::WindowGeom Ga{r->n_bases - 1, align_buf_len, c >> 1};
+		hipLaunchKernelGGL(ngm::gather_pairs_kernel, dim3((na + ngm::kSlots - 1) / ngm::kSlots), dim3(256), 0, m->st, m->d_reads.p, m->d_read_len.p, q,
+				r->d_genome, Ga, m->d_a_read.p, m->d_a_loc.p, m->d_a_sv.p, na, eng->RW, eng->FW, eng->packed.p, eng->lens.p, eng->blk_rows.p);
+		MAP_HIP_TRY(hipGetLastError());
+		MAP_HIP_TRY(hipEventRecord(m->ev[6], m->st));
+		const bool was_prof = eng->profiling;
+		eng->profiling = true;  // brackets DP vs traceback with eng->ev[2]
+		if (int rc = ngm::engine_align_packed(eng, mode, na, m->d_records.p, m->d_runs.p, rs, m->st)) { eng->profiling = was_prof; ngm::pipeline_set_error("%s", ngm_hip_last_error(eng)); return rc; }
+		eng->profiling = was_prof;
+		MAP_HIP_TRY(hipEventRecord(m->ev[7], m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_rec.data(), m->d_records.p, h_rec.size() * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_runs.data(), m->d_runs.p, h_runs.size() * 2, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+	}
+
+	// ---- host: CIGAR / MD, final positions --------------------------------------------------------------
+	for (int i = 0; i < n; ++i) {
+		ngm_hit &h = hits[i];
+		memset(&h, 0, sizeof(h));
+		h.n_candidates = (int) m->h_count[i];
+		h.max_votes = m->h_maxv[i];
+		h.mapq = h_mapq[i];
+		h.n_best = h_nbest[i];
+		h.score = h_best[i];
+		cigars[(size_t) i * str_stride] = 0;
+		mds[(size_t) i * str_stride] = 0;
+	}
+	ngm::CigarParams cp{m->prm.match_bonus, -m->prm.mismatch_penalty, m->prm.variant, m->prm.hard_clip, m->prm.silent_clip};
+	std::vector<char> win((size_t) q + c + 8), qry((size_t) q + 8);
+	for (int j = 0; j < na; ++j) {
+		const int i = (int) a_read[j];
+		ngm_hit &h = hits[i];
+		const bool rev = a_sv[j] & 1u;
+		h.reverse = rev;
+		const uint64_t offset = (uint64_t) a_loc[j] - (uint64_t) (c >> 1);
+		host_window(r, offset, align_buf_len, q + c, win.data());
+		const char *rd = reads + (size_t) i * q;
+		const int L = (int) strnlen(rd, q);
+		memset(qry.data(), 0, qry.size());
+		if (!rev) memcpy(qry.data(), rd, L);
+		else for (int t = 0; t < L; ++t) {
+			const char ch = rd[L - 1 - t];
+			qry[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+		}
+		ngm_hip_align_out ao{};
+		ao.cigar = cigars + (size_t) i * str_stride;
+		ao.md = mds + (size_t) i * str_stride;
+		ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) j * rs], win.data(), qry.data(), &ao);
+		if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
+		h.identity = ao.identity; h.nm = ao.nm; h.qstart = ao.qstart; h.qend = ao.qend;
+		// AlignmentBuffer.cpp:129 then SequenceProvider.convert (AlignmentBuffer.cpp:173)
+		const uint64_t final_loc = (uint64_t) a_loc[j] + (uint64_t) (int64_t) ao.position_offset - (uint64_t) (c >> 1);
+		int contig = 0; uint64_t cpos = 0;
+		if (!ngm_ref_convert(r, final_loc, &contig, &cpos)) { h.mapped = 0; continue; }
+		h.mapped = 1; h.contig = contig; h.pos = cpos;
+	}
+
+	// kernel times
+	auto et = [&](int a, int b) { float t = 0; if (hipEventElapsedTime(&t, m->ev[a], m->ev[b]) != hipSuccess) t = 0; return t; };
+	m->ms[0] = et(0, 1);
+	if (np > 0) { m->ms[1] = et(1, 2); m->ms[2] = et(2, 3); m->ms[3] = et(3, 4); }
+	if (na > 0) {
+		m->ms[4] = et(5, 6);
+		float t = 0;
+		if (hipEventElapsedTime(&t, m->ev[6], eng->ev[2]) == hipSuccess) m->ms[5] = t;
+		if (hipEventElapsedTime(&t, eng->ev[2], m->ev[7]) == hipSuccess) m->ms[6] = t;
+	}
+	return n;
+}
+
+int ngm_mapper_last_kernel_ms(ngm_mapper *m, float ms[8]) {
+	if (!m) return -22;
+	for (int i = 0; i < 8; ++i) ms[i] = m->ms[i];
+	return 0;
+}
+
+}  // extern "C"

@@ -13,7 +13,8 @@
 #include <string>
 #include <vector>
 
-#include "sw_device.h"
+#define NGM_ENGINE_KERNELS
+#include "engine_internal.h"
 #include "align_device.h"
 #include "cigar_md.h"
 
@@ -32,66 +33,8 @@ void set_error(ngm_hip_ctx *ctx, const char *fmt, ...);
 		}                                                                                          \
 	} while (0)
 
-template <typename T>
-struct DevBuf {
-	T *p = nullptr;
-	size_t cap = 0;  // elements
-	int reserve(size_t n) {
-		if (n <= cap) return 0;
-		if (p) (void) hipFree(p);
-		p = nullptr;
-		cap = 0;
-		if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return -1;
-		cap = n;
-		return 0;
-	}
-	void release() { if (p) (void) hipFree(p); p = nullptr; cap = 0; }
-};
-
-template <typename T>
-struct PinnedBuf {
-	T *p = nullptr;
-	size_t cap = 0;
-	int reserve(size_t n) {
-		if (n <= cap) return 0;
-		if (p) (void) hipHostFree(p);
-		p = nullptr;
-		cap = 0;
-		if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) return -1;
-		cap = n;
-		return 0;
-	}
-	void release() { if (p) (void) hipHostFree(p); p = nullptr; cap = 0; }
-};
-
 }  // namespace
 
-struct ngm_hip_ctx {
-	int device = 0;
-	ngm_hip_params prm{};
-	ngm::SwConst K{};
-	int q = 0, c = 0, rl = 0, RW = 0, FW = 0;
-	int max_batch = 0;
-	hipStream_t stream = nullptr;
-	// HBM workspace
-	DevBuf<uint32_t> packed;
-	DevBuf<uint16_t> lens, blk_rows;
-	DevBuf<uint8_t> d_ref, d_qry;
-	DevBuf<float> d_scores;
-	DevBuf<uint32_t> dirs;
-	DevBuf<int32_t> d_records;
-	DevBuf<uint16_t> d_runs;
-	// pinned staging for the host-pointer entry points
-	PinnedBuf<uint8_t> h_ref, h_qry;
-	PinnedBuf<float> h_scores;
-	PinnedBuf<int32_t> h_records;
-	PinnedBuf<uint16_t> h_runs;
-	// profiling
-	bool profiling = false;
-	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-	bool ev_valid[3] = {false, false, false};
-	std::string error;
-};
 
 namespace {
 
@@ -130,7 +73,9 @@ align_kernel_t find_align_kernel(int c, bool endfree) {
 
 int n_blocks_of(int n) { return (n + ngm::kSlots - 1) / ngm::kSlots; }
 
-int reserve_workspace(ngm_hip_ctx *ctx, int n) {
+}  // namespace
+namespace ngm {
+int engine_reserve(ngm_hip_ctx *ctx, int n) {
 	const size_t nb = (size_t) n_blocks_of(n);
 	if (ctx->packed.reserve(nb * (size_t) (ctx->RW + ctx->FW) * ngm::kSlots) || ctx->lens.reserve(nb * ngm::kSlots) ||
 			ctx->blk_rows.reserve(nb)) {
@@ -139,6 +84,34 @@ int reserve_workspace(ngm_hip_ctx *ctx, int n) {
 	}
 	return 0;
 }
+
+int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipStream_t st) {
+	const int nb = n_blocks_of(n);
+	score_kernel_t k = find_score_kernel(ctx->c, (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END);
+	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, d_scores, n, nb,
+			ctx->RW, ctx->K);
+	HIP_TRY(ctx, hipGetLastError());
+	return 0;
+}
+
+int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, uint16_t *d_runs, int run_stride, hipStream_t st) {
+	const int am = mode & NGM_MODE_ALIGN_MASK;
+	const int nb = n_blocks_of(n);
+	const int DW = ngm::dir_words(ctx->c);
+	if (ctx->dirs.reserve((size_t) nb * ctx->q * DW * ngm::kSlots)) { set_error(ctx, "out of device memory for the direction matrix"); return -12; }
+	align_kernel_t k = find_align_kernel(ctx->c, am == NGM_MODE_END_TO_END);
+	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, ctx->dirs.p,
+			d_records, n, nb, ctx->RW, ctx->q, ctx->K);
+	HIP_TRY(ctx, hipGetLastError());
+	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+	hipLaunchKernelGGL(ngm::sw_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, ctx->lens.p, d_records,
+			d_runs, n, ctx->q, ctx->c, run_stride, am == NGM_MODE_END_TO_END ? 1 : 0);
+	HIP_TRY(ctx, hipGetLastError());
+	return 0;
+}
+}  // namespace ngm
+namespace {
+using ngm::engine_reserve;
 
 struct ScopedDevice {
 	int prev = -1;
@@ -248,16 +221,13 @@ int ngm_hip_score_device(ngm_hip_ctx *ctx, int mode, int n, const void *d_ref, c
 	if (am != NGM_MODE_LOCAL && am != NGM_MODE_END_TO_END) { set_error(ctx, "unsupported alignment mode %d", am); return -22; }
 	ScopedDevice sd(ctx->device);
 	hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
-	if (int r = reserve_workspace(ctx, n)) return r;
+	if (int r = engine_reserve(ctx, n)) return r;
 	const int nb = n_blocks_of(n);
 	ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = false;
 	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
 	if (int r = launch_pack(ctx, n, d_ref, d_qry, st)) return r;
 	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-	score_kernel_t k = find_score_kernel(ctx->c, am == NGM_MODE_END_TO_END);
-	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, d_scores, n, nb,
-			ctx->RW, ctx->K);
-	HIP_TRY(ctx, hipGetLastError());
+	if (int r = ngm::engine_score_packed(ctx, mode, n, d_scores, st)) return r;
 	if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st)); ctx->ev_valid[0] = ctx->ev_valid[1] = true; }
 	return n;
 }
@@ -300,22 +270,13 @@ int ngm_hip_align_device(ngm_hip_ctx *ctx, int mode, int n, const void *d_ref, c
 	if (run_stride < ngm::run_stride(ctx->q, ctx->c)) { set_error(ctx, "run_stride %d too small", run_stride); return -22; }
 	ScopedDevice sd(ctx->device);
 	hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
-	if (int r = reserve_workspace(ctx, n)) return r;
+	if (int r = engine_reserve(ctx, n)) return r;
 	const int nb = n_blocks_of(n);
-	const int DW = ngm::dir_words(ctx->c);
-	if (ctx->dirs.reserve((size_t) nb * ctx->q * DW * ngm::kSlots)) { set_error(ctx, "out of device memory for the direction matrix"); return -12; }
 	ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = false;
 	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
 	if (int r = launch_pack(ctx, n, d_ref, d_qry, st)) return r;
 	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-	align_kernel_t k = find_align_kernel(ctx->c, am == NGM_MODE_END_TO_END);
-	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, ctx->dirs.p,
-			d_records, n, nb, ctx->RW, ctx->q, ctx->K);
-	HIP_TRY(ctx, hipGetLastError());
-	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-	hipLaunchKernelGGL(ngm::sw_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, ctx->lens.p, d_records,
-			d_runs, n, ctx->q, ctx->c, run_stride, am == NGM_MODE_END_TO_END ? 1 : 0);
-	HIP_TRY(ctx, hipGetLastError());
+	if (int r = ngm::engine_align_packed(ctx, mode, n, d_records, d_runs, run_stride, st)) return r;
 	if (ctx->profiling) { HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st)); ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = true; }
 	return n;
 }

@@ -84,6 +84,7 @@ __device__ __forceinline__ uint32_t pack8(const uint32_t k[8]) {
 	return k[0] | (k[4] << 4) | (k[1] << 8) | (k[5] << 12) | (k[2] << 16) | (k[6] << 20) | (k[3] << 24) | (k[7] << 28);
 }
 
+#ifdef NGM_ENGINE_KERNELS  // non-template kernels are emitted by exactly one TU (ngm_hip.cpp)
 // ---------------------------------------------------------------------------------------------
 // pack kernel: one workgroup (256 threads) per block of 64 pairs.
 //   ref  : n rows of rl = q + c bytes (flat), qry : n rows of q bytes (flat)
@@ -177,6 +178,8 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restri
 	__syncthreads();
 	if (tid == 0) blk_rows[blk] = (uint16_t) s_blk_rows;
 }
+
+#endif  // NGM_ENGINE_KERNELS
 
 // ---------------------------------------------------------------------------------------------
 // score kernel: BatchScore.  One pair per lane, one packed block per wave, 4 waves per workgroup.
