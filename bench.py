@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the score/align hot path on MI355X.
+"""bench.py -- mapped reads/s and SW Gcells/s of the MI355X mapping path.
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already resident in
-HBM: BatchScore over R*cpr candidate (read, window) pairs, then BatchAlign (DP + traceback) over the R
-winning pairs -- the work NextGenMap's ScoreBuffer / AlignmentBuffer stages do for R reads
- at the 150 bp shape (qry_max_len 152, corridor 27, scoring 10/15/20/20).
+One "step" = one pass of the hot path over one batch of R synthetic 150 bp reads whose bytes are already
+resident in HBM: candidate search over the HBM-resident k-mer index of a synthetic GRCh38-sized genome
+(seeded, with repeat families), device window gather, BatchScore over every candidate, top-1 selection +
+MAPQ, BatchAlign (DP + traceback) of the winners, CIGAR/MD/position on the host.  Shape: qry_max_len 152,
+corridor 27, linear gaps 10/15/20/20, local mode, k 13 / kmer_skip 2 / bin_size 2, sensitivity 0.5 pinned.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--genome-mbp G] [--reads-per-step R]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-          one rank per GPU, reads sharded across ranks (weak scaling: R reads per GPU per step), no
-          data-path collective; the mapping-stats vector is summed with one RCCL all-reduce at the end.
+          one rank per GPU; every rank holds the whole genome + index in its own HBM and maps its own shard of
+          reads (weak scaling, no data-path collective); ONE RCCL all-reduce sums the mapping statistics.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the score DP) from HIP events
-recorded on the launch stream inside this script; `cpu_baseline` is the oracle's C restatement of the
-same arithmetic timed on this host's cores on a bounded sample.
+Prints ONE JSON line (rank 0): `roofline` describes the dominant kernel (candidate search) from HIP events
+recorded on the launch stream; `cpu_baseline` is the REAL reference program (NextGenMap's ngm-core built from
+its sources by oracle/ngm_ref.mk, --affine because the default backend needs an OpenCL CPU device) run on this
+host on a bounded sample of the same reads against the same genome (it loads the index cache files this
+library writes), or, when that binary is absent, the oracle's C restatement of the score stage only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,57 +32,142 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-Q, C, READ_LEN = 152, 27, 150
-CPR = 4  # candidate windows scored per read
+Q, C, READ_LEN, KMER = 152, 27, 150, 13
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-B_SCORE = Q + (Q + C) + 4  # algorithmic bytes per scored pair   (SURVEY.md 8d): 335
-B_ALIGN = Q + (Q + C) + 8 + 4 * (2 * Q + C + 1)  # per aligned pair: 1667
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.zeros(256, np.uint8)
+COMP[list(b"ACGTN")] = list(b"TGCAN")
 
 
-def make_pool(n_pool, seed):
-    from pairgen import make_pairs
-    return make_pairs(n_pool, Q, C, seed=seed, read_len=READ_LEN, mix=(0.55, 0.40, 0.05))
+def make_genome(total_bp, seed):
+    """24 contigs with GRCh38-like relative sizes, random sequence + repeat families (1 kb, 2 % diverged copies)
+    + a few N runs.  Seed 20240601 as in SURVEY.md 8d."""
+    rng = np.random.default_rng(seed)
+    rel = np.array([248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57], float)
+    lens = np.maximum(20000, (rel / rel.sum() * total_bp).astype(np.int64))
+    contigs = [ACGT[rng.integers(0, 4, int(n), dtype=np.uint8)] for n in lens]
+    n_fam = max(4, int(total_bp // 2_000_000))
+    for _ in range(n_fam):
+        fam = ACGT[rng.integers(0, 4, 1000)]
+        for _ in range(int(rng.integers(3, 30))):
+            c = contigs[int(rng.integers(0, len(contigs)))]
+            p = int(rng.integers(0, len(c) - 1000))
+            cp = fam.copy()
+            m = rng.random(1000) < 0.02
+            cp[m] = ACGT[rng.integers(0, 4, int(m.sum()))]
+            c[p:p + 1000] = cp
+    for c in contigs:
+        for _ in range(2):
+            p = int(rng.integers(0, len(c) - 5000))
+            c[p:p + int(rng.integers(50, 3000))] = ord("N")
+    return contigs
 
 
-def cpu_baseline(pool_ref, pool_qry, budget_s=12.0):
-    """Oracle (kind 'port') on all host cores, bounded sample of the same workload."""
+def make_reads(contigs, n, seed):
+    """uniform positions, 50 % reverse strand, 1 % substitutions, one 1-3 bp indel in 15 % of the reads (0.1 % of the
+    bases).  Returns ([n, Q] uint8 rows, truth contig, truth pos)."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in contigs], dtype=np.float64)
+    ci = rng.choice(len(contigs), size=n, p=lens / lens.sum())
+    rows = np.zeros((n, Q), np.uint8)
+    pos = np.zeros(n, np.int64)
+    for k in range(len(contigs)):
+        sel = np.nonzero(ci == k)[0]
+        if sel.size == 0:
+            continue
+        p = rng.integers(0, len(contigs[k]) - READ_LEN - 8, sel.size)
+        pos[sel] = p
+        rows[sel, :READ_LEN] = contigs[k][p[:, None] + np.arange(READ_LEN)[None, :]]
+    sub = rng.random((n, READ_LEN)) < 0.01
+    rows[:, :READ_LEN][sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
+    for i in np.nonzero(rng.random(n) < 0.15)[0]:
+        a = int(rng.integers(20, READ_LEN - 20))
+        L = int(rng.integers(1, 4))
+        r = rows[i, :READ_LEN].copy()
+        if rng.random() < 0.5:  # insertion into the read
+            rows[i, a + L:READ_LEN] = r[a:READ_LEN - L]
+            rows[i, a:a + L] = ACGT[rng.integers(0, 4, L)]
+        else:                   # deletion from the read
+            rows[i, a:READ_LEN - L] = r[a + L:READ_LEN]
+            rows[i, READ_LEN - L:READ_LEN] = ACGT[rng.integers(0, 4, L)]
+    rev = rng.random(n) < 0.5
+    rows[rev, :READ_LEN] = COMP[rows[rev, :READ_LEN][:, ::-1]]
+    return rows, ci, pos
+
+
+def cpu_baseline_reference(ref, rows, budget_reads, workdir):
+    """NextGenMap itself (ngm-core --affine, host cores) on the first `budget_reads` reads vs the same genome."""
+    import ref_files as RF
+    cores = os.cpu_count() or 1
+    fa = os.path.join(workdir, "bench_ref.fa")
+    with open(fa, "w") as f:
+        f.write(">stub\nACGT\n")  # with the caches present the program only checks that the file exists
+    t = time.perf_counter()
+    ref.write_ngm_cache(fa)
+    t_cache = time.perf_counter() - t
+    n = min(budget_reads, rows.shape[0])
+    fq, one = os.path.join(workdir, "sample.fq"), os.path.join(workdir, "one.fq")
+    qual = b"I" * READ_LEN
+    with open(fq, "wb") as f:
+        for i in range(n):
+            f.write(b"@r%d\n" % i + rows[i, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
+    with open(one, "wb") as f:
+        f.write(b"@r0\n" + rows[0, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
+    threads = min(cores, 64)
+
+    def run(reads):
+        cmd = [RF.NGM_CORE, "-r", fa, "-q", reads, "-o", os.path.join(workdir, "ref_out.sam"), "--affine", "-t", str(threads),
+               "--no-progress", "-s", "0.5"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=workdir)
+        dt = time.perf_counter() - t0
+        if "Done" not in (r.stdout + r.stderr):
+            raise RuntimeError("reference run failed: " + (r.stdout + r.stderr)[-400:])
+        return dt
+
+    t_load = run(one)   # index/genome load + start-up
+    t_all = run(fq)
+    t_map = max(t_all - t_load, 1e-3)
+    return {"value": n / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
+            "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d on the first %d reads of the step vs the same genome (index "
+                      "loaded from cache files written by this library): %.1fs total minus %.1fs index load/start-up measured "
+                      "with a 1-read run" % (threads, n, t_all, t_load),
+            "index_cache_write_s": t_cache}
+
+
+def cpu_baseline_port(rows_qry, budget_s=8.0):
     import oracle_lib as O
     cores = os.cpu_count() or 1
-    n0 = min(len(pool_qry), max(2048, 32 * cores))
-    O.oracle_score(0, pool_ref[:256], pool_qry[:256], C, nthreads=cores)  # spin the thread pool up
+    rng = np.random.default_rng(0)
+    wins = ACGT[rng.integers(0, 4, (len(rows_qry), Q + C), dtype=np.uint8)]
+    n0 = min(len(rows_qry), max(2048, 32 * cores))
+    O.oracle_score(0, wins[:256], rows_qry[:256], C, nthreads=cores)
     t = time.perf_counter()
-    O.oracle_score(0, pool_ref[:n0], pool_qry[:n0], C, nthreads=cores)
-    O.oracle_align(0, pool_ref[:n0 // CPR], pool_qry[:n0 // CPR], C, nthreads=cores)
+    O.oracle_score(0, wins[:n0], rows_qry[:n0], C, nthreads=cores)
     dt = max(time.perf_counter() - t, 1e-4)
-    reps = int(max(1, min(4096, budget_s / dt)))
-    n = n0 * reps
-    idx = np.arange(n) % len(pool_qry)
-    ref, qry = pool_ref[idx], pool_qry[idx]
+    reps = int(max(1, min(1024, budget_s / dt)))
+    idx = np.arange(n0 * reps) % len(rows_qry)
     t = time.perf_counter()
-    O.oracle_score(0, ref, qry, C, nthreads=cores)
+    O.oracle_score(0, wins[idx], rows_qry[idx], C, nthreads=cores)
     ts = time.perf_counter() - t
-    t = time.perf_counter()
-    O.oracle_align(0, ref[:n // CPR], qry[:n // CPR], C, nthreads=cores)
-    ta = time.perf_counter() - t
-    reads = n // CPR
-    return {"value": reads / (ts + ta), "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads: %d scored pairs (%.2fs) + %d aligned pairs (%.2fs), oracle C restatement, OpenMP %d threads"
-                      % (reads, n, ts, reads, ta, cores),
-            "sw_gcells_per_s": n * READ_LEN * C / ts / 1e9}
+    return {"value": len(idx) / ts, "unit": "scored pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pairs, oracle C restatement of BatchScore only, OpenMP %d threads (no candidate search)" % (len(idx), cores)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genome-mbp", type=float, default=3100.0, help="synthetic genome size (GRCh38 = 3100)")
     ap.add_argument("--reads-per-step", type=int, default=1 << 20, help="reads per GPU per step")
+    ap.add_argument("--cpu-sample-reads", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    import nextgenmap_amd as N
+    from nextgenmap_amd.pipeline import HIT_DTYPE, Mapper, Reference
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -91,89 +181,63 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     R = args.reads_per_step
-    NS = R * CPR
-    pool_ref, pool_qry = make_pool(16384, seed=20240602 + rank)
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    idx = torch.randint(0, pool_ref.shape[0], (NS,), generator=g).to(dev)
-    p_ref = torch.from_numpy(pool_ref).to(dev)
-    p_qry = torch.from_numpy(pool_qry).to(dev)
-    d_ref = p_ref.index_select(0, idx).contiguous()
-    d_qry = p_qry.index_select(0, idx).contiguous()
-    # the "winning" candidate of read r is pair r*CPR: gather once, outside the timed region (NGM's
-    # align stage re-gathers windows on the host; that gather is not part of this bench yet)
-    a_ref = d_ref[::CPR].contiguous()
-    a_qry = d_qry[::CPR].contiguous()
-    d_scores = torch.empty(NS, dtype=torch.float32, device=dev)
-    eng = N.Engine(Q, C, device=local_rank, max_batch=NS)
-    rs = eng.align_run_stride()
-    d_rec = torch.empty((R, 8), dtype=torch.int32, device=dev)
-    d_runs = torch.empty((R, rs), dtype=torch.int16, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    t0 = time.perf_counter()
+    contigs = make_genome(int(args.genome_mbp * 1e6), seed=20240601)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = Reference.from_contigs(contigs, device=local_rank, kmer=KMER, kmer_skip=2, bin_size=2)
+    t_index = time.perf_counter() - t0
+    rows, truth_c, truth_p = make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank)  # config #2's seed, one shard per rank
+    d_rows = torch.from_numpy(rows).to(dev)
+    mp = Mapper(ref, Q, C, sensitivity=0.5)
+    out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
 
     def step():
-        eng.score_device(N.MODE_LOCAL, NS, d_ref, d_qry, d_scores, stream)
-        eng.align_device(N.MODE_LOCAL, R, a_ref, a_qry, d_rec, d_runs, rs, stream)
+        return mp.map_se_raw(rows, d_rows, out)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-
-    # kernel durations: HIP events on the launch stream (the engine brackets its launches)
-    eng.set_profiling(True)
-    k_pack = k_score = k_apack = k_align = k_tb = 0.0
-    nprof = 5
-    for _ in range(nprof):
-        eng.score_device(N.MODE_LOCAL, NS, d_ref, d_qry, d_scores, stream)
-        torch.cuda.synchronize()
-        ms = eng.last_kernel_ms()
-        k_pack += ms[0]; k_score += ms[1]
-        eng.align_device(N.MODE_LOCAL, R, a_ref, a_qry, d_rec, d_runs, rs, stream)
-        torch.cuda.synchronize()
-        ms = eng.last_kernel_ms()
-        k_apack += ms[0]; k_align += ms[1]; k_tb += ms[2]
-    eng.set_profiling(False)
-    k_pack, k_score, k_apack, k_align, k_tb = (x / nprof for x in (k_pack, k_score, k_apack, k_align, k_tb))
-
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    kms = np.zeros(8)
+    hits = None
     for _ in range(args.steps):
-        step()
+        hits, _, _ = step()
+        kms += np.array(mp.last_kernel_ms())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kms /= max(1, args.steps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # mapping statistics of the last step, summed over ranks with ONE collective
-    valid = d_rec[:, 0].to(torch.int64)
-    stats = torch.stack([torch.tensor(R, device=dev, dtype=torch.int64), valid.sum(), (1 - valid).sum(),
-                         d_scores.to(torch.int64).sum(), torch.tensor(NS, device=dev, dtype=torch.int64),
-                         d_rec[:, 5].to(torch.int64).sum(), torch.zeros((), device=dev, dtype=torch.int64),
-                         torch.zeros((), device=dev, dtype=torch.int64)])
+    kmers, hits_voted, n_cand = mp.cs_counters()
+    mapped = hits["mapped"] == 1
+    correct = mapped & (hits["contig"] == truth_c) & (np.abs(hits["pos"].astype(np.int64) - truth_p) <= C // 2 + 4)
+    stats = torch.tensor([R, int(mapped.sum()), int((~mapped).sum()), int(mapped.sum()), int(correct.sum()), int((hits["mapq"] > 0).sum()),
+                          int(n_cand), int(hits_voted)], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # the ONE collective of the path (RCCL over xGMI)
     stats = [int(x) for x in stats.tolist()]
 
     if rank == 0:
-        reads_total = R * world * args.steps
-        value = reads_total / elapsed
-        score_cells = NS * READ_LEN * C
-        align_cells = R * READ_LEN * C
-        achieved = NS * B_SCORE / (k_score * 1e-3) / 1e9
-        # HBM bytes per launch of the same kernel at the same grid, from the PMC passes committed under
-        # profiles/ (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 read correction applied there)
+        value = R * world * args.steps / elapsed
+        score_cells = n_cand * READ_LEN * C
+        align_cells = int(mapped.sum()) * READ_LEN * C
+        b_cs = 20 * kmers + 4 * hits_voted + 16 * n_cand
+        achieved = b_cs / (kms[0] * 1e-3) / 1e9
         traffic = None
         for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             if fn.endswith("_pmc_traffic.json"):
                 try:
-                    tr = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                    traffic = tr.get("ngm::sw_score_kernel<%d, false>|grid=%d" % (C, ((NS + 255) // 256) * 256))
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", fn))).get("cs_kernel|reads=%d|genome_mbp=%d" % (R, int(args.genome_mbp)))
                 except Exception:
                     traffic = None
                 if traffic is not None:
@@ -183,27 +247,39 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "score+align stages at the 150bp shape (qry_max_len 152, corridor 27, linear gaps "
-                                   "10/15/20/20, local mode): per GPU per step BatchScore over %d candidate pairs (%d reads x %d "
-                                   "candidates) + BatchAlign with traceback over %d pairs; candidate search over a GRCh38 index is "
-                                   "not in this bench yet" % (NS, R, CPR, R),
-                       "reads_per_step_per_gpu": R, "candidates_per_read": CPR, "parallelism": "reads sharded x%d" % world},
-            "sw_gcells_per_s": {"score_kernel": score_cells / (k_score * 1e-3) / 1e9,
-                                "align_kernel": align_cells / (k_align * 1e-3) / 1e9,
-                                "whole_step": (score_cells + align_cells) * world * args.steps / elapsed / 1e9},
-            "kernel_ms": {"pack(score batch)": k_pack, "sw_score": k_score, "pack(align batch)": k_apack,
-                          "sw_align": k_align, "traceback": k_tb},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sw_score_kernel<27,local>", "bytes_per_launch": NS * B_SCORE,
-                         "note": "integer-VALU bound kernel: %.0f Gcells/s; HBM fraction reported per contract"
-                                 % (score_cells / (k_score * 1e-3) / 1e9)},
-            "stats_allreduce": {"reads": stats[0], "aligned": stats[1], "no_alignment": stats[2], "score_sum": stats[3]},
+            "config": {"workload": "%d x 150bp SE synthetic reads per GPU per step vs a synthetic %.0f Mbp genome (24 contigs, repeat "
+                                   "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=0.5) + "
+                                   "score + top-1/MAPQ + align with traceback + CIGAR/MD; reads resident in HBM; single-end (the "
+                                   "paired-end selection of config #2 is not built yet)" % (R, args.genome_mbp),
+                       "qry_max_len": Q, "corridor": C, "scoring": "linear 10/15/20/20 local", "reads_per_step_per_gpu": R,
+                       "parallelism": "reads sharded x%d, genome+index replicated per GPU" % world},
+            "sw_gcells_per_s": {"score_kernel": score_cells / (kms[2] * 1e-3) / 1e9 if kms[2] > 0 else None,
+                                "align_kernel": align_cells / (kms[5] * 1e-3) / 1e9 if kms[5] > 0 else None},
+            "kernel_ms": {"candidate_search": kms[0], "gather_score": kms[1], "sw_score": kms[2], "select": kms[3], "gather_align": kms[4],
+                          "sw_align": kms[5], "traceback": kms[6], "all_kernels": float(kms[:7].sum()),
+                          "candidate_search_stage_incl_host_sync": kms[7]},
+            "per_read": {"candidates": n_cand / R, "index_hits": hits_voted / R, "kmers": kmers / R},
+            "accuracy": {"mapped": stats[1] / stats[0], "within_band_of_truth": stats[4] / stats[0], "mapq_gt0": stats[5] / stats[0]},
+            "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "cs_kernel (candidate search)", "bytes_per_launch": b_cs,
+                         "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); dependent random "
+                                 "8-64 B reads, latency- not bandwidth-limited; the SW kernels are VALU-bound, see sw_gcells_per_s"},
+            "stats_allreduce": {"reads": stats[0], "mapped": stats[1], "unmapped": stats[2], "candidates": stats[6]},
         }
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pool_ref, pool_qry)
+            try:
+                import ref_files as RF
+                if not RF.have_reference_binary():
+                    raise RuntimeError("oracle/_ref/ngm/ngm-core not built")
+                with tempfile.TemporaryDirectory() as wd:
+                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, args.cpu_sample_reads, wd)
+            except Exception as e:  # the port of the score stage only
+                line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
+                line["cpu_baseline"]["note"] = "reference program unavailable: %s" % str(e)[:200]
         print(json.dumps(line))
-    eng.close()
+    mp.close()
+    ref.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -60,6 +60,11 @@ int ngm_ref_decode(const ngm_ref *r, uint64_t offset, int buffer_len, char *out)
  * position lies in a spacer (reported unmapped), 1 otherwise. */
 int ngm_ref_convert(const ngm_ref *r, uint64_t pos, int *contig, uint64_t *contig_pos);
 
+/* Write NextGenMap's own cache files next to `fasta_path` so that the reference program loads this encoded
+ * genome and index instead of rebuilding them: <fasta_path>-enc.2.ngm (src/SequenceProvider.cpp:189-208) and
+ * <fasta_path>-ht-<k>-<skip>.3.ngm (src/PrefixTable.cpp:819-855).  Content is what NGM itself would write. */
+int ngm_ref_write_ngm_cache(const ngm_ref *r, const char *fasta_path);
+
 typedef struct ngm_mapper_params {
 	int qry_max_len;       /* bytes per read row */
 	int corridor;
@@ -102,9 +107,18 @@ typedef struct ngm_hit {
 
 /* Full single-end path for n reads; cigars/mds: n rows of 4*qry_max_len bytes (NUL-terminated strings). */
 int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds);
+/* Same, with the read batch already resident in HBM (d_reads: n rows of qry_max_len bytes, device memory on
+ * the mapper's GPU); `reads` is the host copy the CIGAR/MD pass consults.  What bench.py times. */
+int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads, ngm_hit *hits, char *cigars,
+		char *mds);
+
+/* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted
+ * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */
+int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]);
 
 /* kernel wall-clock of the last ngm_mapper_* call, HIP events on the launch stream, ms:
- * [0] candidate search  [1] gather+pack  [2] score  [3] select  [4] gather+pack (align)  [5] align DP  [6] traceback */
+ * [0] candidate search kernels  [1] gather+pack  [2] score  [3] select  [4] gather+pack (align)  [5] align DP
+ * [6] traceback  [7] candidate-search stage including host round trips between its passes */
 int ngm_mapper_last_kernel_ms(ngm_mapper *m, float ms[8]);
 
 #ifdef __cplusplus

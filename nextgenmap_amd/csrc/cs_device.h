@@ -27,6 +27,7 @@ namespace ngm {
 
 struct CsArgs {
 	const uint8_t *reads;   // n rows of q bytes
+	const uint32_t *read_list;  // optional: workgroup i handles read read_list[i] (re-run of queued reads)
 	int n;
 	int q;
 	int k;
@@ -50,6 +51,7 @@ struct CsArgs {
 	unsigned long long *out_total;  // allocation cursor
 	unsigned long long out_capacity;
 	uint32_t *status;       // [0] output overflow flag, [1] number of queued overflow reads
+	unsigned long long *counters;  // [0] k-mers looked up, [1] hits voted (for the algorithmic-bytes accounting)
 	// overflow queue (written by the LDS pass, consumed by the GLOBAL_TABLE pass)
 	uint32_t *ovf_read;     // [n]
 	uint32_t *ovf_hits;     // [n]
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	const int lane = threadIdx.x;
 	const int item = blockIdx.x;
-	const int read = GLOBAL_TABLE ? (int) A.ovf_read[item] : item;
+	const int read = GLOBAL_TABLE ? (int) A.ovf_read[item] : (A.read_list ? (int) A.read_list[item] : item);
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;                        // [lists_cap]
 	uint32_t *l_pref = cs_lds + A.lists_cap;           // [lists_cap + 1]
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 		t_keys = (uint32_t *) l_code + code_words;
 		t_votes = t_keys + (1u << log2_slots);
 	}
-	const uint32_t n_slots = 1u << log2_slots;
+	uint32_t n_slots = 1u << log2_slots;
 
 	// ---- 1. read -> 2-bit codes (A0 C1 T2 G3, CSstatic.cpp:20-22), N = 4, past the end = 255 ----------------
 	const uint8_t *rp = A.reads + (size_t) read * A.q;
@@ -134,15 +136,15 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	const int L = wave_reduce_min(first_nul);  // MappedRead::length
 	__syncthreads();
 
-	// ---- 2. k-mers and their two position lists ---------------------------------------------------------
+	// ---- 2. k-mers and their two position lists (lane = k-mer, lists 2p = forward, 2p+1 = reverse complement) --
 	const int n_kmers = L - k + 1;
 	const int n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
-	uint32_t carry = 0;
-	for (int base = 0; base < n_lists; base += 64) {
-		const int li = base + lane;
-		uint32_t cnt = 0, start = 0;
-		if (li < n_lists) {
-			const int p = li >> 1;
+	uint32_t carry = 0, n_valid = 0;
+	for (int base = 0; base < n_kmers; base += 64) {
+		const int p = base + lane;
+		uint32_t cf = 0, cr = 0, sf = 0, sr = 0;
+		bool counted = false;
+		if (p < n_kmers) {
 			bool valid = true;
 			uint32_t kmer = 0;
 			for (int j = 0; j < k; ++j) {
@@ -156,15 +158,18 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 			if (valid) {
 				const uint2 ef = A.index[kmer];
 				const uint2 er = A.index[cs_revcomp(kmer, k)];
-				if ((int) (ef.y + er.y) < A.max_kfreq) {  // CS.cpp:122
-					const uint2 e = (li & 1) ? er : ef;
-					cnt = e.y;
-					start = e.x;
-				}
+				if ((int) (ef.y + er.y) < A.max_kfreq) { cf = ef.y; sf = ef.x; cr = er.y; sr = er.x; }  // CS.cpp:122
 			}
+			counted = valid;
 		}
-		const uint32_t incl = wave_inclusive_scan(cnt, lane);
-		if (li < n_lists) { l_start[li] = start; l_pref[li] = carry + incl - cnt; }
+		n_valid += __popcll(__ballot(counted));
+		const uint32_t both = cf + cr;
+		const uint32_t incl = wave_inclusive_scan(both, lane);
+		if (p < n_kmers) {
+			const uint32_t b0 = carry + incl - both;
+			l_start[2 * p] = sf; l_pref[2 * p] = b0;
+			l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = b0 + cf;
+		}
 		carry += __shfl(incl, 63);
 	}
 	if (lane == 0) l_pref[n_lists] = carry;
@@ -180,7 +185,18 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 		return;
 	}
 
+	if (lane == 0 && A.counters) { atomicAdd(&A.counters[0], (unsigned long long) n_valid); atomicAdd(&A.counters[1], (unsigned long long) H); }
+
 	// ---- 3. votes ---------------------------------------------------------------------------------------
+	// the table in use is sized to this read's hit count (power of two >= 2H), so clearing and scanning it cost
+	// what the read needs, not what the allocation allows
+	if (!GLOBAL_TABLE) {
+		int need = 8;
+		while ((1u << need) < 2u * H && need < log2_slots) ++need;
+		log2_slots = need;
+		n_slots = 1u << log2_slots;
+		t_votes = t_keys + n_slots;
+	}
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 	__syncthreads();
 	if (GLOBAL_TABLE) __threadfence_block();

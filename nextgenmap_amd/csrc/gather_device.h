@@ -158,4 +158,18 @@ __global__ void collect_winners_kernel(int n_reads, const uint32_t *__restrict__
 	a_sv[s] = pair_sv[w];
 }
 
+// Traceback runs live in a strided scratch (run_stride u16 per pair); alignments have a handful of runs, so
+// they are compacted before the download.  rec[6] (the argmax row, no longer needed) receives the offset.
+__global__ void compact_runs_kernel(int n, int32_t *__restrict__ records, const uint16_t *__restrict__ runs, int run_stride,
+		uint16_t *__restrict__ out, unsigned long long *__restrict__ cursor) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	int32_t *rec = records + (size_t) i * 8;
+	const int nr = rec[0] ? rec[4] : 0;
+	const unsigned long long off = nr ? atomicAdd(cursor, (unsigned long long) nr) : 0ull;
+	rec[6] = (int32_t) off;
+	const uint16_t *src = runs + (size_t) i * run_stride;
+	for (int k = 0; k < nr; ++k) out[off + k] = src[k];
+}
+
 }  // namespace ngm

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "refindex.h"
@@ -30,18 +31,22 @@ struct ngm_mapper {
 	ngm_hip_ctx *eng = nullptr;
 	hipStream_t st = nullptr;
 	int max_kfreq = 0;
-	int cs_log2_slots = 13;
+	int cs_log2_slots = 13;   // large LDS vote table: 2^13 slots * 8 B = 64 KB
+	int cs_log2_small = 10;   // first-pass table; picked from the index density in ngm_mapper_create
 	// batch state in HBM
 	ngm::DevBuf<uint8_t> d_reads;
 	ngm::DevBuf<uint16_t> d_read_len;
-	ngm::DevBuf<uint32_t> d_cand_base, d_cand_count, d_out_loc, d_out_sv, d_status, d_ovf_read, d_ovf_hits, d_ovf_log2;
+	ngm::DevBuf<uint32_t> d_cand_base, d_cand_count, d_out_loc, d_out_sv, d_status, d_ovf_read, d_ovf_read2, d_ovf_hits, d_ovf_log2;
 	ngm::DevBuf<uint64_t> d_ovf_off;
 	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes;
 	ngm::DevBuf<float> d_max_votes, d_scores, d_best;
-	ngm::DevBuf<unsigned long long> d_total;
+	ngm::DevBuf<unsigned long long> d_total, d_counters;
+	unsigned long long cs_kmers = 0, cs_hits = 0;
+	float cs_kernel_ms = 0.f;
+	hipEvent_t cev[6] = {};
 	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
 	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records;
-	ngm::DevBuf<uint16_t> d_runs;
+	ngm::DevBuf<uint16_t> d_runs, d_runs_c;
 	// last CS result on the host
 	int n_reads = 0;
 	std::vector<uint32_t> h_base, h_count;
@@ -71,7 +76,7 @@ int run_cs(ngm_mapper *m, int n) {
 	const ngm_ref *r = m->ref;
 	const int q = m->prm.qry_max_len;
 	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) ||
-			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_ovf_read.reserve(n) || m->d_ovf_hits.reserve(n)) {
+			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_counters.reserve(4) || m->d_ovf_read.reserve(n) || m->d_ovf_hits.reserve(n)) {
 		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
 		return -12;
 	}
@@ -80,22 +85,45 @@ int run_cs(ngm_mapper *m, int n) {
 		if (m->d_out_loc.reserve(cap) || m->d_out_sv.reserve(cap)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, 8, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, 32, m->st));
+		int passes = 0;
 		ngm::CsArgs A{};
 		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
 		A.index = r->d_index; A.positions = r->d_positions;
 		A.lists_cap = 2 * std::max(1, q - r->prm.kmer + 1);
-		A.log2_slots = m->cs_log2_slots;
-		A.lds_hit_cap = (uint32_t) ((1u << m->cs_log2_slots) * 0.66f);
 		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p;
 		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap;
-		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p;
-		const size_t lds = cs_lds_bytes(A, false);
-		hipLaunchKernelGGL(ngm::cs_kernel<false>, dim3(n), dim3(64), lds, m->st, A);
+		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
+		// pass 1: every read with the small LDS table (many workgroups per CU); reads with too many hits are queued
+		A.log2_slots = m->cs_log2_small;
+		A.lds_hit_cap = (uint32_t) ((1u << A.log2_slots) * 0.66f);
+		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
+		hipLaunchKernelGGL(ngm::cs_kernel<false>, dim3(n), dim3(64), cs_lds_bytes(A, false), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
+		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
+		passes = 1;
 		uint32_t status[4];
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		if (status[1] > 0 && m->cs_log2_slots > m->cs_log2_small) {
+			// pass 2: the queued reads with the large LDS table; what still does not fit is queued again
+			const uint32_t no = status[1];
+			if (m->d_ovf_read2.reserve(no)) { ngm::pipeline_set_error("out of device memory"); return -12; }
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
+			MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
+			ngm::CsArgs B = A;
+			B.log2_slots = m->cs_log2_slots;
+			B.lds_hit_cap = (uint32_t) ((1u << B.log2_slots) * 0.66f);
+			B.read_list = m->d_ovf_read2.p;
+			MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
+			hipLaunchKernelGGL(ngm::cs_kernel<false>, dim3(no), dim3(64), cs_lds_bytes(B, false), m->st, B);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
+			passes = 2;
+			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		}
 		if (status[1] > 0) {  // reads whose hits do not fit the LDS table: second pass with tables in global memory
 			const uint32_t no = status[1];
 			std::vector<uint32_t> hits(no), lg(no);
@@ -116,8 +144,11 @@ int run_cs(ngm_mapper *m, int n) {
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data(), no * 8, hipMemcpyHostToDevice, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data(), no * 4, hipMemcpyHostToDevice, m->st));
 			A.ovf_table_off = m->d_ovf_off.p; A.ovf_log2 = m->d_ovf_log2.p; A.gtable_keys = m->d_gt_keys.p; A.gtable_votes = m->d_gt_votes.p;
+			MAP_HIP_TRY(hipEventRecord(m->cev[4], m->st));
 			hipLaunchKernelGGL(ngm::cs_kernel<true>, dim3(no), dim3(64), cs_lds_bytes(A, true), m->st, A);
 			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipEventRecord(m->cev[5], m->st));
+			passes |= 4;
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		}
@@ -126,6 +157,13 @@ int run_cs(ngm_mapper *m, int n) {
 			MAP_HIP_TRY(hipMemcpy(&total, m->d_total.p, 8, hipMemcpyDeviceToHost));
 			m->n_cand = total;
 			m->n_reads = n;
+			unsigned long long ctr[4];
+			MAP_HIP_TRY(hipMemcpy(ctr, m->d_counters.p, 32, hipMemcpyDeviceToHost));
+			m->cs_kmers = ctr[0]; m->cs_hits = ctr[1];
+			float t = 0; m->cs_kernel_ms = 0;
+			if (hipEventElapsedTime(&t, m->cev[0], m->cev[1]) == hipSuccess) m->cs_kernel_ms += t;
+			if ((passes & 3) == 2 && hipEventElapsedTime(&t, m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t;
+			if ((passes & 4) && hipEventElapsedTime(&t, m->cev[4], m->cev[5]) == hipSuccess) m->cs_kernel_ms += t;
 			m->h_base.resize(n); m->h_count.resize(n); m->h_maxv.resize(n);
 			MAP_HIP_TRY(hipMemcpy(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost));
 			MAP_HIP_TRY(hipMemcpy(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost));
@@ -143,6 +181,24 @@ int upload_reads(ngm_mapper *m, int n, const char *reads) {
 	if (m->d_reads.reserve(bytes)) { ngm::pipeline_set_error("out of device memory (reads)"); return -12; }
 	MAP_HIP_TRY(hipMemcpyAsync(m->d_reads.p, reads, bytes, hipMemcpyHostToDevice, m->st));
 	return 0;
+}
+
+// the host tail of a batch (CIGAR / MD strings, coordinate conversion) is embarrassingly parallel over reads;
+// NextGenMap does it on its CS threads, here a batch is fanned out over the host cores
+template <typename F>
+void parallel_for(int n, F f) {
+	int nt = (int) std::thread::hardware_concurrency();
+	if (const char *e = getenv("NGM_HIP_HOST_THREADS")) nt = atoi(e);
+	nt = std::max(1, std::min(nt, 64));
+	if (n < 4096 || nt == 1) { f(0, n); return; }
+	std::vector<std::thread> th;
+	const int chunk = (n + nt - 1) / nt;
+	for (int t = 0; t < nt; ++t) {
+		const int lo = t * chunk, hi = std::min(n, lo + chunk);
+		if (lo >= hi) break;
+		th.emplace_back([=]() { f(lo, hi); });
+	}
+	for (auto &x : th) x.join();
 }
 
 char class_char(uint8_t c) {
@@ -217,6 +273,15 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	m->ref = ref; m->prm = *p; m->eng = eng; m->st = eng->stream;
 	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
+	for (auto &e : m->cev) (void) hipEventCreate(&e);
+	// first-pass table: sized for the expected hits per read, 2 * (q - k) lists * average list length, x3 headroom
+	{
+		const double avg_list = (double) ref->n_entries / (double) (1ull << (2 * ref->prm.kmer));
+		const double expect = 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer) * avg_list * 3.0;
+		int l = 9;
+		while ((double) (1u << l) * 0.66 < expect && l < m->cs_log2_slots) ++l;
+		m->cs_log2_small = l;
+	}
 	// LDS budget of the vote table: 2^13 slots * 8 B = 64 KB (+ lists and the read)
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len; A.log2_slots = m->cs_log2_slots;
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, false));
@@ -229,11 +294,13 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	DevGuard g(m->ref->device);
 	(void) hipStreamSynchronize(m->st);
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
-	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
+	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_read2.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
 	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
-	m->d_records.release(); m->d_runs.release();
+	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
+	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
+	m->d_counters.release();
 	ngm_hip_destroy(m->eng);
 	delete m;
 }
@@ -273,6 +340,10 @@ int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *vo
 }
 
 int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds) {
+	return ngm_mapper_map_se_resident(m, n, reads, nullptr, hits, cigars, mds);
+}
+
+int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds) {
 	if (!m || n < 0) return -22;
 	if (n == 0) return 0;
 	const ngm_ref *r = m->ref;
@@ -282,8 +353,12 @@ int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, ch
 	const size_t str_stride = (size_t) 4 * std::max(1, q);
 	for (auto &x : m->ms) x = 0.f;
 
+	// reads already in HBM: alias them as the batch (no copy); otherwise upload
+	ngm::DevBuf<uint8_t> own = m->d_reads;
+	struct Restore { ngm_mapper *m; ngm::DevBuf<uint8_t> own; bool on; ~Restore() { if (on) m->d_reads = own; } } restore{m, own, d_reads_ext != nullptr};
+	if (d_reads_ext) { m->d_reads.p = (uint8_t *) d_reads_ext; m->d_reads.cap = (size_t) n * q; }
 	MAP_HIP_TRY(hipEventRecord(m->ev[0], m->st));
-	if (int rc = upload_reads(m, n, reads)) return rc;
+	if (!d_reads_ext) if (int rc = upload_reads(m, n, reads)) return rc;
 	if (int rc = run_cs(m, n)) return rc;
 	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
 	const uint64_t np = m->n_cand;
@@ -326,7 +401,7 @@ int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, ch
 	const int na = (int) a_read.size();
 	const int rs = ngm::run_stride(q, c);
 	std::vector<int32_t> h_rec((size_t) na * 8);
-	std::vector<uint16_t> h_runs((size_t) na * rs);
+	std::vector<uint16_t> h_runs;
 	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
 	if (na > 0) {
 		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
@@ -346,56 +421,69 @@ int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, ch
 		if (int rc = ngm::engine_align_packed(eng, mode, na, m->d_records.p, m->d_runs.p, rs, m->st)) { eng->profiling = was_prof; ngm::pipeline_set_error("%s", ngm_hip_last_error(eng)); return rc; }
 		eng->profiling = was_prof;
 		MAP_HIP_TRY(hipEventRecord(m->ev[7], m->st));
+		if (m->d_runs_c.reserve((size_t) na * rs)) { ngm::pipeline_set_error("out of device memory (runs)"); return -12; }
+		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, 8, m->st));
+		hipLaunchKernelGGL(ngm::compact_runs_kernel, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs.p, rs,
+				m->d_runs_c.p, m->d_total.p);
+		MAP_HIP_TRY(hipGetLastError());
+		unsigned long long n_runs_total = 0;
 		MAP_HIP_TRY(hipMemcpyAsync(h_rec.data(), m->d_records.p, h_rec.size() * 4, hipMemcpyDeviceToHost, m->st));
-		MAP_HIP_TRY(hipMemcpyAsync(h_runs.data(), m->d_runs.p, h_runs.size() * 2, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(&n_runs_total, m->d_total.p, 8, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		h_runs.resize(n_runs_total + 1);
+		MAP_HIP_TRY(hipMemcpy(h_runs.data(), m->d_runs_c.p, n_runs_total * 2, hipMemcpyDeviceToHost));
 	}
 
 	// ---- host: CIGAR / MD, final positions --------------------------------------------------------------
-	for (int i = 0; i < n; ++i) {
-		ngm_hit &h = hits[i];
-		memset(&h, 0, sizeof(h));
-		h.n_candidates = (int) m->h_count[i];
-		h.max_votes = m->h_maxv[i];
-		h.mapq = h_mapq[i];
-		h.n_best = h_nbest[i];
-		h.score = h_best[i];
-		cigars[(size_t) i * str_stride] = 0;
-		mds[(size_t) i * str_stride] = 0;
-	}
-	ngm::CigarParams cp{m->prm.match_bonus, -m->prm.mismatch_penalty, m->prm.variant, m->prm.hard_clip, m->prm.silent_clip};
-	std::vector<char> win((size_t) q + c + 8), qry((size_t) q + 8);
-	for (int j = 0; j < na; ++j) {
-		const int i = (int) a_read[j];
-		ngm_hit &h = hits[i];
-		const bool rev = a_sv[j] & 1u;
-		h.reverse = rev;
-		const uint64_t offset = (uint64_t) a_loc[j] - (uint64_t) (c >> 1);
-		host_window(r, offset, align_buf_len, q + c, win.data());
-		const char *rd = reads + (size_t) i * q;
-		const int L = (int) strnlen(rd, q);
-		memset(qry.data(), 0, qry.size());
-		if (!rev) memcpy(qry.data(), rd, L);
-		else for (int t = 0; t < L; ++t) {
-			const char ch = rd[L - 1 - t];
-			qry[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+	parallel_for(n, [&](int lo, int hi) {
+		for (int i = lo; i < hi; ++i) {
+			ngm_hit &h = hits[i];
+			memset(&h, 0, sizeof(h));
+			h.n_candidates = (int) m->h_count[i];
+			h.max_votes = m->h_maxv[i];
+			h.mapq = h_mapq[i];
+			h.n_best = h_nbest[i];
+			h.score = h_best[i];
+			cigars[(size_t) i * str_stride] = 0;
+			mds[(size_t) i * str_stride] = 0;
 		}
-		ngm_hip_align_out ao{};
-		ao.cigar = cigars + (size_t) i * str_stride;
-		ao.md = mds + (size_t) i * str_stride;
-		ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) j * rs], win.data(), qry.data(), &ao);
-		if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
-		h.identity = ao.identity; h.nm = ao.nm; h.qstart = ao.qstart; h.qend = ao.qend;
-		// AlignmentBuffer.cpp:129 then SequenceProvider.convert (AlignmentBuffer.cpp:173)
-		const uint64_t final_loc = (uint64_t) a_loc[j] + (uint64_t) (int64_t) ao.position_offset - (uint64_t) (c >> 1);
-		int contig = 0; uint64_t cpos = 0;
-		if (!ngm_ref_convert(r, final_loc, &contig, &cpos)) { h.mapped = 0; continue; }
-		h.mapped = 1; h.contig = contig; h.pos = cpos;
-	}
+	});
+	ngm::CigarParams cp{m->prm.match_bonus, -m->prm.mismatch_penalty, m->prm.variant, m->prm.hard_clip, m->prm.silent_clip};
+	parallel_for(na, [&](int lo, int hi) {
+		std::vector<char> win((size_t) q + c + 8), qry((size_t) q + 8);
+		for (int j = lo; j < hi; ++j) {
+			const int i = (int) a_read[j];
+			ngm_hit &h = hits[i];
+			const bool rev = a_sv[j] & 1u;
+			h.reverse = rev;
+			const uint64_t offset = (uint64_t) a_loc[j] - (uint64_t) (c >> 1);
+			host_window(r, offset, align_buf_len, q + c, win.data());
+			const char *rd = reads + (size_t) i * q;
+			const int L = (int) strnlen(rd, q);
+			memset(qry.data(), 0, qry.size());
+			if (!rev) memcpy(qry.data(), rd, L);
+			else for (int t = 0; t < L; ++t) {
+				const char ch = rd[L - 1 - t];
+				qry[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+			}
+			ngm_hip_align_out ao{};
+			ao.cigar = cigars + (size_t) i * str_stride;
+			ao.md = mds + (size_t) i * str_stride;
+			ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), &ao);
+			if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
+			h.identity = ao.identity; h.nm = ao.nm; h.qstart = ao.qstart; h.qend = ao.qend;
+			// AlignmentBuffer.cpp:129 then SequenceProvider.convert (AlignmentBuffer.cpp:173)
+			const uint64_t final_loc = (uint64_t) a_loc[j] + (uint64_t) (int64_t) ao.position_offset - (uint64_t) (c >> 1);
+			int contig = 0; uint64_t cpos = 0;
+			if (!ngm_ref_convert(r, final_loc, &contig, &cpos)) { h.mapped = 0; continue; }
+			h.mapped = 1; h.contig = contig; h.pos = cpos;
+		}
+	});
 
 	// kernel times
 	auto et = [&](int a, int b) { float t = 0; if (hipEventElapsedTime(&t, m->ev[a], m->ev[b]) != hipSuccess) t = 0; return t; };
-	m->ms[0] = et(0, 1);
+	m->ms[0] = m->cs_kernel_ms;  // sum of the candidate-search kernel launches only
+	m->ms[7] = et(0, 1);          // ... and the whole CS stage including the host round trips between passes
 	if (np > 0) { m->ms[1] = et(1, 2); m->ms[2] = et(2, 3); m->ms[3] = et(3, 4); }
 	if (na > 0) {
 		m->ms[4] = et(5, 6);
@@ -404,6 +492,12 @@ int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, ch
 		if (hipEventElapsedTime(&t, eng->ev[2], m->ev[7]) == hipSuccess) m->ms[6] = t;
 	}
 	return n;
+}
+
+int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]) {
+	if (!m) return -22;
+	out[0] = m->cs_kmers; out[1] = m->cs_hits; out[2] = m->n_cand;
+	return 0;
 }
 
 int ngm_mapper_last_kernel_ms(ngm_mapper *m, float ms[8]) {

@@ -48,6 +48,7 @@ def _lib():
         lib.ngm_ref_index_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if not hasattr(lib, "ngm_mapper_create"):
             raise NgmHipError("libngm_hip.so was built without the mapping pipeline")
+        lib.ngm_ref_write_ngm_cache.argtypes = [C.c_void_p, C.c_char_p]
         lib.ngm_ref_decode.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
         lib.ngm_ref_convert.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
         lib.ngm_mapper_create.restype = C.c_void_p
@@ -56,6 +57,8 @@ def _lib():
         lib.ngm_mapper_cs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_mapper_cs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_mapper_map_se.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ngm_mapper_map_se_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ngm_mapper_cs_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _bound = True
     return lib
@@ -134,6 +137,12 @@ class Reference:
             raise _err()
         return counts, raw, pos[:self.index_entries]
 
+    def write_ngm_cache(self, fasta_path):
+        """Write NextGenMap's own index/genome cache files next to fasta_path (the reference program then loads
+        them instead of rebuilding)."""
+        if self.lib.ngm_ref_write_ngm_cache(self.h, fasta_path.encode()) < 0:
+            raise _err()
+
     def decode(self, offset, buffer_len):
         out = np.zeros(buffer_len, np.uint8)
         r = self.lib.ngm_ref_decode(self.h, offset, buffer_len, out.ctypes.data)
@@ -200,18 +209,32 @@ class Mapper:
             raise _err()
         return offs, mx, loc[:tot], strand[:tot], votes[:tot]
 
+    def map_se_raw(self, rows, d_rows=None, out=None):
+        """rows: [n, q] uint8 host array; d_rows: optional device copy (torch tensor / pointer).  Returns
+        (hits, cigar bytes [n, 4q], md bytes [n, 4q]) without turning the strings into Python objects."""
+        n = rows.shape[0]
+        stride = 4 * max(1, self.q)
+        if out is None:
+            out = (np.zeros(n, HIT_DTYPE), np.zeros((n, stride), np.uint8), np.zeros((n, stride), np.uint8))
+        hits, cig, md = out
+        dp = None if d_rows is None else (d_rows.data_ptr() if hasattr(d_rows, "data_ptr") else int(d_rows))
+        r = self.lib.ngm_mapper_map_se_resident(self.h, n, rows.ctypes.data, dp, hits.ctypes.data, cig.ctypes.data, md.ctypes.data)
+        if r < 0:
+            raise _err()
+        return hits, cig, md
+
     def map_se(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
-        n = rows.shape[0]
-        hits = np.zeros(n, HIT_DTYPE)
-        stride = 4 * max(1, self.q)
-        cig = np.zeros((n, stride), np.uint8)
-        md = np.zeros((n, stride), np.uint8)
-        if self.lib.ngm_mapper_map_se(self.h, n, rows.ctypes.data, hits.ctypes.data, cig.ctypes.data, md.ctypes.data) < 0:
-            raise _err()
+        hits, cig, md = self.map_se_raw(rows)
         return hits, [bytes(r).split(b"\0", 1)[0] for r in cig], [bytes(r).split(b"\0", 1)[0] for r in md]
 
     def last_kernel_ms(self):
         ms = (C.c_float * 8)()
         self.lib.ngm_mapper_last_kernel_ms(self.h, ms)
         return list(ms)
+
+    def cs_counters(self):
+        """(k-mers looked up, index hits voted, candidates) of the last candidate search."""
+        out = np.zeros(3, np.uint64)
+        self.lib.ngm_mapper_cs_counters(self.h, out.ctypes.data)
+        return [int(x) for x in out]

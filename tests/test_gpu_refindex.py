@@ -76,3 +76,39 @@ def test_index_matches_the_reference_programs_index(tmp_path):
         assert ref.convert(start + ln - 1) == (ours.index((name, start, ln)), ln - 1)
     assert ref.convert(ours[1][1] - 5) is None
     ref.close(); ref2.close()
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+def test_reference_program_accepts_our_cache_files(tmp_path):
+    """Write <ref>-enc.2.ngm / <ref>-ht-13-2.3.ngm from the GPU-built index: byte-compare with the files the
+    reference writes itself, and check that the reference program maps identically when it loads ours."""
+    from nextgenmap_amd.pipeline import Reference
+    contigs = _tricky_genome()
+    d1, d2 = tmp_path / "theirs", tmp_path / "ours"
+    d1.mkdir(); d2.mkdir()
+    for d in (d1, d2):
+        with open(str(d / "ref.fa"), "wb") as f:
+            for i, g in enumerate(contigs):
+                f.write(b">chr%d\n" % (i + 1))
+                b = g.tobytes()
+                for o in range(0, len(b), 60):
+                    f.write(b[o:o + 60] + b"\n")
+    reads = S.make_reads([c for c in contigs if len(c) > 1000], 400, 100, seed=4)
+    fq = str(tmp_path / "r.fq")
+    S.write_fastq(fq, reads)
+    ref = Reference.from_fasta(str(d2 / "ref.fa"))
+    ref.write_ngm_cache(str(d2 / "ref.fa"))
+    ref.close()
+    outs = []
+    for d in (d1, d2):
+        r = RF.run_ngm(["-r", str(d / "ref.fa"), "-q", fq, "-o", str(d / "out.sam"), "--affine", "-t", "1", "--no-progress", "-s", "0.5"], cwd=str(d))
+        assert "Done" in r.stdout + r.stderr, (r.stdout + r.stderr)[-2000:]
+        if d is d2:
+            assert "Reading RefTable from" in r.stdout + r.stderr and "Building reference table" not in r.stdout + r.stderr
+        outs.append(sorted(l for l in open(str(d / "out.sam")) if not l.startswith("@")))
+    assert outs[0] == outs[1] and len(outs[0]) == 400
+    ht1, ht2 = RF.read_ht_file(str(d1 / "ref.fa-ht-13-2.3.ngm")), RF.read_ht_file(str(d2 / "ref.fa-ht-13-2.3.ngm"))
+    assert np.array_equal(ht1["counts"], ht2["counts"]) and np.array_equal(ht1["positions"], ht2["positions"])
+    e1, e2 = RF.read_enc_file(str(d1 / "ref.fa-enc.2.ngm")), RF.read_enc_file(str(d2 / "ref.fa-enc.2.ngm"))
+    nb = e1["n_bases"] // 2
+    assert e1["n_bases"] == e2["n_bases"] and np.array_equal(e1["data"][:nb], e2["data"][:nb])
