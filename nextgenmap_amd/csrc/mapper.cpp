@@ -32,7 +32,9 @@ struct ngm_mapper {
 	hipStream_t st = nullptr;
 	int max_kfreq = 0;
 	int cs_log2_slots = 13;   // large LDS vote table: 2^13 slots * 8 B = 64 KB
-	int cs_log2_small = 10;   // first-pass table; picked from the index density in ngm_mapper_create
+	int cs_log2_small = 10;   // fast path: small exact table ...
+	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
+	uint32_t cs_queued_exact = 0;
 	// batch state in HBM
 	ngm::DevBuf<uint8_t> d_reads;
 	ngm::DevBuf<uint16_t> d_read_len;
@@ -64,9 +66,10 @@ struct DevGuard {
 	~DevGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
 };
 
-size_t cs_lds_bytes(const ngm::CsArgs &A, bool global_table) {
+size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (!global_table) w += (size_t) 2 << A.log2_slots;
+	if (mode == ngm::kCsFast) w += (size_t) 2 << (A.log2_bits - 5);
+	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
 
@@ -76,7 +79,8 @@ int run_cs(ngm_mapper *m, int n) {
 	const ngm_ref *r = m->ref;
 	const int q = m->prm.qry_max_len;
 	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) ||
-			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_counters.reserve(4) || m->d_ovf_read.reserve(n) || m->d_ovf_hits.reserve(n)) {
+			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_counters.reserve(4) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
+			m->d_ovf_hits.reserve(n)) {
 		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
 		return -12;
 	}
@@ -86,7 +90,6 @@ int run_cs(ngm_mapper *m, int n) {
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, 8, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, 32, m->st));
-		int passes = 0;
 		ngm::CsArgs A{};
 		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
@@ -95,36 +98,40 @@ int run_cs(ngm_mapper *m, int n) {
 		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p;
 		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap;
 		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
-		// pass 1: every read with the small LDS table (many workgroups per CU); reads with too many hits are queued
-		A.log2_slots = m->cs_log2_small;
-		A.lds_hit_cap = (uint32_t) ((1u << A.log2_slots) * 0.66f);
+		uint32_t status[4];
+		m->cs_kernel_ms = 0;
+		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) m->cs_kernel_ms += t; };
+
+		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
+		A.log2_bits = m->cs_log2_bits; A.log2_slots = m->cs_log2_small;
+		A.hit_cap = (1u << m->cs_log2_bits) / 6u;
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
-		hipLaunchKernelGGL(ngm::cs_kernel<false>, dim3(n), dim3(64), cs_lds_bytes(A, false), m->st, A);
+		hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsFast>, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
-		passes = 1;
-		uint32_t status[4];
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
-		if (status[1] > 0 && m->cs_log2_slots > m->cs_log2_small) {
-			// pass 2: the queued reads with the large LDS table; what still does not fit is queued again
+		timed(0);
+		m->cs_queued_exact = status[1];
+		if (status[1] > 0) {
+			// pass 2 -- EXACT path, table in LDS, for the reads the fast path could not certify
 			const uint32_t no = status[1];
-			if (m->d_ovf_read2.reserve(no)) { ngm::pipeline_set_error("out of device memory"); return -12; }
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
 			MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
 			ngm::CsArgs B = A;
 			B.log2_slots = m->cs_log2_slots;
-			B.lds_hit_cap = (uint32_t) ((1u << B.log2_slots) * 0.66f);
+			B.hit_cap = (uint32_t) ((1u << B.log2_slots) * 0.66f);
 			B.read_list = m->d_ovf_read2.p;
 			MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
-			hipLaunchKernelGGL(ngm::cs_kernel<false>, dim3(no), dim3(64), cs_lds_bytes(B, false), m->st, B);
+			hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactLds>, dim3(no), dim3(64), cs_lds_bytes(B, ngm::kCsExactLds), m->st, B);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
-			passes = 2;
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+			timed(2);
 		}
-		if (status[1] > 0) {  // reads whose hits do not fit the LDS table: second pass with tables in global memory
+		if (status[1] > 0) {
+			// pass 3 -- EXACT path with per-read tables in global memory (reads with more hits than LDS holds)
 			const uint32_t no = status[1];
 			std::vector<uint32_t> hits(no), lg(no);
 			std::vector<uint64_t> off(no);
@@ -143,14 +150,17 @@ int run_cs(ngm_mapper *m, int n) {
 			}
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data(), no * 8, hipMemcpyHostToDevice, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data(), no * 4, hipMemcpyHostToDevice, m->st));
-			A.ovf_table_off = m->d_ovf_off.p; A.ovf_log2 = m->d_ovf_log2.p; A.gtable_keys = m->d_gt_keys.p; A.gtable_votes = m->d_gt_votes.p;
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
+			ngm::CsArgs G = A;
+			G.read_list = m->d_ovf_read2.p;
+			G.ovf_table_off = m->d_ovf_off.p; G.ovf_log2 = m->d_ovf_log2.p; G.gtable_keys = m->d_gt_keys.p; G.gtable_votes = m->d_gt_votes.p;
 			MAP_HIP_TRY(hipEventRecord(m->cev[4], m->st));
-			hipLaunchKernelGGL(ngm::cs_kernel<true>, dim3(no), dim3(64), cs_lds_bytes(A, true), m->st, A);
+			hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactGlobal>, dim3(no), dim3(64), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->cev[5], m->st));
-			passes |= 4;
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+			timed(4);
 		}
 		if (status[0] == 0) {
 			unsigned long long total = 0;
@@ -160,10 +170,6 @@ int run_cs(ngm_mapper *m, int n) {
 			unsigned long long ctr[4];
 			MAP_HIP_TRY(hipMemcpy(ctr, m->d_counters.p, 32, hipMemcpyDeviceToHost));
 			m->cs_kmers = ctr[0]; m->cs_hits = ctr[1];
-			float t = 0; m->cs_kernel_ms = 0;
-			if (hipEventElapsedTime(&t, m->cev[0], m->cev[1]) == hipSuccess) m->cs_kernel_ms += t;
-			if ((passes & 3) == 2 && hipEventElapsedTime(&t, m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t;
-			if ((passes & 4) && hipEventElapsedTime(&t, m->cev[4], m->cev[5]) == hipSuccess) m->cs_kernel_ms += t;
 			m->h_base.resize(n); m->h_count.resize(n); m->h_maxv.resize(n);
 			MAP_HIP_TRY(hipMemcpy(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost));
 			MAP_HIP_TRY(hipMemcpy(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost));
@@ -274,18 +280,24 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
 	for (auto &e : m->cev) (void) hipEventCreate(&e);
-	// first-pass table: sized for the expected hits per read, 2 * (q - k) lists * average list length, x3 headroom
+	// fast-path geometry from the expected hits per read H = 2 (q - k) lists x average list length:
+	// bit planes >= 12 H bits (6-8 % of the single background hits collide and survive the filter),
+	// small exact table for the survivors + the real signal with headroom
 	{
 		const double avg_list = (double) ref->n_entries / (double) (1ull << (2 * ref->prm.kmer));
-		const double expect = 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer) * avg_list * 3.0;
-		int l = 9;
-		while ((double) (1u << l) * 0.66 < expect && l < m->cs_log2_slots) ++l;
-		m->cs_log2_small = l;
+		const double hexp = std::max(64.0, 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer) * avg_list);
+		int lb = 12;
+		while ((double) (1u << lb) < 12.0 * hexp && lb < 17) ++lb;
+		int ls = 8;
+		while (0.75 * (double) (1u << ls) < 0.11 * hexp + 200.0 && ls < 12) ++ls;
+		m->cs_log2_bits = lb;
+		m->cs_log2_small = ls;
 	}
-	// LDS budget of the vote table: 2^13 slots * 8 B = 64 KB (+ lists and the read)
-	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len; A.log2_slots = m->cs_log2_slots;
-	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, false));
-	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, true));
+	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
+	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17;
+	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsFast>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
 	return m;
 }
 
