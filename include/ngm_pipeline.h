@@ -89,6 +89,10 @@ void ngm_mapper_destroy(ngm_mapper *m);
 int ngm_mapper_cs(ngm_mapper *m, int n, const char *reads, uint32_t *cand_offsets, float *max_votes);
 int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *votes);
 
+/* after ngm_mapper_cs: per read, the largest forward + reverse vote sum of any bin -- what the reference's
+ * sensitivity estimate is built from (ReadProvider.cpp:57-77, :79-124). out: n floats. */
+int ngm_mapper_cs_max_combined(ngm_mapper *m, float *out);
+
 /* Per-read mapping result (single-end, topn = 1). */
 typedef struct ngm_hit {
 	int mapped;            /* 0: no candidate / no alignment */

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LIB = os.path.join(HERE, "libngm_hip.so")
 SOURCES = ["ngm_hip.cpp", "ialignment_adapter.cpp", "refindex.cpp", "mapper.cpp"]
-HEADERS = ["sw_device.h", "align_device.h", "cigar_md.h", "refindex.h", "cs_device.h", "gather_device.h", os.path.join("..", "..", "include", "ngm_pipeline.h"), os.path.join("..", "..", "include", "ngm_hip.h"),
+HEADERS = ["ngm_cli.cpp", "engine_internal.h", "sw_device.h", "align_device.h", "cigar_md.h", "refindex.h", "cs_device.h", "gather_device.h", os.path.join("..", "..", "include", "ngm_pipeline.h"), os.path.join("..", "..", "include", "ngm_hip.h"),
            os.path.join("..", "..", "include", "ngm_ialignment.h")]
 
 
@@ -32,7 +32,21 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return LIB
+
+
+CLI = os.path.join(HERE, "ngm-hip")
+
+
+def build_cli(verbose=False):
+    """The NextGenMap-compatible command line: plain g++ host program over the C ABI of the library."""
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", os.path.join(CSRC, "ngm_cli.cpp"), LIB, "-lz",
+           "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-o", CLI]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

@@ -54,6 +54,7 @@ struct CsArgs {
 	uint32_t *cand_base;    // [n]
 	uint32_t *cand_count;   // [n]
 	float *max_votes;       // [n]
+	float *max_both;        // [n] optional: max over bins of forward + reverse votes (sensitivity estimation)
 	uint32_t *out_loc;      // candidate bin centres (concatenated coordinates)
 	uint32_t *out_sv;       // votes << 1 | strand
 	unsigned long long *out_total;  // allocation cursor
@@ -287,13 +288,16 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	if (MODE == kCsFast && s_flags[1]) { enqueue(); return; }  // small table full: not provably exact
 
 	// ---- 4. threshold and candidates (CS.cpp:201-205, :263-313) -------------------------------------------
-	int mx = 0;
+	int mx = 0, mxb = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) {
 		const uint32_t v = cs_tload<MODE>(&t_votes[s]);
 		mx = max(mx, (int) max(v & 0xFFFFu, v >> 16));
+		mxb = max(mxb, (int) ((v & 0xFFFFu) + (v >> 16)));
 	}
 	mx = wave_reduce_max(mx);
+	mxb = wave_reduce_max(mxb);
 	if (MODE == kCsFast && H > 0 && mx < 2) mx = 1;  // only single votes survived the filter: the true maximum is 1
+	if (MODE == kCsFast && H > 0 && mxb < 2) mxb = 1;
 	const float max_hit = (float) mx;
 	const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
 	// the filter dropped bins with a single vote: exact only if those cannot be candidates
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 		A.cand_base[read] = (uint32_t) base;
 		A.cand_count[read] = total;
 		A.max_votes[read] = max_hit;
+		if (A.max_both) A.max_both[read] = (float) mxb;
 		A.read_len[read] = (uint16_t) L;
 	}
 	base = __shfl((uint32_t) base, 0) | ((unsigned long long) __shfl((uint32_t) (base >> 32), 0) << 32);

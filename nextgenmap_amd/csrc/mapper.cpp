@@ -41,7 +41,7 @@ struct ngm_mapper {
 	ngm::DevBuf<uint32_t> d_cand_base, d_cand_count, d_out_loc, d_out_sv, d_status, d_ovf_read, d_ovf_read2, d_ovf_hits, d_ovf_log2;
 	ngm::DevBuf<uint64_t> d_ovf_off;
 	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes;
-	ngm::DevBuf<float> d_max_votes, d_scores, d_best;
+	ngm::DevBuf<float> d_max_votes, d_max_both, d_scores, d_best;
 	ngm::DevBuf<unsigned long long> d_total, d_counters;
 	unsigned long long cs_kmers = 0, cs_hits = 0;
 	float cs_kernel_ms = 0.f;
@@ -78,7 +78,7 @@ size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 int run_cs(ngm_mapper *m, int n) {
 	const ngm_ref *r = m->ref;
 	const int q = m->prm.qry_max_len;
-	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) ||
+	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) || m->d_max_both.reserve(n) ||
 			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_counters.reserve(4) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
 			m->d_ovf_hits.reserve(n)) {
 		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
@@ -95,7 +95,7 @@ int run_cs(ngm_mapper *m, int n) {
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
 		A.index = r->d_index; A.positions = r->d_positions;
 		A.lists_cap = 2 * std::max(1, q - r->prm.kmer + 1);
-		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p;
+		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p; A.max_both = m->d_max_both.p;
 		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap;
 		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
 		uint32_t status[4];
@@ -307,7 +307,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	(void) hipStreamSynchronize(m->st);
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
 	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_read2.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
-	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
+	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
@@ -504,6 +504,13 @@ int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const vo
 		if (hipEventElapsedTime(&t, eng->ev[2], m->ev[7]) == hipSuccess) m->ms[6] = t;
 	}
 	return n;
+}
+
+int ngm_mapper_cs_max_combined(ngm_mapper *m, float *out) {
+	if (!m) return -22;
+	DevGuard g(m->ref->device);
+	if (m->n_reads > 0) MAP_HIP_TRY(hipMemcpy(out, m->d_max_both.p, (size_t) m->n_reads * 4, hipMemcpyDeviceToHost));
+	return 0;
 }
 
 int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]) {

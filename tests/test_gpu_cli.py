@@ -1,0 +1,90 @@
+"""-m gpu: the ngm-compatible command line (nextgenmap_amd/ngm-hip) next to the REAL reference program on the
+same FASTA/FASTQ: parameter estimation (qry_max_len, corridor, sensitivity) must agree exactly; SAM records are
+compared field by field where the scoring personality does not matter (the reference can only run --affine here)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import ref_files as RF
+import simulate as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "nextgenmap_amd", "ngm-hip")
+
+
+def _sam(path):
+    recs = {}
+    for line in open(path):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        recs[f[0]] = dict(flag=int(f[1]), rname=f[2], pos=int(f[3]), mapq=int(f[4]), cigar=f[5], seq=f[9], qual=f[10], tags=tags)
+    return recs
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+def test_cli_against_reference_program(tmp_path):
+    from nextgenmap_amd import build
+    build.build()
+    contigs = S.make_genome([300000, 200001], seed=21, repeat_families=6, repeat_len=400, copies=5)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    reads = S.make_reads(contigs, 4000, 100, seed=22, sub_rate=0.02, indel_rate=0.002)
+    reads[5] = (reads[5][0], np.full(100, ord("N"), np.uint8), reads[5][2])
+    fq = str(tmp_path / "reads.fq")
+    S.write_fastq(fq, reads)
+    d1 = tmp_path / "refrun"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    r = RF.run_ngm(["-r", fa1, "-q", fq, "-o", str(d1 / "out.sam"), "--affine", "-t", "1", "--no-progress"], cwd=str(d1))
+    log_ref = r.stdout + r.stderr
+    assert "Done" in log_ref
+    c = subprocess.run([CLI, "-r", fa, "-q", fq, "-o", str(tmp_path / "hip.sam")], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    log_hip = c.stderr
+
+    def grab(pat, log):
+        m = re.search(pat, log)
+        assert m, pat
+        return m.groups()
+    # parameter estimation: identical numbers
+    assert grab(r"Average read length: (\d+) \(min: (\d+), max: (\d+)\)", log_ref) == grab(r"Average read length: (\d+) \(min: (\d+), max: (\d+)\)", log_hip)
+    assert grab(r"Corridor width: (\d+)", log_ref) == grab(r"Corridor width: (\d+)", log_hip)
+    assert grab(r"Estimated sensitivity: ([0-9.]+)", log_ref) == grab(r"Estimated sensitivity: ([0-9.]+)", log_hip)
+
+    a, b = _sam(str(d1 / "out.sam")), _sam(str(tmp_path / "hip.sam"))
+    assert set(a) == set(b) and len(a) == 4000
+    same_place = same_pos = both = 0
+    differ = []
+    for name in a:
+        x, y = a[name], b[name]
+        if (x["flag"] & 4) != (y["flag"] & 4):
+            # the identity / residue filters see different alignments under the two gap models
+            differ.append((name, x["flag"], x["cigar"], x["tags"].get("XI"), y["flag"], y["cigar"], y["tags"].get("XI")))
+            continue
+        if x["flag"] & 4:
+            assert y["rname"] == "*" and y["pos"] == 0 and y["seq"] == x["seq"]
+            continue
+        both += 1
+        assert x["tags"]["XE"] == y["tags"]["XE"], name       # max k-mer votes: personality independent
+        assert x["seq"] == y["seq"] or x["flag"] != y["flag"]
+        if (x["flag"], x["rname"]) == (y["flag"], y["rname"]):
+            same_place += 1
+            same_pos += x["pos"] == y["pos"]
+    print(differ[:10])
+    assert len(differ) <= 0.01 * len(a), differ[:10]
+    assert same_place >= 0.995 * both and same_pos >= 0.97 * both, (both, same_place, same_pos)
+    hdr_ref = [l for l in open(str(d1 / "out.sam")) if l.startswith("@SQ")]
+    hdr_hip = [l for l in open(str(tmp_path / "hip.sam")) if l.startswith("@SQ")]
+    assert hdr_ref == hdr_hip
