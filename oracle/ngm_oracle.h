@@ -104,6 +104,23 @@ void ngm_oracle_batch_align(int mode, int n, const char *ref, long ref_stride, c
 		int hard_clip, int silent_clip, ngm_oracle_align *out, char *cigars, char *mds,
 		long str_stride, int nthreads);
 
+/* ---- affine-gap personality (`--affine`): EndToEndAffine over SeqAn 1.4.1, see ngm_affine_oracle.c ---------- */
+typedef struct ngm_oracle_affine_scoring {
+	int match;       /* Config match_bonus */
+	int mismatch;    /* -mismatch_penalty */
+	int gap_open;    /* -gap_read_penalty: score of the FIRST gap character (SeqAn convention) */
+	int gap_extend;  /* -gap_extend_penalty: every further gap character */
+} ngm_oracle_affine_scoring;
+
+/* EndToEndAffine::BatchScore for one pair (src/seqan/EndToEndAffine.cpp:10-28); mode 0 local, 1 end-to-end. */
+int ngm_oracle_affine_score(int mode, const char *ref, const char *qry, int q, int c, const ngm_oracle_affine_scoring *sc);
+/* EndToEndAffine::BatchAlign + convertToCIGAR (:30-155): CIGAR (S/M/I/D), PositionOffset, QStart, QEnd,
+ * NM = mismatching columns, Identity = matches / (columns + gap runs).  MD is not produced by the reference. */
+void ngm_oracle_affine_align(int mode, const char *ref, const char *qry, int q, int c, const ngm_oracle_affine_scoring *sc,
+		ngm_oracle_align *out, char *cigar);
+void ngm_oracle_affine_batch(int mode, int n, const char *ref, long ref_stride, const char *qry, long qry_stride, int q, int c,
+		const ngm_oracle_affine_scoring *sc, float *scores, ngm_oracle_align *out, char *cigars, long str_stride, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,3 +56,15 @@ $(OUT)/ngm-core-debug: $(DBG_OBJ)
 	$(CXX) -pthread -o $@ $^ -lz -lOpenCL
 
 .PHONY: all
+
+# ---- the reference's affine IAlignment (SeqAn) behind a small driver of ours --------------------------------
+AFF_SRC := seqan/EndToEndAffine.cpp config/Config.cpp log/Logging.cpp core/unix.cpp core/unix_threads.cpp
+AFF_OBJ := $(addprefix $(OUT)/rel/src/,$(AFF_SRC:.cpp=.o))
+$(OUT)/affine_ref_main.o: $(dir $(abspath $(lastword $(MAKEFILE_LIST))))affine_ref_main.cpp
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS_COMMON) -O2 -DNDEBUG $(INC) -I$(R)/src/seqan -c $< -o $@
+$(OUT)/ngm_affine_ref: $(OUT)/affine_ref_main.o $(AFF_OBJ)
+	$(CXX) -pthread -o $@ $^ -lz
+affine: $(OUT)/ngm_affine_ref
+all: affine
+.PHONY: affine

@@ -120,6 +120,71 @@ def oracle_trace(mode, ref, qry, c, scoring=None, variant=0):
 
 
 # ---------------------------------------------------------------------------------------------
+# affine personality: restatement + the reference's own EndToEndAffine behind oracle/_ref/ngm/ngm_affine_ref
+# ---------------------------------------------------------------------------------------------
+class AffScoring(C.Structure):
+    _fields_ = [("match", C.c_int), ("mismatch", C.c_int), ("gap_open", C.c_int), ("gap_extend", C.c_int)]
+
+
+DEFAULT_AFFINE = dict(match=10, mismatch=-15, gap_open=-33, gap_extend=-3)
+AFFINE_REF = os.path.join(ORACLE_DIR, "_ref", "ngm", "ngm_affine_ref")
+
+
+def oracle_affine(mode, ref, qry, c, scoring=None, nthreads=1):
+    """-> (scores float32[n], ALIGN_DTYPE[n], cigars list[bytes])"""
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    n, q = qry.shape
+    s = dict(DEFAULT_AFFINE)
+    if scoring:
+        s.update(scoring)
+    sc = AffScoring(**s)
+    lib = oracle()
+    lib.ngm_oracle_affine_batch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int,
+                                            C.POINTER(AffScoring), C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+    stride = 4 * max(1, q)
+    scores = np.zeros(n, np.float32)
+    res = np.zeros(n, dtype=ALIGN_DTYPE)
+    cig = np.zeros((n, stride), np.uint8)
+    # rows must be NUL terminated inside q+c / q bytes: pad one column
+    refp = np.zeros((n, ref.shape[1] + 1), np.uint8); refp[:, :-1] = ref
+    qryp = np.zeros((n, q + 1), np.uint8); qryp[:, :-1] = qry
+    lib.ngm_oracle_affine_batch(mode, n, refp.ctypes.data, refp.strides[0], qryp.ctypes.data, qryp.strides[0], q, c, C.byref(sc),
+                                scores.ctypes.data, res.ctypes.data, cig.ctypes.data, stride, nthreads)
+    return scores, res, [bytes(r).split(b"\0", 1)[0] for r in cig]
+
+
+def reference_affine(mode, ref, qry, c, scoring=None, workdir="/tmp"):
+    """Run the REFERENCE's EndToEndAffine (SeqAn) on the pairs. -> list of None (empty pair) or
+    (score, cigar, position_offset, qstart, qend, nm, identity)."""
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qry = np.ascontiguousarray(qry, dtype=np.uint8)
+    n, q = qry.shape
+    s = dict(DEFAULT_AFFINE)
+    if scoring:
+        s.update(scoring)
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=workdir) as d:
+        inp, outp = os.path.join(d, "in.bin"), os.path.join(d, "out.txt")
+        with open(inp, "wb") as f:
+            np.array([n, q, c], np.int32).tofile(f)
+            ref.tofile(f)
+            qry.tofile(f)
+        r = subprocess.run([AFFINE_REF, inp, outp, str(mode), str(s["match"]), str(-s["mismatch"]), str(-s["gap_open"]),
+                            str(-s["gap_extend"])], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("affine reference failed: " + r.stderr[-500:])
+        out = []
+        for line in open(outp):
+            f = line.rstrip("\n").split("\t")
+            if f[1] == "EMPTY":
+                out.append(None)
+            else:
+                out.append((int(f[1]), f[2].encode(), int(f[3]), int(f[4]), int(f[5]), int(f[6]), np.float32(float(f[7]))))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # reference kernels on the GPU (oracle/_ref/*.co via oracle/libngm_ref_runner.so)
 # ---------------------------------------------------------------------------------------------
 def ref_co_path(variant, q, c, scoring=None):
