@@ -18,6 +18,8 @@
  *                                         lib/mason/opencl/SWOcl.cpp:33-162
  *   ngm_hip_batch_align                <- IAlignment::BatchAlign         include/IAlignment.h:65-69,
  *                                         lib/mason/opencl/SWOclCigar.cpp:104-370 (+ computeCigarMD :430-615)
+ *   (personality AFFINE: the same two entry points replace EndToEndAffine::BatchScore / BatchAlign,
+ *                                         src/seqan/EndToEndAffine.cpp:10-28, :30-155)
  *   ngm_hip_score_device / _align_device : same operations on batches already resident in HBM
  *                                         (no reference counterpart; what bench.py times).
  *
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NGM_HIP_ABI_VERSION 1
+#define NGM_HIP_ABI_VERSION 2
 
 /* mode argument of batch_score / batch_align: include/IAlignment.h:33-48 */
 #define NGM_MODE_LOCAL 0      /* Smith-Waterman, kernels oclSW / oclSW_Score        */
@@ -48,6 +50,14 @@ extern "C" {
  * (float4) build labels by score == match and scores an empty read -1. */
 #define NGM_VARIANT_OCL_GPU 0
 #define NGM_VARIANT_OCL_CPU 1
+
+/* Which IAlignment implementation of the reference is reproduced (src/NGM.cpp:388-437):
+ * LINEAR = the OpenCL plugin (default; linear gap costs gap_read / gap_ref, CIGAR + MD),
+ * AFFINE = `ngm --affine`: src/seqan/EndToEndAffine.cpp over SeqAn 1.4.1's banded Gotoh alignment
+ *          (gap open = gap_read_penalty, gap extend = gap_extend_penalty, band diagonals 0..corridor,
+ *          CIGAR with S/M/I/D only, NM = mismatches, no MD string: pBuffer2 is left untouched). */
+#define NGM_PERSONALITY_LINEAR 0
+#define NGM_PERSONALITY_AFFINE 1
 
 typedef struct ngm_hip_params {
 	int abi_version;   /* NGM_HIP_ABI_VERSION */
@@ -62,6 +72,8 @@ typedef struct ngm_hip_params {
 	int hard_clip;     /* Config "hard_clip"   (SWOclCigar.cpp:450) */
 	int silent_clip;   /* Config "silent_clip" (SWOclCigar.cpp:454) */
 	int max_batch;     /* largest n the caller will pass (0 = default 1<<20); sizes the HBM workspace */
+	int personality;   /* NGM_PERSONALITY_* */
+	int gap_extend_penalty; /* Config "gap_extend_penalty" (affine personality only), src/config/Config.cpp:444 */
 } ngm_hip_params;
 
 /* Mirrors struct Align (include/IAlignment.h:14-29); buffers are caller-owned. */

@@ -76,6 +76,8 @@ typedef struct ngm_mapper_params {
 	int max_cmrs;          /* Config "max_cmrs" (INT_MAX = unlimited) */
 	int max_kfreq;         /* <= 0: use ngm_ref_auto_max_kfreq */
 	int hard_clip, silent_clip;
+	int personality;       /* NGM_PERSONALITY_* of ngm_hip.h: 1 = `--affine` (EndToEndAffine / SeqAn scoring and CIGARs) */
+	int gap_extend_penalty; /* Config "gap_extend_penalty" (affine personality) */
 } ngm_mapper_params;
 
 ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p);

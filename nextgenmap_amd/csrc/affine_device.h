@@ -1,0 +1,270 @@
+// affine_device.h -- gfx950 kernels of the affine-gap personality (`ngm --affine`): NextGenMap's
+// EndToEndAffine::BatchScore / BatchAlign, i.e. SeqAn 1.4.1's banded Gotoh alignment with band diagonals
+// 0..corridor (src/seqan/EndToEndAffine.cpp:10-52, lib/seqan-library-1.4.1/include/seqan/align/
+// dp_formula_affine.h:390-415, dp_formula.h:152-160, dp_scout.h:142-155, dp_traceback_impl.h:184-470).
+//
+// Same decomposition as the linear kernels (sw_device.h / align_device.h): one pair per lane, the band row in
+// VGPRs, 8 read rows per loop trip from the interleaved packed stream, substitution score by v_perm_b32.
+// Geometry: SeqAn walks columns h (reference) x rows v (read); here a DP row is a read position v and the band
+// column is the diagonal d = h - v in [0, corridor] (CP = corridor + 1 columns).  Three values per cell:
+// S (best), Eh (alignment ending in a reference-only column = horizontal gap), Ev (read-only column = vertical).
+//   Eh(v,d) = max(Eh(v,d-1) + ext, S(v,d-1) + open)        open wins only if strictly greater
+//   Ev(v,d) = max(Ev(v-1,d+1) + ext, S(v-1,d+1) + open)
+//   S(v,d)  = diagonal if S(v-1,d) + sub >= max(Ev, Eh) else the gap maximum (vertical preferred on ties)
+//   local:  S <= 0  ->  S = Eh = Ev = 0
+// Characters compare by value in SeqAn (N matches N); on NextGenMap's alphabet (reads ACGTN, windows ACGTNx) that
+// is equality of the symbol classes, with the read's NUL padding never matching.
+// Values are re-based per row exactly like the linear kernels (X' = X - v * mismatch) so the table bytes are
+// {0, match - mismatch}; "not reachable" is a large negative number.
+// The argmax follows SeqAn's scout: first strict maximum in column-major order = smallest h, then smallest v.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sw_device.h"
+
+namespace ngm {
+
+struct AffConst {
+	int tM;     // match - mismatch
+	int tZ;     // -mismatch : per-row floor step
+	int open;   // gap open (first gap character), negative
+	int ext;    // gap extend, negative
+	int vopen;  // open - mismatch  (vertical predecessor lives one row up)
+	int vext;   // ext - mismatch
+};
+
+constexpr int kAffNeg = -(1 << 28);
+__host__ __device__ constexpr int aff_dir_words(int CP) { return (CP + 3) / 4; }  // one trace byte per cell
+
+// SeqAn's trace bits (align/dp_profile.h:116-123)
+enum { kTDiag = 1, kTHori = 2, kTVert = 4, kTHoriOpen = 8, kTVertOpen = 16, kTMaxH = 32, kTMaxV = 64 };
+// affine records reuse the 8-int layout of align_device.h; rec[6]/rec[7] = end cell (h, v), and
+// rec[5] = best score, rec[3] bit0/bit1 = "Ev == S" / "Eh == S" at the end cell (for _correctTraceValue)
+
+__device__ __forceinline__ uint2 aff_row_table(int rc, const AffConst &K) {
+	uint32_t b[8];
+	// class 4 ("other": the 'x' filler of the window decoder) never equals a read character
+	for (int fc = 0; fc < 8; ++fc) b[fc] = (rc <= 5 && rc != 4 && fc == rc) ? (uint32_t) (K.tM & 0xFF) : 0u;
+	uint2 r;
+	r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+	r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+	return r;
+}
+
+// CP = corridor + 1 band columns.  ALIGN: also write the trace bytes and the end-cell record.
+template <int CP, bool ENDFREE, bool ALIGN>
+__global__ __launch_bounds__(256) void sw_affine_kernel(const uint32_t *__restrict__ packed, const uint16_t *__restrict__ lens,
+		const uint16_t *__restrict__ blk_rows, float *__restrict__ scores, uint32_t *__restrict__ dirs, int32_t *__restrict__ records,
+		int n, int n_blocks, int RW, int q, AffConst K) {
+	__shared__ uint2 s_tab[8];
+	if (threadIdx.x < 8) s_tab[threadIdx.x] = aff_row_table(threadIdx.x, K);
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (blk >= n_blocks) return;
+	constexpr int NRG = sel_regs(CP);
+	constexpr int DW = aff_dir_words(CP);
+	const int FW = RW + NRG / 2;
+	const uint32_t *rd = packed + (size_t) blk * (RW + FW) * kSlots + lane;
+	const uint32_t *fd = rd + (size_t) RW * kSlots;
+	uint32_t *dout = ALIGN ? dirs + (size_t) blk * q * DW * kSlots + lane : nullptr;
+	const int pair = blk * kSlots + lane;
+	const int lenV = (pair < n) ? (int) lens[pair] : 0;
+	const int rows = __builtin_amdgcn_readfirstlane((int) blk_rows[blk]);
+	const int ngroups = (rows + 7) >> 3;
+
+	// window length |H| = first NUL class in the window (TSequence(refSeqList[i]) is a C string); only the
+	// end-to-end scout needs it (the last row's cells with h > |H| do not exist)
+	int lenH = FW * 8;
+	if (ENDFREE) {
+		for (int m = FW - 1; m >= 0; --m) {
+			const uint32_t x = fd[(size_t) m * kSlots];
+			const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
+#pragma unroll
+			for (int j = 7; j >= 0; --j) {
+				const uint32_t cls = (j < 4) ? (lo >> (8 * j)) & 15u : (hi >> (8 * (j - 4))) & 15u;
+				if (cls == 6u) lenH = m * 8 + j;
+			}
+		}
+	}
+
+	int S[CP], Ev[CP];
+#pragma unroll
+	for (int d = 0; d < CP; ++d) { S[d] = 0; Ev[d] = ENDFREE ? kAffNeg : 0; }  // row v = 0
+	uint32_t RG[NRG];
+#pragma unroll
+	for (int r = 0; r < NRG / 2; ++r) {
+		const uint32_t x = fd[(size_t) r * kSlots];
+		RG[2 * r] = x & 0x0F0F0F0Fu;
+		RG[2 * r + 1] = (x >> 4) & 0x0F0F0F0Fu;
+	}
+	int fl = K.tZ;  // re-based zero of row v = 1
+	// scout state: maximum is initialised by the first tracked cell (0,0) with score 0 in local mode
+	int best = ENDFREE ? kAffNeg : 0, bh = 0, bv = 0, bflags = 0;
+	uint32_t rnext = (ngroups > 0) ? rd[0] : 0x66666666u;
+
+	for (int g = 0; g < ngroups; ++g) {
+		const uint32_t rx = rnext;
+		rnext = (g + 1 < ngroups) ? rd[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		const uint32_t fx = fd[(size_t) (g + NRG / 2) * kSlots];
+		const uint32_t rsel[2] = {rx & 0x0F0F0F0Fu, (rx >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {
+			const int i = g * 8 + s;  // read position, v = i + 1
+			uint32_t rc = (rsel[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+			rc = (i < lenV) ? rc : 6u;
+			const uint2 T = s_tab[rc];
+			uint32_t P[NRG];
+#pragma unroll
+			for (int r = 0; r < NRG; ++r) P[r] = ((s + CP - 1) / 4 >= r && s / 4 <= r) ? __builtin_amdgcn_perm(T.y, T.x, RG[r]) : 0u;
+			int leftS = kAffNeg, leftEh = kAffNeg;  // column d = 0 has no horizontal predecessor
+			uint32_t dw[DW];
+#pragma unroll
+			for (int w = 0; w < DW; ++w) dw[w] = 0;
+			int rowkey = -1, rowflags = 0;
+			uint32_t ehq[(CP + 31) / 32];
+#pragma unroll
+			for (int w = 0; w < (CP + 31) / 32; ++w) ehq[w] = 0;
+#pragma unroll
+			for (int d = 0; d < CP; ++d) {
+				const int bi = s + d;
+				const int t = (int) ((P[bi >> 2] >> (8 * (bi & 3))) & 0xFFu);
+				const int dg = S[d] + t;
+				// horizontal gap (reference base only): same row, column d - 1
+				int eh = leftEh + K.ext;
+				const int eho = leftS + K.open;
+				const bool h_open = eh < eho;
+				eh = h_open ? eho : eh;
+				// vertical gap (read base only): previous row, column d + 1
+				int ev, evo;
+				if (d < CP - 1) { ev = Ev[d + 1] + K.vext; evo = S[d + 1] + K.vopen; }
+				else { ev = kAffNeg; evo = kAffNeg; }
+				const bool v_open = ev < evo;
+				ev = v_open ? evo : ev;
+				if (d == 0) eh = kAffNeg;
+				// gap maximum: vertical unless horizontal is strictly greater; diagonal wins ties against it
+				const bool from_h = (d == CP - 1) ? true : ((d == 0) ? false : (ev < eh));
+				const int gapmax = from_h ? eh : ev;
+				const bool diag = gapmax <= dg;
+				int sc = diag ? dg : gapmax;
+				bool none = false;
+				if (!ENDFREE) {
+					none = sc <= fl;
+					sc = none ? fl : sc;
+					eh = none ? fl : eh;
+					ev = none ? fl : ev;
+				}
+				if (ALIGN) {
+					uint32_t tg = 0;
+					if (d > 0) tg |= h_open ? (uint32_t) kTHoriOpen : (uint32_t) kTHori;
+					if (d < CP - 1) tg |= v_open ? (uint32_t) kTVertOpen : (uint32_t) kTVert;
+					uint32_t tr = diag ? (tg | (uint32_t) kTDiag) : (tg | (from_h ? (uint32_t) kTMaxH : (uint32_t) kTMaxV));
+					tr = none ? 0u : tr;
+					dw[d >> 2] |= tr << (8 * (d & 3));
+				}
+				const int key = ((sc - fl) << 8) | (255 - d);  // local: sc - fl >= 0
+				if (!ENDFREE) {
+					if (key > rowkey) { rowkey = key; rowflags = ((ev == sc) ? 1 : 0) | ((eh == sc) ? 2 : 0); }
+				}
+				if (ENDFREE && ALIGN) ehq[d >> 5] |= (eh == sc) ? (1u << (d & 31)) : 0u;
+				S[d] = sc;
+				Ev[d] = ev;
+				leftS = sc;
+				leftEh = eh;
+			}
+			if (ALIGN && i < q) {
+#pragma unroll
+				for (int w = 0; w < DW; ++w) dout[((size_t) i * DW + w) * kSlots] = dw[w];
+			}
+			if (!ENDFREE) {
+				// column-major first maximum: strictly greater, or equal with a smaller h
+				const int rs = rowkey >> 8, rd_ = 255 - (rowkey & 255), rh = i + 1 + rd_;
+				if (i < lenV && (rs > best || (rs == best && rs > 0 && rh < bh))) { best = rs; bh = rh; bv = i + 1; bflags = rowflags; }
+			} else if (i + 1 == lenV) {
+				// end-to-end: the tracked cells are the last row's, h <= |H| only, first strict maximum in h
+				const int dlim = lenH - lenV;
+				const int kv = -fl;  // S = S' + v * mismatch
+#pragma unroll
+				for (int d = 0; d < CP; ++d) {
+					const int v = S[d] + kv;
+					if (d <= dlim && v > best) {
+						best = v; bh = lenV + d; bv = lenV;
+						bflags = ((Ev[d] == S[d]) ? 1 : 0) | ((ALIGN && ((ehq[d >> 5] >> (d & 31)) & 1u)) ? 2 : 0);
+					}
+				}
+			}
+			fl += K.tZ;
+		}
+#pragma unroll
+		for (int r = 0; r + 2 < NRG; ++r) RG[r] = RG[r + 2];
+		RG[NRG - 2] = fx & 0x0F0F0F0Fu;
+		RG[NRG - 1] = (fx >> 4) & 0x0F0F0F0Fu;
+	}
+
+	if (pair < n) {
+		if (lenV < 1 || lenH < 1) { best = 0; bh = bv = 0; bflags = 0; }  // EndToEndAffine: empty sequence, empty alignment
+		if (!ALIGN) {
+			scores[pair] = (float) best;
+		} else {
+			int32_t *rec = records + (size_t) pair * 8;
+			rec[0] = 0; rec[1] = 0; rec[2] = 0; rec[3] = bflags; rec[4] = 0; rec[5] = best; rec[6] = bh; rec[7] = bv;
+		}
+	}
+}
+
+#ifdef NGM_ENGINE_KERNELS
+// SeqAn's single-trace, gaps-left traceback (dp_traceback_impl.h:184-470) over the stored trace bytes.
+// Emits the same compact runs as the linear traceback: (len << 2) | op, op 1 = M, 2 = I, 3 = D, in traceback order.
+__global__ __launch_bounds__(256) void affine_traceback_kernel(const uint32_t *__restrict__ dirs, int32_t *__restrict__ records,
+		uint16_t *__restrict__ runs, int n, int q, int CP, int run_stride) {
+	const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pair >= n) return;
+	int32_t *rec = records + (size_t) pair * 8;
+	int h = rec[6], v = rec[7];
+	const int flags = rec[3];
+	const int DW = aff_dir_words(CP);
+	const uint32_t *dp = dirs + (size_t) (pair >> 6) * q * DW * kSlots + (pair & 63);
+	uint16_t *out = runs + (size_t) pair * run_stride;
+	auto tv_at = [&](int hh, int vv) -> uint32_t {
+		if (vv <= 0 || hh <= 0) return 0u;  // initialisation row / column: NONE
+		const int d = hh - vv;
+		if (d < 0 || d >= CP) return 0u;
+		const uint32_t w = dp[((size_t) (vv - 1) * DW + (d >> 2)) * kSlots];
+		return (w >> (8 * (d & 3))) & 0xFFu;
+	};
+	uint32_t tv = tv_at(h, v);
+	// _correctTraceValue (dp_algorithm_impl.h:1233-1250)
+	if (flags & 1) tv = (tv & ~(uint32_t) kTDiag) | (uint32_t) kTMaxV;
+	else if (flags & 2) tv = (tv & ~(uint32_t) kTDiag) | (uint32_t) kTMaxH;
+	// _retrieveInitialTraceDirection, PreferGapsAtEnd (dp_traceback_impl.h:452-468)
+	if (tv & kTMaxV) tv &= (uint32_t) (kTVert | kTVertOpen | kTMaxV);
+	else if (tv & kTMaxH) tv &= (uint32_t) (kTHori | kTHoriOpen | kTMaxH);
+	int nruns = 0, cur = -1, curlen = 0;
+	auto emit = [&](int op) {
+		if (op == cur) { ++curlen; return; }
+		if (cur >= 0 && nruns < run_stride) out[nruns++] = (uint16_t) ((curlen << 2) | cur);
+		cur = op; curlen = 1;
+	};
+	while (h > 0 && v > 0 && tv != 0u) {
+		if (tv & kTDiag) { emit(1); --h; --v; tv = tv_at(h, v); }
+		else if ((tv & kTMaxV) && (tv & kTVert)) {
+			while ((!(tv & kTVertOpen) || (tv & kTVert)) && v != 1) { emit(2); --v; tv = tv_at(h, v); }
+			emit(2); --v; tv = tv_at(h, v);
+		} else if ((tv & kTMaxV) && (tv & kTVertOpen)) { emit(2); --v; tv = tv_at(h, v); }
+		else if ((tv & kTMaxH) && (tv & kTHori)) {
+			while ((!(tv & kTHoriOpen) || (tv & kTHori)) && h != 1) { emit(3); --h; tv = tv_at(h, v); }
+			emit(3); --h; tv = tv_at(h, v);
+		} else if ((tv & kTMaxH) && (tv & kTHoriOpen)) { emit(3); --h; tv = tv_at(h, v); }
+		else break;
+	}
+	if (cur >= 0 && nruns < run_stride) out[nruns++] = (uint16_t) ((curlen << 2) | cur);
+	rec[0] = 1;        // an alignment (possibly empty) always exists in the reference
+	rec[1] = h;        // PositionOffset: window offset of the first aligned reference base
+	rec[2] = v;        // QStart
+	rec[4] = nruns;
+}
+#endif  // NGM_ENGINE_KERNELS
+
+}  // namespace ngm

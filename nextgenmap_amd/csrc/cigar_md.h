@@ -113,4 +113,40 @@ inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint1
 	out->position_offset = rec[1];
 }
 
+// Affine personality: EndToEndAffine::convertToCIGAR (src/seqan/EndToEndAffine.cpp:52-155) from the device runs.
+// CIGAR uses S / M / I / D only, Identity = matches / (diagonal columns + number of gap runs), NM = mismatches,
+// and neither Align.Score nor pBuffer2 (MD) is written.
+// rec[1] = window offset of the first aligned reference base, rec[2] = first aligned read base, runs in traceback order.
+inline void build_cigar_affine(const int32_t *rec, const uint16_t *runs, const char *ref, const char *qry, int qry_max_len,
+		ngm_hip_align_out *out) {
+	int len_v = 0;
+	while (len_v < qry_max_len && qry[len_v]) ++len_v;
+	char *cigar = out->cigar;
+	int co = 0, match = 0, mismatch = 0, total = 0, pattern_chars = 0;
+	int h = rec[1], v = rec[2];
+	out->position_offset = h;
+	out->qstart = v;
+	if (v > 0) { co += put_num(cigar + co, v); cigar[co++] = 'S'; }
+	for (int k = rec[4] - 1; k >= 0; --k) {
+		const int op = runs[k] & 3, run = runs[k] >> 2;
+		co += put_num(cigar + co, run);
+		if (op == 1) {
+			for (int t = 0; t < run; ++t) { if (ref[h + t] == qry[v + t]) ++match; else ++mismatch; }
+			total += run; h += run; v += run; pattern_chars += run;
+			cigar[co++] = 'M';
+		} else if (op == 2) {
+			total += 1; v += run; pattern_chars += run;
+			cigar[co++] = 'I';
+		} else {
+			total += 1; h += run;
+			cigar[co++] = 'D';
+		}
+	}
+	out->qend = len_v - (pattern_chars + out->qstart);
+	if (out->qend > 0) { co += put_num(cigar + co, out->qend); cigar[co++] = 'S'; }
+	cigar[co] = 0;
+	out->identity = match * 1.0f / total;
+	out->nm = mismatch;
+}
+
 }  // namespace ngm

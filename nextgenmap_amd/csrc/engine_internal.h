@@ -9,6 +9,7 @@
 
 #include "../../include/ngm_hip.h"
 #include "sw_device.h"
+#include "affine_device.h"
 
 namespace ngm {
 template <typename T>
@@ -49,6 +50,7 @@ struct ngm_hip_ctx {
 	int device = 0;
 	ngm_hip_params prm{};
 	ngm::SwConst K{};
+	ngm::AffConst KA{};
 	int q = 0, c = 0, rl = 0, RW = 0, FW = 0;
 	int max_batch = 0;
 	hipStream_t stream = nullptr;

@@ -104,6 +104,12 @@ IAlignment *CreateAlignment(int const mode) {
 	p.hard_clip = cfg.Exists("hard_clip") ? cfg.GetInt("hard_clip") : 0;
 	p.silent_clip = cfg.Exists("silent_clip") ? cfg.GetInt("silent_clip") : 0;
 	p.max_batch = 0;
+	// `--affine` swaps the plugin for EndToEndAffine in the reference (src/NGM.cpp:397-404); here it is a personality
+	p.personality = (cfg.Exists("affine") && cfg.GetInt("affine")) ? NGM_PERSONALITY_AFFINE : NGM_PERSONALITY_LINEAR;
+	if (p.personality == NGM_PERSONALITY_AFFINE && !integral(cfg.GetFloat("gap_extend_penalty"), &p.gap_extend_penalty)) {
+		log_msg(2, "the HIP backend needs an integer gap_extend_penalty");
+		return nullptr;
+	}
 	ngm_hip_ctx *ctx = ngm_hip_create(mode & 0xFF, &p);
 	if (!ctx) { log_msg(2, ngm_hip_last_error(nullptr)); return nullptr; }
 	return new HipAlignment(ctx);

@@ -273,6 +273,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	ep.qry_max_len = p->qry_max_len; ep.corridor = p->corridor;
 	ep.match_bonus = p->match_bonus; ep.mismatch_penalty = p->mismatch_penalty; ep.gap_read_penalty = p->gap_read_penalty; ep.gap_ref_penalty = p->gap_ref_penalty;
 	ep.variant = p->variant; ep.hard_clip = p->hard_clip; ep.silent_clip = p->silent_clip; ep.max_batch = 0;
+	ep.personality = p->personality; ep.gap_extend_penalty = p->gap_extend_penalty;
 	ngm_hip_ctx *eng = ngm_hip_create(ref->device, &ep);
 	if (!eng) { ngm::pipeline_set_error("%s", ngm_hip_last_error(nullptr)); return nullptr; }
 	ngm_mapper *m = new ngm_mapper();
@@ -481,8 +482,14 @@ int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const vo
 			ngm_hip_align_out ao{};
 			ao.cigar = cigars + (size_t) i * str_stride;
 			ao.md = mds + (size_t) i * str_stride;
-			ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), &ao);
-			if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
+			if (m->prm.personality == NGM_PERSONALITY_AFFINE) {
+				// EndToEndAffine never touches pBuffer2: the SAM record carries AlignmentBuffer's "!!!" (AlignmentBuffer.cpp:109)
+				ngm::build_cigar_affine(&h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), q, &ao);
+				memcpy(ao.md, "!!!", 4);
+			} else {
+				ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), &ao);
+				if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
+			}
 			h.identity = ao.identity; h.nm = ao.nm; h.qstart = ao.qstart; h.qend = ao.qend;
 			// AlignmentBuffer.cpp:129 then SequenceProvider.convert (AlignmentBuffer.cpp:173)
 			const uint64_t final_loc = (uint64_t) a_loc[j] + (uint64_t) (int64_t) ao.position_offset - (uint64_t) (c >> 1);

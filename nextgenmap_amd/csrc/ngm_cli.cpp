@@ -75,7 +75,7 @@ private:
 struct Opts {
 	std::string ref, qry, out;
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
-	int match = 10, mismatch = 15, gap_read = 20, gap_ref = 20, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
+	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
 	float sensitivity = -1.f, kmer_min = 0.f, min_identity = 0.65f, min_residues = 0.5f;
 	int batch = 1 << 20;
@@ -89,7 +89,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -104,7 +104,7 @@ Opts parse(int argc, char **argv) {
 		{"device", required_argument, 0, DEVICE}, {"skip-save", no_argument, 0, SKIPSAVE}, {"batch-size", required_argument, 0, BATCH},
 		{"kernel-variant", required_argument, 0, VARIANT},
 		{"qry1", required_argument, 0, UNSUPPORTED}, {"qry2", required_argument, 0, UNSUPPORTED}, {"paired", no_argument, 0, UNSUPPORTED},
-		{"affine", no_argument, 0, UNSUPPORTED}, {"bam", no_argument, 0, UNSUPPORTED}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
+		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, UNSUPPORTED}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
 		{"slam-seq", required_argument, 0, UNSUPPORTED}, {"topn", required_argument, 0, UNSUPPORTED}, {"strata", no_argument, 0, UNSUPPORTED},
 		{"argos", no_argument, 0, UNSUPPORTED}, {"vcf", required_argument, 0, UNSUPPORTED}, {"config", required_argument, 0, UNSUPPORTED},
 		{0, 0, 0, 0}};
@@ -132,6 +132,8 @@ Opts parse(int argc, char **argv) {
 		case MMP: o.mismatch = atoi(optarg); break;
 		case GRP: o.gap_read = atoi(optarg); break;
 		case GFP: o.gap_ref = atoi(optarg); break;
+		case AFFINE: o.affine = 1; break;
+		case GEP: o.gap_extend = atoi(optarg); break;
 		case MAXCMRS: o.max_cmrs = atoi(optarg); break;
 		case NOUNAL: o.no_unal = 1; break;
 		case NOPROG: case SKIPSAVE: break;
@@ -150,6 +152,10 @@ Opts parse(int argc, char **argv) {
 		}
 	}
 	if (o.ref.empty()) die("no reference given (-r/--ref)");
+	// scoring defaults depend on the personality (Config.cpp:433-446)
+	if (o.gap_read < 0) o.gap_read = o.affine ? 33 : 20;
+	if (o.gap_ref < 0) o.gap_ref = o.affine ? 33 : 20;
+	if (o.gap_extend < 0) o.gap_extend = o.affine ? 3 : 5;
 	return o;
 }
 
@@ -208,6 +214,7 @@ int main(int argc, char **argv) {
 	mp.gap_read_penalty = o.gap_read; mp.gap_ref_penalty = o.gap_ref; mp.mode = o.mode; mp.variant = o.variant;
 	mp.sensitivity = 0.5f; mp.kmer_min = o.kmer_min; mp.max_cmrs = o.max_cmrs; mp.max_kfreq = o.max_kfreq;
 	mp.hard_clip = o.hard_clip; mp.silent_clip = o.silent_clip;
+	mp.personality = o.affine ? NGM_PERSONALITY_AFFINE : NGM_PERSONALITY_LINEAR; mp.gap_extend_penalty = o.gap_extend;
 
 	// ---- sensitivity (ReadProvider.cpp:310-385) -----------------------------------------------------------
 	float sens = 0.5f;

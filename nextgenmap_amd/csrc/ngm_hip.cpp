@@ -16,6 +16,7 @@
 #define NGM_ENGINE_KERNELS
 #include "engine_internal.h"
 #include "align_device.h"
+#include "affine_device.h"
 #include "cigar_md.h"
 
 namespace {
@@ -71,6 +72,15 @@ align_kernel_t find_align_kernel(int c, bool endfree) {
 	return nullptr;
 }
 
+typedef void (*affine_kernel_t)(const uint32_t *, const uint16_t *, const uint16_t *, float *, uint32_t *, int32_t *, int, int, int, int, ngm::AffConst);
+affine_kernel_t find_affine_kernel(int c, bool endfree, bool align) {
+#define X(C) if (c == C) return endfree ? (align ? ngm::sw_affine_kernel<C + 1, true, true> : ngm::sw_affine_kernel<C + 1, true, false>) \
+		: (align ? ngm::sw_affine_kernel<C + 1, false, true> : ngm::sw_affine_kernel<C + 1, false, false>);
+	NGM_CORRIDORS(X)
+#undef X
+	return nullptr;
+}
+
 int n_blocks_of(int n) { return (n + ngm::kSlots - 1) / ngm::kSlots; }
 
 }  // namespace
@@ -87,6 +97,13 @@ int engine_reserve(ngm_hip_ctx *ctx, int n) {
 
 int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipStream_t st) {
 	const int nb = n_blocks_of(n);
+	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
+		affine_kernel_t ka = find_affine_kernel(ctx->c, (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END, false);
+		hipLaunchKernelGGL(ka, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, d_scores,
+				(uint32_t *) nullptr, (int32_t *) nullptr, n, nb, ctx->RW, ctx->q, ctx->KA);
+		HIP_TRY(ctx, hipGetLastError());
+		return 0;
+	}
 	score_kernel_t k = find_score_kernel(ctx->c, (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END);
 	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, d_scores, n, nb,
 			ctx->RW, ctx->K);
@@ -97,6 +114,19 @@ int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipS
 int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, uint16_t *d_runs, int run_stride, hipStream_t st) {
 	const int am = mode & NGM_MODE_ALIGN_MASK;
 	const int nb = n_blocks_of(n);
+	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
+		const int CP = ctx->c + 1, ADW = ngm::aff_dir_words(CP);
+		if (ctx->dirs.reserve((size_t) nb * ctx->q * ADW * ngm::kSlots)) { set_error(ctx, "out of device memory for the trace matrix"); return -12; }
+		affine_kernel_t ka = find_affine_kernel(ctx->c, am == NGM_MODE_END_TO_END, true);
+		hipLaunchKernelGGL(ka, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, (float *) nullptr,
+				ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->KA);
+		HIP_TRY(ctx, hipGetLastError());
+		if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+		hipLaunchKernelGGL(ngm::affine_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, d_records, d_runs, n,
+				ctx->q, CP, run_stride);
+		HIP_TRY(ctx, hipGetLastError());
+		return 0;
+	}
 	const int DW = ngm::dir_words(ctx->c);
 	if (ctx->dirs.reserve((size_t) nb * ctx->q * DW * ngm::kSlots)) { set_error(ctx, "out of device memory for the direction matrix"); return -12; }
 	align_kernel_t k = find_align_kernel(ctx->c, am == NGM_MODE_END_TO_END);
@@ -123,7 +153,8 @@ int launch_pack(ngm_hip_ctx *ctx, int n, const void *d_ref, const void *d_qry, h
 	const int nb = n_blocks_of(n);
 	const size_t lds = (size_t) ngm::kSlots * (ctx->rl + ctx->q);
 	hipLaunchKernelGGL(ngm::pack_pairs_kernel, dim3(nb), dim3(256), lds, st, (const uint8_t *) d_ref,
-			(const uint8_t *) d_qry, n, ctx->q, ctx->rl, ctx->RW, ctx->FW, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p);
+			(const uint8_t *) d_qry, n, ctx->q, ctx->rl, ctx->RW, ctx->FW, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p,
+			ctx->prm.personality == NGM_PERSONALITY_AFFINE ? 1 : 0);
 	HIP_TRY(ctx, hipGetLastError());
 	return 0;
 }
@@ -147,6 +178,8 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 		set_error(nullptr, "ngm_hip_create: scores must be positive integers (match %d mismatch %d gap_read %d gap_ref %d)", p->match_bonus, p->mismatch_penalty, p->gap_read_penalty, p->gap_ref_penalty);
 		return nullptr;
 	}
+	if (p->personality != NGM_PERSONALITY_LINEAR && p->personality != NGM_PERSONALITY_AFFINE) { set_error(nullptr, "ngm_hip_create: unknown personality %d", p->personality); return nullptr; }
+	if (p->personality == NGM_PERSONALITY_AFFINE && p->gap_extend_penalty <= 0) { set_error(nullptr, "ngm_hip_create: gap_extend_penalty must be a positive integer"); return nullptr; }
 	if (p->match_bonus + p->mismatch_penalty > 255) { set_error(nullptr, "ngm_hip_create: match_bonus + mismatch_penalty must be <= 255"); return nullptr; }
 	if (!find_score_kernel(p->corridor, false)) {
 		set_error(nullptr, "ngm_hip_create: no kernel compiled for corridor %d (built: 8 12 19 20 27 42 80)", p->corridor);
@@ -163,7 +196,8 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 	ctx->c = p->corridor;
 	ctx->rl = ctx->q + ctx->c;
 	ctx->RW = ngm::read_words(ctx->q);
-	ctx->FW = ngm::ref_words(ctx->q, ctx->c);
+	// the affine band has corridor + 1 diagonals (lDiag = 0 .. uDiag = corridor, EndToEndAffine.h:40-41)
+	ctx->FW = ngm::ref_words(ctx->q, p->personality == NGM_PERSONALITY_AFFINE ? ctx->c + 1 : ctx->c);
 	ctx->max_batch = p->max_batch > 0 ? p->max_batch : (1 << 20);
 	const int match = p->match_bonus, mismatch = -p->mismatch_penalty, gap_read = -p->gap_read_penalty, gap_ref = -p->gap_ref_penalty;
 	ctx->K.tM = match - mismatch;
@@ -172,6 +206,13 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 	ctx->K.gu = gap_read - mismatch;
 	ctx->K.gap_read = gap_read;
 	ctx->K.variant = p->variant;
+	// Score<float, Simple>(match, -mismatch, -gap_extend, -gap_read): extend = gap_extend, open = gap_read (EndToEndAffine.h:37)
+	ctx->KA.tM = match - mismatch;
+	ctx->KA.tZ = -mismatch;
+	ctx->KA.open = gap_read;
+	ctx->KA.ext = -p->gap_extend_penalty;
+	ctx->KA.vopen = gap_read - mismatch;
+	ctx->KA.vext = -p->gap_extend_penalty - mismatch;
 	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "ngm_hip_create: hipStreamCreate failed"); delete ctx; return nullptr; }
 	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) { set_error(nullptr, "ngm_hip_create: hipEventCreate failed"); ngm_hip_destroy(ctx); return nullptr; }
 	// the pack kernel stages 64 raw pairs in LDS
@@ -312,6 +353,11 @@ int ngm_hip_batch_align(ngm_hip_ctx *ctx, int mode, int n, const char *const *re
 	cp.variant = ctx->prm.variant;
 	cp.hard_clip = ctx->prm.hard_clip;
 	cp.silent_clip = ctx->prm.silent_clip;
+	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
+		for (int i = 0; i < n; ++i)
+			ngm::build_cigar_affine(ctx->h_records.p + (size_t) i * 8, ctx->h_runs.p + (size_t) i * rs, ref[i], qry[i], ctx->q, &out[i]);
+		return n;
+	}
 	for (int i = 0; i < n; ++i) {
 		ngm::build_cigar_md(cp, ctx->h_records.p + (size_t) i * 8, ctx->h_runs.p + (size_t) i * rs, ref[i], qry[i], &out[i]);
 	}

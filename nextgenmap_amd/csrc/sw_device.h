@@ -95,10 +95,11 @@ __device__ __forceinline__ uint32_t pack8(const uint32_t k[8]) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restrict__ ref,
 		const uint8_t *__restrict__ qry, int n, int q, int rl, int RW, int FW,
-		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows) {
+		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows, int cstr_ref) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ int s_first_nul[kSlots];
 	__shared__ int s_rows[kSlots];
+	__shared__ int s_ref_nul[kSlots];
 	__shared__ int s_blk_rows;
 	__shared__ uint8_t s_trans[256];
 	uint8_t *lref = lds;
@@ -107,9 +108,10 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restri
 	const int blk = blockIdx.x;
 	const int p0 = blk * kSlots;
 	const int np = min(kSlots, n - p0);
-	if (tid < kSlots) { s_first_nul[tid] = q; s_rows[tid] = 0; }
+	if (tid < kSlots) { s_first_nul[tid] = q; s_rows[tid] = 0; s_ref_nul[tid] = rl; }
 	if (tid == 0) s_blk_rows = 0;
-	s_trans[tid] = (uint8_t) sym_class((uint32_t) tid);
+	// the affine personality compares characters (SeqAn): lower case never equals NextGenMap's upper-case alphabet
+	s_trans[tid] = (uint8_t) ((cstr_ref && tid >= 'a' && tid <= 'z') ? 4u : sym_class((uint32_t) tid));
 
 	// phase 1: coalesced copy of the block's rows into LDS (same linear layout), zero fill the tail
 	{
@@ -139,6 +141,15 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restri
 
 	// phase 2: lane = pair slot, four waves split the dwords; stores are 256-byte coalesced
 	const int slot = tid & 63, part = tid >> 6;
+	if (cstr_ref) {
+		// the affine personality reads the window as a C string (TSequence(refSeqList[i]), EndToEndAffine.cpp:16):
+		// nothing after the first NUL exists
+		const uint8_t *row = lref + slot * rl;
+		int fn = rl;
+		for (int i = part; i < rl; i += 4) if (row[i] == 0) { fn = i; break; }
+		atomicMin(&s_ref_nul[slot], fn);
+		__syncthreads();
+	}
 	uint32_t *ob = out + (size_t) blk * (RW + FW) * kSlots + slot;
 	{
 		const uint8_t *row = lqry + slot * q;
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restri
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				const int i = m * 8 + j;
-				k[j] = s_trans[(i < rl) ? row[i] : 0u];
+				k[j] = s_trans[(i < s_ref_nul[slot]) ? row[i] : 0u];
 			}
 			ob[(size_t) (RW + m) * kSlots] = pack8(k);
 		}

@@ -13,6 +13,9 @@ MODE_LOCAL = 0
 MODE_END_TO_END = 1
 VARIANT_OCL_GPU = 0
 VARIANT_OCL_CPU = 1
+PERSONALITY_LINEAR = 0   # the OpenCL plugin (default)
+PERSONALITY_AFFINE = 1   # `ngm --affine`: EndToEndAffine over SeqAn's banded Gotoh alignment
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -25,7 +28,8 @@ class Params(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("qry_max_len", C.c_int), ("corridor", C.c_int),
                 ("match_bonus", C.c_int), ("mismatch_penalty", C.c_int), ("gap_read_penalty", C.c_int),
                 ("gap_ref_penalty", C.c_int), ("variant", C.c_int), ("hard_clip", C.c_int),
-                ("silent_clip", C.c_int), ("max_batch", C.c_int)]
+                ("silent_clip", C.c_int), ("max_batch", C.c_int), ("personality", C.c_int),
+                ("gap_extend_penalty", C.c_int)]
 
 
 class AlignOut(C.Structure):
@@ -88,10 +92,13 @@ class Engine:
     """One IAlignment instance (NGM creates one per CS thread, src/CS.cpp:455-461)."""
 
     def __init__(self, qry_max_len, corridor, match=10, mismatch=15, gap_read=20, gap_ref=20, device=0,
-                 variant=VARIANT_OCL_GPU, hard_clip=0, silent_clip=0, max_batch=0):
+                 variant=VARIANT_OCL_GPU, hard_clip=0, silent_clip=0, max_batch=0, personality=PERSONALITY_LINEAR,
+                 gap_extend=0):
         self.lib = load_library()
         self.q, self.c = int(qry_max_len), int(corridor)
-        p = Params(1, self.q, self.c, match, mismatch, gap_read, gap_ref, variant, hard_clip, silent_clip, max_batch)
+        self.personality = int(personality)
+        p = Params(ABI_VERSION, self.q, self.c, match, mismatch, gap_read, gap_ref, variant, hard_clip, silent_clip, max_batch,
+                   self.personality, gap_extend)
         self.h = self.lib.ngm_hip_create(device, C.byref(p))
         if not self.h:
             raise NgmHipError(self.lib.ngm_hip_last_error(None).decode())

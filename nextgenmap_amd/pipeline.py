@@ -15,7 +15,7 @@ class MapperParams(C.Structure):
     _fields_ = [("qry_max_len", C.c_int), ("corridor", C.c_int), ("match_bonus", C.c_int), ("mismatch_penalty", C.c_int),
                 ("gap_read_penalty", C.c_int), ("gap_ref_penalty", C.c_int), ("mode", C.c_int), ("variant", C.c_int),
                 ("sensitivity", C.c_float), ("kmer_min", C.c_float), ("max_cmrs", C.c_int), ("max_kfreq", C.c_int),
-                ("hard_clip", C.c_int), ("silent_clip", C.c_int)]
+                ("hard_clip", C.c_int), ("silent_clip", C.c_int), ("personality", C.c_int), ("gap_extend_penalty", C.c_int)]
 
 
 HIT_DTYPE = np.dtype([("mapped", "i4"), ("contig", "i4"), ("pos", "u8"), ("reverse", "i4"), ("mapq", "i4"),
@@ -160,12 +160,13 @@ class Mapper:
     """CS -> gather -> score -> top-1 selection -> align for single-end reads (one CS thread's worth of NGM)."""
 
     def __init__(self, ref, qry_max_len, corridor, sensitivity=0.5, match=10, mismatch=15, gap_read=20, gap_ref=20,
-                 mode=0, variant=0, kmer_min=0.0, max_cmrs=2 ** 31 - 1, max_kfreq=0, hard_clip=0, silent_clip=0):
+                 mode=0, variant=0, kmer_min=0.0, max_cmrs=2 ** 31 - 1, max_kfreq=0, hard_clip=0, silent_clip=0, personality=0,
+                 gap_extend=0):
         self.lib = _lib()
         self.ref = ref
         self.q, self.c = qry_max_len, corridor
         p = MapperParams(qry_max_len, corridor, match, mismatch, gap_read, gap_ref, mode, variant, sensitivity, kmer_min,
-                         max_cmrs, max_kfreq, hard_clip, silent_clip)
+                         max_cmrs, max_kfreq, hard_clip, silent_clip, personality, gap_extend)
         self.h = self.lib.ngm_mapper_create(ref.h, C.byref(p))
         if not self.h:
             raise _err()

@@ -4,13 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import nextgenmap_amd as N
 from pairgen import make_pairs
+AFF = int(os.environ.get('AFFINE','0'))
+kw = dict(personality=1, gap_read=33, gap_ref=33, gap_extend=3) if AFF else {}
 for (q,c,rl) in [(102,20,100),(152,27,150),(252,42,250)]:
     n = 1<<20
     br, bq = make_pairs(8192, q, c, seed=1, read_len=rl, mix=(0.7,0.3,0.0))
     idx = np.random.default_rng(0).integers(0,8192,n)
     ref = torch.from_numpy(br[idx]).cuda(); qry = torch.from_numpy(bq[idx]).cuda()
     out = torch.empty(n, dtype=torch.float32, device="cuda")
-    eng = N.Engine(q,c,max_batch=n); eng.set_profiling(True)
+    eng = N.Engine(q,c,max_batch=n,**kw); eng.set_profiling(True)
     st = torch.cuda.current_stream().cuda_stream
     for mode in (0,1):
         for it in range(3):
