@@ -4,8 +4,11 @@
 One "step" = one pass of the hot path over one batch of R synthetic 150 bp reads whose bytes are already
 resident in HBM: candidate search over the HBM-resident k-mer index of a synthetic GRCh38-sized genome
 (seeded, with repeat families), device window gather, BatchScore over every candidate, top-1 selection +
-MAPQ, BatchAlign (DP + traceback) of the winners, CIGAR/MD/position on the host.  Shape: qry_max_len 152,
-corridor 27, linear gaps 10/15/20/20, local mode, k 13 / kmer_skip 2 / bin_size 2, sensitivity 0.5 pinned.
+MAPQ, BatchAlign (DP + traceback) of the winners, CIGAR/position on the host.  Shape: qry_max_len 152,
+corridor 27, local mode, k 13 / kmer_skip 2 / bin_size 2, sensitivity 0.5 pinned.  Scoring personality:
+--personality affine (default; `ngm --affine`, 10/15/33/3, the personality BASELINE.json's north star names and
+the only one the reference program can run on this host, so cpu_baseline computes the SAME alignments and the
+bench cross-checks its SAM records against ours) or linear (NGM's default OpenCL personality, 10/15/20/20).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--genome-mbp G] [--reads-per-step R]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -95,8 +98,21 @@ def make_reads(contigs, n, seed):
     return rows, ci, pos
 
 
-def cpu_baseline_reference(ref, rows, budget_reads, workdir):
-    """NextGenMap itself (ngm-core --affine, host cores) on the first `budget_reads` reads vs the same genome."""
+def _sam_records(path):
+    recs = {}
+    for line in open(path):
+        if line.startswith("@"):
+            continue
+        f = line.split("\t")
+        tags = {t[:2]: t[5:].strip() for t in f[11:]}
+        recs[int(f[0][1:])] = (int(f[1]), f[2], int(f[3]), int(f[4]), f[5], tags.get("AS"), tags.get("NM"))
+    return recs
+
+
+def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None):
+    """NextGenMap itself (ngm-core --affine, host cores) on the first `budget_reads` reads vs the same genome.
+    ours = (hits, cigar rows, contig names) of the GPU path in the affine personality: the reference's SAM records
+    are then compared with them (flag, contig, position, MAPQ, CIGAR, AS, NM)."""
     import ref_files as RF
     cores = os.cpu_count() or 1
     fa = os.path.join(workdir, "bench_ref.fa")
@@ -128,7 +144,23 @@ def cpu_baseline_reference(ref, rows, budget_reads, workdir):
     t_load = run(one)   # index/genome load + start-up
     t_all = run(fq)
     t_map = max(t_all - t_load, 1e-3)
-    return {"value": n / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
+    parity = None
+    if ours is not None:
+        hits, cig, names = ours
+        recs = _sam_records(os.path.join(workdir, "ref_out.sam"))
+        same = same_place = cmp = 0
+        for i, (flag, rname, pos, mapq, cigar, a_s, nm) in recs.items():
+            h = hits[i]
+            if (flag & 4) or not h["mapped"]:
+                continue  # the writer's identity / residue filter is not part of the timed path
+            cmp += 1
+            mine = (16 if h["reverse"] else 0, names[h["contig"]], int(h["pos"]) + 1, int(h["mapq"]),
+                    bytes(cig[i]).split(b"\0", 1)[0].decode(), str(int(h["score"])), str(int(h["nm"])))
+            same += mine == (flag & 16, rname, pos, mapq, cigar, a_s, nm)
+            same_place += mine[:3] == (flag & 16, rname, pos)
+        parity = {"reads_compared": cmp, "identical_records": same, "same_position": same_place,
+                  "note": "records differing are equal-score repeat copies visited in a different order"}
+    return {"parity_vs_reference_sam": parity, "value": n / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
             "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d on the first %d reads of the step vs the same genome (index "
                       "loaded from cache files written by this library): %.1fs total minus %.1fs index load/start-up measured "
                       "with a 1-read run" % (threads, n, t_all, t_load),
@@ -163,6 +195,7 @@ def main():
     ap.add_argument("--reads-per-step", type=int, default=1 << 20, help="reads per GPU per step")
     ap.add_argument("--cpu-sample-reads", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
     args = ap.parse_args()
 
     import torch
@@ -189,7 +222,12 @@ def main():
     t_index = time.perf_counter() - t0
     rows, truth_c, truth_p = make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank)  # config #2's seed, one shard per rank
     d_rows = torch.from_numpy(rows).to(dev)
-    mp = Mapper(ref, Q, C, sensitivity=0.5)
+    affine = args.personality == "affine"
+    if affine:
+        mp = Mapper(ref, Q, C, sensitivity=0.5, gap_read=33, gap_ref=33, gap_extend=3, personality=1)
+    else:
+        mp = Mapper(ref, Q, C, sensitivity=0.5)
+    band = C + 1 if affine else C  # SeqAn's band has diagonals 0..corridor
     out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
 
     def step():
@@ -229,19 +267,25 @@ def main():
 
     if rank == 0:
         value = R * world * args.steps / elapsed
-        score_cells = n_cand * READ_LEN * C
-        align_cells = int(mapped.sum()) * READ_LEN * C
+        score_cells = n_cand * READ_LEN * band
+        align_cells = int(mapped.sum()) * READ_LEN * band
         b_cs = 20 * kmers + 4 * hits_voted + 16 * n_cand
         achieved = b_cs / (kms[0] * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json, keyed
+        # by kernel name and grid size = 64 threads per read; collected with this default workload)
         traffic = None
-        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-            if fn.endswith("_pmc_traffic.json"):
-                try:
-                    traffic = json.load(open(os.path.join(ROOT, "profiles", fn))).get("cs_kernel|reads=%d|genome_mbp=%d" % (R, int(args.genome_mbp)))
-                except Exception:
-                    traffic = None
-                if traffic is not None:
-                    break
+        if int(args.genome_mbp) == 3100:
+            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if fn.endswith("_pmc_traffic.json"):
+                    try:
+                        tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    except Exception:
+                        continue
+                    for k, v in tj.items():
+                        if k.startswith("ngm::cs_kernel<0>") and k.endswith("|grid=%d" % (R * 64)):
+                            traffic = v
+                    if traffic is not None:
+                        break
         line = {
             "metric": "mapped reads/sec + SW Gcells/sec, 150bp vs GRCh38, at 1/2/4/8 MI355X",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -249,9 +293,9 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "%d x 150bp SE synthetic reads per GPU per step vs a synthetic %.0f Mbp genome (24 contigs, repeat "
                                    "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=0.5) + "
-                                   "score + top-1/MAPQ + align with traceback + CIGAR/MD; reads resident in HBM; single-end (the "
+                                   "score + top-1/MAPQ + align with traceback + CIGAR; reads resident in HBM; single-end (the "
                                    "paired-end selection of config #2 is not built yet)" % (R, args.genome_mbp),
-                       "qry_max_len": Q, "corridor": C, "scoring": "linear 10/15/20/20 local", "reads_per_step_per_gpu": R,
+                       "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R,
                        "parallelism": "reads sharded x%d, genome+index replicated per GPU" % world},
             "sw_gcells_per_s": {"score_kernel": score_cells / (kms[2] * 1e-3) / 1e9 if kms[2] > 0 else None,
                                 "align_kernel": align_cells / (kms[5] * 1e-3) / 1e9 if kms[5] > 0 else None},
@@ -273,7 +317,8 @@ def main():
                 if not RF.have_reference_binary():
                     raise RuntimeError("oracle/_ref/ngm/ngm-core not built")
                 with tempfile.TemporaryDirectory() as wd:
-                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, args.cpu_sample_reads, wd)
+                    ours = (hits, out[1], [c[0] for c in ref.contigs]) if affine else None
+                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, args.cpu_sample_reads, wd, ours)
             except Exception as e:  # the port of the score stage only
                 line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
                 line["cpu_baseline"]["note"] = "reference program unavailable: %s" % str(e)[:200]

@@ -137,36 +137,19 @@ __device__ __forceinline__ void cs_for_each_hit(const uint32_t *__restrict__ pos
 	}
 }
 
-template <int MODE>
-__global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	__shared__ uint32_t s_flags[2];  // [0] distinct bins in the small table (FAST), [1] abort
-	const int lane = threadIdx.x;
-	const int item = blockIdx.x;
-	const int read = A.read_list ? (int) A.read_list[item] : item;
-	const int k = A.k;
-	uint32_t *l_start = cs_lds;                        // [lists_cap]
-	uint32_t *l_pref = cs_lds + A.lists_cap;           // [lists_cap + 1]
-	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);  // [q rounded up to 4]
-	const int code_words = (A.q + 3) / 4;
-	uint32_t *plane1 = (uint32_t *) l_code + code_words;  // FAST only
-	const uint32_t plane_words = (MODE == kCsFast) ? (1u << (A.log2_bits - 5)) : 0u;
-	uint32_t *plane2 = plane1 + plane_words;
-	uint32_t *t_keys, *t_votes;
-	int log2_slots;
-	if (MODE == kCsExactGlobal) {
-		log2_slots = (int) A.ovf_log2[item];
-		t_keys = A.gtable_keys + A.ovf_table_off[item];
-		t_votes = A.gtable_votes + A.ovf_table_off[item];
-	} else {
-		log2_slots = A.log2_slots;
-		t_keys = plane2 + plane_words;
-		t_votes = t_keys + (1u << log2_slots);
-	}
-	uint32_t n_slots = 1u << log2_slots;
-	if (lane < 2) s_flags[lane] = 0;
+// ---- shared phases -------------------------------------------------------------------------------------------
+struct CsRead {
+	int L;            // MappedRead::length
+	int n_lists;      // 2 * k-mers
+	uint32_t H;       // hits of all lists
+	uint32_t n_valid; // k-mers looked up
+};
 
-	// ---- 1. read -> 2-bit codes (A0 C1 T2 G3, CSstatic.cpp:20-22), N = 4, past the end = 255 ----------------
+// 1. read -> 2-bit codes (A0 C1 T2 G3, CSstatic.cpp:20-22), N = 4, past the end = 255;
+// 2. k-mers and their two position lists (lane = k-mer, lists 2p = forward, 2p+1 = reverse complement).
+// The index reads of up to four 64-k-mer rounds are issued before any of them is consumed.
+__device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, uint32_t *l_pref, uint8_t *l_code) {
+	const int k = A.k;
 	const uint8_t *rp = A.reads + (size_t) read * A.q;
 	int first_nul = A.q;
 	for (int i = lane; i < A.q; i += 64) {
@@ -177,117 +160,75 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 		else code = (uint8_t) ((ch >> 1) & 3u);
 		l_code[i] = code;
 	}
-	const int L = wave_reduce_min(first_nul);  // MappedRead::length
+	CsRead R;
+	R.L = wave_reduce_min(first_nul);
 	__syncthreads();
-
-	// ---- 2. k-mers and their two position lists (lane = k-mer, lists 2p = forward, 2p+1 = reverse complement) --
+	const int L = R.L;
 	const int n_kmers = L - k + 1;
-	const int n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
+	R.n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
 	uint32_t carry = 0, n_valid = 0;
-	for (int base = 0; base < n_kmers; base += 64) {
-		const int p = base + lane;
-		uint32_t cf = 0, cr = 0, sf = 0, sr = 0;
-		bool counted = false;
-		if (p < n_kmers) {
-			bool valid = true;
-			uint32_t kmer = 0;
-			for (int j = 0; j < k; ++j) {
-				const uint32_t c = l_code[p + j];
-				valid = valid && (c < 4);
-				kmer = (kmer << 2) | (c & 3u);
+	constexpr int RB = 4;
+	for (int base = 0; base < n_kmers; base += 64 * RB) {
+		uint2 ef[RB], er[RB];
+		bool valid[RB];
+#pragma unroll
+		for (int r = 0; r < RB; ++r) {
+			const int p = base + r * 64 + lane;
+			valid[r] = false;
+			ef[r] = make_uint2(0, 0); er[r] = make_uint2(0, 0);
+			if (p < n_kmers) {
+				bool v = true;
+				uint32_t kmer = 0;
+				for (int j = 0; j < k; ++j) {
+					const uint32_t c = l_code[p + j];
+					v = v && (c < 4);
+					kmer = (kmer << 2) | (c & 3u);
+				}
+				// CSstatic.cpp:30-41: a k-mer that starts right after a restart-position N run and ends exactly at
+				// the read end is never visited
+				if (v && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) v = false;
+				valid[r] = v;
+				if (v) { ef[r] = A.index[kmer]; er[r] = A.index[cs_revcomp(kmer, k)]; }
 			}
-			// CSstatic.cpp:30-41: a k-mer that starts right after a restart-position N run and ends exactly at
-			// the read end is never visited
-			if (valid && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) valid = false;
-			if (valid) {
-				const uint2 ef = A.index[kmer];
-				const uint2 er = A.index[cs_revcomp(kmer, k)];
-				if ((int) (ef.y + er.y) < A.max_kfreq) { cf = ef.y; sf = ef.x; cr = er.y; sr = er.x; }  // CS.cpp:122
+		}
+#pragma unroll
+		for (int r = 0; r < RB; ++r) {
+			if (base + r * 64 >= n_kmers) break;
+			const int p = base + r * 64 + lane;
+			uint32_t cf = 0, cr = 0, sf = 0, sr = 0;
+			if (valid[r] && (int) (ef[r].y + er[r].y) < A.max_kfreq) { cf = ef[r].y; sf = ef[r].x; cr = er[r].y; sr = er[r].x; }  // CS.cpp:122
+			n_valid += __popcll(__ballot(valid[r]));
+			const uint32_t both = cf + cr;
+			const uint32_t incl = wave_inclusive_scan(both, lane);
+			if (p < n_kmers) {
+				const uint32_t b0 = carry + incl - both;
+				l_start[2 * p] = sf; l_pref[2 * p] = b0;
+				l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = b0 + cf;
 			}
-			counted = valid;
+			carry += __shfl(incl, 63);
 		}
-		n_valid += __popcll(__ballot(counted));
-		const uint32_t both = cf + cr;
-		const uint32_t incl = wave_inclusive_scan(both, lane);
-		if (p < n_kmers) {
-			const uint32_t b0 = carry + incl - both;
-			l_start[2 * p] = sf; l_pref[2 * p] = b0;
-			l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = b0 + cf;
-		}
-		carry += __shfl(incl, 63);
 	}
-	if (lane == 0) l_pref[n_lists] = carry;
-	const uint32_t H = carry;
+	if (lane == 0) l_pref[R.n_lists] = carry;
+	R.H = carry;
+	R.n_valid = n_valid;
+	return R;
+}
 
-	auto enqueue = [&]() {  // hand the read to the next, more general path
-		if (lane == 0) {
-			const uint32_t slot = atomicAdd(&A.status[1], 1u);
-			A.ovf_read[slot] = (uint32_t) read;
-			A.ovf_hits[slot] = H;
-			A.read_len[read] = (uint16_t) L;
-		}
-	};
-	if (MODE != kCsExactGlobal && H > A.hit_cap) { enqueue(); return; }
-
-	// ---- 3. votes ---------------------------------------------------------------------------------------
-	auto bin_of = [&](uint32_t pos, int li) -> uint32_t {
-		const int p = li >> 1;
-		const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
-		return (pos - correction) >> A.bin_shift;
-	};
-	if (MODE == kCsExactLds) {
-		// the table in use is sized to this read's hit count (power of two >= 2H): clearing and scanning it cost
-		// what the read needs, not what the allocation allows
-		int need = 8;
-		while ((1u << need) < 2u * H && need < log2_slots) ++need;
-		log2_slots = need;
-		n_slots = 1u << log2_slots;
-		t_votes = t_keys + n_slots;
+__device__ __forceinline__ void cs_enqueue(const CsArgs &A, int read, int lane, const CsRead &R) {  // hand the read to the next path
+	if (lane == 0) {
+		const uint32_t slot = atomicAdd(&A.status[1], 1u);
+		A.ovf_read[slot] = (uint32_t) read;
+		A.ovf_hits[slot] = R.H;
+		A.read_len[read] = (uint16_t) R.L;
 	}
-	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
-	if (MODE == kCsFast) for (uint32_t s = lane; s < 2 * plane_words; s += 64) plane1[s] = 0;
-	__syncthreads();
-	if (MODE == kCsExactGlobal) __threadfence_block();
+}
 
-	auto insert = [&](uint32_t bin, bool rev) -> bool {
-		uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
-		for (;;) {
-			const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
-			if (prev == bin) break;
-			if (prev == 0xFFFFFFFFu) {
-				if (MODE == kCsFast && atomicAdd(&s_flags[0], 1u) > (n_slots * 3u) / 4u) return false;
-				break;
-			}
-			slot = (slot + 1) & (n_slots - 1);
-		}
-		atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
-		return true;
-	};
-
-	if (MODE == kCsFast) {
-		const int sh = 32 - A.log2_bits;
-		cs_for_each_hit(A.positions, l_start, l_pref, n_lists, H, lane, [&](uint32_t pos, int li) {
-			const uint32_t b = (bin_of(pos, li) * 0x9E3779B1u) >> sh;
-			const uint32_t m = 1u << (b & 31);
-			const uint32_t old = atomicOr(&plane1[b >> 5], m);
-			if (old & m) atomicOr(&plane2[b >> 5], m);
-		});
-		__syncthreads();
-		cs_for_each_hit(A.positions, l_start, l_pref, n_lists, H, lane, [&](uint32_t pos, int li) {
-			const uint32_t bin = bin_of(pos, li);
-			const uint32_t b = (bin * 0x9E3779B1u) >> sh;
-			if ((plane2[b >> 5] >> (b & 31)) & 1u) {
-				if (!insert(bin, li & 1)) s_flags[1] = 1;
-			}
-		});
-	} else {
-		cs_for_each_hit(A.positions, l_start, l_pref, n_lists, H, lane, [&](uint32_t pos, int li) { insert(bin_of(pos, li), li & 1); });
-	}
-	__syncthreads();
-	if (MODE == kCsExactGlobal) __threadfence_block();
-	if (MODE == kCsFast && s_flags[1]) { enqueue(); return; }  // small table full: not provably exact
-
-	// ---- 4. threshold and candidates (CS.cpp:201-205, :263-313) -------------------------------------------
+// 4. threshold and candidates (CS.cpp:201-205, :263-313).  Returns false when the FAST path cannot certify the
+// result (final threshold <= 1 vote): the caller queues the read for the exact path.
+template <int MODE>
+__device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, const CsRead &R, const uint32_t *t_keys, const uint32_t *t_votes,
+		uint32_t n_slots) {
+	const uint32_t H = R.H;
 	int mx = 0, mxb = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) {
 		const uint32_t v = cs_tload<MODE>(&t_votes[s]);
@@ -301,8 +242,8 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	const float max_hit = (float) mx;
 	const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
 	// the filter dropped bins with a single vote: exact only if those cannot be candidates
-	if (MODE == kCsFast && H > 0 && !(thresh > 1.0f)) { enqueue(); return; }
-	if (lane == 0 && A.counters) { atomicAdd(&A.counters[0], (unsigned long long) n_valid); atomicAdd(&A.counters[1], (unsigned long long) H); }
+	if (MODE == kCsFast && H > 0 && !(thresh > 1.0f)) return false;
+	if (lane == 0 && A.counters) { atomicAdd(&A.counters[0], (unsigned long long) R.n_valid); atomicAdd(&A.counters[1], (unsigned long long) H); }
 	uint32_t count = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) {
 		if (cs_tload<MODE>(&t_keys[s]) != 0xFFFFFFFFu) {
@@ -321,10 +262,10 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 		A.cand_count[read] = total;
 		A.max_votes[read] = max_hit;
 		if (A.max_both) A.max_both[read] = (float) mxb;
-		A.read_len[read] = (uint16_t) L;
+		A.read_len[read] = (uint16_t) R.L;
 	}
 	base = __shfl((uint32_t) base, 0) | ((unsigned long long) __shfl((uint32_t) (base >> 32), 0) << 32);
-	if (total == 0 || base + total > A.out_capacity) return;
+	if (total == 0 || base + total > A.out_capacity) return true;
 	uint32_t w = (uint32_t) base + (incl - count);
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
 	for (uint32_t s = lane; s < n_slots; s += 64) {
@@ -337,6 +278,185 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 			if ((float) r >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = (r << 1) | 1u; ++w; }
 		}
 	}
+	return true;
+}
+
+// ---- FAST path ---------------------------------------------------------------------------------------------------
+// One sweep over the position lists with kCsFastHpl loads in flight per lane; the bins stay in registers
+// (kCsFastTrips x kCsFastHpl per lane, i.e. up to kCsFastTrips * 64 * kCsFastHpl hits per read), so the lists are
+// read from HBM exactly once.  Sweep 1: atomicOr into one "bin seen" bit plane; a hit that finds its bit already set
+// is a repeat and is inserted into the small exact table at once.  Sweep 2 (registers only): every hit that was the
+// first on its bit adds its vote if -- and only if -- its bin made it into the table.  A bin with >= 2 votes has all
+// but its first vote inserted in sweep 1 and the first one added in sweep 2: exact; bins with a single vote are
+// dropped (never candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
+constexpr int kCsFastHpl = 16;
+constexpr int kCsFastTrips = 6;
+constexpr uint32_t kCsFastMaxHits = (uint32_t) kCsFastTrips * 64u * kCsFastHpl;
+
+__global__ __launch_bounds__(64) void cs_fast_kernel(CsArgs A) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+	__shared__ uint32_t s_flags[2];  // [0] distinct bins in the small table, [1] abort
+	const int lane = threadIdx.x;
+	const int read = blockIdx.x;
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;
+	uint32_t *l_pref = cs_lds + A.lists_cap;
+	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);
+	uint32_t *plane = (uint32_t *) l_code + (A.q + 3) / 4;
+	const uint32_t plane_words = 1u << (A.log2_bits - 5);
+	uint32_t *t_keys = plane + plane_words;
+	const int log2_slots = A.log2_slots;
+	const uint32_t n_slots = 1u << log2_slots;
+	uint32_t *t_votes = t_keys + n_slots;
+	if (lane < 2) s_flags[lane] = 0;
+	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
+
+	const CsRead R = cs_prepare(A, read, lane, l_start, l_pref, l_code);
+	const uint32_t H = R.H;
+	const int L = R.L, n_lists = R.n_lists;
+	if (H > A.hit_cap || H > kCsFastMaxHits) { cs_enqueue(A, read, lane, R); return; }
+	__syncthreads();
+
+	const int sh = 32 - A.log2_bits;
+	const int hs = 32 - log2_slots;
+	constexpr int HPL = kCsFastHpl;
+	uint32_t bins[kCsFastTrips * HPL];  // bin | first-on-its-bit << 30 | reverse strand << 31
+#pragma unroll
+	for (int t = 0; t < kCsFastTrips; ++t) {
+		if ((uint32_t) t * 64u * HPL >= H) break;  // wave-uniform
+		const uint32_t h0 = (uint32_t) t * 64u * HPL + (uint32_t) lane * HPL;
+		int lo = 0, hi = n_lists;  // largest li with pref[li] <= h0
+		if (h0 < H) {
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (l_pref[mid] <= h0) lo = mid; else hi = mid;
+			}
+		}
+		uint32_t pos[HPL], cor[HPL];
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) {
+			const uint32_t h = h0 + j;
+			pos[j] = 0; cor[j] = 0;
+			if (h < H) {
+				while (l_pref[lo + 1] <= h) ++lo;
+				pos[j] = A.positions[l_start[lo] + (h - l_pref[lo])];
+				const int p = lo >> 1;
+				// diagonal of the hit (CS.cpp:140-142); bit 31 = reverse-complement list
+				cor[j] = (lo & 1) ? ((uint32_t) (L - (p + k)) | 0x80000000u) : (uint32_t) p;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) {
+			const uint32_t h = h0 + j;
+			uint32_t e = 0;
+			if (h < H) {
+				const uint32_t bin = (pos[j] - (cor[j] & 0x7FFFFFFFu)) >> A.bin_shift;
+				const uint32_t rev = cor[j] & 0x80000000u;
+				const uint32_t b = (bin * 0x9E3779B1u) >> sh;
+				const uint32_t m = 1u << (b & 31);
+				const uint32_t old = atomicOr(&plane[b >> 5], m);
+				e = (bin & 0x3FFFFFFFu) | rev;
+				if (old & m) {
+					uint32_t slot = ((bin & 0x3FFFFFFFu) * 2654435761u) >> hs;
+					for (;;) {
+						const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin & 0x3FFFFFFFu);
+						if (prev == (bin & 0x3FFFFFFFu)) break;
+						if (prev == 0xFFFFFFFFu) {
+							if (atomicAdd(&s_flags[0], 1u) > (n_slots * 3u) / 4u) s_flags[1] = 1;
+							break;
+						}
+						slot = (slot + 1) & (n_slots - 1);
+					}
+					atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
+				} else {
+					e |= 0x40000000u;
+				}
+			}
+			bins[t * HPL + j] = e;
+		}
+	}
+	__syncthreads();
+	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }  // small table full: not provably exact
+#pragma unroll
+	for (int t = 0; t < kCsFastTrips; ++t) {
+		if ((uint32_t) t * 64u * HPL >= H) break;
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) {
+			const uint32_t e = bins[t * HPL + j];
+			if (e & 0x40000000u) {  // first hit on its bit: counts only if the bin is in the table
+				const uint32_t bin = e & 0x3FFFFFFFu;
+				uint32_t slot = (bin * 2654435761u) >> hs;
+				for (;;) {
+					const uint32_t key = t_keys[slot];
+					if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); break; }
+					if (key == 0xFFFFFFFFu) break;
+					slot = (slot + 1) & (n_slots - 1);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (!cs_finish<kCsFast>(A, read, lane, R, t_keys, t_votes, n_slots)) cs_enqueue(A, read, lane, R);
+}
+
+// ---- EXACT paths: every hit goes into an open-addressing table (LDS, or global memory for very repetitive reads) --
+template <int MODE>
+__global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+	const int lane = threadIdx.x;
+	const int item = blockIdx.x;
+	const int read = A.read_list ? (int) A.read_list[item] : item;
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;                        // [lists_cap]
+	uint32_t *l_pref = cs_lds + A.lists_cap;           // [lists_cap + 1]
+	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);  // [q rounded up to 4]
+	uint32_t *t_keys, *t_votes;
+	int log2_slots;
+	if (MODE == kCsExactGlobal) {
+		log2_slots = (int) A.ovf_log2[item];
+		t_keys = A.gtable_keys + A.ovf_table_off[item];
+		t_votes = A.gtable_votes + A.ovf_table_off[item];
+	} else {
+		log2_slots = A.log2_slots;
+		t_keys = (uint32_t *) l_code + (A.q + 3) / 4;
+		t_votes = t_keys + (1u << log2_slots);
+	}
+	uint32_t n_slots = 1u << log2_slots;
+
+	const CsRead R = cs_prepare(A, read, lane, l_start, l_pref, l_code);
+	const uint32_t H = R.H;
+	const int L = R.L;
+	if (MODE != kCsExactGlobal && H > A.hit_cap) { cs_enqueue(A, read, lane, R); return; }
+
+	if (MODE == kCsExactLds) {
+		// the table in use is sized to this read's hit count (power of two >= 2H): clearing and scanning it cost
+		// what the read needs, not what the allocation allows
+		int need = 8;
+		while ((1u << need) < 2u * H && need < log2_slots) ++need;
+		log2_slots = need;
+		n_slots = 1u << log2_slots;
+		t_votes = t_keys + n_slots;
+	}
+	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+	__syncthreads();
+	if (MODE == kCsExactGlobal) __threadfence_block();
+
+	cs_for_each_hit(A.positions, l_start, l_pref, R.n_lists, H, lane, [&](uint32_t pos, int li) {
+		const int p = li >> 1;
+		const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
+		const uint32_t bin = (pos - correction) >> A.bin_shift;
+		uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
+		for (;;) {
+			const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+			if (prev == bin || prev == 0xFFFFFFFFu) break;
+			slot = (slot + 1) & (n_slots - 1);
+		}
+		atomicAdd(&t_votes[slot], (li & 1) ? 0x10000u : 1u);
+	});
+	__syncthreads();
+	if (MODE == kCsExactGlobal) __threadfence_block();
+	(void) cs_finish<MODE>(A, read, lane, R, t_keys, t_votes, n_slots);
 }
 
 }  // namespace ngm

@@ -68,7 +68,7 @@ struct DevGuard {
 
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (mode == ngm::kCsFast) w += (size_t) 2 << (A.log2_bits - 5);
+	if (mode == ngm::kCsFast) w += (size_t) 1 << (A.log2_bits - 5);
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -105,8 +105,9 @@ int run_cs(ngm_mapper *m, int n) {
 		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
 		A.log2_bits = m->cs_log2_bits; A.log2_slots = m->cs_log2_small;
 		A.hit_cap = (1u << m->cs_log2_bits) / 6u;
+		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
-		hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsFast>, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		hipLaunchKernelGGL(ngm::cs_fast_kernel, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
@@ -290,13 +291,14 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		int lb = 12;
 		while ((double) (1u << lb) < 12.0 * hexp && lb < 17) ++lb;
 		int ls = 8;
-		while (0.75 * (double) (1u << ls) < 0.11 * hexp + 200.0 && ls < 12) ++ls;
+		// table entries: hits that find their bit already set -- H^2 / (2 bits) by collision plus the real repeats
+		while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * (double) (1u << lb)) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
 		m->cs_log2_bits = lb;
 		m->cs_log2_small = ls;
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
 	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17;
-	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsFast>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
 	return m;
