@@ -61,6 +61,7 @@ struct CsArgs {
 	unsigned long long out_capacity;
 	uint32_t *status;       // [0] output overflow flag, [1] number of queued reads
 	unsigned long long *counters;  // [0] k-mers looked up, [1] hits voted (algorithmic-bytes accounting)
+	unsigned long long *phase_cycles;  // optional diagnostics (fast path): [0] lists [1] sweep 1 [2] sweep 2 [3] candidates
 	uint32_t *ovf_read;     // [n] queue written by this pass
 	uint32_t *ovf_hits;     // [n]
 	// kCsExactGlobal
@@ -284,18 +285,23 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 // ---- FAST path ---------------------------------------------------------------------------------------------------
 // One sweep over the position lists with kCsFastHpl loads in flight per lane; the bins stay in registers
 // (kCsFastTrips x kCsFastHpl per lane, i.e. up to kCsFastTrips * 64 * kCsFastHpl hits per read), so the lists are
-// read from HBM exactly once.  Sweep 1: atomicOr into one "bin seen" bit plane; a hit that finds its bit already set
-// is a repeat and is inserted into the small exact table at once.  Sweep 2 (registers only): every hit that was the
-// first on its bit adds its vote if -- and only if -- its bin made it into the table.  A bin with >= 2 votes has all
-// but its first vote inserted in sweep 1 and the first one added in sweep 2: exact; bins with a single vote are
-// dropped (never candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
+// read from HBM exactly once.  Sweep 1: atomicOr into a "bin seen" bit plane; a hit that finds its bit already set
+// is a repeat and goes into the small exact table.  Sweep 2 (registers only): every hit that was the first on its
+// bit adds its vote if -- and only if -- its bin made it into the table.  A bin with >= 2 votes has all but its
+// first vote inserted in sweep 1 and the first one added in sweep 2: exact; bins with a single vote are dropped
+// (never candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
+// Nothing in the sweeps waits on a per-hit LDS round trip: the 16 atomicOr of a trip are issued back to back, the
+// few repeats are appended to a small LDS queue and inserted by the whole wave afterwards; sweep 2 filters the
+// register-resident hits through a bit plane of the table's keys (the plane memory is reused) before probing.
 constexpr int kCsFastHpl = 16;
 constexpr int kCsFastTrips = 6;
 constexpr uint32_t kCsFastMaxHits = (uint32_t) kCsFastTrips * 64u * kCsFastHpl;
+constexpr uint32_t kCsFastQueue = 256;  // LDS queue entries per flush
 
-__global__ __launch_bounds__(64) void cs_fast_kernel(CsArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void cs_fast_kernel(CsArgs A) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	__shared__ uint32_t s_flags[2];  // [0] distinct bins in the small table, [1] abort
+	__shared__ uint32_t s_flags[3];  // [0] distinct bins in the small table, [1] abort, [2] queue length
+	__shared__ uint32_t s_queue[kCsFastQueue];
 	const int lane = threadIdx.x;
 	const int read = blockIdx.x;
 	const int k = A.k;
@@ -308,19 +314,46 @@ __global__ __launch_bounds__(64) void cs_fast_kernel(CsArgs A) {
 	const int log2_slots = A.log2_slots;
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
-	if (lane < 2) s_flags[lane] = 0;
+	if (lane < 3) s_flags[lane] = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 
+	const bool diag = A.phase_cycles && (read & 255) == 0;  // sampled: the global atomics would serialise otherwise
+	const unsigned long long c0 = diag ? wall_clock64() : 0ull;
 	const CsRead R = cs_prepare(A, read, lane, l_start, l_pref, l_code);
 	const uint32_t H = R.H;
 	const int L = R.L, n_lists = R.n_lists;
 	if (H > A.hit_cap || H > kCsFastMaxHits) { cs_enqueue(A, read, lane, R); return; }
 	__syncthreads();
+	const unsigned long long c1 = diag ? wall_clock64() : 0ull;
 
 	const int sh = 32 - A.log2_bits;
 	const int hs = 32 - log2_slots;
 	constexpr int HPL = kCsFastHpl;
+
+	// inserts the queued entries (bin | strand << 31), one per lane per round
+	auto flush_inserts = [&]() {
+		__syncthreads();
+		const uint32_t nq = min(s_flags[2], kCsFastQueue);
+		for (uint32_t i = lane; i < nq; i += 64) {
+			const uint32_t e = s_queue[i];
+			const uint32_t bin = e & 0x3FFFFFFFu;
+			uint32_t slot = (bin * 2654435761u) >> hs;
+			for (;;) {
+				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+				if (prev == bin) break;
+				if (prev == 0xFFFFFFFFu) {
+					if (atomicAdd(&s_flags[0], 1u) > (n_slots * 3u) / 4u) s_flags[1] = 1;
+					break;
+				}
+				slot = (slot + 1) & (n_slots - 1);
+			}
+			atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
+		}
+		__syncthreads();
+		if (lane == 0) s_flags[2] = 0;
+	};
+
 	uint32_t bins[kCsFastTrips * HPL];  // bin | first-on-its-bit << 30 | reverse strand << 31
 #pragma unroll
 	for (int t = 0; t < kCsFastTrips; ++t) {
@@ -333,71 +366,109 @@ __global__ __launch_bounds__(64) void cs_fast_kernel(CsArgs A) {
 				if (l_pref[mid] <= h0) lo = mid; else hi = mid;
 			}
 		}
+		// list state, refreshed only when a hit crosses into the next list
+		uint32_t nb = (h0 < H) ? l_pref[lo + 1] : 0xFFFFFFFFu;
+		uint32_t st = (h0 < H) ? l_start[lo] - l_pref[lo] : 0u;
 		uint32_t pos[HPL], cor[HPL];
 #pragma unroll
 		for (int j = 0; j < HPL; ++j) {
 			const uint32_t h = h0 + j;
 			pos[j] = 0; cor[j] = 0;
 			if (h < H) {
-				while (l_pref[lo + 1] <= h) ++lo;
-				pos[j] = A.positions[l_start[lo] + (h - l_pref[lo])];
+				while (h >= nb) { ++lo; nb = l_pref[lo + 1]; st = l_start[lo] - l_pref[lo]; }
+				pos[j] = A.positions[st + h];
 				const int p = lo >> 1;
 				// diagonal of the hit (CS.cpp:140-142); bit 31 = reverse-complement list
 				cor[j] = (lo & 1) ? ((uint32_t) (L - (p + k)) | 0x80000000u) : (uint32_t) p;
 			}
 		}
+		uint32_t old[HPL], msk[HPL];
 #pragma unroll
 		for (int j = 0; j < HPL; ++j) {
-			const uint32_t h = h0 + j;
-			uint32_t e = 0;
-			if (h < H) {
-				const uint32_t bin = (pos[j] - (cor[j] & 0x7FFFFFFFu)) >> A.bin_shift;
-				const uint32_t rev = cor[j] & 0x80000000u;
+			old[j] = 0; msk[j] = 0;
+			if (h0 + j < H) {
+				const uint32_t bin = ((pos[j] - (cor[j] & 0x7FFFFFFFu)) >> A.bin_shift) & 0x3FFFFFFFu;
 				const uint32_t b = (bin * 0x9E3779B1u) >> sh;
-				const uint32_t m = 1u << (b & 31);
-				const uint32_t old = atomicOr(&plane[b >> 5], m);
-				e = (bin & 0x3FFFFFFFu) | rev;
-				if (old & m) {
-					uint32_t slot = ((bin & 0x3FFFFFFFu) * 2654435761u) >> hs;
-					for (;;) {
-						const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin & 0x3FFFFFFFu);
-						if (prev == (bin & 0x3FFFFFFFu)) break;
-						if (prev == 0xFFFFFFFFu) {
-							if (atomicAdd(&s_flags[0], 1u) > (n_slots * 3u) / 4u) s_flags[1] = 1;
-							break;
-						}
-						slot = (slot + 1) & (n_slots - 1);
-					}
-					atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
-				} else {
-					e |= 0x40000000u;
-				}
+				msk[j] = 1u << (b & 31);
+				old[j] = atomicOr(&plane[b >> 5], msk[j]);
+				pos[j] = bin | (cor[j] & 0x80000000u);
+			}
+		}
+		uint32_t ndup = 0;
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
+		uint32_t qb = ndup ? atomicAdd(&s_flags[2], ndup) : 0u;
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) {
+			uint32_t e = 0;
+			if (h0 + j < H) {
+				e = pos[j];
+				if (old[j] & msk[j]) { if (qb < kCsFastQueue) s_queue[qb] = e; ++qb; }
+				else e |= 0x40000000u;
 			}
 			bins[t * HPL + j] = e;
 		}
+		__syncthreads();
+		if (s_flags[2] > kCsFastQueue) s_flags[1] = 1;  // more repeats than the queue holds: leave it to the exact path
+		flush_inserts();
 	}
+	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
+	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }  // not provably exact here
+
+	// sweep 2: plane := bits of the bins that are in the table; first-on-bit hits whose bit is set are queued, then added
+	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 	__syncthreads();
-	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }  // small table full: not provably exact
-#pragma unroll
-	for (int t = 0; t < kCsFastTrips; ++t) {
-		if ((uint32_t) t * 64u * HPL >= H) break;
-#pragma unroll
-		for (int j = 0; j < HPL; ++j) {
-			const uint32_t e = bins[t * HPL + j];
-			if (e & 0x40000000u) {  // first hit on its bit: counts only if the bin is in the table
-				const uint32_t bin = e & 0x3FFFFFFFu;
-				uint32_t slot = (bin * 2654435761u) >> hs;
-				for (;;) {
-					const uint32_t key = t_keys[slot];
-					if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); break; }
-					if (key == 0xFFFFFFFFu) break;
-					slot = (slot + 1) & (n_slots - 1);
-				}
-			}
+	for (uint32_t s = lane; s < n_slots; s += 64) {
+		const uint32_t key = t_keys[s];
+		if (key != 0xFFFFFFFFu) {
+			const uint32_t b = (key * 0x9E3779B1u) >> sh;
+			atomicOr(&plane[b >> 5], 1u << (b & 31));
 		}
 	}
 	__syncthreads();
+#pragma unroll
+	for (int t = 0; t < kCsFastTrips; ++t) {
+		if ((uint32_t) t * 64u * HPL >= H) break;
+		uint32_t w[HPL];
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) {
+			const uint32_t e = bins[t * HPL + j];
+			const uint32_t b = ((e & 0x3FFFFFFFu) * 0x9E3779B1u) >> sh;
+			w[j] = (e & 0x40000000u) ? (plane[b >> 5] >> (b & 31)) & 1u : 0u;
+		}
+		uint32_t nhit = 0;
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) nhit += w[j];
+		uint32_t qb = nhit ? atomicAdd(&s_flags[2], nhit) : 0u;
+#pragma unroll
+		for (int j = 0; j < HPL; ++j) if (w[j]) { if (qb < kCsFastQueue) s_queue[qb] = bins[t * HPL + j]; ++qb; }
+		__syncthreads();
+		if (s_flags[2] > kCsFastQueue) s_flags[1] = 1;
+		// add the votes of the queued first hits whose bin is in the table (a set bit may also be a collision)
+		__syncthreads();
+		const uint32_t nq = min(s_flags[2], kCsFastQueue);
+		for (uint32_t i = lane; i < nq; i += 64) {
+			const uint32_t e = s_queue[i];
+			const uint32_t bin = e & 0x3FFFFFFFu;
+			uint32_t slot = (bin * 2654435761u) >> hs;
+			for (;;) {
+				const uint32_t key = t_keys[slot];
+				if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); break; }
+				if (key == 0xFFFFFFFFu) break;
+				slot = (slot + 1) & (n_slots - 1);
+			}
+		}
+		__syncthreads();
+		if (lane == 0) s_flags[2] = 0;
+		__syncthreads();
+	}
+	const unsigned long long c3 = diag ? wall_clock64() : 0ull;
+	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }
 	if (!cs_finish<kCsFast>(A, read, lane, R, t_keys, t_votes, n_slots)) cs_enqueue(A, read, lane, R);
+	if (diag && lane == 0) {  // diagnostics: 100 MHz ticks spent per phase, summed over reads
+		atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);
+		atomicAdd(&A.phase_cycles[3], wall_clock64() - c3);
+	}
 }
 
 // ---- EXACT paths: every hit goes into an open-addressing table (LDS, or global memory for very repetitive reads) --

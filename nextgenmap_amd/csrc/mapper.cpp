@@ -79,7 +79,7 @@ int run_cs(ngm_mapper *m, int n) {
 	const ngm_ref *r = m->ref;
 	const int q = m->prm.qry_max_len;
 	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) || m->d_max_both.reserve(n) ||
-			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_counters.reserve(4) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
+			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_counters.reserve(8) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
 			m->d_ovf_hits.reserve(n)) {
 		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
 		return -12;
@@ -89,7 +89,7 @@ int run_cs(ngm_mapper *m, int n) {
 		if (m->d_out_loc.reserve(cap) || m->d_out_sv.reserve(cap)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, 8, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, 32, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, 64, m->st));
 		ngm::CsArgs A{};
 		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
@@ -98,9 +98,11 @@ int run_cs(ngm_mapper *m, int n) {
 		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p; A.max_both = m->d_max_both.p;
 		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap;
 		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
+		A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + 4 : nullptr;
 		uint32_t status[4];
 		m->cs_kernel_ms = 0;
-		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) m->cs_kernel_ms += t; };
+		float pass_ms[3] = {0, 0, 0};
+		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) { m->cs_kernel_ms += t; pass_ms[e / 2] = t; } };
 
 		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
 		A.log2_bits = m->cs_log2_bits; A.log2_slots = m->cs_log2_small;
@@ -168,9 +170,12 @@ int run_cs(ngm_mapper *m, int n) {
 			MAP_HIP_TRY(hipMemcpy(&total, m->d_total.p, 8, hipMemcpyDeviceToHost));
 			m->n_cand = total;
 			m->n_reads = n;
-			unsigned long long ctr[4];
-			MAP_HIP_TRY(hipMemcpy(ctr, m->d_counters.p, 32, hipMemcpyDeviceToHost));
+			unsigned long long ctr[8];
+			MAP_HIP_TRY(hipMemcpy(ctr, m->d_counters.p, 64, hipMemcpyDeviceToHost));
 			m->cs_kmers = ctr[0]; m->cs_hits = ctr[1];
+			if (A.phase_cycles)
+				fprintf(stderr, "[ngm-hip] cs fast path, 100 MHz ticks per read: lists %.1f sweep1 %.1f sweep2 %.1f candidates %.1f; %u of %d reads re-run by the exact path; kernels %.2f + %.2f + %.2f ms\n",
+						(double) ctr[4] * 256 / n, (double) ctr[5] * 256 / n, (double) ctr[6] * 256 / n, (double) ctr[7] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
 			m->h_base.resize(n); m->h_count.resize(n); m->h_maxv.resize(n);
 			MAP_HIP_TRY(hipMemcpy(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost));
 			MAP_HIP_TRY(hipMemcpy(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost));
