@@ -78,6 +78,10 @@ typedef struct ngm_mapper_params {
 	int hard_clip, silent_clip;
 	int personality;       /* NGM_PERSONALITY_* of ngm_hip.h: 1 = `--affine` (EndToEndAffine / SeqAn scoring and CIGARs) */
 	int gap_extend_penalty; /* Config "gap_extend_penalty" (affine personality) */
+	/* paired-end selection (ScoreBuffer::top1PE / CheckPairs, src/ScoreBuffer.cpp:368-502) */
+	int min_insert_size;   /* Config "min_insert_size" (-I), default 0 */
+	int max_insert_size;   /* Config "max_insert_size" (-X), default 1000; <= 0: unlimited (src/NGM.cpp:38-41) */
+	float pair_score_cutoff; /* Config "pair_score_cutoff"; <= 0: 0.9 */
 } ngm_mapper_params;
 
 ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p);
@@ -109,13 +113,27 @@ typedef struct ngm_hit {
 	int n_candidates;      /* CMRs scored for this read */
 	int n_best;            /* NH:i / X0:i : candidates sharing the best score */
 	float max_votes;       /* XE:i */
+	int pair_flags;        /* paired-end runs: NGM_PAIR_* */
 } ngm_hit;
+
+#define NGM_PAIR_SELECTED 1  /* top1PE found a pair inside the insert-size window; n_best = pairs sharing its score and distance */
+#define NGM_PAIR_FAILED 2    /* both mates had candidates but no such pair: NGMNames::PairedFail, mates selected single-end */
 
 /* Full single-end path for n reads; cigars/mds: n rows of 4*qry_max_len bytes (NUL-terminated strings). */
 int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds);
 /* Same, with the read batch already resident in HBM (d_reads: n rows of qry_max_len bytes, device memory on
  * the mapper's GPU); `reads` is the host copy the CIGAR/MD pass consults.  What bench.py times. */
 int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads, ngm_hit *hits, char *cigars,
+		char *mds);
+
+/* Paired-end path: reads 2i and 2i+1 are mates (ReadProvider::GenerateRead, src/ReadProvider.cpp:526-584).
+ * Candidate search, scoring and alignment are per read as above; the selection is ScoreBuffer::top1PE: among the
+ * candidates within pair_score_cutoff of each mate's best, the best-scoring pair whose insert size lies inside
+ * (min_insert_size, max_insert_size), ties by closeness to the running mean insert size (which is carried across
+ * calls, like the reference's per-thread state).  MAPQ of a mate = its own best vs second-best candidate.
+ * What the writer derives from both mates (proper-pair check, TLEN, flags) is the caller's: ngm-hip does it. */
+int ngm_mapper_map_pe(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds);
+int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads, ngm_hit *hits, char *cigars,
 		char *mds);
 
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted

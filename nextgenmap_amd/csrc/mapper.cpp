@@ -3,6 +3,9 @@
 // One ngm_mapper is what one NextGenMap CS thread owns (CS + ScoreBuffer + AlignmentBuffer + IAlignment,
 // src/CS.cpp:455-461); everything between the read upload and the traceback download stays in HBM.
 #include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -35,6 +38,7 @@ struct ngm_mapper {
 	int cs_log2_small = 10;   // fast path: small exact table ...
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
+	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	// batch state in HBM
 	ngm::DevBuf<uint8_t> d_reads;
 	ngm::DevBuf<uint16_t> d_read_len;
@@ -359,12 +363,76 @@ int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *vo
 	return 0;
 }
 
+static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired);
+
 int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds) {
-	return ngm_mapper_map_se_resident(m, n, reads, nullptr, hits, cigars, mds);
+	return map_impl(m, n, reads, nullptr, hits, cigars, mds, false);
+}
+int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds) {
+	return map_impl(m, n, reads, d_reads_ext, hits, cigars, mds, false);
+}
+int ngm_mapper_map_pe(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds) {
+	return map_impl(m, n, reads, nullptr, hits, cigars, mds, true);
+}
+int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds) {
+	return map_impl(m, n, reads, d_reads_ext, hits, cigars, mds, true);
 }
 
-int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds) {
+// ScoreBuffer::top1PE + CheckPairs (src/ScoreBuffer.cpp:368-502) for one pair; `a` = the mate whose scores arrive last
+// (the odd read id: "read"), `b` = its mate.  Candidates are (pair index) lists into loc/score.
+static void select_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
+		const uint32_t *loc, const float *score, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found) {
+	auto sorted = [&](uint32_t base, uint32_t cnt) {
+		std::vector<uint32_t> v(cnt);
+		std::iota(v.begin(), v.end(), base);
+		std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });  // sortLocationScore
+		return v;
+	};
+	auto mq_of = [&](const std::vector<uint32_t> &v) {  // computeMQ(MappedRead*), ScoreBuffer.cpp:42-49
+		if (v.size() <= 1) return 60;
+		const float best = score[v[0]], second = score[v[1]];
+		int mq = 0;
+		if (best > 0 && second >= 0) mq = (int) ceilf(60.0f * (best - second) / best);
+		return mq;
+	};
+	const std::vector<uint32_t> A = sorted(base_a, cnt_a), B = sorted(base_b, cnt_b);
+	*mq_a = mq_of(A); *mq_b = mq_of(B);
+	const float cutoff = m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f;
+	const float min_a = score[A[0]] * cutoff, min_b = score[B[0]] * cutoff;
+	size_t na = 1, nb = 1;
+	while (na < A.size() && min_a <= score[A[na]]) ++na;
+	while (nb < B.size() && min_b <= score[B[nb]]) ++nb;
+	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
+	float top = 0.0f;
+	int distance = 0, equal = 0, ta = -1, tb = -1;
+	for (size_t i = 0; i < na; ++i) {
+		for (size_t j = 0; j < nb; ++j) {
+			const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
+			const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
+			bool take = false;
+			if (cur > min_d && cur < max_d) {
+				const float ps = score[A[i]] + score[B[j]];
+				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; }
+				else if (ps == top) {
+					const int avg = (int) (m->pair_dist_sum / m->pair_dist_count);
+					if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
+					else if (abs(distance) == abs(cur)) equal += 1;
+				}
+			}
+			if (take) { ta = (int) A[i]; tb = (int) B[j]; }
+		}
+	}
+	*found = top > 0.0f;
+	if (*found) {
+		m->pair_dist_sum += distance;
+		m->pair_dist_count += 1;
+		*win_a = ta; *win_b = tb; *equal_out = equal;
+	}
+}
+
+static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired) {
 	if (!m || n < 0) return -22;
+	if (paired && (n & 1)) { ngm::pipeline_set_error("paired-end batches need an even number of reads"); return -22; }
 	if (n == 0) return 0;
 	const ngm_ref *r = m->ref;
 	DevGuard g(r->device);
@@ -387,6 +455,7 @@ int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const vo
 	std::vector<int32_t> h_mapq(n, 0), h_nbest(n, 0);
 	std::vector<float> h_best(n, 0.f);
 	std::vector<uint32_t> h_loc, h_sv;
+	std::vector<int> pair_flags(n, 0);
 	if (np > 0) {
 		// ---- score stage: all candidates of the batch in one BatchScore -------------------------------------
 		if (m->d_pair_read.reserve(np) || m->d_scores.reserve(np) || m->d_winner.reserve(n) || m->d_mapq.reserve(n) || m->d_nbest.reserve(n) ||
@@ -412,7 +481,33 @@ int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const vo
 		h_loc.resize(np); h_sv.resize(np);
 		MAP_HIP_TRY(hipMemcpyAsync(h_loc.data(), m->d_out_loc.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_sv.data(), m->d_out_sv.p, np * 4, hipMemcpyDeviceToHost, m->st));
+		std::vector<float> h_scores;
+		if (paired) {
+			h_scores.resize(np);
+			MAP_HIP_TRY(hipMemcpyAsync(h_scores.data(), m->d_scores.p, np * 4, hipMemcpyDeviceToHost, m->st));
+		}
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		if (paired) {
+			// pairs in input order, like one CS thread of the reference (the running mean insert size is sequential state)
+			for (int p = 0; p + 1 < n; p += 2) {
+				const int rb = p, ra = p + 1;
+				const uint32_t ca = m->h_count[ra], cb = m->h_count[rb];
+				if (ca == 0 || cb == 0) continue;  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
+				int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
+				bool found = false;
+				select_pair(m, m->h_base[ra], ca, (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], cb, (int) strnlen(reads + (size_t) rb * q, q),
+						h_loc.data(), h_scores.data(), &wa, &wb, &mqa, &mqb, &equal, &found);
+				if (found) {
+					h_winner[ra] = (uint32_t) wa; h_winner[rb] = (uint32_t) wb;
+					h_mapq[ra] = mqa; h_mapq[rb] = mqb;
+					h_nbest[ra] = h_nbest[rb] = equal;
+					h_best[ra] = h_scores[wa]; h_best[rb] = h_scores[wb];
+					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED;
+				} else {
+					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;  // no pair inside the window: single-end selection stands
+				}
+			}
+		}
 	}
 
 	// ---- alignment stage: one pair per read that has a winner (AlignmentBuffer::DoRun) --------------------
@@ -464,6 +559,7 @@ int ngm_mapper_map_se_resident(ngm_mapper *m, int n, const char *reads, const vo
 			h.mapq = h_mapq[i];
 			h.n_best = h_nbest[i];
 			h.score = h_best[i];
+			h.pair_flags = pair_flags[i];
 			cigars[(size_t) i * str_stride] = 0;
 			mds[(size_t) i * str_stride] = 0;
 		}

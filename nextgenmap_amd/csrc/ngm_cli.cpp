@@ -73,7 +73,9 @@ private:
 };
 
 struct Opts {
-	std::string ref, qry, out;
+	std::string ref, qry, qry1, qry2, out;
+	int paired = 0, min_insert = 0, max_insert = 1000;
+	char pe_delimiter = '/';
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
 	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
@@ -89,7 +91,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, PEDELIM, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -103,16 +105,24 @@ Opts parse(int argc, char **argv) {
 		{"very-fast", no_argument, 0, VFAST}, {"fast", no_argument, 0, FAST}, {"sensitive", no_argument, 0, SENS}, {"very-sensitive", no_argument, 0, VSENS},
 		{"device", required_argument, 0, DEVICE}, {"skip-save", no_argument, 0, SKIPSAVE}, {"batch-size", required_argument, 0, BATCH},
 		{"kernel-variant", required_argument, 0, VARIANT},
-		{"qry1", required_argument, 0, UNSUPPORTED}, {"qry2", required_argument, 0, UNSUPPORTED}, {"paired", no_argument, 0, UNSUPPORTED},
+		{"qry1", required_argument, 0, '1'}, {"qry2", required_argument, 0, '2'}, {"paired", no_argument, 0, 'p'},
+		{"min-insert-size", required_argument, 0, 'I'}, {"max-insert-size", required_argument, 0, 'X'}, {"pe-delimiter", required_argument, 0, PEDELIM},
+		{"fast-pairing", no_argument, 0, UNSUPPORTED}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
 		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, UNSUPPORTED}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
 		{"slam-seq", required_argument, 0, UNSUPPORTED}, {"topn", required_argument, 0, UNSUPPORTED}, {"strata", no_argument, 0, UNSUPPORTED},
 		{"argos", no_argument, 0, UNSUPPORTED}, {"vcf", required_argument, 0, UNSUPPORTED}, {"config", required_argument, 0, UNSUPPORTED},
 		{0, 0, 0, 0}};
 	int c, idx = 0;
-	while ((c = getopt_long(argc, argv, "o:q:r:t:gs:k:lei:R:C:Q:", lo, &idx)) != -1) {
+	while ((c = getopt_long(argc, argv, "o:q:r:t:gs:k:lei:R:C:Q:p1:2:I:X:", lo, &idx)) != -1) {
 		switch (c) {
 		case 'r': o.ref = optarg; break;
 		case 'q': o.qry = optarg; break;
+		case '1': o.qry1 = optarg; break;
+		case '2': o.qry2 = optarg; break;
+		case 'p': o.paired = 1; break;
+		case 'I': o.min_insert = atoi(optarg); break;
+		case 'X': o.max_insert = atoi(optarg); break;
+		case PEDELIM: o.pe_delimiter = optarg[0]; break;
 		case 'o': o.out = optarg; break;
 		case 't': break;  // host threads follow the machine (NGM_HIP_HOST_THREADS)
 		case 'g': break;  // the GPU is not optional here
@@ -152,6 +162,9 @@ Opts parse(int argc, char **argv) {
 		}
 	}
 	if (o.ref.empty()) die("no reference given (-r/--ref)");
+	if (!o.qry1.empty() && !o.qry2.empty()) o.paired = 1;  // Config.cpp:395-399
+	else if (!o.qry1.empty() || !o.qry2.empty()) die("--qry1 and --qry2 must be given together");
+	if (o.paired && o.qry.empty() && o.qry1.empty()) die("-p/--paired needs -q (interleaved mates) or --qry1/--qry2");
 	// scoring defaults depend on the personality (Config.cpp:433-446)
 	if (o.gap_read < 0) o.gap_read = o.affine ? 33 : 20;
 	if (o.gap_ref < 0) o.gap_ref = o.affine ? 33 : 20;
@@ -179,15 +192,16 @@ int main(int argc, char **argv) {
 	if (!ref) die(ngm_pipeline_last_error());
 	info("PREPROCESS", "index entries: " + std::to_string(ngm_ref_index_entries(ref)) + ", max. k-mer frequency " +
 			std::to_string(o.max_kfreq > 0 ? o.max_kfreq : ngm_ref_auto_max_kfreq(ref)));
-	if (o.qry.empty()) { ngm_ref_destroy(ref); return 0; }  // index only, like `ngm -r ref.fa`
+	const std::string first_input = o.qry1.empty() ? o.qry : o.qry1;  // parser1: what the estimation pass reads (ReadProvider.cpp:201)
+	if (first_input.empty()) { ngm_ref_destroy(ref); return 0; }  // index only, like `ngm -r ref.fa`
 	if (o.out.empty()) die("no output file given (-o/--output)");
 
 	// ---- pass 1: read lengths + the sample for the sensitivity estimate (ReadProvider.cpp:201-305) ----------
 	size_t max_len = 0, min_len = 9999999, sum_len = 0, count = 0;
 	std::vector<Read> sample;
 	{
-		SeqReader in(o.qry.c_str());
-		if (!in.ok()) die("cannot open " + o.qry);
+		SeqReader in(first_input.c_str());
+		if (!in.ok()) die("cannot open " + first_input);
 		Read r;
 		bool finish = false;
 		while (!finish && in.next(r)) {
@@ -215,6 +229,8 @@ int main(int argc, char **argv) {
 	mp.sensitivity = 0.5f; mp.kmer_min = o.kmer_min; mp.max_cmrs = o.max_cmrs; mp.max_kfreq = o.max_kfreq;
 	mp.hard_clip = o.hard_clip; mp.silent_clip = o.silent_clip;
 	mp.personality = o.affine ? NGM_PERSONALITY_AFFINE : NGM_PERSONALITY_LINEAR; mp.gap_extend_penalty = o.gap_extend;
+	mp.min_insert_size = o.min_insert; mp.max_insert_size = o.max_insert; mp.pair_score_cutoff = 0.9f;
+	if (o.paired) info("INPUT", "Input is paired end data.");
 
 	// ---- sensitivity (ReadProvider.cpp:310-385) -----------------------------------------------------------
 	float sens = 0.5f;
@@ -270,60 +286,139 @@ int main(int argc, char **argv) {
 	fprintf(out, "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"%s\"\n", o.cmdline.c_str());
 
 	// ---- pass 2: map in batches ------------------------------------------------------------------------------
-	SeqReader in(o.qry.c_str());
 	std::vector<Read> batch;
 	std::vector<char> rows, cig, md;
 	std::vector<ngm_hit> hits;
 	size_t n_total = 0, n_mapped = 0, n_written = 0;
 	const size_t stride = (size_t) 4 * q;
+	const int max_insert = o.max_insert > 0 ? o.max_insert : 2147483647;
+
+	struct View { const Read *r; const ngm_hit *h; const char *row; int L; const char *cigar, *md; };
+	auto view = [&](int i) { View v{&batch[i], &hits[i], &rows[(size_t) i * q], 0, &cig[(size_t) i * stride], &md[(size_t) i * stride]}; v.L = (int) strnlen(v.row, q); return v; };
+	auto passes = [&](const View &v) {  // GenericReadWriter.h:205-215, :262-273
+		float min_res = o.min_residues;
+		if (min_res <= 1.0f) min_res = v.L * min_res;
+		return v.h->mapped && v.h->mapq >= o.min_mq && v.h->identity >= o.min_identity && (float) (v.L - v.h->qstart - v.h->qend) >= min_res;
+	};
+	// SAMWriter::DoWriteReadGeneric (SAMWriter.cpp:98-228)
+	auto write_mapped = [&](const View &v, int flags, const char *rnext, unsigned long long pnext, long long tlen) {
+		const ngm_hit &h = *v.h;
+		const int L = v.L;
+		const bool noq = v.r->qual.empty();
+		std::string seq(v.row, L), ql = noq ? std::string("*") : v.r->qual.substr(0, L);
+		if (h.reverse) {
+			flags |= 0x10;
+			for (int t = 0; t < L; ++t) { const char ch = v.row[L - 1 - t]; seq[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch; }
+			if (!noq) std::reverse(ql.begin(), ql.end());
+		}
+		const bool clip = o.hard_clip || o.silent_clip;
+		const int s0 = clip ? h.qstart : 0, sl = clip ? L - h.qstart - h.qend : L;
+		const float identity = roundf(h.identity * 10000.0f) / 10000.0f;
+		fprintf(out, "%s\t%d\t%s\t%llu\t%d\t%s\t%s\t%llu\t%lld\t%.*s\t%.*s\tAS:i:%d\tNM:i:%d\tNH:i:%d\tXI:f:%g\tX0:i:%d\tXE:i:%d\tXR:i:%d\tMD:Z:%s\n",
+				v.r->name.c_str(), flags, ngm_ref_contig_name(ref, h.contig), (unsigned long long) h.pos + 1, h.mapq, v.cigar, rnext, pnext, tlen,
+				sl, seq.c_str() + s0, noq ? 1 : sl, noq ? "*" : ql.c_str() + s0,
+				(int) h.score, h.nm, h.n_best, identity, h.n_best, (int) h.max_votes, L - h.qstart - h.qend, v.md);
+		++n_written;
+	};
+	// SAMWriter::DoWriteUnmappedReadGeneric (SAMWriter.cpp:311-372): contig < 0 prints '*'
+	auto write_unmapped = [&](const View &v, int flags, int contig, unsigned long long pos1, char rnext, unsigned long long pnext1) {
+		if (o.no_unal) return;
+		const bool noq = v.r->qual.empty();
+		const int ql = noq ? 1 : std::min<int>((int) v.r->qual.size(), v.L);
+		fprintf(out, "%s\t%d\t%s\t%llu\t0\t*\t%c\t%llu\t0\t%.*s\t%.*s\n", v.r->name.c_str(), flags | 0x4, contig >= 0 ? ngm_ref_contig_name(ref, contig) : "*",
+				pos1, rnext, pnext1, v.L, v.row, ql, noq ? "*" : v.r->qual.c_str());
+		++n_written;
+	};
+
 	auto flush = [&]() {
 		const int n = (int) batch.size();
 		if (n == 0) return;
 		rows.assign((size_t) n * q, 0);
 		for (int i = 0; i < n; ++i) pack_row(batch[i], q, &rows[(size_t) i * q]);
 		hits.resize(n); cig.resize((size_t) n * stride); md.resize((size_t) n * stride);
-		if (ngm_mapper_map_se(m, n, rows.data(), hits.data(), cig.data(), md.data()) < 0) die(ngm_pipeline_last_error());
-		std::string rev;
-		for (int i = 0; i < n; ++i) {
-			const Read &r = batch[i];
-			const ngm_hit &h = hits[i];
-			const char *row = &rows[(size_t) i * q];
-			const int L = (int) strnlen(row, q);
-			if (r.seq.empty()) continue;  // NGMNames::Empty reads are discarded (GenericReadWriter.h:245-247)
-			const char *qual = r.qual.empty() ? "*" : r.qual.c_str();
-			const int qual_len = r.qual.empty() ? 1 : std::min<int>((int) r.qual.size(), L);
-			float min_res = o.min_residues;
-			if (min_res <= 1.0f) min_res = L * min_res;
-			bool mapped = h.mapped && h.mapq >= o.min_mq && h.identity >= o.min_identity && (float) (L - h.qstart - h.qend) >= min_res;
-			++n_total;
-			if (!mapped) {
-				if (o.no_unal) continue;
-				fprintf(out, "%s\t4\t*\t0\t0\t*\t*\t0\t0\t%.*s\t%.*s\n", r.name.c_str(), L, row, qual_len, qual);
-				++n_written;
-				continue;
+		const int rc = o.paired ? ngm_mapper_map_pe(m, n, rows.data(), hits.data(), cig.data(), md.data())
+		                        : ngm_mapper_map_se(m, n, rows.data(), hits.data(), cig.data(), md.data());
+		if (rc < 0) die(ngm_pipeline_last_error());
+		if (!o.paired) {
+			for (int i = 0; i < n; ++i) {
+				const View v = view(i);
+				if (v.r->seq.empty()) continue;  // NGMNames::Empty reads are discarded (GenericReadWriter.h:245-247)
+				++n_total;
+				if (!passes(v)) { write_unmapped(v, 0, -1, 0, '*', 0); continue; }
+				++n_mapped;
+				write_mapped(v, 0, "*", 0, 0);
 			}
-			++n_mapped; ++n_written;
-			int flags = 0;
-			std::string seq(row, L), ql(qual, qual_len);
-			if (h.reverse) {
-				flags |= 0x10;
-				for (int t = 0; t < L; ++t) { const char ch = row[L - 1 - t]; seq[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch; }
-				if (ql[0] != '*' || ql.size() > 1) std::reverse(ql.begin(), ql.end());
+		} else {
+			for (int i = 0; i + 1 < n; i += 2) {
+				// read1 = the first mate (even ReadId), written second by AlignmentBuffer::WriteRead; read2 = its mate
+				const View v1 = view(i), v2 = view(i + 1);
+				if (v1.r->seq.empty() || v2.r->seq.empty()) continue;  // GenericReadWriter.h:250-252
+				n_total += 2;
+				const ngm_hit &h1 = *v1.h, &h2 = *v2.h;
+				// AlignmentBuffer::WriteRead (AlignmentBuffer.cpp:175-199): is the pair consistent?
+				bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
+				if (h1.mapped && h2.mapped) {
+					const long long distance = (h2.pos > h1.pos) ? (long long) (h2.pos - h1.pos) + v1.L : (long long) (h1.pos - h2.pos) + v2.L;
+					if (h1.contig != h2.contig || distance < o.min_insert || distance > max_insert || h1.reverse == h2.reverse) paired_fail = true;
+				}
+				const bool m1 = passes(v1), m2 = passes(v2);  // GenericReadWriter::WritePair
+				n_mapped += (m1 ? 1 : 0) + (m2 ? 1 : 0);
+				const int f1 = 0x1 | 0x40, f2 = 0x1 | 0x80;  // SAMWriter::DoWritePair (SAMWriter.cpp:230-310)
+				const unsigned long long p1 = h1.pos + 1, p2 = h2.pos + 1;
+				if (!m1 && !m2) {
+					write_unmapped(v2, f2 | 0x8, -1, 0, '*', 0);
+					write_unmapped(v1, f1 | 0x8, -1, 0, '*', 0);
+				} else if (!m1) {
+					write_mapped(v2, f2 | 0x8, "=", p2, 0);
+					write_unmapped(v1, f1, h2.contig, p2, '=', p2);
+				} else if (!m2) {
+					write_unmapped(v2, f2, h1.contig, p1, '=', p1);
+					write_mapped(v1, f1 | 0x8, "=", p1, 0);
+				} else if (!paired_fail) {
+					if (!h1.reverse) {
+						const long long d = ((long long) h2.pos + v2.L - h2.qstart - h2.qend) - (long long) h1.pos;
+						write_mapped(v2, f2 | 0x2, "=", p1, -d);
+						write_mapped(v1, f1 | 0x2 | 0x20, "=", p2, d);
+					} else if (!h2.reverse) {
+						const long long d = ((long long) h1.pos + v1.L - h1.qstart - h1.qend) - (long long) h2.pos;
+						write_mapped(v2, f2 | 0x2 | 0x20, "=", p1, d);
+						write_mapped(v1, f1 | 0x2, "=", p2, -d);
+					}
+				} else {
+					write_mapped(v2, f2 | (h1.reverse ? 0x20 : 0), ngm_ref_contig_name(ref, h1.contig), p1, 0);
+					write_mapped(v1, f1 | (h2.reverse ? 0x20 : 0), ngm_ref_contig_name(ref, h2.contig), p2, 0);
+				}
 			}
-			const bool clip = o.hard_clip || o.silent_clip;
-			const int s0 = clip ? h.qstart : 0, sl = clip ? L - h.qstart - h.qend : L;
-			const float identity = roundf(h.identity * 10000.0f) / 10000.0f;
-			fprintf(out, "%s\t%d\t%s\t%llu\t%d\t%s\t*\t0\t0\t%.*s\t%.*s\tAS:i:%d\tNM:i:%d\tNH:i:%d\tXI:f:%g\tX0:i:%d\tXE:i:%d\tXR:i:%d\tMD:Z:%s\n",
-					r.name.c_str(), flags, ngm_ref_contig_name(ref, h.contig), (unsigned long long) h.pos + 1, h.mapq, &cig[(size_t) i * stride],
-					sl, seq.c_str() + s0, (ql.size() == 1 && ql[0] == '*') ? 1 : sl, (ql.size() == 1 && ql[0] == '*') ? "*" : ql.c_str() + s0,
-					(int) h.score, h.nm, h.n_best, identity, h.n_best, (int) h.max_votes, L - h.qstart - h.qend, &md[(size_t) i * stride]);
 		}
 		batch.clear();
 	};
-	Read r;
-	while (in.next(r)) {
-		batch.push_back(r);
-		if ((int) batch.size() == o.batch) flush();
+	auto strip_mate = [&](Read &r) {  // ReadProvider::NextRead (ReadProvider.cpp:419-422)
+		const size_t L = r.name.size();
+		if (L >= 2 && r.name[L - 2] == o.pe_delimiter) r.name.resize(L - 2);
+	};
+	if (!o.paired) {
+		SeqReader in(o.qry.c_str());
+		Read r;
+		while (in.next(r)) {
+			batch.push_back(r);
+			if ((int) batch.size() == o.batch) flush();
+		}
+	} else {
+		const bool interleaved = !o.qry.empty();  // ReadProvider::GenerateRead (ReadProvider.cpp:526-584)
+		SeqReader in1(interleaved ? o.qry.c_str() : o.qry1.c_str());
+		SeqReader *in2 = interleaved ? &in1 : new SeqReader(o.qry2.c_str());
+		if (!in1.ok() || !in2->ok()) die("cannot open the paired-end input");
+		Read a, b;
+		for (;;) {
+			const bool ha = in1.next(a), hb = ha ? in2->next(b) : false;
+			if (!ha) break;
+			if (!hb) die("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode.");
+			strip_mate(a); strip_mate(b);
+			if (a.name != b.name) die("Error while reading paired end reads. Names of mates don't match: " + a.name + " and " + b.name + ".");
+			batch.push_back(a); batch.push_back(b);
+			if ((int) batch.size() >= (o.batch & ~1)) flush();
+		}
+		if (!interleaved) delete in2;
 	}
 	flush();
 	fclose(out);

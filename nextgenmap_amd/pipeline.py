@@ -15,12 +15,13 @@ class MapperParams(C.Structure):
     _fields_ = [("qry_max_len", C.c_int), ("corridor", C.c_int), ("match_bonus", C.c_int), ("mismatch_penalty", C.c_int),
                 ("gap_read_penalty", C.c_int), ("gap_ref_penalty", C.c_int), ("mode", C.c_int), ("variant", C.c_int),
                 ("sensitivity", C.c_float), ("kmer_min", C.c_float), ("max_cmrs", C.c_int), ("max_kfreq", C.c_int),
-                ("hard_clip", C.c_int), ("silent_clip", C.c_int), ("personality", C.c_int), ("gap_extend_penalty", C.c_int)]
+                ("hard_clip", C.c_int), ("silent_clip", C.c_int), ("personality", C.c_int), ("gap_extend_penalty", C.c_int),
+                ("min_insert_size", C.c_int), ("max_insert_size", C.c_int), ("pair_score_cutoff", C.c_float)]
 
 
 HIT_DTYPE = np.dtype([("mapped", "i4"), ("contig", "i4"), ("pos", "u8"), ("reverse", "i4"), ("mapq", "i4"),
                       ("score", "f4"), ("identity", "f4"), ("nm", "i4"), ("qstart", "i4"), ("qend", "i4"),
-                      ("n_candidates", "i4"), ("n_best", "i4"), ("max_votes", "f4")], align=True)
+                      ("n_candidates", "i4"), ("n_best", "i4"), ("max_votes", "f4"), ("pair_flags", "i4")], align=True)
 
 _bound = False
 
@@ -58,6 +59,7 @@ def _lib():
         lib.ngm_mapper_cs_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_mapper_map_se.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_mapper_map_se_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ngm_mapper_map_pe_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_mapper_cs_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _bound = True
@@ -161,12 +163,13 @@ class Mapper:
 
     def __init__(self, ref, qry_max_len, corridor, sensitivity=0.5, match=10, mismatch=15, gap_read=20, gap_ref=20,
                  mode=0, variant=0, kmer_min=0.0, max_cmrs=2 ** 31 - 1, max_kfreq=0, hard_clip=0, silent_clip=0, personality=0,
-                 gap_extend=0):
+                 gap_extend=0, min_insert_size=0, max_insert_size=1000, pair_score_cutoff=0.9):
         self.lib = _lib()
         self.ref = ref
         self.q, self.c = qry_max_len, corridor
         p = MapperParams(qry_max_len, corridor, match, mismatch, gap_read, gap_ref, mode, variant, sensitivity, kmer_min,
-                         max_cmrs, max_kfreq, hard_clip, silent_clip, personality, gap_extend)
+                         max_cmrs, max_kfreq, hard_clip, silent_clip, personality, gap_extend, min_insert_size, max_insert_size,
+                         pair_score_cutoff)
         self.h = self.lib.ngm_mapper_create(ref.h, C.byref(p))
         if not self.h:
             raise _err()
@@ -210,7 +213,16 @@ class Mapper:
             raise _err()
         return offs, mx, loc[:tot], strand[:tot], votes[:tot]
 
-    def map_se_raw(self, rows, d_rows=None, out=None):
+    def map_pe_raw(self, rows, d_rows=None, out=None):
+        """Paired-end: rows 2i and 2i+1 are mates.  Same outputs as map_se_raw."""
+        return self.map_se_raw(rows, d_rows, out, paired=True)
+
+    def map_pe(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        hits, cig, md = self.map_pe_raw(rows)
+        return hits, [bytes(r).split(b"\0", 1)[0] for r in cig], [bytes(r).split(b"\0", 1)[0] for r in md]
+
+    def map_se_raw(self, rows, d_rows=None, out=None, paired=False):
         """rows: [n, q] uint8 host array; d_rows: optional device copy (torch tensor / pointer).  Returns
         (hits, cigar bytes [n, 4q], md bytes [n, 4q]) without turning the strings into Python objects."""
         n = rows.shape[0]
@@ -219,7 +231,8 @@ class Mapper:
             out = (np.zeros(n, HIT_DTYPE), np.zeros((n, stride), np.uint8), np.zeros((n, stride), np.uint8))
         hits, cig, md = out
         dp = None if d_rows is None else (d_rows.data_ptr() if hasattr(d_rows, "data_ptr") else int(d_rows))
-        r = self.lib.ngm_mapper_map_se_resident(self.h, n, rows.ctypes.data, dp, hits.ctypes.data, cig.ctypes.data, md.ctypes.data)
+        fn = self.lib.ngm_mapper_map_pe_resident if paired else self.lib.ngm_mapper_map_se_resident
+        r = fn(self.h, n, rows.ctypes.data, dp, hits.ctypes.data, cig.ctypes.data, md.ctypes.data)
         if r < 0:
             raise _err()
         return hits, cig, md

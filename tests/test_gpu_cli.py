@@ -132,3 +132,65 @@ def test_cli_affine_sam_equals_reference_program(tmp_path, extra):
     assert len(diff) <= 0.005 * len(a), (len(diff), diff[:3])
     for n, x, y in diff:
         assert x["tags"].get("AS") == y["tags"].get("AS") or (x["flag"] & 4) or (y["flag"] & 4), (n, x, y)
+
+
+def _sam_pe(path):
+    recs = {}
+    for line in open(path):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        recs[(f[0], int(f[1]) & 0xC0)] = dict(flag=int(f[1]), rname=f[2], pos=int(f[3]), mapq=int(f[4]), cigar=f[5], rnext=f[6],
+                                              pnext=int(f[7]), tlen=int(f[8]), seq=f[9], qual=f[10], tags=tags)
+    return recs
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+@pytest.mark.parametrize("layout", ["interleaved", "two-files"])
+def test_cli_paired_end_sam_equals_reference_program(tmp_path, layout):
+    """Paired-end: top1PE / CheckPairs selection, the proper-pair check and SAMWriter::DoWritePair (flags, RNEXT,
+    PNEXT, TLEN, mate-unmapped records) against `ngm --affine -p` on the same interleaved FASTQ."""
+    contigs = S.make_genome([300000, 200001], seed=51, repeat_families=6, repeat_len=400, copies=5)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    r1, r2 = S.make_reads(contigs, 3000, 100, seed=52, sub_rate=0.02, indel_rate=0.003, paired=True)
+    # a few pairs that cannot be proper: mate 2 replaced by an unrelated read, by junk, or moved far away
+    rng = np.random.default_rng(5)
+    for k in range(0, 60, 3):
+        r2[k] = (r2[k][0], S.ACGT[rng.integers(0, 4, 100)], r2[k][2])
+    for k in range(1, 60, 3):
+        r2[k] = (r2[k][0], r2[k + 300][1], r2[k][2])
+    d1 = tmp_path / "refrun"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    if layout == "interleaved":
+        fq = str(tmp_path / "pe.fq")
+        S.write_fastq(fq, [x for pair in zip(r1, r2) for x in pair])
+        inp = ["-p", "-q", fq]
+    else:
+        f1, f2 = str(tmp_path / "pe_1.fq"), str(tmp_path / "pe_2.fq")
+        S.write_fastq(f1, r1)
+        S.write_fastq(f2, r2)
+        inp = ["-1", f1, "-2", f2]
+    r = RF.run_ngm(["-r", fa1, "-o", str(d1 / "out.sam"), "--affine", "-t", "1", "--no-progress"] + inp, cwd=str(d1))
+    assert "Done" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-1500:]
+    c = subprocess.run([CLI, "-r", fa, "-o", str(tmp_path / "hip.sam"), "--affine"] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    a, b = _sam_pe(str(d1 / "out.sam")), _sam_pe(str(tmp_path / "hip.sam"))
+    assert set(a) == set(b) and len(a) == 2 * len(r1)
+    diff = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
+    print("records differing:", len(diff), "of", len(a))
+    for d in diff[:4]:
+        print(str(d)[:700])
+    flags = {}
+    for n in a:
+        flags[a[n]["flag"]] = flags.get(a[n]["flag"], 0) + 1
+    print("flag histogram of the reference:", sorted(flags.items()))
+    assert len(diff) <= 0.01 * len(a), (len(diff), diff[:3])
