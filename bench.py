@@ -66,21 +66,42 @@ def make_genome(total_bp, seed):
     return contigs
 
 
-def make_reads(contigs, n, seed):
+def make_reads(contigs, n, seed, paired=False):
     """uniform positions, 50 % reverse strand, 1 % substitutions, one 1-3 bp indel in 15 % of the reads (0.1 % of the
-    bases).  Returns ([n, Q] uint8 rows, truth contig, truth pos)."""
+    bases).  paired: rows 2i / 2i+1 are the two ends of a fragment, insert size ~ N(350, 35), FR orientation, half of
+    the fragments from the reverse strand.  Returns ([n, Q] uint8 rows, truth contig, truth pos)."""
     rng = np.random.default_rng(seed)
     lens = np.array([len(c) for c in contigs], dtype=np.float64)
-    ci = rng.choice(len(contigs), size=n, p=lens / lens.sum())
     rows = np.zeros((n, Q), np.uint8)
     pos = np.zeros(n, np.int64)
-    for k in range(len(contigs)):
-        sel = np.nonzero(ci == k)[0]
-        if sel.size == 0:
-            continue
-        p = rng.integers(0, len(contigs[k]) - READ_LEN - 8, sel.size)
-        pos[sel] = p
-        rows[sel, :READ_LEN] = contigs[k][p[:, None] + np.arange(READ_LEN)[None, :]]
+    if paired:
+        nf = n // 2
+        cf = rng.choice(len(contigs), size=nf, p=lens / lens.sum())
+        ins = np.maximum(READ_LEN + 10, rng.normal(350, 35, nf).astype(np.int64))
+        ci = np.repeat(cf, 2)
+        flip = rng.random(nf) < 0.5
+        for k in range(len(contigs)):
+            sel = np.nonzero(cf == k)[0]
+            if sel.size == 0:
+                continue
+            p = rng.integers(0, len(contigs[k]) - 600, sel.size)
+            left = contigs[k][p[:, None] + np.arange(READ_LEN)[None, :]]
+            pr = p + ins[sel] - READ_LEN
+            right = COMP[contigs[k][pr[:, None] + np.arange(READ_LEN)[None, :]][:, ::-1]]
+            f = flip[sel]
+            rows[2 * sel, :READ_LEN] = np.where(f[:, None], right, left)
+            rows[2 * sel + 1, :READ_LEN] = np.where(f[:, None], left, right)
+            pos[2 * sel] = np.where(f, pr, p)
+            pos[2 * sel + 1] = np.where(f, p, pr)
+    else:
+        ci = rng.choice(len(contigs), size=n, p=lens / lens.sum())
+        for k in range(len(contigs)):
+            sel = np.nonzero(ci == k)[0]
+            if sel.size == 0:
+                continue
+            p = rng.integers(0, len(contigs[k]) - READ_LEN - 8, sel.size)
+            pos[sel] = p
+            rows[sel, :READ_LEN] = contigs[k][p[:, None] + np.arange(READ_LEN)[None, :]]
     sub = rng.random((n, READ_LEN)) < 0.01
     rows[:, :READ_LEN][sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
     for i in np.nonzero(rng.random(n) < 0.15)[0]:
@@ -93,23 +114,27 @@ def make_reads(contigs, n, seed):
         else:                   # deletion from the read
             rows[i, a:READ_LEN - L] = r[a + L:READ_LEN]
             rows[i, READ_LEN - L:READ_LEN] = ACGT[rng.integers(0, 4, L)]
-    rev = rng.random(n) < 0.5
-    rows[rev, :READ_LEN] = COMP[rows[rev, :READ_LEN][:, ::-1]]
+    if not paired:
+        rev = rng.random(n) < 0.5
+        rows[rev, :READ_LEN] = COMP[rows[rev, :READ_LEN][:, ::-1]]
     return rows, ci, pos
 
 
-def _sam_records(path):
+def _sam_records(path, paired=False):
     recs = {}
     for line in open(path):
         if line.startswith("@"):
             continue
         f = line.split("\t")
         tags = {t[:2]: t[5:].strip() for t in f[11:]}
-        recs[int(f[0][1:])] = (int(f[1]), f[2], int(f[3]), int(f[4]), f[5], tags.get("AS"), tags.get("NM"))
+        idx = int(f[0][1:])
+        if paired:  # r<pair> with the mate in the flag
+            idx = 2 * idx + (1 if int(f[1]) & 0x80 else 0)
+        recs[idx] = (int(f[1]), f[2], int(f[3]), int(f[4]), f[5], tags.get("AS"), tags.get("NM"))
     return recs
 
 
-def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None):
+def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None, paired=False):
     """NextGenMap itself (ngm-core --affine, host cores) on the first `budget_reads` reads vs the same genome.
     ours = (hits, cigar rows, contig names) of the GPU path in the affine personality: the reference's SAM records
     are then compared with them (flag, contig, position, MAPQ, CIGAR, AS, NM)."""
@@ -121,19 +146,23 @@ def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None):
     t = time.perf_counter()
     ref.write_ngm_cache(fa)
     t_cache = time.perf_counter() - t
-    n = min(budget_reads, rows.shape[0])
+    n = min(budget_reads, rows.shape[0]) & ~1
     fq, one = os.path.join(workdir, "sample.fq"), os.path.join(workdir, "one.fq")
     qual = b"I" * READ_LEN
+
+    def name(i):
+        return (b"@r%d/%d" % (i // 2, i % 2 + 1)) if paired else (b"@r%d" % i)
     with open(fq, "wb") as f:
         for i in range(n):
-            f.write(b"@r%d\n" % i + rows[i, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
+            f.write(name(i) + b"\n" + rows[i, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
     with open(one, "wb") as f:
-        f.write(b"@r0\n" + rows[0, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
+        for i in range(2):
+            f.write(name(i) + b"\n" + rows[i, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
     threads = min(cores, 64)
 
     def run(reads):
         cmd = [RF.NGM_CORE, "-r", fa, "-q", reads, "-o", os.path.join(workdir, "ref_out.sam"), "--affine", "-t", str(threads),
-               "--no-progress", "-s", "0.5"]
+               "--no-progress", "-s", "0.5"] + (["-p"] if paired else [])
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=workdir)
         dt = time.perf_counter() - t0
@@ -147,8 +176,9 @@ def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None):
     parity = None
     if ours is not None:
         hits, cig, names = ours
-        recs = _sam_records(os.path.join(workdir, "ref_out.sam"))
+        recs = _sam_records(os.path.join(workdir, "ref_out.sam"), paired)
         same = same_place = cmp = 0
+        examples = []
         for i, (flag, rname, pos, mapq, cigar, a_s, nm) in recs.items():
             h = hits[i]
             if (flag & 4) or not h["mapped"]:
@@ -157,11 +187,13 @@ def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None):
             mine = (16 if h["reverse"] else 0, names[h["contig"]], int(h["pos"]) + 1, int(h["mapq"]),
                     bytes(cig[i]).split(b"\0", 1)[0].decode(), str(int(h["score"])), str(int(h["nm"])))
             same += mine == (flag & 16, rname, pos, mapq, cigar, a_s, nm)
+            if len(examples) < 3 and mine != (flag & 16, rname, pos, mapq, cigar, a_s, nm):
+                examples.append({"read": i, "ours": mine, "reference": (flag & 16, rname, pos, mapq, cigar, a_s, nm)})
             same_place += mine[:3] == (flag & 16, rname, pos)
-        parity = {"reads_compared": cmp, "identical_records": same, "same_position": same_place,
+        parity = {"reads_compared": cmp, "identical_records": same, "same_position": same_place, "first_differences": examples,
                   "note": "records differing are equal-score repeat copies visited in a different order"}
     return {"parity_vs_reference_sam": parity, "value": n / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
-            "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d on the first %d reads of the step vs the same genome (index "
+            "sample": "NextGenMap 0.5.5 ngm-core --affine " + ("-p " if paired else "") + "-t %d on the first %d reads of the step vs the same genome (index "
                       "loaded from cache files written by this library): %.1fs total minus %.1fs index load/start-up measured "
                       "with a 1-read run" % (threads, n, t_all, t_load),
             "index_cache_write_s": t_cache}
@@ -196,6 +228,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
+    ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
+    ap.add_argument("--layout", choices=["pe", "se"], default="pe", help="paired-end (BASELINE.json config #2) or single-end reads")
     args = ap.parse_args()
 
     import torch
@@ -220,43 +254,70 @@ def main():
     t0 = time.perf_counter()
     ref = Reference.from_contigs(contigs, device=local_rank, kmer=KMER, kmer_skip=2, bin_size=2)
     t_index = time.perf_counter() - t0
-    rows, truth_c, truth_p = make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank)  # config #2's seed, one shard per rank
+    paired = args.layout == "pe"
+    rows, truth_c, truth_p = make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank, paired=paired)  # config #2's seed, one shard per rank
     d_rows = torch.from_numpy(rows).to(dev)
     affine = args.personality == "affine"
-    if affine:
-        mp = Mapper(ref, Q, C, sensitivity=0.5, gap_read=33, gap_ref=33, gap_extend=3, personality=1)
-    else:
-        mp = Mapper(ref, Q, C, sensitivity=0.5)
     band = C + 1 if affine else C  # SeqAn's band has diagonals 0..corridor
+    # W mapper instances (own stream + workspace each, like NextGenMap's CS threads with their own IAlignment) work on
+    # contiguous slices of the step's reads from W host threads: the host stages of one slice (pair selection, CIGAR,
+    # downloads) overlap the kernels of the others
+    W = max(1, min(args.workers, R // 2048))
+    bounds = [(R * w // W) & ~1 for w in range(W)] + [R]
     out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
+    mps, views = [], []
+    for w in range(W):
+        kw = dict(gap_read=33, gap_ref=33, gap_extend=3, personality=1) if affine else {}
+        mps.append(Mapper(ref, Q, C, sensitivity=0.5, **kw))
+        lo, hi = bounds[w], bounds[w + 1]
+        views.append((rows[lo:hi], d_rows[lo:hi], tuple(o[lo:hi] for o in out)))
 
-    def step():
-        return mp.map_se_raw(rows, d_rows, out)
+    def worker(w, steps, acc):
+        rw, dw, ow = views[w]
+        k = np.zeros(8)
+        for _ in range(steps):
+            if paired:
+                mps[w].map_pe_raw(rw, dw, ow)
+            else:
+                mps[w].map_se_raw(rw, dw, ow)
+            k += np.array(mps[w].last_kernel_ms())
+        acc[w] = k
 
-    for _ in range(args.warmup):
-        step()
+    def run(steps):
+        import threading
+        acc = [None] * W
+        ts = [threading.Thread(target=worker, args=(w, steps, acc)) for w in range(W)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return np.sum(acc, axis=0)
+
+    run(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kms = np.zeros(8)
-    hits = None
-    for _ in range(args.steps):
-        hits, _, _ = step()
-        kms += np.array(mp.last_kernel_ms())
+    kms = run(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kms /= max(1, args.steps)
+    kms /= max(1, args.steps)  # GPU time per step (R reads), summed over the W streams' launches
+    hits = out[0]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kmers, hits_voted, n_cand = mp.cs_counters()
+    # one extra, untimed pass of instance 0 alone: kernel durations without the other streams' kernels sharing the GPU
+    worker(0, 1, iso := [None] * W)
+    iso_ms = iso[0]
+    iso_ctr = mps[0].cs_counters()
+    ctr = np.sum([m_.cs_counters() for m_ in mps], axis=0)
+    kmers, hits_voted, n_cand = int(ctr[0]), int(ctr[1]), int(ctr[2])
     mapped = hits["mapped"] == 1
     correct = mapped & (hits["contig"] == truth_c) & (np.abs(hits["pos"].astype(np.int64) - truth_p) <= C // 2 + 4)
     stats = torch.tensor([R, int(mapped.sum()), int((~mapped).sum()), int(mapped.sum()), int(correct.sum()), int((hits["mapq"] > 0).sum()),
@@ -282,7 +343,7 @@ def main():
                     except Exception:
                         continue
                     for k, v in tj.items():
-                        if k.startswith("ngm::cs_kernel<0>") and k.endswith("|grid=%d" % (R * 64)):
+                        if k.startswith("ngm::cs_fast_kernel") and k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64)):
                             traffic = v
                     if traffic is not None:
                         break
@@ -291,11 +352,11 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "%d x 150bp SE synthetic reads per GPU per step vs a synthetic %.0f Mbp genome (24 contigs, repeat "
-                                   "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=0.5) + "
-                                   "score + top-1/MAPQ + align with traceback + CIGAR; reads resident in HBM; single-end (the "
-                                   "paired-end selection of config #2 is not built yet)" % (R, args.genome_mbp),
-                       "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R,
+            "config": {"workload": ("%d x 150bp %s synthetic reads per GPU per step vs a synthetic %.0f Mbp genome (24 contigs, repeat "
+                                    "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=0.5) + "
+                                    "score + %s/MAPQ + align with traceback + CIGAR; reads resident in HBM")
+                       % (R, "PE (insert ~N(350,35), FR)" if paired else "SE", args.genome_mbp, "pair selection (top1PE)" if paired else "top-1"),
+                       "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R, "mapper_instances_per_gpu": W,
                        "parallelism": "reads sharded x%d, genome+index replicated per GPU" % world},
             "sw_gcells_per_s": {"score_kernel": score_cells / (kms[2] * 1e-3) / 1e9 if kms[2] > 0 else None,
                                 "align_kernel": align_cells / (kms[5] * 1e-3) / 1e9 if kms[5] > 0 else None},
@@ -306,7 +367,10 @@ def main():
             "accuracy": {"mapped": stats[1] / stats[0], "within_band_of_truth": stats[4] / stats[0], "mapq_gt0": stats[5] / stats[0]},
             "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "cs_kernel (candidate search)", "bytes_per_launch": b_cs,
+                         "traffic": traffic, "kernel": "cs_fast_kernel (candidate search)",
+                         "isolated": {"achieved": (20 * iso_ctr[0] + 4 * iso_ctr[1] + 16 * iso_ctr[2]) / (iso_ms[0] * 1e-3) / 1e9, "ms": float(iso_ms[0]),
+                                      "reads": int(bounds[1] - bounds[0]),
+                                      "note": "same kernel, one launch of one mapper instance with nothing else on the GPU (untimed extra pass)"}, "bytes_per_launch": b_cs / W, "launches_per_step": W,
                          "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); dependent random "
                                  "8-64 B reads, latency- not bandwidth-limited; the SW kernels are VALU-bound, see sw_gcells_per_s"},
             "stats_allreduce": {"reads": stats[0], "mapped": stats[1], "unmapped": stats[2], "candidates": stats[6]},
@@ -318,12 +382,13 @@ def main():
                     raise RuntimeError("oracle/_ref/ngm/ngm-core not built")
                 with tempfile.TemporaryDirectory() as wd:
                     ours = (hits, out[1], [c[0] for c in ref.contigs]) if affine else None
-                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, args.cpu_sample_reads, wd, ours)
+                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, args.cpu_sample_reads, wd, ours, paired)
             except Exception as e:  # the port of the score stage only
                 line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
                 line["cpu_baseline"]["note"] = "reference program unavailable: %s" % str(e)[:200]
         print(json.dumps(line))
-    mp.close()
+    for m_ in mps:
+        m_.close()
     ref.close()
     if world > 1:
         dist.destroy_process_group()

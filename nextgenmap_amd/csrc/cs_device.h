@@ -144,12 +144,18 @@ struct CsRead {
 	int n_lists;      // 2 * k-mers
 	uint32_t H;       // hits of all lists
 	uint32_t n_valid; // k-mers looked up
+	uint32_t n_items; // ITEMS: 16-hit segments of all lists
 };
+constexpr int kCsSeg = 8;   // hits per work item of the fast path
 
 // 1. read -> 2-bit codes (A0 C1 T2 G3, CSstatic.cpp:20-22), N = 4, past the end = 255;
 // 2. k-mers and their two position lists (lane = k-mer, lists 2p = forward, 2p+1 = reverse complement).
 // The index reads of up to four 64-k-mer rounds are issued before any of them is consumed.
-__device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, uint32_t *l_pref, uint8_t *l_code) {
+// ITEMS (fast path): l_pref holds the list LENGTHS instead of their prefix sums, and every list is cut into segments of
+// kCsSeg hits, enumerated in l_items as (list << 16 | segment).
+template <bool ITEMS>
+__device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, uint32_t *l_pref, uint8_t *l_code,
+		uint32_t *l_items = nullptr, uint32_t items_cap = 0) {
 	const int k = A.k;
 	const uint8_t *rp = A.reads + (size_t) read * A.q;
 	int first_nul = A.q;
@@ -167,7 +173,7 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 	const int L = R.L;
 	const int n_kmers = L - k + 1;
 	R.n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
-	uint32_t carry = 0, n_valid = 0;
+	uint32_t carry = 0, n_valid = 0, carry_s = 0;
 	constexpr int RB = 4;
 	for (int base = 0; base < n_kmers; base += 64 * RB) {
 		uint2 ef[RB], er[RB];
@@ -201,17 +207,31 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 			n_valid += __popcll(__ballot(valid[r]));
 			const uint32_t both = cf + cr;
 			const uint32_t incl = wave_inclusive_scan(both, lane);
-			if (p < n_kmers) {
-				const uint32_t b0 = carry + incl - both;
-				l_start[2 * p] = sf; l_pref[2 * p] = b0;
-				l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = b0 + cf;
+			if (!ITEMS) {
+				if (p < n_kmers) {
+					const uint32_t b0 = carry + incl - both;
+					l_start[2 * p] = sf; l_pref[2 * p] = b0;
+					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = b0 + cf;
+				}
+			} else {
+				const uint32_t nsf = (cf + kCsSeg - 1) / kCsSeg, nsr = (cr + kCsSeg - 1) / kCsSeg;
+				const uint32_t incl_s = wave_inclusive_scan(nsf + nsr, lane);
+				if (p < n_kmers) {
+					l_start[2 * p] = sf; l_pref[2 * p] = cf;
+					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = cr;
+					uint32_t o = carry_s + incl_s - (nsf + nsr);
+					for (uint32_t sg = 0; sg < nsf; ++sg, ++o) if (o < items_cap) l_items[o] = ((uint32_t) (2 * p) << 16) | sg;
+					for (uint32_t sg = 0; sg < nsr; ++sg, ++o) if (o < items_cap) l_items[o] = ((uint32_t) (2 * p + 1) << 16) | sg;
+				}
+				carry_s += __shfl(incl_s, 63);
 			}
 			carry += __shfl(incl, 63);
 		}
 	}
-	if (lane == 0) l_pref[R.n_lists] = carry;
+	if (!ITEMS && lane == 0) l_pref[R.n_lists] = carry;
 	R.H = carry;
 	R.n_valid = n_valid;
+	R.n_items = carry_s;
 	return R;
 }
 
@@ -283,22 +303,22 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 }
 
 // ---- FAST path ---------------------------------------------------------------------------------------------------
-// One sweep over the position lists with kCsFastHpl loads in flight per lane; the bins stay in registers
-// (kCsFastTrips x kCsFastHpl per lane, i.e. up to kCsFastTrips * 64 * kCsFastHpl hits per read), so the lists are
-// read from HBM exactly once.  Sweep 1: atomicOr into a "bin seen" bit plane; a hit that finds its bit already set
-// is a repeat and goes into the small exact table.  Sweep 2 (registers only): every hit that was the first on its
-// bit adds its vote if -- and only if -- its bin made it into the table.  A bin with >= 2 votes has all but its
-// first vote inserted in sweep 1 and the first one added in sweep 2: exact; bins with a single vote are dropped
-// (never candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
-// Nothing in the sweeps waits on a per-hit LDS round trip: the 16 atomicOr of a trip are issued back to back, the
-// few repeats are appended to a small LDS queue and inserted by the whole wave afterwards; sweep 2 filters the
-// register-resident hits through a bit plane of the table's keys (the plane memory is reused) before probing.
-constexpr int kCsFastHpl = 16;
-constexpr int kCsFastTrips = 6;
-constexpr uint32_t kCsFastMaxHits = (uint32_t) kCsFastTrips * 64u * kCsFastHpl;
-constexpr uint32_t kCsFastQueue = 256;  // LDS queue entries per flush
+// Work item = one segment of up to 8 consecutive hits of ONE position list (constant diagonal correction and strand,
+// two 16-byte loads, no per-hit list walking); a lane owns up to kCsFastItems items, the next item's loads are in
+// flight while the current one votes.  The bins stay in registers, so the lists are read from HBM exactly once.
+// Sweep 1: atomicOr into a "bin seen" bit plane; a hit that finds its bit already set is a repeat and goes (through a
+// small LDS queue, inserted by the whole wave) into the small exact table.  Sweep 2 (registers only): every hit that
+// was the first on its bit adds its vote if -- and only if -- its bin made it into the table (pre-filtered through a
+// bit plane of the table keys that reuses the plane memory).  A bin with >= 2 votes has all but its first vote
+// inserted in sweep 1 and the first one added in sweep 2: exact; bins with a single vote are dropped (never
+// candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
+constexpr int kCsFastItems = 12;   // items per lane -> up to 768 segments (~4 900 typical hits) per read
+constexpr uint32_t kCsFastItemCap = (uint32_t) kCsFastItems * 64u;
+constexpr uint32_t kCsFastQueue = 512;  // LDS queue entries between flushes
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void cs_fast_kernel(CsArgs A) {
+struct __attribute__((packed, aligned(4))) CsU4 { uint32_t x, y, z, w; };
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void cs_fast_kernel(CsArgs A) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	__shared__ uint32_t s_flags[3];  // [0] distinct bins in the small table, [1] abort, [2] queue length
 	__shared__ uint32_t s_queue[kCsFastQueue];
@@ -306,9 +326,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 	const int read = blockIdx.x;
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;
-	uint32_t *l_pref = cs_lds + A.lists_cap;
-	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);
-	uint32_t *plane = (uint32_t *) l_code + (A.q + 3) / 4;
+	uint32_t *l_len = cs_lds + A.lists_cap;
+	uint8_t *l_code = (uint8_t *) (l_len + A.lists_cap + 1);
+	uint32_t *l_items = (uint32_t *) l_code + (A.q + 3) / 4;
+	uint32_t *plane = l_items + kCsFastItemCap;
 	const uint32_t plane_words = 1u << (A.log2_bits - 5);
 	uint32_t *t_keys = plane + plane_words;
 	const int log2_slots = A.log2_slots;
@@ -320,16 +341,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
 	const bool diag = A.phase_cycles && (read & 255) == 0;  // sampled: the global atomics would serialise otherwise
 	const unsigned long long c0 = diag ? wall_clock64() : 0ull;
-	const CsRead R = cs_prepare(A, read, lane, l_start, l_pref, l_code);
+	const CsRead R = cs_prepare<true>(A, read, lane, l_start, l_len, l_code, l_items, kCsFastItemCap);
 	const uint32_t H = R.H;
-	const int L = R.L, n_lists = R.n_lists;
-	if (H > A.hit_cap || H > kCsFastMaxHits) { cs_enqueue(A, read, lane, R); return; }
+	const int L = R.L;
+	if (H > A.hit_cap || R.n_items > kCsFastItemCap) { cs_enqueue(A, read, lane, R); return; }
 	__syncthreads();
 	const unsigned long long c1 = diag ? wall_clock64() : 0ull;
 
 	const int sh = 32 - A.log2_bits;
 	const int hs = 32 - log2_slots;
-	constexpr int HPL = kCsFastHpl;
+	const uint32_t n_items = R.n_items;
 
 	// inserts the queued entries (bin | strand << 31), one per lane per round
 	auto flush_inserts = [&]() {
@@ -354,63 +375,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 		if (lane == 0) s_flags[2] = 0;
 	};
 
-	uint32_t bins[kCsFastTrips * HPL];  // bin | first-on-its-bit << 30 | reverse strand << 31
+	// item -> (hit count << 16 | correction, strand in bit 31) and its positions
+	auto fetch = [&](int it, CsU4 (&d)[kCsSeg / 4]) -> uint32_t {
+		const uint32_t idx = (uint32_t) it * 64u + (uint32_t) lane;
+		uint32_t meta = 0;
+		if (idx < n_items) {
+			const uint32_t item = l_items[idx];
+			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
+			const uint32_t cnt = min((uint32_t) kCsSeg, l_len[li] - sg * kCsSeg);
+			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_start[li] + sg * kCsSeg);
 #pragma unroll
-	for (int t = 0; t < kCsFastTrips; ++t) {
-		if ((uint32_t) t * 64u * HPL >= H) break;  // wave-uniform
-		const uint32_t h0 = (uint32_t) t * 64u * HPL + (uint32_t) lane * HPL;
-		int lo = 0, hi = n_lists;  // largest li with pref[li] <= h0
-		if (h0 < H) {
-			while (hi - lo > 1) {
-				const int mid = (lo + hi) >> 1;
-				if (l_pref[mid] <= h0) lo = mid; else hi = mid;
-			}
+			for (int v = 0; v < kCsSeg / 4; ++v) if ((uint32_t) (4 * v) < cnt) d[v] = src[v];
+			const int p = (int) (li >> 1);
+			// diagonal of the hit (CS.cpp:140-142); bit 31 = reverse-complement list
+			meta = (cnt << 16) | ((li & 1u) ? ((uint32_t) (L - (p + k)) | 0x80000000u) : (uint32_t) p);
 		}
-		// list state, refreshed only when a hit crosses into the next list
-		uint32_t nb = (h0 < H) ? l_pref[lo + 1] : 0xFFFFFFFFu;
-		uint32_t st = (h0 < H) ? l_start[lo] - l_pref[lo] : 0u;
-		uint32_t pos[HPL], cor[HPL];
+		return meta;
+	};
+
+	uint32_t bins[kCsFastItems * kCsSeg];  // bin | first-on-its-bit << 30 | reverse strand << 31 ; 0 = empty slot
+	CsU4 cur[kCsSeg / 4], nxt[kCsSeg / 4];
+	uint32_t meta = fetch(0, cur), meta_n = 0;
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) {
-			const uint32_t h = h0 + j;
-			pos[j] = 0; cor[j] = 0;
-			if (h < H) {
-				while (h >= nb) { ++lo; nb = l_pref[lo + 1]; st = l_start[lo] - l_pref[lo]; }
-				pos[j] = A.positions[st + h];
-				const int p = lo >> 1;
-				// diagonal of the hit (CS.cpp:140-142); bit 31 = reverse-complement list
-				cor[j] = (lo & 1) ? ((uint32_t) (L - (p + k)) | 0x80000000u) : (uint32_t) p;
-			}
+	for (int it = 0; it < kCsFastItems; ++it) {
+		if ((uint32_t) it * 64u >= n_items) {  // wave-uniform
+#pragma unroll
+			for (int j = 0; j < kCsSeg; ++j) bins[it * kCsSeg + j] = 0;
+			continue;
 		}
-		uint32_t old[HPL], msk[HPL];
+		if (it + 1 < kCsFastItems) meta_n = fetch(it + 1, nxt);
+		const uint32_t cnt = (meta >> 16) & 0x1Fu, corr = meta & 0xFFFFu, rev = meta & 0x80000000u;
+		uint32_t old[kCsSeg], msk[kCsSeg], ent[kCsSeg];
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) {
-			old[j] = 0; msk[j] = 0;
-			if (h0 + j < H) {
-				const uint32_t bin = ((pos[j] - (cor[j] & 0x7FFFFFFFu)) >> A.bin_shift) & 0x3FFFFFFFu;
+		for (int j = 0; j < kCsSeg; ++j) {
+			const uint32_t pos = (j & 3) == 0 ? cur[j >> 2].x : (j & 3) == 1 ? cur[j >> 2].y : (j & 3) == 2 ? cur[j >> 2].z : cur[j >> 2].w;
+			old[j] = 0; msk[j] = 0; ent[j] = 0;
+			if ((uint32_t) j < cnt) {
+				const uint32_t bin = ((pos - corr) >> A.bin_shift) & 0x3FFFFFFFu;
 				const uint32_t b = (bin * 0x9E3779B1u) >> sh;
 				msk[j] = 1u << (b & 31);
 				old[j] = atomicOr(&plane[b >> 5], msk[j]);
-				pos[j] = bin | (cor[j] & 0x80000000u);
+				ent[j] = bin | rev;
 			}
 		}
 		uint32_t ndup = 0;
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
+		for (int j = 0; j < kCsSeg; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
 		uint32_t qb = ndup ? atomicAdd(&s_flags[2], ndup) : 0u;
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) {
+		for (int j = 0; j < kCsSeg; ++j) {
 			uint32_t e = 0;
-			if (h0 + j < H) {
-				e = pos[j];
-				if (old[j] & msk[j]) { if (qb < kCsFastQueue) s_queue[qb] = e; ++qb; }
+			if ((uint32_t) j < cnt) {
+				e = ent[j];
+				if (old[j] & msk[j]) { if (qb < kCsFastQueue) s_queue[qb] = e; ++qb; e = 0; }  // voted in sweep 1: nothing left to do
 				else e |= 0x40000000u;
 			}
-			bins[t * HPL + j] = e;
+			bins[it * kCsSeg + j] = e;
 		}
 		__syncthreads();
-		if (s_flags[2] > kCsFastQueue) s_flags[1] = 1;  // more repeats than the queue holds: leave it to the exact path
-		flush_inserts();
+		const uint32_t fill = s_flags[2];
+		if (fill > kCsFastQueue) s_flags[1] = 1;  // more repeats than the queue holds: leave it to the exact path
+		// insert when the next item round (typically ~100 repeats) might not fit any more, and after the last one
+		if (fill > kCsFastQueue - 160 || (uint32_t) (it + 1) * 64u >= n_items || it + 1 == kCsFastItems) flush_inserts();
+		if (it + 1 < kCsFastItems) {
+			meta = meta_n;
+#pragma unroll
+			for (int v = 0; v < kCsSeg / 4; ++v) cur[v] = nxt[v];
+		}
 	}
 	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
 	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }  // not provably exact here
@@ -426,26 +457,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 		}
 	}
 	__syncthreads();
+	uint32_t nhit = 0;
+	uint32_t wmask[kCsFastItems];
 #pragma unroll
-	for (int t = 0; t < kCsFastTrips; ++t) {
-		if ((uint32_t) t * 64u * HPL >= H) break;
-		uint32_t w[HPL];
+	for (int it = 0; it < kCsFastItems; ++it) {
+		wmask[it] = 0;
+		if ((uint32_t) it * 64u >= n_items) continue;
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) {
-			const uint32_t e = bins[t * HPL + j];
+		for (int j = 0; j < kCsSeg; ++j) {
+			const uint32_t e = bins[it * kCsSeg + j];
 			const uint32_t b = ((e & 0x3FFFFFFFu) * 0x9E3779B1u) >> sh;
-			w[j] = (e & 0x40000000u) ? (plane[b >> 5] >> (b & 31)) & 1u : 0u;
+			const uint32_t w = (e & 0x40000000u) ? (plane[b >> 5] >> (b & 31)) & 1u : 0u;
+			wmask[it] |= w << j;
 		}
-		uint32_t nhit = 0;
+		nhit += __popc(wmask[it]);
+	}
+	uint32_t qb = nhit ? atomicAdd(&s_flags[2], nhit) : 0u;
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) nhit += w[j];
-		uint32_t qb = nhit ? atomicAdd(&s_flags[2], nhit) : 0u;
+	for (int it = 0; it < kCsFastItems; ++it) {
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) if (w[j]) { if (qb < kCsFastQueue) s_queue[qb] = bins[t * HPL + j]; ++qb; }
-		__syncthreads();
-		if (s_flags[2] > kCsFastQueue) s_flags[1] = 1;
+		for (int j = 0; j < kCsSeg; ++j) if ((wmask[it] >> j) & 1u) { if (qb < kCsFastQueue) s_queue[qb] = bins[it * kCsSeg + j]; ++qb; }
+	}
+	__syncthreads();
+	if (s_flags[2] > kCsFastQueue) s_flags[1] = 1;
+	{
 		// add the votes of the queued first hits whose bin is in the table (a set bit may also be a collision)
-		__syncthreads();
 		const uint32_t nq = min(s_flags[2], kCsFastQueue);
 		for (uint32_t i = lane; i < nq; i += 64) {
 			const uint32_t e = s_queue[i];
@@ -458,14 +494,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 				slot = (slot + 1) & (n_slots - 1);
 			}
 		}
-		__syncthreads();
-		if (lane == 0) s_flags[2] = 0;
-		__syncthreads();
 	}
+	__syncthreads();
 	const unsigned long long c3 = diag ? wall_clock64() : 0ull;
 	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }
 	if (!cs_finish<kCsFast>(A, read, lane, R, t_keys, t_votes, n_slots)) cs_enqueue(A, read, lane, R);
-	if (diag && lane == 0) {  // diagnostics: 100 MHz ticks spent per phase, summed over reads
+	if (diag && lane == 0) {  // diagnostics: 100 MHz ticks spent per phase, summed over the sampled reads
 		atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);
 		atomicAdd(&A.phase_cycles[3], wall_clock64() - c3);
 	}
@@ -495,7 +529,7 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	}
 	uint32_t n_slots = 1u << log2_slots;
 
-	const CsRead R = cs_prepare(A, read, lane, l_start, l_pref, l_code);
+	const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
 	const uint32_t H = R.H;
 	const int L = R.L;
 	if (MODE != kCsExactGlobal && H > A.hit_cap) { cs_enqueue(A, read, lane, R); return; }

@@ -3,6 +3,8 @@
 // One ngm_mapper is what one NextGenMap CS thread owns (CS + ScoreBuffer + AlignmentBuffer + IAlignment,
 // src/CS.cpp:455-461); everything between the read upload and the traceback download stays in HBM.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -39,6 +41,11 @@ struct ngm_mapper {
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
+	// pinned staging for the per-batch downloads
+	ngm::PinnedBuf<uint32_t> p_winner, p_loc, p_sv;
+	ngm::PinnedBuf<int32_t> p_mapq, p_nbest, p_rec;
+	ngm::PinnedBuf<float> p_best, p_scores;
+	ngm::PinnedBuf<uint16_t> p_runs;
 	// batch state in HBM
 	ngm::DevBuf<uint8_t> d_reads;
 	ngm::DevBuf<uint16_t> d_read_len;
@@ -72,7 +79,7 @@ struct DevGuard {
 
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (mode == ngm::kCsFast) w += (size_t) 1 << (A.log2_bits - 5);
+	if (mode == ngm::kCsFast) w += ((size_t) 1 << (A.log2_bits - 5)) + ngm::kCsFastItemCap;
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -201,9 +208,10 @@ int upload_reads(ngm_mapper *m, int n, const char *reads) {
 
 // the host tail of a batch (CIGAR / MD strings, coordinate conversion) is embarrassingly parallel over reads;
 // NextGenMap does it on its CS threads, here a batch is fanned out over the host cores
+std::atomic<int> g_live_mappers{0};  // mapper instances share the host cores
 template <typename F>
 void parallel_for(int n, F f) {
-	int nt = (int) std::thread::hardware_concurrency();
+	int nt = (int) std::thread::hardware_concurrency() / std::max(1, g_live_mappers.load());
 	if (const char *e = getenv("NGM_HIP_HOST_THREADS")) nt = atoi(e);
 	nt = std::max(1, std::min(nt, 64));
 	if (n < 4096 || nt == 1) { f(0, n); return; }
@@ -287,6 +295,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	ngm_hip_ctx *eng = ngm_hip_create(ref->device, &ep);
 	if (!eng) { ngm::pipeline_set_error("%s", ngm_hip_last_error(nullptr)); return nullptr; }
 	ngm_mapper *m = new ngm_mapper();
+	++g_live_mappers;
 	m->ref = ref; m->prm = *p; m->eng = eng; m->st = eng->stream;
 	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
@@ -315,6 +324,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 
 void ngm_mapper_destroy(ngm_mapper *m) {
 	if (!m) return;
+	--g_live_mappers;
 	DevGuard g(m->ref->device);
 	(void) hipStreamSynchronize(m->st);
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
@@ -325,6 +335,8 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
 	m->d_counters.release();
+	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
+	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	ngm_hip_destroy(m->eng);
 	delete m;
 }
@@ -380,12 +392,28 @@ int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const vo
 
 // ScoreBuffer::top1PE + CheckPairs (src/ScoreBuffer.cpp:368-502) for one pair; `a` = the mate whose scores arrive last
 // (the odd read id: "read"), `b` = its mate.  Candidates are (pair index) lists into loc/score.
-static void select_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
-		const uint32_t *loc, const float *score, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found) {
+static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
+		const uint32_t *loc, const uint32_t *sv, const float *score, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found) {
+	if (cnt_a == 1 && cnt_b == 1) {  // the common case: one candidate per mate
+		*mq_a = *mq_b = 60;
+		const uint64_t l1 = loc[base_a], l2 = loc[base_b];
+		const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
+		const int min_d1 = m->prm.min_insert_size, max_d1 = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
+		const float ps = score[base_a] + score[base_b];
+		*found = cur > min_d1 && cur < max_d1 && ps > 0.0f;
+		if (*found) { dist_sum += cur; dist_count += 1; *win_a = (int) base_a; *win_b = (int) base_b; *equal_out = 0; }
+		return;
+	}
 	auto sorted = [&](uint32_t base, uint32_t cnt) {
 		std::vector<uint32_t> v(cnt);
 		std::iota(v.begin(), v.end(), base);
-		std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });  // sortLocationScore
+		// sortLocationScore; equal scores in (position, strand) order so that the result does not depend on the order
+		// in which the search happened to emit the candidates
+		std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) {
+			if (score[x] != score[y]) return score[x] > score[y];
+			if (loc[x] != loc[y]) return loc[x] < loc[y];
+			return (sv[x] & 1u) < (sv[y] & 1u);
+		});
 		return v;
 	};
 	auto mq_of = [&](const std::vector<uint32_t> &v) {  // computeMQ(MappedRead*), ScoreBuffer.cpp:42-49
@@ -414,7 +442,7 @@ static void select_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_
 				const float ps = score[A[i]] + score[B[j]];
 				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; }
 				else if (ps == top) {
-					const int avg = (int) (m->pair_dist_sum / m->pair_dist_count);
+					const int avg = (int) (dist_sum / dist_count);
 					if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
 					else if (abs(distance) == abs(cur)) equal += 1;
 				}
@@ -424,8 +452,8 @@ static void select_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_
 	}
 	*found = top > 0.0f;
 	if (*found) {
-		m->pair_dist_sum += distance;
-		m->pair_dist_count += 1;
+		dist_sum += distance;
+		dist_count += 1;
 		*win_a = ta; *win_b = tb; *equal_out = equal;
 	}
 }
@@ -445,16 +473,24 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	ngm::DevBuf<uint8_t> own = m->d_reads;
 	struct Restore { ngm_mapper *m; ngm::DevBuf<uint8_t> own; bool on; ~Restore() { if (on) m->d_reads = own; } } restore{m, own, d_reads_ext != nullptr};
 	if (d_reads_ext) { m->d_reads.p = (uint8_t *) d_reads_ext; m->d_reads.cap = (size_t) n * q; }
+	const bool host_timing = getenv("NGM_HIP_HOST_TIMING") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	auto tp0 = now();
+	double t_stage[6] = {0, 0, 0, 0, 0, 0};
+	auto lap = [&](int k) { auto t = now(); t_stage[k] += std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; };
 	MAP_HIP_TRY(hipEventRecord(m->ev[0], m->st));
 	if (!d_reads_ext) if (int rc = upload_reads(m, n, reads)) return rc;
 	if (int rc = run_cs(m, n)) return rc;
 	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
 	const uint64_t np = m->n_cand;
+	lap(0);
 
-	std::vector<uint32_t> h_winner(n, 0xFFFFFFFFu);
-	std::vector<int32_t> h_mapq(n, 0), h_nbest(n, 0);
-	std::vector<float> h_best(n, 0.f);
-	std::vector<uint32_t> h_loc, h_sv;
+	if (m->p_winner.reserve(n) || m->p_mapq.reserve(n) || m->p_nbest.reserve(n) || m->p_best.reserve(n) || m->p_loc.reserve(np + 1) ||
+			m->p_sv.reserve(np + 1) || (paired && m->p_scores.reserve(np + 1))) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+	uint32_t *h_winner = m->p_winner.p, *h_loc = m->p_loc.p, *h_sv = m->p_sv.p;
+	int32_t *h_mapq = m->p_mapq.p, *h_nbest = m->p_nbest.p;
+	float *h_best = m->p_best.p, *h_scores = m->p_scores.p;
+	if (np == 0) for (int i = 0; i < n; ++i) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; h_nbest[i] = 0; h_best[i] = 0.f; }
 	std::vector<int> pair_flags(n, 0);
 	if (np > 0) {
 		// ---- score stage: all candidates of the batch in one BatchScore -------------------------------------
@@ -474,49 +510,55 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				m->d_scores.p, m->d_out_loc.p, m->d_out_sv.p, m->d_winner.p, m->d_mapq.p, m->d_nbest.p, m->d_best.p);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->ev[4], m->st));
-		MAP_HIP_TRY(hipMemcpyAsync(h_winner.data(), m->d_winner.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
-		MAP_HIP_TRY(hipMemcpyAsync(h_mapq.data(), m->d_mapq.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
-		MAP_HIP_TRY(hipMemcpyAsync(h_nbest.data(), m->d_nbest.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
-		MAP_HIP_TRY(hipMemcpyAsync(h_best.data(), m->d_best.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
-		h_loc.resize(np); h_sv.resize(np);
-		MAP_HIP_TRY(hipMemcpyAsync(h_loc.data(), m->d_out_loc.p, np * 4, hipMemcpyDeviceToHost, m->st));
-		MAP_HIP_TRY(hipMemcpyAsync(h_sv.data(), m->d_out_sv.p, np * 4, hipMemcpyDeviceToHost, m->st));
-		std::vector<float> h_scores;
-		if (paired) {
-			h_scores.resize(np);
-			MAP_HIP_TRY(hipMemcpyAsync(h_scores.data(), m->d_scores.p, np * 4, hipMemcpyDeviceToHost, m->st));
-		}
+		MAP_HIP_TRY(hipMemcpyAsync(h_winner, m->d_winner.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_mapq, m->d_mapq.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_nbest, m->d_nbest.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_best, m->d_best.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_loc, m->d_out_loc.p, np * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_sv, m->d_out_sv.p, np * 4, hipMemcpyDeviceToHost, m->st));
+		if (paired) MAP_HIP_TRY(hipMemcpyAsync(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		lap(1);
 		if (paired) {
-			// pairs in input order, like one CS thread of the reference (the running mean insert size is sequential state)
-			for (int p = 0; p + 1 < n; p += 2) {
-				const int rb = p, ra = p + 1;
-				const uint32_t ca = m->h_count[ra], cb = m->h_count[rb];
-				if (ca == 0 || cb == 0) continue;  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
-				int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
-				bool found = false;
-				select_pair(m, m->h_base[ra], ca, (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], cb, (int) strnlen(reads + (size_t) rb * q, q),
-						h_loc.data(), h_scores.data(), &wa, &wb, &mqa, &mqb, &equal, &found);
-				if (found) {
-					h_winner[ra] = (uint32_t) wa; h_winner[rb] = (uint32_t) wb;
-					h_mapq[ra] = mqa; h_mapq[rb] = mqb;
-					h_nbest[ra] = h_nbest[rb] = equal;
-					h_best[ra] = h_scores[wa]; h_best[rb] = h_scores[wb];
-					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED;
-				} else {
-					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;  // no pair inside the window: single-end selection stands
+			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is
+			// sequential state of one CS thread in the reference; here every host thread continues from the value at
+			// the start of the batch and the increments are merged afterwards (NGM_HIP_HOST_THREADS=1: strictly sequential).
+			const long sum0 = m->pair_dist_sum, cnt0 = m->pair_dist_count;
+			std::atomic<long> add_sum{0}, add_cnt{0};
+			parallel_for(n / 2, [&](int plo, int phi) {
+				long dsum = sum0, dcnt = cnt0;
+				for (int pi = plo; pi < phi; ++pi) {
+					const int rb = 2 * pi, ra = 2 * pi + 1;
+					const uint32_t ca = m->h_count[ra], cb = m->h_count[rb];
+					if (ca == 0 || cb == 0) continue;  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
+					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
+					bool found = false;
+					select_pair(m, dsum, dcnt, m->h_base[ra], ca, (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], cb,
+							(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, &wa, &wb, &mqa, &mqb, &equal, &found);
+					if (found) {
+						h_winner[ra] = (uint32_t) wa; h_winner[rb] = (uint32_t) wb;
+						h_mapq[ra] = mqa; h_mapq[rb] = mqb;
+						h_nbest[ra] = h_nbest[rb] = equal;
+						h_best[ra] = h_scores[wa]; h_best[rb] = h_scores[wb];
+						pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED;
+					} else {
+						pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;  // no pair inside the window: single-end selection stands
+					}
 				}
-			}
+				add_sum += dsum - sum0; add_cnt += dcnt - cnt0;
+			});
+			m->pair_dist_sum += add_sum.load(); m->pair_dist_count += add_cnt.load();
 		}
 	}
-
+	lap(2);
 	// ---- alignment stage: one pair per read that has a winner (AlignmentBuffer::DoRun) --------------------
-	std::vector<uint32_t> a_read, a_loc, a_sv;
-	for (int i = 0; i < n; ++i) if (h_winner[i] != 0xFFFFFFFFu) { a_read.push_back(i); a_loc.push_back(h_loc[h_winner[i]]); a_sv.push_back(h_sv[h_winner[i]]); }
-	const int na = (int) a_read.size();
+	std::vector<uint32_t> a_read(n), a_loc(n), a_sv(n);
+	int na = 0;
+	for (int i = 0; i < n; ++i) if (h_winner[i] != 0xFFFFFFFFu) { a_read[na] = i; a_loc[na] = h_loc[h_winner[i]]; a_sv[na] = h_sv[h_winner[i]]; ++na; }
 	const int rs = ngm::run_stride(q, c);
-	std::vector<int32_t> h_rec((size_t) na * 8);
-	std::vector<uint16_t> h_runs;
+	if (m->p_rec.reserve((size_t) na * 8 + 8)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+	int32_t *h_rec = m->p_rec.p;
+	uint16_t *h_runs = nullptr;
 	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
 	if (na > 0) {
 		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
@@ -542,13 +584,15 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				m->d_runs_c.p, m->d_total.p);
 		MAP_HIP_TRY(hipGetLastError());
 		unsigned long long n_runs_total = 0;
-		MAP_HIP_TRY(hipMemcpyAsync(h_rec.data(), m->d_records.p, h_rec.size() * 4, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(h_rec, m->d_records.p, (size_t) na * 8 * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(&n_runs_total, m->d_total.p, 8, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
-		h_runs.resize(n_runs_total + 1);
-		MAP_HIP_TRY(hipMemcpy(h_runs.data(), m->d_runs_c.p, n_runs_total * 2, hipMemcpyDeviceToHost));
+		if (m->p_runs.reserve(n_runs_total + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+		h_runs = m->p_runs.p;
+		MAP_HIP_TRY(hipMemcpy(h_runs, m->d_runs_c.p, n_runs_total * 2, hipMemcpyDeviceToHost));
 	}
 
+	lap(3);
 	// ---- host: CIGAR / MD, final positions --------------------------------------------------------------
 	parallel_for(n, [&](int lo, int hi) {
 		for (int i = lo; i < hi; ++i) {
@@ -602,6 +646,10 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		}
 	});
 
+	lap(4);
+	if (host_timing)
+		fprintf(stderr, "[ngm-hip] host wall ms: candidate search %.1f | score stage + downloads %.1f | pair selection %.1f | align stage + downloads %.1f | CIGAR/positions %.1f\n",
+				t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4]);
 	// kernel times
 	auto et = [&](int a, int b) { float t = 0; if (hipEventElapsedTime(&t, m->ev[a], m->ev[b]) != hipSuccess) t = 0; return t; };
 	m->ms[0] = m->cs_kernel_ms;  // sum of the candidate-search kernel launches only

@@ -153,7 +153,7 @@ int build_index(ngm_ref *r) {
 	REF_HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(n, 1) * 4));
 	REF_HIP_TRY(hipMalloc(&d_vals, std::max<uint64_t>(n, 1) * 4));
 	REF_HIP_TRY(hipMalloc(&d_keys2, std::max<uint64_t>(n, 1) * 4));
-	REF_HIP_TRY(hipMalloc(&r->d_positions, std::max<uint64_t>(n, 1) * 4));
+	REF_HIP_TRY(hipMalloc(&r->d_positions, (std::max<uint64_t>(n, 1) + 16) * 4));  // the search reads 16-entry segments
 	REF_HIP_TRY(hipMalloc(&d_starts, (size_t) n_kmers * 4));
 	REF_HIP_TRY(hipMalloc(&r->d_raw_counts, (size_t) n_kmers * 4));
 	REF_HIP_TRY(hipMalloc(&r->d_index, (size_t) n_kmers * sizeof(uint2)));
