@@ -82,6 +82,9 @@ typedef struct ngm_mapper_params {
 	int min_insert_size;   /* Config "min_insert_size" (-I), default 0 */
 	int max_insert_size;   /* Config "max_insert_size" (-X), default 1000; <= 0: unlimited (src/NGM.cpp:38-41) */
 	float pair_score_cutoff; /* Config "pair_score_cutoff"; <= 0: 0.9 */
+	/* ScoreBuffer::topNSE (src/ScoreBuffer.cpp:279-327), single-end only as in the reference */
+	int topn;              /* Config "topn" (-n): alignments reported per read; <= 1: one */
+	int strata;            /* Config "strata": only the equally best ones, none if there are more than topn */
 } ngm_mapper_params;
 
 ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p);
@@ -119,7 +122,9 @@ typedef struct ngm_hit {
 #define NGM_PAIR_SELECTED 1  /* top1PE found a pair inside the insert-size window; n_best = pairs sharing its score and distance */
 #define NGM_PAIR_FAILED 2    /* both mates had candidates but no such pair: NGMNames::PairedFail, mates selected single-end */
 
-/* Full single-end path for n reads; cigars/mds: n rows of 4*qry_max_len bytes (NUL-terminated strings). */
+/* Full single-end path for n reads; cigars/mds: n rows of 4*qry_max_len bytes (NUL-terminated strings).
+ * With topn > 1 every read owns topn consecutive entries of hits / rows of cigars and mds (entry k = k-th best
+ * candidate, unused entries have mapped = 0 and n_candidates as usual); mapq and n_best are the read's. */
 int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds);
 /* Same, with the read batch already resident in HBM (d_reads: n rows of qry_max_len bytes, device memory on
  * the mapper's GPU); `reads` is the host copy the CIGAR/MD pass consults.  What bench.py times. */

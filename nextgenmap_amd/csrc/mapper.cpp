@@ -460,6 +460,7 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 
 static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired) {
 	if (!m || n < 0) return -22;
+	if (paired && m->prm.topn > 1) { ngm::pipeline_set_error("Paired end mode with topn > 1 not yet supported."); return -38; }  // ScoreBuffer::topNPE
 	if (paired && (n & 1)) { ngm::pipeline_set_error("paired-end batches need an even number of reads"); return -22; }
 	if (n == 0) return 0;
 	const ngm_ref *r = m->ref;
@@ -550,11 +551,61 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			m->pair_dist_sum += add_sum.load(); m->pair_dist_count += add_cnt.load();
 		}
 	}
+	const int topn = (!paired && m->prm.topn > 1) ? m->prm.topn : 1;
+	std::vector<uint32_t> tn_pairs;  // topn > 1: per output entry the candidate (pair index) to align, or none
+	if (!paired && np > 0 && (topn > 1 || m->prm.strata)) {
+		if (topn == 1) {  // top1SE with strata: several equally best candidates -> unmapped (ScoreBuffer.cpp:259-276)
+			for (int i = 0; i < n; ++i) if (h_nbest[i] > 1) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; }
+		} else {
+			// ScoreBuffer::topNSE: sort by score, report min(topn, candidates) (strata: the equally best ones only)
+			if (m->p_scores.reserve(np + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+			h_scores = m->p_scores.p;
+			MAP_HIP_TRY(hipMemcpy(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost));
+			tn_pairs.assign((size_t) n * topn, 0xFFFFFFFFu);
+			parallel_for(n, [&](int lo, int hi) {
+				std::vector<uint32_t> v;
+				for (int i = lo; i < hi; ++i) {
+					const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+					if (cnt == 0) continue;
+					v.resize(cnt);
+					std::iota(v.begin(), v.end(), b);
+					std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) {
+						if (h_scores[x] != h_scores[y]) return h_scores[x] > h_scores[y];
+						if (h_loc[x] != h_loc[y]) return h_loc[x] < h_loc[y];
+						return (h_sv[x] & 1u) < (h_sv[y] & 1u);
+					});
+					int ntop = 1;
+					while (ntop < (int) cnt && h_scores[v[0]] == h_scores[v[ntop]]) ++ntop;
+					h_nbest[i] = ntop;
+					int ns = 0;
+					if (ntop <= topn || !m->prm.strata) {
+						ns = m->prm.strata ? ntop : std::min<int>((int) cnt, topn);
+						int mq = 60;  // computeMQ(MappedRead*)
+						if (cnt > 1) { const float bs = h_scores[v[0]], s2 = h_scores[v[1]]; mq = (bs > 0 && s2 >= 0) ? (int) ceilf(60.0f * (bs - s2) / bs) : 0; }
+						h_mapq[i] = mq;
+					} else {
+						h_mapq[i] = 0;
+					}
+					for (int t = 0; t < ns; ++t) tn_pairs[(size_t) i * topn + t] = v[t];
+					h_winner[i] = ns > 0 ? v[0] : 0xFFFFFFFFu;
+					h_best[i] = h_scores[v[0]];
+				}
+			});
+		}
+	}
 	lap(2);
 	// ---- alignment stage: one pair per read that has a winner (AlignmentBuffer::DoRun) --------------------
-	std::vector<uint32_t> a_read(n), a_loc(n), a_sv(n);
+	std::vector<uint32_t> a_read((size_t) n * topn), a_loc((size_t) n * topn), a_sv((size_t) n * topn), a_out((size_t) n * topn), a_pair((size_t) n * topn);
 	int na = 0;
-	for (int i = 0; i < n; ++i) if (h_winner[i] != 0xFFFFFFFFu) { a_read[na] = i; a_loc[na] = h_loc[h_winner[i]]; a_sv[na] = h_sv[h_winner[i]]; ++na; }
+	if (topn == 1 || np == 0) {
+		for (int i = 0; i < n; ++i) if (h_winner[i] != 0xFFFFFFFFu) { a_read[na] = i; a_out[na] = i; a_pair[na] = h_winner[i]; a_loc[na] = h_loc[h_winner[i]]; a_sv[na] = h_sv[h_winner[i]]; ++na; }
+	} else {
+		for (int i = 0; i < n; ++i) for (int t = 0; t < topn; ++t) {
+			const uint32_t w = tn_pairs[(size_t) i * topn + t];
+			if (w == 0xFFFFFFFFu) break;
+			a_read[na] = i; a_out[na] = (uint32_t) (i * topn + t); a_pair[na] = w; a_loc[na] = h_loc[w]; a_sv[na] = h_sv[w]; ++na;
+		}
+	}
 	const int rs = ngm::run_stride(q, c);
 	if (m->p_rec.reserve((size_t) na * 8 + 8)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
 	int32_t *h_rec = m->p_rec.p;
@@ -595,8 +646,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	lap(3);
 	// ---- host: CIGAR / MD, final positions --------------------------------------------------------------
 	parallel_for(n, [&](int lo, int hi) {
-		for (int i = lo; i < hi; ++i) {
-			ngm_hit &h = hits[i];
+		for (int i = lo; i < hi; ++i) for (int t = 0; t < topn; ++t) {
+			const size_t o = (size_t) i * topn + t;
+			ngm_hit &h = hits[o];
 			memset(&h, 0, sizeof(h));
 			h.n_candidates = (int) m->h_count[i];
 			h.max_votes = m->h_maxv[i];
@@ -604,8 +656,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			h.n_best = h_nbest[i];
 			h.score = h_best[i];
 			h.pair_flags = pair_flags[i];
-			cigars[(size_t) i * str_stride] = 0;
-			mds[(size_t) i * str_stride] = 0;
+			cigars[o * str_stride] = 0;
+			mds[o * str_stride] = 0;
 		}
 	});
 	ngm::CigarParams cp{m->prm.match_bonus, -m->prm.mismatch_penalty, m->prm.variant, m->prm.hard_clip, m->prm.silent_clip};
@@ -613,7 +665,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		std::vector<char> win((size_t) q + c + 8), qry((size_t) q + 8);
 		for (int j = lo; j < hi; ++j) {
 			const int i = (int) a_read[j];
-			ngm_hit &h = hits[i];
+			const size_t o = a_out[j];
+			ngm_hit &h = hits[o];
+			if (topn > 1) h.score = h_scores[a_pair[j]];  // AS:i of this candidate
 			const bool rev = a_sv[j] & 1u;
 			h.reverse = rev;
 			const uint64_t offset = (uint64_t) a_loc[j] - (uint64_t) (c >> 1);
@@ -627,8 +681,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				qry[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
 			}
 			ngm_hip_align_out ao{};
-			ao.cigar = cigars + (size_t) i * str_stride;
-			ao.md = mds + (size_t) i * str_stride;
+			ao.cigar = cigars + o * str_stride;
+			ao.md = mds + o * str_stride;
 			if (m->prm.personality == NGM_PERSONALITY_AFFINE) {
 				// EndToEndAffine never touches pBuffer2: the SAM record carries AlignmentBuffer's "!!!" (AlignmentBuffer.cpp:109)
 				ngm::build_cigar_affine(&h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), q, &ao);

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/ngm_hip.h"
@@ -74,7 +75,7 @@ private:
 
 struct Opts {
 	std::string ref, qry, qry1, qry2, out;
-	int paired = 0, min_insert = 0, max_insert = 1000;
+	int paired = 0, min_insert = 0, max_insert = 1000, topn = 1, strata = 0;
 	char pe_delimiter = '/';
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
 	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
@@ -91,7 +92,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, PEDELIM, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, PEDELIM, STRATA, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -109,17 +110,19 @@ Opts parse(int argc, char **argv) {
 		{"min-insert-size", required_argument, 0, 'I'}, {"max-insert-size", required_argument, 0, 'X'}, {"pe-delimiter", required_argument, 0, PEDELIM},
 		{"fast-pairing", no_argument, 0, UNSUPPORTED}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
 		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, UNSUPPORTED}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
-		{"slam-seq", required_argument, 0, UNSUPPORTED}, {"topn", required_argument, 0, UNSUPPORTED}, {"strata", no_argument, 0, UNSUPPORTED},
+		{"slam-seq", required_argument, 0, UNSUPPORTED}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
 		{"argos", no_argument, 0, UNSUPPORTED}, {"vcf", required_argument, 0, UNSUPPORTED}, {"config", required_argument, 0, UNSUPPORTED},
 		{0, 0, 0, 0}};
 	int c, idx = 0;
-	while ((c = getopt_long(argc, argv, "o:q:r:t:gs:k:lei:R:C:Q:p1:2:I:X:", lo, &idx)) != -1) {
+	while ((c = getopt_long(argc, argv, "o:q:r:t:gs:k:lei:R:C:Q:p1:2:I:X:n:", lo, &idx)) != -1) {
 		switch (c) {
 		case 'r': o.ref = optarg; break;
 		case 'q': o.qry = optarg; break;
 		case '1': o.qry1 = optarg; break;
 		case '2': o.qry2 = optarg; break;
 		case 'p': o.paired = 1; break;
+		case 'n': o.topn = std::max(1, atoi(optarg)); break;
+		case STRATA: o.strata = 1; break;
 		case 'I': o.min_insert = atoi(optarg); break;
 		case 'X': o.max_insert = atoi(optarg); break;
 		case PEDELIM: o.pe_delimiter = optarg[0]; break;
@@ -164,6 +167,7 @@ Opts parse(int argc, char **argv) {
 	if (o.ref.empty()) die("no reference given (-r/--ref)");
 	if (!o.qry1.empty() && !o.qry2.empty()) o.paired = 1;  // Config.cpp:395-399
 	else if (!o.qry1.empty() || !o.qry2.empty()) die("--qry1 and --qry2 must be given together");
+	if (o.paired && o.topn > 1) die("Paired end mode with topn > 1 not yet supported.");  // ScoreBuffer::topNPE
 	if (o.paired && o.qry.empty() && o.qry1.empty()) die("-p/--paired needs -q (interleaved mates) or --qry1/--qry2");
 	// scoring defaults depend on the personality (Config.cpp:433-446)
 	if (o.gap_read < 0) o.gap_read = o.affine ? 33 : 20;
@@ -230,6 +234,7 @@ int main(int argc, char **argv) {
 	mp.hard_clip = o.hard_clip; mp.silent_clip = o.silent_clip;
 	mp.personality = o.affine ? NGM_PERSONALITY_AFFINE : NGM_PERSONALITY_LINEAR; mp.gap_extend_penalty = o.gap_extend;
 	mp.min_insert_size = o.min_insert; mp.max_insert_size = o.max_insert; mp.pair_score_cutoff = 0.9f;
+	mp.topn = o.topn; mp.strata = o.strata;
 	if (o.paired) info("INPUT", "Input is paired end data.");
 
 	// ---- sensitivity (ReadProvider.cpp:310-385) -----------------------------------------------------------
@@ -294,7 +299,13 @@ int main(int argc, char **argv) {
 	const int max_insert = o.max_insert > 0 ? o.max_insert : 2147483647;
 
 	struct View { const Read *r; const ngm_hit *h; const char *row; int L; const char *cigar, *md; };
-	auto view = [&](int i) { View v{&batch[i], &hits[i], &rows[(size_t) i * q], 0, &cig[(size_t) i * stride], &md[(size_t) i * stride]}; v.L = (int) strnlen(v.row, q); return v; };
+	const int topn = o.paired ? 1 : o.topn;
+	auto view = [&](int i, int t = 0) {
+		const size_t e = (size_t) i * topn + t;
+		View v{&batch[i], &hits[e], &rows[(size_t) i * q], 0, &cig[e * stride], &md[e * stride]};
+		v.L = (int) strnlen(v.row, q);
+		return v;
+	};
 	auto passes = [&](const View &v) {  // GenericReadWriter.h:205-215, :262-273
 		float min_res = o.min_residues;
 		if (min_res <= 1.0f) min_res = v.L * min_res;
@@ -335,7 +346,7 @@ int main(int argc, char **argv) {
 		if (n == 0) return;
 		rows.assign((size_t) n * q, 0);
 		for (int i = 0; i < n; ++i) pack_row(batch[i], q, &rows[(size_t) i * q]);
-		hits.resize(n); cig.resize((size_t) n * stride); md.resize((size_t) n * stride);
+		hits.resize((size_t) n * topn); cig.resize((size_t) n * topn * stride); md.resize((size_t) n * topn * stride);
 		const int rc = o.paired ? ngm_mapper_map_pe(m, n, rows.data(), hits.data(), cig.data(), md.data())
 		                        : ngm_mapper_map_se(m, n, rows.data(), hits.data(), cig.data(), md.data());
 		if (rc < 0) die(ngm_pipeline_last_error());
@@ -344,9 +355,26 @@ int main(int argc, char **argv) {
 				const View v = view(i);
 				if (v.r->seq.empty()) continue;  // NGMNames::Empty reads are discarded (GenericReadWriter.h:245-247)
 				++n_total;
-				if (!passes(v)) { write_unmapped(v, 0, -1, 0, '*', 0); continue; }
-				++n_mapped;
-				write_mapped(v, 0, "*", 0, 0);
+				if (topn == 1) {
+					if (!passes(v)) { write_unmapped(v, 0, -1, 0, '*', 0); continue; }
+					++n_mapped;
+					write_mapped(v, 0, "*", 0, 0);
+					continue;
+				}
+				// GenericReadWriter::WriteRead with several alignments (GenericReadWriter.h:199-243): every alignment that
+				// passes the filters, one record per distinct location, 0x100 on all but candidate 0
+				bool once = false;
+				std::vector<std::tuple<int, unsigned long long, int>> seen;
+				for (int t = 0; t < topn; ++t) {
+					const View vt = view(i, t);
+					if (!passes(vt)) continue;
+					once = true;
+					const auto key = std::make_tuple(vt.h->contig, (unsigned long long) vt.h->pos, vt.h->reverse);
+					if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
+					seen.push_back(key);
+					write_mapped(vt, t ? 0x100 : 0, "*", 0, 0);
+				}
+				if (once) ++n_mapped; else write_unmapped(v, 0, -1, 0, '*', 0);
 			}
 		} else {
 			for (int i = 0; i + 1 < n; i += 2) {

@@ -16,7 +16,8 @@ class MapperParams(C.Structure):
                 ("gap_read_penalty", C.c_int), ("gap_ref_penalty", C.c_int), ("mode", C.c_int), ("variant", C.c_int),
                 ("sensitivity", C.c_float), ("kmer_min", C.c_float), ("max_cmrs", C.c_int), ("max_kfreq", C.c_int),
                 ("hard_clip", C.c_int), ("silent_clip", C.c_int), ("personality", C.c_int), ("gap_extend_penalty", C.c_int),
-                ("min_insert_size", C.c_int), ("max_insert_size", C.c_int), ("pair_score_cutoff", C.c_float)]
+                ("min_insert_size", C.c_int), ("max_insert_size", C.c_int), ("pair_score_cutoff", C.c_float),
+                ("topn", C.c_int), ("strata", C.c_int)]
 
 
 HIT_DTYPE = np.dtype([("mapped", "i4"), ("contig", "i4"), ("pos", "u8"), ("reverse", "i4"), ("mapq", "i4"),
@@ -163,13 +164,15 @@ class Mapper:
 
     def __init__(self, ref, qry_max_len, corridor, sensitivity=0.5, match=10, mismatch=15, gap_read=20, gap_ref=20,
                  mode=0, variant=0, kmer_min=0.0, max_cmrs=2 ** 31 - 1, max_kfreq=0, hard_clip=0, silent_clip=0, personality=0,
-                 gap_extend=0, min_insert_size=0, max_insert_size=1000, pair_score_cutoff=0.9):
+                 gap_extend=0, min_insert_size=0, max_insert_size=1000, pair_score_cutoff=0.9, topn=1,
+                 strata=0):
         self.lib = _lib()
         self.ref = ref
         self.q, self.c = qry_max_len, corridor
         p = MapperParams(qry_max_len, corridor, match, mismatch, gap_read, gap_ref, mode, variant, sensitivity, kmer_min,
                          max_cmrs, max_kfreq, hard_clip, silent_clip, personality, gap_extend, min_insert_size, max_insert_size,
-                         pair_score_cutoff)
+                         pair_score_cutoff, topn, strata)
+        self.topn = max(1, topn)
         self.h = self.lib.ngm_mapper_create(ref.h, C.byref(p))
         if not self.h:
             raise _err()
@@ -228,7 +231,8 @@ class Mapper:
         n = rows.shape[0]
         stride = 4 * max(1, self.q)
         if out is None:
-            out = (np.zeros(n, HIT_DTYPE), np.zeros((n, stride), np.uint8), np.zeros((n, stride), np.uint8))
+            no = n * (1 if paired else self.topn)
+            out = (np.zeros(no, HIT_DTYPE), np.zeros((no, stride), np.uint8), np.zeros((no, stride), np.uint8))
         hits, cig, md = out
         dp = None if d_rows is None else (d_rows.data_ptr() if hasattr(d_rows, "data_ptr") else int(d_rows))
         fn = self.lib.ngm_mapper_map_pe_resident if paired else self.lib.ngm_mapper_map_se_resident

@@ -194,3 +194,60 @@ def test_cli_paired_end_sam_equals_reference_program(tmp_path, layout):
         flags[a[n]["flag"]] = flags.get(a[n]["flag"], 0) + 1
     print("flag histogram of the reference:", sorted(flags.items()))
     assert len(diff) <= 0.01 * len(a), (len(diff), diff[:3])
+
+
+def _sam_multi(path):
+    recs = {}
+    for line in open(path):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        recs.setdefault(f[0], []).append((int(f[1]), f[2], int(f[3]), int(f[4]), f[5], tags.get("AS"), tags.get("NM"), tags.get("NH"), tags.get("XI")))
+    return {k: sorted(v) for k, v in recs.items()}
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+@pytest.mark.parametrize("extra", [["-n", "3"], ["-n", "2", "--strata"], ["--strata"]], ids=["top3", "top2-strata", "top1-strata"])
+def test_cli_topn_sam_equals_reference_program(tmp_path, extra):
+    """ScoreBuffer::topNSE / strata and the multi-alignment writer against `ngm --affine -n N [--strata]`; a repeat-rich
+    genome so that many reads have several candidates."""
+    contigs = S.make_genome([200000, 150001], seed=61, repeat_families=12, repeat_len=600, copies=8, divergence=0.03)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    reads = S.make_reads(contigs, 3000, 100, seed=62, sub_rate=0.02, indel_rate=0.003)
+    fq = str(tmp_path / "reads.fq")
+    S.write_fastq(fq, reads)
+    d1 = tmp_path / "refrun"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    r = RF.run_ngm(["-r", fa1, "-q", fq, "-o", str(d1 / "out.sam"), "--affine", "-t", "1", "--no-progress"] + extra, cwd=str(d1))
+    assert "Done" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-1500:]
+    c = subprocess.run([CLI, "-r", fa, "-q", fq, "-o", str(tmp_path / "hip.sam"), "--affine"] + extra, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    a, b = _sam_multi(str(d1 / "out.sam")), _sam_multi(str(tmp_path / "hip.sam"))
+    assert set(a) == set(b)
+    multi = sum(1 for v in a.values() if len(v) > 1)
+    # which of several EQUALLY scoring repeat copies is reported (and which of them is primary) depends on the order
+    # the candidates are visited in; everything that does not depend on that must agree exactly
+    def profile(v):
+        return sorted((x[5], x[3], x[7]) for x in v), sum(1 for x in v if not x[0] & 0x100)
+    bad_profile = [(n, a[n], b[n]) for n in a if profile(a[n]) != profile(b[n])]
+    distinct = [n for n in a if len({x[5] for x in a[n]}) == len(a[n])]
+
+    def above_cut(v):  # the lowest-scoring record may tie with candidates beyond the -n cut
+        lo = min(int(x[5]) for x in v if x[5] is not None) if any(x[5] is not None for x in v) else None
+        return sorted((x[1:7] + (x[0] & 0x10,)) for x in v if len(v) == 1 or x[5] is None or int(x[5]) != lo)
+    diff = [(n, a[n], b[n]) for n in distinct if above_cut(a[n]) != above_cut(b[n])]
+    print("reads with several records in the reference:", multi, "; score/MAPQ/NH profile differs:", len(bad_profile),
+          "; reads without score ties:", len(distinct), "of which differ:", len(diff))
+    for d in (bad_profile + diff)[:3]:
+        print(str(d)[:600])
+    assert len(bad_profile) <= 0.003 * len(a), bad_profile[:3]
+    assert len(diff) <= 0.01 * len(distinct), diff[:3]
