@@ -31,6 +31,7 @@
 namespace ngm {
 
 enum { kCsFast = 0, kCsExactLds = 1, kCsExactGlobal = 2 };
+constexpr int kCsRegions = 256, kCsCursorStride = 16;
 
 struct CsArgs {
 	const uint8_t *reads;       // n rows of q bytes
@@ -57,10 +58,12 @@ struct CsArgs {
 	float *max_both;        // [n] optional: max over bins of forward + reverse votes (sensitivity estimation)
 	uint32_t *out_loc;      // candidate bin centres (concatenated coordinates)
 	uint32_t *out_sv;       // votes << 1 | strand
-	unsigned long long *out_total;  // allocation cursor
-	unsigned long long out_capacity;
+	// candidate output: kCsRegions independent regions of region_capacity entries, each with its own cursor (a single
+	// cursor would make every read of the batch wait on one L2 atomic); compacted afterwards in read order
+	unsigned long long *out_total;  // [kCsRegions * kCsCursorStride]
+	unsigned long long out_capacity;  // entries per region
 	uint32_t *status;       // [0] output overflow flag, [1] number of queued reads
-	unsigned long long *counters;  // [0] k-mers looked up, [1] hits voted (algorithmic-bytes accounting)
+	unsigned long long *counters;  // per region, stride kCsCursorStride: [0] k-mers looked up, [1] hits voted (algorithmic-bytes accounting)
 	unsigned long long *phase_cycles;  // optional diagnostics (fast path): [0] lists [1] sweep 1 [2] sweep 2 [3] candidates
 	uint32_t *ovf_read;     // [n] queue written by this pass
 	uint32_t *ovf_hits;     // [n]
@@ -264,7 +267,11 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 	const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
 	// the filter dropped bins with a single vote: exact only if those cannot be candidates
 	if (MODE == kCsFast && H > 0 && !(thresh > 1.0f)) return false;
-	if (lane == 0 && A.counters) { atomicAdd(&A.counters[0], (unsigned long long) R.n_valid); atomicAdd(&A.counters[1], (unsigned long long) H); }
+	const uint32_t region = (uint32_t) read & (kCsRegions - 1);
+	if (lane == 0 && A.counters) {
+		atomicAdd(&A.counters[region * kCsCursorStride], (unsigned long long) R.n_valid);
+		atomicAdd(&A.counters[region * kCsCursorStride + 1], (unsigned long long) H);
+	}
 	uint32_t count = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) {
 		if (cs_tload<MODE>(&t_keys[s]) != 0xFFFFFFFFu) {
@@ -277,9 +284,9 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 	if ((int64_t) total >= (int64_t) A.max_cmrs) total = 0;  // "if (index < maxScores) AllocScores" (CS.cpp:308-310)
 	unsigned long long base = 0;
 	if (lane == 0) {
-		base = total ? atomicAdd(A.out_total, (unsigned long long) total) : 0ull;
+		base = total ? atomicAdd(&A.out_total[region * kCsCursorStride], (unsigned long long) total) : 0ull;
 		if (base + total > A.out_capacity) { atomicExch(&A.status[0], 1u); }
-		A.cand_base[read] = (uint32_t) base;
+		A.cand_base[read] = (uint32_t) (region * A.out_capacity + base);
 		A.cand_count[read] = total;
 		A.max_votes[read] = max_hit;
 		if (A.max_both) A.max_both[read] = (float) mxb;
@@ -287,7 +294,7 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 	}
 	base = __shfl((uint32_t) base, 0) | ((unsigned long long) __shfl((uint32_t) (base >> 32), 0) << 32);
 	if (total == 0 || base + total > A.out_capacity) return true;
-	uint32_t w = (uint32_t) base + (incl - count);
+	uint32_t w = (uint32_t) (region * A.out_capacity + base) + (incl - count);
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
 	for (uint32_t s = lane; s < n_slots; s += 64) {
 		const uint32_t key = cs_tload<MODE>(&t_keys[s]);
@@ -314,13 +321,13 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 // candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
 constexpr int kCsFastItems = 12;   // items per lane -> up to 768 segments (~4 900 typical hits) per read
 constexpr uint32_t kCsFastItemCap = (uint32_t) kCsFastItems * 64u;
+constexpr int kCsFastDepth = 2;    // segments in flight per lane
 constexpr uint32_t kCsFastQueue = 512;  // LDS queue entries between flushes
 
 struct __attribute__((packed, aligned(4))) CsU4 { uint32_t x, y, z, w; };
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void cs_fast_kernel(CsArgs A) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	__shared__ uint32_t s_flags[3];  // [0] distinct bins in the small table, [1] abort, [2] queue length
 	__shared__ uint32_t s_queue[kCsFastQueue];
 	const int lane = threadIdx.x;
 	const int read = blockIdx.x;
@@ -335,7 +342,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	const int log2_slots = A.log2_slots;
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
-	if (lane < 3) s_flags[lane] = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 
@@ -352,27 +358,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	const int hs = 32 - log2_slots;
 	const uint32_t n_items = R.n_items;
 
+	// wave-uniform bookkeeping lives in registers: queue length, distinct keys in the table, abort flag
+	uint32_t q_len = 0, n_keys = 0;
+	bool abort_fast = false;
+	// queue slots for this lane's `mine` entries: exclusive prefix over the lanes (no LDS counter, no same-address atomics)
+	auto reserve = [&](uint32_t mine) -> uint32_t {
+		const uint32_t incl = wave_inclusive_scan(mine, lane);
+		const uint32_t base = q_len + incl - mine;
+		q_len += __shfl(incl, 63);
+		return base;
+	};
 	// inserts the queued entries (bin | strand << 31), one per lane per round
 	auto flush_inserts = [&]() {
 		__syncthreads();
-		const uint32_t nq = min(s_flags[2], kCsFastQueue);
-		for (uint32_t i = lane; i < nq; i += 64) {
+		const uint32_t nq = min(q_len, kCsFastQueue);
+		if (n_keys + nq >= n_slots) abort_fast = true;  // could fill the table completely: leave the read to the exact path
+		uint32_t fresh = 0;
+		if (!abort_fast) for (uint32_t i = lane; i < nq; i += 64) {
 			const uint32_t e = s_queue[i];
 			const uint32_t bin = e & 0x3FFFFFFFu;
 			uint32_t slot = (bin * 2654435761u) >> hs;
 			for (;;) {
 				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
 				if (prev == bin) break;
-				if (prev == 0xFFFFFFFFu) {
-					if (atomicAdd(&s_flags[0], 1u) > (n_slots * 3u) / 4u) s_flags[1] = 1;
-					break;
-				}
+				if (prev == 0xFFFFFFFFu) { ++fresh; break; }
 				slot = (slot + 1) & (n_slots - 1);
 			}
 			atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
 		}
+		n_keys += __shfl(wave_inclusive_scan(fresh, lane), 63);
+		if (n_keys > (n_slots * 3u) / 4u) abort_fast = true;  // probing gets slow and the spurious entries too many
 		__syncthreads();
-		if (lane == 0) s_flags[2] = 0;
+		q_len = 0;
 	};
 
 	// item -> (hit count << 16 | correction, strand in bit 31) and its positions
@@ -394,8 +411,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	};
 
 	uint32_t bins[kCsFastItems * kCsSeg];  // bin | first-on-its-bit << 30 | reverse strand << 31 ; 0 = empty slot
-	CsU4 cur[kCsSeg / 4], nxt[kCsSeg / 4];
-	uint32_t meta = fetch(0, cur), meta_n = 0;
+	// ring of kCsFastDepth items in flight per lane: the position loads of items it+1 .. it+depth-1 are outstanding
+	// while item it votes (the loop is fully unrolled, so the ring index is a compile-time constant)
+	constexpr int DEPTH = kCsFastDepth;
+	CsU4 ring[DEPTH][kCsSeg / 4];
+	uint32_t rmeta[DEPTH];
+#pragma unroll
+	for (int d = 0; d < DEPTH - 1; ++d) rmeta[d] = fetch(d, ring[d]);
 #pragma unroll
 	for (int it = 0; it < kCsFastItems; ++it) {
 		if ((uint32_t) it * 64u >= n_items) {  // wave-uniform
@@ -403,7 +425,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 			for (int j = 0; j < kCsSeg; ++j) bins[it * kCsSeg + j] = 0;
 			continue;
 		}
-		if (it + 1 < kCsFastItems) meta_n = fetch(it + 1, nxt);
+		if (it + DEPTH - 1 < kCsFastItems) rmeta[(it + DEPTH - 1) % DEPTH] = fetch(it + DEPTH - 1, ring[(it + DEPTH - 1) % DEPTH]);
+		const uint32_t meta = rmeta[it % DEPTH];
+		CsU4 (&cur)[kCsSeg / 4] = ring[it % DEPTH];
 		const uint32_t cnt = (meta >> 16) & 0x1Fu, corr = meta & 0xFFFFu, rev = meta & 0x80000000u;
 		uint32_t old[kCsSeg], msk[kCsSeg], ent[kCsSeg];
 #pragma unroll
@@ -421,7 +445,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		uint32_t ndup = 0;
 #pragma unroll
 		for (int j = 0; j < kCsSeg; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
-		uint32_t qb = ndup ? atomicAdd(&s_flags[2], ndup) : 0u;
+		uint32_t qb = reserve(ndup);
 #pragma unroll
 		for (int j = 0; j < kCsSeg; ++j) {
 			uint32_t e = 0;
@@ -432,19 +456,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 			}
 			bins[it * kCsSeg + j] = e;
 		}
-		__syncthreads();
-		const uint32_t fill = s_flags[2];
-		if (fill > kCsFastQueue) s_flags[1] = 1;  // more repeats than the queue holds: leave it to the exact path
+		const uint32_t fill = q_len;
+		if (fill > kCsFastQueue) abort_fast = true;  // more repeats than the queue holds: leave it to the exact path
 		// insert when the next item round (typically ~100 repeats) might not fit any more, and after the last one
 		if (fill > kCsFastQueue - 160 || (uint32_t) (it + 1) * 64u >= n_items || it + 1 == kCsFastItems) flush_inserts();
-		if (it + 1 < kCsFastItems) {
-			meta = meta_n;
-#pragma unroll
-			for (int v = 0; v < kCsSeg / 4; ++v) cur[v] = nxt[v];
-		}
 	}
 	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
-	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }  // not provably exact here
+	if (abort_fast) { cs_enqueue(A, read, lane, R); return; }  // not provably exact here
 
 	// sweep 2: plane := bits of the bins that are in the table; first-on-bit hits whose bit is set are queued, then added
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
@@ -472,17 +490,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		}
 		nhit += __popc(wmask[it]);
 	}
-	uint32_t qb = nhit ? atomicAdd(&s_flags[2], nhit) : 0u;
+	uint32_t qb = reserve(nhit);
 #pragma unroll
 	for (int it = 0; it < kCsFastItems; ++it) {
 #pragma unroll
 		for (int j = 0; j < kCsSeg; ++j) if ((wmask[it] >> j) & 1u) { if (qb < kCsFastQueue) s_queue[qb] = bins[it * kCsSeg + j]; ++qb; }
 	}
 	__syncthreads();
-	if (s_flags[2] > kCsFastQueue) s_flags[1] = 1;
+	if (q_len > kCsFastQueue) abort_fast = true;
 	{
 		// add the votes of the queued first hits whose bin is in the table (a set bit may also be a collision)
-		const uint32_t nq = min(s_flags[2], kCsFastQueue);
+		const uint32_t nq = min(q_len, kCsFastQueue);
 		for (uint32_t i = lane; i < nq; i += 64) {
 			const uint32_t e = s_queue[i];
 			const uint32_t bin = e & 0x3FFFFFFFu;
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	}
 	__syncthreads();
 	const unsigned long long c3 = diag ? wall_clock64() : 0ull;
-	if (s_flags[1]) { cs_enqueue(A, read, lane, R); return; }
+	if (abort_fast) { cs_enqueue(A, read, lane, R); return; }
 	if (!cs_finish<kCsFast>(A, read, lane, R, t_keys, t_votes, n_slots)) cs_enqueue(A, read, lane, R);
 	if (diag && lane == 0) {  // diagnostics: 100 MHz ticks spent per phase, summed over the sampled reads
 		atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);

@@ -144,6 +144,16 @@ __global__ void expand_pairs_kernel(int n_reads, const uint32_t *__restrict__ ca
 	for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) pair_read[b + j] = (uint32_t) r;
 }
 
+// candidate regions -> one dense array in read order (new_base = exclusive prefix sum of cand_count)
+__global__ void compact_candidates_kernel(int n_reads, const uint32_t *__restrict__ old_base, const uint32_t *__restrict__ new_base,
+		const uint32_t *__restrict__ cand_count, const uint32_t *__restrict__ loc_in, const uint32_t *__restrict__ sv_in,
+		uint32_t *__restrict__ loc_out, uint32_t *__restrict__ sv_out) {
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	const uint32_t ob = old_base[r], nb = new_base[r], n = cand_count[r];
+	for (uint32_t j = 0; j < n; ++j) { loc_out[nb + j] = loc_in[ob + j]; sv_out[nb + j] = sv_in[ob + j]; }
+}
+
 // winners -> compact alignment batch
 __global__ void collect_winners_kernel(int n_reads, const uint32_t *__restrict__ winner, const uint32_t *__restrict__ pair_loc,
 		const uint32_t *__restrict__ pair_sv, const uint32_t *__restrict__ slot_of_read, uint32_t *__restrict__ a_read,

@@ -14,6 +14,9 @@
 #include <thread>
 #include <vector>
 
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
 #include "refindex.h"
 #include "engine_internal.h"
 #include "align_device.h"
@@ -54,6 +57,8 @@ struct ngm_mapper {
 	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes;
 	ngm::DevBuf<float> d_max_votes, d_max_both, d_scores, d_best;
 	ngm::DevBuf<unsigned long long> d_total, d_counters;
+	ngm::DevBuf<uint32_t> d_out_loc2, d_out_sv2, d_new_base;
+	ngm::DevBuf<uint8_t> d_scan_tmp;
 	unsigned long long cs_kmers = 0, cs_hits = 0;
 	float cs_kernel_ms = 0.f;
 	hipEvent_t cev[6] = {};
@@ -90,26 +95,28 @@ int run_cs(ngm_mapper *m, int n) {
 	const ngm_ref *r = m->ref;
 	const int q = m->prm.qry_max_len;
 	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) || m->d_max_both.reserve(n) ||
-			m->d_status.reserve(4) || m->d_total.reserve(1) || m->d_counters.reserve(8) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
+			m->d_status.reserve(4) || m->d_total.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 8) || m->d_counters.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 8) || m->d_new_base.reserve(n) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
 			m->d_ovf_hits.reserve(n)) {
 		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
 		return -12;
 	}
-	size_t cap = std::max<size_t>(m->d_out_loc.cap, (size_t) n * 8 + 1024);
+	const size_t ctr_words = (size_t) ngm::kCsRegions * ngm::kCsCursorStride;
+	size_t cap = std::max<size_t>(m->d_out_loc.cap, (size_t) n * 8 + 64 * ngm::kCsRegions);
+	cap = (cap + ngm::kCsRegions - 1) / ngm::kCsRegions * ngm::kCsRegions;
 	for (int attempt = 0; attempt < 8; ++attempt) {
-		if (m->d_out_loc.reserve(cap) || m->d_out_sv.reserve(cap)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
+		if (m->d_out_loc.reserve(cap) || m->d_out_sv.reserve(cap) || m->d_out_loc2.reserve(cap) || m->d_out_sv2.reserve(cap)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, 8, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, 64, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 8) * 8, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 8) * 8, m->st));
 		ngm::CsArgs A{};
 		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
 		A.index = r->d_index; A.positions = r->d_positions;
 		A.lists_cap = 2 * std::max(1, q - r->prm.kmer + 1);
 		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p; A.max_both = m->d_max_both.p;
-		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap;
+		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap / ngm::kCsRegions;
 		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
-		A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + 4 : nullptr;
+		A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + ctr_words : nullptr;
 		uint32_t status[4];
 		m->cs_kernel_ms = 0;
 		float pass_ms[3] = {0, 0, 0};
@@ -177,20 +184,30 @@ int run_cs(ngm_mapper *m, int n) {
 			timed(4);
 		}
 		if (status[0] == 0) {
-			unsigned long long total = 0;
-			MAP_HIP_TRY(hipMemcpy(&total, m->d_total.p, 8, hipMemcpyDeviceToHost));
-			m->n_cand = total;
+			// regions -> one dense candidate array in read order
+			size_t tmp_bytes = 0;
+			(void) rocprim::exclusive_scan(nullptr, tmp_bytes, m->d_cand_count.p, m->d_new_base.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), m->st);
+			if (m->d_scan_tmp.reserve(tmp_bytes + 16)) { ngm::pipeline_set_error("out of device memory (scan)"); return -12; }
+			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_cand_count.p, m->d_new_base.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), m->st));
+			hipLaunchKernelGGL(ngm::compact_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, m->st, n, m->d_cand_base.p, m->d_new_base.p, m->d_cand_count.p,
+					m->d_out_loc.p, m->d_out_sv.p, m->d_out_loc2.p, m->d_out_sv2.p);
+			MAP_HIP_TRY(hipGetLastError());
+			std::swap(m->d_out_loc, m->d_out_loc2); std::swap(m->d_out_sv, m->d_out_sv2); std::swap(m->d_cand_base, m->d_new_base);
 			m->n_reads = n;
-			unsigned long long ctr[8];
-			MAP_HIP_TRY(hipMemcpy(ctr, m->d_counters.p, 64, hipMemcpyDeviceToHost));
-			m->cs_kmers = ctr[0]; m->cs_hits = ctr[1];
+			std::vector<unsigned long long> ctr(ctr_words + 8);
+			MAP_HIP_TRY(hipMemcpyAsync(ctr.data(), m->d_counters.p, ctr.size() * 8, hipMemcpyDeviceToHost, m->st));
+			m->h_base.resize(n); m->h_count.resize(n); m->h_maxv.resize(n);
+			MAP_HIP_TRY(hipMemcpyAsync(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+			m->n_cand = n > 0 ? (uint64_t) m->h_base[n - 1] + m->h_count[n - 1] : 0;
+			m->cs_kmers = m->cs_hits = 0;
+			for (int g = 0; g < ngm::kCsRegions; ++g) { m->cs_kmers += ctr[(size_t) g * ngm::kCsCursorStride]; m->cs_hits += ctr[(size_t) g * ngm::kCsCursorStride + 1]; }
+			const unsigned long long *ph = ctr.data() + ctr_words;
 			if (A.phase_cycles)
 				fprintf(stderr, "[ngm-hip] cs fast path, 100 MHz ticks per read: lists %.1f sweep1 %.1f sweep2 %.1f candidates %.1f; %u of %d reads re-run by the exact path; kernels %.2f + %.2f + %.2f ms\n",
-						(double) ctr[4] * 256 / n, (double) ctr[5] * 256 / n, (double) ctr[6] * 256 / n, (double) ctr[7] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
-			m->h_base.resize(n); m->h_count.resize(n); m->h_maxv.resize(n);
-			MAP_HIP_TRY(hipMemcpy(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost));
-			MAP_HIP_TRY(hipMemcpy(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost));
-			MAP_HIP_TRY(hipMemcpy(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost));
+						(double) ph[0] * 256 / n, (double) ph[1] * 256 / n, (double) ph[2] * 256 / n, (double) ph[3] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
 			return 0;
 		}
 		cap *= 4;  // candidate buffer too small: grow and redo the batch
@@ -334,7 +351,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
-	m->d_counters.release();
+	m->d_counters.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	ngm_hip_destroy(m->eng);
