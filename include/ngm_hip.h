@@ -62,7 +62,7 @@ extern "C" {
 typedef struct ngm_hip_params {
 	int abi_version;   /* NGM_HIP_ABI_VERSION */
 	int qry_max_len;   /* Config "qry_max_len": bytes per read row, read length <= qry_max_len - 1 */
-	int corridor;      /* Config "corridor": band columns; reference window = qry_max_len + corridor bytes */
+	int corridor;      /* Config "corridor": band columns (2..200); reference window = qry_max_len + corridor bytes */
 	/* NGM config values (positive penalties), src/config/Config.cpp:440-444 */
 	int match_bonus;
 	int mismatch_penalty;
@@ -128,6 +128,13 @@ int ngm_hip_align_device(ngm_hip_ctx *ctx, int mode, int n, const void *d_ref, c
 int ngm_hip_last_kernel_ms(ngm_hip_ctx *ctx, float ms[3]);
 /* Enable/disable the event bracketing above (off by default: no events are recorded). */
 void ngm_hip_set_profiling(ngm_hip_ctx *ctx, int enabled);
+
+/* The band width is a compile-time shape of the DP kernels, as in the reference (its OpenCL kernels are JIT-compiled
+ * with -D corridor_length, lib/mason/opencl/SWOcl.cpp:206-217).  Corridors 8 12 19 20 27 42 80 are built ahead of
+ * time; any other width (<= 200) is compiled by ngm_hip_create with hiprtc, once per process.  This diagnostic compiles
+ * the kernels for `corridor` without touching a device: returns the code-object size in bytes, or -1 with the
+ * compiler log in msg. */
+long ngm_hip_jit_selftest(int corridor, char *msg, int msg_len);
 
 #ifdef __cplusplus
 }

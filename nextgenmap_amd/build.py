@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LIB = os.path.join(HERE, "libngm_hip.so")
-SOURCES = ["ngm_hip.cpp", "ialignment_adapter.cpp", "refindex.cpp", "mapper.cpp"]
+SOURCES = ["ngm_hip.cpp", "jit.cpp", "ialignment_adapter.cpp", "refindex.cpp", "mapper.cpp"]
+JIT_HEADERS = ["sw_device.h", "align_device.h", "affine_device.h"]  # DP kernel templates, also compiled at run time (hiprtc)
 HEADERS = ["ngm_cli.cpp", "engine_internal.h", "sw_device.h", "align_device.h", "cigar_md.h", "refindex.h", "cs_device.h", "gather_device.h", os.path.join("..", "..", "include", "ngm_pipeline.h"), os.path.join("..", "..", "include", "ngm_hip.h"),
            os.path.join("..", "..", "include", "ngm_ialignment.h")]
 
@@ -23,12 +24,31 @@ def _stale():
     return False
 
 
+def write_jit_sources():
+    """csrc/jit_sources.inc: the DP kernel headers as one string for hiprtc (the reference JIT-compiles its kernels with
+    -D corridor_length; here corridors without an ahead-of-time build are compiled on first use)."""
+    parts = []
+    for h in JIT_HEADERS:
+        for line in open(os.path.join(CSRC, h)).read().splitlines():
+            if line.startswith("#include") or line.startswith("#pragma once"):
+                continue
+            parts.append(line)
+    text = "\n".join(parts) + "\n"
+    out = os.path.join(CSRC, "jit_sources.inc")
+    chunks = [text[i:i + 8000] for i in range(0, len(text), 8000)]  # keep every literal well below compiler limits
+    body = "static const char *const kJitSourceChunks[] = {\n" + ",\n".join('R"NGMJIT(' + c + ')NGMJIT"' for c in chunks) + "\n};\n"
+    if not os.path.exists(out) or open(out).read() != body:
+        open(out, "w").write(body)
+    return out
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). Returns the library path."""
+    write_jit_sources()
     if not force and not _stale():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + srcs + ["-lz", "-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + srcs + ["-lz", "-lhiprtc", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

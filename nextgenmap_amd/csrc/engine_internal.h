@@ -10,6 +10,7 @@
 #include "../../include/ngm_hip.h"
 #include "sw_device.h"
 #include "affine_device.h"
+#include "jit.h"
 
 namespace ngm {
 template <typename T>
@@ -51,6 +52,7 @@ struct ngm_hip_ctx {
 	ngm_hip_params prm{};
 	ngm::SwConst K{};
 	ngm::AffConst KA{};
+	const ngm::JitKernels *jit = nullptr;  // run-time compiled DP kernels when the corridor has no ahead-of-time build
 	int q = 0, c = 0, rl = 0, RW = 0, FW = 0;
 	int max_batch = 0;
 	hipStream_t stream = nullptr;

@@ -18,6 +18,7 @@
 #include "align_device.h"
 #include "affine_device.h"
 #include "cigar_md.h"
+#include "jit.h"
 
 namespace {
 
@@ -56,29 +57,37 @@ void set_error(ngm_hip_ctx *ctx, const char *fmt, ...) {
 // 2 * max-consec-indels (src/config/Config.cpp:540-557).
 #define NGM_CORRIDORS(X) X(8) X(12) X(19) X(20) X(27) X(42) X(80)
 
-typedef void (*score_kernel_t)(const uint32_t *, const uint16_t *, const uint16_t *, float *, int, int, int, ngm::SwConst);
-typedef void (*align_kernel_t)(const uint32_t *, const uint16_t *, const uint16_t *, uint32_t *, int32_t *, int, int, int, int, ngm::SwConst);
+// A DP kernel is either one of the ahead-of-time instantiations (host stub) or a function of a run-time compiled module.
+struct KernelRef {
+	const void *aot = nullptr;
+	hipFunction_t jit = nullptr;
+	explicit operator bool() const { return aot || jit; }
+};
 
-score_kernel_t find_score_kernel(int c, bool endfree) {
-#define X(C) if (c == C) return endfree ? ngm::sw_score_kernel<C, true> : ngm::sw_score_kernel<C, false>;
+// kind: 0/1 linear score local/end-to-end, 2/3 linear align, 4/5 affine score, 6/7 affine align (jit.h)
+const void *find_aot_kernel(int c, int kind) {
+#define X(C) if (c == C) switch (kind) { \
+		case 0: return (const void *) ngm::sw_score_kernel<C, false>; case 1: return (const void *) ngm::sw_score_kernel<C, true>; \
+		case 2: return (const void *) ngm::sw_align_kernel<C, false>; case 3: return (const void *) ngm::sw_align_kernel<C, true>; \
+		case 4: return (const void *) ngm::sw_affine_kernel<C + 1, false, false>; case 5: return (const void *) ngm::sw_affine_kernel<C + 1, true, false>; \
+		case 6: return (const void *) ngm::sw_affine_kernel<C + 1, false, true>; default: return (const void *) ngm::sw_affine_kernel<C + 1, true, true>; }
 	NGM_CORRIDORS(X)
 #undef X
 	return nullptr;
 }
-align_kernel_t find_align_kernel(int c, bool endfree) {
-#define X(C) if (c == C) return endfree ? ngm::sw_align_kernel<C, true> : ngm::sw_align_kernel<C, false>;
-	NGM_CORRIDORS(X)
-#undef X
-	return nullptr;
+
+KernelRef find_kernel(ngm_hip_ctx *ctx, int kind) {
+	KernelRef k;
+	k.aot = find_aot_kernel(ctx->c, kind);
+	if (!k.aot && ctx->jit) k.jit = ctx->jit->fn[kind];
+	return k;
 }
 
-typedef void (*affine_kernel_t)(const uint32_t *, const uint16_t *, const uint16_t *, float *, uint32_t *, int32_t *, int, int, int, int, ngm::AffConst);
-affine_kernel_t find_affine_kernel(int c, bool endfree, bool align) {
-#define X(C) if (c == C) return endfree ? (align ? ngm::sw_affine_kernel<C + 1, true, true> : ngm::sw_affine_kernel<C + 1, true, false>) \
-		: (align ? ngm::sw_affine_kernel<C + 1, false, true> : ngm::sw_affine_kernel<C + 1, false, false>);
-	NGM_CORRIDORS(X)
-#undef X
-	return nullptr;
+template <typename... Args>
+hipError_t launch_kernel(const KernelRef &k, dim3 grid, dim3 block, hipStream_t st, Args... args) {
+	void *argv[] = {(void *) &args...};
+	if (k.aot) return hipLaunchKernel(k.aot, grid, block, argv, 0, st);
+	return hipModuleLaunchKernel(k.jit, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, st, argv, nullptr);
 }
 
 int n_blocks_of(int n) { return (n + ngm::kSlots - 1) / ngm::kSlots; }
@@ -98,16 +107,14 @@ int engine_reserve(ngm_hip_ctx *ctx, int n) {
 int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipStream_t st) {
 	const int nb = n_blocks_of(n);
 	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
-		affine_kernel_t ka = find_affine_kernel(ctx->c, (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END, false);
-		hipLaunchKernelGGL(ka, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, d_scores,
-				(uint32_t *) nullptr, (int32_t *) nullptr, n, nb, ctx->RW, ctx->q, ctx->KA);
-		HIP_TRY(ctx, hipGetLastError());
+		const KernelRef ka = find_kernel(ctx, 4 + ((mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END ? 1 : 0));
+		HIP_TRY(ctx, launch_kernel(ka, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+				(const uint16_t *) ctx->blk_rows.p, d_scores, (uint32_t *) nullptr, (int32_t *) nullptr, n, nb, ctx->RW, ctx->q, ctx->KA));
 		return 0;
 	}
-	score_kernel_t k = find_score_kernel(ctx->c, (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END);
-	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, d_scores, n, nb,
-			ctx->RW, ctx->K);
-	HIP_TRY(ctx, hipGetLastError());
+	const KernelRef k = find_kernel(ctx, (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END ? 1 : 0);
+	HIP_TRY(ctx, launch_kernel(k, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+			(const uint16_t *) ctx->blk_rows.p, d_scores, n, nb, ctx->RW, ctx->K));
 	return 0;
 }
 
@@ -117,10 +124,9 @@ int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, u
 	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
 		const int CP = ctx->c + 1, ADW = ngm::aff_dir_words(CP);
 		if (ctx->dirs.reserve((size_t) nb * ctx->q * ADW * ngm::kSlots)) { set_error(ctx, "out of device memory for the trace matrix"); return -12; }
-		affine_kernel_t ka = find_affine_kernel(ctx->c, am == NGM_MODE_END_TO_END, true);
-		hipLaunchKernelGGL(ka, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, (float *) nullptr,
-				ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->KA);
-		HIP_TRY(ctx, hipGetLastError());
+		const KernelRef ka = find_kernel(ctx, 6 + (am == NGM_MODE_END_TO_END ? 1 : 0));
+		HIP_TRY(ctx, launch_kernel(ka, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+				(const uint16_t *) ctx->blk_rows.p, (float *) nullptr, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->KA));
 		if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
 		hipLaunchKernelGGL(ngm::affine_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, d_records, d_runs, n,
 				ctx->q, CP, run_stride);
@@ -129,10 +135,9 @@ int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, u
 	}
 	const int DW = ngm::dir_words(ctx->c);
 	if (ctx->dirs.reserve((size_t) nb * ctx->q * DW * ngm::kSlots)) { set_error(ctx, "out of device memory for the direction matrix"); return -12; }
-	align_kernel_t k = find_align_kernel(ctx->c, am == NGM_MODE_END_TO_END);
-	hipLaunchKernelGGL(k, dim3((nb + 3) / 4), dim3(256), 0, st, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p, ctx->dirs.p,
-			d_records, n, nb, ctx->RW, ctx->q, ctx->K);
-	HIP_TRY(ctx, hipGetLastError());
+	const KernelRef k = find_kernel(ctx, 2 + (am == NGM_MODE_END_TO_END ? 1 : 0));
+	HIP_TRY(ctx, launch_kernel(k, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+			(const uint16_t *) ctx->blk_rows.p, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->K));
 	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
 	hipLaunchKernelGGL(ngm::sw_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, ctx->lens.p, d_records,
 			d_runs, n, ctx->q, ctx->c, run_stride, am == NGM_MODE_END_TO_END ? 1 : 0);
@@ -181,10 +186,7 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 	if (p->personality != NGM_PERSONALITY_LINEAR && p->personality != NGM_PERSONALITY_AFFINE) { set_error(nullptr, "ngm_hip_create: unknown personality %d", p->personality); return nullptr; }
 	if (p->personality == NGM_PERSONALITY_AFFINE && p->gap_extend_penalty <= 0) { set_error(nullptr, "ngm_hip_create: gap_extend_penalty must be a positive integer"); return nullptr; }
 	if (p->match_bonus + p->mismatch_penalty > 255) { set_error(nullptr, "ngm_hip_create: match_bonus + mismatch_penalty must be <= 255"); return nullptr; }
-	if (!find_score_kernel(p->corridor, false)) {
-		set_error(nullptr, "ngm_hip_create: no kernel compiled for corridor %d (built: 8 12 19 20 27 42 80)", p->corridor);
-		return nullptr;
-	}
+	if (p->corridor > 200) { set_error(nullptr, "ngm_hip_create: corridor %d too wide (the band row lives in registers)", p->corridor); return nullptr; }
 	int ndev = ngm_hip_device_count();
 	if (ndev <= 0) { set_error(nullptr, "ngm_hip_create: no HIP device available (this library has no CPU fallback)"); return nullptr; }
 	if (device < 0 || device >= ndev) { set_error(nullptr, "ngm_hip_create: device %d out of range (%d devices)", device, ndev); return nullptr; }
@@ -199,6 +201,12 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 	// the affine band has corridor + 1 diagonals (lDiag = 0 .. uDiag = corridor, EndToEndAffine.h:40-41)
 	ctx->FW = ngm::ref_words(ctx->q, p->personality == NGM_PERSONALITY_AFFINE ? ctx->c + 1 : ctx->c);
 	ctx->max_batch = p->max_batch > 0 ? p->max_batch : (1 << 20);
+	if (!find_aot_kernel(ctx->c, 0)) {
+		// no ahead-of-time build for this band width: compile the kernels now, like the reference's OpenCL JIT
+		std::string err;
+		ctx->jit = ngm::jit_kernels_for_corridor(ctx->c, &err);
+		if (!ctx->jit) { set_error(nullptr, "ngm_hip_create: %s", err.c_str()); delete ctx; return nullptr; }
+	}
 	const int match = p->match_bonus, mismatch = -p->mismatch_penalty, gap_read = -p->gap_read_penalty, gap_ref = -p->gap_ref_penalty;
 	ctx->K.tM = match - mismatch;
 	ctx->K.tZ = -mismatch;

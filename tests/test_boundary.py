@@ -98,3 +98,16 @@ def test_cpp_host_drives_plugin_like_ngm(tmp_path, mode):
         assert (int(row[4]), int(row[5]), int(row[6]), int(row[7])) == (
             int(res["position_offset"][i]), int(res["qstart"][i]), int(res["qend"][i]), int(res["nm"][i]))
         assert np.float32(float(row[8])) == np.float32(res["identity"][i])
+
+
+def test_runtime_kernel_compilation_for_other_corridors():
+    """Band widths without an ahead-of-time build are compiled with hiprtc from the embedded kernel headers (the
+    reference JIT-compiles its OpenCL kernels with -D corridor_length); compiling needs no GPU."""
+    import ctypes as C
+    from nextgenmap_amd import build
+    lib = C.CDLL(build.build())
+    lib.ngm_hip_jit_selftest.restype = C.c_long
+    msg = C.create_string_buffer(4096)
+    size = lib.ngm_hip_jit_selftest(23, msg, 4096)
+    assert size > 10000, msg.value.decode()
+    assert b"sw_score_kernelILi23E" in msg.value

@@ -125,3 +125,31 @@ def test_device_resident_path_and_large_batch_properties():
     torch.cuda.synchronize()
     assert torch.equal(out2, out[perm])
     eng.close()
+
+
+@pytest.mark.parametrize("q,c,rl", [(78, 16, 75), (128, 23, 125)])
+def test_runtime_compiled_corridors_match_oracle(q, c, rl):
+    """Corridors NextGenMap derives for other read lengths (5 + 0.15 * avg) have no ahead-of-time build: the kernels are
+    compiled at engine creation (hiprtc) and must be bit-exact like the built-in shapes, in both personalities."""
+    import nextgenmap_amd as N
+    from nextgenmap_amd import engine as E
+    ref, qry = make_pairs(1500, q, c, seed=900 + c, read_len=rl)
+    eng = N.Engine(q, c)
+    for mode in (0, 1):
+        want = O.oracle_score(mode, ref, qry, c)
+        got = eng.BatchScore(mode, ref, qry)
+        assert np.array_equal(got, want)
+        al = eng.BatchAlign(mode, ref, qry)
+        res, cig, md = O.oracle_align(mode, ref, qry, c)
+        for i, a in enumerate(al):
+            if res["ok"][i]:
+                assert (a["cigar"], a["md"], a["position_offset"], a["nm"]) == (cig[i], md[i], int(res["position_offset"][i]), int(res["nm"][i])), i
+    eng.close()
+    eng = N.Engine(q, c, personality=E.PERSONALITY_AFFINE, gap_read=33, gap_ref=33, gap_extend=3)
+    for mode in (0, 1):
+        sc, res, cig = O.oracle_affine(mode, ref, qry, c, nthreads=8)
+        assert np.array_equal(eng.BatchScore(mode, ref, qry), sc)
+        al = eng.BatchAlign(mode, ref, qry)
+        for i, a in enumerate(al):
+            assert (a["cigar"], a["position_offset"], a["nm"]) == (cig[i], int(res["position_offset"][i]), int(res["nm"][i])), i
+    eng.close()
