@@ -41,6 +41,11 @@ ngm_ref *ngm_ref_create(int device, const ngm_ref_params *p, int n_contigs, cons
 		const uint8_t *const *seqs, const uint64_t *lens);
 /* Same, reading a (optionally gzip-compressed) FASTA file. */
 ngm_ref *ngm_ref_create_from_fasta(int device, const ngm_ref_params *p, const char *path);
+/* Loads NextGenMap's own cache files next to fasta_path -- <fasta>-enc.2.ngm (SequenceProvider.cpp:189-262) and
+ * <fasta>-ht-<kmer>-<kmer_skip>.3.ngm (PrefixTable.cpp:819-930) -- written by `ngm` or by ngm_ref_write_ngm_cache, so
+ * an existing NextGenMap index drops in.  NULL when absent / built with other parameters / multi-unit.
+ * ngm_ref_create_from_fasta tries this first, like the reference (NGM_HIP_NO_CACHE=1 forces a rebuild). */
+ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *params, const char *fasta_path);
 void ngm_ref_destroy(ngm_ref *r);
 
 int ngm_ref_contig_count(const ngm_ref *r);

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <string>
 #include <tuple>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/ngm_hip.h"
@@ -79,6 +80,7 @@ struct Opts {
 	char pe_delimiter = '/';
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
 	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
+	int skip_save = 0;
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
 	float sensitivity = -1.f, kmer_min = 0.f, min_identity = 0.65f, min_residues = 0.5f;
 	int batch = 1 << 20;
@@ -149,7 +151,8 @@ Opts parse(int argc, char **argv) {
 		case GEP: o.gap_extend = atoi(optarg); break;
 		case MAXCMRS: o.max_cmrs = atoi(optarg); break;
 		case NOUNAL: o.no_unal = 1; break;
-		case NOPROG: case SKIPSAVE: break;
+		case NOPROG: break;
+		case SKIPSAVE: o.skip_save = 1; break;
 		case MAXRL: o.max_read_length = atoi(optarg); break;
 		case BINSZ: o.bin_size = atoi(optarg); break;
 		case MAXKF: o.max_kfreq = atoi(optarg); break;
@@ -192,8 +195,17 @@ int main(int argc, char **argv) {
 	Opts o = parse(argc, argv);
 	ngm_ref_params rp{o.kmer, o.kmer_skip, o.bin_size};
 	info("MAIN", "NextGenMap-compatible HIP backend (gfx950)");
+	// an index cache next to the FASTA is loaded instead of rebuilding; a fresh build is saved for the next run unless
+	// --skip-save (src/PrefixTable.cpp:232-262, SequenceProvider.cpp:264-330)
+	const std::string ht_cache = o.ref + "-ht-" + std::to_string(o.kmer) + "-" + std::to_string(o.kmer_skip) + ".3.ngm";
+	const bool had_cache = access(ht_cache.c_str(), R_OK) == 0 && access((o.ref + "-enc.2.ngm").c_str(), R_OK) == 0 && !getenv("NGM_HIP_NO_CACHE");
 	ngm_ref *ref = ngm_ref_create_from_fasta(o.device, &rp, o.ref.c_str());
 	if (!ref) die(ngm_pipeline_last_error());
+	if (had_cache) info("PREPROCESS", "Reading reference index from " + ht_cache);
+	else if (!o.skip_save) {
+		if (ngm_ref_write_ngm_cache(ref, o.ref.c_str()) < 0) info("PREPROCESS", std::string("could not save the index: ") + ngm_pipeline_last_error());
+		else info("PREPROCESS", "Writing reference index to " + ht_cache);
+	}
 	info("PREPROCESS", "index entries: " + std::to_string(ngm_ref_index_entries(ref)) + ", max. k-mer frequency " +
 			std::to_string(o.max_kfreq > 0 ? o.max_kfreq : ngm_ref_auto_max_kfreq(ref)));
 	const std::string first_input = o.qry1.empty() ? o.qry : o.qry1;  // parser1: what the estimation pass reads (ReadProvider.cpp:201)

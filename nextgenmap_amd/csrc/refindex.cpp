@@ -128,6 +128,8 @@ __global__ void apply_usage_rule_kernel(uint32_t n_kmers, int k, const uint32_t 
 	if (total > 9900u) index[p].y = 0;
 }
 
+void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw);
+
 int build_index(ngm_ref *r) {
 	const int k = r->prm.kmer;
 	const uint32_t n_kmers = 1u << (2 * k);
@@ -180,19 +182,24 @@ int build_index(ngm_ref *r) {
 	REF_HIP_TRY(hipDeviceSynchronize());
 	(void) hipFree(d_keys); (void) hipFree(d_vals); (void) hipFree(d_keys2); (void) hipFree(d_starts);
 
-	// CompactPrefixTable::stats (PrefixTable.cpp:150-194): integer sums are exact in double, order-free
 	std::vector<uint32_t> raw(n_kmers);
 	REF_HIP_TRY(hipMemcpy(raw.data(), r->d_raw_counts, (size_t) n_kmers * 4, hipMemcpyDeviceToHost));
+	index_stats(r, raw);
+	return 0;
+}
+
+// CompactPrefixTable::stats (PrefixTable.cpp:150-194): integer sums are exact in double, order-free
+void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw) {
+	const uint32_t n_kmers = (uint32_t) raw.size();
 	double sum = 0.0, sum2 = 0.0;
 	for (uint32_t j = 0; j < n_kmers; ++j) { sum += raw[j]; sum2 += (double) raw[j] * (double) raw[j]; }
 	const double len = (double) n_kmers;
 	const double avg = sum / len;
 	const double stdev = sqrt(sum2 / (len - 1) - 2.0 * avg * (sum / (len - 1)) + ((len * avg * avg) / (len - 1)));
 	r->auto_max_kfreq = (int) ceil(std::max(100.0, avg + 5 * stdev));
-	return 0;
 }
 
-int finish_ref(ngm_ref *r) {
+int upload_genome(ngm_ref *r) {
 	// artificial upper bound for positions on the last contig (SequenceProvider.cpp:378)
 	r->start_pos.clear();
 	for (const NgmContig &c : r->contigs) r->start_pos.push_back(c.start);
@@ -207,6 +214,11 @@ int finish_ref(ngm_ref *r) {
 	}
 	REF_HIP_TRY(hipMalloc(&r->d_genome, r->genome_words * 4));
 	REF_HIP_TRY(hipMemcpy(r->d_genome, packed.data(), r->genome_words * 4, hipMemcpyHostToDevice));
+	return 0;
+}
+
+int finish_ref(ngm_ref *r) {
+	if (int rc = upload_genome(r)) return rc;
 	return build_index(r);
 }
 
@@ -278,7 +290,81 @@ ngm_ref *ngm_ref_create(int device, const ngm_ref_params *p, int n_contigs, cons
 	return seal(r);
 }
 
+// NextGenMap's own cache files next to the FASTA: <ref>-enc.2.ngm (SequenceProvider.cpp:189-208, :228-262) and
+// <ref>-ht-<k>-<skip>.3.ngm (PrefixTable.cpp:819-855, :857-930).  nullptr (with the reason as last error) when they are
+// absent, were written with other parameters or are not single-unit indexes.
+ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *p, const char *fasta_path) {
+	if (!p || !fasta_path) { ngm::pipeline_set_error("ngm_ref_create_from_cache: null argument"); return nullptr; }
+	const std::string enc_fn = std::string(fasta_path) + "-enc.2.ngm";
+	const std::string ht_fn = std::string(fasta_path) + "-ht-" + std::to_string(p->kmer) + "-" + std::to_string(p->kmer_skip) + ".3.ngm";
+	FILE *fe = fopen(enc_fn.c_str(), "rb");
+	FILE *fh = fe ? fopen(ht_fn.c_str(), "rb") : nullptr;
+	if (!fe || !fh) { if (fe) fclose(fe); ngm::pipeline_set_error("no index cache next to %s", fasta_path); return nullptr; }
+	ngm_ref *r = new_ref(device, p);
+	if (!r) { fclose(fe); fclose(fh); return nullptr; }
+	auto fail = [&](const char *why) -> ngm_ref * { ngm::pipeline_set_error("index cache of %s: %s", fasta_path, why); fclose(fe); fclose(fh); ngm_ref_destroy(r); return nullptr; };
+	struct RefIdx { uint32_t SeqId, Flags; uint64_t SeqStart; uint32_t SeqLen, NameLen; char name[100]; uint32_t pad; };
+	static_assert(sizeof(RefIdx) == 128, "RefIdx layout");
+	uint32_t cookie = 0, ref_count = 0;
+	uint64_t bin_ref_index = 0, enc_size = 0;
+	if (fread(&cookie, 4, 1, fe) != 1 || fread(&ref_count, 4, 1, fe) != 1 || fread(&bin_ref_index, 8, 1, fe) != 1 || fread(&enc_size, 8, 1, fe) != 1 ||
+			cookie != 0x74656 || ref_count == 0 || bin_ref_index >= 0xFFFFFFFFull || enc_size < bin_ref_index / 2) return fail("bad header of the encoded reference");
+	for (uint32_t i = 0; i < ref_count; ++i) {
+		RefIdx x;
+		if (fread(&x, sizeof(x), 1, fe) != 1) return fail("truncated contig table");
+		NgmContig c;
+		c.name.assign(x.name, std::min<uint32_t>(x.NameLen, 100));
+		c.start = x.SeqStart; c.len = x.SeqLen;
+		r->contigs.push_back(c);
+	}
+	{
+		std::vector<uint8_t> data(enc_size);
+		if (fread(data.data(), 1, enc_size, fe) != enc_size) return fail("truncated sequence data");
+		// 4 bits per base, first base in the high nibble, A0 T1 G2 C3 N4 (SequenceProvider.cpp:72-85) -> classes A0 C1 G2 T3 N5
+		static const uint8_t dec[16] = {0, 3, 2, 1, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
+		r->host_cls.resize(bin_ref_index);
+		for (uint64_t i = 0; i < bin_ref_index; ++i) r->host_cls[i] = dec[(i & 1) ? (data[i >> 1] & 15) : (data[i >> 1] >> 4)];
+	}
+	r->n_bases = bin_ref_index;
+	uint32_t kk = 0, skip = 0, units = 0, index_size = 0, table_len = 0;
+	cookie = 0;
+	if (fread(&cookie, 4, 1, fh) != 1 || fread(&kk, 4, 1, fh) != 1 || fread(&skip, 4, 1, fh) != 1 || fread(&units, 4, 1, fh) != 1 ||
+			fread(&index_size, 4, 1, fh) != 1 || fread(&table_len, 4, 1, fh) != 1 || cookie != 0x74656) return fail("bad header of the k-mer table");
+	const uint32_t n_kmers = 1u << (2 * p->kmer);
+	if ((int) kk != p->kmer || (int) skip != p->kmer_skip || index_size != n_kmers + 1) return fail("k-mer table was built with other parameters");
+	if (units != 1) return fail("multi-unit k-mer tables (references >= 4 Gbp) are not supported yet");
+	std::vector<uint8_t> ib((size_t) index_size * 5);
+	std::vector<uint32_t> pos((size_t) table_len + 16, 0);
+	if (fread(ib.data(), 1, ib.size(), fh) != ib.size() || fread(pos.data(), 4, table_len, fh) != table_len) return fail("truncated k-mer table");
+	fclose(fe); fclose(fh);
+	std::vector<uint32_t> raw(n_kmers);
+	std::vector<uint2> idx(n_kmers);
+	for (uint32_t q = 0; q < n_kmers; ++q) {
+		uint32_t t0, t1;
+		memcpy(&t0, &ib[(size_t) q * 5], 4);
+		memcpy(&t1, &ib[(size_t) (q + 1) * 5], 4);
+		raw[q] = t1 - t0;
+		// the usage byte doubles as "skip this k-mer" (PrefixTable.cpp:468-478, :771-775)
+		idx[q] = make_uint2(t0 - 1, ib[(size_t) q * 5 + 4] ? raw[q] : 0u);
+	}
+	r->n_entries = table_len;
+	if (upload_genome(r) != 0) { ngm_ref_destroy(r); return nullptr; }
+	auto up = [&](void **d, const void *h, size_t bytes, size_t alloc) { return hipMalloc(d, alloc) == hipSuccess && hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+	if (!up((void **) &r->d_index, idx.data(), (size_t) n_kmers * 8, (size_t) n_kmers * 8) || !up((void **) &r->d_raw_counts, raw.data(), (size_t) n_kmers * 4, (size_t) n_kmers * 4) ||
+			!up((void **) &r->d_positions, pos.data(), pos.size() * 4, pos.size() * 4)) {
+		ngm::pipeline_set_error("out of device memory loading the index cache");
+		ngm_ref_destroy(r);
+		return nullptr;
+	}
+	index_stats(r, raw);
+	return r;
+}
+
 ngm_ref *ngm_ref_create_from_fasta(int device, const ngm_ref_params *p, const char *path) {
+	// like the reference, an index cache next to the FASTA is used instead of rebuilding (NGM_HIP_NO_CACHE=1: always rebuild)
+	if (!getenv("NGM_HIP_NO_CACHE")) {
+		if (ngm_ref *cached = ngm_ref_create_from_cache(device, p, path)) return cached;
+	}
 	gzFile f = gzopen(path, "rb");
 	if (!f) { ngm::pipeline_set_error("cannot open reference %s", path); return nullptr; }
 	ngm_ref *r = new_ref(device, p);

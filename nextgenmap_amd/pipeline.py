@@ -36,6 +36,8 @@ def _lib():
         lib.ngm_ref_create.argtypes = [C.c_int, C.POINTER(RefParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_ref_create_from_fasta.restype = C.c_void_p
         lib.ngm_ref_create_from_fasta.argtypes = [C.c_int, C.POINTER(RefParams), C.c_char_p]
+        lib.ngm_ref_create_from_cache.restype = C.c_void_p
+        lib.ngm_ref_create_from_cache.argtypes = [C.c_int, C.POINTER(RefParams), C.c_char_p]
         lib.ngm_ref_destroy.argtypes = [C.c_void_p]
         lib.ngm_ref_contig_count.argtypes = [C.c_void_p]
         lib.ngm_ref_contig_name.restype = C.c_char_p
@@ -99,6 +101,16 @@ class Reference:
         lib = _lib()
         p = RefParams(kmer, kmer_skip, bin_size)
         h = lib.ngm_ref_create_from_fasta(device, C.byref(p), path.encode())
+        if not h:
+            raise _err()
+        return cls(h, kmer)
+
+    @classmethod
+    def from_cache(cls, fasta_path, device=0, kmer=13, kmer_skip=2, bin_size=2):
+        """NextGenMap's own <fasta>-enc.2.ngm / <fasta>-ht-<k>-<skip>.3.ngm cache files."""
+        lib = _lib()
+        p = RefParams(kmer, kmer_skip, bin_size)
+        h = lib.ngm_ref_create_from_cache(device, C.byref(p), fasta_path.encode())
         if not h:
             raise _err()
         return cls(h, kmer)

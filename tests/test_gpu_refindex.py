@@ -29,8 +29,9 @@ def _tricky_genome():
 
 
 @pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
-def test_index_matches_the_reference_programs_index(tmp_path):
+def test_index_matches_the_reference_programs_index(tmp_path, monkeypatch):
     from nextgenmap_amd.pipeline import Reference
+    monkeypatch.setenv("NGM_HIP_NO_CACHE", "1")  # build from the FASTA, do not load what the reference program wrote
     contigs = _tricky_genome()
     fa = str(tmp_path / "ref.fa")
     with open(fa, "wb") as f:
@@ -112,3 +113,45 @@ def test_reference_program_accepts_our_cache_files(tmp_path):
     e1, e2 = RF.read_enc_file(str(d1 / "ref.fa-enc.2.ngm")), RF.read_enc_file(str(d2 / "ref.fa-enc.2.ngm"))
     nb = e1["n_bases"] // 2
     assert e1["n_bases"] == e2["n_bases"] and np.array_equal(e1["data"][:nb], e2["data"][:nb])
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+def test_loads_the_reference_programs_cache_files(tmp_path, monkeypatch):
+    """An index written by NextGenMap itself drops in: <fasta>-enc.2.ngm + <fasta>-ht-13-2.3.ngm are loaded instead of
+    rebuilding, and give the same reference, index, windows and mappings as our own build."""
+    from nextgenmap_amd.pipeline import Mapper, Reference
+    contigs = _tricky_genome()
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d some description\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 61):
+                f.write(b[o:o + 61] + b"\n")
+    r = RF.run_ngm(["-r", fa], cwd=str(tmp_path))
+    assert os.path.exists(fa + "-ht-13-2.3.ngm"), r.stdout + r.stderr
+    cached = Reference.from_cache(fa)
+    also = Reference.from_fasta(fa)            # finds the cache, like the reference program does
+    monkeypatch.setenv("NGM_HIP_NO_CACHE", "1")
+    built = Reference.from_fasta(fa)
+    for other in (cached, also):
+        assert other.contigs == built.contigs and other.concat_len == built.concat_len
+        assert other.auto_max_kfreq == built.auto_max_kfreq and other.index_entries == built.index_entries
+        c1, r1, p1 = other.index_copy()
+        c2, r2, p2 = built.index_copy()
+        assert np.array_equal(c1, c2) and np.array_equal(r1, r2)
+        starts = np.concatenate([[0], np.cumsum(r1.astype(np.int64))])[:-1]
+        for k in np.nonzero(c1 > 0)[0][::97]:
+            assert np.array_equal(p1[starts[k]:starts[k] + c1[k]], p2[starts[k]:starts[k] + c2[k]])
+    for off in (0, 1, 999, 1000, 1001, 5003, 60990, 61999, 62003, built.concat_len - 50, built.concat_len - 1):
+        assert cached.decode(off, 180) == built.decode(off, 180), off
+    reads = S.make_reads(contigs[:3], 400, 100, seed=5)
+    rows = Mapper.reads_to_rows([x[1] for x in reads], 102)
+    m1, m2 = Mapper(cached, 102, 20), Mapper(built, 102, 20)
+    h1, c1, d1 = m1.map_se(rows)
+    h2, c2, d2 = m2.map_se(rows)
+    assert np.array_equal(h1, h2) and c1 == c2 and d1 == d2
+    m1.close(); m2.close(); cached.close(); also.close(); built.close()
+    # wrong parameters are refused, not silently used
+    with pytest.raises(Exception):
+        Reference.from_cache(fa, kmer=12)
