@@ -217,8 +217,11 @@ __global__ __launch_bounds__(256) void sw_affine_kernel(const uint32_t *__restri
 #ifdef NGM_ENGINE_KERNELS
 // SeqAn's single-trace, gaps-left traceback (dp_traceback_impl.h:184-470) over the stored trace bytes.
 // Emits the same compact runs as the linear traceback: (len << 2) | op, op 1 = M, 2 = I, 3 = D, in traceback order.
+// With `packed` (the batch the DP ran on) the kernel also counts matching / mismatching diagonal columns
+// (rec[3] = matches, rec[7] = mismatches: characters compare like symbol classes on NextGenMap's alphabet), so the host
+// needs neither the window nor the read to finish NM and identity.
 __global__ __launch_bounds__(256) void affine_traceback_kernel(const uint32_t *__restrict__ dirs, int32_t *__restrict__ records,
-		uint16_t *__restrict__ runs, int n, int q, int CP, int run_stride) {
+		uint16_t *__restrict__ runs, int n, int q, int CP, int run_stride, const uint32_t *__restrict__ packed, int RW, int FW) {
 	const int pair = blockIdx.x * blockDim.x + threadIdx.x;
 	if (pair >= n) return;
 	int32_t *rec = records + (size_t) pair * 8;
@@ -234,6 +237,14 @@ __global__ __launch_bounds__(256) void affine_traceback_kernel(const uint32_t *_
 		const uint32_t w = dp[((size_t) (vv - 1) * DW + (d >> 2)) * kSlots];
 		return (w >> (8 * (d & 3))) & 0xFFu;
 	};
+	// symbol class of read base v-1 / window base h-1 of this pair in the packed batch (nibble 2k = base k, 2k+1 = base k+4)
+	const uint32_t *pk = packed ? packed + (size_t) (pair >> 6) * (RW + FW) * kSlots + (pair & 63) : nullptr;
+	auto cls_at = [&](int word0, int idx) -> uint32_t {
+		const uint32_t x = pk[(size_t) (word0 + (idx >> 3)) * kSlots];
+		const int j = idx & 7;
+		return (x >> (4 * ((j & 3) * 2 + (j >> 2)))) & 15u;
+	};
+	int n_match = 0, n_mis = 0;
 	uint32_t tv = tv_at(h, v);
 	// _correctTraceValue (dp_algorithm_impl.h:1233-1250)
 	if (flags & 1) tv = (tv & ~(uint32_t) kTDiag) | (uint32_t) kTMaxV;
@@ -248,7 +259,14 @@ __global__ __launch_bounds__(256) void affine_traceback_kernel(const uint32_t *_
 		cur = op; curlen = 1;
 	};
 	while (h > 0 && v > 0 && tv != 0u) {
-		if (tv & kTDiag) { emit(1); --h; --v; tv = tv_at(h, v); }
+		if (tv & kTDiag) {
+			emit(1);
+			if (pk) {
+				const uint32_t rc = cls_at(0, v - 1), fc = cls_at(RW, h - 1);
+				if (rc == fc && rc <= 5u && rc != 4u) ++n_match; else ++n_mis;
+			}
+			--h; --v; tv = tv_at(h, v);
+		}
 		else if ((tv & kTMaxV) && (tv & kTVert)) {
 			while ((!(tv & kTVertOpen) || (tv & kTVert)) && v != 1) { emit(2); --v; tv = tv_at(h, v); }
 			emit(2); --v; tv = tv_at(h, v);
@@ -263,7 +281,9 @@ __global__ __launch_bounds__(256) void affine_traceback_kernel(const uint32_t *_
 	rec[0] = 1;        // an alignment (possibly empty) always exists in the reference
 	rec[1] = h;        // PositionOffset: window offset of the first aligned reference base
 	rec[2] = v;        // QStart
+	rec[3] = n_match;
 	rec[4] = nruns;
+	rec[7] = n_mis;
 }
 #endif  // NGM_ENGINE_KERNELS
 

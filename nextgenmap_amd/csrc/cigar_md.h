@@ -117,10 +117,13 @@ inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint1
 // CIGAR uses S / M / I / D only, Identity = matches / (diagonal columns + number of gap runs), NM = mismatches,
 // and neither Align.Score nor pBuffer2 (MD) is written.
 // rec[1] = window offset of the first aligned reference base, rec[2] = first aligned read base, runs in traceback order.
+// ref / qry may be null: the diagonal columns' match / mismatch counts then come from the device (rec[3], rec[7]) and
+// read_len is the read's length.
 inline void build_cigar_affine(const int32_t *rec, const uint16_t *runs, const char *ref, const char *qry, int qry_max_len,
-		ngm_hip_align_out *out) {
+		ngm_hip_align_out *out, int read_len = -1) {
 	int len_v = 0;
-	while (len_v < qry_max_len && qry[len_v]) ++len_v;
+	if (qry) { while (len_v < qry_max_len && qry[len_v]) ++len_v; }
+	else len_v = read_len;
 	char *cigar = out->cigar;
 	int co = 0, match = 0, mismatch = 0, total = 0, pattern_chars = 0;
 	int h = rec[1], v = rec[2];
@@ -131,7 +134,7 @@ inline void build_cigar_affine(const int32_t *rec, const uint16_t *runs, const c
 		const int op = runs[k] & 3, run = runs[k] >> 2;
 		co += put_num(cigar + co, run);
 		if (op == 1) {
-			for (int t = 0; t < run; ++t) { if (ref[h + t] == qry[v + t]) ++match; else ++mismatch; }
+			if (ref && qry) for (int t = 0; t < run; ++t) { if (ref[h + t] == qry[v + t]) ++match; else ++mismatch; }
 			total += run; h += run; v += run; pattern_chars += run;
 			cigar[co++] = 'M';
 		} else if (op == 2) {
@@ -145,6 +148,7 @@ inline void build_cigar_affine(const int32_t *rec, const uint16_t *runs, const c
 	out->qend = len_v - (pattern_chars + out->qstart);
 	if (out->qend > 0) { co += put_num(cigar + co, out->qend); cigar[co++] = 'S'; }
 	cigar[co] = 0;
+	if (!(ref && qry)) { match = rec[3]; mismatch = rec[7]; }
 	out->identity = match * 1.0f / total;
 	out->nm = mismatch;
 }

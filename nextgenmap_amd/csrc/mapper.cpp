@@ -228,7 +228,13 @@ int upload_reads(ngm_mapper *m, int n, const char *reads) {
 std::atomic<int> g_live_mappers{0};  // mapper instances share the host cores
 template <typename F>
 void parallel_for(int n, F f) {
-	int nt = (int) std::thread::hardware_concurrency() / std::max(1, g_live_mappers.load());
+	// the host cores are shared by the mapper instances of this process and, under torchrun, by the other ranks of the node
+	static const int ranks_on_node = [] {
+		const char *e = getenv("LOCAL_WORLD_SIZE");
+		if (!e) e = getenv("WORLD_SIZE");
+		return std::max(1, e ? atoi(e) : 1);
+	}();
+	int nt = (int) std::thread::hardware_concurrency() / std::max(1, g_live_mappers.load() * ranks_on_node);
 	if (const char *e = getenv("NGM_HIP_HOST_THREADS")) nt = atoi(e);
 	nt = std::max(1, std::min(nt, 64));
 	if (n < 4096 || nt == 1) { f(0, n); return; }
@@ -687,24 +693,25 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			if (topn > 1) h.score = h_scores[a_pair[j]];  // AS:i of this candidate
 			const bool rev = a_sv[j] & 1u;
 			h.reverse = rev;
-			const uint64_t offset = (uint64_t) a_loc[j] - (uint64_t) (c >> 1);
-			host_window(r, offset, align_buf_len, q + c, win.data());
 			const char *rd = reads + (size_t) i * q;
 			const int L = (int) strnlen(rd, q);
-			memset(qry.data(), 0, qry.size());
-			if (!rev) memcpy(qry.data(), rd, L);
-			else for (int t = 0; t < L; ++t) {
-				const char ch = rd[L - 1 - t];
-				qry[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
-			}
 			ngm_hip_align_out ao{};
 			ao.cigar = cigars + o * str_stride;
 			ao.md = mds + o * str_stride;
 			if (m->prm.personality == NGM_PERSONALITY_AFFINE) {
+				// matches / mismatches were counted by the traceback kernel: no window decode, no reverse complement here.
 				// EndToEndAffine never touches pBuffer2: the SAM record carries AlignmentBuffer's "!!!" (AlignmentBuffer.cpp:109)
-				ngm::build_cigar_affine(&h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), q, &ao);
+				ngm::build_cigar_affine(&h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], nullptr, nullptr, q, &ao, L);
 				memcpy(ao.md, "!!!", 4);
 			} else {
+				const uint64_t offset = (uint64_t) a_loc[j] - (uint64_t) (c >> 1);
+				host_window(r, offset, align_buf_len, q + c, win.data());
+				memset(qry.data(), 0, qry.size());
+				if (!rev) memcpy(qry.data(), rd, L);
+				else for (int t = 0; t < L; ++t) {
+					const char ch = rd[L - 1 - t];
+					qry[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+				}
 				ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), &ao);
 				if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
 			}

@@ -129,7 +129,7 @@ int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, u
 				(const uint16_t *) ctx->blk_rows.p, (float *) nullptr, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->KA));
 		if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
 		hipLaunchKernelGGL(ngm::affine_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, d_records, d_runs, n,
-				ctx->q, CP, run_stride);
+				ctx->q, CP, run_stride, (const uint32_t *) ctx->packed.p, ctx->RW, ctx->FW);
 		HIP_TRY(ctx, hipGetLastError());
 		return 0;
 	}
