@@ -251,3 +251,30 @@ def test_cli_topn_sam_equals_reference_program(tmp_path, extra):
         print(str(d)[:600])
     assert len(bad_profile) <= 0.003 * len(a), bad_profile[:3]
     assert len(diff) <= 0.01 * len(distinct), diff[:3]
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+@pytest.mark.parametrize("read_len", [75, 250], ids=["75bp-jit-corridor16", "250bp-corridor42"])
+def test_cli_other_read_lengths(tmp_path, read_len):
+    """Read lengths whose derived corridor (5 + 0.15 * avg) has no ahead-of-time kernel build (75 bp -> 16, compiled at
+    run time) and long reads (250 bp -> 42): estimation and SAM records against `ngm --affine`."""
+    fa, fq = _write_case(tmp_path, n_reads=2000, read_len=read_len, seed=71 + read_len)
+    d1 = tmp_path / "refrun"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    r = RF.run_ngm(["-r", fa1, "-q", fq, "-o", str(d1 / "out.sam"), "--affine", "-t", "1", "--no-progress"], cwd=str(d1))
+    log_ref = r.stdout + r.stderr
+    assert "Done" in log_ref
+    c = subprocess.run([CLI, "-r", fa, "-q", fq, "-o", str(tmp_path / "hip.sam"), "--affine", "--skip-save"], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    for pat in (r"Average read length: (\d+) \(min: (\d+), max: (\d+)\)", r"Corridor width: (\d+)", r"Estimated sensitivity: ([0-9.]+)"):
+        assert re.search(pat, log_ref).groups() == re.search(pat, c.stderr).groups(), pat
+    a, b = _sam(str(d1 / "out.sam")), _sam(str(tmp_path / "hip.sam"))
+    assert set(a) == set(b) and len(a) == 2000
+    diff = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
+    print("records differing:", len(diff), "of", len(a))
+    # only reads whose best score is shared by several repeat copies (MAPQ 0) may land on another copy
+    for n, x, y in diff:
+        assert x["mapq"] == 0 and y["mapq"] == 0 and x["tags"].get("AS") == y["tags"].get("AS") and x["tags"].get("NH") == y["tags"].get("NH"), (n, x, y)
+    assert len(diff) <= 0.02 * len(a), len(diff)
