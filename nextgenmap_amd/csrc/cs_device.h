@@ -582,4 +582,93 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	(void) cs_finish<MODE>(A, read, lane, R, t_keys, t_votes, n_slots);
 }
 
+// ---- candidate ORDER --------------------------------------------------------------------------------------------
+// The reference lists a read's candidates in the order in which their bins first reached the running threshold
+// (rList, CS::AddLocationStd, src/CS.cpp:196-211), and ScoreBuffer::top1SE keeps the FIRST of several equally scoring
+// candidates.  The set of candidates does not depend on that order, so the search kernels above do not track it; for
+// the few reads where it matters (several candidates share the best score) this kernel replays the votes of one read
+// sequentially -- hits in exactly the reference's order: k-mers left to right, forward list then reverse-complement
+// list, list entries in index order -- and records for every bin its position in rList.  One wave per read: all lanes
+// fetch 64 hits at a time into LDS, lane 0 replays them against an exact table in LDS.
+// out: cand_rank[c] = 2 * (rList position of the candidate's bin) + strand for every candidate c of the read, i.e. its
+// index order in CollectResultsStd's output (forward before reverse of one bin, src/CS.cpp:289-304).
+constexpr int kCsOrderLog2Slots = 13;                       // exact table of the replay: 8192 slots in LDS
+constexpr uint32_t kCsOrderMaxHits = 6000;                  // reads with more hits keep the position order
+constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
+		uint32_t *__restrict__ cand_rank) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+	__shared__ uint32_t s_bin[64];
+	const int lane = threadIdx.x;
+	const int read = (int) A.read_list[blockIdx.x];
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;
+	uint32_t *l_pref = cs_lds + A.lists_cap;
+	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);
+	uint32_t *t_keys = (uint32_t *) l_code + (A.q + 3) / 4;
+	constexpr uint32_t n_slots = 1u << kCsOrderLog2Slots;
+	uint32_t *t_votes = t_keys + n_slots;
+	uint16_t *t_rank = (uint16_t *) (t_votes + n_slots);
+	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_rank[s] = 0xFFFF; }
+	const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
+	const uint32_t H = R.H;
+	const int L = R.L, n_lists = R.n_lists;
+	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
+	if (H > kCsOrderMaxHits) {  // too many hits for the LDS table: leave the order undefined (the caller falls back)
+		for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown;
+		return;
+	}
+	__syncthreads();
+	float max_hit = 0.0f, thresh = 0.0f;
+	uint32_t next_rank = 0;
+	for (uint32_t h0 = 0; h0 < H; h0 += 64) {
+		const uint32_t h = h0 + (uint32_t) lane;
+		uint32_t e = 0xFFFFFFFFu;
+		if (h < H) {
+			int lo = 0, hi = n_lists;  // largest li with pref[li] <= h
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (l_pref[mid] <= h) lo = mid; else hi = mid;
+			}
+			const uint32_t pos = A.positions[l_start[lo] + (h - l_pref[lo])];
+			const int p = lo >> 1;
+			const uint32_t correction = (lo & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
+			e = (((pos - correction) >> A.bin_shift) & 0x3FFFFFFFu) | ((lo & 1) ? 0x80000000u : 0u);
+		}
+		s_bin[lane] = e;
+		__syncthreads();
+		if (lane == 0) {
+			const uint32_t cnt = min(64u, H - h0);
+			for (uint32_t i = 0; i < cnt; ++i) {
+				const uint32_t ev = s_bin[i];
+				const uint32_t bin = ev & 0x3FFFFFFFu;
+				uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+				while (t_keys[slot] != 0xFFFFFFFFu && t_keys[slot] != bin) slot = (slot + 1) & (n_slots - 1);
+				t_keys[slot] = bin;
+				uint32_t v = t_votes[slot];
+				uint32_t score;
+				if (ev & 0x80000000u) { v += 0x10000u; score = v >> 16; } else { v += 1u; score = v & 0xFFFFu; }
+				t_votes[slot] = v;
+				if ((float) score > max_hit) { max_hit = (float) score; thresh = max_hit * A.sensitivity; }  // CS.cpp:197-202
+				if (t_rank[slot] == 0xFFFF && (float) score >= thresh) t_rank[slot] = (uint16_t) next_rank++;  // CS.cpp:205-208
+			}
+		}
+		__syncthreads();
+	}
+	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
+	for (uint32_t c = lane; c < cn; c += 64) {
+		const uint32_t bin = ((cand_loc[cb + c] - centre) >> A.bin_shift) & 0x3FFFFFFFu;
+		uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+		uint32_t rank = kCsOrderUnknown;
+		for (uint32_t probes = 0; probes < n_slots; ++probes) {
+			const uint32_t key = t_keys[slot];
+			if (key == bin) { if (t_rank[slot] != 0xFFFF) rank = 2u * t_rank[slot] + (cand_sv[cb + c] & 1u); break; }
+			if (key == 0xFFFFFFFFu) break;
+			slot = (slot + 1) & (n_slots - 1);
+		}
+		cand_rank[cb + c] = rank;
+	}
+}
+
 }  // namespace ngm

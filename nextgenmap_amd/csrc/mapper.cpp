@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -44,6 +45,9 @@ struct ngm_mapper {
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
+	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
+	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank;
+	ngm::PinnedBuf<uint32_t> p_rank;
 	// pinned staging for the per-batch downloads
 	ngm::PinnedBuf<uint32_t> p_winner, p_loc, p_sv;
 	ngm::PinnedBuf<int32_t> p_mapq, p_nbest, p_rec;
@@ -193,6 +197,7 @@ int run_cs(ngm_mapper *m, int n) {
 					m->d_out_loc.p, m->d_out_sv.p, m->d_out_loc2.p, m->d_out_sv2.p);
 			MAP_HIP_TRY(hipGetLastError());
 			std::swap(m->d_out_loc, m->d_out_loc2); std::swap(m->d_out_sv, m->d_out_sv2); std::swap(m->d_cand_base, m->d_new_base);
+			m->last_cs = A;
 			m->n_reads = n;
 			std::vector<unsigned long long> ctr(ctr_words + 8);
 			MAP_HIP_TRY(hipMemcpyAsync(ctr.data(), m->d_counters.p, ctr.size() * 8, hipMemcpyDeviceToHost, m->st));
@@ -357,7 +362,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
-	m->d_counters.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
+	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->p_rank.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	ngm_hip_destroy(m->eng);
@@ -400,6 +405,27 @@ int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *vo
 
 static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired);
 
+// Reference order of the candidates of the listed reads (cs_order_kernel): h_rank[c] for every candidate c of those
+// reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
+static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank) {
+	const uint32_t nl = (uint32_t) list.size();
+	if (m->d_order_list.reserve(nl) || m->d_cand_rank.reserve(np + 1) || m->p_rank.reserve(np + 1)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
+	MAP_HIP_TRY(hipMemcpyAsync(m->d_order_list.p, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, m->st));
+	ngm::CsArgs A = m->last_cs;
+	A.read_list = m->d_order_list.p;
+	A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p;
+	A.counters = nullptr; A.phase_cycles = nullptr;
+	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4) * 4 + ((size_t) 10 << ngm::kCsOrderLog2Slots);
+	static std::once_flag once;
+	std::call_once(once, [&] { (void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+	hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(nl), dim3(64), lds, m->st, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
+	MAP_HIP_TRY(hipGetLastError());
+	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, m->st));
+	MAP_HIP_TRY(hipStreamSynchronize(m->st));
+	*h_rank = m->p_rank.p;
+	return 0;
+}
+
 int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds) {
 	return map_impl(m, n, reads, nullptr, hits, cigars, mds, false);
 }
@@ -416,7 +442,7 @@ int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const vo
 // ScoreBuffer::top1PE + CheckPairs (src/ScoreBuffer.cpp:368-502) for one pair; `a` = the mate whose scores arrive last
 // (the odd read id: "read"), `b` = its mate.  Candidates are (pair index) lists into loc/score.
 static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
-		const uint32_t *loc, const uint32_t *sv, const float *score, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found) {
+		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found) {
 	if (cnt_a == 1 && cnt_b == 1) {  // the common case: one candidate per mate
 		*mq_a = *mq_b = 60;
 		const uint64_t l1 = loc[base_a], l2 = loc[base_b];
@@ -434,6 +460,8 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 		// in which the search happened to emit the candidates
 		std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) {
 			if (score[x] != score[y]) return score[x] > score[y];
+			// equal scores keep the reference's candidate order (std::sort is an insertion sort below 17 elements)
+			if (rank && rank[x] != ngm::kCsOrderUnknown && rank[y] != ngm::kCsOrderUnknown && rank[x] != rank[y]) return rank[x] < rank[y];
 			if (loc[x] != loc[y]) return loc[x] < loc[y];
 			return (sv[x] & 1u) < (sv[y] & 1u);
 		});
@@ -543,10 +571,63 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		if (paired) MAP_HIP_TRY(hipMemcpyAsync(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		lap(1);
+		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
+		if (!paired && m->prm.topn <= 1 && !position_order) {
+			// several candidates share the best score: the reference keeps the first one in ITS candidate order
+			// (ScoreBuffer::top1SE over CollectResultsStd's rList order); replay the votes of just those reads
+			std::vector<uint32_t> tied;
+			for (int i = 0; i < n; ++i) if (h_nbest[i] != 1 && m->h_count[i] > 1) tied.push_back((uint32_t) i);  // 0: no positive score, the first candidate is kept
+			if (!tied.empty()) {
+				uint32_t *h_rank = nullptr;
+				if (int rc = candidate_order(m, tied, np, &h_rank)) return rc;
+				if (m->p_scores.reserve(np + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+				h_scores = m->p_scores.p;
+				MAP_HIP_TRY(hipMemcpy(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost));
+				for (uint32_t i : tied) {
+					const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+					float best = h_scores[b];
+					for (uint32_t c = 1; c < cnt; ++c) best = std::max(best, h_scores[b + c]);
+					uint32_t pick = 0xFFFFFFFFu, pick_rank = ngm::kCsOrderUnknown;
+					bool known = true;
+					for (uint32_t c = 0; c < cnt; ++c) if (h_scores[b + c] == best || !(best > 0.0f)) {
+						if (h_rank[b + c] == ngm::kCsOrderUnknown) { known = false; break; }
+						if (h_rank[b + c] < pick_rank) { pick_rank = h_rank[b + c]; pick = b + c; }
+					}
+					if (known && pick != 0xFFFFFFFFu) h_winner[i] = pick;
+				}
+			}
+		}
 		if (paired) {
 			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is
 			// sequential state of one CS thread in the reference; here every host thread continues from the value at
 			// the start of the batch and the increments are merged afterwards (NGM_HIP_HOST_THREADS=1: strictly sequential).
+			// reads with equally scoring candidates: fetch the reference's candidate order for them first
+			uint32_t *h_rank_pe = nullptr;
+			if (!position_order) {
+				std::vector<uint32_t> need;
+				for (int i = 0; i < n; ++i) {
+					const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+					bool eq = false;
+					for (uint32_t x = 0; x + 1 < cnt && !eq; ++x) for (uint32_t y = x + 1; y < cnt; ++y) if (h_scores[b + x] == h_scores[b + y]) { eq = true; break; }
+					if (eq) need.push_back((uint32_t) i);
+				}
+				if (!need.empty()) {
+					if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
+					// the single-end fallback (no pair in the window / mate without candidates) keeps the first best candidate
+					for (uint32_t i : need) {
+						const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+						float best = h_scores[b];
+						for (uint32_t c2 = 1; c2 < cnt; ++c2) best = std::max(best, h_scores[b + c2]);
+						uint32_t pick = 0xFFFFFFFFu, pick_rank = ngm::kCsOrderUnknown;
+						bool known = true;
+						for (uint32_t c2 = 0; c2 < cnt; ++c2) if (h_scores[b + c2] == best || !(best > 0.0f)) {
+							if (h_rank_pe[b + c2] == ngm::kCsOrderUnknown) { known = false; break; }
+							if (h_rank_pe[b + c2] < pick_rank) { pick_rank = h_rank_pe[b + c2]; pick = b + c2; }
+						}
+						if (known && pick != 0xFFFFFFFFu) h_winner[i] = pick;
+					}
+				}
+			}
 			const long sum0 = m->pair_dist_sum, cnt0 = m->pair_dist_count;
 			std::atomic<long> add_sum{0}, add_cnt{0};
 			parallel_for(n / 2, [&](int plo, int phi) {
@@ -558,7 +639,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
 					bool found = false;
 					select_pair(m, dsum, dcnt, m->h_base[ra], ca, (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], cb,
-							(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, &wa, &wb, &mqa, &mqb, &equal, &found);
+							(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, h_rank_pe, &wa, &wb, &mqa, &mqb, &equal, &found);
 					if (found) {
 						h_winner[ra] = (uint32_t) wa; h_winner[rb] = (uint32_t) wb;
 						h_mapq[ra] = mqa; h_mapq[rb] = mqb;
@@ -585,6 +666,18 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			h_scores = m->p_scores.p;
 			MAP_HIP_TRY(hipMemcpy(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost));
 			tn_pairs.assign((size_t) n * topn, 0xFFFFFFFFu);
+			// equally scoring candidates keep the reference's candidate order (the cut at -n is order dependent)
+			uint32_t *h_rank_tn = nullptr;
+			if (!getenv("NGM_HIP_POSITION_ORDER")) {
+				std::vector<uint32_t> need;
+				for (int i = 0; i < n; ++i) {
+					const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+					bool eq = false;
+					for (uint32_t x = 0; x + 1 < cnt && !eq; ++x) for (uint32_t y = x + 1; y < cnt; ++y) if (h_scores[b + x] == h_scores[b + y]) { eq = true; break; }
+					if (eq) need.push_back((uint32_t) i);
+				}
+				if (!need.empty()) if (int rc = candidate_order(m, need, np, &h_rank_tn)) return rc;
+			}
 			parallel_for(n, [&](int lo, int hi) {
 				std::vector<uint32_t> v;
 				for (int i = lo; i < hi; ++i) {
@@ -594,6 +687,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					std::iota(v.begin(), v.end(), b);
 					std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) {
 						if (h_scores[x] != h_scores[y]) return h_scores[x] > h_scores[y];
+						if (h_rank_tn && h_rank_tn[x] != ngm::kCsOrderUnknown && h_rank_tn[y] != ngm::kCsOrderUnknown && h_rank_tn[x] != h_rank_tn[y]) return h_rank_tn[x] < h_rank_tn[y];
 						if (h_loc[x] != h_loc[y]) return h_loc[x] < h_loc[y];
 						return (h_sv[x] & 1u) < (h_sv[y] & 1u);
 					});

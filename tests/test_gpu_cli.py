@@ -127,11 +127,9 @@ def test_cli_affine_sam_equals_reference_program(tmp_path, extra):
     print("records differing:", len(diff), "of", len(a))
     for d in diff[:2]:
         print(str(d)[:400])
-    # equal-score candidates are visited in a different order (first threshold crossing vs location): such a
-    # read may legitimately land on the other copy of a repeat; everything else is identical
-    assert len(diff) <= 0.005 * len(a), (len(diff), diff[:3])
-    for n, x, y in diff:
-        assert x["tags"].get("AS") == y["tags"].get("AS") or (x["flag"] & 4) or (y["flag"] & 4), (n, x, y)
+    # equally scoring candidates are resolved in the reference's own candidate order (cs_order_kernel): every record,
+    # multi-mappers included, is identical
+    assert len(diff) == 0, (len(diff), str(diff[:2])[:1500])
 
 
 def _sam_pe(path):
@@ -249,8 +247,13 @@ def test_cli_topn_sam_equals_reference_program(tmp_path, extra):
           "; reads without score ties:", len(distinct), "of which differ:", len(diff))
     for d in (bad_profile + diff)[:3]:
         print(str(d)[:600])
-    assert len(bad_profile) <= 0.003 * len(a), bad_profile[:3]
-    assert len(diff) <= 0.01 * len(distinct), diff[:3]
+    assert len(bad_profile) == 0, bad_profile[:3]
+    assert len(diff) == 0, diff[:3]
+    # with the reference's candidate order replayed, ties at the cut resolve the same way too (std::sort is an insertion
+    # sort for the <= 16 candidates seen here)
+    exact = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
+    print("reads whose records differ in any field:", len(exact))
+    assert len(exact) <= 0.002 * len(a), str(exact[:2])[:1500]
 
 
 @pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
@@ -274,7 +277,4 @@ def test_cli_other_read_lengths(tmp_path, read_len):
     assert set(a) == set(b) and len(a) == 2000
     diff = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
     print("records differing:", len(diff), "of", len(a))
-    # only reads whose best score is shared by several repeat copies (MAPQ 0) may land on another copy
-    for n, x, y in diff:
-        assert x["mapq"] == 0 and y["mapq"] == 0 and x["tags"].get("AS") == y["tags"].get("AS") and x["tags"].get("NH") == y["tags"].get("NH"), (n, x, y)
-    assert len(diff) <= 0.02 * len(a), len(diff)
+    assert len(diff) == 0, (len(diff), str(diff[:2])[:1500])

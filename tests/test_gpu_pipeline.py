@@ -137,20 +137,27 @@ def test_map_se_matches_oracle_composition(tmp_path, mode):
         w, mq, num, best = HM.top1(list(sc), keys)
         assert (h["mapq"], h["n_best"]) == (mq, num), (i, h, mq, num, sc)
         assert h["score"] == (best if best > 0 else sc[w])
-        j = offs[i] + w
-        ok, aw = HM.decode_ref(g, n_bases, int(loc[j]) - (c >> 1), (q + c) | 2)
-        res, ocig, omd = O.oracle_align(mode, aw[None, :q + c], qrys[w][None, :], c)
-        if not res["ok"][0]:
-            assert not h["mapped"]
+        # several candidates with the best score: the product keeps the first one in the reference's candidate order
+        # (tests/test_gpu_cli.py checks that order against the real program); here any of the tied ones is consistent
+        tied = [w] if num == 1 else [t for t in range(nc) if (sc[t] == best or not best > 0)]
+
+        def expect(w):
+            j = offs[i] + w
+            ok, aw = HM.decode_ref(g, n_bases, int(loc[j]) - (c >> 1), (q + c) | 2)
+            res, ocig, omd = O.oracle_align(mode, aw[None, :q + c], qrys[w][None, :], c)
+            if not res["ok"][0]:
+                return None
+            conv = HM.convert(geom, int(loc[j]) + int(res["position_offset"][0]) - (c >> 1))
+            if conv is None:
+                return None
+            return (conv[0], conv[1], int(strand[j]), ocig[0], omd[0], int(res["nm"][0]), int(res["qstart"][0]), int(res["qend"][0]),
+                    np.float32(res["identity"][0]))
+        wants = [expect(t) for t in tied]
+        if not h["mapped"]:
+            assert None in wants, (i, h, wants)
             continue
-        final = int(loc[j]) + int(res["position_offset"][0]) - (c >> 1)
-        conv = HM.convert(geom, final)
-        if conv is None:
-            assert not h["mapped"]
-            continue
-        assert h["mapped"] and (h["contig"], h["pos"], h["reverse"]) == (conv[0], conv[1], int(strand[j])), (i, h, conv)
-        assert (cig[i], md[i], h["nm"], h["qstart"], h["qend"]) == (ocig[0], omd[0], int(res["nm"][0]), int(res["qstart"][0]), int(res["qend"][0]))
-        assert np.float32(h["identity"]) == np.float32(res["identity"][0])
+        got = (h["contig"], h["pos"], h["reverse"], cig[i], md[i], h["nm"], h["qstart"], h["qend"], np.float32(h["identity"]))
+        assert got in [x for x in wants if x is not None], (i, got, wants)
         n_mapped += 1
     assert n_mapped > 0.9 * len(reads)
     # truth check: simulated origin within the band of the reported position
