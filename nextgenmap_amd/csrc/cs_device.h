@@ -137,7 +137,7 @@ __device__ __forceinline__ void cs_for_each_hit(const uint32_t *__restrict__ pos
 			}
 		}
 #pragma unroll
-		for (int j = 0; j < HPL; ++j) if (li[j] >= 0) f(pos[j], li[j]);
+		for (int j = 0; j < HPL; ++j) if (li[j] >= 0) f(pos[j], li[j], h0 + (uint32_t) j);
 	}
 }
 
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	__syncthreads();
 	if (MODE == kCsExactGlobal) __threadfence_block();
 
-	cs_for_each_hit(A.positions, l_start, l_pref, R.n_lists, H, lane, [&](uint32_t pos, int li) {
+	cs_for_each_hit(A.positions, l_start, l_pref, R.n_lists, H, lane, [&](uint32_t pos, int li, uint32_t) {
 		const int p = li >> 1;
 		const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
 		const uint32_t bin = (pos - correction) >> A.bin_shift;
@@ -586,76 +586,111 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 // The reference lists a read's candidates in the order in which their bins first reached the running threshold
 // (rList, CS::AddLocationStd, src/CS.cpp:196-211), and ScoreBuffer::top1SE keeps the FIRST of several equally scoring
 // candidates.  The set of candidates does not depend on that order, so the search kernels above do not track it; for
-// the few reads where it matters (several candidates share the best score) this kernel replays the votes of one read
-// sequentially -- hits in exactly the reference's order: k-mers left to right, forward list then reverse-complement
-// list, list entries in index order -- and records for every bin its position in rList.  One wave per read: all lanes
-// fetch 64 hits at a time into LDS, lane 0 replays them against an exact table in LDS.
-// out: cand_rank[c] = 2 * (rList position of the candidate's bin) + strand for every candidate c of the read, i.e. its
-// index order in CollectResultsStd's output (forward before reverse of one bin, src/CS.cpp:289-304).
-constexpr int kCsOrderLog2Slots = 13;                       // exact table of the replay: 8192 slots in LDS
-constexpr uint32_t kCsOrderMaxHits = 6000;                  // reads with more hits keep the position order
+// the reads where it matters (equal scores among the candidates) this kernel replays the votes of one read in exactly
+// the reference's order -- k-mers left to right, forward list then reverse-complement list, list entries in index
+// order -- and records when each bin entered rList.  Only bins with >= 2 votes can move the running maximum beyond 1
+// or become candidates, so the replay is restricted to them: sweep A finds those bins (bit plane + exact table, as in
+// the fast path), sweep B counts their votes and marks their hits on a time line in LDS, then the marked hits
+// (a few hundred of ~4 300) are replayed in time order by the whole wave in lock step.
+// out: cand_rank[c] = 2 * (rList position among the tracked bins) + strand for every candidate c of the read, i.e. its
+// relative order in CollectResultsStd's output (forward before reverse of one bin, src/CS.cpp:289-304).
+constexpr int kCsOrderLog2Slots = 10;       // tracked bins (>= 2 votes, plus bit collisions): 1024 slots
+constexpr uint32_t kCsOrderMaxHits = 6144;  // time line entries in LDS; reads with more hits keep the position order
 constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
 		uint32_t *__restrict__ cand_rank) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	__shared__ uint32_t s_bin[64];
+	__shared__ uint32_t s_keys;  // distinct tracked bins
 	const int lane = threadIdx.x;
 	const int read = (int) A.read_list[blockIdx.x];
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;
 	uint32_t *l_pref = cs_lds + A.lists_cap;
 	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);
-	uint32_t *t_keys = (uint32_t *) l_code + (A.q + 3) / 4;
-	constexpr uint32_t n_slots = 1u << kCsOrderLog2Slots;
-	uint32_t *t_votes = t_keys + n_slots;
-	uint16_t *t_rank = (uint16_t *) (t_votes + n_slots);
-	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_rank[s] = 0xFFFF; }
+	uint32_t *plane = (uint32_t *) l_code + (A.q + 3) / 4;
+	constexpr uint32_t plane_words = 2048, n_slots = 1u << kCsOrderLog2Slots;
+	uint32_t *t_keys = plane + plane_words;
+	uint32_t *t_votes = t_keys + n_slots;   // final votes: forward | reverse << 16
+	uint32_t *t_run = t_votes + n_slots;    // votes so far during the replay
+	uint32_t *t_rank = t_run + n_slots;
+	uint32_t *ev_at = t_rank + n_slots;     // [kCsOrderMaxHits]: slot | strand << 31 of the hit at that time, or empty
+	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
+	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; }
+	if (lane == 0) s_keys = 0;
 	const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
 	const uint32_t H = R.H;
 	const int L = R.L, n_lists = R.n_lists;
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
-	if (H > kCsOrderMaxHits) {  // too many hits for the LDS table: leave the order undefined (the caller falls back)
-		for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown;
-		return;
+	auto give_up = [&]() { for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown; };
+	if (H > kCsOrderMaxHits) { give_up(); return; }
+	__syncthreads();
+	auto bin_of = [&](uint32_t pos, int li) -> uint32_t {
+		const int p = li >> 1;
+		const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
+		return ((pos - correction) >> A.bin_shift) & 0x3FFFFFFFu;
+	};
+	// sweep A (the only pass over the position lists): every hit is written to the time line (bin | strand << 31);
+	// bins hit at least twice (or colliding on a plane bit) become tracked keys
+	cs_for_each_hit(A.positions, l_start, l_pref, n_lists, H, lane, [&](uint32_t pos, int li, uint32_t t) {
+		const uint32_t bin = bin_of(pos, li);
+		ev_at[t] = bin | ((li & 1) ? 0x80000000u : 0u);
+		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
+		const uint32_t msk = 1u << (b & 31);
+		if (atomicOr(&plane[b >> 5], msk) & msk) {
+			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+			for (uint32_t probes = 0; probes < n_slots; ++probes) {
+				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+				if (prev == bin) break;
+				if (prev == 0xFFFFFFFFu) { atomicAdd(&s_keys, 1u); break; }
+				slot = (slot + 1) & (n_slots - 1);
+			}
+		}
+	});
+	__syncthreads();
+	if (s_keys > (n_slots * 3u) / 4u) { give_up(); return; }
+	// sweep B (LDS only): exact votes of the tracked bins; their time line entries become slot | strand << 31, all others empty
+	for (uint32_t t = lane; t < H; t += 64) {
+		const uint32_t e = ev_at[t];
+		const uint32_t bin = e & 0x3FFFFFFFu;
+		uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+		uint32_t out = 0xFFFFFFFFu;
+		for (;;) {
+			const uint32_t key = t_keys[slot];
+			if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); out = slot | (e & 0x80000000u); break; }
+			if (key == 0xFFFFFFFFu) break;
+			slot = (slot + 1) & (n_slots - 1);
+		}
+		ev_at[t] = out;
 	}
 	__syncthreads();
-	float max_hit = 0.0f, thresh = 0.0f;
+	// replay in time order.  A bin with one vote never moves the maximum beyond 1 and is never a candidate: the very
+	// first hit of the read already sets the maximum to 1 (CS.cpp:197-202), so only bins with >= 2 votes are replayed.
+	float max_hit = H > 0 ? 1.0f : 0.0f, thresh = max_hit * A.sensitivity;
 	uint32_t next_rank = 0;
-	for (uint32_t h0 = 0; h0 < H; h0 += 64) {
-		const uint32_t h = h0 + (uint32_t) lane;
-		uint32_t e = 0xFFFFFFFFu;
-		if (h < H) {
-			int lo = 0, hi = n_lists;  // largest li with pref[li] <= h
-			while (hi - lo > 1) {
-				const int mid = (lo + hi) >> 1;
-				if (l_pref[mid] <= h) lo = mid; else hi = mid;
-			}
-			const uint32_t pos = A.positions[l_start[lo] + (h - l_pref[lo])];
-			const int p = lo >> 1;
-			const uint32_t correction = (lo & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
-			e = (((pos - correction) >> A.bin_shift) & 0x3FFFFFFFu) | ((lo & 1) ? 0x80000000u : 0u);
+	for (uint32_t t0 = 0; t0 < H; t0 += 64) {
+		const uint32_t t = t0 + (uint32_t) lane;
+		uint32_t e = (t < H) ? ev_at[t] : 0xFFFFFFFFu;
+		if (e != 0xFFFFFFFFu) {
+			const uint32_t v = t_votes[e & 0x7FFFFFFFu];
+			if ((v & 0xFFFFu) + (v >> 16) < 2u) e = 0xFFFFFFFFu;
 		}
-		s_bin[lane] = e;
-		__syncthreads();
-		if (lane == 0) {
-			const uint32_t cnt = min(64u, H - h0);
-			for (uint32_t i = 0; i < cnt; ++i) {
-				const uint32_t ev = s_bin[i];
-				const uint32_t bin = ev & 0x3FFFFFFFu;
-				uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
-				while (t_keys[slot] != 0xFFFFFFFFu && t_keys[slot] != bin) slot = (slot + 1) & (n_slots - 1);
-				t_keys[slot] = bin;
-				uint32_t v = t_votes[slot];
-				uint32_t score;
-				if (ev & 0x80000000u) { v += 0x10000u; score = v >> 16; } else { v += 1u; score = v & 0xFFFFu; }
-				t_votes[slot] = v;
-				if ((float) score > max_hit) { max_hit = (float) score; thresh = max_hit * A.sensitivity; }  // CS.cpp:197-202
-				if (t_rank[slot] == 0xFFFF && (float) score >= thresh) t_rank[slot] = (uint16_t) next_rank++;  // CS.cpp:205-208
-			}
+		unsigned long long todo = __ballot(e != 0xFFFFFFFFu);
+		while (todo) {
+			const int i = __ffsll((long long) todo) - 1;
+			todo &= todo - 1;
+			const uint32_t ev = (uint32_t) __shfl((int) e, i);
+			const uint32_t slot = ev & 0x7FFFFFFFu;
+			uint32_t run = t_run[slot];
+			uint32_t score;
+			if (ev & 0x80000000u) { run += 0x10000u; score = run >> 16; } else { run += 1u; score = run & 0xFFFFu; }
+			if (lane == 0) t_run[slot] = run;
+			if ((float) score > max_hit) { max_hit = (float) score; thresh = max_hit * A.sensitivity; }      // CS.cpp:197-202
+			if (t_rank[slot] == kCsOrderUnknown && (float) score >= thresh) { if (lane == 0) t_rank[slot] = next_rank; ++next_rank; }  // CS.cpp:205-208
+			__builtin_amdgcn_wave_barrier();  // one wave: LDS operations complete in program order
 		}
-		__syncthreads();
 	}
+	__syncthreads();
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
 	for (uint32_t c = lane; c < cn; c += 64) {
 		const uint32_t bin = ((cand_loc[cb + c] - centre) >> A.bin_shift) & 0x3FFFFFFFu;
@@ -663,10 +698,12 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		uint32_t rank = kCsOrderUnknown;
 		for (uint32_t probes = 0; probes < n_slots; ++probes) {
 			const uint32_t key = t_keys[slot];
-			if (key == bin) { if (t_rank[slot] != 0xFFFF) rank = 2u * t_rank[slot] + (cand_sv[cb + c] & 1u); break; }
+			if (key == bin) { if (t_rank[slot] != kCsOrderUnknown) rank = 2u * t_rank[slot] + (cand_sv[cb + c] & 1u); break; }
 			if (key == 0xFFFFFFFFu) break;
 			slot = (slot + 1) & (n_slots - 1);
 		}
+		// a candidate with a single vote (possible only when the final threshold is <= 1) entered rList at its only hit:
+		// not tracked here, its order stays unknown and the caller falls back to the position order for that read
 		cand_rank[cb + c] = rank;
 	}
 }

@@ -409,13 +409,14 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 // reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
 static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank) {
 	const uint32_t nl = (uint32_t) list.size();
+	const auto t_begin = std::chrono::steady_clock::now();
 	if (m->d_order_list.reserve(nl) || m->d_cand_rank.reserve(np + 1) || m->p_rank.reserve(np + 1)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
 	MAP_HIP_TRY(hipMemcpyAsync(m->d_order_list.p, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, m->st));
 	ngm::CsArgs A = m->last_cs;
 	A.read_list = m->d_order_list.p;
 	A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p;
 	A.counters = nullptr; A.phase_cycles = nullptr;
-	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4) * 4 + ((size_t) 10 << ngm::kCsOrderLog2Slots);
+	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits) * 4;
 	static std::once_flag once;
 	std::call_once(once, [&] { (void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
 	hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(nl), dim3(64), lds, m->st, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
@@ -423,6 +424,8 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, m->st));
 	MAP_HIP_TRY(hipStreamSynchronize(m->st));
 	*h_rank = m->p_rank.p;
+	if (getenv("NGM_HIP_HOST_TIMING"))
+		fprintf(stderr, "[ngm-hip] candidate order replay: %u reads, %.2f ms\n", nl, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 	return 0;
 }
 
@@ -442,7 +445,9 @@ int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const vo
 // ScoreBuffer::top1PE + CheckPairs (src/ScoreBuffer.cpp:368-502) for one pair; `a` = the mate whose scores arrive last
 // (the odd read id: "read"), `b` = its mate.  Candidates are (pair index) lists into loc/score.
 static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
-		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found) {
+		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found,
+		bool *ambiguous = nullptr) {
+	if (ambiguous) *ambiguous = false;
 	if (cnt_a == 1 && cnt_b == 1) {  // the common case: one candidate per mate
 		*mq_a = *mq_b = 60;
 		const uint64_t l1 = loc[base_a], l2 = loc[base_b];
@@ -483,7 +488,7 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 	while (nb < B.size() && min_b <= score[B[nb]]) ++nb;
 	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
 	float top = 0.0f;
-	int distance = 0, equal = 0, ta = -1, tb = -1;
+	int distance = 0, equal = 0, ta = -1, tb = -1, n_top = 0;
 	for (size_t i = 0; i < na; ++i) {
 		for (size_t j = 0; j < nb; ++j) {
 			const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
@@ -491,8 +496,9 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 			bool take = false;
 			if (cur > min_d && cur < max_d) {
 				const float ps = score[A[i]] + score[B[j]];
-				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; }
+				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; n_top = 1; }
 				else if (ps == top) {
+					++n_top;
 					const int avg = (int) (dist_sum / dist_count);
 					if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
 					else if (abs(distance) == abs(cur)) equal += 1;
@@ -502,6 +508,8 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 		}
 	}
 	*found = top > 0.0f;
+	// several pairs share the best pair score: which one is kept depends on the order of the equally scoring candidates
+	if (ambiguous && *found && n_top > 1) { *ambiguous = true; return; }
 	if (*found) {
 		dist_sum += distance;
 		dist_count += 1;
@@ -601,58 +609,76 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is
 			// sequential state of one CS thread in the reference; here every host thread continues from the value at
 			// the start of the batch and the increments are merged afterwards (NGM_HIP_HOST_THREADS=1: strictly sequential).
-			// reads with equally scoring candidates: fetch the reference's candidate order for them first
-			uint32_t *h_rank_pe = nullptr;
-			if (!position_order) {
-				std::vector<uint32_t> need;
-				for (int i = 0; i < n; ++i) {
-					const uint32_t b = m->h_base[i], cnt = m->h_count[i];
-					bool eq = false;
-					for (uint32_t x = 0; x + 1 < cnt && !eq; ++x) for (uint32_t y = x + 1; y < cnt; ++y) if (h_scores[b + x] == h_scores[b + y]) { eq = true; break; }
-					if (eq) need.push_back((uint32_t) i);
-				}
-				if (!need.empty()) {
-					if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
-					// the single-end fallback (no pair in the window / mate without candidates) keeps the first best candidate
-					for (uint32_t i : need) {
-						const uint32_t b = m->h_base[i], cnt = m->h_count[i];
-						float best = h_scores[b];
-						for (uint32_t c2 = 1; c2 < cnt; ++c2) best = std::max(best, h_scores[b + c2]);
-						uint32_t pick = 0xFFFFFFFFu, pick_rank = ngm::kCsOrderUnknown;
-						bool known = true;
-						for (uint32_t c2 = 0; c2 < cnt; ++c2) if (h_scores[b + c2] == best || !(best > 0.0f)) {
-							if (h_rank_pe[b + c2] == ngm::kCsOrderUnknown) { known = false; break; }
-							if (h_rank_pe[b + c2] < pick_rank) { pick_rank = h_rank_pe[b + c2]; pick = b + c2; }
-						}
-						if (known && pick != 0xFFFFFFFFu) h_winner[i] = pick;
-					}
-				}
-			}
 			const long sum0 = m->pair_dist_sum, cnt0 = m->pair_dist_count;
 			std::atomic<long> add_sum{0}, add_cnt{0};
+			std::mutex amb_mu;
+			std::vector<int> amb_pairs;          // pairs whose outcome depends on the order of equally scoring candidates
+			auto commit = [&](int ra, int rb, bool found, int wa, int wb, int mqa, int mqb, int equal) {
+				if (found) {
+					h_winner[ra] = (uint32_t) wa; h_winner[rb] = (uint32_t) wb;
+					h_mapq[ra] = mqa; h_mapq[rb] = mqb;
+					h_nbest[ra] = h_nbest[rb] = equal;
+					h_best[ra] = h_scores[wa]; h_best[rb] = h_scores[wb];
+					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED;
+				} else {
+					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;  // no pair inside the window: single-end selection stands
+				}
+			};
 			parallel_for(n / 2, [&](int plo, int phi) {
 				long dsum = sum0, dcnt = cnt0;
+				std::vector<int> amb_local;
 				for (int pi = plo; pi < phi; ++pi) {
 					const int rb = 2 * pi, ra = 2 * pi + 1;
 					const uint32_t ca = m->h_count[ra], cb = m->h_count[rb];
 					if (ca == 0 || cb == 0) continue;  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
 					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
-					bool found = false;
+					bool found = false, ambiguous = false;
 					select_pair(m, dsum, dcnt, m->h_base[ra], ca, (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], cb,
-							(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, h_rank_pe, &wa, &wb, &mqa, &mqb, &equal, &found);
-					if (found) {
-						h_winner[ra] = (uint32_t) wa; h_winner[rb] = (uint32_t) wb;
-						h_mapq[ra] = mqa; h_mapq[rb] = mqb;
-						h_nbest[ra] = h_nbest[rb] = equal;
-						h_best[ra] = h_scores[wa]; h_best[rb] = h_scores[wb];
-						pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED;
-					} else {
-						pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;  // no pair inside the window: single-end selection stands
-					}
+							(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, nullptr, &wa, &wb, &mqa, &mqb, &equal, &found,
+							position_order ? nullptr : &ambiguous);
+					if (ambiguous) { amb_local.push_back(pi); continue; }
+					commit(ra, rb, found, wa, wb, mqa, mqb, equal);
 				}
 				add_sum += dsum - sum0; add_cnt += dcnt - cnt0;
+				if (!amb_local.empty()) { std::lock_guard<std::mutex> lk(amb_mu); amb_pairs.insert(amb_pairs.end(), amb_local.begin(), amb_local.end()); }
 			});
 			m->pair_dist_sum += add_sum.load(); m->pair_dist_count += add_cnt.load();
+			if (!position_order) {
+				// the reference's candidate order is needed for: the ambiguous pairs, and mates selected single-end
+				// (no pair in the window / mate without candidates) whose best score is shared
+				std::sort(amb_pairs.begin(), amb_pairs.end());
+				std::vector<uint32_t> need;
+				for (int pi : amb_pairs) { need.push_back((uint32_t) (2 * pi)); need.push_back((uint32_t) (2 * pi + 1)); }
+				std::vector<uint32_t> se_tied;
+				for (int i = 0; i < n; ++i)
+					if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] != 1 && m->h_count[i] > 1 && !std::binary_search(amb_pairs.begin(), amb_pairs.end(), i / 2)) se_tied.push_back((uint32_t) i);
+				need.insert(need.end(), se_tied.begin(), se_tied.end());
+				if (!need.empty()) {
+					uint32_t *h_rank_pe = nullptr;
+					if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
+					auto first_best = [&](uint32_t i) {  // ScoreBuffer::top1SE keeps the first of the equally best candidates
+						const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+						float best = h_scores[b];
+						for (uint32_t c2 = 1; c2 < cnt; ++c2) best = std::max(best, h_scores[b + c2]);
+						uint32_t pick = 0xFFFFFFFFu, pick_rank = ngm::kCsOrderUnknown;
+						for (uint32_t c2 = 0; c2 < cnt; ++c2) if (h_scores[b + c2] == best || !(best > 0.0f)) {
+							if (h_rank_pe[b + c2] == ngm::kCsOrderUnknown) return;
+							if (h_rank_pe[b + c2] < pick_rank) { pick_rank = h_rank_pe[b + c2]; pick = b + c2; }
+						}
+						if (pick != 0xFFFFFFFFu) h_winner[i] = pick;
+					};
+					for (int pi : amb_pairs) {
+						const int rb = 2 * pi, ra = 2 * pi + 1;
+						int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
+						bool found = false;
+						select_pair(m, m->pair_dist_sum, m->pair_dist_count, m->h_base[ra], m->h_count[ra], (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb],
+								m->h_count[rb], (int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, h_rank_pe, &wa, &wb, &mqa, &mqb, &equal, &found);
+						commit(ra, rb, found, wa, wb, mqa, mqb, equal);
+						if (!found) { if (h_nbest[ra] != 1 && m->h_count[ra] > 1) first_best((uint32_t) ra); if (h_nbest[rb] != 1 && m->h_count[rb] > 1) first_best((uint32_t) rb); }
+					}
+					for (uint32_t i : se_tied) first_best(i);
+				}
+			}
 		}
 	}
 	const int topn = (!paired && m->prm.topn > 1) ? m->prm.topn : 1;
