@@ -191,7 +191,7 @@ def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None, paired=F
                 examples.append({"read": i, "ours": mine, "reference": (flag & 16, rname, pos, mapq, cigar, a_s, nm)})
             same_place += mine[:3] == (flag & 16, rname, pos)
         parity = {"reads_compared": cmp, "identical_records": same, "same_position": same_place, "first_differences": examples,
-                  "note": "records differing are equal-score repeat copies visited in a different order"}
+                  "note": "all SAM fields compared for reads both sides report as mapped; equal scores are resolved in the reference's own candidate order (cs_order_kernel)"}
     return {"parity_vs_reference_sam": parity, "value": n / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
             "sample": "NextGenMap 0.5.5 ngm-core --affine " + ("-p " if paired else "") + "-t %d on the first %d reads of the step vs the same genome (index "
                       "loaded from cache files written by this library): %.1fs total minus %.1fs index load/start-up measured "
