@@ -154,8 +154,9 @@ constexpr int kCsSeg = 8;   // hits per work item of the fast path
 // 1. read -> 2-bit codes (A0 C1 T2 G3, CSstatic.cpp:20-22), N = 4, past the end = 255;
 // 2. k-mers and their two position lists (lane = k-mer, lists 2p = forward, 2p+1 = reverse complement).
 // The index reads of up to four 64-k-mer rounds are issued before any of them is consumed.
-// ITEMS (fast path): l_pref holds the list LENGTHS instead of their prefix sums, and every list is cut into segments of
-// kCsSeg hits, enumerated in l_items as (list << 16 | segment).
+// ITEMS (fast path, order replay): l_pref holds per list (length | time of its first hit << 16) instead of the prefix sums
+// (both < 65536 for every read these paths accept), and every list is cut into segments of kCsSeg hits, enumerated in
+// l_items as (list << 16 | segment).
 template <bool ITEMS>
 __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, uint32_t *l_pref, uint8_t *l_code,
 		uint32_t *l_items = nullptr, uint32_t items_cap = 0) {
@@ -220,8 +221,9 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 				const uint32_t nsf = (cf + kCsSeg - 1) / kCsSeg, nsr = (cr + kCsSeg - 1) / kCsSeg;
 				const uint32_t incl_s = wave_inclusive_scan(nsf + nsr, lane);
 				if (p < n_kmers) {
-					l_start[2 * p] = sf; l_pref[2 * p] = cf;
-					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = cr;
+					const uint32_t b0 = carry + incl - both;  // time (flattened hit index) of the forward list's first hit
+					l_start[2 * p] = sf; l_pref[2 * p] = (cf & 0xFFFFu) | (b0 << 16);
+					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = (cr & 0xFFFFu) | ((b0 + cf) << 16);
 					uint32_t o = carry_s + incl_s - (nsf + nsr);
 					for (uint32_t sg = 0; sg < nsf; ++sg, ++o) if (o < items_cap) l_items[o] = ((uint32_t) (2 * p) << 16) | sg;
 					for (uint32_t sg = 0; sg < nsr; ++sg, ++o) if (o < items_cap) l_items[o] = ((uint32_t) (2 * p + 1) << 16) | sg;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		if (idx < n_items) {
 			const uint32_t item = l_items[idx];
 			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
-			const uint32_t cnt = min((uint32_t) kCsSeg, l_len[li] - sg * kCsSeg);
+			const uint32_t cnt = min((uint32_t) kCsSeg, (l_len[li] & 0xFFFFu) - sg * kCsSeg);
 			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_start[li] + sg * kCsSeg);
 #pragma unroll
 			for (int v = 0; v < kCsSeg / 4; ++v) if ((uint32_t) (4 * v) < cnt) d[v] = src[v];
@@ -597,6 +599,7 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 constexpr int kCsOrderLog2Slots = 10;       // tracked bins (>= 2 votes, plus bit collisions): 1024 slots
 constexpr uint32_t kCsOrderMaxHits = 6144;  // time line entries in LDS; reads with more hits keep the position order
 constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
+constexpr uint32_t kCsOrderItemCap = 1280; // 8-hit list segments of such a read
 
 __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
 		uint32_t *__restrict__ cand_rank) {
@@ -618,12 +621,13 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; }
 	if (lane == 0) s_keys = 0;
-	const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
+	uint32_t *l_items = ev_at + kCsOrderMaxHits;  // [kCsOrderItemCap]
+	const CsRead R = cs_prepare<true>(A, read, lane, l_start, l_pref, l_code, l_items, kCsOrderItemCap);
 	const uint32_t H = R.H;
-	const int L = R.L, n_lists = R.n_lists;
+	const int L = R.L;
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
 	auto give_up = [&]() { for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown; };
-	if (H > kCsOrderMaxHits) { give_up(); return; }
+	if (H > kCsOrderMaxHits || R.n_items > kCsOrderItemCap) { give_up(); return; }
 	__syncthreads();
 	auto bin_of = [&](uint32_t pos, int li) -> uint32_t {
 		const int p = li >> 1;
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	};
 	// sweep A (the only pass over the position lists): every hit is written to the time line (bin | strand << 31);
 	// bins hit at least twice (or colliding on a plane bit) become tracked keys
-	cs_for_each_hit(A.positions, l_start, l_pref, n_lists, H, lane, [&](uint32_t pos, int li, uint32_t t) {
+	auto vote = [&](uint32_t pos, int li, uint32_t t) {
 		const uint32_t bin = bin_of(pos, li);
 		ev_at[t] = bin | ((li & 1) ? 0x80000000u : 0u);
 		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
@@ -646,20 +650,54 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 				slot = (slot + 1) & (n_slots - 1);
 			}
 		}
-	});
+	};
+	// work item = 8 consecutive hits of one list (two 16-byte loads), the next item's loads in flight
+	{
+		CsU4 cur[2], nxt[2];
+		auto fetch = [&](uint32_t idx, CsU4 (&d)[2]) -> uint32_t {
+			if (idx >= R.n_items) return 0xFFFFFFFFu;
+			const uint32_t item = l_items[idx];
+			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
+			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_start[li] + sg * kCsSeg);
+			d[0] = src[0]; d[1] = src[1];  // the table is padded by 16 entries
+			return item;
+		};
+		uint32_t item = fetch((uint32_t) lane, cur);
+		for (uint32_t idx = (uint32_t) lane; idx < R.n_items; idx += 64) {
+			const uint32_t item_n = fetch(idx + 64, nxt);
+			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
+			const uint32_t meta = l_pref[li];
+			const uint32_t cnt = min((uint32_t) kCsSeg, (meta & 0xFFFFu) - sg * kCsSeg), t0 = (meta >> 16) + sg * kCsSeg;
+			const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+#pragma unroll
+			for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cnt) vote(pos8[j], (int) li, t0 + (uint32_t) j);
+			item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1];
+		}
+	}
 	__syncthreads();
 	if (s_keys > (n_slots * 3u) / 4u) { give_up(); return; }
-	// sweep B (LDS only): exact votes of the tracked bins; their time line entries become slot | strand << 31, all others empty
+	// sweep B (LDS only): exact votes of the tracked bins; their time line entries become slot | strand << 31, all others
+	// empty.  The plane is rebuilt as a bit set of the tracked keys first, so that the ~90 % untracked hits cost one read.
+	for (uint32_t s2 = lane; s2 < plane_words; s2 += 64) plane[s2] = 0;
+	__syncthreads();
+	for (uint32_t s2 = lane; s2 < n_slots; s2 += 64) {
+		const uint32_t key = t_keys[s2];
+		if (key != 0xFFFFFFFFu) { const uint32_t b = (key * 0x9E3779B1u) >> 16; atomicOr(&plane[b >> 5], 1u << (b & 31)); }
+	}
+	__syncthreads();
 	for (uint32_t t = lane; t < H; t += 64) {
 		const uint32_t e = ev_at[t];
 		const uint32_t bin = e & 0x3FFFFFFFu;
-		uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
 		uint32_t out = 0xFFFFFFFFu;
-		for (;;) {
-			const uint32_t key = t_keys[slot];
-			if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); out = slot | (e & 0x80000000u); break; }
-			if (key == 0xFFFFFFFFu) break;
-			slot = (slot + 1) & (n_slots - 1);
+		if ((plane[b >> 5] >> (b & 31)) & 1u) {
+			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+			for (;;) {
+				const uint32_t key = t_keys[slot];
+				if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); out = slot | (e & 0x80000000u); break; }
+				if (key == 0xFFFFFFFFu) break;
+				slot = (slot + 1) & (n_slots - 1);
+			}
 		}
 		ev_at[t] = out;
 	}

@@ -416,7 +416,7 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	A.read_list = m->d_order_list.p;
 	A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p;
 	A.counters = nullptr; A.phase_cycles = nullptr;
-	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits) * 4;
+	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits + ngm::kCsOrderItemCap) * 4;
 	static std::once_flag once;
 	std::call_once(once, [&] { (void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
 	hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(nl), dim3(64), lds, m->st, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
@@ -653,6 +653,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				for (int i = 0; i < n; ++i)
 					if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] != 1 && m->h_count[i] > 1 && !std::binary_search(amb_pairs.begin(), amb_pairs.end(), i / 2)) se_tied.push_back((uint32_t) i);
 				need.insert(need.end(), se_tied.begin(), se_tied.end());
+				if (host_timing) fprintf(stderr, "[ngm-hip] order needed: %zu ambiguous pairs, %zu single-end ties\n", amb_pairs.size(), se_tied.size());
 				if (!need.empty()) {
 					uint32_t *h_rank_pe = nullptr;
 					if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
