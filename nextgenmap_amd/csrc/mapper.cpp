@@ -489,6 +489,7 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
 	float top = 0.0f;
 	int distance = 0, equal = 0, ta = -1, tb = -1, n_top = 0;
+	int top_d[16];  // insert sizes of the pairs that share the best pair score
 	for (size_t i = 0; i < na; ++i) {
 		for (size_t j = 0; j < nb; ++j) {
 			const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
@@ -496,8 +497,9 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 			bool take = false;
 			if (cur > min_d && cur < max_d) {
 				const float ps = score[A[i]] + score[B[j]];
-				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; n_top = 1; }
+				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; n_top = 1; top_d[0] = cur; }
 				else if (ps == top) {
+					if (n_top < 16) top_d[n_top] = cur;
 					++n_top;
 					const int avg = (int) (dist_sum / dist_count);
 					if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
@@ -508,8 +510,24 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 		}
 	}
 	*found = top > 0.0f;
-	// several pairs share the best pair score: which one is kept depends on the order of the equally scoring candidates
-	if (ambiguous && *found && n_top > 1) { *ambiguous = true; return; }
+	// Several pairs share the best pair score.  CheckPairs keeps the one whose insert size is closest to the running mean
+	// (whatever the order) and counts a later pair with the SAME insert size as "equal": the outcome depends on the order
+	// of the equally scoring candidates only if the closest insert size is not unique or two of these pairs have the
+	// same insert size.
+	if (ambiguous && *found && n_top > 1) {
+		bool order_matters = n_top > 16;
+		if (!order_matters) {
+			const int avg = (int) (dist_sum / dist_count);
+			int best_c = INT_MAX, n_best_c = 0;
+			for (int x = 0; x < n_top; ++x) {
+				const int cx = abs(top_d[x] - avg);
+				if (cx < best_c) { best_c = cx; n_best_c = 1; } else if (cx == best_c) ++n_best_c;
+				for (int y = x + 1; y < n_top; ++y) if (abs(top_d[x]) == abs(top_d[y])) order_matters = true;
+			}
+			if (n_best_c > 1) order_matters = true;
+		}
+		if (order_matters) { *ambiguous = true; return; }
+	}
 	if (*found) {
 		dist_sum += distance;
 		dist_count += 1;
