@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		const uint32_t fill = q_len;
 		if (fill > kCsFastQueue) abort_fast = true;  // more repeats than the queue holds: leave it to the exact path
 		// insert when the next item round (typically ~100 repeats) might not fit any more, and after the last one
-		if (fill > kCsFastQueue - 160 || (uint32_t) (it + 1) * 64u >= n_items || it + 1 == kCsFastItems) flush_inserts();
+		if (fill > 96u || (uint32_t) (it + 1) * 64u >= n_items || it + 1 == kCsFastItems) flush_inserts();  // small batches: the table-capacity guard of flush_inserts stays loose
 	}
 	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
 	if (abort_fast) { cs_enqueue(A, read, lane, R); return; }  // not provably exact here
