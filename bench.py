@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
-    ap.add_argument("--workers", type=int, default=3, help="mapper instances (streams + host threads) per GPU")
+    ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
     ap.add_argument("--layout", choices=["pe", "se"], default="pe", help="paired-end (BASELINE.json config #2) or single-end reads")
     args = ap.parse_args()
 

@@ -231,6 +231,15 @@ int upload_reads(ngm_mapper *m, int n, const char *reads) {
 // the host tail of a batch (CIGAR / MD strings, coordinate conversion) is embarrassingly parallel over reads;
 // NextGenMap does it on its CS threads, here a batch is fanned out over the host cores
 std::atomic<int> g_live_mappers{0};  // mapper instances share the host cores
+// GPU stages (candidate search / score / align, each from its first launch to its stream sync) of the mapper instances of
+// one process take turns: kernels of different instances then do not slow each other down, while the host stages of one
+// instance still overlap the GPU stages of the others (NGM_HIP_GPU_STAGE_LOCK=0: let the streams share the GPU)
+std::mutex g_gpu_stage_mu;
+struct GpuStage {
+	std::unique_lock<std::mutex> lk;
+	GpuStage() : lk(g_gpu_stage_mu, std::defer_lock) { static const bool on = !(getenv("NGM_HIP_GPU_STAGE_LOCK") && atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) == 0); if (on) lk.lock(); }
+	void done() { if (lk.owns_lock()) lk.unlock(); }
+};
 template <typename F>
 void parallel_for(int n, F f) {
 	// the host cores are shared by the mapper instances of this process and, under torchrun, by the other ranks of the node
@@ -558,6 +567,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	auto lap = [&](int k) { auto t = now(); t_stage[k] += std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; };
 	MAP_HIP_TRY(hipEventRecord(m->ev[0], m->st));
 	if (!d_reads_ext) if (int rc = upload_reads(m, n, reads)) return rc;
+	GpuStage stage_cs;
 	if (int rc = run_cs(m, n)) return rc;
 	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
 	const uint64_t np = m->n_cand;
@@ -596,6 +606,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipMemcpyAsync(h_sv, m->d_out_sv.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		if (paired) MAP_HIP_TRY(hipMemcpyAsync(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		stage_cs.done();
 		lap(1);
 		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
 		if (!paired && m->prm.topn <= 1 && !position_order) {
@@ -755,6 +766,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			});
 		}
 	}
+	stage_cs.done();
 	lap(2);
 	// ---- alignment stage: one pair per read that has a winner (AlignmentBuffer::DoRun) --------------------
 	std::vector<uint32_t> a_read((size_t) n * topn), a_loc((size_t) n * topn), a_sv((size_t) n * topn), a_out((size_t) n * topn), a_pair((size_t) n * topn);
@@ -773,6 +785,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	int32_t *h_rec = m->p_rec.p;
 	uint16_t *h_runs = nullptr;
 	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
+	GpuStage stage_align;
 	if (na > 0) {
 		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
 				m->d_runs.reserve((size_t) na * rs)) { ngm::pipeline_set_error("out of device memory (align stage)"); return -12; }
@@ -804,6 +817,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		h_runs = m->p_runs.p;
 		MAP_HIP_TRY(hipMemcpy(h_runs, m->d_runs_c.p, n_runs_total * 2, hipMemcpyDeviceToHost));
 	}
+	stage_align.done();
 
 	lap(3);
 	// ---- host: CIGAR / MD, final positions --------------------------------------------------------------
