@@ -103,6 +103,21 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 	return v;
 }
 
+// exclusive prefix sum over the lanes of a small per-lane count (< 2^BITS), bit-sliced: one ballot + mbcnt per bit, no
+// cross-lane data movement; total = sum over all lanes (wave-uniform)
+template <int BITS>
+__device__ __forceinline__ uint32_t wave_prefix_small(uint32_t v, uint32_t &total) {
+	uint32_t pre = 0;
+	total = 0;
+#pragma unroll
+	for (int b = 0; b < BITS; ++b) {
+		const unsigned long long m = __ballot((v >> b) & 1u);
+		pre += __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) << b;
+		total += (uint32_t) __popcll(m) << b;
+	}
+	return pre;
+}
+
 // table reads after the voting phase: a global-memory table was updated by L2 atomics, so bypass L1
 template <int MODE>
 __device__ __forceinline__ uint32_t cs_tload(const uint32_t *p) {
@@ -364,10 +379,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	uint32_t q_len = 0, n_keys = 0;
 	bool abort_fast = false;
 	// queue slots for this lane's `mine` entries: exclusive prefix over the lanes (no LDS counter, no same-address atomics)
-	auto reserve = [&](uint32_t mine) -> uint32_t {
-		const uint32_t incl = wave_inclusive_scan(mine, lane);
-		const uint32_t base = q_len + incl - mine;
-		q_len += __shfl(incl, 63);
+	auto reserve = [&](uint32_t mine) -> uint32_t {  // mine <= 96
+		uint32_t total;
+		const uint32_t base = q_len + wave_prefix_small<7>(mine, total);
+		q_len += total;
 		return base;
 	};
 	// inserts the queued entries (bin | strand << 31), one per lane per round
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 			}
 			atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
 		}
-		n_keys += __shfl(wave_inclusive_scan(fresh, lane), 63);
+		{ uint32_t total; (void) wave_prefix_small<4>(fresh, total); n_keys += total; }  // fresh <= kCsFastQueue / 64
 		if (n_keys > (n_slots * 3u) / 4u) abort_fast = true;  // probing gets slow and the spurious entries too many
 		__syncthreads();
 		q_len = 0;
@@ -431,32 +446,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		const uint32_t meta = rmeta[it % DEPTH];
 		CsU4 (&cur)[kCsSeg / 4] = ring[it % DEPTH];
 		const uint32_t cnt = (meta >> 16) & 0x1Fu, corr = meta & 0xFFFFu, rev = meta & 0x80000000u;
+		// branch-free per hit (the loop is unrolled 12 x 8 times; the kernel has to stay small enough for the instruction
+		// cache): empty slots vote with an all-zero mask (a no-op on whatever plane word their garbage position selects)
 		uint32_t old[kCsSeg], msk[kCsSeg], ent[kCsSeg];
 #pragma unroll
 		for (int j = 0; j < kCsSeg; ++j) {
 			const uint32_t pos = (j & 3) == 0 ? cur[j >> 2].x : (j & 3) == 1 ? cur[j >> 2].y : (j & 3) == 2 ? cur[j >> 2].z : cur[j >> 2].w;
-			old[j] = 0; msk[j] = 0; ent[j] = 0;
-			if ((uint32_t) j < cnt) {
-				const uint32_t bin = ((pos - corr) >> A.bin_shift) & 0x3FFFFFFFu;
-				const uint32_t b = (bin * 0x9E3779B1u) >> sh;
-				msk[j] = 1u << (b & 31);
-				old[j] = atomicOr(&plane[b >> 5], msk[j]);
-				ent[j] = bin | rev;
-			}
+			const bool valid = (uint32_t) j < cnt;
+			const uint32_t bin = ((pos - corr) >> A.bin_shift) & 0x3FFFFFFFu;
+			const uint32_t b = (bin * 0x9E3779B1u) >> sh;
+			msk[j] = valid ? (1u << (b & 31)) : 0u;
+			old[j] = atomicOr(&plane[b >> 5], msk[j]);
+			ent[j] = bin | rev;
 		}
 		uint32_t ndup = 0;
 #pragma unroll
 		for (int j = 0; j < kCsSeg; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
-		uint32_t qb = reserve(ndup);
+		uint32_t qb;
+		{ uint32_t total; qb = q_len + wave_prefix_small<4>(ndup, total); q_len += total; }  // ndup <= 8
 #pragma unroll
 		for (int j = 0; j < kCsSeg; ++j) {
-			uint32_t e = 0;
-			if ((uint32_t) j < cnt) {
-				e = ent[j];
-				if (old[j] & msk[j]) { if (qb < kCsFastQueue) s_queue[qb] = e; ++qb; e = 0; }  // voted in sweep 1: nothing left to do
-				else e |= 0x40000000u;
-			}
-			bins[it * kCsSeg + j] = e;
+			const bool dup = (old[j] & msk[j]) != 0u;           // implies a valid slot
+			const bool first = msk[j] != 0u && !dup;            // valid and first on its bit
+			if (dup) { if (qb < kCsFastQueue) s_queue[qb] = ent[j]; ++qb; }
+			bins[it * kCsSeg + j] = first ? (ent[j] | 0x40000000u) : 0u;  // repeats voted in sweep 1: nothing left to do
 		}
 		const uint32_t fill = q_len;
 		if (fill > kCsFastQueue) abort_fast = true;  // more repeats than the queue holds: leave it to the exact path
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		for (int j = 0; j < kCsSeg; ++j) {
 			const uint32_t e = bins[it * kCsSeg + j];
 			const uint32_t b = ((e & 0x3FFFFFFFu) * 0x9E3779B1u) >> sh;
-			const uint32_t w = (e & 0x40000000u) ? (plane[b >> 5] >> (b & 31)) & 1u : 0u;
+			const uint32_t w = (plane[b >> 5] >> (b & 31)) & (e >> 30) & 1u;  // bit 30 = first on its bit (0 for empty slots)
 			wmask[it] |= w << j;
 		}
 		nhit += __popc(wmask[it]);
@@ -495,8 +508,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	uint32_t qb = reserve(nhit);
 #pragma unroll
 	for (int it = 0; it < kCsFastItems; ++it) {
+		if (wmask[it])
 #pragma unroll
-		for (int j = 0; j < kCsSeg; ++j) if ((wmask[it] >> j) & 1u) { if (qb < kCsFastQueue) s_queue[qb] = bins[it * kCsSeg + j]; ++qb; }
+			for (int j = 0; j < kCsSeg; ++j) if ((wmask[it] >> j) & 1u) { if (qb < kCsFastQueue) s_queue[qb] = bins[it * kCsSeg + j]; ++qb; }
 	}
 	__syncthreads();
 	if (q_len > kCsFastQueue) abort_fast = true;
