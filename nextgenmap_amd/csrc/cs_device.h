@@ -49,6 +49,7 @@ struct CsArgs {
 	int lists_cap;          // LDS capacity for lists (>= 2*(q-k+1))
 	int log2_slots;         // exact table slots (power of two) in LDS
 	int log2_bits;          // FAST: bits per plane
+	int fast_items;         // FAST: items per lane of the kernel instantiation in use
 	uint32_t hit_cap;       // reads with more hits than this are queued for the next path
 	// outputs
 	uint16_t *read_len;     // [n]
@@ -336,14 +337,17 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 // bit plane of the table keys that reuses the plane memory).  A bin with >= 2 votes has all but its first vote
 // inserted in sweep 1 and the first one added in sweep 2: exact; bins with a single vote are dropped (never
 // candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
-constexpr int kCsFastItems = 12;   // items per lane -> up to 768 segments (~4 900 typical hits) per read
-constexpr uint32_t kCsFastItemCap = (uint32_t) kCsFastItems * 64u;
+// items per lane (template parameter of the kernel): 12 -> up to 768 segments (~4 900 typical hits, 150 bp reads vs a
+// human-size index), 24 -> 1 536 segments (250 bp reads)
+constexpr int kCsFastItemsShort = 12, kCsFastItemsLong = 24;
 constexpr int kCsFastDepth = 2;    // segments in flight per lane
 constexpr uint32_t kCsFastQueue = 512;  // LDS queue entries between flushes
 
 struct __attribute__((packed, aligned(4))) CsU4 { uint32_t x, y, z, w; };
 
+template <int kCsFastItems>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void cs_fast_kernel(CsArgs A) {
+	constexpr uint32_t kCsFastItemCap = (uint32_t) kCsFastItems * 64u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	__shared__ uint32_t s_queue[kCsFastQueue];
 	const int lane = threadIdx.x;
@@ -379,9 +383,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	uint32_t q_len = 0, n_keys = 0;
 	bool abort_fast = false;
 	// queue slots for this lane's `mine` entries: exclusive prefix over the lanes (no LDS counter, no same-address atomics)
-	auto reserve = [&](uint32_t mine) -> uint32_t {  // mine <= 96
+	auto reserve = [&](uint32_t mine) -> uint32_t {  // mine <= 8 * kCsFastItems <= 192
 		uint32_t total;
-		const uint32_t base = q_len + wave_prefix_small<7>(mine, total);
+		const uint32_t base = q_len + wave_prefix_small<8>(mine, total);
 		q_len += total;
 		return base;
 	};

@@ -44,6 +44,7 @@ struct ngm_mapper {
 	int cs_log2_small = 10;   // fast path: small exact table ...
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
+	int cs_fast_items = ngm::kCsFastItemsShort;
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank;
@@ -88,7 +89,7 @@ struct DevGuard {
 
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (mode == ngm::kCsFast) w += ((size_t) 1 << (A.log2_bits - 5)) + ngm::kCsFastItemCap;
+	if (mode == ngm::kCsFast) w += ((size_t) 1 << (A.log2_bits - 5)) + (size_t) A.fast_items * 64;
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -127,11 +128,12 @@ int run_cs(ngm_mapper *m, int n) {
 		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) { m->cs_kernel_ms += t; pass_ms[e / 2] = t; } };
 
 		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
-		A.log2_bits = m->cs_log2_bits; A.log2_slots = m->cs_log2_small;
+		A.log2_bits = m->cs_log2_bits; A.log2_slots = m->cs_log2_small; A.fast_items = m->cs_fast_items;
 		A.hit_cap = (1u << m->cs_log2_bits) / 6u;
 		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
-		hipLaunchKernelGGL(ngm::cs_fast_kernel, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		if (A.fast_items == ngm::kCsFastItemsShort) hipLaunchKernelGGL(ngm::cs_fast_kernel<ngm::kCsFastItemsShort>, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		else hipLaunchKernelGGL(ngm::cs_fast_kernel<ngm::kCsFastItemsLong>, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
@@ -350,10 +352,16 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * (double) (1u << lb)) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
 		m->cs_log2_bits = lb;
 		m->cs_log2_small = ls;
+		// expected 8-hit segments per read: every list contributes its hits / 8 plus, on average, half a segment of slack
+		const double segs = hexp / 8.0 + 0.6 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
+		m->cs_fast_items = segs * 1.12 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
+		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
 	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17;
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	A.fast_items = ngm::kCsFastItemsLong;
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsShort>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
 	return m;

@@ -50,7 +50,9 @@ def _world(tmp_path, n_reads=3000, read_len=100, seed=5):
 
 
 @pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
-def test_candidate_search_matches_reference_program(tmp_path):
+@pytest.mark.parametrize("fast_items", [12, 24], ids=["12-items-per-lane", "24-items-per-lane"])
+def test_candidate_search_matches_reference_program(tmp_path, monkeypatch, fast_items):
+    monkeypatch.setenv("NGM_HIP_CS_FAST_ITEMS", str(fast_items))  # both instantiations of the fast kernel
     from nextgenmap_amd.pipeline import Mapper, Reference
     contigs, reads, fa, fq = _world(tmp_path)
     r = RF.run_ngm(["-r", fa, "-q", fq, "-o", str(tmp_path / "out.sam"), "--affine", "-t", "1", "--no-progress", "-s", "0.5",
