@@ -352,9 +352,9 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * (double) (1u << lb)) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
 		m->cs_log2_bits = lb;
 		m->cs_log2_small = ls;
-		// expected 8-hit segments per read: every list contributes its hits / 8 plus, on average, half a segment of slack
-		const double segs = hexp / 8.0 + 0.6 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
-		m->cs_fast_items = segs * 1.12 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
+		// expected 8-hit segments per read: every list contributes its hits / 8 plus, on average, 7/16 of a segment of slack
+		const double segs = hexp / 8.0 + 0.44 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
+		m->cs_fast_items = segs * 1.10 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
 		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
