@@ -375,7 +375,9 @@ def main():
                                  "8-64 B reads, latency- not bandwidth-limited; the SW kernels are VALU-bound, see sw_gcells_per_s"},
             "stats_allreduce": {"reads": stats[0], "mapped": stats[1], "unmapped": stats[2], "candidates": stats[6]},
         }
-        if not args.no_cpu_baseline:
+        if world > 1:
+            line["cpu_baseline"] = None  # the host baseline is timed on rank 0 of a 1-GPU run only
+        elif not args.no_cpu_baseline:
             try:
                 import ref_files as RF
                 if not RF.have_reference_binary():
