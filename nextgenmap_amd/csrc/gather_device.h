@@ -65,29 +65,57 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(const uint8_t *__rest
 	const bool rev = live ? (pair_sv[pair] & 1u) : false;
 	const int L = live ? (int) read_len[ridx] : 0;
 	const uint8_t *rp = reads + (size_t) ridx * q;
+	struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
 	for (int m = part; m < RW; m += 4) {
 		uint32_t k[8];
+		// the 8 read characters of this word: two (unaligned) dword loads when they lie inside the row
+		const int first = rev ? L - 8 * m - 8 : 8 * m;  // row offset of the lowest-addressed of the 8 characters
+		uint32_t lo4 = 0, hi4 = 0;
+		const bool fast = live && first >= 0 && first + 8 <= q;
+		if (fast) { lo4 = reinterpret_cast<const U32 *>(rp + first)->v; hi4 = reinterpret_cast<const U32 *>(rp + first + 4)->v; }
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			const int i = m * 8 + j;
 			uint32_t c = 6u;
 			if (live && i < L) {
-				if (!rev) c = read_class_fwd(rp[i]);
-				else {  // reverse complement: A<->T, C<->G, N stays (MappedRead.cpp:32-43, :53-68)
-					c = read_class_fwd(rp[L - 1 - i]);
-					c = (c <= 3u) ? 3u - c : c;
-				}
+				uint32_t ch;
+				if (fast) { const int b = rev ? 7 - j : j; ch = ((b < 4 ? lo4 : hi4) >> (8 * (b & 3))) & 0xFFu; }
+				else ch = rev ? rp[L - 1 - i] : rp[i];
+				c = read_class_fwd(ch);
+				if (rev) c = (c <= 3u) ? 3u - c : c;  // reverse complement: A<->T, C<->G, N stays (MappedRead.cpp:32-43, :53-68)
 			}
 			k[j] = c;
 		}
 		ob[(size_t) m * kSlots] = pack8(k);
 	}
 	const uint64_t offset = live ? (uint64_t) pair_loc[pair] - (uint64_t) G.half_corridor : 0;
+	// bases [0, plain) of the window are plain genome nibbles (window_class: before the odd-length 'x' and the fill past
+	// the genome end): words that lie entirely inside are cut out of two genome dwords with a funnel shift
+	uint64_t plain = 0;
+	if (live && offset < G.concat_len) {
+		uint64_t len = (uint64_t) G.buffer_len - 2, end = 0;
+		if (offset + len > G.concat_len) { end = offset + len - G.concat_len; len -= end; }
+		const uint64_t emitted = ((offset & 1) ? 1 : 0) + 2 * ((len + 1) / 2);
+		plain = (len & 1) ? emitted - 1 : emitted;
+	}
 	for (int m = part; m < FW; m += 4) {
-		uint32_t k[8];
+		uint32_t word;
+		if ((uint64_t) (m * 8 + 8) <= plain) {
+			const uint64_t pos = offset + (uint64_t) m * 8;
+			const uint32_t w0 = genome[pos >> 3], w1 = genome[(pos >> 3) + 1];
+			const uint32_t r = 4u * (uint32_t) (pos & 7);
+			const uint32_t v = r ? ((w0 >> r) | (w1 << (32u - r))) : w0;  // nibble j = base j
+			uint32_t lo = v & 0xFFFFu, hi = v >> 16;                       // pack8: nibble 2j = base j, 2j+1 = base j+4
+			lo = (lo | (lo << 8)) & 0x00FF00FFu; lo = (lo | (lo << 4)) & 0x0F0F0F0Fu;
+			hi = (hi | (hi << 8)) & 0x00FF00FFu; hi = (hi | (hi << 4)) & 0x0F0F0F0Fu;
+			word = lo | (hi << 4);
+		} else {
+			uint32_t k[8];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) k[j] = live ? window_class(genome, G, offset, m * 8 + j) : 6u;
-		ob[(size_t) (RW + m) * kSlots] = pack8(k);
+			for (int j = 0; j < 8; ++j) k[j] = live ? window_class(genome, G, offset, m * 8 + j) : 6u;
+			word = pack8(k);
+		}
+		ob[(size_t) (RW + m) * kSlots] = word;
 	}
 	if (part == 0) {
 		if (live) lens[pair] = (uint16_t) L;
