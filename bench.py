@@ -372,7 +372,11 @@ def main():
                                       "reads": int(bounds[1] - bounds[0]),
                                       "note": "same kernel, one launch of one mapper instance with nothing else on the GPU (untimed extra pass)"}, "bytes_per_launch": b_cs / W, "launches_per_step": W,
                          "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); dependent random "
-                                 "8-64 B reads, latency- not bandwidth-limited; the SW kernels are VALU-bound, see sw_gcells_per_s"},
+                                 "4-16 B gathers; the kernel is bound by LDS atomics and instruction issue rather than HBM (DESIGN.md 4); the SW kernels are "
+                                 "VALU-bound, see sw_gcells_per_s"},
+            # SURVEY.md 8d's whole-path figure: (pairs * B_score + alignments * B_align + B_cs) per second of wall time
+            "path_algorithmic_gbs": (n_cand * (Q + Q + C + 4) + int(mapped.sum()) * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)) + b_cs) * world
+                                    / (elapsed / args.steps) / 1e9,
             "stats_allreduce": {"reads": stats[0], "mapped": stats[1], "unmapped": stats[2], "candidates": stats[6]},
         }
         if world > 1:

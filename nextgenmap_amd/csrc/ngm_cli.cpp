@@ -81,6 +81,7 @@ struct Opts {
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
 	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
 	int skip_save = 0;
+	std::string rg[12];  // read group: ID CN DS DT FO KS LB PG PI PL PU SM (SAMWriter.cpp:46-80)
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
 	float sensitivity = -1.f, kmer_min = 0.f, min_identity = 0.65f, min_residues = 0.5f;
 	int batch = 1 << 20;
@@ -94,7 +95,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, PEDELIM, STRATA, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, PEDELIM, STRATA, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -110,6 +111,10 @@ Opts parse(int argc, char **argv) {
 		{"kernel-variant", required_argument, 0, VARIANT},
 		{"qry1", required_argument, 0, '1'}, {"qry2", required_argument, 0, '2'}, {"paired", no_argument, 0, 'p'},
 		{"min-insert-size", required_argument, 0, 'I'}, {"max-insert-size", required_argument, 0, 'X'}, {"pe-delimiter", required_argument, 0, PEDELIM},
+		{"rg-id", required_argument, 0, RG0}, {"rg-cn", required_argument, 0, RG0 + 1}, {"rg-ds", required_argument, 0, RG0 + 2},
+		{"rg-dt", required_argument, 0, RG0 + 3}, {"rg-fo", required_argument, 0, RG0 + 4}, {"rg-ks", required_argument, 0, RG0 + 5},
+		{"rg-lb", required_argument, 0, RG0 + 6}, {"rg-pg", required_argument, 0, RG0 + 7}, {"rg-pi", required_argument, 0, RG0 + 8},
+		{"rg-pl", required_argument, 0, RG0 + 9}, {"rg-pu", required_argument, 0, RG0 + 10}, {"rg-sm", required_argument, 0, RG0 + 11},
 		{"fast-pairing", no_argument, 0, UNSUPPORTED}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
 		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, UNSUPPORTED}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
 		{"slam-seq", required_argument, 0, UNSUPPORTED}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
@@ -148,6 +153,8 @@ Opts parse(int argc, char **argv) {
 		case GRP: o.gap_read = atoi(optarg); break;
 		case GFP: o.gap_ref = atoi(optarg); break;
 		case AFFINE: o.affine = 1; break;
+		case RG0: case RG0 + 1: case RG0 + 2: case RG0 + 3: case RG0 + 4: case RG0 + 5: case RG0 + 6: case RG0 + 7: case RG0 + 8: case RG0 + 9:
+		case RG0 + 10: case RG0 + 11: o.rg[c - RG0] = optarg; break;
 		case GEP: o.gap_extend = atoi(optarg); break;
 		case MAXCMRS: o.max_cmrs = atoi(optarg); break;
 		case NOUNAL: o.no_unal = 1; break;
@@ -301,6 +308,14 @@ int main(int argc, char **argv) {
 	for (int i = 0; i < ngm_ref_contig_count(ref); ++i)
 		fprintf(out, "@SQ\tSN:%s\tLN:%llu\n", ngm_ref_contig_name(ref, i), (unsigned long long) ngm_ref_contig_len(ref, i));
 	fprintf(out, "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"%s\"\n", o.cmdline.c_str());
+	if (!o.rg[0].empty()) {  // SAMWriter.cpp:46-80
+		static const char *tag[12] = {"ID", "CN", "DS", "DT", "FO", "KS", "LB", "PG", "PI", "PL", "PU", "SM"};
+		fprintf(out, "@RG\tID:%s", o.rg[0].c_str());
+		for (int t = 1; t < 12; ++t) if (!o.rg[t].empty()) fprintf(out, "\t%s:%s", tag[t], o.rg[t].c_str());
+		fprintf(out, "\n");
+	}
+	const std::string rg_mapped = o.rg[0].empty() ? std::string() : "RG:Z:" + o.rg[0] + "\t";
+	const std::string rg_unmapped = o.rg[0].empty() ? std::string() : "\tRG:Z:" + o.rg[0];
 
 	// ---- pass 2: map in batches ------------------------------------------------------------------------------
 	std::vector<Read> batch;
@@ -337,9 +352,9 @@ int main(int argc, char **argv) {
 		const bool clip = o.hard_clip || o.silent_clip;
 		const int s0 = clip ? h.qstart : 0, sl = clip ? L - h.qstart - h.qend : L;
 		const float identity = roundf(h.identity * 10000.0f) / 10000.0f;
-		fprintf(out, "%s\t%d\t%s\t%llu\t%d\t%s\t%s\t%llu\t%lld\t%.*s\t%.*s\tAS:i:%d\tNM:i:%d\tNH:i:%d\tXI:f:%g\tX0:i:%d\tXE:i:%d\tXR:i:%d\tMD:Z:%s\n",
+		fprintf(out, "%s\t%d\t%s\t%llu\t%d\t%s\t%s\t%llu\t%lld\t%.*s\t%.*s\t%sAS:i:%d\tNM:i:%d\tNH:i:%d\tXI:f:%g\tX0:i:%d\tXE:i:%d\tXR:i:%d\tMD:Z:%s\n",
 				v.r->name.c_str(), flags, ngm_ref_contig_name(ref, h.contig), (unsigned long long) h.pos + 1, h.mapq, v.cigar, rnext, pnext, tlen,
-				sl, seq.c_str() + s0, noq ? 1 : sl, noq ? "*" : ql.c_str() + s0,
+				sl, seq.c_str() + s0, noq ? 1 : sl, noq ? "*" : ql.c_str() + s0, rg_mapped.c_str(),
 				(int) h.score, h.nm, h.n_best, identity, h.n_best, (int) h.max_votes, L - h.qstart - h.qend, v.md);
 		++n_written;
 	};
@@ -348,8 +363,8 @@ int main(int argc, char **argv) {
 		if (o.no_unal) return;
 		const bool noq = v.r->qual.empty();
 		const int ql = noq ? 1 : std::min<int>((int) v.r->qual.size(), v.L);
-		fprintf(out, "%s\t%d\t%s\t%llu\t0\t*\t%c\t%llu\t0\t%.*s\t%.*s\n", v.r->name.c_str(), flags | 0x4, contig >= 0 ? ngm_ref_contig_name(ref, contig) : "*",
-				pos1, rnext, pnext1, v.L, v.row, ql, noq ? "*" : v.r->qual.c_str());
+		fprintf(out, "%s\t%d\t%s\t%llu\t0\t*\t%c\t%llu\t0\t%.*s\t%.*s%s\n", v.r->name.c_str(), flags | 0x4, contig >= 0 ? ngm_ref_contig_name(ref, contig) : "*",
+				pos1, rnext, pnext1, v.L, v.row, ql, noq ? "*" : v.r->qual.c_str(), rg_unmapped.c_str());
 		++n_written;
 	};
 

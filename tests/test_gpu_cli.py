@@ -107,8 +107,10 @@ def _write_case(tmp_path, n_reads=4000, read_len=100, seed=31):
 
 
 @pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
-@pytest.mark.parametrize("extra", [[], ["-e"], ["--gap-extend-penalty", "5", "--gap-read-penalty", "25", "--gap-ref-penalty", "25"]],
-                         ids=["local", "end-to-end", "custom-gaps"])
+@pytest.mark.parametrize("extra", [[], ["-e"], ["--gap-extend-penalty", "5", "--gap-read-penalty", "25", "--gap-ref-penalty", "25"],
+                                   ["--rg-id", "grp1", "--rg-sm", "sample1", "--rg-pl", "ILLUMINA"], ["--hard-clip", "-R", "0.8"],
+                                   ["--no-unal", "-Q", "20", "-i", "0.9"]],
+                         ids=["local", "end-to-end", "custom-gaps", "read-group", "hard-clip", "no-unal-minmq"])
 def test_cli_affine_sam_equals_reference_program(tmp_path, extra):
     """`ngm-hip --affine` against `ngm --affine` (the one personality the reference can run here): every SAM field
     of every read, including CIGAR, NM, XI, XS, XE, XR, MAPQ and the "!!!" MD placeholder."""
@@ -122,7 +124,9 @@ def test_cli_affine_sam_equals_reference_program(tmp_path, extra):
     c = subprocess.run([CLI, "-r", fa, "-q", fq, "-o", str(tmp_path / "hip.sam"), "--affine"] + extra, capture_output=True, text=True)
     assert c.returncode == 0, c.stderr[-2000:]
     a, b = _sam(str(d1 / "out.sam")), _sam(str(tmp_path / "hip.sam"))
-    assert set(a) == set(b) and len(a) == 4000
+    assert set(a) == set(b) and (len(a) == 4000 or "--no-unal" in extra)
+    hdr = lambda p: [l for l in open(p) if l.startswith("@") and not l.startswith("@PG")]
+    assert hdr(str(d1 / "out.sam")) == hdr(str(tmp_path / "hip.sam"))
     diff = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
     print("records differing:", len(diff), "of", len(a))
     for d in diff[:2]:
