@@ -76,6 +76,14 @@ const void *find_aot_kernel(int c, int kind) {
 	return nullptr;
 }
 
+// packed 16-bit linear score kernels (two pairs per lane) of the ahead-of-time corridors
+const void *find_pk_score_kernel(int c, bool endfree) {
+#define X(C) if (c == C) return endfree ? (const void *) ngm::sw_score_pk_kernel<C, true> : (const void *) ngm::sw_score_pk_kernel<C, false>;
+	NGM_CORRIDORS(X)
+#undef X
+	return nullptr;
+}
+
 KernelRef find_kernel(ngm_hip_ctx *ctx, int kind) {
 	KernelRef k;
 	k.aot = find_aot_kernel(ctx->c, kind);
@@ -112,7 +120,19 @@ int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipS
 				(const uint16_t *) ctx->blk_rows.p, d_scores, (uint32_t *) nullptr, (int32_t *) nullptr, n, nb, ctx->RW, ctx->q, ctx->KA));
 		return 0;
 	}
-	const KernelRef k = find_kernel(ctx, (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END ? 1 : 0);
+	const bool endfree = (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END;
+	// two pairs per lane in 16-bit halves while every re-based value fits (rows * (match - mismatch) and the end-to-end
+	// sentinel stay inside int16); NGM_HIP_SCORE_32BIT=1 forces the 32-bit kernel
+	static const bool force32 = getenv("NGM_HIP_SCORE_32BIT") != nullptr;
+	if (!force32 && (long) ctx->q * ctx->K.tM < 30000 && (long) ctx->q * ctx->K.tZ < 14000) {
+		if (const void *pk = find_pk_score_kernel(ctx->c, endfree)) {
+			KernelRef kp; kp.aot = pk;
+			HIP_TRY(ctx, launch_kernel(kp, dim3((nb + 7) / 8), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+					(const uint16_t *) ctx->blk_rows.p, d_scores, n, nb, ctx->RW, ctx->K));
+			return 0;
+		}
+	}
+	const KernelRef k = find_kernel(ctx, endfree ? 1 : 0);
 	HIP_TRY(ctx, launch_kernel(k, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
 			(const uint16_t *) ctx->blk_rows.p, d_scores, n, nb, ctx->RW, ctx->K));
 	return 0;

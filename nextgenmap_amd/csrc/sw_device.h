@@ -293,4 +293,116 @@ __global__ __launch_bounds__(256) void sw_score_kernel(const uint32_t *__restric
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// score kernel, packed 16-bit: TWO pairs per lane (blocks 2w and 2w+1 of the packed batch), every band value
+// is a 16-bit half of one VGPR and every DP operation a v_pk_add_i16 / v_pk_max_i16 on both pairs at once.
+// Same recurrences and re-basing as sw_score_kernel; valid while the re-based values fit 16 bits
+// (rows * (match - mismatch) < 2^15, checked by the host, which otherwise uses the 32-bit kernel).
+// The substitution bytes of the two pairs come from two v_perm lookups and are merged into the two halves by a third.
+// ---------------------------------------------------------------------------------------------
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2s pk_splat(int x) { v2s r; r.x = (short) x; r.y = (short) x; return r; }
+__device__ __forceinline__ v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+
+template <int C, bool ENDFREE>
+__global__ __launch_bounds__(256) void sw_score_pk_kernel(const uint32_t *__restrict__ packed,
+		const uint16_t *__restrict__ lens, const uint16_t *__restrict__ blk_rows,
+		float *__restrict__ scores, int n, int n_blocks, int RW, SwConst K) {
+	__shared__ uint2 s_tab[8];
+	if (threadIdx.x < 8) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int blkA = 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));
+	if (blkA >= n_blocks) return;
+	const bool hasB = blkA + 1 < n_blocks;
+	const int blkB = hasB ? blkA + 1 : blkA;
+	constexpr int NRG = sel_regs(C);
+	const int FW = RW + NRG / 2;
+	const uint32_t *rdA = packed + (size_t) blkA * (RW + FW) * kSlots + lane, *rdB = packed + (size_t) blkB * (RW + FW) * kSlots + lane;
+	const uint32_t *fdA = rdA + (size_t) RW * kSlots, *fdB = rdB + (size_t) RW * kSlots;
+	const int rows = max(__builtin_amdgcn_readfirstlane((int) blk_rows[blkA]), __builtin_amdgcn_readfirstlane((int) blk_rows[blkB]));
+	const int ngroups = (rows + 7) >> 3;
+
+	v2s H[C];
+#pragma unroll
+	for (int d = 0; d < C; ++d) H[d] = pk_splat(0);
+	uint32_t RGA[NRG], RGB[NRG];
+#pragma unroll
+	for (int r = 0; r < NRG / 2; ++r) {
+		const uint32_t xa = fdA[(size_t) r * kSlots], xb = fdB[(size_t) r * kSlots];
+		RGA[2 * r] = xa & 0x0F0F0F0Fu; RGA[2 * r + 1] = (xa >> 4) & 0x0F0F0F0Fu;
+		RGB[2 * r] = xb & 0x0F0F0F0Fu; RGB[2 * r + 1] = (xb >> 4) & 0x0F0F0F0Fu;
+	}
+	int fl = K.tZ;
+	v2s best = pk_splat(0);
+	const v2s gl2 = pk_splat(K.gl), gu2 = pk_splat(K.gu);
+	uint32_t rnA = (ngroups > 0) ? rdA[0] : 0x66666666u, rnB = (ngroups > 0) ? rdB[0] : 0x66666666u;
+
+	for (int g = 0; g < ngroups; ++g) {
+		const uint32_t rxA = rnA, rxB = rnB;
+		rnA = (g + 1 < ngroups) ? rdA[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		rnB = (g + 1 < ngroups) ? rdB[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		const uint32_t fxA = fdA[(size_t) (g + NRG / 2) * kSlots], fxB = fdB[(size_t) (g + NRG / 2) * kSlots];
+		const uint32_t rsA[2] = {rxA & 0x0F0F0F0Fu, (rxA >> 4) & 0x0F0F0F0Fu}, rsB[2] = {rxB & 0x0F0F0F0Fu, (rxB >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {
+			const uint2 TA = s_tab[(rsA[s >> 2] >> (8 * (s & 3))) & 0xFFu], TB = s_tab[(rsB[s >> 2] >> (8 * (s & 3))) & 0xFFu];
+			uint32_t PA[NRG], PB[NRG];
+#pragma unroll
+			for (int r = 0; r < NRG; ++r) {
+				const bool used = (s + C - 1) / 4 >= r && s / 4 <= r;
+				PA[r] = used ? __builtin_amdgcn_perm(TA.y, TA.x, RGA[r]) : 0u;
+				PB[r] = used ? __builtin_amdgcn_perm(TB.y, TB.x, RGB[r]) : 0u;
+			}
+			const v2s fl2 = pk_splat(fl);
+			v2s left = ENDFREE ? pk_splat(fl + kShortMin) : fl2;
+			v2s rowmax = fl2;
+#pragma unroll
+			for (int d = 0; d < C; ++d) {
+				const int bi = s + d, kb = bi & 3;
+				// byte kb of PA -> low half, byte kb of PB -> high half, zero-extended
+				const uint32_t sel = 0x0C000C00u | (uint32_t) kb | ((uint32_t) (4 + kb) << 16);
+				const uint32_t tt = __builtin_amdgcn_perm(PB[bi >> 2], PA[bi >> 2], sel);
+				const v2s t = __builtin_bit_cast(v2s, tt);
+				const v2s dg = H[d] + t;
+				const v2s a = left + gl2;
+				v2s h;
+				if (d < C - 1) h = pk_max(pk_max(a, H[d + 1] + gu2), dg);
+				else if (ENDFREE) h = pk_max(pk_max(a, pk_splat(fl + kShortMin + K.gap_read)), dg);
+				else h = pk_max(a, dg);
+				if (!ENDFREE) { h = pk_max(h, fl2); rowmax = pk_max(rowmax, h); }
+				H[d] = h;
+				left = h;
+			}
+			if (!ENDFREE) best = pk_max(best, rowmax - fl2);
+			fl += K.tZ;
+		}
+#pragma unroll
+		for (int r = 0; r + 2 < NRG; ++r) { RGA[r] = RGA[r + 2]; RGB[r] = RGB[r + 2]; }
+		RGA[NRG - 2] = fxA & 0x0F0F0F0Fu; RGA[NRG - 1] = (fxA >> 4) & 0x0F0F0F0Fu;
+		RGB[NRG - 2] = fxB & 0x0F0F0F0Fu; RGB[NRG - 1] = (fxB >> 4) & 0x0F0F0F0Fu;
+	}
+
+	int resA, resB;
+	if (ENDFREE) {
+		const v2s klast = pk_splat(-(fl - K.tZ));
+		v2s mx = pk_splat(kShortMin);
+#pragma unroll
+		for (int d = 0; d < C; ++d) mx = pk_max(mx, H[d] + klast);
+		resA = mx.x; resB = mx.y;
+	} else {
+		resA = best.x; resB = best.y;
+	}
+	const int pairA = blkA * kSlots + lane, pairB = blkB * kSlots + lane;
+	if (pairA < n) {
+		if (K.variant == 1 && lens[pairA] == 0) resA = ENDFREE ? kShortMin : -1;
+		scores[pairA] = (float) resA;
+	}
+	if (hasB && pairB < n) {
+		if (K.variant == 1 && lens[pairB] == 0) resB = ENDFREE ? kShortMin : -1;
+		scores[pairB] = (float) resB;
+	}
+}
+
 }  // namespace ngm
