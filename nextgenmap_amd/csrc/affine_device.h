@@ -214,6 +214,137 @@ __global__ __launch_bounds__(256) void sw_affine_kernel(const uint32_t *__restri
 	}
 }
 
+// Score-only variant, packed 16-bit: two pairs per lane (blocks 2w and 2w+1), S / Eh / Ev in the 16-bit halves of one
+// VGPR, v_pk_add_i16 / v_pk_max_i16 on both pairs at once.  Only the maximum is needed here (no end cell), so SeqAn's
+// tie rules drop out; the local clamp "S <= 0 -> S = Eh = Ev = 0" is the only select and is done arithmetically:
+// nz = min(max(S' - floor, 0), 1) is 1 exactly where the cell survives, X' = floor + (X' - floor) * nz.
+// Valid while the re-based values fit 16 bits (checked by the host, which otherwise uses the 32-bit kernel).
+constexpr int kAffNeg16 = -20000;
+
+template <int CP, bool ENDFREE>
+__global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t *__restrict__ packed, const uint16_t *__restrict__ lens,
+		const uint16_t *__restrict__ blk_rows, float *__restrict__ scores, int n, int n_blocks, int RW, AffConst K) {
+	__shared__ uint2 s_tab[8];
+	if (threadIdx.x < 8) s_tab[threadIdx.x] = aff_row_table(threadIdx.x, K);
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int blkA = 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));
+	if (blkA >= n_blocks) return;
+	const bool hasB = blkA + 1 < n_blocks;
+	const int blkB = hasB ? blkA + 1 : blkA;
+	constexpr int NRG = sel_regs(CP);
+	const int FW = RW + NRG / 2;
+	const uint32_t *rdA = packed + (size_t) blkA * (RW + FW) * kSlots + lane, *rdB = packed + (size_t) blkB * (RW + FW) * kSlots + lane;
+	const uint32_t *fdA = rdA + (size_t) RW * kSlots, *fdB = rdB + (size_t) RW * kSlots;
+	const int pairA = blkA * kSlots + lane, pairB = blkB * kSlots + lane;
+	const int lenVA = (pairA < n) ? (int) lens[pairA] : 0, lenVB = (pairB < n) ? (int) lens[pairB] : 0;
+	const int rows = max(__builtin_amdgcn_readfirstlane((int) blk_rows[blkA]), __builtin_amdgcn_readfirstlane((int) blk_rows[blkB]));
+	const int ngroups = (rows + 7) >> 3;
+
+	auto window_len = [&](const uint32_t *fd) {  // first NUL class of the window (see sw_affine_kernel)
+		int len = FW * 8;
+		for (int m = FW - 1; m >= 0; --m) {
+			const uint32_t x = fd[(size_t) m * kSlots];
+			const uint32_t lo = x & 0x0F0F0F0Fu, hi = (x >> 4) & 0x0F0F0F0Fu;
+#pragma unroll
+			for (int j = 7; j >= 0; --j) {
+				const uint32_t cls = (j < 4) ? (lo >> (8 * j)) & 15u : (hi >> (8 * (j - 4))) & 15u;
+				if (cls == 6u) len = m * 8 + j;
+			}
+		}
+		return len;
+	};
+	const int lenHA = ENDFREE ? window_len(fdA) : FW * 8, lenHB = ENDFREE ? window_len(fdB) : FW * 8;
+
+	v2s S[CP], Ev[CP];
+#pragma unroll
+	for (int d = 0; d < CP; ++d) { S[d] = pk_splat(0); Ev[d] = pk_splat(ENDFREE ? kAffNeg16 : 0); }
+	uint32_t RGA[NRG], RGB[NRG];
+#pragma unroll
+	for (int r = 0; r < NRG / 2; ++r) {
+		const uint32_t xa = fdA[(size_t) r * kSlots], xb = fdB[(size_t) r * kSlots];
+		RGA[2 * r] = xa & 0x0F0F0F0Fu; RGA[2 * r + 1] = (xa >> 4) & 0x0F0F0F0Fu;
+		RGB[2 * r] = xb & 0x0F0F0F0Fu; RGB[2 * r + 1] = (xb >> 4) & 0x0F0F0F0Fu;
+	}
+	int fl = K.tZ;
+	v2s best2 = pk_splat(0);                 // local: running maximum of both pairs
+	int bestA = kAffNeg, bestB = kAffNeg;    // end-to-end: latched at each pair's last row
+	const v2s ext2 = pk_splat(K.ext), open2 = pk_splat(K.open), vext2 = pk_splat(K.vext), vopen2 = pk_splat(K.vopen);
+	const v2s neg2 = pk_splat(kAffNeg16), one2 = pk_splat(1), zero2 = pk_splat(0);
+	uint32_t rnA = (ngroups > 0) ? rdA[0] : 0x66666666u, rnB = (ngroups > 0) ? rdB[0] : 0x66666666u;
+
+	for (int g = 0; g < ngroups; ++g) {
+		const uint32_t rxA = rnA, rxB = rnB;
+		rnA = (g + 1 < ngroups) ? rdA[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		rnB = (g + 1 < ngroups) ? rdB[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		const uint32_t fxA = fdA[(size_t) (g + NRG / 2) * kSlots], fxB = fdB[(size_t) (g + NRG / 2) * kSlots];
+		const uint32_t rsA[2] = {rxA & 0x0F0F0F0Fu, (rxA >> 4) & 0x0F0F0F0Fu}, rsB[2] = {rxB & 0x0F0F0F0Fu, (rxB >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {
+			const int i = g * 8 + s;
+			uint32_t rcA = (rsA[s >> 2] >> (8 * (s & 3))) & 0xFFu, rcB = (rsB[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+			rcA = (i < lenVA) ? rcA : 6u;
+			rcB = (i < lenVB) ? rcB : 6u;
+			const uint2 TA = s_tab[rcA], TB = s_tab[rcB];
+			uint32_t PA[NRG], PB[NRG];
+#pragma unroll
+			for (int r = 0; r < NRG; ++r) {
+				const bool used = (s + CP - 1) / 4 >= r && s / 4 <= r;
+				PA[r] = used ? __builtin_amdgcn_perm(TA.y, TA.x, RGA[r]) : 0u;
+				PB[r] = used ? __builtin_amdgcn_perm(TB.y, TB.x, RGB[r]) : 0u;
+			}
+			const v2s fl2 = pk_splat(fl);
+			v2s leftS = neg2, leftEh = neg2;  // column d = 0 has no horizontal predecessor
+			v2s rowmax = fl2;
+#pragma unroll
+			for (int d = 0; d < CP; ++d) {
+				const int bi = s + d, kb = bi & 3;
+				const uint32_t sel = 0x0C000C00u | (uint32_t) kb | ((uint32_t) (4 + kb) << 16);
+				const v2s t = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(PB[bi >> 2], PA[bi >> 2], sel));
+				const v2s dg = S[d] + t;
+				v2s eh = (d == 0) ? neg2 : pk_max(leftEh + ext2, leftS + open2);
+				v2s ev = (d < CP - 1) ? pk_max(Ev[d + 1] + vext2, S[d + 1] + vopen2) : neg2;
+				v2s sc = pk_max(pk_max(ev, eh), dg);
+				if (!ENDFREE) {
+					const v2s nz = __builtin_elementwise_min(pk_max(sc - fl2, zero2), one2);  // 1 where the cell is not clamped
+					sc = pk_max(sc, fl2);
+					eh = fl2 + (eh - fl2) * nz;
+					ev = fl2 + (ev - fl2) * nz;
+					rowmax = pk_max(rowmax, sc);
+				}
+				S[d] = sc;
+				Ev[d] = ev;
+				leftS = sc;
+				leftEh = eh;
+			}
+			if (!ENDFREE) {
+				best2 = pk_max(best2, rowmax - fl2);
+			} else if (i + 1 == lenVA || i + 1 == lenVB) {
+				// end-to-end: maximum of the pair's last row over the cells with h <= |H|
+				const int kv = -fl;
+				if (i + 1 == lenVA) {
+					const int dlim = lenHA - lenVA;
+#pragma unroll
+					for (int d = 0; d < CP; ++d) { const int v = (int) S[d].x + kv; if (d <= dlim && v > bestA) bestA = v; }
+				}
+				if (i + 1 == lenVB) {
+					const int dlim = lenHB - lenVB;
+#pragma unroll
+					for (int d = 0; d < CP; ++d) { const int v = (int) S[d].y + kv; if (d <= dlim && v > bestB) bestB = v; }
+				}
+			}
+			fl += K.tZ;
+		}
+#pragma unroll
+		for (int r = 0; r + 2 < NRG; ++r) { RGA[r] = RGA[r + 2]; RGB[r] = RGB[r + 2]; }
+		RGA[NRG - 2] = fxA & 0x0F0F0F0Fu; RGA[NRG - 1] = (fxA >> 4) & 0x0F0F0F0Fu;
+		RGB[NRG - 2] = fxB & 0x0F0F0F0Fu; RGB[NRG - 1] = (fxB >> 4) & 0x0F0F0F0Fu;
+	}
+	if (!ENDFREE) { bestA = best2.x; bestB = best2.y; }
+	if (pairA < n) { if (lenVA < 1 || lenHA < 1) bestA = 0; scores[pairA] = (float) bestA; }
+	if (hasB && pairB < n) { if (lenVB < 1 || lenHB < 1) bestB = 0; scores[pairB] = (float) bestB; }
+}
+
 #ifdef NGM_ENGINE_KERNELS
 // SeqAn's single-trace, gaps-left traceback (dp_traceback_impl.h:184-470) over the stored trace bytes.
 // Emits the same compact runs as the linear traceback: (len << 2) | op, op 1 = M, 2 = I, 3 = D, in traceback order.

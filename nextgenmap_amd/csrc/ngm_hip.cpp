@@ -84,6 +84,13 @@ const void *find_pk_score_kernel(int c, bool endfree) {
 	return nullptr;
 }
 
+const void *find_pk_affine_score_kernel(int c, bool endfree) {
+#define X(C) if (c == C) return endfree ? (const void *) ngm::sw_affine_score_pk_kernel<C + 1, true> : (const void *) ngm::sw_affine_score_pk_kernel<C + 1, false>;
+	NGM_CORRIDORS(X)
+#undef X
+	return nullptr;
+}
+
 KernelRef find_kernel(ngm_hip_ctx *ctx, int kind) {
 	KernelRef k;
 	k.aot = find_aot_kernel(ctx->c, kind);
@@ -114,7 +121,17 @@ int engine_reserve(ngm_hip_ctx *ctx, int n) {
 
 int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipStream_t st) {
 	const int nb = n_blocks_of(n);
+	static const bool force32 = getenv("NGM_HIP_SCORE_32BIT") != nullptr;  // NGM_HIP_SCORE_32BIT=1: never use the packed 16-bit kernels
 	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
+		const bool ef = (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END;
+		if (!force32 && (long) ctx->q * ctx->KA.tM < 30000 && ctx->prm.gap_read_penalty + (long) ctx->q * (ctx->prm.gap_extend_penalty + ctx->KA.tZ) < 19000) {
+			if (const void *pk = find_pk_affine_score_kernel(ctx->c, ef)) {
+				KernelRef kp; kp.aot = pk;
+				HIP_TRY(ctx, launch_kernel(kp, dim3((nb + 7) / 8), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+						(const uint16_t *) ctx->blk_rows.p, d_scores, n, nb, ctx->RW, ctx->KA));
+				return 0;
+			}
+		}
 		const KernelRef ka = find_kernel(ctx, 4 + ((mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END ? 1 : 0));
 		HIP_TRY(ctx, launch_kernel(ka, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
 				(const uint16_t *) ctx->blk_rows.p, d_scores, (uint32_t *) nullptr, (int32_t *) nullptr, n, nb, ctx->RW, ctx->q, ctx->KA));
@@ -122,8 +139,7 @@ int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipS
 	}
 	const bool endfree = (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END;
 	// two pairs per lane in 16-bit halves while every re-based value fits (rows * (match - mismatch) and the end-to-end
-	// sentinel stay inside int16); NGM_HIP_SCORE_32BIT=1 forces the 32-bit kernel
-	static const bool force32 = getenv("NGM_HIP_SCORE_32BIT") != nullptr;
+	// sentinel stay inside int16)
 	if (!force32 && (long) ctx->q * ctx->K.tM < 30000 && (long) ctx->q * ctx->K.tZ < 14000) {
 		if (const void *pk = find_pk_score_kernel(ctx->c, endfree)) {
 			KernelRef kp; kp.aot = pk;
