@@ -229,8 +229,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
     ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
+    ap.add_argument("--read-len", type=int, default=150, help="read length (150: BASELINE config #2/#3; 250: config #5's shape)")
+    ap.add_argument("--corridor", type=int, default=0, help="band width; 0: NextGenMap's 5 + 0.15 * read length")
     ap.add_argument("--layout", choices=["pe", "se"], default="pe", help="paired-end (BASELINE.json config #2) or single-end reads")
     args = ap.parse_args()
+    global Q, C, READ_LEN
+    READ_LEN = args.read_len
+    Q = (READ_LEN | 1) + 1                                   # ReadProvider.cpp:288
+    C = args.corridor if args.corridor > 0 else int(5 + 0.15 * READ_LEN)  # ReadProvider.cpp:304
 
     import torch
     import torch.distributed as dist
@@ -352,10 +358,10 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": ("%d x 150bp %s synthetic reads per GPU per step vs a synthetic %.0f Mbp genome (24 contigs, repeat "
+            "config": {"workload": ("%d x %dbp %s synthetic reads per GPU per step vs a synthetic %.0f Mbp genome (24 contigs, repeat "
                                     "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=0.5) + "
                                     "score + %s/MAPQ + align with traceback + CIGAR; reads resident in HBM")
-                       % (R, "PE (insert ~N(350,35), FR)" if paired else "SE", args.genome_mbp, "pair selection (top1PE)" if paired else "top-1"),
+                       % (R, READ_LEN, "PE (insert ~N(350,35), FR)" if paired else "SE", args.genome_mbp, "pair selection (top1PE)" if paired else "top-1"),
                        "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R, "mapper_instances_per_gpu": W,
                        "parallelism": "reads sharded x%d, genome+index replicated per GPU" % world},
             "sw_gcells_per_s": {"score_kernel": score_cells / (kms[2] * 1e-3) / 1e9 if kms[2] > 0 else None,
