@@ -50,6 +50,7 @@ struct CsArgs {
 	int log2_slots;         // exact table slots (power of two) in LDS
 	int log2_bits;          // FAST: bits per plane
 	int fast_items;         // FAST: items per lane of the kernel instantiation in use
+	int items16;            // FAST: 16-bit work items
 	uint32_t hit_cap;       // reads with more hits than this are queued for the next path
 	// outputs
 	uint16_t *read_len;     // [n]
@@ -173,9 +174,23 @@ constexpr int kCsSeg = 8;   // hits per work item of the fast path
 // ITEMS (fast path, order replay): l_pref holds per list (length | time of its first hit << 16) instead of the prefix sums
 // (both < 65536 for every read these paths accept), and every list is cut into segments of kCsSeg hits, enumerated in
 // l_items as (list << 16 | segment).
-template <bool ITEMS>
+// work item encodings: 32-bit (list << 16 | segment) or, when every list index is < 512 and every list has at most
+// 128 segments, 16-bit (list << 7 | segment), which halves the item list in LDS
+template <typename ItemT> struct CsItem;
+template <> struct CsItem<uint32_t> {
+	static __device__ __forceinline__ uint32_t make(uint32_t li, uint32_t sg) { return (li << 16) | sg; }
+	static __device__ __forceinline__ uint32_t list(uint32_t it) { return it >> 16; }
+	static __device__ __forceinline__ uint32_t seg(uint32_t it) { return it & 0xFFFFu; }
+};
+template <> struct CsItem<uint16_t> {
+	static __device__ __forceinline__ uint16_t make(uint32_t li, uint32_t sg) { return (uint16_t) ((li << 7) | sg); }
+	static __device__ __forceinline__ uint32_t list(uint32_t it) { return it >> 7; }
+	static __device__ __forceinline__ uint32_t seg(uint32_t it) { return it & 0x7Fu; }
+};
+
+template <bool ITEMS, typename ItemT = uint32_t>
 __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, uint32_t *l_pref, uint8_t *l_code,
-		uint32_t *l_items = nullptr, uint32_t items_cap = 0) {
+		ItemT *l_items = nullptr, uint32_t items_cap = 0) {
 	const int k = A.k;
 	const uint8_t *rp = A.reads + (size_t) read * A.q;
 	int first_nul = A.q;
@@ -241,8 +256,8 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 					l_start[2 * p] = sf; l_pref[2 * p] = (cf & 0xFFFFu) | (b0 << 16);
 					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = (cr & 0xFFFFu) | ((b0 + cf) << 16);
 					uint32_t o = carry_s + incl_s - (nsf + nsr);
-					for (uint32_t sg = 0; sg < nsf; ++sg, ++o) if (o < items_cap) l_items[o] = ((uint32_t) (2 * p) << 16) | sg;
-					for (uint32_t sg = 0; sg < nsr; ++sg, ++o) if (o < items_cap) l_items[o] = ((uint32_t) (2 * p + 1) << 16) | sg;
+					for (uint32_t sg = 0; sg < nsf; ++sg, ++o) if (o < items_cap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p), sg);
+					for (uint32_t sg = 0; sg < nsr; ++sg, ++o) if (o < items_cap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p + 1), sg);
 				}
 				carry_s += __shfl(incl_s, 63);
 			}
@@ -341,34 +356,36 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 // human-size index), 24 -> 1 536 segments (250 bp reads)
 constexpr int kCsFastItemsShort = 12, kCsFastItemsLong = 24;
 constexpr int kCsFastDepth = 2;    // segments in flight per lane
-constexpr uint32_t kCsFastQueue = 512;  // LDS queue entries between flushes
+// LDS queue: as many entries as the table may hold keys (3/4 of its slots) -- sweep 2 queues at most one hit per key;
+// sweep 1 flushes whenever more than 96 repeats are waiting
 
 struct __attribute__((packed, aligned(4))) CsU4 { uint32_t x, y, z, w; };
 
-template <int kCsFastItems>
+template <int kCsFastItems, typename ItemT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void cs_fast_kernel(CsArgs A) {
 	constexpr uint32_t kCsFastItemCap = (uint32_t) kCsFastItems * 64u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	__shared__ uint32_t s_queue[kCsFastQueue];
 	const int lane = threadIdx.x;
 	const int read = blockIdx.x;
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;
 	uint32_t *l_len = cs_lds + A.lists_cap;
 	uint8_t *l_code = (uint8_t *) (l_len + A.lists_cap + 1);
-	uint32_t *l_items = (uint32_t *) l_code + (A.q + 3) / 4;
-	uint32_t *plane = l_items + kCsFastItemCap;
+	ItemT *l_items = (ItemT *) ((uint32_t *) l_code + (A.q + 3) / 4);
+	uint32_t *plane = (uint32_t *) (l_items + kCsFastItemCap);  // kCsFastItemCap is a multiple of 64: stays 4-byte aligned
 	const uint32_t plane_words = 1u << (A.log2_bits - 5);
 	uint32_t *t_keys = plane + plane_words;
 	const int log2_slots = A.log2_slots;
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
+	uint32_t *s_queue = t_votes + n_slots;
+	const uint32_t kCsFastQueue = (n_slots * 3u) / 4u;
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 
 	const bool diag = A.phase_cycles && (read & 255) == 0;  // sampled: the global atomics would serialise otherwise
 	const unsigned long long c0 = diag ? wall_clock64() : 0ull;
-	const CsRead R = cs_prepare<true>(A, read, lane, l_start, l_len, l_code, l_items, kCsFastItemCap);
+	const CsRead R = cs_prepare<true, ItemT>(A, read, lane, l_start, l_len, l_code, l_items, kCsFastItemCap);
 	const uint32_t H = R.H;
 	const int L = R.L;
 	if (H > A.hit_cap || R.n_items > kCsFastItemCap) { cs_enqueue(A, read, lane, R); return; }
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 			}
 			atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
 		}
-		{ uint32_t total; (void) wave_prefix_small<4>(fresh, total); n_keys += total; }  // fresh <= kCsFastQueue / 64
+		{ uint32_t total; (void) wave_prefix_small<4>(fresh, total); n_keys += total; }  // fresh <= 12 per lane
 		if (n_keys > (n_slots * 3u) / 4u) abort_fast = true;  // probing gets slow and the spurious entries too many
 		__syncthreads();
 		q_len = 0;
@@ -419,7 +436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		uint32_t meta = 0;
 		if (idx < n_items) {
 			const uint32_t item = l_items[idx];
-			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
+			const uint32_t li = CsItem<ItemT>::list(item), sg = CsItem<ItemT>::seg(item);
 			const uint32_t cnt = min((uint32_t) kCsSeg, (l_len[li] & 0xFFFFu) - sg * kCsSeg);
 			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_start[li] + sg * kCsSeg);
 #pragma unroll
@@ -640,7 +657,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; }
 	if (lane == 0) s_keys = 0;
 	uint32_t *l_items = ev_at + kCsOrderMaxHits;  // [kCsOrderItemCap]
-	const CsRead R = cs_prepare<true>(A, read, lane, l_start, l_pref, l_code, l_items, kCsOrderItemCap);
+	const CsRead R = cs_prepare<true, uint32_t>(A, read, lane, l_start, l_pref, l_code, l_items, kCsOrderItemCap);
 	const uint32_t H = R.H;
 	const int L = R.L;
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];

@@ -89,7 +89,7 @@ struct DevGuard {
 
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (mode == ngm::kCsFast) w += ((size_t) 1 << (A.log2_bits - 5)) + (size_t) A.fast_items * 64;
+	if (mode == ngm::kCsFast) w += ((size_t) 1 << (A.log2_bits - 5)) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) + ((size_t) 3 << A.log2_slots) / 4;
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -132,8 +132,12 @@ int run_cs(ngm_mapper *m, int n) {
 		A.hit_cap = (1u << m->cs_log2_bits) / 6u;
 		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
-		if (A.fast_items == ngm::kCsFastItemsShort) hipLaunchKernelGGL(ngm::cs_fast_kernel<ngm::kCsFastItemsShort>, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
-		else hipLaunchKernelGGL(ngm::cs_fast_kernel<ngm::kCsFastItemsLong>, dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		// 16-bit work items when every list index fits 9 bits and no used list can have more than 128 segments
+		A.items16 = (A.lists_cap <= 512 && m->max_kfreq <= 128 * ngm::kCsSeg) ? 1 : 0;
+		if (!A.items16) A.fast_items = ngm::kCsFastItemsLong;  // the 32-bit item list only exists in the large size
+		if (A.fast_items == ngm::kCsFastItemsShort && A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		else if (A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		else hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
@@ -360,8 +364,10 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
 	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17;
 	A.fast_items = ngm::kCsFastItemsLong;
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsShort>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	A.items16 = 0;
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
 	return m;
