@@ -48,7 +48,8 @@ struct CsArgs {
 	const uint32_t *positions;
 	int lists_cap;          // LDS capacity for lists (>= 2*(q-k+1))
 	int log2_slots;         // exact table slots (power of two) in LDS
-	int log2_bits;          // FAST: bits per plane
+	int log2_bits;          // (unused by the kernels; kept for diagnostics)
+	uint32_t plane_bits;    // FAST: bits of the plane, a multiple of 2048 (any size: the hash is reduced with a multiply-high)
 	int fast_items;         // FAST: items per lane of the kernel instantiation in use
 	int items16;            // FAST: 16-bit work items
 	uint32_t hit_cap;       // reads with more hits than this are queued for the next path
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	uint8_t *l_code = (uint8_t *) (l_len + A.lists_cap + 1);
 	ItemT *l_items = (ItemT *) ((uint32_t *) l_code + (A.q + 3) / 4);
 	uint32_t *plane = (uint32_t *) (l_items + kCsFastItemCap);  // kCsFastItemCap is a multiple of 64: stays 4-byte aligned
-	const uint32_t plane_words = 1u << (A.log2_bits - 5);
+	const uint32_t plane_words = A.plane_bits >> 5;
 	uint32_t *t_keys = plane + plane_words;
 	const int log2_slots = A.log2_slots;
 	const uint32_t n_slots = 1u << log2_slots;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	__syncthreads();
 	const unsigned long long c1 = diag ? wall_clock64() : 0ull;
 
-	const int sh = 32 - A.log2_bits;
+	const uint32_t pbits = A.plane_bits;
 	const int hs = 32 - log2_slots;
 	const uint32_t n_items = R.n_items;
 
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 			const uint32_t pos = (j & 3) == 0 ? cur[j >> 2].x : (j & 3) == 1 ? cur[j >> 2].y : (j & 3) == 2 ? cur[j >> 2].z : cur[j >> 2].w;
 			const bool valid = (uint32_t) j < cnt;
 			const uint32_t bin = ((pos - corr) >> A.bin_shift) & 0x3FFFFFFFu;
-			const uint32_t b = (bin * 0x9E3779B1u) >> sh;
+			const uint32_t b = __umulhi(bin * 0x9E3779B1u, pbits);
 			msk[j] = valid ? (1u << (b & 31)) : 0u;
 			old[j] = atomicOr(&plane[b >> 5], msk[j]);
 			ent[j] = bin | rev;
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	for (uint32_t s = lane; s < n_slots; s += 64) {
 		const uint32_t key = t_keys[s];
 		if (key != 0xFFFFFFFFu) {
-			const uint32_t b = (key * 0x9E3779B1u) >> sh;
+			const uint32_t b = __umulhi(key * 0x9E3779B1u, pbits);
 			atomicOr(&plane[b >> 5], 1u << (b & 31));
 		}
 	}
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
 		for (int j = 0; j < kCsSeg; ++j) {
 			const uint32_t e = bins[it * kCsSeg + j];
-			const uint32_t b = ((e & 0x3FFFFFFFu) * 0x9E3779B1u) >> sh;
+			const uint32_t b = __umulhi((e & 0x3FFFFFFFu) * 0x9E3779B1u, pbits);
 			const uint32_t w = (plane[b >> 5] >> (b & 31)) & (e >> 30) & 1u;  // bit 30 = first on its bit (0 for empty slots)
 			wmask[it] |= w << j;
 		}

@@ -42,6 +42,7 @@ struct ngm_mapper {
 	int max_kfreq = 0;
 	int cs_log2_slots = 13;   // large LDS vote table: 2^13 slots * 8 B = 64 KB
 	int cs_log2_small = 10;   // fast path: small exact table ...
+	uint32_t cs_plane_bits = 65536;
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
 	int cs_fast_items = ngm::kCsFastItemsShort;
@@ -89,7 +90,7 @@ struct DevGuard {
 
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (mode == ngm::kCsFast) w += ((size_t) 1 << (A.log2_bits - 5)) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) + ((size_t) 3 << A.log2_slots) / 4;
+	if (mode == ngm::kCsFast) w += ((size_t) A.plane_bits >> 5) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) + ((size_t) 3 << A.log2_slots) / 4;
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -128,8 +129,8 @@ int run_cs(ngm_mapper *m, int n) {
 		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) { m->cs_kernel_ms += t; pass_ms[e / 2] = t; } };
 
 		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
-		A.log2_bits = m->cs_log2_bits; A.log2_slots = m->cs_log2_small; A.fast_items = m->cs_fast_items;
-		A.hit_cap = (1u << m->cs_log2_bits) / 6u;
+		A.log2_bits = m->cs_log2_bits; A.plane_bits = m->cs_plane_bits; A.log2_slots = m->cs_log2_small; A.fast_items = m->cs_fast_items;
+		A.hit_cap = m->cs_plane_bits / 6u;
 		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
 		// 16-bit work items when every list index fits 9 bits and no used list can have more than 128 segments
@@ -351,18 +352,25 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		const double hexp = std::max(64.0, 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer) * avg_list);
 		int lb = 12;
 		while ((double) (1u << lb) < 12.0 * hexp && lb < 17) ++lb;
-		int ls = 8;
-		// table entries: hits that find their bit already set -- H^2 / (2 bits) by collision plus the real repeats
-		while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * (double) (1u << lb)) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
 		m->cs_log2_bits = lb;
-		m->cs_log2_small = ls;
+		// plane of P bits (any multiple of 2048 from 12 bits per expected hit up to the next power of two) and table of
+		// 2^ls slots, 3/4 of which may fill: entries = hits that find their bit already set -- H^2 / (2 P) by collision
+		// -- plus the real repeats, with headroom.  Take the pair that needs the least LDS.
+		size_t best_bytes = ~(size_t) 0;
+		const double p_lo = std::min(131072.0, std::max(4096.0, ceil(12.0 * hexp / 2048.0) * 2048.0)), p_hi = (double) (1u << lb);
+		for (double P = p_lo; P <= p_hi; P += 2048.0) {
+			int ls = 8;
+			while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * P) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
+			const size_t bytes = (size_t) P / 8 + ((size_t) 8 << ls) + ((size_t) 3 << ls);  // plane + keys/votes + queue
+			if (bytes < best_bytes) { best_bytes = bytes; m->cs_plane_bits = (uint32_t) P; m->cs_log2_small = ls; }
+		}
 		// expected 8-hit segments per read: every list contributes its hits / 8 plus, on average, 7/16 of a segment of slack
 		const double segs = hexp / 8.0 + 0.44 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
 		m->cs_fast_items = segs * 1.10 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
 		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
-	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17;
+	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17; A.plane_bits = 131072;
 	A.fast_items = ngm::kCsFastItemsLong;
 	A.items16 = 0;
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
