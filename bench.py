@@ -341,7 +341,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json, keyed
         # by kernel name and grid size = 64 threads per read; collected with this default workload)
         traffic = None
-        if int(args.genome_mbp) == 3100:
+        if int(args.genome_mbp) == 3100 and READ_LEN == 150:
             for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
                 if fn.endswith("_pmc_traffic.json"):
                     try:
