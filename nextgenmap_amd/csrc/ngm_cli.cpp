@@ -279,7 +279,8 @@ int main(int argc, char **argv) {
 			if (mx > 1.0f && both[i] <= mx) { sum += both[i] / mx; ++n_used; }
 		}
 		ngm_mapper_destroy(em);
-		if (n_used > 0) {
+		{
+			// ReadProvider.cpp:324-352; with no usable sample read the average is 0/0 = NaN and std::max(0.3f, NaN) is 0.3
 			const float avg = sum / n_used * 1.0f;
 			sens = std::min(std::max(0.3f, avg), 0.9f);
 			snprintf(msg, sizeof(msg), "Estimated sensitivity: %f", sens);
