@@ -52,7 +52,19 @@ def main():
         pe = os.path.join(d, "pe.fq")
         S.write_fastq(pe, [x for pair in zip(r1, r2) for x in pair])
         gz(pe, os.path.join(OUT, "pe.fq.gz"))
-        cases = {"se_local": ["-q", fq], "se_endtoend": ["-q", fq, "-e"], "se_top3": ["-q", fq, "-n", "3"], "pe_local": ["-p", "-q", pe]}
+        # FASTA reads of mixed length (40-100), lower case and IUPAC characters, fewer than 1 000 reads (no estimation)
+        rng2 = np.random.default_rng(8)
+        mixed = os.path.join(d, "mixed.fa")
+        with open(mixed, "wb") as f:
+            for i, (name, seq, _) in enumerate(S.make_reads(contigs, 600, 100, seed=94, sub_rate=0.03, indel_rate=0.004)):
+                s2 = seq[:int(rng2.integers(40, 101))].copy()
+                if i % 7 == 0:
+                    s2[: len(s2) // 2] |= 0x20
+                if i % 11 == 0:
+                    s2[int(rng2.integers(0, len(s2)))] = ord("R")
+                f.write(b">" + name.encode() + b" some comment\n" + s2.tobytes() + b"\n")
+        gz(mixed, os.path.join(OUT, "mixed.fa.gz"))
+        cases = {"mixed_fasta": ["-q", mixed], "se_local": ["-q", fq], "se_endtoend": ["-q", fq, "-e"], "se_top3": ["-q", fq, "-n", "3"], "pe_local": ["-p", "-q", pe]}
         for name, extra in cases.items():
             out = os.path.join(d, name + ".sam")
             r = RF.run_ngm(["-r", fa, "-o", out, "--affine", "-t", "1", "--no-progress"] + extra, cwd=d)
