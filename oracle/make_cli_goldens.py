@@ -64,7 +64,23 @@ def main():
                     s2[int(rng2.integers(0, len(s2)))] = ord("R")
                 f.write(b">" + name.encode() + b" some comment\n" + s2.tobytes() + b"\n")
         gz(mixed, os.path.join(OUT, "mixed.fa.gz"))
-        cases = {"mixed_fasta": ["-q", mixed], "se_local": ["-q", fq], "se_endtoend": ["-q", fq, "-e"], "se_top3": ["-q", fq, "-n", "3"], "pe_local": ["-p", "-q", pe]}
+        # paired-end corner cases: mates of different / very short length, all-N mates, narrow insert window, --no-unal
+        o1, o2 = S.make_reads(contigs, 1100, 100, seed=95, sub_rate=0.02, indel_rate=0.003, paired=True)
+        odd = os.path.join(d, "pe_odd.fq")
+        with open(odd, "wb") as f:
+            for i, (a, b) in enumerate(zip(o1, o2)):
+                for j, (name, seq, qual) in enumerate((a, b)):
+                    L = 100
+                    if (i + j) % 5 == 0:
+                        L = int(rng2.integers(60, 100))
+                    if i % 97 == 3 and j == 1:
+                        L = int(rng2.integers(5, 20))
+                    s2 = seq[:L].copy()
+                    if i % 131 == 7 and j == 0:
+                        s2[:] = ord("N")
+                    f.write(b"@" + name.encode() + b"\n" + s2.tobytes() + b"\n+\n" + qual[:L] + b"\n")
+        gz(odd, os.path.join(OUT, "pe_odd.fq.gz"))
+        cases = {"pe_odd": ["-p", "-q", odd, "-X", "420", "--no-unal", "-R", "0.6"], "mixed_fasta": ["-q", mixed], "se_local": ["-q", fq], "se_endtoend": ["-q", fq, "-e"], "se_top3": ["-q", fq, "-n", "3"], "pe_local": ["-p", "-q", pe]}
         for name, extra in cases.items():
             out = os.path.join(d, name + ".sam")
             r = RF.run_ngm(["-r", fa, "-o", out, "--affine", "-t", "1", "--no-progress"] + extra, cwd=d)
