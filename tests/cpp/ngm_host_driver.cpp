@@ -53,6 +53,9 @@ int main(int argc, char **argv) {
 	TestConfig cfg;
 	cfg.kv = {{"qry_max_len", std::to_string(q)}, {"corridor", std::to_string(c)}, {"match_bonus", "10"},
 			{"mismatch_penalty", "15"}, {"gap_read_penalty", "20"}, {"gap_ref_penalty", "20"}, {"bs_mapping", "0"}};
+	if (argc > 4 && std::string(argv[4]) == "affine") {  // `ngm --affine`: Config.cpp:433-439
+		cfg.kv["affine"] = "1"; cfg.kv["gap_read_penalty"] = "33"; cfg.kv["gap_ref_penalty"] = "33"; cfg.kv["gap_extend_penalty"] = "3";
+	}
 	SetLog(&log);
 	SetConfig(&cfg);
 	if (Cookie() != cCookie) { fprintf(stderr, "cookie mismatch\n"); return 3; }

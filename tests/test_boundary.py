@@ -100,6 +100,37 @@ def test_cpp_host_drives_plugin_like_ngm(tmp_path, mode):
         assert np.float32(float(row[8])) == np.float32(res["identity"][i])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cpp_host_drives_plugin_in_the_affine_personality(tmp_path, mode):
+    """Config "affine" = 1 makes the same plugin exports behave like EndToEndAffine (the class NextGenMap instantiates for
+    `--affine`, src/NGM.cpp:397-404): scores, CIGARs, NM, identity as SeqAn's banded Gotoh, pBuffer2 untouched."""
+    lib = _lib()
+    exe = str(tmp_path / "ngm_host_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(CPP, "ngm_host_driver.cpp"), "-I", INC, lib,
+                           "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    q, c, n = 152, 27, 700
+    ref, qry = make_pairs(n, q, c, seed=41 + mode, read_len=150)
+    inp = str(tmp_path / "in.bin")
+    with open(inp, "wb") as f:
+        np.array([n, q, c], dtype=np.int32).tofile(f)
+        ref.tofile(f)
+        qry.tofile(f)
+    outp = str(tmp_path / "out.txt")
+    r = subprocess.run([exe, inp, outp, str(mode), "affine"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sc, res, cig = O.oracle_affine(mode, ref, qry, c, nthreads=4)
+    rows = [l.rstrip("\n").split("\t") for l in open(outp)]
+    assert len(rows) == n
+    for i, row in enumerate(rows):
+        assert int(row[1]) == int(sc[i])
+        assert row[2].encode() == cig[i] and row[3] == "!!!"
+        assert (int(row[4]), int(row[5]), int(row[6]), int(row[7])) == (
+            int(res["position_offset"][i]), int(res["qstart"][i]), int(res["qend"][i]), int(res["nm"][i]))
+        wi, hi = np.float32(res["identity"][i]), np.float32(float(row[8]))
+        assert wi == hi or (np.isnan(wi) and np.isnan(hi))
+
+
 def test_runtime_kernel_compilation_for_other_corridors():
     """Band widths without an ahead-of-time build are compiled with hiprtc from the embedded kernel headers (the
     reference JIT-compiles its OpenCL kernels with -D corridor_length); compiling needs no GPU."""
