@@ -153,3 +153,23 @@ def test_runtime_compiled_corridors_match_oracle(q, c, rl):
         for i, a in enumerate(al):
             assert (a["cigar"], a["position_offset"], a["nm"]) == (cig[i], int(res["position_offset"][i]), int(res["nm"][i])), i
     eng.close()
+
+
+@pytest.mark.parametrize("q,c,rl", [(1000, 80, 998), (602, 42, 600), (1000, 42, 990)])
+def test_long_reads_at_the_limits_of_the_packed_16_bit_kernels(q, c, rl):
+    """qry_max_len 1000 is NextGenMap's maximum (ReadProvider.cpp:292-299): re-based band values reach 25 000, just inside
+    the 16-bit range the packed score kernels may use; the 32-bit align kernels see the same pairs."""
+    import nextgenmap_amd as N
+    from nextgenmap_amd import engine as E
+    ref, qry = make_pairs(300, q, c, seed=q + c, read_len=rl, indel_rate=0.01)
+    eng = N.Engine(q, c)
+    for mode in (0, 1):
+        assert np.array_equal(eng.BatchScore(mode, ref, qry), O.oracle_score(mode, ref, qry, c, nthreads=8))
+    eng.close()
+    eng = N.Engine(q, c, personality=E.PERSONALITY_AFFINE, gap_read=33, gap_ref=33, gap_extend=3)
+    for mode in (0, 1):
+        sc, res, cig = O.oracle_affine(mode, ref, qry, c, nthreads=8)
+        assert np.array_equal(eng.BatchScore(mode, ref, qry), sc)
+        al = eng.BatchAlign(mode, ref, qry)
+        assert [a["cigar"] for a in al] == cig
+    eng.close()
