@@ -48,6 +48,7 @@ struct ngm_mapper {
 	int cs_fast_items = ngm::kCsFastItemsShort;
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
+	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
 	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank;
 	ngm::PinnedBuf<uint32_t> p_rank;
 	// pinned staging for the per-batch downloads
@@ -341,6 +342,11 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	ngm_mapper *m = new ngm_mapper();
 	++g_live_mappers;
 	m->ref = ref; m->prm = *p; m->eng = eng; m->st = eng->stream;
+	{
+		int lo = 0, hi = 0;
+		(void) hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = greatest priority
+		if (hipStreamCreateWithPriority(&m->st_hi, hipStreamNonBlocking, hi) != hipSuccess) m->st_hi = nullptr;
+	}
 	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
 	for (auto &e : m->cev) (void) hipEventCreate(&e);
@@ -386,6 +392,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	--g_live_mappers;
 	DevGuard g(m->ref->device);
 	(void) hipStreamSynchronize(m->st);
+	if (m->st_hi) { (void) hipStreamSynchronize(m->st_hi); (void) hipStreamDestroy(m->st_hi); }
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
 	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_read2.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
 	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
@@ -440,9 +447,10 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 // reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
 static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank) {
 	const uint32_t nl = (uint32_t) list.size();
+	hipStream_t ost = m->st_hi ? m->st_hi : m->st;  // everything this depends on has been synchronised by the caller
 	const auto t_begin = std::chrono::steady_clock::now();
 	if (m->d_order_list.reserve(nl) || m->d_cand_rank.reserve(np + 1) || m->p_rank.reserve(np + 1)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
-	MAP_HIP_TRY(hipMemcpyAsync(m->d_order_list.p, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, m->st));
+	MAP_HIP_TRY(hipMemcpyAsync(m->d_order_list.p, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ost));
 	ngm::CsArgs A = m->last_cs;
 	A.read_list = m->d_order_list.p;
 	A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p;
@@ -450,10 +458,10 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits + ngm::kCsOrderItemCap) * 4;
 	static std::once_flag once;
 	std::call_once(once, [&] { (void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
-	hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(nl), dim3(64), lds, m->st, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
+	hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(nl), dim3(64), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
 	MAP_HIP_TRY(hipGetLastError());
-	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, m->st));
-	MAP_HIP_TRY(hipStreamSynchronize(m->st));
+	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
+	MAP_HIP_TRY(hipStreamSynchronize(ost));
 	*h_rank = m->p_rank.p;
 	if (getenv("NGM_HIP_HOST_TIMING"))
 		fprintf(stderr, "[ngm-hip] candidate order replay: %u reads, %.2f ms\n", nl, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
