@@ -67,6 +67,8 @@ struct CsArgs {
 	unsigned long long out_capacity;  // entries per region
 	uint32_t *status;       // [0] output overflow flag, [1] number of queued reads
 	unsigned long long *counters;  // per region, stride kCsCursorStride: [0] k-mers looked up, [1] hits voted (algorithmic-bytes accounting)
+	uint32_t *order_scratch;    // cs_order_kernel: time lines in global memory for reads with more hits than LDS holds
+	uint32_t order_gcap;        // ... entries per workgroup
 	unsigned long long *phase_cycles;  // optional diagnostics (fast path): [0] lists [1] sweep 1 [2] sweep 2 [3] candidates
 	uint32_t *ovf_read;     // [n] queue written by this pass
 	uint32_t *ovf_hits;     // [n]
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	uint32_t *t_votes = t_keys + n_slots;   // final votes: forward | reverse << 16
 	uint32_t *t_run = t_votes + n_slots;    // votes so far during the replay
 	uint32_t *t_rank = t_run + n_slots;
-	uint32_t *ev_at = t_rank + n_slots;     // [kCsOrderMaxHits]: slot | strand << 31 of the hit at that time, or empty
+	uint32_t *ev_at = t_rank + n_slots;     // [kCsOrderMaxHits]: slot | strand << 31 of the hit at that time, or empty (reads with more hits: global memory)
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; }
 	if (lane == 0) s_keys = 0;
@@ -663,7 +665,13 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	const int L = R.L;
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
 	auto give_up = [&]() { for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown; };
-	if (H > kCsOrderMaxHits || R.n_items > kCsOrderItemCap) { give_up(); return; }
+	// very repetitive reads: the time line moves to global memory and the lists are walked hit by hit (rare, slow, exact);
+	// the 16-bit list offsets of l_pref bound that at 65 535 hits
+	const bool big = H > kCsOrderMaxHits || R.n_items > kCsOrderItemCap;
+	if (big) {
+		if (!A.order_scratch || H > A.order_gcap || H >= 65536u) { give_up(); return; }
+		ev_at = A.order_scratch + (size_t) blockIdx.x * A.order_gcap;
+	}
 	__syncthreads();
 	auto bin_of = [&](uint32_t pos, int li) -> uint32_t {
 		const int p = li >> 1;
@@ -687,8 +695,19 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 			}
 		}
 	};
-	// work item = 8 consecutive hits of one list (two 16-byte loads), the next item's loads in flight
-	{
+	if (big) {
+		const int n_lists = R.n_lists;
+		for (uint32_t h = (uint32_t) lane; h < H; h += 64) {
+			int lo = 0, hi = n_lists;  // largest list whose first hit is at or before h (empty lists share their successor's offset)
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if ((l_pref[mid] >> 16) <= h) lo = mid; else hi = mid;
+			}
+			while ((l_pref[lo] & 0xFFFFu) == 0u || h - (l_pref[lo] >> 16) >= (l_pref[lo] & 0xFFFFu)) --lo;  // skip empty lists that start at the same offset
+			vote(A.positions[l_start[lo] + (h - (l_pref[lo] >> 16))], lo, h);
+		}
+	} else {
+		// work item = 8 consecutive hits of one list (two 16-byte loads), the next item's loads in flight
 		CsU4 cur[2], nxt[2];
 		auto fetch = [&](uint32_t idx, CsU4 (&d)[2]) -> uint32_t {
 			if (idx >= R.n_items) return 0xFFFFFFFFu;

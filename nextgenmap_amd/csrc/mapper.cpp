@@ -49,7 +49,7 @@ struct ngm_mapper {
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
-	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank;
+	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank, d_order_scratch;
 	ngm::PinnedBuf<uint32_t> p_rank;
 	// pinned staging for the per-batch downloads
 	ngm::PinnedBuf<uint32_t> p_winner, p_loc, p_sv;
@@ -249,7 +249,7 @@ struct GpuStage {
 	void done() { if (lk.owns_lock()) lk.unlock(); }
 };
 template <typename F>
-void parallel_for(int n, F f) {
+void parallel_for(int n, F f, int min_grain = 0) {
 	// the host cores are shared by the mapper instances of this process and, under torchrun, by the other ranks of the node
 	static const int ranks_on_node = [] {
 		const char *e = getenv("LOCAL_WORLD_SIZE");
@@ -259,7 +259,8 @@ void parallel_for(int n, F f) {
 	int nt = (int) std::thread::hardware_concurrency() / std::max(1, g_live_mappers.load() * ranks_on_node);
 	if (const char *e = getenv("NGM_HIP_HOST_THREADS")) nt = atoi(e);
 	nt = std::max(1, std::min(nt, 64));
-	if (n < 4096 || nt == 1) { f(0, n); return; }
+	if (min_grain > 0) nt = std::min(nt, n / min_grain);  // small jobs: fewer threads, starting one costs ~20 us
+	if ((min_grain <= 0 && n < 4096) || nt <= 1) { f(0, n); return; }
 	std::vector<std::thread> th;
 	const int chunk = (n + nt - 1) / nt;
 	for (int t = 0; t < nt; ++t) {
@@ -400,7 +401,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
-	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->p_rank.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
+	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->p_rank.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	ngm_hip_destroy(m->eng);
@@ -458,8 +459,15 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits + ngm::kCsOrderItemCap) * 4;
 	static std::once_flag once;
 	std::call_once(once, [&] { (void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
-	hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(nl), dim3(64), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
-	MAP_HIP_TRY(hipGetLastError());
+	// reads with more hits than the LDS time line holds use a slice of a global scratch: launches of at most 4096 reads
+	constexpr uint32_t kChunk = 4096, kGcap = 49152;
+	if (m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap)) { A.order_scratch = nullptr; A.order_gcap = 0; }
+	else { A.order_scratch = m->d_order_scratch.p; A.order_gcap = kGcap; }
+	for (uint32_t off = 0; off < nl; off += kChunk) {
+		A.read_list = m->d_order_list.p + off;
+		hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(std::min(kChunk, nl - off)), dim3(64), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
+		MAP_HIP_TRY(hipGetLastError());
+	}
 	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
 	MAP_HIP_TRY(hipStreamSynchronize(ost));
 	*h_rank = m->p_rank.p;
@@ -481,12 +489,41 @@ int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const vo
 	return map_impl(m, n, reads, d_reads_ext, hits, cigars, mds, true);
 }
 
+// ScoreBuffer::top1PE's std::sort(Scores, sortLocationScore) (src/ScoreBuffer.cpp:373-376) over one read's candidates.
+static std::vector<uint32_t> sort_like_reference(uint32_t base, uint32_t cnt, const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank,
+	bool *ranked_out = nullptr) {
+	std::vector<uint32_t> v(cnt);
+	std::iota(v.begin(), v.end(), base);
+	// The reference sorts its candidate list (CollectResultsStd's order) with std::sort(sortLocationScore): not a
+	// stable sort above 16 elements, so do exactly that on the same sequence.  Without the candidate order
+	// (first pass; only pairs whose result does not depend on it are kept) any deterministic order will do.
+	auto by_place = [&](uint32_t x, uint32_t y) { return loc[x] != loc[y] ? loc[x] < loc[y] : (sv[x] & 1u) < (sv[y] & 1u); };
+	bool ranked = rank != nullptr;
+	for (uint32_t x = base; ranked && x < base + cnt; ++x) ranked = rank[x] != ngm::kCsOrderUnknown;
+	if (ranked) std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return rank[x] != rank[y] ? rank[x] < rank[y] : by_place(x, y); });
+	else std::sort(v.begin(), v.end(), by_place);
+	if (ranked) std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
+	else std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
+	if (ranked_out) *ranked_out = ranked;
+	return v;
+}
+
+// What select_pair learns about the equally scoring pairs of one read pair (see the comment at the end of select_pair).
+struct PairTies {
+	bool equal_scores = false;   // two in-window pairs share a pair score: the running mean insert size is consulted
+	bool dup = false;            // ... and two of them also share the insert size: the candidate order decides, NH/X0 counts them
+	bool unique_closest = true;  // at the mean passed in, exactly one best-scoring pair is closest to it
+	int dmin_top = 0, dmax_top = 0;  // range of the insert sizes of the best-scoring pairs
+	int n_top = 0;               // the best-scoring pairs themselves (insert size, candidates), at most 8 unless `dup`
+	int top_d[8], top_a[8], top_b[8];
+};
+
 // ScoreBuffer::top1PE + CheckPairs (src/ScoreBuffer.cpp:368-502) for one pair; `a` = the mate whose scores arrive last
 // (the odd read id: "read"), `b` = its mate.  Candidates are (pair index) lists into loc/score.
-static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
+static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_count, int *dist_out, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
 		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found,
-		bool *ambiguous = nullptr) {
-	if (ambiguous) *ambiguous = false;
+		PairTies *ties = nullptr) {
+	if (ties) *ties = PairTies{};
 	if (cnt_a == 1 && cnt_b == 1) {  // the common case: one candidate per mate
 		*mq_a = *mq_b = 60;
 		const uint64_t l1 = loc[base_a], l2 = loc[base_b];
@@ -494,23 +531,10 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 		const int min_d1 = m->prm.min_insert_size, max_d1 = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
 		const float ps = score[base_a] + score[base_b];
 		*found = cur > min_d1 && cur < max_d1 && ps > 0.0f;
-		if (*found) { dist_sum += cur; dist_count += 1; *win_a = (int) base_a; *win_b = (int) base_b; *equal_out = 0; }
+		if (*found) { *dist_out = cur; *win_a = (int) base_a; *win_b = (int) base_b; *equal_out = 0; }
 		return;
 	}
-	auto sorted = [&](uint32_t base, uint32_t cnt) {
-		std::vector<uint32_t> v(cnt);
-		std::iota(v.begin(), v.end(), base);
-		// sortLocationScore; equal scores in (position, strand) order so that the result does not depend on the order
-		// in which the search happened to emit the candidates
-		std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) {
-			if (score[x] != score[y]) return score[x] > score[y];
-			// equal scores keep the reference's candidate order (std::sort is an insertion sort below 17 elements)
-			if (rank && rank[x] != ngm::kCsOrderUnknown && rank[y] != ngm::kCsOrderUnknown && rank[x] != rank[y]) return rank[x] < rank[y];
-			if (loc[x] != loc[y]) return loc[x] < loc[y];
-			return (sv[x] & 1u) < (sv[y] & 1u);
-		});
-		return v;
-	};
+	auto sorted = [&](uint32_t base, uint32_t cnt) { return sort_like_reference(base, cnt, loc, sv, score, rank); };
 	auto mq_of = [&](const std::vector<uint32_t> &v) {  // computeMQ(MappedRead*), ScoreBuffer.cpp:42-49
 		if (v.size() <= 1) return 60;
 		const float best = score[v[0]], second = score[v[1]];
@@ -527,8 +551,10 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 	while (nb < B.size() && min_b <= score[B[nb]]) ++nb;
 	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
 	float top = 0.0f;
-	int distance = 0, equal = 0, ta = -1, tb = -1, n_top = 0;
-	int top_d[16];  // insert sizes of the pairs that share the best pair score
+	int distance = 0, equal = 0, ta = -1, tb = -1, n_combo = 0;
+	float combo_s[64];  // pair score, insert size and candidates of every pair inside the insert-size window
+	int combo_d[64], combo_a[64], combo_b[64];
+	const int avg = (int) (dist_sum / std::max(1L, dist_count));
 	for (size_t i = 0; i < na; ++i) {
 		for (size_t j = 0; j < nb; ++j) {
 			const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
@@ -536,11 +562,10 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 			bool take = false;
 			if (cur > min_d && cur < max_d) {
 				const float ps = score[A[i]] + score[B[j]];
-				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; n_top = 1; top_d[0] = cur; }
+				if (n_combo < 64) { combo_s[n_combo] = ps; combo_d[n_combo] = cur; combo_a[n_combo] = (int) A[i]; combo_b[n_combo] = (int) B[j]; }
+				++n_combo;
+				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; }
 				else if (ps == top) {
-					if (n_top < 16) top_d[n_top] = cur;
-					++n_top;
-					const int avg = (int) (dist_sum / dist_count);
 					if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
 					else if (abs(distance) == abs(cur)) equal += 1;
 				}
@@ -549,28 +574,31 @@ static void select_pair(ngm_mapper *m, long &dist_sum, long &dist_count, uint32_
 		}
 	}
 	*found = top > 0.0f;
-	// Several pairs share the best pair score.  CheckPairs keeps the one whose insert size is closest to the running mean
-	// (whatever the order) and counts a later pair with the SAME insert size as "equal": the outcome depends on the order
-	// of the equally scoring candidates only if the closest insert size is not unique or two of these pairs have the
-	// same insert size.
-	if (ambiguous && *found && n_top > 1) {
-		bool order_matters = n_top > 16;
-		if (!order_matters) {
-			const int avg = (int) (dist_sum / dist_count);
-			int best_c = INT_MAX, n_best_c = 0;
-			for (int x = 0; x < n_top; ++x) {
-				const int cx = abs(top_d[x] - avg);
+	if (*found) { *dist_out = distance; *win_a = ta; *win_b = tb; *equal_out = equal; }
+	// Which state does the outcome depend on besides the scores?  CheckPairs consults the running mean insert size (the
+	// sequential state of the reference's CS thread) only when a pair's score equals the best so far, keeping the pair
+	// closer to the mean; and it counts a pair as "equal" (NH / X0, never reset) when it ties with the current best in
+	// score AND insert size.  So: no two in-window pairs of equal score -> the result is fixed.  Otherwise the winner is
+	// the best-scoring pair closest to the mean, whatever the order, provided no two pairs share score and insert size
+	// (`dup`: the first one in candidate order wins, later ones are counted) and the closest one is unique.
+	if (ties && n_combo > 1) {
+		if (n_combo > 64) { ties->equal_scores = ties->dup = true; ties->unique_closest = false; ties->dmin_top = min_d; ties->dmax_top = max_d; return; }
+		int best_c = INT_MAX, n_best_c = 0, dmin = INT_MAX, dmax = 0;
+		for (int x = 0; x < n_combo; ++x) {
+			if (combo_s[x] == top) {
+				const int cx = abs(combo_d[x] - avg);
 				if (cx < best_c) { best_c = cx; n_best_c = 1; } else if (cx == best_c) ++n_best_c;
-				for (int y = x + 1; y < n_top; ++y) if (abs(top_d[x]) == abs(top_d[y])) order_matters = true;
+				dmin = std::min(dmin, combo_d[x]); dmax = std::max(dmax, combo_d[x]);
+				if (*found) {
+					if (ties->n_top < 8) { ties->top_d[ties->n_top] = combo_d[x]; ties->top_a[ties->n_top] = combo_a[x]; ties->top_b[ties->n_top] = combo_b[x]; }
+					++ties->n_top;
+				}
 			}
-			if (n_best_c > 1) order_matters = true;
+			for (int y = x + 1; y < n_combo; ++y) if (combo_s[x] == combo_s[y]) { ties->equal_scores = true; if (combo_d[x] == combo_d[y]) ties->dup = true; }
 		}
-		if (order_matters) { *ambiguous = true; return; }
-	}
-	if (*found) {
-		dist_sum += distance;
-		dist_count += 1;
-		*win_a = ta; *win_b = tb; *equal_out = equal;
+		ties->unique_closest = n_best_c <= 1;
+		if (*found) { ties->dmin_top = dmin; ties->dmax_top = dmax; }
+		if (ties->n_top > 8) ties->dup = true;  // too many to list: left to the exact sequential pass
 	}
 }
 
@@ -602,6 +630,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
 	const uint64_t np = m->n_cand;
 	lap(0);
+	if (const char *dump = getenv("NGM_HIP_DUMP_COUNTS")) {  // diagnostics: candidates per read, appended batch after batch
+		if (FILE *f = fopen(dump, "ab")) { fwrite(m->h_count.data(), 4, (size_t) n, f); fclose(f); }
+	}
 
 	if (m->p_winner.reserve(n) || m->p_mapq.reserve(n) || m->p_nbest.reserve(n) || m->p_best.reserve(n) || m->p_loc.reserve(np + 1) ||
 			m->p_sv.reserve(np + 1) || (paired && m->p_scores.reserve(np + 1))) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
@@ -668,12 +699,14 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is
 			// sequential state of one CS thread in the reference; here every host thread continues from the value at
 			// the start of the batch and the increments are merged afterwards (NGM_HIP_HOST_THREADS=1: strictly sequential).
-			const long sum0 = m->pair_dist_sum, cnt0 = m->pair_dist_count;
-			std::atomic<long> add_sum{0}, add_cnt{0};
-			std::mutex amb_mu;
-			std::vector<int> amb_pairs;          // pairs whose outcome depends on the order of equally scoring candidates
+			std::vector<int> pair_dist((size_t) n / 2, 0);  // insert size of the selected pair (0: none), summed in input order below
+			const bool pe_strata = m->prm.strata != 0;
 			auto commit = [&](int ra, int rb, bool found, int wa, int wb, int mqa, int mqb, int equal) {
-				if (found) {
+				if (found && pe_strata && equal > 0) {  // "To many equal scoring positions": both mates unmapped (ScoreBuffer.cpp:437-446)
+					h_winner[ra] = h_winner[rb] = 0xFFFFFFFFu;
+					h_mapq[ra] = h_mapq[rb] = 0;
+					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED;
+				} else if (found) {
 					h_winner[ra] = (uint32_t) wa; h_winner[rb] = (uint32_t) wb;
 					h_mapq[ra] = mqa; h_mapq[rb] = mqb;
 					h_nbest[ra] = h_nbest[rb] = equal;
@@ -683,41 +716,96 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;  // no pair inside the window: single-end selection stands
 				}
 			};
+			auto run_pair = [&](int pi, long sum, long cnt, const uint32_t *rank, int *wa, int *wb, int *mqa, int *mqb, int *equal, int *dist, bool *found, PairTies *ties) {
+				const int rb = 2 * pi, ra = 2 * pi + 1;
+				select_pair(m, sum, cnt, dist, m->h_base[ra], m->h_count[ra], (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], m->h_count[rb],
+						(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, rank, wa, wb, mqa, mqb, equal, found, ties);
+			};
+			// Pass 1 (parallel): every pair whose result depends on the scores alone -- nearly all of them.  The others
+			// ("tied": equally scoring pairs inside the window) depend on the running mean insert size, which is sequential
+			// state of the reference's CS thread (pairDistSum / pairDistCount), and some also on the candidate order.
+			struct Tied { int pi; bool found, dup, open; int dmin, dmax, mqa, mqb; long avg_lo, avg_hi; int n_top, top_d[8], top_a[8], top_b[8]; };
+			auto tq0 = now(); double tq[5] = {0, 0, 0, 0, 0};
+			auto qlap = [&](int k) { auto t = now(); tq[k] += std::chrono::duration<double, std::milli>(t - tq0).count(); tq0 = t; };
+			std::mutex tied_mu;
+			std::vector<Tied> tied;
 			parallel_for(n / 2, [&](int plo, int phi) {
-				long dsum = sum0, dcnt = cnt0;
-				std::vector<int> amb_local;
+				std::vector<Tied> local;
 				for (int pi = plo; pi < phi; ++pi) {
 					const int rb = 2 * pi, ra = 2 * pi + 1;
-					const uint32_t ca = m->h_count[ra], cb = m->h_count[rb];
-					if (ca == 0 || cb == 0) continue;  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
-					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
-					bool found = false, ambiguous = false;
-					select_pair(m, dsum, dcnt, m->h_base[ra], ca, (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], cb,
-							(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, nullptr, &wa, &wb, &mqa, &mqb, &equal, &found,
-							position_order ? nullptr : &ambiguous);
-					if (ambiguous) { amb_local.push_back(pi); continue; }
+					if (m->h_count[ra] == 0 || m->h_count[rb] == 0) continue;  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
+					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0, dist = 0;
+					bool found = false;
+					PairTies ties;
+					run_pair(pi, 0, 1, nullptr, &wa, &wb, &mqa, &mqb, &equal, &dist, &found, &ties);
+					if (ties.equal_scores) {
+						Tied t{pi, found, ties.dup || pe_strata, true, ties.dmin_top, ties.dmax_top, mqa, mqb, 0, 0, std::min(ties.n_top, 8), {}, {}, {}};
+						for (int x = 0; x < t.n_top; ++x) { t.top_d[x] = ties.top_d[x]; t.top_a[x] = ties.top_a[x]; t.top_b[x] = ties.top_b[x]; }
+						local.push_back(t);
+						continue;
+					}
 					commit(ra, rb, found, wa, wb, mqa, mqb, equal);
+					if (found) pair_dist[pi] = dist;
 				}
-				add_sum += dsum - sum0; add_cnt += dcnt - cnt0;
-				if (!amb_local.empty()) { std::lock_guard<std::mutex> lk(amb_mu); amb_pairs.insert(amb_pairs.end(), amb_local.begin(), amb_local.end()); }
+				if (!local.empty()) { std::lock_guard<std::mutex> lk(tied_mu); tied.insert(tied.end(), local.begin(), local.end()); }
 			});
-			m->pair_dist_sum += add_sum.load(); m->pair_dist_count += add_cnt.load();
-			if (!position_order) {
-				// the reference's candidate order is needed for: the ambiguous pairs, and mates selected single-end
+			qlap(0);
+			std::sort(tied.begin(), tied.end(), [](const Tied &x, const Tied &y) { return x.pi < y.pi; });
+			// Pass 2 (sequential, cheap): the running mean at every tied pair, as bounds -- a tied pair that stays open
+			// contributes one of the insert sizes of its best-scoring pairs.  Without pairs of equal score AND insert size the
+			// winner is the best-scoring pair closest to the mean: the same unique winner at both bounds is the winner for
+			// every mean in between, and its insert size keeps the bounds exact.  (With --strata a tied pair may contribute
+			// nothing at all; then every tied pair simply waits for pass 4.)
+			if (!pe_strata) {
+				long sum_lo = m->pair_dist_sum, sum_hi = m->pair_dist_sum, cnt = m->pair_dist_count;
+				size_t nt = 0;
+				for (int pi = 0; pi < n / 2 && nt < tied.size(); ++pi) {
+					if (tied[nt].pi != pi) { if (pair_dist[pi]) { sum_lo += pair_dist[pi]; sum_hi += pair_dist[pi]; ++cnt; } continue; }
+					Tied &t = tied[nt++];
+					t.avg_lo = sum_lo / std::max(1L, cnt); t.avg_hi = sum_hi / std::max(1L, cnt);
+					if (!t.found) { commit(2 * pi + 1, 2 * pi, false, -1, -1, 0, 0, 0); t.open = false; continue; }
+					if (!t.dup) {
+						auto closest = [&](long avg, bool *unique) {
+							int best = 0, n_best = 0; long best_c = LONG_MAX;
+							for (int x = 0; x < t.n_top; ++x) {
+								const long cx = labs((long) t.top_d[x] - avg);
+								if (cx < best_c) { best_c = cx; best = x; n_best = 1; } else if (cx == best_c) ++n_best;
+							}
+							*unique = n_best == 1;
+							return best;
+						};
+						bool u_lo = false, u_hi = false;
+						const int x_lo = closest(t.avg_lo, &u_lo), x_hi = closest(t.avg_hi, &u_hi);
+						if (x_lo == x_hi && u_lo && u_hi) {
+							commit(2 * pi + 1, 2 * pi, true, t.top_a[x_lo], t.top_b[x_lo], t.mqa, t.mqb, 0);
+							pair_dist[pi] = t.top_d[x_lo];
+							sum_lo += t.top_d[x_lo]; sum_hi += t.top_d[x_lo]; ++cnt;
+							t.open = false;
+							continue;
+						}
+					}
+					sum_lo += t.dmin; sum_hi += t.dmax; ++cnt;
+				}
+			}
+			qlap(1);
+			tied.erase(std::remove_if(tied.begin(), tied.end(), [](const Tied &t) { return !t.open; }), tied.end());
+			{
+				// the reference's candidate order is needed for: the pairs still open, and mates selected single-end
 				// (no pair in the window / mate without candidates) whose best score is shared
-				std::sort(amb_pairs.begin(), amb_pairs.end());
+				auto is_open = [&](int pi) { auto it = std::lower_bound(tied.begin(), tied.end(), pi, [](const Tied &t, int v) { return t.pi < v; }); return it != tied.end() && it->pi == pi; };
 				std::vector<uint32_t> need;
-				for (int pi : amb_pairs) { need.push_back((uint32_t) (2 * pi)); need.push_back((uint32_t) (2 * pi + 1)); }
+				for (const Tied &t : tied) { need.push_back((uint32_t) (2 * t.pi)); need.push_back((uint32_t) (2 * t.pi + 1)); }
 				std::vector<uint32_t> se_tied;
 				for (int i = 0; i < n; ++i)
-					if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] != 1 && m->h_count[i] > 1 && !std::binary_search(amb_pairs.begin(), amb_pairs.end(), i / 2)) se_tied.push_back((uint32_t) i);
+					if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] != 1 && m->h_count[i] > 1 && !is_open(i / 2)) se_tied.push_back((uint32_t) i);
 				need.insert(need.end(), se_tied.begin(), se_tied.end());
-				if (host_timing) fprintf(stderr, "[ngm-hip] order needed: %zu ambiguous pairs, %zu single-end ties\n", amb_pairs.size(), se_tied.size());
-				if (!need.empty()) {
+				if (host_timing) fprintf(stderr, "[ngm-hip] order needed: %zu tied pairs, %zu single-end ties\n", tied.size(), se_tied.size());
+				{
 					uint32_t *h_rank_pe = nullptr;
-					if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
+					if (!need.empty() && !position_order) if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
 					auto first_best = [&](uint32_t i) {  // ScoreBuffer::top1SE keeps the first of the equally best candidates
 						const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+						if (!h_rank_pe) return;
 						float best = h_scores[b];
 						for (uint32_t c2 = 1; c2 < cnt; ++c2) best = std::max(best, h_scores[b + c2]);
 						uint32_t pick = 0xFFFFFFFFu, pick_rank = ngm::kCsOrderUnknown;
@@ -727,20 +815,62 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						}
 						if (pick != 0xFFFFFFFFu) h_winner[i] = pick;
 					};
-					for (int pi : amb_pairs) {
+					// ... but when both mates have candidates top1PE has already SORTED the arrays before it falls back to
+					// top1SE (ScoreBuffer.cpp:373-376, 449-455): the first of the best is the head of that (unstable) sort
+					auto first_sorted = [&](uint32_t i) {
+						if (!h_rank_pe) return;
+						if (m->h_count[i] <= 16) { first_best(i); return; }  // insertion sort: stable
+						bool ranked = false;
+						const std::vector<uint32_t> v = sort_like_reference(m->h_base[i], m->h_count[i], h_loc, h_sv, h_scores, h_rank_pe, &ranked);
+						if (ranked) h_winner[i] = v[0];
+					};
+					qlap(2);
+					// Pass 3 (parallel): an open pair whose outcome is the same for every mean inside its bounds is settled too
+					struct Outcome { int wa, wb, mqa, mqb, equal, dist; bool found; };
+					auto outcome_at = [&](int pi, long sum, long cnt) {
+						Outcome o{-1, -1, 0, 0, 0, 0, false};
+						run_pair(pi, sum, cnt, h_rank_pe, &o.wa, &o.wb, &o.mqa, &o.mqb, &o.equal, &o.dist, &o.found, nullptr);
+						return o;
+					};
+					std::vector<Outcome> settled(tied.size());
+					if (!pe_strata) parallel_for((int) tied.size(), [&](int lo, int hi) {
+						for (int x = lo; x < hi; ++x) {
+							Tied &t = tied[x];
+							if (t.avg_hi - t.avg_lo > 3) continue;
+							const Outcome o = outcome_at(t.pi, t.avg_lo, 1);
+							bool same = true;
+							for (long a = t.avg_lo + 1; a <= t.avg_hi && same; ++a) {
+								const Outcome o2 = outcome_at(t.pi, a, 1);
+								same = o2.found == o.found && o2.wa == o.wa && o2.wb == o.wb && o2.equal == o.equal && o2.dist == o.dist;
+							}
+							if (same) { settled[x] = o; t.open = false; }
+						}
+					}, 128);
+					// Pass 4 (sequential): the running mean in input order; the open pairs see exactly the reference's value
+					size_t nt = 0;
+					for (int pi = 0; pi < n / 2; ++pi) {
+						if (nt >= tied.size() || tied[nt].pi != pi) {
+							if (pair_dist[pi]) { m->pair_dist_sum += pair_dist[pi]; m->pair_dist_count += 1; }
+							continue;
+						}
+						const Tied &t = tied[nt];
+						const Outcome o = t.open ? outcome_at(pi, m->pair_dist_sum, m->pair_dist_count) : settled[nt];
+						++nt;
 						const int rb = 2 * pi, ra = 2 * pi + 1;
-						int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0;
-						bool found = false;
-						select_pair(m, m->pair_dist_sum, m->pair_dist_count, m->h_base[ra], m->h_count[ra], (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb],
-								m->h_count[rb], (int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, h_rank_pe, &wa, &wb, &mqa, &mqb, &equal, &found);
-						commit(ra, rb, found, wa, wb, mqa, mqb, equal);
-						if (!found) { if (h_nbest[ra] != 1 && m->h_count[ra] > 1) first_best((uint32_t) ra); if (h_nbest[rb] != 1 && m->h_count[rb] > 1) first_best((uint32_t) rb); }
+						const bool found = o.found;
+						commit(ra, rb, o.found, o.wa, o.wb, o.mqa, o.mqb, o.equal);
+						if (found && !(pe_strata && o.equal > 0)) { m->pair_dist_sum += o.dist; m->pair_dist_count += 1; }
+						if (!found) { if (h_nbest[ra] != 1 && m->h_count[ra] > 1) first_sorted((uint32_t) ra); if (h_nbest[rb] != 1 && m->h_count[rb] > 1) first_sorted((uint32_t) rb); }
 					}
-					for (uint32_t i : se_tied) first_best(i);
+					for (uint32_t i : se_tied) { if (m->h_count[i ^ 1u] > 0) first_sorted(i); else first_best(i); }
+					qlap(3);
+					if (host_timing) fprintf(stderr, "[ngm-hip] pair selection ms: pass 1 %.2f | pass 2 %.2f | order %.2f | pass 3+4 %.2f\n", tq[0], tq[1], tq[2], tq[3]);
 				}
 			}
 		}
 	}
+	if (paired && np > 0 && m->prm.strata)  // mates selected single-end (top1SE): several equally best candidates -> unmapped
+		for (int i = 0; i < n; ++i) if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] > 1) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; }
 	const int topn = (!paired && m->prm.topn > 1) ? m->prm.topn : 1;
 	std::vector<uint32_t> tn_pairs;  // topn > 1: per output entry the candidate (pair index) to align, or none
 	if (!paired && np > 0 && (topn > 1 || m->prm.strata)) {
@@ -771,12 +901,17 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					if (cnt == 0) continue;
 					v.resize(cnt);
 					std::iota(v.begin(), v.end(), b);
-					std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) {
-						if (h_scores[x] != h_scores[y]) return h_scores[x] > h_scores[y];
-						if (h_rank_tn && h_rank_tn[x] != ngm::kCsOrderUnknown && h_rank_tn[y] != ngm::kCsOrderUnknown && h_rank_tn[x] != h_rank_tn[y]) return h_rank_tn[x] < h_rank_tn[y];
-						if (h_loc[x] != h_loc[y]) return h_loc[x] < h_loc[y];
-						return (h_sv[x] & 1u) < (h_sv[y] & 1u);
-					});
+					// std::sort(sortLocationScore) over the reference's candidate order, as in select_pair
+					auto by_place = [&](uint32_t x, uint32_t y) { return h_loc[x] != h_loc[y] ? h_loc[x] < h_loc[y] : (h_sv[x] & 1u) < (h_sv[y] & 1u); };
+					bool ranked = h_rank_tn != nullptr;
+					for (uint32_t x = b; ranked && x < b + cnt; ++x) ranked = h_rank_tn[x] != ngm::kCsOrderUnknown;
+					if (ranked) {
+						std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return h_rank_tn[x] != h_rank_tn[y] ? h_rank_tn[x] < h_rank_tn[y] : by_place(x, y); });
+						std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return h_scores[x] > h_scores[y]; });
+					} else {
+						std::sort(v.begin(), v.end(), by_place);
+						std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return h_scores[x] > h_scores[y]; });
+					}
 					int ntop = 1;
 					while (ntop < (int) cnt && h_scores[v[0]] == h_scores[v[ntop]]) ++ntop;
 					h_nbest[i] = ntop;
