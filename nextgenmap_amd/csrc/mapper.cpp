@@ -74,8 +74,15 @@ struct ngm_mapper {
 	ngm::DevBuf<uint16_t> d_runs, d_runs_c;
 	// last CS result on the host
 	int n_reads = 0;
-	std::vector<uint32_t> h_base, h_count;
-	std::vector<float> h_maxv;
+	// per-read candidate offsets / counts / best vote counts of the last search, downloaded into pinned memory
+	template <typename T> struct HostArr {
+		ngm::PinnedBuf<T> b;
+		T &operator[](size_t i) { return b.p[i]; }
+		const T &operator[](size_t i) const { return b.p[i]; }
+		T *data() { return b.p; }
+	};
+	HostArr<uint32_t> h_base, h_count;
+	HostArr<float> h_maxv;
 	uint64_t n_cand = 0;
 	hipEvent_t ev[10] = {};
 	float ms[8] = {};
@@ -209,7 +216,7 @@ int run_cs(ngm_mapper *m, int n) {
 			m->n_reads = n;
 			std::vector<unsigned long long> ctr(ctr_words + 8);
 			MAP_HIP_TRY(hipMemcpyAsync(ctr.data(), m->d_counters.p, ctr.size() * 8, hipMemcpyDeviceToHost, m->st));
-			m->h_base.resize(n); m->h_count.resize(n); m->h_maxv.resize(n);
+			if (m->h_base.b.reserve(n) || m->h_count.b.reserve(n) || m->h_maxv.b.reserve(n)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
 			MAP_HIP_TRY(hipMemcpyAsync(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
@@ -401,7 +408,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
-	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->p_rank.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
+	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	ngm_hip_destroy(m->eng);
@@ -446,7 +453,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 
 // Reference order of the candidates of the listed reads (cs_order_kernel): h_rank[c] for every candidate c of those
 // reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
-static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank) {
+static int candidate_order_wait(ngm_mapper *m, uint32_t **h_rank) {
+	MAP_HIP_TRY(hipStreamSynchronize(m->st_hi ? m->st_hi : m->st));
+	*h_rank = m->p_rank.p;
+	return 0;
+}
+// wait = false: only enqueue (the list must stay alive until candidate_order_wait)
+static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank, bool wait = true) {
 	const uint32_t nl = (uint32_t) list.size();
 	hipStream_t ost = m->st_hi ? m->st_hi : m->st;  // everything this depends on has been synchronised by the caller
 	const auto t_begin = std::chrono::steady_clock::now();
@@ -469,6 +482,7 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 		MAP_HIP_TRY(hipGetLastError());
 	}
 	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
+	if (!wait) return 0;
 	MAP_HIP_TRY(hipStreamSynchronize(ost));
 	*h_rank = m->p_rank.p;
 	if (getenv("NGM_HIP_HOST_TIMING"))
@@ -490,26 +504,27 @@ int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const vo
 }
 
 // ScoreBuffer::top1PE's std::sort(Scores, sortLocationScore) (src/ScoreBuffer.cpp:373-376) over one read's candidates.
-static std::vector<uint32_t> sort_like_reference(uint32_t base, uint32_t cnt, const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank,
+static void sort_like_reference(uint32_t *v, uint32_t base, uint32_t cnt, const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank,
 	bool *ranked_out = nullptr) {
-	std::vector<uint32_t> v(cnt);
-	std::iota(v.begin(), v.end(), base);
-	// The reference sorts its candidate list (CollectResultsStd's order) with std::sort(sortLocationScore): not a
-	// stable sort above 16 elements, so do exactly that on the same sequence.  Without the candidate order
-	// (first pass; only pairs whose result does not depend on it are kept) any deterministic order will do.
+	std::iota(v, v + cnt, base);
+	// The reference sorts its candidate list (CollectResultsStd's order) with std::sort(sortLocationScore): an insertion
+	// sort -- stable -- up to 16 elements, an unstable introsort above, so there do exactly that on the same sequence.
+	// Without the candidate order (first pass; only pairs whose result does not depend on it are kept) any deterministic
+	// order will do.
 	auto by_place = [&](uint32_t x, uint32_t y) { return loc[x] != loc[y] ? loc[x] < loc[y] : (sv[x] & 1u) < (sv[y] & 1u); };
 	bool ranked = rank != nullptr;
 	for (uint32_t x = base; ranked && x < base + cnt; ++x) ranked = rank[x] != ngm::kCsOrderUnknown;
-	if (ranked) std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return rank[x] != rank[y] ? rank[x] < rank[y] : by_place(x, y); });
-	else std::sort(v.begin(), v.end(), by_place);
-	if (ranked) std::sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
-	else std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
 	if (ranked_out) *ranked_out = ranked;
-	return v;
+	if (!ranked) { std::sort(v, v + cnt, [&](uint32_t x, uint32_t y) { return score[x] != score[y] ? score[x] > score[y] : by_place(x, y); }); return; }
+	auto by_rank = [&](uint32_t x, uint32_t y) { return rank[x] != rank[y] ? rank[x] < rank[y] : by_place(x, y); };
+	if (cnt <= 16) { std::sort(v, v + cnt, [&](uint32_t x, uint32_t y) { return score[x] != score[y] ? score[x] > score[y] : by_rank(x, y); }); return; }
+	std::sort(v, v + cnt, by_rank);
+	std::sort(v, v + cnt, [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
 }
 
 // What select_pair learns about the equally scoring pairs of one read pair (see the comment at the end of select_pair).
 struct PairTies {
+	PairTies() {}  // the arrays stay uninitialised: this is constructed once per pair
 	bool equal_scores = false;   // two in-window pairs share a pair score: the running mean insert size is consulted
 	bool dup = false;            // ... and two of them also share the insert size: the candidate order decides, NH/X0 counts them
 	bool unique_closest = true;  // at the mean passed in, exactly one best-scoring pair is closest to it
@@ -534,21 +549,26 @@ static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_coun
 		if (*found) { *dist_out = cur; *win_a = (int) base_a; *win_b = (int) base_b; *equal_out = 0; }
 		return;
 	}
-	auto sorted = [&](uint32_t base, uint32_t cnt) { return sort_like_reference(base, cnt, loc, sv, score, rank); };
-	auto mq_of = [&](const std::vector<uint32_t> &v) {  // computeMQ(MappedRead*), ScoreBuffer.cpp:42-49
-		if (v.size() <= 1) return 60;
+	auto mq_of = [&](const uint32_t *v, uint32_t cnt) {  // computeMQ(MappedRead*), ScoreBuffer.cpp:42-49
+		if (cnt <= 1) return 60;
 		const float best = score[v[0]], second = score[v[1]];
 		int mq = 0;
 		if (best > 0 && second >= 0) mq = (int) ceilf(60.0f * (best - second) / best);
 		return mq;
 	};
-	const std::vector<uint32_t> A = sorted(base_a, cnt_a), B = sorted(base_b, cnt_b);
-	*mq_a = mq_of(A); *mq_b = mq_of(B);
+	uint32_t small_a[32], small_b[32];  // nearly always enough; no allocation then
+	std::vector<uint32_t> big_a, big_b;
+	if (cnt_a > 32) big_a.resize(cnt_a);
+	if (cnt_b > 32) big_b.resize(cnt_b);
+	uint32_t *A = cnt_a > 32 ? big_a.data() : small_a, *B = cnt_b > 32 ? big_b.data() : small_b;
+	sort_like_reference(A, base_a, cnt_a, loc, sv, score, rank);
+	sort_like_reference(B, base_b, cnt_b, loc, sv, score, rank);
+	*mq_a = mq_of(A, cnt_a); *mq_b = mq_of(B, cnt_b);
 	const float cutoff = m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f;
 	const float min_a = score[A[0]] * cutoff, min_b = score[B[0]] * cutoff;
 	size_t na = 1, nb = 1;
-	while (na < A.size() && min_a <= score[A[na]]) ++na;
-	while (nb < B.size() && min_b <= score[B[nb]]) ++nb;
+	while (na < cnt_a && min_a <= score[A[na]]) ++na;
+	while (nb < cnt_b && min_b <= score[B[nb]]) ++nb;
 	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
 	float top = 0.0f;
 	int distance = 0, equal = 0, ta = -1, tb = -1, n_combo = 0;
@@ -699,7 +719,6 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is
 			// sequential state of one CS thread in the reference; here every host thread continues from the value at
 			// the start of the batch and the increments are merged afterwards (NGM_HIP_HOST_THREADS=1: strictly sequential).
-			std::vector<int> pair_dist((size_t) n / 2, 0);  // insert size of the selected pair (0: none), summed in input order below
 			const bool pe_strata = m->prm.strata != 0;
 			auto commit = [&](int ra, int rb, bool found, int wa, int wb, int mqa, int mqb, int equal) {
 				if (found && pe_strata && equal > 0) {  // "To many equal scoring positions": both mates unmapped (ScoreBuffer.cpp:437-446)
@@ -724,33 +743,56 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// Pass 1 (parallel): every pair whose result depends on the scores alone -- nearly all of them.  The others
 			// ("tied": equally scoring pairs inside the window) depend on the running mean insert size, which is sequential
 			// state of the reference's CS thread (pairDistSum / pairDistCount), and some also on the candidate order.
-			struct Tied { int pi; bool found, dup, open; int dmin, dmax, mqa, mqb; long avg_lo, avg_hi; int n_top, top_d[8], top_a[8], top_b[8]; };
+			// gap_*: insert sizes / number of the pairs selected since the previous tied pair; dist: this pair's once it is closed
+			struct Tied { int pi; bool found, dup, open; int dmin, dmax, mqa, mqb; long avg_lo, avg_hi; int n_top, top_d[8], top_a[8], top_b[8]; long gap_sum, gap_cnt; int dist; };
 			auto tq0 = now(); double tq[5] = {0, 0, 0, 0, 0};
 			auto qlap = [&](int k) { auto t = now(); tq[k] += std::chrono::duration<double, std::milli>(t - tq0).count(); tq0 = t; };
 			std::mutex tied_mu;
 			std::vector<Tied> tied;
+			std::vector<uint32_t> se_tied;  // mates selected single-end (no pair in the window / mate without candidates) whose best score is shared
+			struct Chunk { int plo; std::vector<Tied> tied; std::vector<uint32_t> se; long tail_sum, tail_cnt; };
+			std::vector<Chunk> chunks;
+			auto se_check = [&](std::vector<uint32_t> &out, int i) { if (h_nbest[i] != 1 && m->h_count[i] > 1) out.push_back((uint32_t) i); };
 			parallel_for(n / 2, [&](int plo, int phi) {
 				std::vector<Tied> local;
+				std::vector<uint32_t> local_se;
+				long gsum = 0, gcnt = 0;
 				for (int pi = plo; pi < phi; ++pi) {
 					const int rb = 2 * pi, ra = 2 * pi + 1;
-					if (m->h_count[ra] == 0 || m->h_count[rb] == 0) continue;  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
+					if (m->h_count[ra] == 0 || m->h_count[rb] == 0) { se_check(local_se, rb); se_check(local_se, ra); continue; }  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
 					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0, dist = 0;
 					bool found = false;
 					PairTies ties;
 					run_pair(pi, 0, 1, nullptr, &wa, &wb, &mqa, &mqb, &equal, &dist, &found, &ties);
 					if (ties.equal_scores) {
-						Tied t{pi, found, ties.dup || pe_strata, true, ties.dmin_top, ties.dmax_top, mqa, mqb, 0, 0, std::min(ties.n_top, 8), {}, {}, {}};
+						Tied t{pi, found, ties.dup || pe_strata, true, ties.dmin_top, ties.dmax_top, mqa, mqb, 0, 0, std::min(ties.n_top, 8), {}, {}, {}, gsum, gcnt, 0};
+						gsum = gcnt = 0;
 						for (int x = 0; x < t.n_top; ++x) { t.top_d[x] = ties.top_d[x]; t.top_a[x] = ties.top_a[x]; t.top_b[x] = ties.top_b[x]; }
 						local.push_back(t);
 						continue;
 					}
 					commit(ra, rb, found, wa, wb, mqa, mqb, equal);
-					if (found) pair_dist[pi] = dist;
+					if (found) { gsum += dist; ++gcnt; } else { se_check(local_se, rb); se_check(local_se, ra); }
 				}
-				if (!local.empty()) { std::lock_guard<std::mutex> lk(tied_mu); tied.insert(tied.end(), local.begin(), local.end()); }
+				{ std::lock_guard<std::mutex> lk(tied_mu); chunks.push_back(Chunk{plo, std::move(local), std::move(local_se), gsum, gcnt}); }
 			});
+			std::sort(chunks.begin(), chunks.end(), [](const Chunk &x, const Chunk &y) { return x.plo < y.plo; });  // pairs in input order again
+			long carry_sum = 0, carry_cnt = 0;  // selected pairs after the last tied pair so far
+			for (Chunk &c : chunks) {
+				if (!c.tied.empty()) { c.tied[0].gap_sum += carry_sum; c.tied[0].gap_cnt += carry_cnt; carry_sum = carry_cnt = 0; }
+				carry_sum += c.tail_sum; carry_cnt += c.tail_cnt;
+				tied.insert(tied.end(), c.tied.begin(), c.tied.end());
+				se_tied.insert(se_tied.end(), c.se.begin(), c.se.end());
+			}
+			// the reference's candidate order is needed for: the pairs that stay open, and mates selected single-end (no pair
+			// in the window / mate without candidates) whose best score is shared.  Most of them are known by now: their
+			// replay runs on the GPU while pass 2 runs here.
+			std::vector<uint32_t> need, need_late;
+			for (const Tied &t : tied) if (t.dup) { need.push_back((uint32_t) (2 * t.pi)); need.push_back((uint32_t) (2 * t.pi + 1)); }
+			need.insert(need.end(), se_tied.begin(), se_tied.end());
+			uint32_t *h_rank_pe = nullptr;
+			if (!need.empty() && !position_order) if (int rc = candidate_order(m, need, np, &h_rank_pe, false)) return rc;
 			qlap(0);
-			std::sort(tied.begin(), tied.end(), [](const Tied &x, const Tied &y) { return x.pi < y.pi; });
 			// Pass 2 (sequential, cheap): the running mean at every tied pair, as bounds -- a tied pair that stays open
 			// contributes one of the insert sizes of its best-scoring pairs.  Without pairs of equal score AND insert size the
 			// winner is the best-scoring pair closest to the mean: the same unique winner at both bounds is the winner for
@@ -758,12 +800,18 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// nothing at all; then every tied pair simply waits for pass 4.)
 			if (!pe_strata) {
 				long sum_lo = m->pair_dist_sum, sum_hi = m->pair_dist_sum, cnt = m->pair_dist_count;
-				size_t nt = 0;
-				for (int pi = 0; pi < n / 2 && nt < tied.size(); ++pi) {
-					if (tied[nt].pi != pi) { if (pair_dist[pi]) { sum_lo += pair_dist[pi]; sum_hi += pair_dist[pi]; ++cnt; } continue; }
-					Tied &t = tied[nt++];
+				for (Tied &t : tied) {
+					const int pi = t.pi;
+					sum_lo += t.gap_sum; sum_hi += t.gap_sum; cnt += t.gap_cnt;
 					t.avg_lo = sum_lo / std::max(1L, cnt); t.avg_hi = sum_hi / std::max(1L, cnt);
-					if (!t.found) { commit(2 * pi + 1, 2 * pi, false, -1, -1, 0, 0, 0); t.open = false; continue; }
+					if (!t.found) {
+						commit(2 * pi + 1, 2 * pi, false, -1, -1, 0, 0, 0);
+						const size_t before = se_tied.size();
+						se_check(se_tied, 2 * pi); se_check(se_tied, 2 * pi + 1);
+						if (!t.dup) need_late.insert(need_late.end(), se_tied.begin() + before, se_tied.end());
+						t.open = false;
+						continue;
+					}
 					if (!t.dup) {
 						auto closest = [&](long avg, bool *unique) {
 							int best = 0, n_best = 0; long best_c = LONG_MAX;
@@ -778,31 +826,24 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						const int x_lo = closest(t.avg_lo, &u_lo), x_hi = closest(t.avg_hi, &u_hi);
 						if (x_lo == x_hi && u_lo && u_hi) {
 							commit(2 * pi + 1, 2 * pi, true, t.top_a[x_lo], t.top_b[x_lo], t.mqa, t.mqb, 0);
-							pair_dist[pi] = t.top_d[x_lo];
+							t.dist = t.top_d[x_lo];
 							sum_lo += t.top_d[x_lo]; sum_hi += t.top_d[x_lo]; ++cnt;
 							t.open = false;
 							continue;
 						}
 					}
+					if (!t.dup) { need_late.push_back((uint32_t) (2 * pi)); need_late.push_back((uint32_t) (2 * pi + 1)); }
 					sum_lo += t.dmin; sum_hi += t.dmax; ++cnt;
 				}
 			}
 			qlap(1);
-			tied.erase(std::remove_if(tied.begin(), tied.end(), [](const Tied &t) { return !t.open; }), tied.end());
 			{
-				// the reference's candidate order is needed for: the pairs still open, and mates selected single-end
-				// (no pair in the window / mate without candidates) whose best score is shared
-				auto is_open = [&](int pi) { auto it = std::lower_bound(tied.begin(), tied.end(), pi, [](const Tied &t, int v) { return t.pi < v; }); return it != tied.end() && it->pi == pi; };
-				std::vector<uint32_t> need;
-				for (const Tied &t : tied) { need.push_back((uint32_t) (2 * t.pi)); need.push_back((uint32_t) (2 * t.pi + 1)); }
-				std::vector<uint32_t> se_tied;
-				for (int i = 0; i < n; ++i)
-					if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] != 1 && m->h_count[i] > 1 && !is_open(i / 2)) se_tied.push_back((uint32_t) i);
-				need.insert(need.end(), se_tied.begin(), se_tied.end());
-				if (host_timing) fprintf(stderr, "[ngm-hip] order needed: %zu tied pairs, %zu single-end ties\n", tied.size(), se_tied.size());
+				size_t n_open = 0;
+				for (const Tied &t : tied) n_open += t.open;
+				if (host_timing) fprintf(stderr, "[ngm-hip] order needed: %zu of %zu tied pairs, %zu single-end ties, %zu reads late\n", n_open, tied.size(), se_tied.size(), need_late.size());
 				{
-					uint32_t *h_rank_pe = nullptr;
-					if (!need.empty() && !position_order) if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
+					if (!need.empty() && !position_order) if (int rc = candidate_order_wait(m, &h_rank_pe)) return rc;
+					if (!need_late.empty() && !position_order) if (int rc = candidate_order(m, need_late, np, &h_rank_pe)) return rc;
 					auto first_best = [&](uint32_t i) {  // ScoreBuffer::top1SE keeps the first of the equally best candidates
 						const uint32_t b = m->h_base[i], cnt = m->h_count[i];
 						if (!h_rank_pe) return;
@@ -821,7 +862,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						if (!h_rank_pe) return;
 						if (m->h_count[i] <= 16) { first_best(i); return; }  // insertion sort: stable
 						bool ranked = false;
-						const std::vector<uint32_t> v = sort_like_reference(m->h_base[i], m->h_count[i], h_loc, h_sv, h_scores, h_rank_pe, &ranked);
+						std::vector<uint32_t> v(m->h_count[i]);
+						sort_like_reference(v.data(), m->h_base[i], m->h_count[i], h_loc, h_sv, h_scores, h_rank_pe, &ranked);
 						if (ranked) h_winner[i] = v[0];
 					};
 					qlap(2);
@@ -832,10 +874,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						run_pair(pi, sum, cnt, h_rank_pe, &o.wa, &o.wb, &o.mqa, &o.mqb, &o.equal, &o.dist, &o.found, nullptr);
 						return o;
 					};
-					std::vector<Outcome> settled(tied.size());
-					if (!pe_strata) parallel_for((int) tied.size(), [&](int lo, int hi) {
+					std::vector<int> open_ix;
+					for (size_t x = 0; x < tied.size(); ++x) if (tied[x].open) open_ix.push_back((int) x);
+					std::vector<Outcome> settled(open_ix.size());
+					std::vector<char> is_settled(open_ix.size(), 0);
+					if (!pe_strata) parallel_for((int) open_ix.size(), [&](int lo, int hi) {
 						for (int x = lo; x < hi; ++x) {
-							Tied &t = tied[x];
+							Tied &t = tied[open_ix[x]];
 							if (t.avg_hi - t.avg_lo > 3) continue;
 							const Outcome o = outcome_at(t.pi, t.avg_lo, 1);
 							bool same = true;
@@ -843,25 +888,24 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 								const Outcome o2 = outcome_at(t.pi, a, 1);
 								same = o2.found == o.found && o2.wa == o.wa && o2.wb == o.wb && o2.equal == o.equal && o2.dist == o.dist;
 							}
-							if (same) { settled[x] = o; t.open = false; }
+							if (same) { settled[x] = o; is_settled[x] = 1; }
 						}
 					}, 128);
 					// Pass 4 (sequential): the running mean in input order; the open pairs see exactly the reference's value
-					size_t nt = 0;
-					for (int pi = 0; pi < n / 2; ++pi) {
-						if (nt >= tied.size() || tied[nt].pi != pi) {
-							if (pair_dist[pi]) { m->pair_dist_sum += pair_dist[pi]; m->pair_dist_count += 1; }
-							continue;
-						}
-						const Tied &t = tied[nt];
-						const Outcome o = t.open ? outcome_at(pi, m->pair_dist_sum, m->pair_dist_count) : settled[nt];
-						++nt;
+					size_t no = 0;
+					for (const Tied &t : tied) {
+						const int pi = t.pi;
+						m->pair_dist_sum += t.gap_sum; m->pair_dist_count += t.gap_cnt;
+						if (!t.open) { if (t.dist) { m->pair_dist_sum += t.dist; m->pair_dist_count += 1; } continue; }  // closed by pass 2
+						const Outcome o = is_settled[no] ? settled[no] : outcome_at(pi, m->pair_dist_sum, m->pair_dist_count);
+						++no;
 						const int rb = 2 * pi, ra = 2 * pi + 1;
 						const bool found = o.found;
 						commit(ra, rb, o.found, o.wa, o.wb, o.mqa, o.mqb, o.equal);
 						if (found && !(pe_strata && o.equal > 0)) { m->pair_dist_sum += o.dist; m->pair_dist_count += 1; }
 						if (!found) { if (h_nbest[ra] != 1 && m->h_count[ra] > 1) first_sorted((uint32_t) ra); if (h_nbest[rb] != 1 && m->h_count[rb] > 1) first_sorted((uint32_t) rb); }
 					}
+					m->pair_dist_sum += carry_sum; m->pair_dist_count += carry_cnt;
 					for (uint32_t i : se_tied) { if (m->h_count[i ^ 1u] > 0) first_sorted(i); else first_best(i); }
 					qlap(3);
 					if (host_timing) fprintf(stderr, "[ngm-hip] pair selection ms: pass 1 %.2f | pass 2 %.2f | order %.2f | pass 3+4 %.2f\n", tq[0], tq[1], tq[2], tq[3]);
