@@ -50,8 +50,9 @@ def main():
     pe = os.path.join(d, "pe.fq")
     S.write_fastq(pe, [x for pair in zip(r1, r2) for x in pair])
     print("reads written %.0fs" % (time.time() - t), flush=True)
-    for name, args, is_pe in (("se", ["-q", fq], False), ("pe", ["-p", "-q", pe], True)):
-        if only and only != name:
+    for name, args, is_pe in (("se", ["-q", fq], False), ("pe", ["-p", "-q", pe], True), ("topn", ["-q", fq, "-n", "4"], False),
+                              ("topn-strata", ["-q", fq, "-n", "3", "--strata"], False), ("pe-strata", ["-p", "-q", pe, "--strata"], True)):
+        if only and name not in only.split(","):
             continue
         t = time.time()
         r = RF.run_ngm(["-r", fa, "-o", os.path.join(d, name + "_ref.sam"), "--affine", "-t", "1", "--no-progress"] + args, cwd=d, timeout=3000)
@@ -65,7 +66,7 @@ def main():
         a, b = recs(os.path.join(d, name + "_ref.sam"), is_pe), recs(os.path.join(d, name + "_hip.sam"), is_pe)
         diff = [k for k in a if a[k] != b.get(k)]
         print("%s: %d records, %d differ; reference %.0fs (1 thread, incl. index), ngm-hip %.0fs (incl. index)" % (name, len(a), len(diff), t_ref, t_hip), flush=True)
-        if is_pe:
+        if is_pe and os.environ.get("BIG_EARLY"):
             cnt = np.fromfile(os.path.join(d, name + "_counts.bin"), dtype=np.uint32).astype(np.int64)
             bcs = (1800000 // 125) & ~1
             early = set()

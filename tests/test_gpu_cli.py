@@ -283,3 +283,38 @@ def test_cli_other_read_lengths(tmp_path, read_len):
     diff = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
     print("records differing:", len(diff), "of", len(a))
     assert len(diff) == 0, (len(diff), str(diff[:2])[:1500])
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+def test_cli_paired_end_repeat_rich_genome(tmp_path):
+    """Paired-end selection where it is order and history dependent: 40 repeat families x 12 copies per contig give mates
+    with more than 16 candidates (top1PE's std::sort is unstable there), many pairs of equal score (tie-break by the
+    running mean insert size, sequential state of the reference's CS thread) and equal score AND insert size (NH/X0 =
+    `equalScoreFound`, candidate order).  Every SAM record must equal `ngm --affine -t 1 -p`'s (tests/big_parity.py is the
+    same at 60 Mbp / 100 000 pairs)."""
+    contigs = S.make_genome([3_000_000, 2_000_001], seed=71, repeat_families=40, repeat_len=800, copies=12, divergence=0.01)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 60):
+                f.write(b[o:o + 60] + b"\n")
+    r1, r2 = S.make_reads(contigs, 20000, 125, seed=72, sub_rate=0.015, indel_rate=0.002, paired=True)
+    fq = str(tmp_path / "pe.fq")
+    S.write_fastq(fq, [x for pair in zip(r1, r2) for x in pair])
+    d1 = tmp_path / "refrun"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    r = RF.run_ngm(["-r", fa1, "-o", str(d1 / "out.sam"), "--affine", "-t", "1", "--no-progress", "-p", "-q", fq], cwd=str(d1))
+    assert "Done" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-1500:]
+    c = subprocess.run([CLI, "-r", fa, "-o", str(tmp_path / "hip.sam"), "--affine", "-p", "-q", fq], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    a, b = _sam_pe(str(d1 / "out.sam")), _sam_pe(str(tmp_path / "hip.sam"))
+    assert set(a) == set(b) and len(a) == 2 * len(r1)
+    diff = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
+    multi = sum(1 for n in a if a[n]["tags"].get("NH", "0") not in ("0", "1"))
+    print("records differing:", len(diff), "of", len(a), "; records with NH > 1:", multi)
+    assert multi > 50  # the case really has pairs of equal score and insert size
+    assert len(diff) == 0, (len(diff), diff[:3])
