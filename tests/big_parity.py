@@ -51,7 +51,8 @@ def main():
     S.write_fastq(pe, [x for pair in zip(r1, r2) for x in pair])
     print("reads written %.0fs" % (time.time() - t), flush=True)
     for name, args, is_pe in (("se", ["-q", fq], False), ("pe", ["-p", "-q", pe], True), ("topn", ["-q", fq, "-n", "4"], False),
-                              ("topn-strata", ["-q", fq, "-n", "3", "--strata"], False), ("pe-strata", ["-p", "-q", pe, "--strata"], True)):
+                              ("topn-strata", ["-q", fq, "-n", "3", "--strata"], False), ("pe-strata", ["-p", "-q", pe, "--strata"], True),
+                              ("pe-e2e", ["-p", "-q", pe, "-e"], True), ("pe-window", ["-p", "-q", pe, "-I", "250", "-X", "420"], True)):
         if only and name not in only.split(","):
             continue
         t = time.time()
