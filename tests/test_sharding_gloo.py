@@ -39,7 +39,8 @@ WORKER = textwrap.dedent('''
     assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1))
     assert tot["reads"] == n_reads, tot
     assert tot["mapped"] == sum((b - a) // 3 for a, b in bounds)
-    print("rank", rank, "ok", tot["reads"])
+    # one file per rank: the ranks' stdout lines can interleave character by character
+    open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "rank%%d.ok" %% rank), "w").write("ok %%d" %% tot["reads"])
     dist.destroy_process_group()
 ''')
 
@@ -53,4 +54,4 @@ def test_two_rank_sharding_and_stats_reduce(tmp_path):
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok 100003") == 2
+    assert [(tmp_path / ("rank%d.ok" % k)).read_text() for k in range(2)] == ["ok 100003"] * 2
