@@ -9,17 +9,23 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LIB = os.path.join(HERE, "libngm_hip.so")
 SOURCES = ["ngm_hip.cpp", "jit.cpp", "ialignment_adapter.cpp", "refindex.cpp", "mapper.cpp"]
 JIT_HEADERS = ["sw_device.h", "align_device.h", "affine_device.h"]  # DP kernel templates, also compiled at run time (hiprtc)
-HEADERS = ["ngm_cli.cpp", "engine_internal.h", "sw_device.h", "align_device.h", "cigar_md.h", "refindex.h", "cs_device.h", "gather_device.h", os.path.join("..", "..", "include", "ngm_pipeline.h"), os.path.join("..", "..", "include", "ngm_hip.h"),
-           os.path.join("..", "..", "include", "ngm_ialignment.h")]
+OBJ_DIR = os.path.join(HERE, "build")
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _inputs():
+    """every file the library or the CLI is built from (a hand-kept header list went stale)"""
+    import glob
+    inc = os.path.join(HERE, "..", "include")
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(inc, "*.h")))
+
+
+def _stale(target=None, inputs=None):
+    target = target or LIB
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
+    t = os.path.getmtime(target)
+    for p in (inputs or _inputs()):
+        if not p.endswith("jit_sources.inc") and os.path.getmtime(p) > t:
             return True
     return False
 
@@ -43,12 +49,30 @@ def write_jit_sources():
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU). Returns the library path."""
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU), one translation unit per process. Returns the library path."""
+    from concurrent.futures import ThreadPoolExecutor
     write_jit_sources()
     if not force and not _stale():
+        if _stale(CLI, [os.path.join(CSRC, "ngm_cli.cpp"), LIB] + [p for p in _inputs() if p.endswith(".h")]):
+            build_cli(verbose)
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"] + srcs + ["-lz", "-lhiprtc", "-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [p for p in _inputs() if p.endswith(".h")] + [os.path.join(CSRC, "jit_sources.inc")]
+
+    def compile_one(src):
+        obj = os.path.join(OBJ_DIR, src.replace(".cpp", ".o"))
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [path] + headers):
+            return obj
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lz", "-lhiprtc", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -130,6 +130,40 @@ __global__ void apply_usage_rule_kernel(uint32_t n_kmers, int k, const uint32_t 
 
 void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw);
 
+// bucket b of k-mer p: word 0 = count (0: unused, or more than 9900 occurrences), words 1.. = its positions; a list that
+// does not fit keeps (count | 1 << 31, start in d_positions).  One thread per bucket word: coalesced stores.
+__global__ void fill_buckets_kernel(uint32_t n_kmers, int log2_w, const uint2 *__restrict__ index, const uint32_t *__restrict__ positions,
+		uint32_t *__restrict__ buckets) {
+	const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t p = (uint32_t) (g >> log2_w), w = (uint32_t) g & ((1u << log2_w) - 1u);
+	if (p >= n_kmers) return;
+	const uint2 e = index[p];
+	const bool inl = e.y < (1u << log2_w);
+	uint32_t v = 0;
+	if (w == 0) v = inl ? e.y : (e.y | 0x80000000u);
+	else if (inl) v = (w <= e.y) ? positions[e.x + (w - 1)] : 0u;
+	else if (w == 1) v = e.x;
+	buckets[g] = v;
+}
+
+int build_buckets(ngm_ref *r) {
+	const int k = r->prm.kmer;
+	const uint32_t n_kmers = 1u << (2 * k);
+	// W - 1 >= mean + 4 standard deviations of a Poisson list length (real genomes have a heavy tail on top: those
+	// lists overflow into d_positions, which costs them one more request)
+	const double mu = (double) r->n_entries / (double) n_kmers;
+	int lw = 2;
+	while (lw < 5 && (double) ((1 << lw) - 1) < mu + 4.0 * sqrt(mu) + 0.5) ++lw;
+	if (const char *e = getenv("NGM_HIP_BUCKET_LOG2_WORDS")) lw = std::max(2, std::min(5, atoi(e)));  // tests
+	r->bucket_log2_words = lw;
+	const uint64_t words = (uint64_t) n_kmers << lw;
+	REF_HIP_TRY(hipMalloc(&r->d_buckets, words * 4));
+	hipLaunchKernelGGL(fill_buckets_kernel, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, 0, n_kmers, lw, r->d_index, r->d_positions, r->d_buckets);
+	REF_HIP_TRY(hipGetLastError());
+	REF_HIP_TRY(hipDeviceSynchronize());
+	return 0;
+}
+
 int build_index(ngm_ref *r) {
 	const int k = r->prm.kmer;
 	const uint32_t n_kmers = 1u << (2 * k);
@@ -185,7 +219,7 @@ int build_index(ngm_ref *r) {
 	std::vector<uint32_t> raw(n_kmers);
 	REF_HIP_TRY(hipMemcpy(raw.data(), r->d_raw_counts, (size_t) n_kmers * 4, hipMemcpyDeviceToHost));
 	index_stats(r, raw);
-	return 0;
+	return build_buckets(r);
 }
 
 // CompactPrefixTable::stats (PrefixTable.cpp:150-194): integer sums are exact in double, order-free
@@ -198,6 +232,7 @@ void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw) {
 	const double stdev = sqrt(sum2 / (len - 1) - 2.0 * avg * (sum / (len - 1)) + ((len * avg * avg) / (len - 1)));
 	r->auto_max_kfreq = (int) ceil(std::max(100.0, avg + 5 * stdev));
 }
+
 
 int upload_genome(ngm_ref *r) {
 	// artificial upper bound for positions on the last contig (SequenceProvider.cpp:378)
@@ -357,6 +392,7 @@ ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *p, const ch
 		return nullptr;
 	}
 	index_stats(r, raw);
+	if (build_buckets(r) != 0) { ngm_ref_destroy(r); return nullptr; }
 	return r;
 }
 
@@ -411,6 +447,7 @@ void ngm_ref_destroy(ngm_ref *r) {
 	if (r->d_index) (void) hipFree(r->d_index);
 	if (r->d_raw_counts) (void) hipFree(r->d_raw_counts);
 	if (r->d_positions) (void) hipFree(r->d_positions);
+	if (r->d_buckets) (void) hipFree(r->d_buckets);
 	delete r;
 }
 

@@ -11,6 +11,12 @@
 //                 5-byte packed entries, PrefixTable.h:27-61); count is already 0 for k-mers that the reference
 //                 treats as unused (>= 9901 occurrences fwd+revcomp, PrefixTable.cpp:468-478)  -- 537 MB
 //   d_positions : one uint32 per indexed k-mer occurrence, grouped by k-mer, ascending        -- ~4.1 GB
+//   d_buckets   : the layout the candidate search actually gathers from: one aligned bucket of W = 4..32 dwords per
+//                 k-mer, {count, position 0 .. W-2}, so that a lookup is ONE memory request instead of index entry ->
+//                 position list (measured on MI355X, profiles/r02_gather_calibration.txt: random gathers are bound by
+//                 ~50 G requests/s whatever their size up to 128 B, where they reach the 6.2 TB/s streaming ceiling).
+//                 Lists longer than W-1 keep {count | 1<<31, offset into d_positions}.  W from the mean list length
+//                 (GRCh38 size: 15.4 -> W = 32, 128 B, 99.98 % of the lists inline)                -- 8.6 GB
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -42,6 +48,9 @@ struct ngm_ref {
 	uint2 *d_index = nullptr;
 	uint32_t *d_raw_counts = nullptr;
 	uint32_t *d_positions = nullptr;
+	uint32_t *d_buckets = nullptr;
+	int bucket_log2_words = 2;        // W = 1 << bucket_log2_words dwords per k-mer bucket
+	double overflow_hit_share = 0.0;  // share of all index entries that live in lists longer than W-1
 };
 
 namespace ngm {

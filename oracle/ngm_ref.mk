@@ -68,3 +68,16 @@ $(OUT)/ngm_affine_ref: $(OUT)/affine_ref_main.o $(AFF_OBJ)
 affine: $(OUT)/ngm_affine_ref
 all: affine
 .PHONY: affine
+
+# ---- the reference's SWOclCigar::computeCigarMD (default personality: CIGAR / MD / NM / Identity) behind a driver of ours ----
+# The method is private and SWOcl's constructor needs an OpenCL device: the driver (and only the driver) is compiled with
+# -fno-access-control and calls the method on zeroed storage with alignment_length set.  The objects are the ones ngm-core links.
+LIN_OBJ := $(addprefix $(OUT)/rel/ocl/,$(OCL_SRC:.cpp=.o)) $(addprefix $(OUT)/rel/src/,config/Config.o log/Logging.o core/unix.o core/unix_threads.o)
+$(OUT)/linear_cigar_ref_main.o: $(dir $(abspath $(lastword $(MAKEFILE_LIST))))linear_cigar_ref_main.cpp $(GEN_HDR)
+	@mkdir -p $(dir $@)
+	$(CXX) $(CXXFLAGS_COMMON) -fno-access-control -O2 -DNDEBUG $(INC) -c $< -o $@
+$(OUT)/ngm_linear_cigar_ref: $(OUT)/linear_cigar_ref_main.o $(LIN_OBJ)
+	$(CXX) -pthread -o $@ $^ -lz -lOpenCL
+linear_cigar: $(OUT)/ngm_linear_cigar_ref
+all: linear_cigar
+.PHONY: linear_cigar

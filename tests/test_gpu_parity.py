@@ -72,7 +72,29 @@ def test_custom_scoring_and_clipping():
         eng.close()
 
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ngm_ocl_*.npz")))
+GOLDEN = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ngm_ocl_*.npz"))) if not p.endswith("_cigar.npz")]
+CIGAR_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ngm_ocl_*_cigar.npz")))
+
+
+@pytest.mark.parametrize("path", CIGAR_GOLDEN, ids=[os.path.basename(p) for p in CIGAR_GOLDEN])
+@pytest.mark.parametrize("mode", [0, 1], ids=["local", "endfree"])
+@pytest.mark.parametrize("clip", [0, 1, 2], ids=["soft", "hardclip", "silentclip"])
+def test_batch_align_matches_reference_cigar_goldens(path, mode, clip):
+    """BatchAlign of the default personality against the output of the REFERENCE'S OWN computeCigarMD
+    (lib/mason/opencl/SWOclCigar.cpp:430-615; fixtures from oracle/make_cigar_goldens.py) fed with what the reference's
+    own kernels produced for the same pairs: CIGAR, MD, NM, Identity, QStart, QEnd, PositionOffset, validity token."""
+    from test_oracle_golden import cigar_golden_rows
+    g = np.load(path.replace("_cigar.npz", ".npz"))
+    ref, qry, c, variant = g["ref"], g["qry"], int(g["c"]), int(g["variant"])
+    rows, want = cigar_golden_rows(path, mode, clip)
+    eng = _engine(qry.shape[1], c, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2))
+    got = eng.BatchAlign(mode, ref, qry)
+    for j, i in enumerate(rows):
+        a = got[i]
+        have = (True, a["cigar"], a["md"], a["nm"], np.float32(a["identity"]).tobytes(), a["qstart"], a["qend"], a["position_offset"],
+                float(a["score_token"]))
+        assert have == want[j], "row %d: %r != %r" % (i, have, want[j])
+    eng.close()
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])

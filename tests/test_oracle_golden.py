@@ -9,7 +9,7 @@ import pytest
 
 import oracle_lib as O
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ngm_ocl_*.npz")))
+GOLDEN = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ngm_ocl_*.npz"))) if not p.endswith("_cigar.npz")]
 
 
 def test_goldens_present():
@@ -61,3 +61,40 @@ def test_threads_agree():
     a = O.oracle_score(0, ref, qry, 12, nthreads=1)
     b = O.oracle_score(0, ref, qry, 12, nthreads=4)
     assert np.array_equal(a, b)
+
+
+CIGAR_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ngm_ocl_*_cigar.npz")))
+
+
+def cigar_golden_rows(path, mode, clip):
+    """(row indices, expected tuples) from the fixtures written by oracle/make_cigar_goldens.py: the output of the
+    REFERENCE'S OWN SWOclCigar::computeCigarMD (lib/mason/opencl/SWOclCigar.cpp:430-615) on the golden RLE rows."""
+    g = np.load(path)
+    mn = "local" if mode == 0 else "endfree"
+    cn = ("soft", "hard", "silent")[clip]
+    rows = g[mn + "_rows"]
+    f = lambda k: g["%s_%s_%s" % (mn, cn, k)]
+    want = [(bool(f("ok")[j]), bytes(f("cigar")[j]), bytes(f("md")[j]), int(f("nm")[j]), np.float32(f("identity")[j]).tobytes(),
+             int(f("qstart")[j]), int(f("qend")[j]), int(f("position_offset")[j]), float(f("score_token")[j])) for j in range(len(rows))]
+    return rows, want
+
+
+def test_cigar_goldens_present():
+    assert len(CIGAR_GOLDEN) >= 7
+
+
+@pytest.mark.parametrize("path", CIGAR_GOLDEN, ids=[os.path.basename(p) for p in CIGAR_GOLDEN])
+@pytest.mark.parametrize("mode", [0, 1], ids=["local", "endfree"])
+@pytest.mark.parametrize("clip", [0, 1, 2], ids=["soft", "hardclip", "silentclip"])
+def test_oracle_cigar_md_matches_reference_function(path, mode, clip):
+    """CIGAR / MD / NM / Identity / QStart / QEnd of the restatement == the reference's computeCigarMD."""
+    g = np.load(path.replace("_cigar.npz", ".npz"))
+    ref, qry, c, variant = g["ref"], g["qry"], int(g["c"]), int(g["variant"])
+    if clip and qry.shape[1] > 152:
+        pytest.skip("clipping modes only change the string conversion: covered on the shapes up to 150 bp (CPU-suite time)")
+    rows, want = cigar_golden_rows(path, mode, clip)
+    res, cig, md = O.oracle_align(mode, ref, qry, c, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2), nthreads=8)
+    for j, i in enumerate(rows):
+        have = (bool(res["ok"][i]), cig[i], md[i], int(res["nm"][i]), np.float32(res["identity"][i]).tobytes(), int(res["qstart"][i]),
+                int(res["qend"][i]), int(res["position_offset"][i]), float(res["score_token"][i]))
+        assert have == want[j], "row %d" % i
