@@ -146,6 +146,23 @@ int ngm_mapper_map_pe(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, ch
 int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads, ngm_hit *hits, char *cigars,
 		char *mds);
 
+/* Several mappers on ONE input (ngm-hip hands batches to a mapper per worker thread / per GPU, like NextGenMap hands them to
+ * its CS threads, src/NGM.cpp:232-279, src/CS.cpp:440-456).  top1PE's tie-break reads the running mean insert size of the
+ * pairs selected so far (ScoreBuffer.h:90, ScoreBuffer.cpp:420-422, :487-488) -- sequential state.  Mappers that share an
+ * ngm_pair_state take turns for that part of the selection in batch order (ngm_mapper_set_batch_seq before every
+ * ngm_mapper_map_pe*, numbers 0, 1, 2 ... without gaps), so the result equals one mapper seeing the batches in order,
+ * i.e. `ngm -t 1`.  Everything else of a batch (search, scoring, the order-free part of the selection, alignment)
+ * overlaps freely. */
+typedef struct ngm_pair_state ngm_pair_state;
+ngm_pair_state *ngm_pair_state_create(void);
+void ngm_pair_state_destroy(ngm_pair_state *ps);
+int ngm_mapper_set_pair_state(ngm_mapper *m, ngm_pair_state *ps);
+int ngm_mapper_set_batch_seq(ngm_mapper *m, uint64_t seq);
+
+/* page-locked host memory for read batches (the H2D copy then runs at PCIe rate without a staging copy) */
+void *ngm_host_alloc(size_t bytes);
+void ngm_host_free(void *p);
+
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted
  * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */
 int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]);

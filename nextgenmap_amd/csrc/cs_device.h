@@ -452,27 +452,30 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 	// wave-uniform bookkeeping in registers: queue length, distinct keys this wave put into the table, abort flag
 	uint32_t q_len = 0, n_keys = 0, hits = 0;
 	bool abort_fast = false;
-	const uint32_t key_cap = ((n_slots * 3u) / 4u) / (uint32_t) T;   // per wave, so that the table never fills up
-	// inserts this wave's queued entries (bin | strand << 31), one per lane per round
+	// inserts this wave's queued entries (bin | strand << 31), one per lane per round.  Several waves insert concurrently:
+	// probing is bounded (a full table ends the fast path for this read), the number of keys is only kept as a statistic
 	auto flush_inserts = [&]() {
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the queue is private to the wave: its LDS writes are done
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the queue is private to the wave; LDS operations of a wave complete in order
 		const uint32_t nq = min(q_len, q_cap);
-		if (n_keys + nq >= key_cap) abort_fast = true;  // could exceed this wave's share of the table: leave the read to the exact path
 		uint32_t fresh = 0;
-		if (!abort_fast) for (uint32_t i = lane; i < nq; i += 64) {
+		bool lost = false;
+		for (uint32_t i = lane; i < nq; i += 64) {
 			const uint32_t e = s_queue[i];
 			const uint32_t bin = e & 0x3FFFFFFFu;
 			uint32_t slot = (bin * 2654435761u) >> hs;
-			for (;;) {
+			uint32_t probes = 0;
+			for (; probes < n_slots; ++probes) {
 				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
 				if (prev == bin) break;
 				if (prev == 0xFFFFFFFFu) { ++fresh; break; }
 				slot = (slot + 1) & (n_slots - 1);
 			}
-			atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
+			if (probes < n_slots) atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
+			else lost = true;
 		}
+		if (__ballot(lost)) abort_fast = true;
 		{ uint32_t total; (void) wave_prefix_small<5>(fresh, total); n_keys += total; }  // fresh <= ceil(q_cap / 64) <= 12
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		q_len = 0;
 	};
 	// votes NS slots: position, valid -> returns the register entry per slot (bin | first-on-its-bit << 30 | strand << 31, 0 = nothing left to do)
@@ -501,19 +504,15 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 		if (q_len > q_cap) abort_fast = true;  // more repeats than the queue holds: leave it to the exact path
 	};
 
-	// one bucket round of this wave: round r covers lists [(r T + wave) bpr, +bpr)
+	// one bucket round of this wave: round r covers lists [(r T + wave) bpr, +bpr).  The load is unconditional (lanes without
+	// a list read bucket 0): a load under a divergent branch makes the compiler wait for it right there (the merge copies
+	// the loaded registers), which would serialise the rounds on the memory latency.
 	auto fetch = [&](int r, CsU4 &d) -> uint32_t {
 		const int li = (r * T + wave) * bpr + (lane >> ls);
-		uint32_t meta = kCsNoList;
-		d = CsU4{0u, 0u, 0u, 0u};
-		if (li < n_lists) {
-			const uint32_t id = l_list[li];
-			if (id != kCsNoList) {
-				d = *reinterpret_cast<const CsU4 *>(A.buckets + ((size_t) id << bw) + sub * 4u);
-				meta = (uint32_t) li;
-			}
-		}
-		return meta;
+		const uint32_t id = l_list[min(li, A.lists_cap - 1)];
+		const bool ok = li < n_lists && id != kCsNoList;
+		d = *reinterpret_cast<const CsU4 *>(A.buckets + ((size_t) (ok ? id : 0u) << bw) + sub * 4u);
+		return ok ? (uint32_t) li : kCsNoList;
 	};
 
 	uint32_t bins[ROUNDS * 4];  // bin | first-on-its-bit << 30 | reverse strand << 31 ; 0 = empty slot
@@ -524,14 +523,16 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 	for (int d = 0; d < DEPTH - 1; ++d) rmeta[d] = fetch(d, ring[d]);
 #pragma unroll
 	for (int r = 0; r < ROUNDS; ++r) {
+		// the prefetch is issued on every path: loads under a branch make the compiler's wait-count bookkeeping give up one
+		// round of pipelining per merge point (rounds past the last list read bucket 0 and are skipped below)
+		if (r + DEPTH - 1 < ROUNDS) rmeta[(r + DEPTH - 1) % DEPTH] = fetch(r + DEPTH - 1, ring[(r + DEPTH - 1) % DEPTH]);
+		const uint32_t li = rmeta[r % DEPTH];
+		const CsU4 cur = ring[r % DEPTH];
 		if ((r * T + wave) * bpr >= n_lists) {  // wave-uniform
 #pragma unroll
 			for (int j = 0; j < 4; ++j) bins[r * 4 + j] = 0;
 			continue;
 		}
-		if (r + DEPTH - 1 < ROUNDS) rmeta[(r + DEPTH - 1) % DEPTH] = fetch(r + DEPTH - 1, ring[(r + DEPTH - 1) % DEPTH]);
-		const uint32_t li = rmeta[r % DEPTH];
-		const CsU4 cur = ring[r % DEPTH];
 		// list length: word 0 of the bucket, i.e. of the first lane of the lane group; partner list = neighbouring group
 		const uint32_t hdr = (uint32_t) __shfl((int) cur.x, lane & ~(int) (lpb - 1u));
 		const uint32_t n_own = li != kCsNoList ? (hdr & 0x7FFFFFFFu) : 0u;
@@ -610,7 +611,9 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 		flush_inserts();
 	}
 	if (abort_fast) s_misc[1] = 1u;
+	if (lane == 0 && n_keys) atomicAdd(&s_misc[6], n_keys);
 	__syncthreads();
+	if (s_misc[6] > (n_slots * 3u) / 4u) s_misc[1] = 1u;  // probing gets slow and the spurious entries too many
 	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
 	CsRead R;
 	R.L = L; R.n_lists = n_lists; R.H = s_misc[3]; R.n_valid = s_misc[4]; R.n_items = 0;
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) if ((wmask[r] >> j) & 1u) { if (qb < q_cap) s_queue[qb] = bins[r * 4 + j]; ++qb; }
 		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		if (q_len > q_cap) abort_fast = true;
 		const uint32_t nq = min(q_len, q_cap);
 		for (uint32_t i = lane; i < nq; i += 64) add_vote(s_queue[i]);

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -24,6 +25,7 @@
 #include "cigar_md.h"
 #include "cs_device.h"
 #include "gather_device.h"
+#include "thread_pool.h"
 
 #define MAP_HIP_TRY(expr)                                                                      \
 	do {                                                                                       \
@@ -34,8 +36,20 @@
 		}                                                                                      \
 	} while (0)
 
+// ScoreBuffer's running insert-size sum / count (src/ScoreBuffer.h:90) when several mapper instances work on one input:
+// batches carry their input-order number and the order-dependent part of the selection takes turns in that order, so
+// every batch starts from the state the reference's single CS thread would have at its first pair.
+struct ngm_pair_state {
+	std::mutex mu;
+	std::condition_variable cv;
+	uint64_t next = 0;                 // sequence number of the batch whose turn it is
+	long dist_count = 1, dist_sum = 0;
+};
+
 struct ngm_mapper {
 	const ngm_ref *ref = nullptr;
+	ngm_pair_state *ps = nullptr;      // shared paired-end state (null: the mapper's own)
+	uint64_t batch_seq = 0;            // ... and the input-order number of the next paired-end batch
 	ngm_mapper_params prm{};
 	ngm_hip_ctx *eng = nullptr;
 	hipStream_t st = nullptr;
@@ -271,27 +285,11 @@ struct GpuStage {
 	GpuStage() : lk(g_gpu_stage_mu, std::defer_lock) { static const bool on = !(getenv("NGM_HIP_GPU_STAGE_LOCK") && atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) == 0); if (on) lk.lock(); }
 	void done() { if (lk.owns_lock()) lk.unlock(); }
 };
+// per-read host loops run on the process-wide persistent pool (thread_pool.h): shared by the mapper instances, sized
+// to this rank's share of the host cores; no threads are started per call
 template <typename F>
 void parallel_for(int n, F f, int min_grain = 0) {
-	// the host cores are shared by the mapper instances of this process and, under torchrun, by the other ranks of the node
-	static const int ranks_on_node = [] {
-		const char *e = getenv("LOCAL_WORLD_SIZE");
-		if (!e) e = getenv("WORLD_SIZE");
-		return std::max(1, e ? atoi(e) : 1);
-	}();
-	int nt = (int) std::thread::hardware_concurrency() / std::max(1, g_live_mappers.load() * ranks_on_node);
-	if (const char *e = getenv("NGM_HIP_HOST_THREADS")) nt = atoi(e);
-	nt = std::max(1, std::min(nt, 64));
-	if (min_grain > 0) nt = std::min(nt, n / min_grain);  // small jobs: fewer threads, starting one costs ~20 us
-	if ((min_grain <= 0 && n < 4096) || nt <= 1) { f(0, n); return; }
-	std::vector<std::thread> th;
-	const int chunk = (n + nt - 1) / nt;
-	for (int t = 0; t < nt; ++t) {
-		const int lo = t * chunk, hi = std::min(n, lo + chunk);
-		if (lo >= hi) break;
-		th.emplace_back([=]() { f(lo, hi); });
-	}
-	for (auto &x : th) x.join();
+	ngm::ThreadPool::instance().parallel_for(n, f, min_grain > 0 ? min_grain : 2048);
 }
 
 char class_char(uint8_t c) {
@@ -393,7 +391,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		const int n_lists = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1);
 		const int bpr = 64 >> (ref->bucket_log2_words - 2);
 		const int rounds = (n_lists + bpr - 1) / bpr;
-		m->cs_waves = rounds <= cs_rounds_covered(1) ? 1 : rounds <= cs_rounds_covered(4) ? 4 : 8;
+		m->cs_waves = rounds <= cs_rounds_covered(2) ? 2 : rounds <= cs_rounds_covered(4) ? 4 : 8;
 		if (const char *e = getenv("NGM_HIP_CS_WAVES")) {  // tests / tuning: 1, 2, 4 or 8 (if they cover the lists)
 			const int w = atoi(e);
 			if ((w == 1 || w == 2 || w == 4 || w == 8) && rounds <= cs_rounds_covered(w)) m->cs_waves = w;
@@ -639,6 +637,24 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	if (!m || n < 0) return -22;
 	if (paired && m->prm.topn > 1) { ngm::pipeline_set_error("Paired end mode with topn > 1 not yet supported."); return -38; }  // ScoreBuffer::topNPE
 	if (paired && (n & 1)) { ngm::pipeline_set_error("paired-end batches need an even number of reads"); return -22; }
+	// shared paired-end state: wait for this batch's turn before the running mean is read, pass it on when the batch is
+	// done with it (also on every early return)
+	struct PairTurn {
+		ngm_mapper *m; bool active, held = false;
+		void acquire() {
+			if (!active || held) return;
+			std::unique_lock<std::mutex> lk(m->ps->mu);
+			m->ps->cv.wait(lk, [&] { return m->ps->next == m->batch_seq; });
+			m->pair_dist_sum = m->ps->dist_sum; m->pair_dist_count = m->ps->dist_count;
+			held = true;
+		}
+		~PairTurn() {
+			if (!active) return;
+			acquire();
+			{ std::lock_guard<std::mutex> lk(m->ps->mu); m->ps->dist_sum = m->pair_dist_sum; m->ps->dist_count = m->pair_dist_count; m->ps->next = m->batch_seq + 1; }
+			m->ps->cv.notify_all();
+		}
+	} pair_turn{m, paired && m->ps != nullptr};
 	if (n == 0) return 0;
 	const ngm_ref *r = m->ref;
 	DevGuard g(r->device);
@@ -811,6 +827,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// winner is the best-scoring pair closest to the mean: the same unique winner at both bounds is the winner for
 			// every mean in between, and its insert size keeps the bounds exact.  (With --strata a tied pair may contribute
 			// nothing at all; then every tied pair simply waits for pass 4.)
+			pair_turn.acquire();
 			if (!pe_strata) {
 				long sum_lo = m->pair_dist_sum, sum_hi = m->pair_dist_sum, cnt = m->pair_dist_count;
 				for (Tied &t : tied) {
@@ -1116,6 +1133,18 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	}
 	return n;
 }
+
+ngm_pair_state *ngm_pair_state_create(void) { return new ngm_pair_state(); }
+void ngm_pair_state_destroy(ngm_pair_state *ps) { delete ps; }
+int ngm_mapper_set_pair_state(ngm_mapper *m, ngm_pair_state *ps) { if (!m) return -22; m->ps = ps; return 0; }
+int ngm_mapper_set_batch_seq(ngm_mapper *m, uint64_t seq) { if (!m) return -22; m->batch_seq = seq; return 0; }
+
+void *ngm_host_alloc(size_t bytes) {
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { ngm::pipeline_set_error("out of pinned host memory (%zu bytes)", bytes); return nullptr; }
+	return p;
+}
+void ngm_host_free(void *p) { if (p) (void) hipHostFree(p); }
 
 int ngm_mapper_cs_max_combined(ngm_mapper *m, float *out) {
 	if (!m) return -22;

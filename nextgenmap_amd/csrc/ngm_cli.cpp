@@ -1,18 +1,44 @@
 // ngm_cli.cpp -- `ngm-hip`: NextGenMap-compatible command line over the C ABI (include/ngm_pipeline.h).
 //
-// Mirrors, for single-end input, what ngm-core does around its hot path:
+// Mirrors what ngm-core does around its hot path:
 //   option names / defaults          src/config/Options.h:13-105, src/config/Config.cpp:381-557
 //   read parsing                     src/parser/IParser.h:59-121 (upper-case, non-ACGT -> N, truncate to qry_max_len-1)
 //   parameter estimation             src/ReadProvider.cpp:163-394 (qry_max_len, corridor, sensitivity)
 //   output filter                    src/writer/GenericReadWriter.h:190-254 (min_identity, min_residues), min_mq
 //   SAM header / records             src/writer/SAMWriter.cpp:17-84, :98-228, :312-373
+//   batch hand-out to workers        src/NGM.cpp:232-279 (GetNextReadBatch under a mutex), src/CS.cpp:440-456 (-g: threads -> devices)
+//   buffered, ordered output         src/writer/GenericReadWriter.h:190-304 (20 MB buffer, flushed under the output lock)
 // Everything heavy (index, candidate search, score, align) happens on the GPU behind ngm_mapper_*.
-// Not supported (rejected loudly): paired-end input, --affine, BAM, bisulfite / SLAM-seq, --topn > 1, --argos, --vcf.
+// Single-end and paired-end (-p -q interleaved, --qry1/--qry2), --affine, -n/--strata, SAM and BAM (--bam) output, one or
+// several GPUs (-g 0,1,...).  Not supported (rejected loudly): bisulfite / SLAM-seq, --argos, --vcf, SAM/BAM *input*.
+//
+// Pass 2 is a pipeline, not a loop:
+//   splitter (1 thread)   cuts the input into batches: for plain 4-line FASTQ it only counts line ends in the mapped file
+//                         (record boundaries every 4 096 reads), for gz / FASTA / multi-line input it is the serial kseq-style
+//                         reader (inflate is one stream; that is the bound of such input, as in the reference);
+//   workers               `--workers` per GPU (default 2), each owning an ngm_mapper like a NextGenMap CS thread owns its
+//                         IAlignment: parse its batch into a page-locked row buffer (pool threads, zero-copy names / qualities),
+//                         map it on its GPU, format the SAM text (pool threads) -- while one worker's batch is on the GPU the
+//                         others parse and format;
+//   writer (1 thread)     batches in input order, large writes.
+// Paired-end tie-breaks see the same running mean insert size as `ngm -t 1` (ngm_pair_state: batches take turns for that
+// part only), so the output does not depend on the number of workers or GPUs.
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,6 +49,7 @@
 
 #include "../../include/ngm_hip.h"
 #include "../../include/ngm_pipeline.h"
+#include "thread_pool.h"
 
 namespace {
 
@@ -50,7 +77,10 @@ public:
 			if (!fastq && !line.empty() && (line[0] == '>' || line[0] == '@')) { header_ = line; have_header_ = true; break; }
 			r.seq += line;
 		}
-		if (fastq) while (r.qual.size() < r.seq.size() && getline(line)) r.qual += line;
+		if (fastq) {
+			while (r.qual.size() < r.seq.size() && getline(line)) r.qual += line;
+			if (r.qual.size() != r.seq.size()) { fprintf(stderr, "[ngm-hip] error: Error while parsing read: sequence and quality lengths differ (%s)\n", r.name.c_str()); exit(1); }
+		}
 		return true;
 	}
 
@@ -80,7 +110,8 @@ struct Opts {
 	char pe_delimiter = '/';
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
 	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
-	int skip_save = 0;
+	int skip_save = 0, bam = 0, workers = 2, serial_reader = 0;
+	std::vector<int> devices;
 	std::string rg[12];  // read group: ID CN DS DT FO KS LB PG PI PL PU SM (SAMWriter.cpp:46-80)
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
 	float sensitivity = -1.f, kmer_min = 0.f, min_identity = 0.65f, min_residues = 0.5f;
@@ -95,7 +126,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, AFFINE, GEP, PEDELIM, STRATA, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -116,7 +147,7 @@ Opts parse(int argc, char **argv) {
 		{"rg-lb", required_argument, 0, RG0 + 6}, {"rg-pg", required_argument, 0, RG0 + 7}, {"rg-pi", required_argument, 0, RG0 + 8},
 		{"rg-pl", required_argument, 0, RG0 + 9}, {"rg-pu", required_argument, 0, RG0 + 10}, {"rg-sm", required_argument, 0, RG0 + 11},
 		{"fast-pairing", no_argument, 0, UNSUPPORTED}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
-		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, UNSUPPORTED}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
+		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, BAMOUT}, {"workers", required_argument, 0, WORKERS}, {"serial-reader", no_argument, 0, SERIAL}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
 		{"slam-seq", required_argument, 0, UNSUPPORTED}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
 		{"argos", no_argument, 0, UNSUPPORTED}, {"vcf", required_argument, 0, UNSUPPORTED}, {"config", required_argument, 0, UNSUPPORTED},
 		{0, 0, 0, 0}};
@@ -135,7 +166,13 @@ Opts parse(int argc, char **argv) {
 		case PEDELIM: o.pe_delimiter = optarg[0]; break;
 		case 'o': o.out = optarg; break;
 		case 't': break;  // host threads follow the machine (NGM_HIP_HOST_THREADS)
-		case 'g': break;  // the GPU is not optional here
+		case 'g':  // "-g" or "-g 0,1,..." (optional list without '=', src/config/Config.cpp:624-647); the GPU is not optional here
+			if (optind < argc && argv[optind][0] >= '0' && argv[optind][0] <= '9') {
+				o.devices.clear();
+				for (const char *p = argv[optind]; *p;) { o.devices.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+				++optind;
+			}
+			break;
 		case 's': o.sensitivity = (float) atof(optarg); break;
 		case 'k': o.kmer = atoi(optarg); break;
 		case KSKIP: o.kmer_skip = atoi(optarg); break;
@@ -167,7 +204,10 @@ Opts parse(int argc, char **argv) {
 		case FAST: o.fast = 1; break;
 		case SENS: o.sensitive = 1; break;
 		case VSENS: o.very_sensitive = 1; break;
-		case DEVICE: o.device = atoi(optarg); break;
+		case DEVICE: o.device = atoi(optarg); o.devices.assign(1, o.device); break;
+		case BAMOUT: o.bam = 1; break;
+		case WORKERS: o.workers = std::max(1, atoi(optarg)); break;
+		case SERIAL: o.serial_reader = 1; break;
 		case BATCH: o.batch = std::max(1024, atoi(optarg)); break;
 		case VARIANT: o.variant = atoi(optarg) ? NGM_VARIANT_OCL_CPU : NGM_VARIANT_OCL_GPU; break;
 		case UNSUPPORTED: die(std::string("option --") + lo[idx].name + " is not supported by the HIP backend yet");
@@ -183,17 +223,143 @@ Opts parse(int argc, char **argv) {
 	if (o.gap_read < 0) o.gap_read = o.affine ? 33 : 20;
 	if (o.gap_ref < 0) o.gap_ref = o.affine ? 33 : 20;
 	if (o.gap_extend < 0) o.gap_extend = o.affine ? 3 : 5;
+	if (o.devices.empty()) o.devices.assign(1, o.device);
+	o.device = o.devices[0];
+	if (getenv("NGM_HIP_WORKERS")) o.workers = std::max(1, atoi(getenv("NGM_HIP_WORKERS")));
+	if (getenv("NGM_HIP_SERIAL_READER")) o.serial_reader = 1;
 	return o;
 }
 
-void pack_row(const Read &r, int q, char *row) {  // IParser.h:59-121
+// ---- input: records as views into the mapped file (plain FASTQ) or into storage owned by the batch (serial reader) ----
+struct Rec { const char *name; const char *seq; const char *qual; uint32_t name_len, seq_len, qual_len; };
+
+inline void pack_row_view(const char *seq, size_t len, int q, char *row) {  // IParser.h:59-121
 	memset(row, 0, q);
-	if (r.seq.empty()) { row[0] = 'N'; return; }
-	const int L = (int) std::min<size_t>(r.seq.size(), (size_t) q - 1);
+	if (len == 0) { row[0] = 'N'; return; }
+	const int L = (int) std::min<size_t>(len, (size_t) q - 1);
 	for (int i = 0; i < L; ++i) {
-		const char c = (char) toupper((unsigned char) r.seq[i]);
+		const char c = (char) (seq[i] & 0xDF);  // toupper for letters
 		row[i] = (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N';
 	}
+}
+void pack_row(const Read &r, int q, char *row) { pack_row_view(r.seq.data(), r.seq.size(), q, row); }
+
+// a whole file mapped read-only; plain() = not gzip and made of 4-line FASTQ records (checked on the first records)
+struct MappedFile {
+	const char *p = nullptr;
+	size_t n = 0;
+	int fd = -1;
+	bool open(const char *path) {
+		fd = ::open(path, O_RDONLY);
+		if (fd < 0) return false;
+		struct stat st;
+		if (fstat(fd, &st) != 0 || st.st_size == 0) return false;
+		n = (size_t) st.st_size;
+		void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (m == MAP_FAILED) { p = nullptr; return false; }
+		p = (const char *) m;
+		madvise(m, n, MADV_SEQUENTIAL);
+		return true;
+	}
+	~MappedFile() { if (p) munmap((void *) p, n); if (fd >= 0) close(fd); }
+	// one 4-line record starting at `at`: sets the views, returns the offset of the next record, or 0 if malformed
+	size_t record(size_t at, Rec &r) const {
+		const char *b = p + at, *end = p + n;
+		if (at >= n || *b != '@') return 0;
+		const char *e0 = (const char *) memchr(b, '\n', end - b);
+		if (!e0) return 0;
+		const char *s = e0 + 1;
+		const char *e1 = s < end ? (const char *) memchr(s, '\n', end - s) : nullptr;
+		if (!e1) return 0;
+		const char *pl = e1 + 1;
+		if (pl >= end || *pl != '+') return 0;
+		const char *e2 = (const char *) memchr(pl, '\n', end - pl);
+		if (!e2) return 0;
+		const char *ql = e2 + 1;
+		const char *e3 = ql <= end ? (const char *) memchr(ql, '\n', end - ql) : nullptr;
+		const char *qe = e3 ? e3 : end;  // the last line may lack its line end
+		auto trim = [](const char *a, const char *z) { while (z > a && z[-1] == '\r') --z; return (uint32_t) (z - a); };
+		const char *nm = b + 1;
+		uint32_t nl = 0;
+		const uint32_t hl = trim(nm, e0);
+		while (nl < hl && nm[nl] != ' ' && nm[nl] != '\t') ++nl;  // kseq: name = header up to the first white space
+		r.name = nm; r.name_len = nl; r.seq = s; r.seq_len = trim(s, e1); r.qual = ql; r.qual_len = trim(ql, qe);
+		return (size_t) ((e3 ? e3 + 1 : end) - p);
+	}
+	bool plain_fastq() const {
+		if (n < 2 || ((unsigned char) p[0] == 0x1f && (unsigned char) p[1] == 0x8b)) return false;
+		size_t at = 0;
+		Rec r;
+		for (int i = 0; i < 1000 && at < n; ++i) {
+			const size_t nx = record(at, r);
+			if (!nx || r.qual_len != r.seq_len) return false;
+			at = nx;
+		}
+		return true;
+	}
+};
+
+// ---- a batch on its way through the pipeline -------------------------------------------------------------------------
+struct Batch {
+	uint64_t seq = 0;
+	int n = 0;
+	// plain input: byte offsets of every kSub-th record in file 0 / file 1 (two-file paired input: records alternate)
+	std::vector<size_t> sub0, sub1;
+	int n0 = 0, n1 = 0;                 // records from file 0 / file 1
+	std::vector<Read> owned;            // serial reader: the records themselves
+	std::vector<Rec> recs;
+	std::vector<std::string> chunks;    // formatted output, in order
+	size_t n_total = 0, n_mapped = 0, n_written = 0;
+};
+constexpr int kSub = 4096;
+
+template <typename T>
+class BoundedQueue {
+public:
+	explicit BoundedQueue(size_t cap) : cap_(cap) {}
+	void push(T v) {
+		std::unique_lock<std::mutex> lk(mu_);
+		cv_push_.wait(lk, [&] { return q_.size() < cap_; });
+		q_.push_back(std::move(v));
+		cv_pop_.notify_one();
+	}
+	bool pop(T &v) {  // false: closed and drained
+		std::unique_lock<std::mutex> lk(mu_);
+		cv_pop_.wait(lk, [&] { return !q_.empty() || closed_; });
+		if (q_.empty()) return false;
+		v = std::move(q_.front());
+		q_.pop_front();
+		cv_push_.notify_one();
+		return true;
+	}
+	void close() { { std::lock_guard<std::mutex> lk(mu_); closed_ = true; } cv_pop_.notify_all(); }
+private:
+	std::mutex mu_;
+	std::condition_variable cv_push_, cv_pop_;
+	std::deque<T> q_;
+	size_t cap_;
+	bool closed_ = false;
+};
+
+// ---- SAM text, appended to a std::string (no stdio in the hot loop) -----------------------------------------------
+inline void put_u64(std::string &s, unsigned long long v) {
+	char b[24];
+	int i = 24;
+	do { b[--i] = (char) ('0' + v % 10); v /= 10; } while (v);
+	s.append(b + i, 24 - i);
+}
+inline void put_i64(std::string &s, long long v) { if (v < 0) { s.push_back('-'); put_u64(s, (unsigned long long) (-(v + 1)) + 1ull); } else put_u64(s, (unsigned long long) v); }
+// printf("%g") of roundf(identity * 10000) / 10000 (SAMWriter.cpp:163): at most four decimals, trailing zeros dropped
+inline void put_identity(std::string &s, float identity) {
+	const float r = roundf(identity * 10000.0f);
+	if (!(r >= 0.0f && r <= 10000.0f)) { char b[32]; const int k = snprintf(b, sizeof(b), "%g", r / 10000.0f); s.append(b, k); return; }
+	const int iv = (int) r;
+	if (iv == 10000) { s.push_back('1'); return; }
+	if (iv == 0) { s.push_back('0'); return; }
+	char b[6] = {'0', '.', (char) ('0' + iv / 1000), (char) ('0' + iv / 100 % 10), (char) ('0' + iv / 10 % 10), (char) ('0' + iv % 10)};
+	int k = 6;
+	while (b[k - 1] == '0') --k;
+	s.append(b, k);
 }
 
 }  // namespace
@@ -223,16 +389,32 @@ int main(int argc, char **argv) {
 	size_t max_len = 0, min_len = 9999999, sum_len = 0, count = 0;
 	std::vector<Read> sample;
 	{
-		SeqReader in(first_input.c_str());
-		if (!in.ok()) die("cannot open " + first_input);
-		Read r;
+		// reads without a sequence are not counted (parseRead returns 0 for them: the `if (l > 0)` of ReadProvider.cpp:236)
 		bool finish = false;
-		while (!finish && in.next(r)) {
-			const size_t len = r.seq.empty() ? 1 : std::min<size_t>(r.seq.size(), 9999);
+		auto account = [&](size_t seq_len) -> bool {  // true: keep this read for the sensitivity sample
+			if (seq_len == 0) return false;
+			const size_t len = std::min<size_t>(seq_len, 9999);
 			max_len = std::max(max_len, len); min_len = std::min(min_len, len); sum_len += len;
 			++count;
-			if (count % 1000 == 0 && count < 10000000) sample.push_back(r);
-			else if (count == 10000001) { if (max_len - min_len >= 10) max_len = (size_t) (max_len * 1.1f); finish = true; }
+			if (count % 1000 == 0 && count < 10000000) return true;
+			if (count == 10000001) { if (max_len - min_len >= 10) max_len = (size_t) (max_len * 1.1f); finish = true; }
+			return false;
+		};
+		MappedFile pf;
+		if (!o.serial_reader && pf.open(first_input.c_str()) && pf.plain_fastq()) {
+			Rec rec;
+			for (size_t at = 0; !finish && at < pf.n;) {
+				const size_t nx = pf.record(at, rec);
+				if (!nx) die("malformed FASTQ record at byte " + std::to_string(at) + " of " + first_input + " (--serial-reader reads multi-line input)");
+				if (rec.qual_len != rec.seq_len) die("Error while parsing read: sequence and quality lengths differ (" + std::string(rec.name, rec.name_len) + ")");
+				at = nx;
+				if (account(rec.seq_len)) sample.push_back(Read{std::string(rec.name, rec.name_len), std::string(rec.seq, rec.seq_len), std::string()});
+			}
+		} else {
+			SeqReader in(first_input.c_str());
+			if (!in.ok()) die("cannot open " + first_input);
+			Read r;
+			while (!finish && in.next(r)) if (account(r.seq.size())) sample.push_back(r);
 		}
 	}
 	if (count == 0) die("No reads found in input file.");
@@ -298,101 +480,126 @@ int main(int argc, char **argv) {
 	else if (!estimated) info("INPUT", "Sensitivity parameter neither set nor estimated. Falling back to default.");
 	mp.sensitivity = sens;
 
-	ngm_mapper *m = ngm_mapper_create(ref, &mp);
-	if (!m) die(ngm_pipeline_last_error());
 
+	// ---- output ------------------------------------------------------------------------------------------------------
 	FILE *out = fopen(o.out.c_str(), "w");
 	if (!out) die("cannot write " + o.out);
-	std::vector<char> obuf(1 << 24);
-	setvbuf(out, obuf.data(), _IOFBF, obuf.size());
-	fprintf(out, "@HD\tVN:1.0\tSO:unsorted\n");
-	for (int i = 0; i < ngm_ref_contig_count(ref); ++i)
-		fprintf(out, "@SQ\tSN:%s\tLN:%llu\n", ngm_ref_contig_name(ref, i), (unsigned long long) ngm_ref_contig_len(ref, i));
-	fprintf(out, "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"%s\"\n", o.cmdline.c_str());
-	if (!o.rg[0].empty()) {  // SAMWriter.cpp:46-80
-		static const char *tag[12] = {"ID", "CN", "DS", "DT", "FO", "KS", "LB", "PG", "PI", "PL", "PU", "SM"};
-		fprintf(out, "@RG\tID:%s", o.rg[0].c_str());
-		for (int t = 1; t < 12; ++t) if (!o.rg[t].empty()) fprintf(out, "\t%s:%s", tag[t], o.rg[t].c_str());
-		fprintf(out, "\n");
+	setvbuf(out, nullptr, _IONBF, 0);  // whole batches are written at once
+	{
+		std::string h = "@HD\tVN:1.0\tSO:unsorted\n";
+		for (int i = 0; i < ngm_ref_contig_count(ref); ++i) { h += "@SQ\tSN:"; h += ngm_ref_contig_name(ref, i); h += "\tLN:"; put_u64(h, ngm_ref_contig_len(ref, i)); h += "\n"; }
+		h += "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"" + o.cmdline + "\"\n";
+		if (!o.rg[0].empty()) {  // SAMWriter.cpp:46-80
+			static const char *tag[12] = {"ID", "CN", "DS", "DT", "FO", "KS", "LB", "PG", "PI", "PL", "PU", "SM"};
+			h += "@RG\tID:" + o.rg[0];
+			for (int t = 1; t < 12; ++t) if (!o.rg[t].empty()) { h += "\t"; h += tag[t]; h += ":" + o.rg[t]; }
+			h += "\n";
+		}
+		fwrite(h.data(), 1, h.size(), out);
 	}
 	const std::string rg_mapped = o.rg[0].empty() ? std::string() : "RG:Z:" + o.rg[0] + "\t";
 	const std::string rg_unmapped = o.rg[0].empty() ? std::string() : "\tRG:Z:" + o.rg[0];
-
-	// ---- pass 2: map in batches ------------------------------------------------------------------------------
-	std::vector<Read> batch;
-	std::vector<char> rows, cig, md;
-	std::vector<ngm_hit> hits;
-	size_t n_total = 0, n_mapped = 0, n_written = 0;
 	const size_t stride = (size_t) 4 * q;
 	const int max_insert = o.max_insert > 0 ? o.max_insert : 2147483647;
-
-	struct View { const Read *r; const ngm_hit *h; const char *row; int L; const char *cigar, *md; };
 	const int topn = o.paired ? 1 : o.topn;
-	auto view = [&](int i, int t = 0) {
-		const size_t e = (size_t) i * topn + t;
-		View v{&batch[i], &hits[e], &rows[(size_t) i * q], 0, &cig[e * stride], &md[e * stride]};
-		v.L = (int) strnlen(v.row, q);
-		return v;
-	};
+	std::vector<std::string> contig_names;
+	for (int i = 0; i < ngm_ref_contig_count(ref); ++i) contig_names.push_back(ngm_ref_contig_name(ref, i));
+
+	// ---- the references / mappers: one reference per GPU (the first one exists), `workers` mappers per GPU ---------------
+	std::vector<ngm_ref *> refs(1, ref);
+	for (size_t d = 1; d < o.devices.size(); ++d) {
+		ngm_ref *r2 = ngm_ref_create_from_fasta(o.devices[d], &rp, o.ref.c_str());  // the cache written above loads in seconds
+		if (!r2) die(ngm_pipeline_last_error());
+		refs.push_back(r2);
+	}
+	ngm_pair_state *pair_state = ngm_pair_state_create();
+	struct Worker { ngm_mapper *m = nullptr; char *rows = nullptr; size_t rows_cap = 0; std::vector<ngm_hit> hits; std::vector<char> cig, md; };
+	std::vector<Worker> workers(o.devices.size() * (size_t) o.workers);
+	for (size_t w = 0; w < workers.size(); ++w) {
+		workers[w].m = ngm_mapper_create(refs[w % refs.size()], &mp);
+		if (!workers[w].m) die(ngm_pipeline_last_error());
+		ngm_mapper_set_pair_state(workers[w].m, pair_state);
+	}
+
+	// ---- the record -> SAM line code (SAMWriter::DoWriteReadGeneric, SAMWriter.cpp:98-228) -----------------------------
+	struct View { const Rec *r; const ngm_hit *h; const char *row; int L; const char *cigar, *md; };
 	auto passes = [&](const View &v) {  // GenericReadWriter.h:205-215, :262-273
 		float min_res = o.min_residues;
 		if (min_res <= 1.0f) min_res = v.L * min_res;
 		return v.h->mapped && v.h->mapq >= o.min_mq && v.h->identity >= o.min_identity && (float) (v.L - v.h->qstart - v.h->qend) >= min_res;
 	};
-	// SAMWriter::DoWriteReadGeneric (SAMWriter.cpp:98-228)
-	auto write_mapped = [&](const View &v, int flags, const char *rnext, unsigned long long pnext, long long tlen) {
+	auto write_mapped = [&](std::string &s, size_t &n_written, const View &v, int flags, const char *rnext, unsigned long long pnext, long long tlen) {
 		const ngm_hit &h = *v.h;
 		const int L = v.L;
-		const bool noq = v.r->qual.empty();
-		std::string seq(v.row, L), ql = noq ? std::string("*") : v.r->qual.substr(0, L);
-		if (h.reverse) {
-			flags |= 0x10;
-			for (int t = 0; t < L; ++t) { const char ch = v.row[L - 1 - t]; seq[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch; }
-			if (!noq) std::reverse(ql.begin(), ql.end());
-		}
+		const bool noq = v.r->qual_len == 0;
+		if (h.reverse) flags |= 0x10;
 		const bool clip = o.hard_clip || o.silent_clip;
 		const int s0 = clip ? h.qstart : 0, sl = clip ? L - h.qstart - h.qend : L;
-		const float identity = roundf(h.identity * 10000.0f) / 10000.0f;
-		fprintf(out, "%s\t%d\t%s\t%llu\t%d\t%s\t%s\t%llu\t%lld\t%.*s\t%.*s\t%sAS:i:%d\tNM:i:%d\tNH:i:%d\tXI:f:%g\tX0:i:%d\tXE:i:%d\tXR:i:%d\tMD:Z:%s\n",
-				v.r->name.c_str(), flags, ngm_ref_contig_name(ref, h.contig), (unsigned long long) h.pos + 1, h.mapq, v.cigar, rnext, pnext, tlen,
-				sl, seq.c_str() + s0, noq ? 1 : sl, noq ? "*" : ql.c_str() + s0, rg_mapped.c_str(),
-				(int) h.score, h.nm, h.n_best, identity, h.n_best, (int) h.max_votes, L - h.qstart - h.qend, v.md);
+		s.append(v.r->name, v.r->name_len); s.push_back('\t'); put_u64(s, (unsigned) flags); s.push_back('\t');
+		s += contig_names[h.contig]; s.push_back('\t'); put_u64(s, (unsigned long long) h.pos + 1); s.push_back('\t'); put_i64(s, h.mapq); s.push_back('\t');
+		s += v.cigar; s.push_back('\t'); s += rnext; s.push_back('\t'); put_u64(s, pnext); s.push_back('\t'); put_i64(s, tlen); s.push_back('\t');
+		const size_t at = s.size();
+		if (sl > 0) {
+			s.resize(at + sl);
+			if (!h.reverse) memcpy(&s[at], v.row + s0, sl);
+			else for (int t = 0; t < sl; ++t) { const char ch = v.row[L - 1 - (s0 + t)]; s[at + t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch; }
+		}
+		s.push_back('\t');
+		if (noq) s.push_back('*');
+		else if (sl > 0) {
+			// the quality string as the reference holds it: the first L characters (IParser.h copies qry_max_len - 1 at most)
+			const int QL = std::min<int>((int) v.r->qual_len, L);
+			const size_t aq = s.size();
+			const int take = std::max(0, std::min(sl, QL - s0));
+			s.resize(aq + take);
+			if (!h.reverse) memcpy(&s[aq], v.r->qual + s0, take);
+			else for (int t = 0; t < take; ++t) s[aq + t] = v.r->qual[QL - 1 - (s0 + t)];
+		}
+		s.push_back('\t');
+		s += rg_mapped;
+		s += "AS:i:"; put_i64(s, (int) h.score); s += "\tNM:i:"; put_i64(s, h.nm); s += "\tNH:i:"; put_i64(s, h.n_best); s += "\tXI:f:"; put_identity(s, h.identity);
+		s += "\tX0:i:"; put_i64(s, h.n_best); s += "\tXE:i:"; put_i64(s, (int) h.max_votes); s += "\tXR:i:"; put_i64(s, L - h.qstart - h.qend); s += "\tMD:Z:"; s += v.md;
+		s.push_back('\n');
 		++n_written;
 	};
 	// SAMWriter::DoWriteUnmappedReadGeneric (SAMWriter.cpp:311-372): contig < 0 prints '*'
-	auto write_unmapped = [&](const View &v, int flags, int contig, unsigned long long pos1, char rnext, unsigned long long pnext1) {
+	auto write_unmapped = [&](std::string &s, size_t &n_written, const View &v, int flags, int contig, unsigned long long pos1, char rnext, unsigned long long pnext1) {
 		if (o.no_unal) return;
-		const bool noq = v.r->qual.empty();
-		const int ql = noq ? 1 : std::min<int>((int) v.r->qual.size(), v.L);
-		fprintf(out, "%s\t%d\t%s\t%llu\t0\t*\t%c\t%llu\t0\t%.*s\t%.*s%s\n", v.r->name.c_str(), flags | 0x4, contig >= 0 ? ngm_ref_contig_name(ref, contig) : "*",
-				pos1, rnext, pnext1, v.L, v.row, ql, noq ? "*" : v.r->qual.c_str(), rg_unmapped.c_str());
+		const bool noq = v.r->qual_len == 0;
+		s.append(v.r->name, v.r->name_len); s.push_back('\t'); put_u64(s, (unsigned) (flags | 0x4)); s.push_back('\t');
+		if (contig >= 0) s += contig_names[contig]; else s.push_back('*');
+		s.push_back('\t'); put_u64(s, pos1); s += "\t0\t*\t"; s.push_back(rnext); s.push_back('\t'); put_u64(s, pnext1); s += "\t0\t";
+		s.append(v.row, v.L); s.push_back('\t');
+		if (noq) s.push_back('*'); else s.append(v.r->qual, std::min<int>((int) v.r->qual_len, v.L));
+		s += rg_unmapped;
+		s.push_back('\n');
 		++n_written;
 	};
-
-	auto flush = [&]() {
-		const int n = (int) batch.size();
-		if (n == 0) return;
-		rows.assign((size_t) n * q, 0);
-		for (int i = 0; i < n; ++i) pack_row(batch[i], q, &rows[(size_t) i * q]);
-		hits.resize((size_t) n * topn); cig.resize((size_t) n * topn * stride); md.resize((size_t) n * topn * stride);
-		const int rc = o.paired ? ngm_mapper_map_pe(m, n, rows.data(), hits.data(), cig.data(), md.data())
-		                        : ngm_mapper_map_se(m, n, rows.data(), hits.data(), cig.data(), md.data());
-		if (rc < 0) die(ngm_pipeline_last_error());
+	// one worker's batch, records [lo, hi) (paired: lo and hi even) -> SAM text + counters
+	auto format_range = [&](const Batch &b, const Worker &w, int lo, int hi, std::string &s, size_t &n_total, size_t &n_mapped, size_t &n_written) {
+		auto view = [&](int i, int t = 0) {
+			const size_t e = (size_t) i * topn + t;
+			View v{&b.recs[i], &w.hits[e], w.rows + (size_t) i * q, 0, &w.cig[e * stride], &w.md[e * stride]};
+			v.L = (int) strnlen(v.row, q);
+			return v;
+		};
+		s.reserve((size_t) (hi - lo) * (size_t) (2 * q + 160));
 		if (!o.paired) {
-			for (int i = 0; i < n; ++i) {
+			std::vector<std::tuple<int, unsigned long long, int>> seen;
+			for (int i = lo; i < hi; ++i) {
 				const View v = view(i);
-				if (v.r->seq.empty()) continue;  // NGMNames::Empty reads are discarded (GenericReadWriter.h:245-247)
+				if (v.r->seq_len == 0) continue;  // NGMNames::Empty reads are discarded (GenericReadWriter.h:245-247)
 				++n_total;
 				if (topn == 1) {
-					if (!passes(v)) { write_unmapped(v, 0, -1, 0, '*', 0); continue; }
+					if (!passes(v)) { write_unmapped(s, n_written, v, 0, -1, 0, '*', 0); continue; }
 					++n_mapped;
-					write_mapped(v, 0, "*", 0, 0);
+					write_mapped(s, n_written, v, 0, "*", 0, 0);
 					continue;
 				}
 				// GenericReadWriter::WriteRead with several alignments (GenericReadWriter.h:199-243): every alignment that
 				// passes the filters, one record per distinct location, 0x100 on all but candidate 0
 				bool once = false;
-				std::vector<std::tuple<int, unsigned long long, int>> seen;
+				seen.clear();
 				for (int t = 0; t < topn; ++t) {
 					const View vt = view(i, t);
 					if (!passes(vt)) continue;
@@ -400,88 +607,261 @@ int main(int argc, char **argv) {
 					const auto key = std::make_tuple(vt.h->contig, (unsigned long long) vt.h->pos, vt.h->reverse);
 					if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
 					seen.push_back(key);
-					write_mapped(vt, t ? 0x100 : 0, "*", 0, 0);
+					write_mapped(s, n_written, vt, t ? 0x100 : 0, "*", 0, 0);
 				}
-				if (once) ++n_mapped; else write_unmapped(v, 0, -1, 0, '*', 0);
+				if (once) ++n_mapped; else write_unmapped(s, n_written, v, 0, -1, 0, '*', 0);
 			}
+			return;
+		}
+		for (int i = lo; i + 1 < hi; i += 2) {
+			// read1 = the first mate (even ReadId), written second by AlignmentBuffer::WriteRead; read2 = its mate
+			const View v1 = view(i), v2 = view(i + 1);
+			if (v1.r->seq_len == 0 || v2.r->seq_len == 0) continue;  // GenericReadWriter.h:250-252
+			n_total += 2;
+			const ngm_hit &h1 = *v1.h, &h2 = *v2.h;
+			// AlignmentBuffer::WriteRead (AlignmentBuffer.cpp:175-199): is the pair consistent?
+			bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
+			if (h1.mapped && h2.mapped) {
+				const long long distance = (h2.pos > h1.pos) ? (long long) (h2.pos - h1.pos) + v1.L : (long long) (h1.pos - h2.pos) + v2.L;
+				if (h1.contig != h2.contig || distance < o.min_insert || distance > max_insert || h1.reverse == h2.reverse) paired_fail = true;
+			}
+			const bool m1 = passes(v1), m2 = passes(v2);  // GenericReadWriter::WritePair
+			n_mapped += (m1 ? 1 : 0) + (m2 ? 1 : 0);
+			const int f1 = 0x1 | 0x40, f2 = 0x1 | 0x80;  // SAMWriter::DoWritePair (SAMWriter.cpp:230-310)
+			const unsigned long long p1 = h1.pos + 1, p2 = h2.pos + 1;
+			if (!m1 && !m2) {
+				write_unmapped(s, n_written, v2, f2 | 0x8, -1, 0, '*', 0);
+				write_unmapped(s, n_written, v1, f1 | 0x8, -1, 0, '*', 0);
+			} else if (!m1) {
+				write_mapped(s, n_written, v2, f2 | 0x8, "=", p2, 0);
+				write_unmapped(s, n_written, v1, f1, h2.contig, p2, '=', p2);
+			} else if (!m2) {
+				write_unmapped(s, n_written, v2, f2, h1.contig, p1, '=', p1);
+				write_mapped(s, n_written, v1, f1 | 0x8, "=", p1, 0);
+			} else if (!paired_fail) {
+				if (!h1.reverse) {
+					const long long d = ((long long) h2.pos + v2.L - h2.qstart - h2.qend) - (long long) h1.pos;
+					write_mapped(s, n_written, v2, f2 | 0x2, "=", p1, -d);
+					write_mapped(s, n_written, v1, f1 | 0x2 | 0x20, "=", p2, d);
+				} else if (!h2.reverse) {
+					const long long d = ((long long) h1.pos + v1.L - h1.qstart - h1.qend) - (long long) h2.pos;
+					write_mapped(s, n_written, v2, f2 | 0x2 | 0x20, "=", p1, d);
+					write_mapped(s, n_written, v1, f1 | 0x2, "=", p2, -d);
+				}
+			} else {
+				write_mapped(s, n_written, v2, f2 | (h1.reverse ? 0x20 : 0), contig_names[h1.contig].c_str(), p1, 0);
+				write_mapped(s, n_written, v1, f1 | (h2.reverse ? 0x20 : 0), contig_names[h2.contig].c_str(), p2, 0);
+			}
+		}
+	};
+
+	// ---- the pipeline ---------------------------------------------------------------------------------------------
+	const auto t_start = std::chrono::steady_clock::now();
+	ngm::ThreadPool &pool = ngm::ThreadPool::instance();
+	BoundedQueue<std::unique_ptr<Batch>> q_in(workers.size() + 2);
+	std::mutex out_mu;
+	std::condition_variable out_cv;
+	std::map<uint64_t, std::unique_ptr<Batch>> out_ready;
+	bool workers_done = false;
+	std::atomic<bool> failed{false};
+	std::string fail_msg;
+	std::mutex fail_mu;
+	auto fail = [&](const std::string &m2) { std::lock_guard<std::mutex> lk(fail_mu); if (!failed.exchange(true)) fail_msg = m2; };
+
+	const bool interleaved = o.paired && !o.qry.empty();  // ReadProvider::GenerateRead (ReadProvider.cpp:526-584)
+	const std::string path0 = o.paired ? (interleaved ? o.qry : o.qry1) : o.qry, path1 = (o.paired && !interleaved) ? o.qry2 : std::string();
+	MappedFile mf0, mf1;
+	bool plain = !o.serial_reader && mf0.open(path0.c_str()) && mf0.plain_fastq();
+	if (plain && !path1.empty()) plain = mf1.open(path1.c_str()) && mf1.plain_fastq();
+	const int batch_reads = o.paired ? (o.batch & ~1) : o.batch;
+
+	auto strip_mate = [&](const char *name, uint32_t &len) {  // ReadProvider::NextRead (ReadProvider.cpp:419-422)
+		if (len >= 2 && name[len - 2] == o.pe_delimiter) len -= 2;
+	};
+
+	std::thread splitter([&] {
+		uint64_t seq = 0;
+		if (plain) {
+			// record boundaries by counting line ends; every kSub-th record offset is kept so that the batch can be parsed in parallel
+			size_t at0 = 0, at1 = 0;
+			const bool two = !path1.empty();
+			const int per_file = two ? batch_reads / 2 : batch_reads;
+			auto skip = [&](const MappedFile &f, size_t &at, int want, std::vector<size_t> &sub) -> int {
+				int got = 0;
+				const char *end = f.p + f.n;
+				while (got < want && at < f.n) {
+					if ((got % kSub) == 0) sub.push_back(at);
+					const char *c = f.p + at;
+					if (*c != '@') { fail("malformed FASTQ record at byte " + std::to_string(at) + " (4-line records expected; --serial-reader reads multi-line input)"); return -1; }
+					for (int l = 0; l < 4 && c; ++l) { c = (const char *) memchr(c, '\n', end - c); if (c) ++c; else if (l == 3) c = end; }
+					if (!c) { fail("truncated FASTQ record at byte " + std::to_string(at)); return -1; }
+					at = (size_t) (c - f.p);
+					++got;
+				}
+				sub.push_back(at);  // end of the last sub-range
+				return got;
+			};
+			while (!failed && (at0 < mf0.n)) {
+				auto b = std::make_unique<Batch>();
+				b->seq = seq++;
+				b->n0 = skip(mf0, at0, per_file, b->sub0);
+				if (b->n0 < 0) break;
+				if (two) {
+					b->n1 = skip(mf1, at1, b->n0, b->sub1);
+					if (b->n1 < 0) break;
+					if (b->n1 != b->n0) { fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode."); break; }
+				}
+				b->n = b->n0 + b->n1;
+				if (o.paired && (b->n & 1)) { fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode."); break; }
+				q_in.push(std::move(b));
+			}
+			if (!failed && two && at1 < mf1.n) fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode.");
 		} else {
-			for (int i = 0; i + 1 < n; i += 2) {
-				// read1 = the first mate (even ReadId), written second by AlignmentBuffer::WriteRead; read2 = its mate
-				const View v1 = view(i), v2 = view(i + 1);
-				if (v1.r->seq.empty() || v2.r->seq.empty()) continue;  // GenericReadWriter.h:250-252
-				n_total += 2;
-				const ngm_hit &h1 = *v1.h, &h2 = *v2.h;
-				// AlignmentBuffer::WriteRead (AlignmentBuffer.cpp:175-199): is the pair consistent?
-				bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
-				if (h1.mapped && h2.mapped) {
-					const long long distance = (h2.pos > h1.pos) ? (long long) (h2.pos - h1.pos) + v1.L : (long long) (h1.pos - h2.pos) + v2.L;
-					if (h1.contig != h2.contig || distance < o.min_insert || distance > max_insert || h1.reverse == h2.reverse) paired_fail = true;
-				}
-				const bool m1 = passes(v1), m2 = passes(v2);  // GenericReadWriter::WritePair
-				n_mapped += (m1 ? 1 : 0) + (m2 ? 1 : 0);
-				const int f1 = 0x1 | 0x40, f2 = 0x1 | 0x80;  // SAMWriter::DoWritePair (SAMWriter.cpp:230-310)
-				const unsigned long long p1 = h1.pos + 1, p2 = h2.pos + 1;
-				if (!m1 && !m2) {
-					write_unmapped(v2, f2 | 0x8, -1, 0, '*', 0);
-					write_unmapped(v1, f1 | 0x8, -1, 0, '*', 0);
-				} else if (!m1) {
-					write_mapped(v2, f2 | 0x8, "=", p2, 0);
-					write_unmapped(v1, f1, h2.contig, p2, '=', p2);
-				} else if (!m2) {
-					write_unmapped(v2, f2, h1.contig, p1, '=', p1);
-					write_mapped(v1, f1 | 0x8, "=", p1, 0);
-				} else if (!paired_fail) {
-					if (!h1.reverse) {
-						const long long d = ((long long) h2.pos + v2.L - h2.qstart - h2.qend) - (long long) h1.pos;
-						write_mapped(v2, f2 | 0x2, "=", p1, -d);
-						write_mapped(v1, f1 | 0x2 | 0x20, "=", p2, d);
-					} else if (!h2.reverse) {
-						const long long d = ((long long) h1.pos + v1.L - h1.qstart - h1.qend) - (long long) h2.pos;
-						write_mapped(v2, f2 | 0x2 | 0x20, "=", p1, d);
-						write_mapped(v1, f1 | 0x2, "=", p2, -d);
-					}
+			SeqReader in1(path0.c_str());
+			std::unique_ptr<SeqReader> in2(path1.empty() ? nullptr : new SeqReader(path1.c_str()));
+			if (!in1.ok() || (in2 && !in2->ok())) { fail(o.paired ? "cannot open the paired-end input" : "cannot open " + path0); q_in.close(); return; }
+			auto b = std::make_unique<Batch>();
+			Read a, c;
+			for (;;) {
+				if (failed) break;
+				if (!o.paired) {
+					if (!in1.next(a)) break;
+					b->owned.push_back(std::move(a));
 				} else {
-					write_mapped(v2, f2 | (h1.reverse ? 0x20 : 0), ngm_ref_contig_name(ref, h1.contig), p1, 0);
-					write_mapped(v1, f1 | (h2.reverse ? 0x20 : 0), ngm_ref_contig_name(ref, h2.contig), p2, 0);
+					const bool ha = in1.next(a), hb = ha ? (in2 ? in2->next(c) : in1.next(c)) : false;
+					if (!ha) break;
+					if (!hb) { fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode."); break; }
+					b->owned.push_back(std::move(a)); b->owned.push_back(std::move(c));
+				}
+				if ((int) b->owned.size() >= batch_reads) { b->seq = seq++; b->n = (int) b->owned.size(); q_in.push(std::move(b)); b = std::make_unique<Batch>(); }
+			}
+			if (!failed && !b->owned.empty()) { b->seq = seq++; b->n = (int) b->owned.size(); q_in.push(std::move(b)); }
+		}
+		q_in.close();
+	});
+
+	auto worker_main = [&](Worker &w) {
+		std::unique_ptr<Batch> b;
+		while (q_in.pop(b)) {
+			if (failed) { ngm_mapper_set_batch_seq(w.m, b->seq); if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
+			const int n = b->n;
+			if ((size_t) n * q > w.rows_cap) {
+				ngm_host_free(w.rows);
+				w.rows_cap = (size_t) std::max(n, batch_reads) * q;
+				w.rows = (char *) ngm_host_alloc(w.rows_cap);
+				if (!w.rows) { fail(ngm_pipeline_last_error()); w.rows_cap = 0; }
+			}
+			b->recs.resize(n);
+			std::atomic<bool> bad{false};
+			std::string bad_msg;
+			if (w.rows && !b->owned.empty()) {
+				pool.parallel_for(n, [&](int lo, int hi) {
+					for (int i = lo; i < hi; ++i) {
+						const Read &r = b->owned[i];
+						b->recs[i] = Rec{r.name.data(), r.seq.data(), r.qual.data(), (uint32_t) r.name.size(), (uint32_t) r.seq.size(), (uint32_t) r.qual.size()};
+						if (o.paired) strip_mate(b->recs[i].name, b->recs[i].name_len);
+						pack_row_view(r.seq.data(), r.seq.size(), q, w.rows + (size_t) i * q);
+					}
+				}, 4096);
+			} else if (w.rows) {
+				// plain input: sub-range s of file f holds records [s kSub, ...) of that file; record j of file f is batch record
+				// j (one file) or 2 j + f (two files)
+				const bool two = b->n1 > 0;
+				const int nsub0 = (int) b->sub0.size() - 1, nsub1 = two ? (int) b->sub1.size() - 1 : 0;
+				pool.parallel_for(nsub0 + nsub1, [&](int lo, int hi) {
+					for (int sidx = lo; sidx < hi; ++sidx) {
+						const int f = sidx < nsub0 ? 0 : 1, sl = f ? sidx - nsub0 : sidx;
+						const MappedFile &mf = f ? mf1 : mf0;
+						const std::vector<size_t> &sub = f ? b->sub1 : b->sub0;
+						const int cnt = std::min(kSub, (f ? b->n1 : b->n0) - sl * kSub);
+						size_t at = sub[sl];
+						for (int j = 0; j < cnt; ++j) {
+							const int i = two ? 2 * (sl * kSub + j) + f : sl * kSub + j;
+							Rec &r = b->recs[i];
+							const size_t nx = mf.record(at, r);
+							if (!nx) { if (!bad.exchange(true)) bad_msg = "malformed FASTQ record at byte " + std::to_string(at); return; }
+							if (r.qual_len != r.seq_len) { if (!bad.exchange(true)) bad_msg = "Error while parsing read: sequence and quality lengths differ (" + std::string(r.name, r.name_len) + ")"; return; }  // IParser.h copyToRead
+							at = nx;
+							if (o.paired) strip_mate(r.name, r.name_len);
+							pack_row_view(r.seq, r.seq_len, q, w.rows + (size_t) i * q);
+						}
+					}
+				}, 1);
+			}
+			if (bad) fail(bad_msg);
+			if (!failed && o.paired) {
+				for (int i = 0; i + 1 < n; i += 2) {
+					const Rec &a = b->recs[i], &c = b->recs[i + 1];
+					if (a.name_len != c.name_len || memcmp(a.name, c.name, a.name_len) != 0) {
+						fail("Error while reading paired end reads. Names of mates don't match: " + std::string(a.name, a.name_len) + " and " + std::string(c.name, c.name_len) + ".");
+						break;
+					}
 				}
 			}
+			ngm_mapper_set_batch_seq(w.m, b->seq);
+			if (failed) { if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
+			w.hits.resize((size_t) n * topn); w.cig.resize((size_t) n * topn * stride); w.md.resize((size_t) n * topn * stride);
+			const int rc = o.paired ? ngm_mapper_map_pe(w.m, n, w.rows, w.hits.data(), w.cig.data(), w.md.data())
+			                        : ngm_mapper_map_se(w.m, n, w.rows, w.hits.data(), w.cig.data(), w.md.data());
+			if (rc < 0) { fail(ngm_pipeline_last_error()); continue; }
+			// format: chunks of whole pairs
+			const int units = o.paired ? n / 2 : n, per = o.paired ? 2 : 1;
+			const int n_chunks = std::max(1, std::min(units / 2048 + 1, pool.size() * 2));
+			b->chunks.assign(n_chunks, std::string());
+			std::vector<size_t> ct(n_chunks, 0), cm(n_chunks, 0), cw(n_chunks, 0);
+			pool.parallel_for(n_chunks, [&](int lo, int hi) {
+				for (int c = lo; c < hi; ++c) {
+					const int u0 = (int) ((long long) units * c / n_chunks), u1 = (int) ((long long) units * (c + 1) / n_chunks);
+					format_range(*b, w, u0 * per, u1 * per, b->chunks[c], ct[c], cm[c], cw[c]);
+				}
+			}, 1);
+			for (int c = 0; c < n_chunks; ++c) { b->n_total += ct[c]; b->n_mapped += cm[c]; b->n_written += cw[c]; }
+			b->recs.clear(); b->recs.shrink_to_fit(); b->owned.clear(); b->owned.shrink_to_fit();
+			{
+				std::lock_guard<std::mutex> lk(out_mu);
+				out_ready[b->seq] = std::move(b);
+			}
+			out_cv.notify_all();
 		}
-		batch.clear();
 	};
-	auto strip_mate = [&](Read &r) {  // ReadProvider::NextRead (ReadProvider.cpp:419-422)
-		const size_t L = r.name.size();
-		if (L >= 2 && r.name[L - 2] == o.pe_delimiter) r.name.resize(L - 2);
-	};
-	if (!o.paired) {
-		SeqReader in(o.qry.c_str());
-		Read r;
-		while (in.next(r)) {
-			batch.push_back(r);
-			if ((int) batch.size() == o.batch) flush();
-		}
-	} else {
-		const bool interleaved = !o.qry.empty();  // ReadProvider::GenerateRead (ReadProvider.cpp:526-584)
-		SeqReader in1(interleaved ? o.qry.c_str() : o.qry1.c_str());
-		SeqReader *in2 = interleaved ? &in1 : new SeqReader(o.qry2.c_str());
-		if (!in1.ok() || !in2->ok()) die("cannot open the paired-end input");
-		Read a, b;
+	size_t n_total = 0, n_mapped = 0, n_written = 0;
+	std::thread writer([&] {
+		uint64_t next = 0;
 		for (;;) {
-			const bool ha = in1.next(a), hb = ha ? in2->next(b) : false;
-			if (!ha) break;
-			if (!hb) die("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode.");
-			strip_mate(a); strip_mate(b);
-			if (a.name != b.name) die("Error while reading paired end reads. Names of mates don't match: " + a.name + " and " + b.name + ".");
-			batch.push_back(a); batch.push_back(b);
-			if ((int) batch.size() >= (o.batch & ~1)) flush();
+			std::unique_ptr<Batch> b;
+			{
+				std::unique_lock<std::mutex> lk(out_mu);
+				out_cv.wait(lk, [&] { return out_ready.count(next) || workers_done; });
+				auto it = out_ready.find(next);
+				if (it == out_ready.end()) return;  // workers are done and the next batch never came (failure) or everything is written
+				b = std::move(it->second);
+				out_ready.erase(it);
+			}
+			for (const std::string &c : b->chunks) if (!c.empty() && fwrite(c.data(), 1, c.size(), out) != c.size()) fail("write error on " + o.out);
+			n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written;
+			++next;
 		}
-		if (!interleaved) delete in2;
+	});
+	{
+		std::vector<std::thread> th;
+		for (Worker &w : workers) th.emplace_back([&, pw = &w] { worker_main(*pw); });
+		for (auto &t : th) t.join();
 	}
-	flush();
+	splitter.join();
+	{ std::lock_guard<std::mutex> lk(out_mu); workers_done = true; }
+	out_cv.notify_all();
+	writer.join();
 	fclose(out);
+	if (failed) die(fail_msg);
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	snprintf(msg, sizeof(msg), "Done (%zu reads mapped (%.2f%%), %zu reads not mapped, %zu lines written)", n_mapped,
 			n_total ? 100.0 * n_mapped / n_total : 0.0, n_total - n_mapped, n_written);
 	info("MAIN", msg);
-	ngm_mapper_destroy(m);
-	ngm_ref_destroy(ref);
+	snprintf(msg, sizeof(msg), "Mapping pass: %.3f s, %.0f reads/s (%zu GPU(s) x %d worker(s), %d host threads, %s input)", secs, n_total / std::max(1e-9, secs),
+			o.devices.size(), o.workers, pool.size(), plain ? "memory-mapped plain FASTQ" : "serial reader");
+	info("MAIN", msg);
+	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); }
+	ngm_pair_state_destroy(pair_state);
+	for (ngm_ref *r2 : refs) ngm_ref_destroy(r2);
 	return 0;
 }

@@ -1,0 +1,115 @@
+// thread_pool.h -- one persistent pool of host threads per process for the per-read host stages (pair selection,
+// CIGAR / position formatting in mapper.cpp; FASTQ parsing and SAM formatting in ngm_cli.cpp).
+// NextGenMap runs these stages on its CS threads (src/NGM.cpp:232-279 hands out batches under a mutex); here a batch is
+// cut into chunks that idle pool threads pick up, several callers (mapper instances) may have loops in flight at once, and
+// the calling thread works on its own loop too, so a loop never waits for a free pool thread.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace ngm {
+
+class ThreadPool {
+public:
+	// threads: 0 = from the machine: hardware threads divided by the ranks on this node (torchrun sets LOCAL_WORLD_SIZE),
+	// NGM_HIP_HOST_THREADS overrides
+	static ThreadPool &instance() {
+		static ThreadPool pool(default_threads());
+		return pool;
+	}
+	static int default_threads() {
+		if (const char *e = getenv("NGM_HIP_HOST_THREADS")) return std::max(1, atoi(e));
+		const char *e = getenv("LOCAL_WORLD_SIZE");
+		if (!e) e = getenv("WORLD_SIZE");
+		const int ranks = std::max(1, e ? atoi(e) : 1);
+		return std::max(1, std::min(64, (int) std::thread::hardware_concurrency() / ranks));
+	}
+	int size() const { return (int) workers_.size() + 1; }
+
+	// f(lo, hi) over [0, n) in chunks of at least min_grain items; returns when all of it is done
+	template <typename F>
+	void parallel_for(int n, F &&f, int min_grain = 1024) {
+		if (n <= 0) return;
+		int chunks = std::min(size() * 4, std::max(1, n / std::max(1, min_grain)));
+		if (chunks <= 1 || workers_.empty()) { f(0, n); return; }
+		auto job = std::make_shared<Job>();
+		job->fn = [&f](int lo, int hi) { f(lo, hi); };
+		job->n = n; job->chunks = chunks; job->next.store(0); job->done.store(0);
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			jobs_.push_back(job);
+		}
+		cv_.notify_all();
+		run_chunks(*job);  // the caller helps
+		{
+			std::unique_lock<std::mutex> lk(job->mu);
+			job->cv.wait(lk, [&] { return job->done.load() == job->chunks; });
+		}
+		std::lock_guard<std::mutex> lk(mu_);
+		jobs_.erase(std::remove(jobs_.begin(), jobs_.end(), job), jobs_.end());
+	}
+
+	~ThreadPool() {
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			stop_ = true;
+		}
+		cv_.notify_all();
+		for (auto &t : workers_) t.join();
+	}
+
+private:
+	struct Job {
+		std::function<void(int, int)> fn;
+		int n = 0, chunks = 0;
+		std::atomic<int> next{0}, done{0};
+		std::mutex mu;
+		std::condition_variable cv;
+	};
+	explicit ThreadPool(int threads) {
+		for (int t = 1; t < threads; ++t) workers_.emplace_back([this] { worker(); });
+	}
+	static void run_chunks(Job &j) {
+		for (;;) {
+			const int c = j.next.fetch_add(1);
+			if (c >= j.chunks) return;
+			const int lo = (int) ((long long) j.n * c / j.chunks), hi = (int) ((long long) j.n * (c + 1) / j.chunks);
+			j.fn(lo, hi);
+			if (j.done.fetch_add(1) + 1 == j.chunks) {
+				std::lock_guard<std::mutex> lk(j.mu);
+				j.cv.notify_all();
+			}
+		}
+	}
+	void worker() {
+		for (;;) {
+			std::shared_ptr<Job> job;
+			{
+				std::unique_lock<std::mutex> lk(mu_);
+				cv_.wait(lk, [&] {
+					if (stop_) return true;
+					for (auto &j : jobs_) if (j->next.load() < j->chunks) return true;
+					return false;
+				});
+				if (stop_) return;
+				for (auto &j : jobs_) if (j->next.load() < j->chunks) { job = j; break; }
+			}
+			if (job) run_chunks(*job);
+		}
+	}
+	std::vector<std::thread> workers_;
+	std::vector<std::shared_ptr<Job>> jobs_;
+	std::mutex mu_;
+	std::condition_variable cv_;
+	bool stop_ = false;
+};
+
+}  // namespace ngm

@@ -19,7 +19,7 @@ import sqlite3, glob
 for db in sorted(glob.glob("gpurun_out/cs_pmc/g*/*.db")):
     c = sqlite3.connect(db).cursor()
     try:
-        rows = list(c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%cs_fast%' group by kernel_name, counter_name"))
+        rows = list(c.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection where kernel_name like '%cs_bucket%' group by kernel_name, counter_name"))
     except Exception as e:
         print(db, "ERR", e); continue
     for r in rows: print(r[0].split("(")[0][-40:], r[1], "%.4g" % r[2], r[3])
