@@ -15,11 +15,20 @@ bench cross-checks its SAM records against ours) or linear (NGM's default OpenCL
           one rank per GPU; every rank holds the whole genome + index in its own HBM and maps its own shard of
           reads (weak scaling, no data-path collective); ONE RCCL all-reduce sums the mapping statistics.
 
+          Rank 0 builds the genome + index once and writes NextGenMap's cache files; the other ranks load those
+          (nextgenmap_amd.sharding: shard_range / reduce_stats are the same two functions `ngm-hip` semantics follow).
+
 Prints ONE JSON line (rank 0): `roofline` describes the dominant kernel (candidate search) from HIP events
 recorded on the launch stream; `cpu_baseline` is the REAL reference program (NextGenMap's ngm-core built from
 its sources by oracle/ngm_ref.mk, --affine because the default backend needs an OpenCL CPU device) run on this
 host on a bounded sample of the same reads against the same genome (it loads the index cache files this
 library writes), or, when that binary is absent, the oracle's C restatement of the score stage only.
+`end_to_end` (N = 1, unless --no-end-to-end) is the DROP-IN measured: the `ngm-hip` program from the first input byte to
+the closed SAM file -- FASTQ parsing, H2D copies, mapping, SAM text -- on --e2e-reads reads written as two plain FASTQ
+files, index loaded from the cache files, next to `ngm-core -t <cores>` on a slice of the same files.
+
+  --stub-mapper: no GPU, no library -- the mapping call is replaced by a deterministic fake so that the N > 1 control path
+  (sharding, cache hand-over between ranks, stats all-reduce, the JSON line) runs under gloo on CPU (tests/test_sharding_gloo.py).
 """
 import argparse
 import json
@@ -66,7 +75,7 @@ def make_genome(total_bp, seed):
     return contigs
 
 
-def make_reads(contigs, n, seed, paired=False):
+def make_reads(contigs, n, seed, paired=False, subs=0.01, indel_bases=0.0):
     """uniform positions, 50 % reverse strand, 1 % substitutions, one 1-3 bp indel in 15 % of the reads (0.1 % of the
     bases).  paired: rows 2i / 2i+1 are the two ends of a fragment, insert size ~ N(350, 35), FR orientation, half of
     the fragments from the reverse strand.  Returns ([n, Q] uint8 rows, truth contig, truth pos)."""
@@ -102,9 +111,14 @@ def make_reads(contigs, n, seed, paired=False):
             p = rng.integers(0, len(contigs[k]) - READ_LEN - 8, sel.size)
             pos[sel] = p
             rows[sel, :READ_LEN] = contigs[k][p[:, None] + np.arange(READ_LEN)[None, :]]
-    sub = rng.random((n, READ_LEN)) < 0.01
+    sub = rng.random((n, READ_LEN)) < subs
     rows[:, :READ_LEN][sub] = ACGT[rng.integers(0, 4, int(sub.sum()))]
-    for i in np.nonzero(rng.random(n) < 0.15)[0]:
+    # indels: one 1-3 bp indel in 15 % of the reads (0.1 % of the bases); with indel_bases > 0 (config #5: 3 %) every read gets
+    # READ_LEN * indel_bases / 2 more of them
+    events = np.nonzero(rng.random(n) < 0.15)[0]
+    if indel_bases > 0:
+        events = np.concatenate([events, np.repeat(np.arange(n), max(1, int(round(READ_LEN * indel_bases / 2.0))))])
+    for i in events:
         a = int(rng.integers(20, READ_LEN - 20))
         L = int(rng.integers(1, 4))
         r = rows[i, :READ_LEN].copy()
@@ -134,69 +148,105 @@ def _sam_records(path, paired=False):
     return recs
 
 
-def cpu_baseline_reference(ref, rows, budget_reads, workdir, ours=None, paired=False):
-    """NextGenMap itself (ngm-core --affine, host cores) on the first `budget_reads` reads vs the same genome.
-    ours = (hits, cigar rows, contig names) of the GPU path in the affine personality: the reference's SAM records
-    are then compared with them (flag, contig, position, MAPQ, CIGAR, AS, NM)."""
+def write_fastq_pair(rows, path1, path2):
+    """rows 2i / 2i+1 -> two plain 4-line FASTQ files with fixed-width names r<8 digits>/1 and /2 (numpy, no Python loop).
+    Returns the bytes per record."""
+    n = rows.shape[0] // 2
+    idx = np.arange(n, dtype=np.int64)
+    for mate, path in ((0, path1), (1, path2)):
+        hdr = np.empty((n, 12), np.uint8)
+        hdr[:, 0] = ord("@"); hdr[:, 1] = ord("r")
+        for d in range(8):
+            hdr[:, 2 + d] = ord("0") + (idx // 10 ** (7 - d)) % 10
+        hdr[:, 10] = ord("/"); hdr[:, 11] = ord("1") + mate
+        nl = np.full((n, 1), ord("\n"), np.uint8)
+        a = np.concatenate([hdr, nl, rows[mate::2, :READ_LEN], np.frombuffer(b"\n+\n", np.uint8)[None, :].repeat(n, 0),
+                            np.full((n, READ_LEN), ord("I"), np.uint8), nl], axis=1)
+        a.tofile(path)
+    return 12 + 1 + READ_LEN + 3 + READ_LEN + 1
+
+
+def _sam_body(path):
+    out = {}
+    with open(path, "rb") as f:
+        for line in f:
+            if line[:1] == b"@":
+                continue
+            t = line.split(b"\t", 2)
+            out[(t[0], int(t[1]) & 0xC0)] = line
+    return out
+
+
+def end_to_end(ref, contigs, workdir, args, paired, affine):
+    """The drop-in, measured: `ngm-hip` from the first input byte to the closed SAM file, and NextGenMap itself on a slice."""
     import ref_files as RF
+    from nextgenmap_amd import build as B
     cores = os.cpu_count() or 1
     fa = os.path.join(workdir, "bench_ref.fa")
-    with open(fa, "w") as f:
-        f.write(">stub\nACGT\n")  # with the caches present the program only checks that the file exists
-    t = time.perf_counter()
-    ref.write_ngm_cache(fa)
-    t_cache = time.perf_counter() - t
-    n = min(budget_reads, rows.shape[0]) & ~1
-    fq, one = os.path.join(workdir, "sample.fq"), os.path.join(workdir, "one.fq")
-    qual = b"I" * READ_LEN
+    if not os.path.exists(fa):
+        with open(fa, "w") as f:
+            f.write(">stub\nACGT\n")  # with the caches present both programs only check that the file exists
+        ref.write_ngm_cache(fa)
+    n = args.e2e_reads & ~1
+    t0 = time.perf_counter()
+    rows, _, _ = make_reads(contigs, n, seed=20240602 + 3, paired=True, subs=args.subs, indel_bases=args.indel_bases)  # config #3's seed
+    f1, f2 = os.path.join(workdir, "e2e_1.fq"), os.path.join(workdir, "e2e_2.fq")
+    rec = write_fastq_pair(rows, f1, f2)
+    t_make = time.perf_counter() - t0
+    sam = os.path.join(workdir, "e2e.sam")
+    pers = ["--affine"] if affine else []
+    cmd = [B.CLI, "-r", fa, "-1", f1, "-2", f2, "-o", sam, "-s", "0.5", "--no-progress"] + pers
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    t_wall = time.perf_counter() - t0
+    log = r.stdout + r.stderr
+    if r.returncode != 0 or "Done" not in log:
+        raise RuntimeError("ngm-hip failed: " + log[-600:])
+    import re
+    m = re.search(r"Input to output: ([0-9.]+) s", log)
+    t_io = float(m.group(1)) if m else t_wall
+    out = {"reads": n, "seconds_first_input_byte_to_sam_closed": t_io, "value": n / t_io, "unit": "reads/s",
+           "process_wall_s_incl_index_load_from_cache": t_wall, "sam_bytes": os.path.getsize(sam), "fastq_bytes": 2 * (n // 2) * rec,
+           "command": " ".join(["ngm-hip"] + cmd[1:]), "cli_log_tail": [l for l in log.splitlines() if "MAIN" in l][-3:],
+           "input": "two plain FASTQ files (%d x %d bp pairs, fixed-width names), page cache warm; index from NextGenMap cache files" % (n // 2, READ_LEN),
+           "make_input_s": t_make}
+    base = None
+    if not args.no_cpu_baseline and RF.have_reference_binary() and affine:
+        ns = min(args.cpu_sample_reads, n) & ~1
+        s1, s2, o1 = os.path.join(workdir, "s_1.fq"), os.path.join(workdir, "s_2.fq"), os.path.join(workdir, "one_1.fq")
+        o2 = os.path.join(workdir, "one_2.fq")
+        for src, dst, cnt in ((f1, s1, ns // 2), (f2, s2, ns // 2), (f1, o1, 1), (f2, o2, 1)):
+            with open(src, "rb") as fi, open(dst, "wb") as fo:
+                fo.write(fi.read(cnt * rec))
+        threads = min(cores, 64)
 
-    def name(i):
-        return (b"@r%d/%d" % (i // 2, i % 2 + 1)) if paired else (b"@r%d" % i)
-    with open(fq, "wb") as f:
-        for i in range(n):
-            f.write(name(i) + b"\n" + rows[i, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
-    with open(one, "wb") as f:
-        for i in range(2):
-            f.write(name(i) + b"\n" + rows[i, :READ_LEN].tobytes() + b"\n+\n" + qual + b"\n")
-    threads = min(cores, 64)
-
-    def run(reads):
-        cmd = [RF.NGM_CORE, "-r", fa, "-q", reads, "-o", os.path.join(workdir, "ref_out.sam"), "--affine", "-t", str(threads),
-               "--no-progress", "-s", "0.5"] + (["-p"] if paired else [])
-        t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True, cwd=workdir)
-        dt = time.perf_counter() - t0
-        if "Done" not in (r.stdout + r.stderr):
-            raise RuntimeError("reference run failed: " + (r.stdout + r.stderr)[-400:])
-        return dt
-
-    t_load = run(one)   # index/genome load + start-up
-    t_all = run(fq)
-    t_map = max(t_all - t_load, 1e-3)
-    parity = None
-    if ours is not None:
-        hits, cig, names = ours
-        recs = _sam_records(os.path.join(workdir, "ref_out.sam"), paired)
-        same = same_place = cmp = 0
-        examples = []
-        for i, (flag, rname, pos, mapq, cigar, a_s, nm) in recs.items():
-            h = hits[i]
-            if (flag & 4) or not h["mapped"]:
-                continue  # the writer's identity / residue filter is not part of the timed path
-            cmp += 1
-            mine = (16 if h["reverse"] else 0, names[h["contig"]], int(h["pos"]) + 1, int(h["mapq"]),
-                    bytes(cig[i]).split(b"\0", 1)[0].decode(), str(int(h["score"])), str(int(h["nm"])))
-            same += mine == (flag & 16, rname, pos, mapq, cigar, a_s, nm)
-            if len(examples) < 3 and mine != (flag & 16, rname, pos, mapq, cigar, a_s, nm):
-                examples.append({"read": i, "ours": mine, "reference": (flag & 16, rname, pos, mapq, cigar, a_s, nm)})
-            same_place += mine[:3] == (flag & 16, rname, pos)
-        parity = {"reads_compared": cmp, "identical_records": same, "same_position": same_place, "first_differences": examples,
-                  "note": "all SAM fields compared for reads both sides report as mapped; equal scores are resolved in the reference's own candidate order (cs_order_kernel)"}
-    return {"parity_vs_reference_sam": parity, "value": n / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
-            "sample": "NextGenMap 0.5.5 ngm-core --affine " + ("-p " if paired else "") + "-t %d on the first %d reads of the step vs the same genome (index "
-                      "loaded from cache files written by this library): %.1fs total minus %.1fs index load/start-up measured "
-                      "with a 1-read run" % (threads, n, t_all, t_load),
-            "index_cache_write_s": t_cache}
+        def run(q1, q2, outp):
+            c = [RF.NGM_CORE, "-r", fa, "-1", q1, "-2", q2, "-o", outp, "--affine", "-t", str(threads), "--no-progress", "-s", "0.5"]
+            t = time.perf_counter()
+            rr = subprocess.run(c, capture_output=True, text=True, cwd=workdir)
+            dt = time.perf_counter() - t
+            if "Done" not in (rr.stdout + rr.stderr):
+                raise RuntimeError("reference run failed: " + (rr.stdout + rr.stderr)[-400:])
+            return dt
+        ref_sam = os.path.join(workdir, "ref.sam")
+        t_load = run(o1, o2, os.path.join(workdir, "one.sam"))
+        t_all = run(s1, s2, ref_sam)
+        t_map = max(t_all - t_load, 1e-3)
+        ours, theirs = _sam_body(sam), _sam_body(ref_sam)
+        same = sum(1 for k, v in theirs.items() if ours.get(k) == v)
+        diffs = [(theirs[k].decode()[:160], ours.get(k, b"").decode()[:160]) for k in theirs if ours.get(k) != theirs[k]][:2]
+        base = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
+                "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d on the first %d reads of the end-to-end input vs the same genome (index loaded "
+                          "from the same cache files): %.1f s total minus %.1f s index load/start-up measured with a 1-pair run" % (threads, ns, t_all, t_load),
+                "parity_vs_reference_sam": {"records_compared": len(theirs), "identical_lines": same, "first_differences": diffs,
+                                            "note": "whole SAM lines; the reference runs %d CS threads, each with its own running mean insert size "
+                                                    "(ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output, which is what ngm-hip reproduces" % threads}}
+    for fn in (sam, f1, f2):
+        try:
+            os.remove(fn)
+        except OSError:
+            pass
+    return out, base
 
 
 def cpu_baseline_port(rows_qry, budget_s=8.0):
@@ -225,13 +275,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome-mbp", type=float, default=3100.0, help="synthetic genome size (GRCh38 = 3100)")
     ap.add_argument("--reads-per-step", type=int, default=1 << 20, help="reads per GPU per step")
-    ap.add_argument("--cpu-sample-reads", type=int, default=200000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
     ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
     ap.add_argument("--read-len", type=int, default=150, help="read length (150: BASELINE config #2/#3; 250: config #5's shape)")
     ap.add_argument("--corridor", type=int, default=0, help="band width; 0: NextGenMap's 5 + 0.15 * read length")
     ap.add_argument("--layout", choices=["pe", "se"], default="pe", help="paired-end (BASELINE.json config #2) or single-end reads")
+    ap.add_argument("--subs", type=float, default=0.01, help="substitution rate of the simulated reads (config #5: 0.12)")
+    ap.add_argument("--indel-bases", type=float, default=0.0, help="extra share of read bases in indels (config #5: 0.03)")
+    ap.add_argument("--sensitive", action="store_true", help="config #5: sensitivity 0.5 - 0.35 * 0.5 (what --sensitive does to an estimate of 0.5)")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end ngm-hip run (BASELINE config #3: 10 000 000)")
+    ap.add_argument("--stub-mapper", action="store_true", help="CPU-only control-path run (tests)")
     args = ap.parse_args()
     global Q, C, READ_LEN
     READ_LEN = args.read_len
@@ -240,49 +296,126 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from nextgenmap_amd.pipeline import HIT_DTYPE, Mapper, Reference
+    from nextgenmap_amd import sharding
+    stub = args.stub_mapper
+    if not stub:
+        from nextgenmap_amd.pipeline import HIT_DTYPE, Mapper, Reference
+    else:
+        HIT_DTYPE = np.dtype([("mapped", np.int32), ("contig", np.int32), ("pos", np.uint64), ("reverse", np.int32), ("mapq", np.int32), ("score", np.float32),
+                              ("identity", np.float32), ("nm", np.int32), ("qstart", np.int32), ("qend", np.int32), ("n_candidates", np.int32),
+                              ("n_best", np.int32), ("max_votes", np.float32), ("pair_flags", np.int32)])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
 
     R = args.reads_per_step
-    t0 = time.perf_counter()
-    contigs = make_genome(int(args.genome_mbp * 1e6), seed=20240601)
-    t_gen = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ref = Reference.from_contigs(contigs, device=local_rank, kmer=KMER, kmer_skip=2, bin_size=2)
-    t_index = time.perf_counter() - t0
     paired = args.layout == "pe"
-    rows, truth_c, truth_p = make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank, paired=paired)  # config #2's seed, one shard per rank
-    d_rows = torch.from_numpy(rows).to(dev)
     affine = args.personality == "affine"
     band = C + 1 if affine else C  # SeqAn's band has diagonals 0..corridor
+
+    # ---- genome + index: rank 0 builds them once; the other ranks of the node load NextGenMap's cache files it writes ----
+    wd = [tempfile.mkdtemp(prefix="ngm_bench_") if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(wd, src=0)
+    workdir = wd[0]
+    fa = os.path.join(workdir, "bench_ref.fa")
+    gen_file = os.path.join(workdir, "genome.u8")
+    t_gen = t_index = 0.0
+    ref = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        contigs = make_genome(int(args.genome_mbp * 1e6), seed=20240601)
+        t_gen = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        if not stub:
+            ref = Reference.from_contigs(contigs, device=local_rank, kmer=KMER, kmer_skip=2, bin_size=2)
+        t_index = time.perf_counter() - t0
+        if world > 1:
+            np.save(os.path.join(workdir, "lens.npy"), np.array([len(c) for c in contigs], np.int64))
+            with open(gen_file, "wb") as f:
+                for c in contigs:
+                    c.tofile(f)
+            if not stub:
+                with open(fa, "w") as f:
+                    f.write(">stub\nACGT\n")
+                ref.write_ngm_cache(fa)
+    barrier()
+    if rank != 0:
+        lens = np.load(os.path.join(workdir, "lens.npy"))
+        flat = np.memmap(gen_file, dtype=np.uint8, mode="r")
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        contigs = [flat[offs[i]:offs[i + 1]] for i in range(len(lens))]
+        t0 = time.perf_counter()
+        if not stub:
+            ref = Reference.from_cache(fa, device=local_rank, kmer=KMER, kmer_skip=2, bin_size=2)
+        t_index = time.perf_counter() - t0
+
+    # ---- this rank's shard of the job's reads (weak scaling: R reads per rank per step) ----------------------------------
+    lo_g, hi_g = sharding.shard_range(R * world, rank, world, paired=paired)
+    assert hi_g - lo_g == R
+    rows, truth_c, truth_p = make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank, paired=paired, subs=args.subs,
+                                        indel_bases=args.indel_bases)  # config #2's seed, one shard per rank
+    sens = 0.5 - 0.35 * 0.5 if args.sensitive else 0.5
+    d_rows = None if stub else torch.from_numpy(rows).to(dev)
     # W mapper instances (own stream + workspace each, like NextGenMap's CS threads with their own IAlignment) work on
     # contiguous slices of the step's reads from W host threads: the host stages of one slice (pair selection, CIGAR,
     # downloads) overlap the kernels of the others
     W = max(1, min(args.workers, R // 2048))
     bounds = [(R * w // W) & ~1 for w in range(W)] + [R]
     out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
+
+    class StubMapper:
+        """control-path stand-in (tests): every read 'maps' where the simulator put it, 1 read in 1000 does not"""
+        def map(self, rw, ow, lo):
+            h = ow[0]
+            h["mapped"] = 1; h["contig"] = truth_c[lo:lo + len(h)]; h["pos"] = truth_p[lo:lo + len(h)]; h["mapq"] = 60; h["pair_flags"] = 1
+            h["mapped"][(np.arange(lo, lo + len(h)) + lo_g) % 1000 == 999] = 0
+        def last_kernel_ms(self): return [1.0] * 8
+        def cs_counters(self): return [138 * R // W, 4000 * R // W, R // W]
+        def close(self): pass
+
     mps, views = [], []
     for w in range(W):
-        kw = dict(gap_read=33, gap_ref=33, gap_extend=3, personality=1) if affine else {}
-        mps.append(Mapper(ref, Q, C, sensitivity=0.5, **kw))
         lo, hi = bounds[w], bounds[w + 1]
-        views.append((rows[lo:hi], d_rows[lo:hi], tuple(o[lo:hi] for o in out)))
+        if stub:
+            mps.append(StubMapper())
+            views.append((rows[lo:hi], None, tuple(o[lo:hi] for o in out), lo))
+            continue
+        kw = dict(gap_read=33, gap_ref=33, gap_extend=3, personality=1) if affine else {}
+        mps.append(Mapper(ref, Q, C, sensitivity=sens, **kw))
+        views.append((rows[lo:hi], d_rows[lo:hi], tuple(o[lo:hi] for o in out), lo))
 
     def worker(w, steps, acc):
-        rw, dw, ow = views[w]
+        rw, dw, ow, lo = views[w]
         k = np.zeros(8)
         for _ in range(steps):
-            if paired:
+            if stub:
+                mps[w].map(rw, ow, lo)
+            elif paired:
                 mps[w].map_pe_raw(rw, dw, ow)
             else:
                 mps[w].map_se_raw(rw, dw, ow)
@@ -300,16 +433,10 @@ def main():
         return np.sum(acc, axis=0)
 
     run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     kms = run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     kms /= max(1, args.steps)  # GPU time per step (R reads), summed over the W streams' launches
     hits = out[0]
@@ -326,31 +453,33 @@ def main():
     kmers, hits_voted, n_cand = int(ctr[0]), int(ctr[1]), int(ctr[2])
     mapped = hits["mapped"] == 1
     correct = mapped & (hits["contig"] == truth_c) & (np.abs(hits["pos"].astype(np.int64) - truth_p) <= C // 2 + 4)
-    stats = torch.tensor([R, int(mapped.sum()), int((~mapped).sum()), int(mapped.sum()), int(correct.sum()), int((hits["mapq"] > 0).sum()),
-                          int(n_cand), int(hits_voted)], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)  # the ONE collective of the path (RCCL over xGMI)
-    stats = [int(x) for x in stats.tolist()]
+    # ONE collective of the path -- the int64[8] mapping statistics, summed over the ranks (RCCL over xGMI)
+    local = {"reads": R, "mapped": int(mapped.sum()), "unmapped": int((~mapped).sum()), "written": R}
+    if paired:
+        sel = ((hits["pair_flags"][0::2] & 1) != 0) & mapped[0::2] & mapped[1::2]
+        ins = np.abs(hits["pos"][0::2].astype(np.int64) - hits["pos"][1::2].astype(np.int64)) + READ_LEN
+        local.update(pairs_total=R // 2, pairs_broken=int(((hits["pair_flags"][0::2] & 2) != 0).sum()), insert_sum=int(ins[sel].sum()), insert_cnt=int(sel.sum()))
+    stats = sharding.reduce_stats(local, device=dev)
 
     if rank == 0:
         value = R * world * args.steps / elapsed
         score_cells = n_cand * READ_LEN * band
         align_cells = int(mapped.sum()) * READ_LEN * band
         b_cs = 20 * kmers + 4 * hits_voted + 16 * n_cand
-        achieved = b_cs / (kms[0] * 1e-3) / 1e9
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json, keyed
-        # by kernel name and grid size = 64 threads per read; collected with this default workload)
-        traffic = None
-        if int(args.genome_mbp) == 3100 and READ_LEN == 150:
+        achieved = b_cs / (kms[0] * 1e-3) / 1e9 if kms[0] > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel: NOT measured in this run -- taken from the committed PMC passes
+        # (profiles/*_pmc_traffic.json, keyed by kernel name and grid size; collected with this default workload)
+        traffic = traffic_source = None
+        if int(args.genome_mbp) == 3100 and READ_LEN == 150 and not stub:
             for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
                 if fn.endswith("_pmc_traffic.json"):
                     try:
                         tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     except Exception:
                         continue
-                    for k, v in tj.items():
-                        if k.startswith("ngm::cs_fast_kernel") and k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64)):
-                            traffic = v
+                    for k, v in tj.items():  # grid = 64 T threads per read, T = waves per read of the instantiation
+                        if k.startswith("ngm::cs_bucket_kernel") and any(k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64 * T)) for T in (1, 2, 4, 8)):
+                            traffic, traffic_source = v, "profiles/" + fn
                     if traffic is not None:
                         break
         line = {
@@ -358,50 +487,67 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": ("%d x %dbp %s synthetic reads per GPU per step vs a synthetic %.0f Mbp genome (24 contigs, repeat "
-                                    "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=0.5) + "
+            "config": {"workload": ("%d x %dbp %s synthetic reads per GPU per step (%.1f %% substitutions%s) vs a synthetic %.0f Mbp genome (24 contigs, repeat "
+                                    "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=%.3f) + "
                                     "score + %s/MAPQ + align with traceback + CIGAR; reads resident in HBM")
-                       % (R, READ_LEN, "PE (insert ~N(350,35), FR)" if paired else "SE", args.genome_mbp, "pair selection (top1PE)" if paired else "top-1"),
+                       % (R, READ_LEN, "PE (insert ~N(350,35), FR)" if paired else "SE", 100 * args.subs,
+                          ", %.0f %% indel bases" % (100 * args.indel_bases) if args.indel_bases else "", args.genome_mbp, sens,
+                          "pair selection (top1PE)" if paired else "top-1"),
                        "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R, "mapper_instances_per_gpu": W,
-                       "parallelism": "reads sharded x%d, genome+index replicated per GPU" % world},
+                       "parallelism": "reads sharded x%d (nextgenmap_amd.sharding.shard_range), genome+index replicated per GPU (built by rank 0, loaded from NextGenMap cache files by the others)" % world},
             "sw_gcells_per_s": {"score_kernel": score_cells / (kms[2] * 1e-3) / 1e9 if kms[2] > 0 else None,
                                 "align_kernel": align_cells / (kms[5] * 1e-3) / 1e9 if kms[5] > 0 else None},
             "kernel_ms": {"candidate_search": kms[0], "gather_score": kms[1], "sw_score": kms[2], "select": kms[3], "gather_align": kms[4],
                           "sw_align": kms[5], "traceback": kms[6], "all_kernels": float(kms[:7].sum()),
                           "candidate_search_stage_incl_host_sync": kms[7]},
             "per_read": {"candidates": n_cand / R, "index_hits": hits_voted / R, "kmers": kmers / R},
-            "accuracy": {"mapped": stats[1] / stats[0], "within_band_of_truth": stats[4] / stats[0], "mapq_gt0": stats[5] / stats[0]},
-            "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries},
+            "accuracy_rank0_shard": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
+            "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries if ref else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "cs_fast_kernel (candidate search)",
-                         "isolated": {"achieved": (20 * iso_ctr[0] + 4 * iso_ctr[1] + 16 * iso_ctr[2]) / (iso_ms[0] * 1e-3) / 1e9, "ms": float(iso_ms[0]),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "cs_bucket_kernel (candidate search)",
+                         "isolated": {"achieved": (20 * iso_ctr[0] + 4 * iso_ctr[1] + 16 * iso_ctr[2]) / (iso_ms[0] * 1e-3) / 1e9 if iso_ms[0] > 0 else 0.0, "ms": float(iso_ms[0]),
                                       "reads": int(bounds[1] - bounds[0]),
                                       "note": "same kernel, one launch of one mapper instance with nothing else on the GPU (untimed extra pass)"}, "bytes_per_launch": b_cs / W, "launches_per_step": W,
-                         "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); dependent random "
-                                 "4-16 B gathers; the kernel is bound by LDS atomics and instruction issue rather than HBM (DESIGN.md 4); the SW kernels are "
-                                 "VALU-bound, see sw_gcells_per_s"},
+                         "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); one 16..128-byte bucket gather per "
+                                 "k-mer lookup; random gathers on MI355X are bound by ~50 G requests/s (profiles/r02_gather_calibration.txt), the vote side "
+                                 "by VALU + LDS atomics (DESIGN.md 4); `traffic` comes from the committed rocprofv3 PMC pass named in traffic_source, "
+                                 "it is not measured in this run; the SW kernels are VALU-bound, see sw_gcells_per_s"},
             # SURVEY.md 8d's whole-path figure: (pairs * B_score + alignments * B_align + B_cs) per second of wall time
             "path_algorithmic_gbs": (n_cand * (Q + Q + C + 4) + int(mapped.sum()) * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)) + b_cs) * world
                                     / (elapsed / args.steps) / 1e9,
-            "stats_allreduce": {"reads": stats[0], "mapped": stats[1], "unmapped": stats[2], "candidates": stats[6]},
+            "stats_allreduce": stats,
         }
-        if world > 1:
+        if world > 1 or stub:
             line["cpu_baseline"] = None  # the host baseline is timed on rank 0 of a 1-GPU run only
-        elif not args.no_cpu_baseline:
-            try:
-                import ref_files as RF
-                if not RF.have_reference_binary():
-                    raise RuntimeError("oracle/_ref/ngm/ngm-core not built")
-                with tempfile.TemporaryDirectory() as wd:
+            line["end_to_end"] = None
+        else:
+            e2e_base = None
+            if not args.no_end_to_end and paired and READ_LEN == 150:
+                try:
+                    line["end_to_end"], e2e_base = end_to_end(ref, contigs, workdir, args, paired, affine)
+                except Exception as e:
+                    line["end_to_end"] = {"error": str(e)[:400]}
+            if e2e_base is not None:
+                line["cpu_baseline"] = e2e_base
+            elif not args.no_cpu_baseline:
+                try:
+                    import ref_files as RF
+                    if not RF.have_reference_binary():
+                        raise RuntimeError("oracle/_ref/ngm/ngm-core not built")
                     ours = (hits, out[1], [c[0] for c in ref.contigs]) if affine else None
-                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, args.cpu_sample_reads, wd, ours, paired)
-            except Exception as e:  # the port of the score stage only
-                line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
-                line["cpu_baseline"]["note"] = "reference program unavailable: %s" % str(e)[:200]
+                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, min(args.cpu_sample_reads, 200000), workdir, ours, paired)
+                except Exception as e:  # the port of the score stage only
+                    line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
+                    line["cpu_baseline"]["note"] = "reference program unavailable: %s" % str(e)[:200]
         print(json.dumps(line))
     for m_ in mps:
         m_.close()
-    ref.close()
+    if ref is not None:
+        ref.close()
+    barrier()
+    if rank == 0:
+        import shutil
+        shutil.rmtree(workdir, ignore_errors=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -46,6 +46,8 @@ ngm_ref *ngm_ref_create_from_fasta(int device, const ngm_ref_params *p, const ch
  * an existing NextGenMap index drops in.  NULL when absent / built with other parameters / multi-unit.
  * ngm_ref_create_from_fasta tries this first, like the reference (NGM_HIP_NO_CACHE=1 forces a rebuild). */
 ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *params, const char *fasta_path);
+/* 1 when the reference came from those cache files (a corrupt / mismatching cache falls back to a build: the caller rewrites it) */
+int ngm_ref_loaded_from_cache(const ngm_ref *r);
 void ngm_ref_destroy(ngm_ref *r);
 
 int ngm_ref_contig_count(const ngm_ref *r);

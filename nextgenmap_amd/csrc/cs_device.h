@@ -347,33 +347,37 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 }
 
 // ---- FAST path ---------------------------------------------------------------------------------------------------
-// T waves per read (workgroup = 64 T lanes).  Phase 1: lanes own k-mer start positions and write the bucket number of
-// every list (2p = forward k-mer, 2p+1 = reverse complement) to LDS -- no memory access, no dependent index read.
-// Phase 2 (sweep 1): the lists are taken in rounds; in a round a wave loads 64/LPB whole buckets, LPB = W/4 lanes x 16
-// bytes each, i.e. one aligned request per bucket (the random-request rate, ~50 G/s on MI355X, is what bounds this kernel:
-// profiles/r02_gather_calibration.txt) with kCsBucketDepth rounds in flight.  A lane gets 4 bucket words; the list length
-// sits in word 0 (broadcast inside the lane group), the partner list of the same k-mer (other strand) is the neighbouring
-// lane group (CS.cpp:122 needs the sum of both lengths).  Slots past the list end vote with an all-zero mask.
-//   vote: atomicOr into a "bin seen" bit plane; a hit that finds its bit already set is a repeat and goes (through a
-//   wave-private LDS queue, inserted by the whole wave) into the small exact table.  The bins stay in registers.
-// Lists that do not fit their bucket (count >= W) are collected in LDS and voted from d_positions in 8-hit segments by a
-// run-time loop after the bucket rounds (their "first on its bit" flags go back into the item list).
-// Sweep 2: the plane is rebuilt as the bit set of the table keys; every hit that was the first on its bit adds its vote
-// if -- and only if -- its bin made it into the table.  A bin with >= 2 votes has all but its first vote inserted in
-// sweep 1 and the first one added in sweep 2: exact; bins with a single vote are dropped (never candidates when the
-// final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
+// T waves per read (workgroup = 64 T lanes).
+// Phase 1: lanes own k-mer start positions and write the bucket number of every list (2p = forward k-mer, 2p+1 = reverse
+// complement) to LDS -- no memory access, no dependent index read.
+// Sweep 1: the lists are taken in rounds; in a round a wave loads 64/LPB whole buckets, LPB = W/4 lanes x 16 bytes each,
+// i.e. ONE aligned request per bucket (the random-request rate, ~50 G/s on MI355X, is the memory-side bound of this
+// kernel: profiles/r02_gather_calibration.txt), kCsBucketDepth rounds in flight.  A lane gets 4 bucket words; word 0 of
+// the bucket carries the list length, the length of the other strand's list of the same k-mer (CS.cpp:122 needs the
+// sum) and the "does not fit" flag, and is broadcast inside the lane group.  Slots past the list end vote with an
+// all-zero mask.  A vote is two LDS atomics and no branch: atomicOr into plane 1 ("bin seen"); the returned word tells
+// whether the bit was already set, and that bit is OR-ed into plane 2 ("bin seen again").  The bins stay in registers.
+// Lists longer than a bucket are collected in LDS and voted from d_positions in 8-hit segments by a run-time loop.
+// Sweep 2 (registers + LDS only): every hit whose plane-2 bit is set is appended to its lane's private queue (branch
+// free: always store, advance the cursor on a hit) and then inserted into the small exact table (key = bin, value =
+// forward | reverse votes).  A bin with >= 2 votes has set its plane-2 bit, so ALL its hits are counted: exact; bins
+// with a single vote are dropped (never candidates when the final threshold exceeds 1); bit collisions only cost
+// spurious table entries with their exact counts.
 constexpr int kCsBucketDepth = 8;      // bucket rounds in flight per wave (one 16-byte load per lane each)
 constexpr int kCsOvfLists = 64;        // lists longer than a bucket, per read, that the fast path takes
-constexpr uint32_t kCsNoList = 0xFFFFFFFFu;
+constexpr uint32_t kCsEmptySlot = 0u;  // register entry of a slot without a hit (a hit is bin | 1 << 30 | strand << 31)
 
 struct __attribute__((packed, aligned(4))) CsU4 { uint32_t x, y, z, w; };
 
-// LDS words of the fast path (host twin: cs_fast_lds_words in mapper.cpp)
-__host__ __device__ inline uint32_t cs_fast_lds_words(int q, int lists_cap, uint32_t plane_bits, int log2_slots, uint32_t ovf_items) {
-	return (uint32_t) ((q + 3) / 4) + (uint32_t) lists_cap + (plane_bits >> 5) + (2u << log2_slots) + ((3u << log2_slots) >> 2) + 2u * kCsOvfLists + ovf_items + 16u;
-}
+// bucket word 0 (written by fill_buckets_kernel, refindex.cpp)
+constexpr uint32_t kCsHdrCountMask = 0x3FFFu;   // bits 0-13 own list length (<= 9900), bits 14-27 the other strand's
+constexpr uint32_t kCsHdrOverflow = 0x80000000u;
 
-__device__ __forceinline__ uint32_t cs_plane_hash(uint32_t bin, uint32_t pmask) { return (bin ^ (bin >> 15)) & pmask; }
+// LDS words of the fast path: plane 1 first (its word address is a bit field of the bin: no base to add); the lane
+// queues of sweep 2 reuse plane 1
+__host__ __device__ inline uint32_t cs_fast_lds_words(int q, int lists_cap, uint32_t plane_bits, int log2_slots, uint32_t ovf_items) {
+	return (plane_bits >> 5) + (plane_bits >> 7) + (2u << log2_slots) + (uint32_t) ((q + 3) / 4) + (uint32_t) lists_cap + 1u + 2u * kCsOvfLists + ovf_items + 16u;
+}
 
 template <int ROUNDS, int T>
 __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
@@ -381,21 +385,20 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int read = blockIdx.x;
 	const int k = A.k, q = A.q;
-	uint8_t *l_code = (uint8_t *) cs_lds;
-	uint32_t *l_list = cs_lds + (q + 3) / 4;                 // [lists_cap] bucket number per list, or kCsNoList
-	uint32_t *plane = l_list + A.lists_cap;
-	const uint32_t plane_words = A.plane_bits >> 5, pmask = A.plane_bits - 1u;
-	uint32_t *t_keys = plane + plane_words;
+	uint32_t *plane1 = cs_lds;                                   // [plane_bits / 32]
+	const uint32_t p1_words = A.plane_bits >> 5, p2_words = A.plane_bits >> 7;
+	uint32_t *plane2 = plane1 + p1_words;                        // [plane_bits / 128]: a quarter of plane 1, same bit-in-word
+	uint32_t *t_keys = plane2 + p2_words;
 	const int log2_slots = A.log2_slots;
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
-	const uint32_t q_cap = ((n_slots * 3u) / 4u) / (uint32_t) T;  // queue entries per wave
-	uint32_t *s_queue = t_votes + n_slots + (uint32_t) wave * q_cap;
-	uint32_t *l_ovf = t_votes + n_slots + (n_slots * 3u) / 4u;      // [2 * kCsOvfLists] start, count << 11 | list
-	uint32_t *l_items = l_ovf + 2 * kCsOvfLists;                    // [ovf_items] list slot << 16 | segment (| owner bits << 24 after sweep 1)
-	uint32_t *s_misc = l_items + A.ovf_items;                       // [0] read length [1] abort [2] overflow lists [3] hits [4] k-mers [5] overflow items
+	uint8_t *l_code = (uint8_t *) (t_votes + n_slots);
+	uint32_t *l_list = t_votes + n_slots + (q + 3) / 4;          // [lists_cap + 1] bucket number per list; the last entry = the all-zero bucket
+	uint32_t *l_ovf = l_list + A.lists_cap + 1;                  // [2 * kCsOvfLists] start, count << 11 | list
+	uint32_t *l_items = l_ovf + 2 * kCsOvfLists;                 // [ovf_items] list slot << 16 | segment
+	uint32_t *s_misc = l_items + A.ovf_items;                    // [0] read length [1] abort [2] overflow lists [3] hits [4] k-mers [5] overflow items
+	for (uint32_t s = tid; s < p1_words + p2_words; s += 64 * T) plane1[s] = 0;
 	for (uint32_t s = tid; s < n_slots; s += 64 * T) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
-	for (uint32_t s = tid; s < plane_words; s += 64 * T) plane[s] = 0;
 	if (tid < 16) s_misc[tid] = tid == 0 ? (uint32_t) q : 0u;
 	__syncthreads();
 	const bool diag = A.phase_cycles && (read & 255) == 0;  // sampled: the global atomics would serialise otherwise
@@ -420,6 +423,7 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 	const int L = (int) s_misc[0];
 	const int n_kmers = L - k + 1;
 	const int n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
+	const uint32_t zero_bucket = 1u << (2 * k);   // one bucket past the last k-mer: all zero
 	{
 		uint32_t nv = 0;
 		for (int p = tid; p < n_kmers; p += 64 * T) {
@@ -433,10 +437,11 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 			// CSstatic.cpp:30-41: a k-mer that starts right after a restart-position N run and ends exactly at the
 			// read end is never visited
 			if (v && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) v = false;
-			l_list[2 * p] = v ? kmer : kCsNoList;
-			l_list[2 * p + 1] = v ? cs_revcomp(kmer, k) : kCsNoList;
+			l_list[2 * p] = v ? kmer : zero_bucket;
+			l_list[2 * p + 1] = v ? cs_revcomp(kmer, k) : zero_bucket;
 			nv += v ? 1u : 0u;
 		}
+		for (int i = n_lists + tid; i <= A.lists_cap; i += 64 * T) l_list[i] = zero_bucket;
 		{ uint32_t total; (void) wave_prefix_small<5>(nv, total); if (lane == 0 && total) atomicAdd(&s_misc[4], total); }  // nv <= 16 (q <= 1024)
 	}
 	__syncthreads();
@@ -448,120 +453,80 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 	const int bpr = 64 >> ls;                // buckets per wave round
 	const uint32_t sub = (uint32_t) lane & (lpb - 1u);
 	const int hs = 32 - log2_slots;
+	const uint32_t a1_mask = (p1_words - 1u) << 2, a2_mask = (p2_words - 1u) << 2;   // byte address of the plane word = (bin >> 3) & mask
+	const int bin_shift = A.bin_shift;
+	// this lane's list in round r is li = (r T + wave) bpr + (lane >> ls): its strand and the step of its diagonal
+	// correction are the same in every round (bpr is even)
+	const uint32_t strand = ((uint32_t) lane >> ls) & 1u;
+	const uint32_t tag = (strand << 31) | 0x40000000u;                 // register entry of a hit = bin | tag
+	const int li0 = wave * bpr + (lane >> ls);
+	const int p0 = li0 >> 1;
+	// diagonal of the hit (CS.cpp:140-142): forward lists p, reverse-complement lists L - (p + k)
+	uint32_t corr = strand ? (uint32_t) (L - (p0 + k)) : (uint32_t) p0;
+	const uint32_t corr_step = strand ? (uint32_t) -(T * bpr / 2) : (uint32_t) (T * bpr / 2);
+	const uint32_t w0 = sub * 4u - 1u;   // bucket word of slot j is 4 sub + j; it holds position (4 sub + j - 1) of the list
 
-	// wave-uniform bookkeeping in registers: queue length, distinct keys this wave put into the table, abort flag
-	uint32_t q_len = 0, n_keys = 0, hits = 0;
+	uint32_t hits = 0;
 	bool abort_fast = false;
-	// inserts this wave's queued entries (bin | strand << 31), one per lane per round.  Several waves insert concurrently:
-	// probing is bounded (a full table ends the fast path for this read), the number of keys is only kept as a statistic
-	auto flush_inserts = [&]() {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the queue is private to the wave; LDS operations of a wave complete in order
-		const uint32_t nq = min(q_len, q_cap);
-		uint32_t fresh = 0;
-		bool lost = false;
-		for (uint32_t i = lane; i < nq; i += 64) {
-			const uint32_t e = s_queue[i];
-			const uint32_t bin = e & 0x3FFFFFFFu;
-			uint32_t slot = (bin * 2654435761u) >> hs;
-			uint32_t probes = 0;
-			for (; probes < n_slots; ++probes) {
-				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
-				if (prev == bin) break;
-				if (prev == 0xFFFFFFFFu) { ++fresh; break; }
-				slot = (slot + 1) & (n_slots - 1);
-			}
-			if (probes < n_slots) atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
-			else lost = true;
+	// one vote: returns the register entry (bin | tag, or kCsEmptySlot).  The LDS atomics run under the execution mask of the
+	// lanes that have a hit: the kernel is bound by LDS bank cycles (64 random addresses on 32 banks), and lanes that are
+	// switched off cost none -- half of the bucket slots are empty, and the second atomic is needed by 2-3 % of the hits
+	auto vote = [&](uint32_t pos, uint32_t cr, bool valid, uint32_t tg) -> uint32_t {
+		uint32_t out = kCsEmptySlot;
+		if (valid) {
+			const uint32_t bin = __builtin_amdgcn_ubfe(pos - cr, (uint32_t) bin_shift, 30u);
+			const uint32_t msk = 1u << (bin & 31u);
+			const uint32_t a = bin >> 3;
+			const uint32_t old = atomicOr((uint32_t *) ((char *) plane1 + (a & a1_mask)), msk);
+			if (old & msk) atomicOr((uint32_t *) ((char *) plane2 + (a & a2_mask)), msk);
+			out = bin | tg;
 		}
-		if (__ballot(lost)) abort_fast = true;
-		{ uint32_t total; (void) wave_prefix_small<5>(fresh, total); n_keys += total; }  // fresh <= ceil(q_cap / 64) <= 12
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		q_len = 0;
-	};
-	// votes NS slots: position, valid -> returns the register entry per slot (bin | first-on-its-bit << 30 | strand << 31, 0 = nothing left to do)
-	auto vote4 = [&](const uint32_t (&pos)[4], const bool (&valid)[4], uint32_t corr, uint32_t rev, uint32_t (&out)[4]) {
-		uint32_t old[4], msk[4], ent[4];
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t bin = ((pos[j] - corr) >> A.bin_shift) & 0x3FFFFFFFu;
-			const uint32_t b = cs_plane_hash(bin, pmask);
-			msk[j] = valid[j] ? (1u << (b & 31)) : 0u;   // empty slots: a no-op on whatever plane word their garbage selects
-			old[j] = atomicOr(&plane[b >> 5], msk[j]);
-			ent[j] = bin | rev;
-		}
-		uint32_t ndup = 0;
-#pragma unroll
-		for (int j = 0; j < 4; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
-		uint32_t qb;
-		{ uint32_t total; qb = q_len + wave_prefix_small<3>(ndup, total); q_len += total; }  // ndup <= 4
-#pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const bool dup = (old[j] & msk[j]) != 0u;           // implies a valid slot
-			const bool first = msk[j] != 0u && !dup;            // valid and first on its bit
-			if (dup) { if (qb < q_cap) s_queue[qb] = ent[j]; ++qb; }
-			out[j] = first ? (ent[j] | 0x40000000u) : 0u;      // repeats voted in sweep 1: nothing left to do
-		}
-		if (q_len > q_cap) abort_fast = true;  // more repeats than the queue holds: leave it to the exact path
+		return out;
 	};
 
 	// one bucket round of this wave: round r covers lists [(r T + wave) bpr, +bpr).  The load is unconditional (lanes without
-	// a list read bucket 0): a load under a divergent branch makes the compiler wait for it right there (the merge copies
-	// the loaded registers), which would serialise the rounds on the memory latency.
-	auto fetch = [&](int r, CsU4 &d) -> uint32_t {
+	// a list read the all-zero bucket): a load under a divergent branch makes the compiler wait for it right there (the merge
+	// copies the loaded registers), which would serialise the rounds on the memory latency.
+	auto fetch = [&](int r, CsU4 &d) {
 		const int li = (r * T + wave) * bpr + (lane >> ls);
-		const uint32_t id = l_list[min(li, A.lists_cap - 1)];
-		const bool ok = li < n_lists && id != kCsNoList;
-		d = *reinterpret_cast<const CsU4 *>(A.buckets + ((size_t) (ok ? id : 0u) << bw) + sub * 4u);
-		return ok ? (uint32_t) li : kCsNoList;
+		const uint32_t id = l_list[min(li, A.lists_cap)];
+		d = *reinterpret_cast<const CsU4 *>(A.buckets + ((size_t) id << bw) + sub * 4u);
 	};
 
-	uint32_t bins[ROUNDS * 4];  // bin | first-on-its-bit << 30 | reverse strand << 31 ; 0 = empty slot
+	uint32_t bins[ROUNDS * 4];
 	constexpr int DEPTH = kCsBucketDepth < ROUNDS ? kCsBucketDepth : ROUNDS;
 	CsU4 ring[DEPTH];
-	uint32_t rmeta[DEPTH];
 #pragma unroll
-	for (int d = 0; d < DEPTH - 1; ++d) rmeta[d] = fetch(d, ring[d]);
+	for (int d = 0; d < DEPTH - 1; ++d) fetch(d, ring[d]);
 #pragma unroll
 	for (int r = 0; r < ROUNDS; ++r) {
 		// the prefetch is issued on every path: loads under a branch make the compiler's wait-count bookkeeping give up one
-		// round of pipelining per merge point (rounds past the last list read bucket 0 and are skipped below)
-		if (r + DEPTH - 1 < ROUNDS) rmeta[(r + DEPTH - 1) % DEPTH] = fetch(r + DEPTH - 1, ring[(r + DEPTH - 1) % DEPTH]);
-		const uint32_t li = rmeta[r % DEPTH];
+		// round of pipelining per merge point (rounds past the last list read the zero bucket and are skipped below)
+		if (r + DEPTH - 1 < ROUNDS) fetch(r + DEPTH - 1, ring[(r + DEPTH - 1) % DEPTH]);
 		const CsU4 cur = ring[r % DEPTH];
+		const uint32_t cr = corr;
+		corr += corr_step;
 		if ((r * T + wave) * bpr >= n_lists) {  // wave-uniform
 #pragma unroll
-			for (int j = 0; j < 4; ++j) bins[r * 4 + j] = 0;
+			for (int j = 0; j < 4; ++j) bins[r * 4 + j] = kCsEmptySlot;
 			continue;
 		}
-		// list length: word 0 of the bucket, i.e. of the first lane of the lane group; partner list = neighbouring group
 		const uint32_t hdr = (uint32_t) __shfl((int) cur.x, lane & ~(int) (lpb - 1u));
-		const uint32_t n_own = li != kCsNoList ? (hdr & 0x7FFFFFFFu) : 0u;
-		const uint32_t n_other = (uint32_t) __shfl_xor((int) n_own, (int) lpb);
+		const uint32_t n_own = hdr & kCsHdrCountMask, n_other = (hdr >> 14) & kCsHdrCountMask;
 		const uint32_t n_used = ((int) (n_own + n_other) < A.max_kfreq) ? n_own : 0u;   // CS.cpp:122
-		const bool ovf = (hdr >> 31) != 0u;
-		if (sub == 0u) {
-			hits += n_used;
-			if (ovf && n_used) {
-				const uint32_t slot = atomicAdd(&s_misc[2], 1u);
-				if (slot < (uint32_t) kCsOvfLists) { l_ovf[2 * slot] = cur.y; l_ovf[2 * slot + 1] = (n_used << 11) | li; }
-			}
+		hits += n_used;   // every lane of the group counts it: divided by the group size at the end
+		const bool ovf = (hdr & kCsHdrOverflow) != 0u;
+		if (ovf && n_used && sub == 0u) {   // rare
+			const uint32_t slot = atomicAdd(&s_misc[2], 1u);
+			const uint32_t li = (uint32_t) ((r * T + wave) * bpr + (lane >> ls));
+			if (slot < (uint32_t) kCsOvfLists) { l_ovf[2 * slot] = cur.y; l_ovf[2 * slot + 1] = (n_used << 11) | li; }
 		}
 		const uint32_t n_inl = ovf ? 0u : n_used;
-		const uint32_t p = li >> 1;
-		// diagonal of the hit (CS.cpp:140-142); bit 31 = reverse-complement list
-		const uint32_t rev = (li & 1u) << 31, corr = (li & 1u) ? (uint32_t) (L - ((int) p + k)) : p;
 		const uint32_t pos[4] = {cur.x, cur.y, cur.z, cur.w};
-		bool valid[4];
 #pragma unroll
-		for (int j = 0; j < 4; ++j) valid[j] = (sub * 4u + (uint32_t) j - 1u) < n_inl;  // bucket words 1 .. n
-		uint32_t out[4];
-		vote4(pos, valid, corr, rev, out);
-#pragma unroll
-		for (int j = 0; j < 4; ++j) bins[r * 4 + j] = out[j];
-		if (q_len > 128u) flush_inserts();  // small batches: the table-capacity guard of flush_inserts stays loose
+		for (int j = 0; j < 4; ++j) bins[r * 4 + j] = vote(pos[j], cr, (w0 + (uint32_t) j) < n_inl, tag);
 	}
-	flush_inserts();
-	{ uint32_t h = hits; for (int o = 32; o > 0; o >>= 1) h += __shfl_xor((int) h, o); if (lane == 0 && h) atomicAdd(&s_misc[3], h); }
+	{ uint32_t h = hits; for (int o = 32; o > 0; o >>= 1) h += __shfl_xor((int) h, o); h >>= ls; if (lane == 0 && h) atomicAdd(&s_misc[3], h); }
 	__syncthreads();
 
 	// lists longer than their bucket: 8-hit segments straight from d_positions, run-time loop, all waves
@@ -578,118 +543,96 @@ __global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
 	}
 	const uint32_t n_items = s_misc[5];
 	if (n_ovf > (uint32_t) kCsOvfLists || n_items > A.ovf_items) abort_fast = true;
-	if (!abort_fast && n_items > 0u) {
-		for (uint32_t idx = (uint32_t) tid; idx < ((n_items + 64u * T - 1u) / (64u * T)) * (64u * T); idx += 64u * T) {  // whole waves: vote4 is wave-wide
-			uint32_t pos8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-			uint32_t cnt = 0, corr = 0, rev = 0;
-			if (idx < n_items) {
-				const uint32_t item = l_items[idx];
-				const uint32_t lo = item >> 16, sg = item & 0xFFFFu;
-				const uint32_t meta = l_ovf[2 * lo + 1], li = meta & 0x7FFu;
-				cnt = min((uint32_t) kCsSeg, (meta >> 11) - sg * kCsSeg);
-				const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_ovf[2 * lo] + sg * kCsSeg);
-				const CsU4 a = src[0], b = cnt > 4u ? src[1] : CsU4{0u, 0u, 0u, 0u};
-				pos8[0] = a.x; pos8[1] = a.y; pos8[2] = a.z; pos8[3] = a.w; pos8[4] = b.x; pos8[5] = b.y; pos8[6] = b.z; pos8[7] = b.w;
-				const uint32_t p = li >> 1;
-				rev = (li & 1u) << 31; corr = (li & 1u) ? (uint32_t) (L - ((int) p + k)) : p;
-			}
-			uint32_t owner = 0;
+	// item -> its up to 8 positions, diagonal correction and tag
+	auto ovf_item = [&](uint32_t idx, uint32_t (&pos8)[8], uint32_t &cnt, uint32_t &cr, uint32_t &tg) {
+		const uint32_t item = l_items[idx];
+		const uint32_t lo = item >> 16, sg = item & 0xFFFFu;
+		const uint32_t meta = l_ovf[2 * lo + 1], li = meta & 0x7FFu;
+		cnt = min((uint32_t) kCsSeg, (meta >> 11) - sg * kCsSeg);
+		const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_ovf[2 * lo] + sg * kCsSeg);  // the table is padded by 16 entries
+		const CsU4 a = src[0], b = src[1];
+		pos8[0] = a.x; pos8[1] = a.y; pos8[2] = a.z; pos8[3] = a.w; pos8[4] = b.x; pos8[5] = b.y; pos8[6] = b.z; pos8[7] = b.w;
+		const uint32_t p = li >> 1;
+		tg = ((li & 1u) << 31) | 0x40000000u;
+		cr = (li & 1u) ? (uint32_t) (L - ((int) p + k)) : p;
+	};
+	if (!abort_fast) for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += 64u * T) {
+		uint32_t pos8[8], cnt, cr, tg;
+		ovf_item(idx, pos8, cnt, cr, tg);
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				const uint32_t ph[4] = {pos8[4 * h], pos8[4 * h + 1], pos8[4 * h + 2], pos8[4 * h + 3]};
-				bool valid[4];
-#pragma unroll
-				for (int j = 0; j < 4; ++j) valid[j] = (uint32_t) (4 * h + j) < cnt;
-				uint32_t out[4];
-				vote4(ph, valid, corr, rev, out);
-#pragma unroll
-				for (int j = 0; j < 4; ++j) owner |= ((out[j] >> 30) & 1u) << (4 * h + j);
-				if (q_len > 128u) flush_inserts();
-			}
-			if (idx < n_items) l_items[idx] |= owner << 24;
-		}
-		flush_inserts();
+		for (int j = 0; j < kCsSeg; ++j) (void) vote(pos8[j], cr, (uint32_t) j < cnt, tg);
 	}
 	if (abort_fast) s_misc[1] = 1u;
-	if (lane == 0 && n_keys) atomicAdd(&s_misc[6], n_keys);
 	__syncthreads();
-	if (s_misc[6] > (n_slots * 3u) / 4u) s_misc[1] = 1u;  // probing gets slow and the spurious entries too many
 	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
 	CsRead R;
 	R.L = L; R.n_lists = n_lists; R.H = s_misc[3]; R.n_valid = s_misc[4]; R.n_items = 0;
-	if (s_misc[1] != 0u || R.H > A.hit_cap) { if (wave == 0) cs_enqueue(A, read, lane, R); return; }  // not provably exact here
+	if (s_misc[1] != 0u || R.H > A.hit_cap) {  // not provably exact here
+		if (A.phase_cycles && tid == 0) atomicAdd(&A.phase_cycles[R.H > A.hit_cap ? 8 : 9], 1ull);
+		if (wave == 0) cs_enqueue(A, read, lane, R);
+		return;
+	}
 
-	// sweep 2: plane := bits of the bins that are in the table; first-on-bit hits whose bit is set are queued, then added
-	for (uint32_t s = tid; s < plane_words; s += 64 * T) plane[s] = 0;
-	__syncthreads();
-	for (uint32_t s = tid; s < n_slots; s += 64 * T) {
-		const uint32_t key = t_keys[s];
-		if (key != 0xFFFFFFFFu) {
-			const uint32_t b = cs_plane_hash(key, pmask);
-			atomicOr(&plane[b >> 5], 1u << (b & 31));
+	// sweep 2.  Lane queues in what was plane 1: entry i of lane l of wave w at [(w cap1 + i) * 64 + l], the last row takes
+	// the stores of full queues
+	const uint32_t cap = p1_words / (64u * T) - 1u;
+	uint32_t *qrow = plane1 + (uint32_t) wave * (cap + 1u) * 64u + (uint32_t) lane;
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int r = 0; r < ROUNDS; ++r) {
+		if ((r * T + wave) * bpr >= n_lists) continue;  // wave-uniform
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t e = bins[r * 4 + j];
+			if (e != kCsEmptySlot) {
+				const uint32_t w = *(const uint32_t *) ((const char *) plane2 + ((e >> 3) & a2_mask));
+				if ((w >> (e & 31u)) & 1u) { qrow[min(cnt, cap) * 64u] = e; ++cnt; }
+			}
 		}
 	}
-	__syncthreads();
-	auto add_vote = [&](uint32_t e) {  // the vote of a first hit whose bin is in the table (a set bit may also be a collision)
+	// (plane 1 is only written above by its own wave's lanes: no barrier needed before the queues are read back)
+	auto insert = [&](uint32_t e) -> bool {
 		const uint32_t bin = e & 0x3FFFFFFFu;
 		uint32_t slot = (bin * 2654435761u) >> hs;
-		for (;;) {
-			const uint32_t key = t_keys[slot];
-			if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); break; }
-			if (key == 0xFFFFFFFFu) break;
+		for (uint32_t probes = 0; probes < n_slots; ++probes) {
+			const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+			if (prev == bin || prev == 0xFFFFFFFFu) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); return true; }
 			slot = (slot + 1) & (n_slots - 1);
 		}
+		return false;
 	};
+	bool lost = cnt > cap;
+	if (A.phase_cycles) {  // diagnostics: [4] queue entries [5] reads with a full lane queue
+		uint32_t t = cnt; for (int o = 32; o > 0; o >>= 1) t += __shfl_xor((int) t, o);
+		if (lane == 0) { atomicAdd(&A.phase_cycles[4], (unsigned long long) t); if (__ballot(cnt > cap)) atomicAdd(&A.phase_cycles[5], 1ull); }
+	}
 	{
-		uint32_t nhit = 0;
-		uint32_t wmask[ROUNDS];
-#pragma unroll
-		for (int r = 0; r < ROUNDS; ++r) {
-			wmask[r] = 0;
-			if ((r * T + wave) * bpr >= n_lists) continue;
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const uint32_t e = bins[r * 4 + j];
-				const uint32_t b = cs_plane_hash(e & 0x3FFFFFFFu, pmask);
-				const uint32_t w = (plane[b >> 5] >> (b & 31)) & (e >> 30) & 1u;  // bit 30 = first on its bit (0 for empty slots)
-				wmask[r] |= w << j;
-			}
-			nhit += __popc(wmask[r]);
-		}
-		uint32_t total;
-		uint32_t qb = wave_prefix_small<8>(nhit, total);  // nhit <= 4 ROUNDS <= 144
-		q_len = total;
-#pragma unroll
-		for (int r = 0; r < ROUNDS; ++r) {
-			if (wmask[r])
-#pragma unroll
-				for (int j = 0; j < 4; ++j) if ((wmask[r] >> j) & 1u) { if (qb < q_cap) s_queue[qb] = bins[r * 4 + j]; ++qb; }
-		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		if (q_len > q_cap) abort_fast = true;
-		const uint32_t nq = min(q_len, q_cap);
-		for (uint32_t i = lane; i < nq; i += 64) add_vote(s_queue[i]);
+		const uint32_t mx = (uint32_t) wave_reduce_max((int) min(cnt, cap));
+		for (uint32_t i = 0; i < mx; ++i) if (i < cnt) { if (!insert(qrow[i * 64u])) lost = true; }
 	}
 	for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += 64u * T) {  // the overflow lists again (L2 / Infinity Cache hits)
-		const uint32_t item = l_items[idx];
-		const uint32_t owner = item >> 24;
-		if (!owner) continue;
-		const uint32_t lo = (item >> 16) & 0xFFu, sg = item & 0xFFFFu;
-		const uint32_t li = l_ovf[2 * lo + 1] & 0x7FFu;
-		const uint32_t *src = A.positions + l_ovf[2 * lo] + sg * kCsSeg;
-		const uint32_t p = li >> 1;
-		const uint32_t rev = (li & 1u) << 31, corr = (li & 1u) ? (uint32_t) (L - ((int) p + k)) : p;
-		for (int j = 0; j < kCsSeg; ++j) if ((owner >> j) & 1u) {
-			const uint32_t bin = ((src[j] - corr) >> A.bin_shift) & 0x3FFFFFFFu;
-			const uint32_t b = cs_plane_hash(bin, pmask);
-			if ((plane[b >> 5] >> (b & 31)) & 1u) add_vote(bin | rev);
+		uint32_t pos8[8], n8, cr, tg;
+		ovf_item(idx, pos8, n8, cr, tg);
+		for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < n8) {
+			const uint32_t bin = __builtin_amdgcn_ubfe(pos8[j] - cr, (uint32_t) bin_shift, 30u);
+			const uint32_t w = *(const uint32_t *) ((const char *) plane2 + ((bin >> 3) & a2_mask));
+			if ((w >> (bin & 31u)) & 1u) { if (!insert(bin | tg)) lost = true; }
 		}
 	}
-	if (abort_fast) s_misc[1] = 1u;
+	if (__ballot(lost)) s_misc[1] = 1u;
 	__syncthreads();
 	const unsigned long long c3 = diag ? wall_clock64() : 0ull;
 	if (wave != 0) return;
 	if (s_misc[1] != 0u) { cs_enqueue(A, read, lane, R); return; }
+	{
+		// more than 3/4 full: too many spurious entries for this table -- the exact path has the room
+		uint32_t keys = 0;
+		for (uint32_t s2 = lane; s2 < n_slots; s2 += 64) keys += t_keys[s2] != 0xFFFFFFFFu;
+		for (int o = 32; o > 0; o >>= 1) keys += __shfl_xor((int) keys, o);
+		if (A.phase_cycles && lane == 0) { atomicAdd(&A.phase_cycles[6], (unsigned long long) keys); if (keys > (n_slots * 3u) / 4u) atomicAdd(&A.phase_cycles[7], 1ull); }
+		if (keys > (n_slots * 3u) / 4u) { cs_enqueue(A, read, lane, R); return; }
+	}
 	if (!cs_finish<kCsFast>(A, read, lane, R, t_keys, t_votes, n_slots)) cs_enqueue(A, read, lane, R);
 	if (diag && lane == 0) {  // diagnostics: 100 MHz ticks spent per phase, summed over the sampled reads
 		atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);

@@ -142,8 +142,9 @@ void set_cs_fast_lds_limit(int bytes) {
 int run_cs(ngm_mapper *m, int n) {
 	const ngm_ref *r = m->ref;
 	const int q = m->prm.qry_max_len;
+	if (n <= 0) { m->n_reads = 0; m->n_cand = 0; return 0; }
 	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) || m->d_max_both.reserve(n) ||
-			m->d_status.reserve(4) || m->d_total.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 8) || m->d_counters.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 8) || m->d_new_base.reserve(n) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
+			m->d_status.reserve(4) || m->d_total.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 16) || m->d_counters.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 16) || m->d_new_base.reserve(n) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
 			m->d_ovf_hits.reserve(n)) {
 		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
 		return -12;
@@ -152,10 +153,12 @@ int run_cs(ngm_mapper *m, int n) {
 	size_t cap = std::max<size_t>(m->d_out_loc.cap, (size_t) n * 8 + 64 * ngm::kCsRegions);
 	cap = (cap + ngm::kCsRegions - 1) / ngm::kCsRegions * ngm::kCsRegions;
 	for (int attempt = 0; attempt < 8; ++attempt) {
+		// candidate offsets are 32-bit (base = region * capacity + cursor; the prefix sums over the counts)
+		if (cap >= 0xFFFFFFFFull) { ngm::pipeline_set_error("more than 2^32 candidate slots needed for %d reads: use smaller batches or a higher sensitivity", n); return -75; }
 		if (m->d_out_loc.reserve(cap) || m->d_out_sv.reserve(cap) || m->d_out_loc2.reserve(cap) || m->d_out_sv2.reserve(cap)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 8) * 8, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 8) * 8, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 16) * 8, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 16) * 8, m->st));
 		ngm::CsArgs A{};
 		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
@@ -244,7 +247,7 @@ int run_cs(ngm_mapper *m, int n) {
 			std::swap(m->d_out_loc, m->d_out_loc2); std::swap(m->d_out_sv, m->d_out_sv2); std::swap(m->d_cand_base, m->d_new_base);
 			m->last_cs = A;
 			m->n_reads = n;
-			std::vector<unsigned long long> ctr(ctr_words + 8);
+			std::vector<unsigned long long> ctr(ctr_words + 16);
 			MAP_HIP_TRY(hipMemcpyAsync(ctr.data(), m->d_counters.p, ctr.size() * 8, hipMemcpyDeviceToHost, m->st));
 			if (m->h_base.b.reserve(n) || m->h_count.b.reserve(n) || m->h_maxv.b.reserve(n)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
 			MAP_HIP_TRY(hipMemcpyAsync(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
@@ -252,12 +255,23 @@ int run_cs(ngm_mapper *m, int n) {
 			MAP_HIP_TRY(hipMemcpyAsync(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 			m->n_cand = n > 0 ? (uint64_t) m->h_base[n - 1] + m->h_count[n - 1] : 0;
+			{
+				// the 32-bit prefix sums wrap silently: cross-check the total against the 64-bit region cursors
+				std::vector<unsigned long long> tot(ctr_words);
+				MAP_HIP_TRY(hipMemcpy(tot.data(), m->d_total.p, ctr_words * 8, hipMemcpyDeviceToHost));
+				unsigned long long sum = 0;
+				for (int g = 0; g < ngm::kCsRegions; ++g) sum += tot[(size_t) g * ngm::kCsCursorStride];
+				if (sum != m->n_cand) { ngm::pipeline_set_error("%llu candidates in one batch of %d reads exceed the 32-bit candidate index: use smaller batches", sum, n); return -75; }
+			}
 			m->cs_kmers = m->cs_hits = 0;
 			for (int g = 0; g < ngm::kCsRegions; ++g) { m->cs_kmers += ctr[(size_t) g * ngm::kCsCursorStride]; m->cs_hits += ctr[(size_t) g * ngm::kCsCursorStride + 1]; }
 			const unsigned long long *ph = ctr.data() + ctr_words;
 			if (A.phase_cycles)
 				fprintf(stderr, "[ngm-hip] cs fast path, 100 MHz ticks per read: lists %.1f sweep1 %.1f sweep2 %.1f candidates %.1f; %u of %d reads re-run by the exact path; kernels %.2f + %.2f + %.2f ms\n",
 						(double) ph[0] * 256 / n, (double) ph[1] * 256 / n, (double) ph[2] * 256 / n, (double) ph[3] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
+			if (A.phase_cycles)
+				fprintf(stderr, "[ngm-hip] cs fast path: queue entries per read %.1f, table keys per read %.1f; reads leaving the fast path: lane queue full %llu, table > 3/4 %llu, "
+						"too many hits %llu, sweep-1 abort %llu\n", (double) ph[4] / n, (double) ph[6] / n, ph[5], ph[7], ph[8], ph[9]);
 			return 0;
 		}
 		cap *= 4;  // candidate buffer too small: grow and redo the batch
@@ -382,11 +396,17 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		while ((double) (1u << lb) < 12.0 * hexp && lb < 17) ++lb;
 		m->cs_log2_bits = lb;
 		m->cs_plane_bits = 1u << lb;
-		// table of 2^ls slots, 3/4 of which may fill: entries = hits that find their bit already set -- H^2 / (2 P) by
-		// collision -- plus the real repeats, with headroom
-		int ls = 8;
-		while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * m->cs_plane_bits) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
-		m->cs_log2_small = ls;
+		// table of 2^ls slots, 3/4 of which may fill.  Keys = the bins whose plane-2 bit is set: both partners of every
+		// plane-1 collision (H^2 / P), the real repeats (~3 % of the hits), and what collides with those in the four times
+		// smaller plane 2 -- with headroom
+		auto table_log2 = [&](double P) {
+			const double dups = hexp * hexp / (2.0 * P) + 0.03 * hexp;
+			const double keys = 2.0 * hexp * hexp / (2.0 * P) + 0.03 * hexp + dups / (P / 4.0) * hexp;
+			int ls = 8;
+			while (0.75 * (double) (1u << ls) < 1.3 * keys + 100.0 && ls < 12) ++ls;
+			return ls;
+		};
+		m->cs_log2_small = table_log2((double) m->cs_plane_bits);
 		// waves per read: every wave takes kCsRounds (one wave) or kCsRounds / 2 bucket rounds of 64 / (W / 4) lists
 		const int n_lists = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1);
 		const int bpr = 64 >> (ref->bucket_log2_words - 2);
@@ -397,6 +417,9 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 			if ((w == 1 || w == 2 || w == 4 || w == 8) && rounds <= cs_rounds_covered(w)) m->cs_waves = w;
 		}
 		m->cs_fast_ok = rounds <= cs_rounds_covered(m->cs_waves);
+		// sweep 2 keeps one queue row of 64 entries per wave per 2048 plane bits: at least 8 rows per wave
+		while (m->cs_plane_bits < 16384u * (uint32_t) m->cs_waves) m->cs_plane_bits <<= 1;
+		m->cs_log2_small = table_log2((double) m->cs_plane_bits);
 		if (const char *e = getenv("NGM_HIP_CS_OVF_ITEMS")) m->cs_ovf_items = (uint32_t) std::max(8, atoi(e));
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;

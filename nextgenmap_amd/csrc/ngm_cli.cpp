@@ -49,6 +49,7 @@
 
 #include "../../include/ngm_hip.h"
 #include "../../include/ngm_pipeline.h"
+#include "bam_writer.h"
 #include "thread_pool.h"
 
 namespace {
@@ -371,9 +372,9 @@ int main(int argc, char **argv) {
 	// an index cache next to the FASTA is loaded instead of rebuilding; a fresh build is saved for the next run unless
 	// --skip-save (src/PrefixTable.cpp:232-262, SequenceProvider.cpp:264-330)
 	const std::string ht_cache = o.ref + "-ht-" + std::to_string(o.kmer) + "-" + std::to_string(o.kmer_skip) + ".3.ngm";
-	const bool had_cache = access(ht_cache.c_str(), R_OK) == 0 && access((o.ref + "-enc.2.ngm").c_str(), R_OK) == 0 && !getenv("NGM_HIP_NO_CACHE");
 	ngm_ref *ref = ngm_ref_create_from_fasta(o.device, &rp, o.ref.c_str());
 	if (!ref) die(ngm_pipeline_last_error());
+	const bool had_cache = ngm_ref_loaded_from_cache(ref) != 0;  // (an unreadable or corrupt cache was rebuilt and is rewritten below)
 	if (had_cache) info("PREPROCESS", "Reading reference index from " + ht_cache);
 	else if (!o.skip_save) {
 		if (ngm_ref_write_ngm_cache(ref, o.ref.c_str()) < 0) info("PREPROCESS", std::string("could not save the index: ") + ngm_pipeline_last_error());
@@ -386,6 +387,7 @@ int main(int argc, char **argv) {
 	if (o.out.empty()) die("no output file given (-o/--output)");
 
 	// ---- pass 1: read lengths + the sample for the sensitivity estimate (ReadProvider.cpp:201-305) ----------
+	const auto t_input = std::chrono::steady_clock::now();  // the first input byte is read below
 	size_t max_len = 0, min_len = 9999999, sum_len = 0, count = 0;
 	std::vector<Read> sample;
 	{
@@ -485,25 +487,39 @@ int main(int argc, char **argv) {
 	FILE *out = fopen(o.out.c_str(), "w");
 	if (!out) die("cannot write " + o.out);
 	setvbuf(out, nullptr, _IONBF, 0);  // whole batches are written at once
+	std::vector<std::string> contig_names;
+	std::vector<uint64_t> contig_lens;
+	for (int i = 0; i < ngm_ref_contig_count(ref); ++i) { contig_names.push_back(ngm_ref_contig_name(ref, i)); contig_lens.push_back(ngm_ref_contig_len(ref, i)); }
 	{
+		static const char *tag[12] = {"ID", "CN", "DS", "DT", "FO", "KS", "LB", "PG", "PI", "PL", "PU", "SM"};
 		std::string h = "@HD\tVN:1.0\tSO:unsorted\n";
-		for (int i = 0; i < ngm_ref_contig_count(ref); ++i) { h += "@SQ\tSN:"; h += ngm_ref_contig_name(ref, i); h += "\tLN:"; put_u64(h, ngm_ref_contig_len(ref, i)); h += "\n"; }
-		h += "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"" + o.cmdline + "\"\n";
+		std::string rg;
 		if (!o.rg[0].empty()) {  // SAMWriter.cpp:46-80
-			static const char *tag[12] = {"ID", "CN", "DS", "DT", "FO", "KS", "LB", "PG", "PI", "PL", "PU", "SM"};
-			h += "@RG\tID:" + o.rg[0];
-			for (int t = 1; t < 12; ++t) if (!o.rg[t].empty()) { h += "\t"; h += tag[t]; h += ":" + o.rg[t]; }
-			h += "\n";
+			rg = "@RG\tID:" + o.rg[0];
+			for (int t = 1; t < 12; ++t) if (!o.rg[t].empty()) { rg += "\t"; rg += tag[t]; rg += ":" + o.rg[t]; }
+			rg += "\n";
 		}
-		fwrite(h.data(), 1, h.size(), out);
+		if (!o.bam) {
+			for (size_t i = 0; i < contig_names.size(); ++i) { h += "@SQ\tSN:" + contig_names[i] + "\tLN:"; put_u64(h, contig_lens[i]); h += "\n"; }
+			h += "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"" + o.cmdline + "\"\n";
+			h += rg;
+			fwrite(h.data(), 1, h.size(), out);
+		} else {
+			// BAMWriter::DoWriteProlog (BAMWriter.cpp:18-110) through bamtools' SamFormatPrinter: @HD, @RG, @PG (ID PN CL VN); the
+			// contigs only in the binary dictionary
+			h += rg;
+			h += "@PG\tID:ngm\tPN:ngm\tCL:\"" + o.cmdline + "\"\tVN:0.5.5-hip\n";
+			std::string raw, z;
+			ngm::bam::put_header(raw, h, contig_names, contig_lens);
+			if (!ngm::bam::bgzf_compress(raw.data(), raw.size(), z)) die("BGZF compression failed");
+			fwrite(z.data(), 1, z.size(), out);
+		}
 	}
 	const std::string rg_mapped = o.rg[0].empty() ? std::string() : "RG:Z:" + o.rg[0] + "\t";
 	const std::string rg_unmapped = o.rg[0].empty() ? std::string() : "\tRG:Z:" + o.rg[0];
 	const size_t stride = (size_t) 4 * q;
 	const int max_insert = o.max_insert > 0 ? o.max_insert : 2147483647;
 	const int topn = o.paired ? 1 : o.topn;
-	std::vector<std::string> contig_names;
-	for (int i = 0; i < ngm_ref_contig_count(ref); ++i) contig_names.push_back(ngm_ref_contig_name(ref, i));
 
 	// ---- the references / mappers: one reference per GPU (the first one exists), `workers` mappers per GPU ---------------
 	std::vector<ngm_ref *> refs(1, ref);
@@ -528,13 +544,37 @@ int main(int argc, char **argv) {
 		if (min_res <= 1.0f) min_res = v.L * min_res;
 		return v.h->mapped && v.h->mapq >= o.min_mq && v.h->identity >= o.min_identity && (float) (v.L - v.h->qstart - v.h->qend) >= min_res;
 	};
-	auto write_mapped = [&](std::string &s, size_t &n_written, const View &v, int flags, const char *rnext, unsigned long long pnext, long long tlen) {
+	struct BamMate { int ref; long long pos0; long long tlen; };  // what BAMWriter::DoWritePair passes on (0-based, -1 = none; its own TLEN rule)
+	auto write_mapped = [&](std::string &s, size_t &n_written, const View &v, int flags, const char *rnext, unsigned long long pnext, long long tlen, const BamMate &bm) {
 		const ngm_hit &h = *v.h;
 		const int L = v.L;
 		const bool noq = v.r->qual_len == 0;
 		if (h.reverse) flags |= 0x10;
 		const bool clip = o.hard_clip || o.silent_clip;
 		const int s0 = clip ? h.qstart : 0, sl = clip ? L - h.qstart - h.qend : L;
+		if (o.bam) {  // BAMWriter::DoWriteReadGeneric (BAMWriter.cpp:147-298)
+			char seq[1024], qual[1024];
+			const int n = std::max(0, std::min(sl, 1000));
+			const int QL = std::min<int>((int) v.r->qual_len, L);
+			for (int t = 0; t < n; ++t) {
+				if (!h.reverse) { seq[t] = v.row[s0 + t]; qual[t] = (s0 + t < QL) ? v.r->qual[s0 + t] : ':'; }
+				else {
+					const char ch = v.row[L - 1 - (s0 + t)];
+					seq[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+					qual[t] = (QL - 1 - (s0 + t) >= 0) ? v.r->qual[QL - 1 - (s0 + t)] : ':';
+				}
+			}
+			ngm::bam::Tags tg;
+			tg.add_int("AS", (int) h.score); tg.add_int("NM", h.nm); tg.add_int("NH", h.n_best);
+			tg.add_float("XI", roundf(h.identity * 10000.0f) / 10000.0f);
+			tg.add_int("X0", h.n_best); tg.add_int("XE", (int) h.max_votes); tg.add_int("XR", L - h.qstart - h.qend);
+			tg.add_string("MD", v.md, strlen(v.md));
+			if (!o.rg[0].empty()) tg.add_string("RG", o.rg[0].data(), o.rg[0].size());
+			ngm::bam::put_record(s, v.r->name, v.r->name_len, (uint32_t) flags, h.contig, (int) h.pos, h.mapq, v.cigar, seq, (size_t) n, noq ? nullptr : qual,
+					bm.ref, (int) bm.pos0, (int) bm.tlen, tg);
+			++n_written;
+			return;
+		}
 		s.append(v.r->name, v.r->name_len); s.push_back('\t'); put_u64(s, (unsigned) flags); s.push_back('\t');
 		s += contig_names[h.contig]; s.push_back('\t'); put_u64(s, (unsigned long long) h.pos + 1); s.push_back('\t'); put_i64(s, h.mapq); s.push_back('\t');
 		s += v.cigar; s.push_back('\t'); s += rnext; s.push_back('\t'); put_u64(s, pnext); s.push_back('\t'); put_i64(s, tlen); s.push_back('\t');
@@ -566,6 +606,18 @@ int main(int argc, char **argv) {
 	auto write_unmapped = [&](std::string &s, size_t &n_written, const View &v, int flags, int contig, unsigned long long pos1, char rnext, unsigned long long pnext1) {
 		if (o.no_unal) return;
 		const bool noq = v.r->qual_len == 0;
+		if (o.bam) {  // BAMWriter::DoWriteUnmappedReadGeneric (BAMWriter.cpp:300-375): reference / mate fields = the mapped mate's, 0-based
+			char qual[1024];
+			const int n = std::min(v.L, 1000), QL = std::min<int>((int) v.r->qual_len, v.L);
+			for (int t = 0; t < n; ++t) qual[t] = t < QL ? v.r->qual[t] : ':';
+			ngm::bam::Tags tg;
+			if (!o.rg[0].empty()) tg.add_string("RG", o.rg[0].data(), o.rg[0].size());
+			const int p0 = contig >= 0 ? (int) pos1 - 1 : -1;
+			ngm::bam::put_record(s, v.r->name, v.r->name_len, (uint32_t) (flags | 0x4), contig >= 0 ? contig : -1, p0, 0, nullptr, v.row, (size_t) n,
+					noq ? nullptr : qual, contig >= 0 ? contig : -1, p0, 0, tg);
+			++n_written;
+			return;
+		}
 		s.append(v.r->name, v.r->name_len); s.push_back('\t'); put_u64(s, (unsigned) (flags | 0x4)); s.push_back('\t');
 		if (contig >= 0) s += contig_names[contig]; else s.push_back('*');
 		s.push_back('\t'); put_u64(s, pos1); s += "\t0\t*\t"; s.push_back(rnext); s.push_back('\t'); put_u64(s, pnext1); s += "\t0\t";
@@ -593,7 +645,7 @@ int main(int argc, char **argv) {
 				if (topn == 1) {
 					if (!passes(v)) { write_unmapped(s, n_written, v, 0, -1, 0, '*', 0); continue; }
 					++n_mapped;
-					write_mapped(s, n_written, v, 0, "*", 0, 0);
+					write_mapped(s, n_written, v, 0, "*", 0, 0, BamMate{-1, -1, 0});
 					continue;
 				}
 				// GenericReadWriter::WriteRead with several alignments (GenericReadWriter.h:199-243): every alignment that
@@ -607,7 +659,7 @@ int main(int argc, char **argv) {
 					const auto key = std::make_tuple(vt.h->contig, (unsigned long long) vt.h->pos, vt.h->reverse);
 					if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
 					seen.push_back(key);
-					write_mapped(s, n_written, vt, t ? 0x100 : 0, "*", 0, 0);
+					write_mapped(s, n_written, vt, t ? 0x100 : 0, "*", 0, 0, BamMate{-1, -1, 0});
 				}
 				if (once) ++n_mapped; else write_unmapped(s, n_written, v, 0, -1, 0, '*', 0);
 			}
@@ -633,24 +685,26 @@ int main(int argc, char **argv) {
 				write_unmapped(s, n_written, v2, f2 | 0x8, -1, 0, '*', 0);
 				write_unmapped(s, n_written, v1, f1 | 0x8, -1, 0, '*', 0);
 			} else if (!m1) {
-				write_mapped(s, n_written, v2, f2 | 0x8, "=", p2, 0);
+				write_mapped(s, n_written, v2, f2 | 0x8, "=", p2, 0, BamMate{h2.contig, (long long) h2.pos, 0});
 				write_unmapped(s, n_written, v1, f1, h2.contig, p2, '=', p2);
 			} else if (!m2) {
 				write_unmapped(s, n_written, v2, f2, h1.contig, p1, '=', p1);
-				write_mapped(s, n_written, v1, f1 | 0x8, "=", p1, 0);
+				write_mapped(s, n_written, v1, f1 | 0x8, "=", p1, 0, BamMate{h1.contig, (long long) h1.pos, 0});
 			} else if (!paired_fail) {
 				if (!h1.reverse) {
 					const long long d = ((long long) h2.pos + v2.L - h2.qstart - h2.qend) - (long long) h1.pos;
-					write_mapped(s, n_written, v2, f2 | 0x2, "=", p1, -d);
-					write_mapped(s, n_written, v1, f1 | 0x2 | 0x20, "=", p2, d);
+					const long long db = (long long) h2.pos + v2.L - (long long) h1.pos;  // BAMWriter.cpp:428-433: the whole read length
+					write_mapped(s, n_written, v2, f2 | 0x2, "=", p1, -d, BamMate{h2.contig, (long long) h1.pos, -db});
+					write_mapped(s, n_written, v1, f1 | 0x2 | 0x20, "=", p2, d, BamMate{h2.contig, (long long) h2.pos, db});
 				} else if (!h2.reverse) {
 					const long long d = ((long long) h1.pos + v1.L - h1.qstart - h1.qend) - (long long) h2.pos;
-					write_mapped(s, n_written, v2, f2 | 0x2 | 0x20, "=", p1, d);
-					write_mapped(s, n_written, v1, f1 | 0x2, "=", p2, -d);
+					const long long db = (long long) h1.pos + v1.L - (long long) h2.pos;
+					write_mapped(s, n_written, v2, f2 | 0x2 | 0x20, "=", p1, d, BamMate{h2.contig, (long long) h1.pos, db});
+					write_mapped(s, n_written, v1, f1 | 0x2, "=", p2, -d, BamMate{h2.contig, (long long) h2.pos, -db});
 				}
 			} else {
-				write_mapped(s, n_written, v2, f2 | (h1.reverse ? 0x20 : 0), contig_names[h1.contig].c_str(), p1, 0);
-				write_mapped(s, n_written, v1, f1 | (h2.reverse ? 0x20 : 0), contig_names[h2.contig].c_str(), p2, 0);
+				write_mapped(s, n_written, v2, f2 | (h1.reverse ? 0x20 : 0), contig_names[h1.contig].c_str(), p1, 0, BamMate{h1.contig, (long long) h1.pos, 0});
+				write_mapped(s, n_written, v1, f1 | (h2.reverse ? 0x20 : 0), contig_names[h2.contig].c_str(), p2, 0, BamMate{h2.contig, (long long) h2.pos, 0});
 			}
 		}
 	};
@@ -813,6 +867,12 @@ int main(int argc, char **argv) {
 				for (int c = lo; c < hi; ++c) {
 					const int u0 = (int) ((long long) units * c / n_chunks), u1 = (int) ((long long) units * (c + 1) / n_chunks);
 					format_range(*b, w, u0 * per, u1 * per, b->chunks[c], ct[c], cm[c], cw[c]);
+					if (o.bam && !b->chunks[c].empty()) {  // every chunk becomes whole BGZF blocks: they concatenate into one valid file
+						std::string z;
+						z.reserve(b->chunks[c].size() / 3 + 64);
+						if (!ngm::bam::bgzf_compress(b->chunks[c].data(), b->chunks[c].size(), z)) fail("BGZF compression failed");
+						b->chunks[c].swap(z);
+					}
 				}
 			}, 1);
 			for (int c = 0; c < n_chunks; ++c) { b->n_total += ct[c]; b->n_mapped += cm[c]; b->n_written += cw[c]; }
@@ -851,6 +911,7 @@ int main(int argc, char **argv) {
 	{ std::lock_guard<std::mutex> lk(out_mu); workers_done = true; }
 	out_cv.notify_all();
 	writer.join();
+	if (o.bam) { std::string z; ngm::bam::bgzf_eof(z); fwrite(z.data(), 1, z.size(), out); }
 	fclose(out);
 	if (failed) die(fail_msg);
 	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
@@ -859,6 +920,9 @@ int main(int argc, char **argv) {
 	info("MAIN", msg);
 	snprintf(msg, sizeof(msg), "Mapping pass: %.3f s, %.0f reads/s (%zu GPU(s) x %d worker(s), %d host threads, %s input)", secs, n_total / std::max(1e-9, secs),
 			o.devices.size(), o.workers, pool.size(), plain ? "memory-mapped plain FASTQ" : "serial reader");
+	info("MAIN", msg);
+	snprintf(msg, sizeof(msg), "Input to output: %.3f s (estimation pass + mapping pass, first input byte to output closed)",
+			std::chrono::duration<double>(std::chrono::steady_clock::now() - t_input).count());
 	info("MAIN", msg);
 	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); }
 	ngm_pair_state_destroy(pair_state);

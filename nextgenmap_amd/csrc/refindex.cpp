@@ -130,17 +130,20 @@ __global__ void apply_usage_rule_kernel(uint32_t n_kmers, int k, const uint32_t 
 
 void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw);
 
-// bucket b of k-mer p: word 0 = count (0: unused, or more than 9900 occurrences), words 1.. = its positions; a list that
-// does not fit keeps (count | 1 << 31, start in d_positions).  One thread per bucket word: coalesced stores.
-__global__ void fill_buckets_kernel(uint32_t n_kmers, int log2_w, const uint2 *__restrict__ index, const uint32_t *__restrict__ positions,
+// bucket of k-mer p: word 0 = own list length (bits 0-13; 0: unused, or more than 9900 occurrences) | list length of the
+// reverse-complement k-mer << 14 (the search needs the sum of both, CS.cpp:122) | 1 << 31 when the list does not fit;
+// words 1.. = the positions, or word 1 = start in d_positions for a list that does not fit.  One bucket more than there
+// are k-mers: the last one stays zero (what lanes without a list read).  One thread per bucket word: coalesced stores.
+__global__ void fill_buckets_kernel(uint32_t n_kmers, int k, int log2_w, const uint2 *__restrict__ index, const uint32_t *__restrict__ positions,
 		uint32_t *__restrict__ buckets) {
 	const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t p = (uint32_t) (g >> log2_w), w = (uint32_t) g & ((1u << log2_w) - 1u);
-	if (p >= n_kmers) return;
+	if (p > n_kmers) return;
+	if (p == n_kmers) { buckets[g] = 0; return; }
 	const uint2 e = index[p];
 	const bool inl = e.y < (1u << log2_w);
 	uint32_t v = 0;
-	if (w == 0) v = inl ? e.y : (e.y | 0x80000000u);
+	if (w == 0) v = e.y | (index[d_revcomp(p, k)].y << 14) | (inl ? 0u : 0x80000000u);
 	else if (inl) v = (w <= e.y) ? positions[e.x + (w - 1)] : 0u;
 	else if (w == 1) v = e.x;
 	buckets[g] = v;
@@ -156,9 +159,9 @@ int build_buckets(ngm_ref *r) {
 	while (lw < 5 && (double) ((1 << lw) - 1) < mu + 4.0 * sqrt(mu) + 0.5) ++lw;
 	if (const char *e = getenv("NGM_HIP_BUCKET_LOG2_WORDS")) lw = std::max(2, std::min(5, atoi(e)));  // tests
 	r->bucket_log2_words = lw;
-	const uint64_t words = (uint64_t) n_kmers << lw;
+	const uint64_t words = ((uint64_t) n_kmers + 1) << lw;
 	REF_HIP_TRY(hipMalloc(&r->d_buckets, words * 4));
-	hipLaunchKernelGGL(fill_buckets_kernel, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, 0, n_kmers, lw, r->d_index, r->d_positions, r->d_buckets);
+	hipLaunchKernelGGL(fill_buckets_kernel, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, 0, n_kmers, k, lw, r->d_index, r->d_positions, r->d_buckets);
 	REF_HIP_TRY(hipGetLastError());
 	REF_HIP_TRY(hipDeviceSynchronize());
 	return 0;
@@ -371,6 +374,25 @@ ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *p, const ch
 	std::vector<uint8_t> ib((size_t) index_size * 5);
 	std::vector<uint32_t> pos((size_t) table_len + 16, 0);
 	if (fread(ib.data(), 1, ib.size(), fh) != ib.size() || fread(pos.data(), 4, table_len, fh) != table_len) return fail("truncated k-mer table");
+	{
+		// trailer: offset of the unit + signature (PrefixTable.cpp:838-846, checked by the reference at :892-903)
+		uint64_t unit_offset = 0;
+		uint32_t signature = 0;
+		if (fread(&unit_offset, 8, 1, fh) != 1 || fread(&signature, 4, 1, fh) != 1 || signature != cookie + kk + skip + units + index_size)
+			return fail("k-mer table without a valid signature (truncated or written by another version)");
+	}
+	// a corrupt file must not turn into out-of-bounds reads on the GPU: contigs inside the encoded genome, index offsets
+	// monotonic and inside the position table
+	for (const NgmContig &c : r->contigs) if (c.start + c.len > bin_ref_index || c.len == 0) return fail("contig table does not match the sequence data");
+	{
+		uint32_t prev = 1;
+		for (uint32_t q = 0; q <= n_kmers; ++q) {
+			uint32_t t;
+			memcpy(&t, &ib[(size_t) q * 5], 4);
+			if (t < prev || t > table_len + 1) return fail("corrupt k-mer table index");
+			prev = t;
+		}
+	}
 	fclose(fe); fclose(fh);
 	std::vector<uint32_t> raw(n_kmers);
 	std::vector<uint2> idx(n_kmers);
@@ -393,6 +415,7 @@ ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *p, const ch
 	}
 	index_stats(r, raw);
 	if (build_buckets(r) != 0) { ngm_ref_destroy(r); return nullptr; }
+	r->from_cache = true;
 	return r;
 }
 
@@ -457,6 +480,7 @@ uint64_t ngm_ref_contig_start(const ngm_ref *r, int i) { return r->contigs[i].st
 uint64_t ngm_ref_contig_len(const ngm_ref *r, int i) { return r->contigs[i].len; }
 uint64_t ngm_ref_concat_len(const ngm_ref *r) { return r->n_bases - 1; }  // SequenceProvider.cpp:454-456
 int ngm_ref_auto_max_kfreq(const ngm_ref *r) { return r->auto_max_kfreq; }
+int ngm_ref_loaded_from_cache(const ngm_ref *r) { return r->from_cache ? 1 : 0; }
 uint64_t ngm_ref_index_entries(const ngm_ref *r) { return r->n_entries; }
 
 int ngm_ref_index_copy(const ngm_ref *r, uint32_t *counts, uint32_t *raw_counts, uint32_t *positions) {

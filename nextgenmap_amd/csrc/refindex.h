@@ -42,6 +42,7 @@ struct ngm_ref {
 	std::vector<uint8_t> host_cls;    // one class per base (kept for the host-side helpers)
 	uint64_t n_entries = 0;
 	int auto_max_kfreq = 100;
+	bool from_cache = false;          // loaded from NextGenMap's cache files instead of being built
 	// device
 	uint32_t *d_genome = nullptr;
 	uint64_t genome_words = 0;

@@ -1,0 +1,79 @@
+"""-m gpu: the REAL NextGenMap program with libngm_hip.so plugged in behind IAlignment (oracle/build_dropin.sh: the
+reference's own translation units, _NGM::CreateAlignment patched as INTEGRATION.md section A says) against the stock program.
+This is the drop-in claim itself: the reference's CS / ScoreBuffer / AlignmentBuffer / SAMWriter drive BatchScore / BatchAlign
+of this library through the reference's own vtable calls, and the SAM file must not change."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ref_files as RF
+import simulate as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "dropin", "ngm-core-hip")
+CLI = os.path.join(ROOT, "nextgenmap_amd", "ngm-hip")
+needs = pytest.mark.skipif(not (RF.have_reference_binary() and os.path.exists(DROPIN)), reason="oracle/_ref/ngm/ngm-core or oracle/_ref/dropin/ngm-core-hip not built")
+
+
+def _case(tmp_path, paired):
+    contigs = S.make_genome([400000, 300001], seed=901, repeat_families=10, repeat_len=500, copies=6)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    fq = str(tmp_path / "reads.fq")
+    if paired:
+        r1, r2 = S.make_reads(contigs, 2500, 100, seed=902, sub_rate=0.02, indel_rate=0.003, paired=True)
+        S.write_fastq(fq, [x for pair in zip(r1, r2) for x in pair])
+        return fa, ["-p", "-q", fq], 5000
+    S.write_fastq(fq, S.make_reads(contigs, 4000, 100, seed=903, sub_rate=0.02, indel_rate=0.003))
+    return fa, ["-q", fq], 4000
+
+
+def _body(path):
+    return [l for l in open(path) if not l.startswith("@PG")]
+
+
+def _run(binary, fa, args, out, cwd):
+    r = subprocess.run([binary, "-r", fa, "-o", out, "-t", "1", "--no-progress"] + args, capture_output=True, text=True, cwd=cwd, timeout=1800)
+    assert "Done" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-2500:]
+    return r.stdout + r.stderr
+
+
+@needs
+@pytest.mark.parametrize("layout", ["single-end", "paired-end", "single-end-end-to-end"])
+def test_real_ngm_with_hip_plugin_writes_the_same_sam(tmp_path, layout):
+    fa, inp, n = _case(tmp_path, layout == "paired-end")
+    extra = ["-e"] if layout.endswith("end-to-end") else []
+    stock, plug = str(tmp_path / "stock.sam"), str(tmp_path / "plugin.sam")
+    _run(RF.NGM_CORE, fa, inp + ["--affine"] + extra, stock, str(tmp_path))
+    log = _run(DROPIN, fa, inp + ["--affine"] + extra, plug, str(tmp_path))
+    a, b = _body(stock), _body(plug)
+    assert len([l for l in a if not l.startswith("@")]) == n
+    diff = [(x, y) for x, y in zip(a, b) if x != y]
+    print("lines differing:", len(diff), "of", len(a))
+    assert len(a) == len(b) and not diff, str(diff[:2])[:1200]
+
+
+@needs
+def test_real_ngm_with_hip_plugin_default_personality_equals_ngm_hip(tmp_path):
+    """NGM's default (linear-gap, OpenCL) personality cannot run in the stock build here (no OpenCL device); through the plugin
+    it runs on the MI355X.  Its SAM records must equal what the ngm-hip command line writes for the same input: two
+    independent hosts (the reference's own pipeline vs. this repository's device-resident pipeline) above the same kernels."""
+    fa, inp, n = _case(tmp_path, False)
+    plug, ours = str(tmp_path / "plugin.sam"), str(tmp_path / "ours.sam")
+    _run(DROPIN, fa, inp, plug, str(tmp_path))
+    c = subprocess.run([CLI, "-r", fa, "-o", ours] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    rec = lambda p: {l.split("\t", 1)[0]: l for l in open(p) if not l.startswith("@")}
+    a, b = rec(plug), rec(ours)
+    assert set(a) == set(b) and len(a) == n
+    diff = [(a[k], b[k]) for k in a if a[k] != b[k]]
+    print("records differing:", len(diff), "of", len(a))
+    assert not diff, str(diff[:2])[:1200]

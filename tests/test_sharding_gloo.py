@@ -55,3 +55,29 @@ def test_two_rank_sharding_and_stats_reduce(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert [(tmp_path / ("rank%d.ok" % k)).read_text() for k in range(2)] == ["ok 100003"] * 2
+
+
+def test_bench_control_path_two_ranks(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per 'GPU'), with --stub-mapper so that it
+    runs on CPU over gloo: the tested code is the executed code -- shard_range for the read shards, rank 0 builds the genome and
+    hands it to rank 1 through files, reduce_stats is the one stats collective, rank 0 prints the one JSON line."""
+    import json
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--stub-mapper", "--genome-mbp", "2", "--reads-per-step", "20000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["unit"] == "reads/s"
+    st = j["stats_allreduce"]
+    from nextgenmap_amd.sharding import STAT_NAMES
+    assert tuple(st.keys()) == STAT_NAMES
+    # 40 000 reads over both ranks; the stub leaves global reads 999, 1999, ... unmapped
+    assert st["reads"] == 40000 and st["unmapped"] == 40 and st["mapped"] == 40000 - 40 and st["written"] == 40000
+    assert st["pairs_total"] == 20000 and st["insert_cnt"] == 20000 - 40
+    assert abs(j["value"] - 40000 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
+    assert j["cpu_baseline"] is None and j["end_to_end"] is None
