@@ -46,13 +46,15 @@ struct CsArgs {
 	int max_cmrs;
 	const uint2 *index;
 	const uint32_t *positions;
-	const uint32_t *buckets;   // FAST: one bucket of 1 << bucket_log2_words dwords per k-mer (refindex.h)
-	int bucket_log2_words;
-	uint32_t ovf_items;        // FAST: LDS capacity for 8-hit segments of lists longer than a bucket
+	const uint32_t *buckets;   // FAST: the bucketed index followed by a copy of the position table (refindex.h), one array
+	int bucket_log2_words;     // FAST: bucket = 1 << this dwords
+	uint32_t pos_base;         // FAST: word offset of the position table copy inside `buckets`
 	int lists_cap;          // LDS capacity for lists (>= 2*(q-k+1))
 	int log2_slots;         // exact table slots (power of two) in LDS
 	int log2_bits;          // (unused by the kernels; kept for diagnostics)
-	uint32_t plane_bits;    // FAST: bits of the plane, a power of two
+	uint32_t plane_bits;    // FAST: bits of the plane, a multiple of 2048 (any size: the hash is reduced with a multiply-high)
+	int fast_items;         // FAST: items per lane of the kernel instantiation in use
+	int items16;            // FAST: 16-bit work items
 	uint32_t hit_cap;       // reads with more hits than this are queued for the next path
 	// outputs
 	uint16_t *read_len;     // [n]
@@ -192,7 +194,15 @@ template <> struct CsItem<uint16_t> {
 	static __device__ __forceinline__ uint32_t seg(uint32_t it) { return it & 0x7Fu; }
 };
 
-template <bool ITEMS, typename ItemT = uint32_t>
+// bucket word 0 (written by fill_buckets_kernel, refindex.cpp)
+constexpr uint32_t kCsHdrCountMask = 0x3FFFu;   // bits 0-13 own list length (<= 9900), bits 14-27 the other strand's
+constexpr uint32_t kCsHdrOverflow = 0x80000000u;
+
+// BUCKETS: the lists come from the bucketed index: one 8-byte read of bucket words 0 and 1 per list -- the header (length,
+// "does not fit" flag) and either the first position or, for a list that does not fit, its start in the position table --
+// which also pulls the first 64-byte sector of the bucket (15 positions) towards the L2; {start, count} is then the same
+// pair the plain index holds, with `start` a word offset into A.buckets.
+template <bool ITEMS, typename ItemT = uint32_t, bool BUCKETS = false>
 __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, uint32_t *l_pref, uint8_t *l_code,
 		ItemT *l_items = nullptr, uint32_t items_cap = 0) {
 	const int k = A.k;
@@ -234,7 +244,14 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 				// the read end is never visited
 				if (v && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) v = false;
 				valid[r] = v;
-				if (v) { ef[r] = A.index[kmer]; er[r] = A.index[cs_revcomp(kmer, k)]; }
+				if (v && !BUCKETS) { ef[r] = A.index[kmer]; er[r] = A.index[cs_revcomp(kmer, k)]; }
+				if (v && BUCKETS) {
+					const uint32_t kf = kmer, kr = cs_revcomp(kmer, k);
+					const uint2 hf = *reinterpret_cast<const uint2 *>(A.buckets + ((size_t) kf << A.bucket_log2_words));
+					const uint2 hr = *reinterpret_cast<const uint2 *>(A.buckets + ((size_t) kr << A.bucket_log2_words));
+					ef[r] = make_uint2((hf.x & kCsHdrOverflow) ? A.pos_base + hf.y : (kf << A.bucket_log2_words) + 1u, hf.x & kCsHdrCountMask);
+					er[r] = make_uint2((hr.x & kCsHdrOverflow) ? A.pos_base + hr.y : (kr << A.bucket_log2_words) + 1u, hr.x & kCsHdrCountMask);
+				}
 			}
 		}
 #pragma unroll
@@ -347,292 +364,216 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 }
 
 // ---- FAST path ---------------------------------------------------------------------------------------------------
-// T waves per read (workgroup = 64 T lanes).
-// Phase 1: lanes own k-mer start positions and write the bucket number of every list (2p = forward k-mer, 2p+1 = reverse
-// complement) to LDS -- no memory access, no dependent index read.
-// Sweep 1: the lists are taken in rounds; in a round a wave loads 64/LPB whole buckets, LPB = W/4 lanes x 16 bytes each,
-// i.e. ONE aligned request per bucket (the random-request rate, ~50 G/s on MI355X, is the memory-side bound of this
-// kernel: profiles/r02_gather_calibration.txt), kCsBucketDepth rounds in flight.  A lane gets 4 bucket words; word 0 of
-// the bucket carries the list length, the length of the other strand's list of the same k-mer (CS.cpp:122 needs the
-// sum) and the "does not fit" flag, and is broadcast inside the lane group.  Slots past the list end vote with an
-// all-zero mask.  A vote is two LDS atomics and no branch: atomicOr into plane 1 ("bin seen"); the returned word tells
-// whether the bit was already set, and that bit is OR-ed into plane 2 ("bin seen again").  The bins stay in registers.
-// Lists longer than a bucket are collected in LDS and voted from d_positions in 8-hit segments by a run-time loop.
-// Sweep 2 (registers + LDS only): every hit whose plane-2 bit is set is appended to its lane's private queue (branch
-// free: always store, advance the cursor on a hit) and then inserted into the small exact table (key = bin, value =
-// forward | reverse votes).  A bin with >= 2 votes has set its plane-2 bit, so ALL its hits are counted: exact; bins
-// with a single vote are dropped (never candidates when the final threshold exceeds 1); bit collisions only cost
-// spurious table entries with their exact counts.
-constexpr int kCsBucketDepth = 8;      // bucket rounds in flight per wave (one 16-byte load per lane each)
-constexpr int kCsOvfLists = 64;        // lists longer than a bucket, per read, that the fast path takes
-constexpr uint32_t kCsEmptySlot = 0u;  // register entry of a slot without a hit (a hit is bin | 1 << 30 | strand << 31)
+// Work item = one segment of up to 8 consecutive hits of ONE position list (constant diagonal correction and strand,
+// two 16-byte loads, no per-hit list walking); a lane owns up to kCsFastItems items, the next item's loads are in
+// flight while the current one votes.  The bins stay in registers, so the lists are read from HBM exactly once.
+// Sweep 1: atomicOr into a "bin seen" bit plane; a hit that finds its bit already set is a repeat and goes (through a
+// small LDS queue, inserted by the whole wave) into the small exact table.  Sweep 2 (registers only): every hit that
+// was the first on its bit adds its vote if -- and only if -- its bin made it into the table (pre-filtered through a
+// bit plane of the table keys that reuses the plane memory).  A bin with >= 2 votes has all but its first vote
+// inserted in sweep 1 and the first one added in sweep 2: exact; bins with a single vote are dropped (never
+// candidates when the final threshold exceeds 1), bit collisions only cost a spurious 1-vote entry.
+// items per lane (template parameter of the kernel): 12 -> up to 768 segments (~4 900 typical hits, 150 bp reads vs a
+// human-size index), 24 -> 1 536 segments (250 bp reads)
+constexpr int kCsFastItemsShort = 12, kCsFastItemsLong = 24;
+constexpr int kCsFastDepth = 2;    // segments in flight per lane
+// LDS queue: as many entries as the table may hold keys (3/4 of its slots) -- sweep 2 queues at most one hit per key;
+// sweep 1 flushes whenever more than 96 repeats are waiting
 
 struct __attribute__((packed, aligned(4))) CsU4 { uint32_t x, y, z, w; };
 
-// bucket word 0 (written by fill_buckets_kernel, refindex.cpp)
-constexpr uint32_t kCsHdrCountMask = 0x3FFFu;   // bits 0-13 own list length (<= 9900), bits 14-27 the other strand's
-constexpr uint32_t kCsHdrOverflow = 0x80000000u;
-
-// LDS words of the fast path: plane 1 first (its word address is a bit field of the bin: no base to add); the lane
-// queues of sweep 2 reuse plane 1
-__host__ __device__ inline uint32_t cs_fast_lds_words(int q, int lists_cap, uint32_t plane_bits, int log2_slots, uint32_t ovf_items) {
-	return (plane_bits >> 5) + (plane_bits >> 7) + (2u << log2_slots) + (uint32_t) ((q + 3) / 4) + (uint32_t) lists_cap + 1u + 2u * kCsOvfLists + ovf_items + 16u;
-}
-
-template <int ROUNDS, int T>
-__global__ __launch_bounds__(64 * T) void cs_bucket_kernel(CsArgs A) {
+template <int kCsFastItems, typename ItemT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void cs_fast_kernel(CsArgs A) {
+	constexpr uint32_t kCsFastItemCap = (uint32_t) kCsFastItems * 64u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int lane = threadIdx.x;
 	const int read = blockIdx.x;
-	const int k = A.k, q = A.q;
-	uint32_t *plane1 = cs_lds;                                   // [plane_bits / 32]
-	const uint32_t p1_words = A.plane_bits >> 5, p2_words = A.plane_bits >> 7;
-	uint32_t *plane2 = plane1 + p1_words;                        // [plane_bits / 128]: a quarter of plane 1, same bit-in-word
-	uint32_t *t_keys = plane2 + p2_words;
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;
+	uint32_t *l_len = cs_lds + A.lists_cap;
+	uint8_t *l_code = (uint8_t *) (l_len + A.lists_cap + 1);
+	ItemT *l_items = (ItemT *) ((uint32_t *) l_code + (A.q + 3) / 4);
+	uint32_t *plane = (uint32_t *) (l_items + kCsFastItemCap);  // kCsFastItemCap is a multiple of 64: stays 4-byte aligned
+	const uint32_t plane_words = A.plane_bits >> 5;
+	uint32_t *t_keys = plane + plane_words;
 	const int log2_slots = A.log2_slots;
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
-	uint8_t *l_code = (uint8_t *) (t_votes + n_slots);
-	uint32_t *l_list = t_votes + n_slots + (q + 3) / 4;          // [lists_cap + 1] bucket number per list; the last entry = the all-zero bucket
-	uint32_t *l_ovf = l_list + A.lists_cap + 1;                  // [2 * kCsOvfLists] start, count << 11 | list
-	uint32_t *l_items = l_ovf + 2 * kCsOvfLists;                 // [ovf_items] list slot << 16 | segment
-	uint32_t *s_misc = l_items + A.ovf_items;                    // [0] read length [1] abort [2] overflow lists [3] hits [4] k-mers [5] overflow items
-	for (uint32_t s = tid; s < p1_words + p2_words; s += 64 * T) plane1[s] = 0;
-	for (uint32_t s = tid; s < n_slots; s += 64 * T) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
-	if (tid < 16) s_misc[tid] = tid == 0 ? (uint32_t) q : 0u;
-	__syncthreads();
+	uint32_t *s_queue = t_votes + n_slots;
+	const uint32_t kCsFastQueue = (n_slots * 3u) / 4u;
+	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
+
 	const bool diag = A.phase_cycles && (read & 255) == 0;  // sampled: the global atomics would serialise otherwise
 	const unsigned long long c0 = diag ? wall_clock64() : 0ull;
-
-	// read -> 2-bit codes (A0 C1 T2 G3, CSstatic.cpp:20-22), N = 4, past the end = 255
-	{
-		const uint8_t *rp = A.reads + (size_t) read * q;
-		int first_nul = q;
-		for (int i = tid; i < q; i += 64 * T) {
-			const uint32_t ch = rp[i];
-			uint8_t code;
-			if (ch == 0) { code = 255; first_nul = min(first_nul, i); }
-			else if (ch == 'N') code = 4;
-			else code = (uint8_t) ((ch >> 1) & 3u);
-			l_code[i] = code;
-		}
-		first_nul = wave_reduce_min(first_nul);
-		if (lane == 0 && first_nul < q) atomicMin(&s_misc[0], (uint32_t) first_nul);
-	}
-	__syncthreads();
-	const int L = (int) s_misc[0];
-	const int n_kmers = L - k + 1;
-	const int n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
-	const uint32_t zero_bucket = 1u << (2 * k);   // one bucket past the last k-mer: all zero
-	{
-		uint32_t nv = 0;
-		for (int p = tid; p < n_kmers; p += 64 * T) {
-			bool v = true;
-			uint32_t kmer = 0;
-			for (int j = 0; j < k; ++j) {
-				const uint32_t c = l_code[p + j];
-				v = v && (c < 4);
-				kmer = (kmer << 2) | (c & 3u);
-			}
-			// CSstatic.cpp:30-41: a k-mer that starts right after a restart-position N run and ends exactly at the
-			// read end is never visited
-			if (v && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) v = false;
-			l_list[2 * p] = v ? kmer : zero_bucket;
-			l_list[2 * p + 1] = v ? cs_revcomp(kmer, k) : zero_bucket;
-			nv += v ? 1u : 0u;
-		}
-		for (int i = n_lists + tid; i <= A.lists_cap; i += 64 * T) l_list[i] = zero_bucket;
-		{ uint32_t total; (void) wave_prefix_small<5>(nv, total); if (lane == 0 && total) atomicAdd(&s_misc[4], total); }  // nv <= 16 (q <= 1024)
-	}
+	const CsRead R = cs_prepare<true, ItemT, true>(A, read, lane, l_start, l_len, l_code, l_items, kCsFastItemCap);
+	const uint32_t H = R.H;
+	const int L = R.L;
+	if (H > A.hit_cap || R.n_items > kCsFastItemCap) { cs_enqueue(A, read, lane, R); return; }
 	__syncthreads();
 	const unsigned long long c1 = diag ? wall_clock64() : 0ull;
 
-	const int bw = A.bucket_log2_words;      // bucket = 1 << bw dwords
-	const int ls = bw - 2;                   // lanes per bucket = 1 << ls
-	const uint32_t lpb = 1u << ls;
-	const int bpr = 64 >> ls;                // buckets per wave round
-	const uint32_t sub = (uint32_t) lane & (lpb - 1u);
+	const uint32_t pbits = A.plane_bits;
 	const int hs = 32 - log2_slots;
-	const uint32_t a1_mask = (p1_words - 1u) << 2, a2_mask = (p2_words - 1u) << 2;   // byte address of the plane word = (bin >> 3) & mask
-	const int bin_shift = A.bin_shift;
-	// this lane's list in round r is li = (r T + wave) bpr + (lane >> ls): its strand and the step of its diagonal
-	// correction are the same in every round (bpr is even)
-	const uint32_t strand = ((uint32_t) lane >> ls) & 1u;
-	const uint32_t tag = (strand << 31) | 0x40000000u;                 // register entry of a hit = bin | tag
-	const int li0 = wave * bpr + (lane >> ls);
-	const int p0 = li0 >> 1;
-	// diagonal of the hit (CS.cpp:140-142): forward lists p, reverse-complement lists L - (p + k)
-	uint32_t corr = strand ? (uint32_t) (L - (p0 + k)) : (uint32_t) p0;
-	const uint32_t corr_step = strand ? (uint32_t) -(T * bpr / 2) : (uint32_t) (T * bpr / 2);
-	const uint32_t w0 = sub * 4u - 1u;   // bucket word of slot j is 4 sub + j; it holds position (4 sub + j - 1) of the list
+	const uint32_t n_items = R.n_items;
 
-	uint32_t hits = 0;
+	// wave-uniform bookkeeping lives in registers: queue length, distinct keys in the table, abort flag
+	uint32_t q_len = 0, n_keys = 0;
 	bool abort_fast = false;
-	// one vote: returns the register entry (bin | tag, or kCsEmptySlot).  The LDS atomics run under the execution mask of the
-	// lanes that have a hit: the kernel is bound by LDS bank cycles (64 random addresses on 32 banks), and lanes that are
-	// switched off cost none -- half of the bucket slots are empty, and the second atomic is needed by 2-3 % of the hits
-	auto vote = [&](uint32_t pos, uint32_t cr, bool valid, uint32_t tg) -> uint32_t {
-		uint32_t out = kCsEmptySlot;
-		if (valid) {
-			const uint32_t bin = __builtin_amdgcn_ubfe(pos - cr, (uint32_t) bin_shift, 30u);
-			const uint32_t msk = 1u << (bin & 31u);
-			const uint32_t a = bin >> 3;
-			const uint32_t old = atomicOr((uint32_t *) ((char *) plane1 + (a & a1_mask)), msk);
-			if (old & msk) atomicOr((uint32_t *) ((char *) plane2 + (a & a2_mask)), msk);
-			out = bin | tg;
+	// queue slots for this lane's `mine` entries: exclusive prefix over the lanes (no LDS counter, no same-address atomics)
+	auto reserve = [&](uint32_t mine) -> uint32_t {  // mine <= 8 * kCsFastItems <= 192
+		uint32_t total;
+		const uint32_t base = q_len + wave_prefix_small<8>(mine, total);
+		q_len += total;
+		return base;
+	};
+	// inserts the queued entries (bin | strand << 31), one per lane per round
+	auto flush_inserts = [&]() {
+		__syncthreads();
+		const uint32_t nq = min(q_len, kCsFastQueue);
+		if (n_keys + nq >= n_slots) abort_fast = true;  // could fill the table completely: leave the read to the exact path
+		uint32_t fresh = 0;
+		if (!abort_fast) for (uint32_t i = lane; i < nq; i += 64) {
+			const uint32_t e = s_queue[i];
+			const uint32_t bin = e & 0x3FFFFFFFu;
+			uint32_t slot = (bin * 2654435761u) >> hs;
+			for (;;) {
+				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+				if (prev == bin) break;
+				if (prev == 0xFFFFFFFFu) { ++fresh; break; }
+				slot = (slot + 1) & (n_slots - 1);
+			}
+			atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u);
 		}
-		return out;
+		{ uint32_t total; (void) wave_prefix_small<4>(fresh, total); n_keys += total; }  // fresh <= 12 per lane
+		if (n_keys > (n_slots * 3u) / 4u) abort_fast = true;  // probing gets slow and the spurious entries too many
+		__syncthreads();
+		q_len = 0;
 	};
 
-	// one bucket round of this wave: round r covers lists [(r T + wave) bpr, +bpr).  The load is unconditional (lanes without
-	// a list read the all-zero bucket): a load under a divergent branch makes the compiler wait for it right there (the merge
-	// copies the loaded registers), which would serialise the rounds on the memory latency.
-	auto fetch = [&](int r, CsU4 &d) {
-		const int li = (r * T + wave) * bpr + (lane >> ls);
-		const uint32_t id = l_list[min(li, A.lists_cap)];
-		d = *reinterpret_cast<const CsU4 *>(A.buckets + ((size_t) id << bw) + sub * 4u);
+	// item -> (hit count << 16 | correction, strand in bit 31) and its positions
+	auto fetch = [&](int it, CsU4 (&d)[kCsSeg / 4]) -> uint32_t {
+		const uint32_t idx = (uint32_t) it * 64u + (uint32_t) lane;
+		uint32_t meta = 0;
+		if (idx < n_items) {
+			const uint32_t item = l_items[idx];
+			const uint32_t li = CsItem<ItemT>::list(item), sg = CsItem<ItemT>::seg(item);
+			const uint32_t cnt = min((uint32_t) kCsSeg, (l_len[li] & 0xFFFFu) - sg * kCsSeg);
+			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.buckets + l_start[li] + sg * kCsSeg);
+#pragma unroll
+			for (int v = 0; v < kCsSeg / 4; ++v) if ((uint32_t) (4 * v) < cnt) d[v] = src[v];
+			const int p = (int) (li >> 1);
+			// diagonal of the hit (CS.cpp:140-142); bit 31 = reverse-complement list
+			meta = (cnt << 16) | ((li & 1u) ? ((uint32_t) (L - (p + k)) | 0x80000000u) : (uint32_t) p);
+		}
+		return meta;
 	};
 
-	uint32_t bins[ROUNDS * 4];
-	constexpr int DEPTH = kCsBucketDepth < ROUNDS ? kCsBucketDepth : ROUNDS;
-	CsU4 ring[DEPTH];
+	uint32_t bins[kCsFastItems * kCsSeg];  // bin | first-on-its-bit << 30 | reverse strand << 31 ; 0 = empty slot
+	// ring of kCsFastDepth items in flight per lane: the position loads of items it+1 .. it+depth-1 are outstanding
+	// while item it votes (the loop is fully unrolled, so the ring index is a compile-time constant)
+	constexpr int DEPTH = kCsFastDepth;
+	CsU4 ring[DEPTH][kCsSeg / 4];
+	uint32_t rmeta[DEPTH];
 #pragma unroll
-	for (int d = 0; d < DEPTH - 1; ++d) fetch(d, ring[d]);
+	for (int d = 0; d < DEPTH - 1; ++d) rmeta[d] = fetch(d, ring[d]);
 #pragma unroll
-	for (int r = 0; r < ROUNDS; ++r) {
-		// the prefetch is issued on every path: loads under a branch make the compiler's wait-count bookkeeping give up one
-		// round of pipelining per merge point (rounds past the last list read the zero bucket and are skipped below)
-		if (r + DEPTH - 1 < ROUNDS) fetch(r + DEPTH - 1, ring[(r + DEPTH - 1) % DEPTH]);
-		const CsU4 cur = ring[r % DEPTH];
-		const uint32_t cr = corr;
-		corr += corr_step;
-		if ((r * T + wave) * bpr >= n_lists) {  // wave-uniform
+	for (int it = 0; it < kCsFastItems; ++it) {
+		if ((uint32_t) it * 64u >= n_items) {  // wave-uniform
 #pragma unroll
-			for (int j = 0; j < 4; ++j) bins[r * 4 + j] = kCsEmptySlot;
+			for (int j = 0; j < kCsSeg; ++j) bins[it * kCsSeg + j] = 0;
 			continue;
 		}
-		const uint32_t hdr = (uint32_t) __shfl((int) cur.x, lane & ~(int) (lpb - 1u));
-		const uint32_t n_own = hdr & kCsHdrCountMask, n_other = (hdr >> 14) & kCsHdrCountMask;
-		const uint32_t n_used = ((int) (n_own + n_other) < A.max_kfreq) ? n_own : 0u;   // CS.cpp:122
-		hits += n_used;   // every lane of the group counts it: divided by the group size at the end
-		const bool ovf = (hdr & kCsHdrOverflow) != 0u;
-		if (ovf && n_used && sub == 0u) {   // rare
-			const uint32_t slot = atomicAdd(&s_misc[2], 1u);
-			const uint32_t li = (uint32_t) ((r * T + wave) * bpr + (lane >> ls));
-			if (slot < (uint32_t) kCsOvfLists) { l_ovf[2 * slot] = cur.y; l_ovf[2 * slot + 1] = (n_used << 11) | li; }
-		}
-		const uint32_t n_inl = ovf ? 0u : n_used;
-		const uint32_t pos[4] = {cur.x, cur.y, cur.z, cur.w};
+		if (it + DEPTH - 1 < kCsFastItems) rmeta[(it + DEPTH - 1) % DEPTH] = fetch(it + DEPTH - 1, ring[(it + DEPTH - 1) % DEPTH]);
+		const uint32_t meta = rmeta[it % DEPTH];
+		CsU4 (&cur)[kCsSeg / 4] = ring[it % DEPTH];
+		const uint32_t cnt = (meta >> 16) & 0x1Fu, corr = meta & 0xFFFFu, rev = meta & 0x80000000u;
+		// branch-free per hit (the loop is unrolled 12 x 8 times; the kernel has to stay small enough for the instruction
+		// cache): empty slots vote with an all-zero mask (a no-op on whatever plane word their garbage position selects)
+		uint32_t old[kCsSeg], msk[kCsSeg], ent[kCsSeg];
 #pragma unroll
-		for (int j = 0; j < 4; ++j) bins[r * 4 + j] = vote(pos[j], cr, (w0 + (uint32_t) j) < n_inl, tag);
-	}
-	{ uint32_t h = hits; for (int o = 32; o > 0; o >>= 1) h += __shfl_xor((int) h, o); h >>= ls; if (lane == 0 && h) atomicAdd(&s_misc[3], h); }
-	__syncthreads();
-
-	// lists longer than their bucket: 8-hit segments straight from d_positions, run-time loop, all waves
-	const uint32_t n_ovf = s_misc[2];
-	if (n_ovf > 0u && n_ovf <= (uint32_t) kCsOvfLists) {
-		if (wave == 0) {
-			const uint32_t nseg = (uint32_t) lane < n_ovf ? ((l_ovf[2 * lane + 1] >> 11) + kCsSeg - 1) / kCsSeg : 0u;
-			const uint32_t incl = wave_inclusive_scan(nseg, lane);
-			uint32_t o = incl - nseg;
-			for (uint32_t sg = 0; sg < nseg; ++sg, ++o) if (o < A.ovf_items) l_items[o] = ((uint32_t) lane << 16) | sg;
-			if (lane == 63) s_misc[5] = incl;
+		for (int j = 0; j < kCsSeg; ++j) {
+			const uint32_t pos = (j & 3) == 0 ? cur[j >> 2].x : (j & 3) == 1 ? cur[j >> 2].y : (j & 3) == 2 ? cur[j >> 2].z : cur[j >> 2].w;
+			const bool valid = (uint32_t) j < cnt;
+			const uint32_t bin = ((pos - corr) >> A.bin_shift) & 0x3FFFFFFFu;
+			const uint32_t b = __umulhi(bin * 0x9E3779B1u, pbits);
+			msk[j] = valid ? (1u << (b & 31)) : 0u;
+			old[j] = atomicOr(&plane[b >> 5], msk[j]);
+			ent[j] = bin | rev;
 		}
-		__syncthreads();
-	}
-	const uint32_t n_items = s_misc[5];
-	if (n_ovf > (uint32_t) kCsOvfLists || n_items > A.ovf_items) abort_fast = true;
-	// item -> its up to 8 positions, diagonal correction and tag
-	auto ovf_item = [&](uint32_t idx, uint32_t (&pos8)[8], uint32_t &cnt, uint32_t &cr, uint32_t &tg) {
-		const uint32_t item = l_items[idx];
-		const uint32_t lo = item >> 16, sg = item & 0xFFFFu;
-		const uint32_t meta = l_ovf[2 * lo + 1], li = meta & 0x7FFu;
-		cnt = min((uint32_t) kCsSeg, (meta >> 11) - sg * kCsSeg);
-		const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_ovf[2 * lo] + sg * kCsSeg);  // the table is padded by 16 entries
-		const CsU4 a = src[0], b = src[1];
-		pos8[0] = a.x; pos8[1] = a.y; pos8[2] = a.z; pos8[3] = a.w; pos8[4] = b.x; pos8[5] = b.y; pos8[6] = b.z; pos8[7] = b.w;
-		const uint32_t p = li >> 1;
-		tg = ((li & 1u) << 31) | 0x40000000u;
-		cr = (li & 1u) ? (uint32_t) (L - ((int) p + k)) : p;
-	};
-	if (!abort_fast) for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += 64u * T) {
-		uint32_t pos8[8], cnt, cr, tg;
-		ovf_item(idx, pos8, cnt, cr, tg);
+		uint32_t ndup = 0;
 #pragma unroll
-		for (int j = 0; j < kCsSeg; ++j) (void) vote(pos8[j], cr, (uint32_t) j < cnt, tg);
+		for (int j = 0; j < kCsSeg; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
+		uint32_t qb;
+		{ uint32_t total; qb = q_len + wave_prefix_small<4>(ndup, total); q_len += total; }  // ndup <= 8
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) {
+			const bool dup = (old[j] & msk[j]) != 0u;           // implies a valid slot
+			const bool first = msk[j] != 0u && !dup;            // valid and first on its bit
+			if (dup) { if (qb < kCsFastQueue) s_queue[qb] = ent[j]; ++qb; }
+			bins[it * kCsSeg + j] = first ? (ent[j] | 0x40000000u) : 0u;  // repeats voted in sweep 1: nothing left to do
+		}
+		const uint32_t fill = q_len;
+		if (fill > kCsFastQueue) abort_fast = true;  // more repeats than the queue holds: leave it to the exact path
+		// insert when the next item round (typically ~100 repeats) might not fit any more, and after the last one
+		if (fill > 96u || (uint32_t) (it + 1) * 64u >= n_items || it + 1 == kCsFastItems) flush_inserts();  // small batches: the table-capacity guard of flush_inserts stays loose
 	}
-	if (abort_fast) s_misc[1] = 1u;
-	__syncthreads();
 	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
-	CsRead R;
-	R.L = L; R.n_lists = n_lists; R.H = s_misc[3]; R.n_valid = s_misc[4]; R.n_items = 0;
-	if (s_misc[1] != 0u || R.H > A.hit_cap) {  // not provably exact here
-		if (A.phase_cycles && tid == 0) atomicAdd(&A.phase_cycles[R.H > A.hit_cap ? 8 : 9], 1ull);
-		if (wave == 0) cs_enqueue(A, read, lane, R);
-		return;
-	}
+	if (abort_fast) { cs_enqueue(A, read, lane, R); return; }  // not provably exact here
 
-	// sweep 2.  Lane queues in what was plane 1: entry i of lane l of wave w at [(w cap1 + i) * 64 + l], the last row takes
-	// the stores of full queues
-	const uint32_t cap = p1_words / (64u * T) - 1u;
-	uint32_t *qrow = plane1 + (uint32_t) wave * (cap + 1u) * 64u + (uint32_t) lane;
-	uint32_t cnt = 0;
+	// sweep 2: plane := bits of the bins that are in the table; first-on-bit hits whose bit is set are queued, then added
+	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
+	__syncthreads();
+	for (uint32_t s = lane; s < n_slots; s += 64) {
+		const uint32_t key = t_keys[s];
+		if (key != 0xFFFFFFFFu) {
+			const uint32_t b = __umulhi(key * 0x9E3779B1u, pbits);
+			atomicOr(&plane[b >> 5], 1u << (b & 31));
+		}
+	}
+	__syncthreads();
+	uint32_t nhit = 0;
+	uint32_t wmask[kCsFastItems];
 #pragma unroll
-	for (int r = 0; r < ROUNDS; ++r) {
-		if ((r * T + wave) * bpr >= n_lists) continue;  // wave-uniform
+	for (int it = 0; it < kCsFastItems; ++it) {
+		wmask[it] = 0;
+		if ((uint32_t) it * 64u >= n_items) continue;
 #pragma unroll
-		for (int j = 0; j < 4; ++j) {
-			const uint32_t e = bins[r * 4 + j];
-			if (e != kCsEmptySlot) {
-				const uint32_t w = *(const uint32_t *) ((const char *) plane2 + ((e >> 3) & a2_mask));
-				if ((w >> (e & 31u)) & 1u) { qrow[min(cnt, cap) * 64u] = e; ++cnt; }
+		for (int j = 0; j < kCsSeg; ++j) {
+			const uint32_t e = bins[it * kCsSeg + j];
+			const uint32_t b = __umulhi((e & 0x3FFFFFFFu) * 0x9E3779B1u, pbits);
+			const uint32_t w = (plane[b >> 5] >> (b & 31)) & (e >> 30) & 1u;  // bit 30 = first on its bit (0 for empty slots)
+			wmask[it] |= w << j;
+		}
+		nhit += __popc(wmask[it]);
+	}
+	uint32_t qb = reserve(nhit);
+#pragma unroll
+	for (int it = 0; it < kCsFastItems; ++it) {
+		if (wmask[it])
+#pragma unroll
+			for (int j = 0; j < kCsSeg; ++j) if ((wmask[it] >> j) & 1u) { if (qb < kCsFastQueue) s_queue[qb] = bins[it * kCsSeg + j]; ++qb; }
+	}
+	__syncthreads();
+	if (q_len > kCsFastQueue) abort_fast = true;
+	{
+		// add the votes of the queued first hits whose bin is in the table (a set bit may also be a collision)
+		const uint32_t nq = min(q_len, kCsFastQueue);
+		for (uint32_t i = lane; i < nq; i += 64) {
+			const uint32_t e = s_queue[i];
+			const uint32_t bin = e & 0x3FFFFFFFu;
+			uint32_t slot = (bin * 2654435761u) >> hs;
+			for (;;) {
+				const uint32_t key = t_keys[slot];
+				if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); break; }
+				if (key == 0xFFFFFFFFu) break;
+				slot = (slot + 1) & (n_slots - 1);
 			}
 		}
 	}
-	// (plane 1 is only written above by its own wave's lanes: no barrier needed before the queues are read back)
-	auto insert = [&](uint32_t e) -> bool {
-		const uint32_t bin = e & 0x3FFFFFFFu;
-		uint32_t slot = (bin * 2654435761u) >> hs;
-		for (uint32_t probes = 0; probes < n_slots; ++probes) {
-			const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
-			if (prev == bin || prev == 0xFFFFFFFFu) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); return true; }
-			slot = (slot + 1) & (n_slots - 1);
-		}
-		return false;
-	};
-	bool lost = cnt > cap;
-	if (A.phase_cycles) {  // diagnostics: [4] queue entries [5] reads with a full lane queue
-		uint32_t t = cnt; for (int o = 32; o > 0; o >>= 1) t += __shfl_xor((int) t, o);
-		if (lane == 0) { atomicAdd(&A.phase_cycles[4], (unsigned long long) t); if (__ballot(cnt > cap)) atomicAdd(&A.phase_cycles[5], 1ull); }
-	}
-	{
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		const uint32_t mx = (uint32_t) wave_reduce_max((int) min(cnt, cap));
-		for (uint32_t i = 0; i < mx; ++i) if (i < cnt) { if (!insert(qrow[i * 64u])) lost = true; }
-	}
-	for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += 64u * T) {  // the overflow lists again (L2 / Infinity Cache hits)
-		uint32_t pos8[8], n8, cr, tg;
-		ovf_item(idx, pos8, n8, cr, tg);
-		for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < n8) {
-			const uint32_t bin = __builtin_amdgcn_ubfe(pos8[j] - cr, (uint32_t) bin_shift, 30u);
-			const uint32_t w = *(const uint32_t *) ((const char *) plane2 + ((bin >> 3) & a2_mask));
-			if ((w >> (bin & 31u)) & 1u) { if (!insert(bin | tg)) lost = true; }
-		}
-	}
-	if (__ballot(lost)) s_misc[1] = 1u;
 	__syncthreads();
 	const unsigned long long c3 = diag ? wall_clock64() : 0ull;
-	if (wave != 0) return;
-	if (s_misc[1] != 0u) { cs_enqueue(A, read, lane, R); return; }
-	{
-		// more than 3/4 full: too many spurious entries for this table -- the exact path has the room
-		uint32_t keys = 0;
-		for (uint32_t s2 = lane; s2 < n_slots; s2 += 64) keys += t_keys[s2] != 0xFFFFFFFFu;
-		for (int o = 32; o > 0; o >>= 1) keys += __shfl_xor((int) keys, o);
-		if (A.phase_cycles && lane == 0) { atomicAdd(&A.phase_cycles[6], (unsigned long long) keys); if (keys > (n_slots * 3u) / 4u) atomicAdd(&A.phase_cycles[7], 1ull); }
-		if (keys > (n_slots * 3u) / 4u) { cs_enqueue(A, read, lane, R); return; }
-	}
+	if (abort_fast) { cs_enqueue(A, read, lane, R); return; }
 	if (!cs_finish<kCsFast>(A, read, lane, R, t_keys, t_votes, n_slots)) cs_enqueue(A, read, lane, R);
 	if (diag && lane == 0) {  // diagnostics: 100 MHz ticks spent per phase, summed over the sampled reads
 		atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);

@@ -59,9 +59,7 @@ struct ngm_mapper {
 	uint32_t cs_plane_bits = 65536;
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
-	bool cs_fast_ok = true;           // the fast path's rounds cover every list of a read of qry_max_len
-	int cs_waves = 1;                 // waves per read of the fast path (cs_bucket_kernel<kCsRounds, T>)
-	uint32_t cs_ovf_items = 128;      // LDS room for 8-hit segments of lists longer than an index bucket
+	int cs_fast_items = ngm::kCsFastItemsShort;
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
@@ -113,28 +111,10 @@ struct DevGuard {
 };
 
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
-	if (mode == ngm::kCsFast) return (size_t) ngm::cs_fast_lds_words(A.q, A.lists_cap, A.plane_bits, A.log2_slots, A.ovf_items) * 4;
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
+	if (mode == ngm::kCsFast) w += ((size_t) A.plane_bits >> 5) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) + ((size_t) 3 << A.log2_slots) / 4;
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
-}
-
-// fast path: T waves per read, kCsRounds bucket rounds per wave (T from the list count: T * kCsRounds rounds must cover them)
-constexpr int kCsRounds = 36, kCsRounds8 = 32;
-int cs_rounds_covered(int waves) { return waves == 1 ? kCsRounds : waves == 2 ? kCsRounds : waves == 4 ? 2 * kCsRounds : 8 * kCsRounds8; }
-void launch_cs_fast(int waves, int n, size_t lds, hipStream_t st, const ngm::CsArgs &A) {
-	switch (waves) {
-	case 1: hipLaunchKernelGGL((ngm::cs_bucket_kernel<kCsRounds, 1>), dim3(n), dim3(64), lds, st, A); break;
-	case 2: hipLaunchKernelGGL((ngm::cs_bucket_kernel<kCsRounds / 2, 2>), dim3(n), dim3(128), lds, st, A); break;
-	case 4: hipLaunchKernelGGL((ngm::cs_bucket_kernel<kCsRounds / 2, 4>), dim3(n), dim3(256), lds, st, A); break;
-	default: hipLaunchKernelGGL((ngm::cs_bucket_kernel<kCsRounds8, 8>), dim3(n), dim3(512), lds, st, A); break;
-	}
-}
-void set_cs_fast_lds_limit(int bytes) {
-	(void) hipFuncSetAttribute((const void *) ngm::cs_bucket_kernel<kCsRounds, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_bucket_kernel<kCsRounds / 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_bucket_kernel<kCsRounds / 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_bucket_kernel<kCsRounds8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 // candidate search for the reads already in m->d_reads; leaves per-read base/count/max votes and the
@@ -174,12 +154,17 @@ int run_cs(ngm_mapper *m, int n) {
 		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) { m->cs_kernel_ms += t; pass_ms[e / 2] = t; } };
 
 		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
-		A.log2_bits = m->cs_log2_bits; A.plane_bits = m->cs_plane_bits; A.log2_slots = m->cs_log2_small;
-		A.buckets = r->d_buckets; A.bucket_log2_words = r->bucket_log2_words; A.ovf_items = m->cs_ovf_items;
+		A.log2_bits = m->cs_log2_bits; A.plane_bits = m->cs_plane_bits; A.log2_slots = m->cs_log2_small; A.fast_items = m->cs_fast_items;
+		A.buckets = r->d_buckets; A.bucket_log2_words = r->bucket_log2_words; A.pos_base = r->bucket_pos_base;
 		A.hit_cap = m->cs_plane_bits / 6u;
-		if (A.bin_shift < 2 || !m->cs_fast_ok) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
+		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
-		launch_cs_fast(m->cs_waves, n, cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		// 16-bit work items when every list index fits 9 bits and no used list can have more than 128 segments
+		A.items16 = (A.lists_cap <= 512 && m->max_kfreq <= 128 * ngm::kCsSeg) ? 1 : 0;
+		if (!A.items16) A.fast_items = ngm::kCsFastItemsLong;  // the 32-bit item list only exists in the large size
+		if (A.fast_items == ngm::kCsFastItemsShort && A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		else if (A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		else hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
@@ -269,9 +254,6 @@ int run_cs(ngm_mapper *m, int n) {
 			if (A.phase_cycles)
 				fprintf(stderr, "[ngm-hip] cs fast path, 100 MHz ticks per read: lists %.1f sweep1 %.1f sweep2 %.1f candidates %.1f; %u of %d reads re-run by the exact path; kernels %.2f + %.2f + %.2f ms\n",
 						(double) ph[0] * 256 / n, (double) ph[1] * 256 / n, (double) ph[2] * 256 / n, (double) ph[3] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
-			if (A.phase_cycles)
-				fprintf(stderr, "[ngm-hip] cs fast path: queue entries per read %.1f, table keys per read %.1f; reads leaving the fast path: lane queue full %llu, table > 3/4 %llu, "
-						"too many hits %llu, sweep-1 abort %llu\n", (double) ph[4] / n, (double) ph[6] / n, ph[5], ph[7], ph[8], ph[9]);
 			return 0;
 		}
 		cap *= 4;  // candidate buffer too small: grow and redo the batch
@@ -387,7 +369,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
 	for (auto &e : m->cev) (void) hipEventCreate(&e);
 	// fast-path geometry from the expected hits per read H = 2 (q - k) lists x average list length:
-	// bit plane: the power of two >= 12 H bits (6-8 % of the single background hits collide and survive the filter),
+	// bit planes >= 12 H bits (6-8 % of the single background hits collide and survive the filter),
 	// small exact table for the survivors + the real signal with headroom
 	{
 		const double avg_list = (double) ref->n_entries / (double) (1ull << (2 * ref->prm.kmer));
@@ -395,36 +377,29 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		int lb = 12;
 		while ((double) (1u << lb) < 12.0 * hexp && lb < 17) ++lb;
 		m->cs_log2_bits = lb;
-		m->cs_plane_bits = 1u << lb;
-		// table of 2^ls slots, 3/4 of which may fill.  Keys = the bins whose plane-2 bit is set: both partners of every
-		// plane-1 collision (H^2 / P), the real repeats (~3 % of the hits), and what collides with those in the four times
-		// smaller plane 2 -- with headroom
-		auto table_log2 = [&](double P) {
-			const double dups = hexp * hexp / (2.0 * P) + 0.03 * hexp;
-			const double keys = 2.0 * hexp * hexp / (2.0 * P) + 0.03 * hexp + dups / (P / 4.0) * hexp;
+		// plane of P bits (any multiple of 2048 from 12 bits per expected hit up to the next power of two) and table of
+		// 2^ls slots, 3/4 of which may fill: entries = hits that find their bit already set -- H^2 / (2 P) by collision
+		// -- plus the real repeats, with headroom.  Take the pair that needs the least LDS.
+		size_t best_bytes = ~(size_t) 0;
+		const double p_lo = std::min(131072.0, std::max(4096.0, ceil(12.0 * hexp / 2048.0) * 2048.0)), p_hi = (double) (1u << lb);
+		for (double P = p_lo; P <= p_hi; P += 2048.0) {
 			int ls = 8;
-			while (0.75 * (double) (1u << ls) < 1.3 * keys + 100.0 && ls < 12) ++ls;
-			return ls;
-		};
-		m->cs_log2_small = table_log2((double) m->cs_plane_bits);
-		// waves per read: every wave takes kCsRounds (one wave) or kCsRounds / 2 bucket rounds of 64 / (W / 4) lists
-		const int n_lists = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1);
-		const int bpr = 64 >> (ref->bucket_log2_words - 2);
-		const int rounds = (n_lists + bpr - 1) / bpr;
-		m->cs_waves = rounds <= cs_rounds_covered(2) ? 2 : rounds <= cs_rounds_covered(4) ? 4 : 8;
-		if (const char *e = getenv("NGM_HIP_CS_WAVES")) {  // tests / tuning: 1, 2, 4 or 8 (if they cover the lists)
-			const int w = atoi(e);
-			if ((w == 1 || w == 2 || w == 4 || w == 8) && rounds <= cs_rounds_covered(w)) m->cs_waves = w;
+			while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * P) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
+			const size_t bytes = (size_t) P / 8 + ((size_t) 8 << ls) + ((size_t) 3 << ls);  // plane + keys/votes + queue
+			if (bytes < best_bytes) { best_bytes = bytes; m->cs_plane_bits = (uint32_t) P; m->cs_log2_small = ls; }
 		}
-		m->cs_fast_ok = rounds <= cs_rounds_covered(m->cs_waves);
-		// sweep 2 keeps one queue row of 64 entries per wave per 2048 plane bits: at least 8 rows per wave
-		while (m->cs_plane_bits < 16384u * (uint32_t) m->cs_waves) m->cs_plane_bits <<= 1;
-		m->cs_log2_small = table_log2((double) m->cs_plane_bits);
-		if (const char *e = getenv("NGM_HIP_CS_OVF_ITEMS")) m->cs_ovf_items = (uint32_t) std::max(8, atoi(e));
+		// expected 8-hit segments per read: every list contributes its hits / 8 plus, on average, 7/16 of a segment of slack
+		const double segs = hexp / 8.0 + 0.44 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
+		m->cs_fast_items = segs * 1.10 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
+		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
-	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17; A.plane_bits = 131072; A.ovf_items = 4096;
-	set_cs_fast_lds_limit(std::min(160 * 1024, (int) cs_lds_bytes(A, ngm::kCsFast)));
+	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17; A.plane_bits = 131072;
+	A.fast_items = ngm::kCsFastItemsLong;
+	A.items16 = 0;
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));

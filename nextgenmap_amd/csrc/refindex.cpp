@@ -158,11 +158,16 @@ int build_buckets(ngm_ref *r) {
 	int lw = 2;
 	while (lw < 5 && (double) ((1 << lw) - 1) < mu + 4.0 * sqrt(mu) + 0.5) ++lw;
 	if (const char *e = getenv("NGM_HIP_BUCKET_LOG2_WORDS")) lw = std::max(2, std::min(5, atoi(e)));  // tests
+	// the buckets are followed by a copy of the position table, so that one 32-bit word offset addresses an inline list and a
+	// list that did not fit alike; both must stay below 2^32 words
+	while (lw > 2 && (((uint64_t) n_kmers + 1) << lw) + r->n_entries + 16 >= 0xFFFFFFFFull) --lw;
 	r->bucket_log2_words = lw;
 	const uint64_t words = ((uint64_t) n_kmers + 1) << lw;
-	REF_HIP_TRY(hipMalloc(&r->d_buckets, words * 4));
+	r->bucket_pos_base = (uint32_t) words;
+	REF_HIP_TRY(hipMalloc(&r->d_buckets, (words + r->n_entries + 16) * 4));
 	hipLaunchKernelGGL(fill_buckets_kernel, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, 0, n_kmers, k, lw, r->d_index, r->d_positions, r->d_buckets);
 	REF_HIP_TRY(hipGetLastError());
+	REF_HIP_TRY(hipMemcpy(r->d_buckets + words, r->d_positions, (r->n_entries + 16) * 4, hipMemcpyDeviceToDevice));
 	REF_HIP_TRY(hipDeviceSynchronize());
 	return 0;
 }

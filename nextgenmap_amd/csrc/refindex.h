@@ -15,7 +15,8 @@
 //                 k-mer, {count, position 0 .. W-2}, so that a lookup is ONE memory request instead of index entry ->
 //                 position list (measured on MI355X, profiles/r02_gather_calibration.txt: random gathers are bound by
 //                 ~50 G requests/s whatever their size up to 128 B, where they reach the 6.2 TB/s streaming ceiling).
-//                 Lists longer than W-1 keep {count | 1<<31, offset into d_positions}.  W from the mean list length
+//                 Lists longer than W-1 keep {count | 1<<31, offset into the position table}; a copy of that table follows the
+//                 buckets in the same allocation, so one 32-bit word offset addresses either kind of list.  W from the mean list length
 //                 (GRCh38 size: 15.4 -> W = 32, 128 B, 99.98 % of the lists inline)                -- 8.6 GB
 #pragma once
 
@@ -51,6 +52,7 @@ struct ngm_ref {
 	uint32_t *d_positions = nullptr;
 	uint32_t *d_buckets = nullptr;
 	int bucket_log2_words = 2;        // W = 1 << bucket_log2_words dwords per k-mer bucket
+	uint32_t bucket_pos_base = 0;     // word offset of the position table copy that follows the buckets in d_buckets
 	double overflow_hit_share = 0.0;  // share of all index entries that live in lists longer than W-1
 };
 

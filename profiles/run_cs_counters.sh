@@ -11,7 +11,7 @@ GROUPS_=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 SEL=${@:-1 2 3 4}
 for i in $SEL; do
   grp=${GROUPS_[$((i-1))]}
-  timeout 900 rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/cs_pmc/g$i -o g$i -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --workers 1 > $R/gpurun_out/cs_pmc/g$i.log 2>&1
+  timeout 900 rocprofv3 --pmc $grp --kernel-trace -d $R/gpurun_out/cs_pmc/g$i -o g$i -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --workers 1 > $R/gpurun_out/cs_pmc/g$i.log 2>&1
 done
 cd $R
 python - <<'PY' | tee gpurun_out/cs_pmc/summary.txt

@@ -99,8 +99,17 @@ def test_bam_equals_reference_program(tmp_path, layout, extra):
     strip = lambda t: [l.split("\tCL:")[0] if l.startswith("@PG") else l for l in t.splitlines()]
     assert strip(ta) == strip(tb), (ta, tb)
     assert len(a) == len(b) and len(a) >= 4000
-    diff = [(x, y) for x, y in zip(a, b) if x != y]
-    print("records differing:", len(diff), "of", len(a), "; unmapped:", sum(1 for x in a if x["flag"] & 4))
+    # the reference writes reads without candidates as soon as the search is done and the others after the alignment stage
+    # (src/CS.cpp, src/AlignmentBuffer.cpp): its record ORDER is not the input order; compare per read (and mate)
+    def by_read(recs):
+        out = {}
+        for x in recs:
+            out.setdefault((x["name"], x["flag"] & 0xC0), []).append(tuple(sorted((k, v) for k, v in x.items())))
+        return {k: sorted(v) for k, v in out.items()}
+    da, db = by_read(a), by_read(b)
+    assert set(da) == set(db)
+    diff = [(da[k], db[k]) for k in da if da[k] != db[k]]
+    print("reads differing:", len(diff), "of", len(da), "; unmapped:", sum(1 for x in a if x["flag"] & 4))
     for x, y in diff[:3]:
-        print({k: (x[k], y[k]) for k in x if x[k] != y[k]})
+        print([(u, v) for u, v in zip(x[0], y[0]) if u != v])
     assert not diff
