@@ -673,9 +673,10 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	uint32_t *t_votes = t_keys + n_slots;   // final votes: forward | reverse << 16
 	uint32_t *t_run = t_votes + n_slots;    // votes so far during the replay
 	uint32_t *t_rank = t_run + n_slots;
-	uint32_t *ev_at = t_rank + n_slots;     // [kCsOrderMaxHits]: slot | strand << 31 of the hit at that time, or empty (reads with more hits: global memory)
+	uint32_t *t_cand = t_rank + n_slots;    // 1: the bin is one of the read's candidates (tracked even with a single vote)
+	uint32_t *ev_at = t_cand + n_slots;     // [kCsOrderMaxHits]: slot | strand << 31 of the hit at that time, or empty (reads with more hits: global memory)
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
-	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; }
+	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; t_cand[s] = 0; }
 	if (lane == 0) s_keys = 0;
 	uint32_t *l_items = ev_at + kCsOrderMaxHits;  // [kCsOrderItemCap]
 	const CsRead R = cs_prepare<true, uint32_t>(A, read, lane, l_start, l_pref, l_code, l_items, kCsOrderItemCap);
@@ -689,6 +690,22 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	if (big) {
 		if (!A.order_scratch || H > A.order_gcap || H >= 65536u) { give_up(); return; }
 		ev_at = A.order_scratch + (size_t) blockIdx.x * A.order_gcap;
+	}
+	__syncthreads();
+	// the candidates themselves are tracked whatever their votes: with a final threshold <= 1 (few votes: sensitive settings,
+	// diverged reads) single-vote bins are candidates too, and entered rList at their only hit
+	{
+		const uint32_t centre0 = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
+		for (uint32_t c = lane; c < cn; c += 64) {
+			const uint32_t bin = ((cand_loc[cb + c] - centre0) >> A.bin_shift) & 0x3FFFFFFFu;
+			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+			for (uint32_t probes = 0; probes < n_slots; ++probes) {
+				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+				if (prev == bin) { t_cand[slot] = 1u; break; }
+				if (prev == 0xFFFFFFFFu) { atomicAdd(&s_keys, 1u); t_cand[slot] = 1u; break; }
+				slot = (slot + 1) & (n_slots - 1);
+			}
+		}
 	}
 	__syncthreads();
 	auto bin_of = [&](uint32_t pos, int li) -> uint32_t {
@@ -784,7 +801,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		uint32_t e = (t < H) ? ev_at[t] : 0xFFFFFFFFu;
 		if (e != 0xFFFFFFFFu) {
 			const uint32_t v = t_votes[e & 0x7FFFFFFFu];
-			if ((v & 0xFFFFu) + (v >> 16) < 2u) e = 0xFFFFFFFFu;
+			if ((v & 0xFFFFu) + (v >> 16) < 2u && !t_cand[e & 0x7FFFFFFFu]) e = 0xFFFFFFFFu;
 		}
 		unsigned long long todo = __ballot(e != 0xFFFFFFFFu);
 		while (todo) {
@@ -813,8 +830,6 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 			if (key == 0xFFFFFFFFu) break;
 			slot = (slot + 1) & (n_slots - 1);
 		}
-		// a candidate with a single vote (possible only when the final threshold is <= 1) entered rList at its only hit:
-		// not tracked here, its order stays unknown and the caller falls back to the position order for that read
 		cand_rank[cb + c] = rank;
 	}
 }

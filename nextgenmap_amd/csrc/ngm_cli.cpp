@@ -24,6 +24,7 @@
 // Paired-end tie-breaks see the same running mean insert size as `ngm -t 1` (ngm_pair_state: batches take turns for that
 // part only), so the output does not depend on the number of workers or GPUs.
 #include <fcntl.h>
+#include <malloc.h>
 #include <getopt.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -116,7 +117,7 @@ struct Opts {
 	std::string rg[12];  // read group: ID CN DS DT FO KS LB PG PI PL PU SM (SAMWriter.cpp:46-80)
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
 	float sensitivity = -1.f, kmer_min = 0.f, min_identity = 0.65f, min_residues = 0.5f;
-	int batch = 1 << 20;
+	int batch = 1 << 18;
 	std::string cmdline;
 };
 
@@ -263,6 +264,19 @@ struct MappedFile {
 		return true;
 	}
 	~MappedFile() { if (p) munmap((void *) p, n); if (fd >= 0) close(fd); }
+	// touch every page from the pool threads: the page-table entries of a multi-GB input are then set up in parallel instead
+	// of one minor fault at a time under the (single) splitter thread
+	void prefault() const {
+		if (!p) return;
+		const size_t step = (size_t) 8 << 20;
+		const int chunks = (int) ((n + step - 1) / step);
+		std::atomic<unsigned> sink{0};
+		ngm::ThreadPool::instance().parallel_for(chunks, [&](int lo, int hi) {
+			unsigned acc = 0;
+			for (int c = lo; c < hi; ++c) for (size_t o = (size_t) c * step, e = std::min(n, o + step); o < e; o += 4096) acc += (unsigned char) p[o];
+			sink += acc;
+		}, 1);
+	}
 	// one 4-line record starting at `at`: sets the views, returns the offset of the next record, or 0 if malformed
 	size_t record(size_t at, Rec &r) const {
 		const char *b = p + at, *end = p + n;
@@ -366,6 +380,12 @@ inline void put_identity(std::string &s, float identity) {
 }  // namespace
 
 int main(int argc, char **argv) {
+	// every batch allocates and frees a few hundred MB in MB-sized pieces from ~64 threads (output chunks, record views): with
+	// glibc's defaults each of them is an mmap / page-fault / munmap cycle, and the kernel's address-space lock serialises the
+	// formatter threads (measured: 55 ms per 256 k reads instead of ~2).  Keep that memory in the heap.
+	mallopt(M_MMAP_THRESHOLD, 32 << 20);
+	mallopt(M_TRIM_THRESHOLD, 1 << 30);
+	mallopt(M_TOP_PAD, 64 << 20);
 	Opts o = parse(argc, argv);
 	ngm_ref_params rp{o.kmer, o.kmer_skip, o.bin_size};
 	info("MAIN", "NextGenMap-compatible HIP backend (gfx950)");
@@ -404,6 +424,7 @@ int main(int argc, char **argv) {
 		};
 		MappedFile pf;
 		if (!o.serial_reader && pf.open(first_input.c_str()) && pf.plain_fastq()) {
+			pf.prefault();
 			Rec rec;
 			for (size_t at = 0; !finish && at < pf.n;) {
 				const size_t nx = pf.record(at, rec);
@@ -476,6 +497,11 @@ int main(int argc, char **argv) {
 			else if (o.sensitive) modifier = -0.35f * sens;
 			sens += modifier;
 			estimated = true;
+			// the reference hands the estimate to the search through its string-typed configuration: Override("sensitivity",
+			// float) prints it with "%f" (src/config/Config.cpp:185-189) and CS reads it back with atof -- six decimals.  On a
+			// threshold like 29 votes x 0.7241379 = 21 that rounding decides whether a 21-vote region is a candidate (found by
+			// the drop-in run of the real program, tests/test_gpu_dropin.py)
+			{ char b[32]; snprintf(b, sizeof(b), "%f", sens); sens = (float) atof(b); }
 		}
 	}
 	if (o.sensitivity >= 0) sens = o.sensitivity;
@@ -484,9 +510,19 @@ int main(int argc, char **argv) {
 
 
 	// ---- output ------------------------------------------------------------------------------------------------------
-	FILE *out = fopen(o.out.c_str(), "w");
-	if (!out) die("cannot write " + o.out);
-	setvbuf(out, nullptr, _IONBF, 0);  // whole batches are written at once
+	// the output is written with pwrite at offsets the writer thread hands out in input order, by pool threads: copying 400+
+	// bytes per read into the page cache from ONE thread would bound the whole program at a few million reads per second
+	const int out_fd = ::open(o.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (out_fd < 0) die("cannot write " + o.out);
+	uint64_t out_off = 0;
+	auto put_all = [&](const char *p, size_t n, uint64_t off) -> bool {
+		while (n) {
+			const ssize_t w = pwrite(out_fd, p, n, (off_t) off);
+			if (w <= 0) return false;
+			p += w; n -= (size_t) w; off += (uint64_t) w;
+		}
+		return true;
+	};
 	std::vector<std::string> contig_names;
 	std::vector<uint64_t> contig_lens;
 	for (int i = 0; i < ngm_ref_contig_count(ref); ++i) { contig_names.push_back(ngm_ref_contig_name(ref, i)); contig_lens.push_back(ngm_ref_contig_len(ref, i)); }
@@ -503,7 +539,8 @@ int main(int argc, char **argv) {
 			for (size_t i = 0; i < contig_names.size(); ++i) { h += "@SQ\tSN:" + contig_names[i] + "\tLN:"; put_u64(h, contig_lens[i]); h += "\n"; }
 			h += "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"" + o.cmdline + "\"\n";
 			h += rg;
-			fwrite(h.data(), 1, h.size(), out);
+			if (!put_all(h.data(), h.size(), out_off)) die("write error on " + o.out);
+			out_off += h.size();
 		} else {
 			// BAMWriter::DoWriteProlog (BAMWriter.cpp:18-110) through bamtools' SamFormatPrinter: @HD, @RG, @PG (ID PN CL VN); the
 			// contigs only in the binary dictionary
@@ -512,7 +549,8 @@ int main(int argc, char **argv) {
 			std::string raw, z;
 			ngm::bam::put_header(raw, h, contig_names, contig_lens);
 			if (!ngm::bam::bgzf_compress(raw.data(), raw.size(), z)) die("BGZF compression failed");
-			fwrite(z.data(), 1, z.size(), out);
+			if (!put_all(z.data(), z.size(), out_off)) die("write error on " + o.out);
+			out_off += z.size();
 		}
 	}
 	const std::string rg_mapped = o.rg[0].empty() ? std::string() : "RG:Z:" + o.rg[0] + "\t";
@@ -727,6 +765,7 @@ int main(int argc, char **argv) {
 	MappedFile mf0, mf1;
 	bool plain = !o.serial_reader && mf0.open(path0.c_str()) && mf0.plain_fastq();
 	if (plain && !path1.empty()) plain = mf1.open(path1.c_str()) && mf1.plain_fastq();
+	if (plain) { mf0.prefault(); mf1.prefault(); }
 	const int batch_reads = o.paired ? (o.batch & ~1) : o.batch;
 
 	auto strip_mate = [&](const char *name, uint32_t &len) {  // ReadProvider::NextRead (ReadProvider.cpp:419-422)
@@ -758,11 +797,14 @@ int main(int argc, char **argv) {
 			while (!failed && (at0 < mf0.n)) {
 				auto b = std::make_unique<Batch>();
 				b->seq = seq++;
+				std::thread other;  // two files: the second one is scanned by a helper thread at the same time
+				int n1 = 0;
+				if (two) other = std::thread([&] { n1 = skip(mf1, at1, per_file, b->sub1); });
 				b->n0 = skip(mf0, at0, per_file, b->sub0);
-				if (b->n0 < 0) break;
+				if (two) other.join();
+				if (b->n0 < 0 || n1 < 0) break;
 				if (two) {
-					b->n1 = skip(mf1, at1, b->n0, b->sub1);
-					if (b->n1 < 0) break;
+					b->n1 = n1;
 					if (b->n1 != b->n0) { fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode."); break; }
 				}
 				b->n = b->n0 + b->n1;
@@ -794,9 +836,15 @@ int main(int argc, char **argv) {
 		q_in.close();
 	});
 
+	std::atomic<long long> t_wait_us{0}, t_parse_us{0}, t_map_us{0}, t_format_us{0};
+	auto us_since = [](std::chrono::steady_clock::time_point t0) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
 	auto worker_main = [&](Worker &w) {
 		std::unique_ptr<Batch> b;
-		while (q_in.pop(b)) {
+		for (;;) {
+			auto tw = std::chrono::steady_clock::now();
+			if (!q_in.pop(b)) break;
+			t_wait_us += us_since(tw);
+			auto tp = std::chrono::steady_clock::now();
 			if (failed) { ngm_mapper_set_batch_seq(w.m, b->seq); if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
 			const int n = b->n;
 			if ((size_t) n * q > w.rows_cap) {
@@ -854,10 +902,14 @@ int main(int argc, char **argv) {
 			}
 			ngm_mapper_set_batch_seq(w.m, b->seq);
 			if (failed) { if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
+			t_parse_us += us_since(tp);
+			auto tm = std::chrono::steady_clock::now();
 			w.hits.resize((size_t) n * topn); w.cig.resize((size_t) n * topn * stride); w.md.resize((size_t) n * topn * stride);
 			const int rc = o.paired ? ngm_mapper_map_pe(w.m, n, w.rows, w.hits.data(), w.cig.data(), w.md.data())
 			                        : ngm_mapper_map_se(w.m, n, w.rows, w.hits.data(), w.cig.data(), w.md.data());
 			if (rc < 0) { fail(ngm_pipeline_last_error()); continue; }
+			t_map_us += us_since(tm);
+			auto tf = std::chrono::steady_clock::now();
 			// format: chunks of whole pairs
 			const int units = o.paired ? n / 2 : n, per = o.paired ? 2 : 1;
 			const int n_chunks = std::max(1, std::min(units / 2048 + 1, pool.size() * 2));
@@ -877,6 +929,7 @@ int main(int argc, char **argv) {
 			}, 1);
 			for (int c = 0; c < n_chunks; ++c) { b->n_total += ct[c]; b->n_mapped += cm[c]; b->n_written += cw[c]; }
 			b->recs.clear(); b->recs.shrink_to_fit(); b->owned.clear(); b->owned.shrink_to_fit();
+			t_format_us += us_since(tf);
 			{
 				std::lock_guard<std::mutex> lk(out_mu);
 				out_ready[b->seq] = std::move(b);
@@ -897,7 +950,11 @@ int main(int argc, char **argv) {
 				b = std::move(it->second);
 				out_ready.erase(it);
 			}
-			for (const std::string &c : b->chunks) if (!c.empty() && fwrite(c.data(), 1, c.size(), out) != c.size()) fail("write error on " + o.out);
+			std::vector<uint64_t> offs(b->chunks.size());
+			for (size_t c = 0; c < b->chunks.size(); ++c) { offs[c] = out_off; out_off += b->chunks[c].size(); }
+			pool.parallel_for((int) b->chunks.size(), [&](int lo, int hi) {
+				for (int c = lo; c < hi; ++c) if (!b->chunks[c].empty() && !put_all(b->chunks[c].data(), b->chunks[c].size(), offs[c])) fail("write error on " + o.out);
+			}, 1);
 			n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written;
 			++next;
 		}
@@ -911,8 +968,8 @@ int main(int argc, char **argv) {
 	{ std::lock_guard<std::mutex> lk(out_mu); workers_done = true; }
 	out_cv.notify_all();
 	writer.join();
-	if (o.bam) { std::string z; ngm::bam::bgzf_eof(z); fwrite(z.data(), 1, z.size(), out); }
-	fclose(out);
+	if (o.bam) { std::string z; ngm::bam::bgzf_eof(z); if (!put_all(z.data(), z.size(), out_off)) fail("write error on " + o.out); out_off += z.size(); }
+	if (close(out_fd) != 0) fail("write error on " + o.out);
 	if (failed) die(fail_msg);
 	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 	snprintf(msg, sizeof(msg), "Done (%zu reads mapped (%.2f%%), %zu reads not mapped, %zu lines written)", n_mapped,
@@ -924,6 +981,11 @@ int main(int argc, char **argv) {
 	snprintf(msg, sizeof(msg), "Input to output: %.3f s (estimation pass + mapping pass, first input byte to output closed)",
 			std::chrono::duration<double>(std::chrono::steady_clock::now() - t_input).count());
 	info("MAIN", msg);
+	if (getenv("NGM_HIP_HOST_TIMING")) {
+		snprintf(msg, sizeof(msg), "Worker time summed over %zu workers, s: waiting for input %.3f | parse + pack %.3f | map (GPU + library host stages) %.3f | format %.3f",
+				workers.size(), t_wait_us / 1e6, t_parse_us / 1e6, t_map_us / 1e6, t_format_us / 1e6);
+		info("MAIN", msg);
+	}
 	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); }
 	ngm_pair_state_destroy(pair_state);
 	for (ngm_ref *r2 : refs) ngm_ref_destroy(r2);

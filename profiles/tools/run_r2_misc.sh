@@ -1,4 +1,9 @@
 mkdir -p gpurun_out/r2
-hipcc --offload-arch=gfx950 -O3 profiles/tools/lds_atomic_calib.hip -o gpurun_out/r2/lds_calib && gpurun_out/r2/lds_calib | tee gpurun_out/r2/lds_calib.txt; rm -f gpurun_out/r2/lds_calib
-timeout 900 python -m pytest tests/test_gpu_tails.py -x -q -m gpu 2>&1 | tail -8
-timeout 1500 python -m pytest tests/test_gpu_bam.py tests/test_gpu_configs.py -q -m gpu 2>&1 | tail -12
+NGM_HIP_HOST_TIMING=1 timeout 1500 python bench.py > gpurun_out/r2/bench_default.log 2>&1; tail -1 gpurun_out/r2/bench_default.log | cut -c1-300; grep "host wall\|pair selection ms" gpurun_out/r2/bench_default.log | tail -4
+python - <<'PY'
+import json
+l=[x for x in open("gpurun_out/r2/bench_default.log") if x.startswith("{")][-1]
+j=json.loads(l)
+print(json.dumps({k:j[k] for k in ("value","ms_per_step","kernel_ms","end_to_end","cpu_baseline","stats_allreduce")}, indent=1)[:3500])
+PY
+timeout 600 python tests/debug_dropin_linear.py > gpurun_out/r2/debug_dropin.log 2>&1; tail -24 gpurun_out/r2/debug_dropin.log

@@ -27,7 +27,7 @@ for nm in want:
     print("read", nm, "pipeline: mapq", hits[i]["mapq"], "score", hits[i]["score"], "n_cand", hits[i]["n_candidates"], "n_best", hits[i]["n_best"])
     L = int(np.count_nonzero(rows[i]))
     for k in range(offs[i], offs[i + 1]):
-        win = np.frombuffer(ref.decode(int(loc[k]) - c // 2, ((q + c) | 1) + 1), np.uint8)[:q + c].copy()
+        win = np.frombuffer(ref.decode(int(loc[k]) - c // 2, ((q + c) | 1) + 1)[1], np.uint8)[:q + c].copy()
         qry = rows[i].copy()
         if strand[k]:
             qry[:L] = comp[qry[:L][::-1]]

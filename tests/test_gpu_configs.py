@@ -66,6 +66,8 @@ def test_config5_250bp_15pct_divergence_wide_band_sensitive(tmp_path):
     mapped = sum(1 for n in a if not a[n]["flag"] & 4)
     diff = [(n, a[n], b[n]) for n in a if a[n] != b[n]]
     print("config 5: %d of %d reads mapped by the reference; records differing: %d" % (mapped, len(a), len(diff)))
+    for n, x, y in diff[:6]:
+        print(n, {k: (x[k], y[k]) for k in x if x[k] != y[k]}, "NH", x["tags"].get("NH"), y["tags"].get("NH"), "XE", x["tags"].get("XE"))
     assert mapped > 0.5 * len(a)  # the case is hard but not degenerate
     assert len(diff) == 0, (len(diff), str(diff[:2])[:1500])
 

@@ -68,8 +68,10 @@ def test_real_ngm_with_hip_plugin_default_personality_equals_ngm_hip(tmp_path):
     independent hosts (the reference's own pipeline vs. this repository's device-resident pipeline) above the same kernels."""
     fa, inp, n = _case(tmp_path, False)
     plug, ours = str(tmp_path / "plugin.sam"), str(tmp_path / "ours.sam")
-    _run(DROPIN, fa, inp, plug, str(tmp_path))
+    log_plug = _run(DROPIN, fa, inp, plug, str(tmp_path))
     c = subprocess.run([CLI, "-r", fa, "-o", ours] + inp, capture_output=True, text=True)
+    print("\n".join(l for l in log_plug.splitlines() if "ensitivity" in l or "orridor" in l or "read length" in l))
+    print("\n".join(l for l in c.stderr.splitlines() if "ensitivity" in l or "orridor" in l or "read length" in l))
     assert c.returncode == 0, c.stderr[-2000:]
     rec = lambda p: {l.split("\t", 1)[0]: l for l in open(p) if not l.startswith("@")}
     a, b = rec(plug), rec(ours)

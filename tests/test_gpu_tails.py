@@ -23,7 +23,10 @@ def test_batch_score_every_tail_length(personality, q, c, rl):
         eng = N.Engine(q, c, gap_read=33, gap_ref=33, gap_extend=3, personality=1)
         want = {m: O.oracle_affine(m, ref, qry, c, nthreads=8)[0] for m in (0, 1)}
     bad = []
-    for n in list(range(1, 200)) + [255, 256, 257, 319, 320, 321, 383, 385, 400]:
+    # ascending, then a shuffled order: a small batch after a large one sees what the large one left in the workspace
+    rng = np.random.default_rng(99)
+    order = list(range(1, 200)) + [255, 256, 257, 319, 320, 321, 383, 385, 400] + [int(x) for x in rng.integers(1, 401, 150)]
+    for n in order:
         for mode in (0, 1):
             got = eng.BatchScore(mode, ref[:n], qry[:n])
             w = want[mode][:n]
