@@ -477,8 +477,8 @@ def main():
                         tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     except Exception:
                         continue
-                    for k, v in tj.items():  # grid = 64 T threads per read, T = waves per read of the instantiation
-                        if k.startswith("ngm::cs_bucket_kernel") and any(k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64 * T)) for T in (1, 2, 4, 8)):
+                    for k, v in tj.items():  # grid = 64 threads per read
+                        if k.startswith("ngm::cs_fast_kernel") and k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64)):
                             traffic, traffic_source = v, "profiles/" + fn
                     if traffic is not None:
                         break
@@ -504,14 +504,15 @@ def main():
             "accuracy_rank0_shard": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
             "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries if ref else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "cs_bucket_kernel (candidate search)",
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "cs_fast_kernel (candidate search)",
                          "isolated": {"achieved": (20 * iso_ctr[0] + 4 * iso_ctr[1] + 16 * iso_ctr[2]) / (iso_ms[0] * 1e-3) / 1e9 if iso_ms[0] > 0 else 0.0, "ms": float(iso_ms[0]),
                                       "reads": int(bounds[1] - bounds[0]),
                                       "note": "same kernel, one launch of one mapper instance with nothing else on the GPU (untimed extra pass)"}, "bytes_per_launch": b_cs / W, "launches_per_step": W,
-                         "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); one 16..128-byte bucket gather per "
-                                 "k-mer lookup; random gathers on MI355X are bound by ~50 G requests/s (profiles/r02_gather_calibration.txt), the vote side "
-                                 "by VALU + LDS atomics (DESIGN.md 4); `traffic` comes from the committed rocprofv3 PMC pass named in traffic_source, "
-                                 "it is not measured in this run; the SW kernels are VALU-bound, see sw_gcells_per_s"},
+                         "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); lists gathered from the bucketed "
+                                 "index (8-byte header + 32-byte segments); random gathers on MI355X are bound by ~50 G requests/s "
+                                 "(profiles/r02_gather_calibration.txt); the kernel is bound by per-read latency x reads in flight (DESIGN.md 4); "
+                                 "`traffic` = FETCH_SIZE x 1 (calibrated for <= 64-byte gathers) + WRITE_SIZE from the committed rocprofv3 PMC pass "
+                                 "named in traffic_source -- it is not measured in this run; the SW kernels are VALU-bound, see sw_gcells_per_s"},
             # SURVEY.md 8d's whole-path figure: (pairs * B_score + alignments * B_align + B_cs) per second of wall time
             "path_algorithmic_gbs": (n_cand * (Q + Q + C + 4) + int(mapped.sum()) * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)) + b_cs) * world
                                     / (elapsed / args.steps) / 1e9,

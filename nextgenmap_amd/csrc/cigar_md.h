@@ -41,7 +41,18 @@ inline bool column_is_eq(const CigarParams &p, unsigned char r, unsigned char f)
 	return rc <= 3 && rc == fc;
 }
 
-inline int put_num(char *dst, int v) { return sprintf(dst, "%d", v); }
+// "%d" without stdio (this runs once per CIGAR / MD element of every read on the host threads)
+inline int put_num(char *dst, int v) {
+	char b[12];
+	int n = 0, i = 0;
+	unsigned u = v < 0 ? 0u - (unsigned) v : (unsigned) v;
+	if (v < 0) dst[i++] = '-';
+	do { b[n++] = (char) ('0' + u % 10u); u /= 10u; } while (u);
+	while (n) dst[i++] = b[--n];
+	dst[i] = 0;
+	return i;
+}
+inline int put_op(char *dst, int v, char op) { const int n = put_num(dst, v); dst[n] = op; dst[n + 1] = 0; return n + 1; }
 
 // rec: the 8-int record, runs: rec[4] entries in traceback order.
 inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint16_t *runs, const char *ref,
@@ -60,8 +71,8 @@ inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint1
 	const int lead = rec[2], trail = rec[3], nruns = rec[4];
 	const char *refseq = ref + rec[1];
 	if (lead > 0) {
-		if (p.hard_clip == 1) co += sprintf(cigar + co, "%dH", lead);
-		else if (p.silent_clip != 1) co += sprintf(cigar + co, "%dS", lead);
+		if (p.hard_clip == 1) co += put_op(cigar + co, lead, 'H');
+		else if (p.silent_clip != 1) co += put_op(cigar + co, lead, 'S');
 		out->qstart = lead;
 	}
 	int match = 0, mismatch = 0, total = 0, m_len = 0, md_eq = 0, ref_i = 0, read_i = out->qstart;
@@ -83,8 +94,8 @@ inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint1
 			}
 		} else if (op == 3) {  // deletion: reference bases only
 			in_x_run = false;
-			if (m_len > 0) { co += sprintf(cigar + co, "%dM", m_len); m_len = 0; }
-			co += sprintf(cigar + co, "%dD", len);
+			if (m_len > 0) { co += put_op(cigar + co, m_len, 'M'); m_len = 0; }
+			co += put_op(cigar + co, len, 'D');
 			mo += put_num(md + mo, md_eq);
 			md_eq = 0;
 			md[mo++] = '^';
@@ -92,17 +103,17 @@ inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint1
 			mismatch += len;
 		} else {  // insertion: read bases only
 			in_x_run = false;
-			if (m_len > 0) { co += sprintf(cigar + co, "%dM", m_len); m_len = 0; }
-			co += sprintf(cigar + co, "%dI", len);
+			if (m_len > 0) { co += put_op(cigar + co, m_len, 'M'); m_len = 0; }
+			co += put_op(cigar + co, len, 'I');
 			read_i += len;
 			mismatch += len;
 		}
 	}
 	mo += put_num(md + mo, md_eq);
-	if (m_len > 0) co += sprintf(cigar + co, "%dM", m_len);
+	if (m_len > 0) co += put_op(cigar + co, m_len, 'M');
 	if (trail > 0) {
-		if (p.hard_clip == 1) co += sprintf(cigar + co, "%dH", trail);
-		else if (p.silent_clip != 1) co += sprintf(cigar + co, "%dS", trail);
+		if (p.hard_clip == 1) co += put_op(cigar + co, trail, 'H');
+		else if (p.silent_clip != 1) co += put_op(cigar + co, trail, 'S');
 		out->qend = trail;
 	}
 	cigar[co] = 0;

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "refindex.h"
+#include "thread_pool.h"
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -130,6 +131,134 @@ __global__ void apply_usage_rule_kernel(uint32_t n_kmers, int k, const uint32_t 
 
 void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw);
 
+// ---- the same enumeration on the GPU ------------------------------------------------------------------------
+// KmerWalker above, position-parallel.  Which k-mers the reference visits (CS::PrefixIteration, src/CSstatic.cpp:26-76, with
+// prefixskip = kmer_skip) follows from the N-free runs of a contig alone: in a maximal N-free run [a, b) the k-mers start at
+// a, a + (skip+1), ... while start + k <= b (the skip counter restarts at every restart), except the run of exactly k bases at
+// the contig end behind an N run that the walker meets at a restart position (CSstatic.cpp:37).  Which of them are stored
+// (CompactPrefixTable::CountKmer / BuildPrefixTable, src/PrefixTable.cpp:641-709: a k-mer equal to the previously visited one is
+// dropped when it falls into the same bin as that one, from the third of such a run on) depends on the two visited k-mers before
+// it only.  So: N marks -> inclusive max-scan = start of the current run -> visit flags -> compaction -> keys -> store flags ->
+// compaction; all in HBM (12.4 GB of scratch for a GRCh38-size genome).
+__device__ __forceinline__ uint32_t d_class_at(const uint32_t *g, uint64_t i) { return (g[i >> 3] >> (4 * (int) (i & 7))) & 15u; }
+
+__global__ void walk_mark_n_kernel(const uint32_t *__restrict__ genome, uint64_t n, uint32_t *__restrict__ v) {
+	const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] = d_class_at(genome, i) == 5u ? (uint32_t) i + 1u : 0u;
+}
+// the last two bases of every contig act as 'A' for the walk (see build_index below)
+__global__ void walk_unmark_tails_kernel(const uint64_t *__restrict__ cend, int n_contigs, uint32_t *__restrict__ v) {
+	const int c = blockIdx.x * blockDim.x + threadIdx.x;
+	if (c < n_contigs) { v[cend[c] - 1] = 0; v[cend[c] - 2] = 0; }
+}
+__device__ __forceinline__ int walk_contig_of(const uint64_t *cstart, int n_contigs, uint64_t pos) {  // last contig with start <= pos
+	int lo = 0, hi = n_contigs;
+	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cstart[mid] <= pos) lo = mid; else hi = mid; }
+	return lo;
+}
+__global__ void walk_visit_flags_kernel(const uint32_t *__restrict__ run_start, const uint32_t *__restrict__ genome, uint64_t n, int k, int step,
+		const uint64_t *__restrict__ cstart, const uint64_t *__restrict__ cend, int n_contigs, uint8_t *__restrict__ flag) {
+	const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	uint8_t f = 0;
+	if (i + k <= n) {
+		const uint64_t a = run_start[i + k - 1];  // index after the last N at or before i + k - 1
+		if (a <= i && (i - a) % (uint64_t) step == 0) {
+			f = 1;
+			if (i == a) {  // CSstatic.cpp:37: exactly k bases left behind an N run met at a restart position
+				const int c = walk_contig_of(cstart, n_contigs, i);
+				const uint64_t p = i - cstart[c];
+				if (i + k == cend[c] && p >= 1 && d_class_at(genome, i - 1) == 5u && (p == 1 || d_class_at(genome, i - 2) == 5u)) f = 0;
+			}
+		}
+	}
+	flag[i] = f;
+}
+__global__ void walk_keys_kernel(const uint32_t *__restrict__ pos, uint64_t m, const uint32_t *__restrict__ genome, int k, const uint64_t *__restrict__ cstart,
+		const uint64_t *__restrict__ cend, int n_contigs, uint32_t *__restrict__ keys) {
+	const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	const uint64_t p = pos[j];
+	const uint64_t tail = cend[walk_contig_of(cstart, n_contigs, p)] - 2;  // from here on the walk sees 'A'
+	uint32_t key = 0;
+	for (int t = 0; t < k; ++t) {
+		const uint32_t cls = (p + t >= tail) ? 0u : d_class_at(genome, p + t);
+		key = (key << 2) | (cls == 2u ? 3u : (cls == 3u ? 2u : cls));  // A0 C1 T2 G3 (CSstatic.cpp:20-22)
+	}
+	keys[j] = key;
+}
+// PrefixTable.cpp:641-709 (fire() of the host walker): stored unless it repeats the previous visited k-mer of its contig in the
+// same bin, where the bin memory starts with the second k-mer of such a run
+__global__ void walk_store_flags_kernel(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ keys, uint64_t m, int bin_shift,
+		const uint64_t *__restrict__ cstart, int n_contigs, uint8_t *__restrict__ flag) {
+	const uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= m) return;
+	const uint64_t cs = cstart[walk_contig_of(cstart, n_contigs, pos[j])];
+	const bool has1 = j >= 1 && pos[j - 1] >= cs, has2 = j >= 2 && pos[j - 2] >= cs;
+	const uint32_t prev = has1 ? keys[j - 1] : 111111u;        // PrefixTable.cpp:335-336: lastPrefix starts as 111111 per contig
+	bool store = true;
+	if (keys[j] == prev) {
+		// the bin remembered when k-mer j is looked at: none after a k-mer that differed from ITS predecessor
+		bool have_bin = false;
+		if (has1) { const uint32_t prev2 = has2 ? keys[j - 2] : 111111u; have_bin = keys[j - 1] == prev2; }
+		if (have_bin && (pos[j] >> bin_shift) == (pos[j - 1] >> bin_shift)) store = false;
+	}
+	flag[j] = store ? 1 : 0;
+}
+
+// -> d_keys / d_vals (device, n entries, genome order).  Returns 0 or a negative error.
+int gpu_kmer_walk(ngm_ref *r, uint32_t **d_keys_out, uint32_t **d_vals_out, uint64_t *n_out) {
+	const uint64_t n = r->n_bases;
+	const int k = r->prm.kmer, nc = (int) r->contigs.size();
+	std::vector<uint64_t> hs(nc), he(nc);
+	for (int c = 0; c < nc; ++c) { hs[c] = r->contigs[c].start; he[c] = r->contigs[c].start + r->contigs[c].len; }
+	uint64_t *d_cs = nullptr, *d_ce = nullptr;
+	uint32_t *d_run = nullptr, *d_pos = nullptr, *d_keys = nullptr, *d_keys2 = nullptr, *d_pos2 = nullptr;
+	uint8_t *d_flag = nullptr;
+	uint64_t *d_count = nullptr;
+	void *d_tmp = nullptr;
+	auto cleanup = [&]() { (void) hipFree(d_cs); (void) hipFree(d_ce); (void) hipFree(d_run); (void) hipFree(d_flag); (void) hipFree(d_count); (void) hipFree(d_tmp); };
+	REF_HIP_TRY(hipMalloc(&d_cs, std::max(1, nc) * 8)); REF_HIP_TRY(hipMalloc(&d_ce, std::max(1, nc) * 8));
+	REF_HIP_TRY(hipMemcpy(d_cs, hs.data(), nc * 8, hipMemcpyHostToDevice)); REF_HIP_TRY(hipMemcpy(d_ce, he.data(), nc * 8, hipMemcpyHostToDevice));
+	REF_HIP_TRY(hipMalloc(&d_run, std::max<uint64_t>(n, 1) * 4)); REF_HIP_TRY(hipMalloc(&d_flag, std::max<uint64_t>(n, 1))); REF_HIP_TRY(hipMalloc(&d_count, 8));
+	const unsigned nb = (unsigned) ((n + 255) / 256);
+	hipLaunchKernelGGL(walk_mark_n_kernel, dim3(nb), dim3(256), 0, 0, r->d_genome, n, d_run);
+	if (nc > 0) hipLaunchKernelGGL(walk_unmark_tails_kernel, dim3((nc + 255) / 256), dim3(256), 0, 0, d_ce, nc, d_run);
+	size_t tb = 0, tb2 = 0;
+	(void) rocprim::inclusive_scan(nullptr, tb, d_run, d_run, (size_t) n, rocprim::maximum<uint32_t>());
+	(void) rocprim::select(nullptr, tb2, rocprim::counting_iterator<uint32_t>(0), d_flag, (uint32_t *) nullptr, d_count, (size_t) n);
+	size_t tb3 = 0;
+	(void) rocprim::select(nullptr, tb3, (uint32_t *) nullptr, d_flag, (uint32_t *) nullptr, d_count, (size_t) n);
+	tb = std::max(tb, std::max(tb2, tb3)) + 256;
+	REF_HIP_TRY(hipMalloc(&d_tmp, tb));
+	REF_HIP_TRY(rocprim::inclusive_scan(d_tmp, tb, d_run, d_run, (size_t) n, rocprim::maximum<uint32_t>()));
+	hipLaunchKernelGGL(walk_visit_flags_kernel, dim3(nb), dim3(256), 0, 0, d_run, r->d_genome, n, k, r->prm.kmer_skip + 1, d_cs, d_ce, nc, d_flag);
+	REF_HIP_TRY(hipGetLastError());
+	// upper bound of visited k-mers: every (skip+1)-th position plus one per run
+	const uint64_t cap = n / (uint64_t) (r->prm.kmer_skip + 1) + n / 1000 + 4096;
+	REF_HIP_TRY(hipMalloc(&d_pos, cap * 4));
+	REF_HIP_TRY(rocprim::select(d_tmp, tb, rocprim::counting_iterator<uint32_t>(0), d_flag, d_pos, d_count, (size_t) n));
+	uint64_t m = 0;
+	REF_HIP_TRY(hipMemcpy(&m, d_count, 8, hipMemcpyDeviceToHost));
+	if (m > cap) { cleanup(); (void) hipFree(d_pos); ngm::pipeline_set_error("k-mer walk: more visited k-mers than expected"); return -75; }
+	(void) hipFree(d_run); d_run = nullptr;
+	REF_HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(m, 1) * 4)); REF_HIP_TRY(hipMalloc(&d_keys2, std::max<uint64_t>(m, 1) * 4)); REF_HIP_TRY(hipMalloc(&d_pos2, std::max<uint64_t>(m, 1) * 4));
+	uint64_t kept = 0;
+	if (m > 0) {
+		const unsigned mb = (unsigned) ((m + 255) / 256);
+		hipLaunchKernelGGL(walk_keys_kernel, dim3(mb), dim3(256), 0, 0, d_pos, m, r->d_genome, k, d_cs, d_ce, nc, d_keys);
+		hipLaunchKernelGGL(walk_store_flags_kernel, dim3(mb), dim3(256), 0, 0, d_pos, d_keys, m, r->prm.bin_size, d_cs, nc, d_flag);
+		REF_HIP_TRY(hipGetLastError());
+		REF_HIP_TRY(rocprim::select(d_tmp, tb, d_keys, d_flag, d_keys2, d_count, (size_t) m));
+		REF_HIP_TRY(rocprim::select(d_tmp, tb, d_pos, d_flag, d_pos2, d_count, (size_t) m));
+		REF_HIP_TRY(hipMemcpy(&kept, d_count, 8, hipMemcpyDeviceToHost));
+	}
+	cleanup();
+	(void) hipFree(d_pos); (void) hipFree(d_keys);
+	*d_keys_out = d_keys2; *d_vals_out = d_pos2; *n_out = kept;
+	return 0;
+}
+
 // bucket of k-mer p: word 0 = own list length (bits 0-13; 0: unused, or more than 9900 occurrences) | list length of the
 // reverse-complement k-mer << 14 (the search needs the sum of both, CS.cpp:122) | 1 << 31 when the list does not fit;
 // words 1.. = the positions, or word 1 = start in d_positions for a list that does not fit.  One bucket more than there
@@ -175,34 +304,41 @@ int build_buckets(ngm_ref *r) {
 int build_index(ngm_ref *r) {
 	const int k = r->prm.kmer;
 	const uint32_t n_kmers = 1u << (2 * k);
-	std::vector<uint32_t> keys, vals;
-	keys.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
-	vals.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
-	KmerWalker w{k, r->prm.kmer_skip, r->prm.bin_size, (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u), 111111u, -1, &keys, &vals};
-	std::vector<uint8_t> tmp;
-	for (const NgmContig &c : r->contigs) {
-		w.last_prefix = 111111u;  // PrefixTable.cpp:335-336
-		w.last_bin = -1;
-		// CountKmerFreq decodes the contig with bufferLength = len, and DecodeRefSequence emits bufferLength-2
-		// bases ('x' / NUL after that, SequenceProvider.cpp:384, :424-439); PrefixIteration then still walks
-		// all len characters and encode() maps both fillers to 0: the last two bases act as 'A'.
-		tmp.assign(r->host_cls.begin() + c.start, r->host_cls.begin() + c.start + c.len);
-		if (c.len >= 2) { tmp[c.len - 2] = 0; tmp[c.len - 1] = 0; }
-		w.iterate(tmp.data(), c.len, c.start);
-	}
-	const uint64_t n = keys.size();
-	r->n_entries = n;
-
 	uint32_t *d_keys = nullptr, *d_vals = nullptr, *d_keys2 = nullptr, *d_starts = nullptr;
-	REF_HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(n, 1) * 4));
-	REF_HIP_TRY(hipMalloc(&d_vals, std::max<uint64_t>(n, 1) * 4));
+	uint64_t n = 0;
+	if (!getenv("NGM_HIP_HOST_KMER_WALK")) {
+		// the walk on the GPU (CountKmerFreq decodes a contig with bufferLength = len and DecodeRefSequence emits len - 2 bases,
+		// 'x' / NUL after that, which encode() maps to 0: the last two bases of a contig act as 'A' -- handled in the kernels)
+		if (int rc = gpu_kmer_walk(r, &d_keys, &d_vals, &n)) return rc;
+	} else {
+		std::vector<uint32_t> keys, vals;
+		keys.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
+		vals.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
+		KmerWalker w{k, r->prm.kmer_skip, r->prm.bin_size, (k == 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u), 111111u, -1, &keys, &vals};
+		std::vector<uint8_t> tmp;
+		for (const NgmContig &c : r->contigs) {
+			w.last_prefix = 111111u;  // PrefixTable.cpp:335-336
+			w.last_bin = -1;
+			// CountKmerFreq decodes the contig with bufferLength = len, and DecodeRefSequence emits bufferLength-2
+			// bases ('x' / NUL after that, SequenceProvider.cpp:384, :424-439); PrefixIteration then still walks
+			// all len characters and encode() maps both fillers to 0: the last two bases act as 'A'.
+			tmp.assign(r->host_cls.begin() + c.start, r->host_cls.begin() + c.start + c.len);
+			if (c.len >= 2) { tmp[c.len - 2] = 0; tmp[c.len - 1] = 0; }
+			w.iterate(tmp.data(), c.len, c.start);
+		}
+		n = keys.size();
+		REF_HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(n, 1) * 4));
+		REF_HIP_TRY(hipMalloc(&d_vals, std::max<uint64_t>(n, 1) * 4));
+		REF_HIP_TRY(hipMemcpy(d_keys, keys.data(), n * 4, hipMemcpyHostToDevice));
+		REF_HIP_TRY(hipMemcpy(d_vals, vals.data(), n * 4, hipMemcpyHostToDevice));
+	}
+	r->n_entries = n;
 	REF_HIP_TRY(hipMalloc(&d_keys2, std::max<uint64_t>(n, 1) * 4));
 	REF_HIP_TRY(hipMalloc(&r->d_positions, (std::max<uint64_t>(n, 1) + 16) * 4));  // the search reads 16-entry segments
+	REF_HIP_TRY(hipMemset(r->d_positions, 0, (std::max<uint64_t>(n, 1) + 16) * 4));
 	REF_HIP_TRY(hipMalloc(&d_starts, (size_t) n_kmers * 4));
 	REF_HIP_TRY(hipMalloc(&r->d_raw_counts, (size_t) n_kmers * 4));
 	REF_HIP_TRY(hipMalloc(&r->d_index, (size_t) n_kmers * sizeof(uint2)));
-	REF_HIP_TRY(hipMemcpy(d_keys, keys.data(), n * 4, hipMemcpyHostToDevice));
-	REF_HIP_TRY(hipMemcpy(d_vals, vals.data(), n * 4, hipMemcpyHostToDevice));
 	REF_HIP_TRY(hipMemset(d_starts, 0, (size_t) n_kmers * 4));
 	REF_HIP_TRY(hipMemset(r->d_raw_counts, 0, (size_t) n_kmers * 4));
 	if (n > 0) {
@@ -250,10 +386,21 @@ int upload_genome(ngm_ref *r) {
 	// upload the genome as packed nibbles (+ one guard word so window reads never run off the end)
 	r->genome_words = (r->n_bases + 7) / 8 + 64;
 	std::vector<uint32_t> packed(r->genome_words, 0x66666666u);  // NUL class beyond the end
-	for (uint64_t i = 0; i < r->n_bases; ++i) {
-		uint32_t &w = packed[i >> 3];
-		const int sh = 4 * (int) (i & 7);
-		w = (w & ~(0xFu << sh)) | ((uint32_t) r->host_cls[i] << sh);
+	{
+		const uint64_t nb = r->n_bases, nw = (nb + 7) / 8;
+		const uint8_t *cls = r->host_cls.data();
+		uint32_t *out = packed.data();
+		const int blocks = (int) ((nw + (1u << 17) - 1) >> 17);  // 128 Kword blocks on the pool threads
+		ngm::ThreadPool::instance().parallel_for(blocks, [&](int lo, int hi) {
+			for (uint64_t wi = (uint64_t) lo << 17, e = std::min<uint64_t>(nw, (uint64_t) hi << 17); wi < e; ++wi) {
+				uint32_t w = 0x66666666u;
+				for (int b = 0; b < 8; ++b) {
+					const uint64_t i = wi * 8 + (uint64_t) b;
+					if (i < nb) w = (w & ~(0xFu << (4 * b))) | ((uint32_t) cls[i] << (4 * b));
+				}
+				out[wi] = w;
+			}
+		}, 1);
 	}
 	REF_HIP_TRY(hipMalloc(&r->d_genome, r->genome_words * 4));
 	REF_HIP_TRY(hipMemcpy(r->d_genome, packed.data(), r->genome_words * 4, hipMemcpyHostToDevice));
@@ -274,7 +421,14 @@ void append_contig(ngm_ref *r, const std::string &name, const uint8_t *seq, uint
 	c.start = r->host_cls.size();
 	c.len = len;
 	r->host_cls.reserve(r->host_cls.size() + len + 1002);
-	for (uint64_t i = 0; i < len; ++i) r->host_cls.push_back(class_of_base(seq[i]));
+	r->host_cls.resize(c.start + len);
+	{
+		uint8_t *dst = r->host_cls.data() + c.start;
+		const int blocks = (int) ((len + (1u << 20) - 1) >> 20);  // 1 Mbase blocks on the pool threads
+		ngm::ThreadPool::instance().parallel_for(blocks, [&](int lo, int hi) {
+			for (uint64_t i = (uint64_t) lo << 20, e = std::min<uint64_t>(len, (uint64_t) hi << 20); i < e; ++i) dst[i] = class_of_base(seq[i]);
+		}, 1);
+	}
 	if (len & 1) r->host_cls.push_back(5);  // odd contig: the second nibble of the last byte is an N
 	append_spacer(r->host_cls);
 	r->contigs.push_back(c);

@@ -10,7 +10,15 @@ write_db : rocprofv3 --pmc WRITE_SIZE --kernel-trace  /-> <tag>_pmc_hbm.csv + <t
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB, and on
 gfx950 FETCH_SIZE counts a coalesced streaming read at half its bytes (128-B requests tallied as 64 B),
 so read bytes = 2 * FETCH_SIZE * 1024 (confirmed here: see the "expected" column notes in DESIGN.md).
+Round 2 calibration (profiles/r02_gather_calibration.txt, profiles/tools/gather_calib.hip): FETCH_SIZE = memory requests x 64 B;
+a random gather of <= 64 bytes is ONE 64-byte request (FETCH_SIZE exact), an aligned 128-byte gather one 128-byte request
+(FETCH_SIZE half).  The candidate-search kernels gather 8-byte headers and 32-byte list segments: factor 1 for them
+(kernel names containing "cs_"), factor 2 for the streaming kernels.
 """
+
+
+def fetch_factor(name):
+    return 1 if "cs_" in name else 2
 import csv
 import json
 import os
@@ -48,11 +56,11 @@ def main():
         with open(os.path.join(HERE, tag + "_pmc_hbm.csv"), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["kernel", "grid_size", "dispatches", "FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg",
-                        "hbm_read_bytes(2x FETCH, gfx950 correction)", "hbm_write_bytes", "hbm_bytes_per_launch"])
+                        "hbm_read_bytes(FETCH x calibrated factor: 1 gathers, 2 streaming)", "hbm_write_bytes", "hbm_bytes_per_launch"])
             for (name, grid), d in sorted(agg.items()):
                 fe = d.get("FETCH_SIZE", (0, 0.0, 0))[1]
                 wr = d.get("WRITE_SIZE", (0, 0.0, 0))[1]
-                rb, wb = 2 * fe * 1024, wr * 1024
+                rb, wb = fetch_factor(name) * fe * 1024, wr * 1024
                 w.writerow([name, grid, d.get("FETCH_SIZE", (0,))[0], "%.1f" % fe, "%.1f" % wr, int(rb), int(wb), int(rb + wb)])
                 traffic["%s|grid=%d" % (name, grid)] = int(rb + wb)
         with open(os.path.join(HERE, tag + "_pmc_traffic.json"), "w") as f:

@@ -79,3 +79,36 @@ def test_real_ngm_with_hip_plugin_default_personality_equals_ngm_hip(tmp_path):
     diff = [(a[k], b[k]) for k in a if a[k] != b[k]]
     print("records differing:", len(diff), "of", len(a))
     assert not diff, str(diff[:2])[:1200]
+
+
+@needs
+def test_default_personality_paired_end_real_program_vs_ngm_hip(tmp_path):
+    """Linear (default) personality, paired-end: the real program driving this library through IAlignment (its own top1PE /
+    CheckPairs / SAMWriter::DoWritePair above BatchScore / BatchAlign) against the device-resident pipeline of ngm-hip."""
+    fa, inp, n = _case(tmp_path, True)
+    plug, ours = str(tmp_path / "plugin.sam"), str(tmp_path / "ours.sam")
+    _run(DROPIN, fa, inp, plug, str(tmp_path))
+    c = subprocess.run([CLI, "-r", fa, "-o", ours] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    rec = lambda p: {(l.split("\t", 2)[0], int(l.split("\t", 2)[1]) & 0xC0): l for l in open(p) if not l.startswith("@")}
+    a, b = rec(plug), rec(ours)
+    assert set(a) == set(b) and len(a) == n
+    diff = [(a[k], b[k]) for k in a if a[k] != b[k]]
+    print("records differing:", len(diff), "of", len(a))
+    assert not diff, str(diff[:2])[:1500]
+
+
+def test_two_device_entries_on_one_gpu_give_the_same_output(tmp_path):
+    """`-g 0,0`: two references and two sets of mappers (the multi-GPU code path: one reference per listed device, workers
+    spread over them, one shared paired-end state, one ordered writer) -- on the one GPU of the test box.  Output must equal the
+    single-device run byte for byte."""
+    fa, inp, n = _case(tmp_path, True)
+    outs = []
+    for tag, extra in (("one", []), ("two", ["-g", "0,0", "--batch-size", "1024"])):
+        out = str(tmp_path / (tag + ".sam"))
+        c = subprocess.run([CLI, "-r", fa, "-o", out, "--affine"] + inp + extra, capture_output=True, text=True)
+        assert c.returncode == 0, c.stderr[-2000:]
+        if extra:
+            assert "2 GPU(s)" in c.stderr
+        outs.append([l for l in open(out) if not l.startswith("@PG")])
+    assert outs[0] == outs[1] and len([l for l in outs[0] if not l.startswith("@")]) == n
