@@ -202,8 +202,10 @@ constexpr uint32_t kCsHdrOverflow = 0x80000000u;
 // "does not fit" flag) and either the first position or, for a list that does not fit, its start in the position table --
 // which also pulls the first 64-byte sector of the bucket (15 positions) towards the L2; {start, count} is then the same
 // pair the plain index holds, with `start` a word offset into A.buckets.
-template <bool ITEMS, typename ItemT = uint32_t, bool BUCKETS = false>
-__device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, uint32_t *l_pref, uint8_t *l_code,
+// PrefT: uint32_t keeps (length | time of the list's first hit << 16) per list (order replay), uint16_t the length only (the
+// fast path: 560 bytes of LDS less per read, which is what lets a tenth read fit a CU)
+template <bool ITEMS, typename ItemT = uint32_t, bool BUCKETS = false, typename PrefT = uint32_t>
+__device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane, uint32_t *l_start, PrefT *l_pref, uint8_t *l_code,
 		ItemT *l_items = nullptr, uint32_t items_cap = 0) {
 	const int k = A.k;
 	const uint8_t *rp = A.reads + (size_t) read * A.q;
@@ -266,16 +268,16 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 			if (!ITEMS) {
 				if (p < n_kmers) {
 					const uint32_t b0 = carry + incl - both;
-					l_start[2 * p] = sf; l_pref[2 * p] = b0;
-					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = b0 + cf;
+					l_start[2 * p] = sf; l_pref[2 * p] = (PrefT) b0;
+					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = (PrefT) (b0 + cf);
 				}
 			} else {
 				const uint32_t nsf = (cf + kCsSeg - 1) / kCsSeg, nsr = (cr + kCsSeg - 1) / kCsSeg;
 				const uint32_t incl_s = wave_inclusive_scan(nsf + nsr, lane);
 				if (p < n_kmers) {
 					const uint32_t b0 = carry + incl - both;  // time (flattened hit index) of the forward list's first hit
-					l_start[2 * p] = sf; l_pref[2 * p] = (cf & 0xFFFFu) | (b0 << 16);
-					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = (cr & 0xFFFFu) | ((b0 + cf) << 16);
+					l_start[2 * p] = sf; l_pref[2 * p] = (PrefT) ((cf & 0xFFFFu) | (b0 << 16));
+					l_start[2 * p + 1] = sr; l_pref[2 * p + 1] = (PrefT) ((cr & 0xFFFFu) | ((b0 + cf) << 16));
 					uint32_t o = carry_s + incl_s - (nsf + nsr);
 					for (uint32_t sg = 0; sg < nsf; ++sg, ++o) if (o < items_cap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p), sg);
 					for (uint32_t sg = 0; sg < nsr; ++sg, ++o) if (o < items_cap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p + 1), sg);
@@ -285,7 +287,7 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 			carry += __shfl(incl, 63);
 		}
 	}
-	if (!ITEMS && lane == 0) l_pref[R.n_lists] = carry;
+	if (!ITEMS && lane == 0) l_pref[R.n_lists] = (PrefT) carry;
 	R.H = carry;
 	R.n_valid = n_valid;
 	R.n_items = carry_s;
@@ -383,15 +385,15 @@ constexpr int kCsFastDepth = 2;    // segments in flight per lane
 struct __attribute__((packed, aligned(4))) CsU4 { uint32_t x, y, z, w; };
 
 template <int kCsFastItems, typename ItemT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void cs_fast_kernel(CsArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void cs_fast_kernel(CsArgs A) {
 	constexpr uint32_t kCsFastItemCap = (uint32_t) kCsFastItems * 64u;
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	const int lane = threadIdx.x;
 	const int read = blockIdx.x;
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;
-	uint32_t *l_len = cs_lds + A.lists_cap;
-	uint8_t *l_code = (uint8_t *) (l_len + A.lists_cap + 1);
+	uint16_t *l_len = (uint16_t *) (cs_lds + A.lists_cap);   // [lists_cap] (lists_cap is even)
+	uint8_t *l_code = (uint8_t *) (l_len + A.lists_cap);
 	ItemT *l_items = (ItemT *) ((uint32_t *) l_code + (A.q + 3) / 4);
 	uint32_t *plane = (uint32_t *) (l_items + kCsFastItemCap);  // kCsFastItemCap is a multiple of 64: stays 4-byte aligned
 	const uint32_t plane_words = A.plane_bits >> 5;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 	const bool diag = A.phase_cycles && (read & 255) == 0;  // sampled: the global atomics would serialise otherwise
 	const unsigned long long c0 = diag ? wall_clock64() : 0ull;
-	const CsRead R = cs_prepare<true, ItemT, true>(A, read, lane, l_start, l_len, l_code, l_items, kCsFastItemCap);
+	const CsRead R = cs_prepare<true, ItemT, true, uint16_t>(A, read, lane, l_start, l_len, l_code, l_items, kCsFastItemCap);
 	const uint32_t H = R.H;
 	const int L = R.L;
 	if (H > A.hit_cap || R.n_items > kCsFastItemCap) { cs_enqueue(A, read, lane, R); return; }
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 		if (idx < n_items) {
 			const uint32_t item = l_items[idx];
 			const uint32_t li = CsItem<ItemT>::list(item), sg = CsItem<ItemT>::seg(item);
-			const uint32_t cnt = min((uint32_t) kCsSeg, (l_len[li] & 0xFFFFu) - sg * kCsSeg);
+			const uint32_t cnt = min((uint32_t) kCsSeg, (uint32_t) l_len[li] - sg * kCsSeg);
 			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.buckets + l_start[li] + sg * kCsSeg);
 #pragma unroll
 			for (int v = 0; v < kCsSeg / 4; ++v) if ((uint32_t) (4 * v) < cnt) d[v] = src[v];

@@ -112,7 +112,9 @@ struct DevGuard {
 
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (mode == ngm::kCsFast) w += ((size_t) A.plane_bits >> 5) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) + ((size_t) 3 << A.log2_slots) / 4;
+	if (mode == ngm::kCsFast)  // list starts (32-bit) + lengths (16-bit), codes, plane, items, table, queue
+		w = (size_t) A.lists_cap + (size_t) A.lists_cap / 2 + (A.q + 3) / 4 + ((size_t) A.plane_bits >> 5) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) +
+				((size_t) 3 << A.log2_slots) / 4;
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -392,6 +394,23 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		const double segs = hexp / 8.0 + 0.44 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
 		m->cs_fast_items = segs * 1.10 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
 		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
+		// The kernel is bound by reads in flight per CU, and those by LDS: when trimming the plane by a few
+		// per cent (it is sized to 12 bits per expected hit; 11 still keep the spurious table entries in bounds) lets one
+		// more read fit the 160 KB of a CU, do it.
+		{
+			ngm::CsArgs G{};
+			G.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); G.q = p->qry_max_len; G.log2_slots = m->cs_log2_small;
+			G.fast_items = m->cs_fast_items; G.items16 = (G.lists_cap <= 512) ? 1 : 0; G.plane_bits = m->cs_plane_bits;
+			const size_t bytes = cs_lds_bytes(G, ngm::kCsFast), lds = 160 * 1024;
+			const size_t per_cu = lds / std::max<size_t>(bytes, 1);
+			if (per_cu >= 1 && per_cu < 12) {
+				const size_t target = lds / (per_cu + 1);  // bytes that would let one more read in
+				if (bytes > target && (bytes - target) * 8 <= (size_t) m->cs_plane_bits / 12) {  // at most a twelfth of the plane
+					const uint32_t cut_bits = (uint32_t) (((bytes - target) * 8 + 31) / 32 * 32);
+					m->cs_plane_bits -= cut_bits;
+				}
+			}
+		}
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
 	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17; A.plane_bits = 131072;
