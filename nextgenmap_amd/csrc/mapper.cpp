@@ -23,6 +23,7 @@
 #include "engine_internal.h"
 #include "align_device.h"
 #include "cigar_md.h"
+#include "cigar_device.h"
 #include "cs_device.h"
 #include "gather_device.h"
 #include "thread_pool.h"
@@ -86,6 +87,10 @@ struct ngm_mapper {
 	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
 	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records;
 	ngm::DevBuf<uint16_t> d_runs, d_runs_c;
+	ngm::DevBuf<char> d_cig_rows, d_md_rows, d_str;   // CIGAR / MD on the device: scratch rows and the compact stream
+	ngm::DevBuf<ngm::CigarDevOut> d_cigout;
+	ngm::PinnedBuf<ngm::CigarDevOut> p_cigout;
+	ngm::PinnedBuf<char> p_str;
 	// last CS result on the host
 	int n_reads = 0;
 	// per-read candidate offsets / counts / best vote counts of the last search, downloaded into pinned memory
@@ -277,10 +282,16 @@ std::atomic<int> g_live_mappers{0};  // mapper instances share the host cores
 // GPU stages (candidate search / score / align, each from its first launch to its stream sync) of the mapper instances of
 // one process take turns: kernels of different instances then do not slow each other down, while the host stages of one
 // instance still overlap the GPU stages of the others (NGM_HIP_GPU_STAGE_LOCK=0: let the streams share the GPU)
-std::mutex g_gpu_stage_mu;
+// NGM_HIP_GPU_STAGE_LOCK=2: one lock per stage KIND -- the align stage of one instance (1 wave per SIMD, hardly any LDS) may then
+// run under the search stage of another (LDS-bound at 10 waves per CU), only stages of the same kind take turns.
+std::mutex g_gpu_stage_mu[2];
 struct GpuStage {
 	std::unique_lock<std::mutex> lk;
-	GpuStage() : lk(g_gpu_stage_mu, std::defer_lock) { static const bool on = !(getenv("NGM_HIP_GPU_STAGE_LOCK") && atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) == 0); if (on) lk.lock(); }
+	explicit GpuStage(int kind = 0) {
+		static const int mode = getenv("NGM_HIP_GPU_STAGE_LOCK") ? atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) : 1;
+		if (mode == 0) return;
+		lk = std::unique_lock<std::mutex>(g_gpu_stage_mu[mode == 2 ? kind : 0]);
+	}
 	void done() { if (lk.owns_lock()) lk.unlock(); }
 };
 // per-read host loops run on the process-wide persistent pool (thread_pool.h): shared by the mapper instances, sized
@@ -441,6 +452,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
+	m->d_cig_rows.release(); m->d_md_rows.release(); m->d_str.release(); m->d_cigout.release(); m->p_cigout.release(); m->p_str.release();
 	ngm_hip_destroy(m->eng);
 	delete m;
 }
@@ -1041,7 +1053,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	int32_t *h_rec = m->p_rec.p;
 	uint16_t *h_runs = nullptr;
 	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
-	GpuStage stage_align;
+	static const bool dev_strings = !getenv("NGM_HIP_HOST_CIGAR");
+	GpuStage stage_align(1);
 	if (na > 0) {
 		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
 				m->d_runs.reserve((size_t) na * rs)) { ngm::pipeline_set_error("out of device memory (align stage)"); return -12; }
@@ -1065,13 +1078,36 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		hipLaunchKernelGGL(ngm::compact_runs_kernel, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs.p, rs,
 				m->d_runs_c.p, m->d_total.p);
 		MAP_HIP_TRY(hipGetLastError());
-		unsigned long long n_runs_total = 0;
+		unsigned long long n_runs_total = 0, n_str_total = 0;
+		// CIGAR / MD / NM / identity on the GPU (cigar_device.h); NGM_HIP_HOST_CIGAR=1 keeps the host builders (tests)
+		if (dev_strings) {
+			const int sstride = 4 * std::max(1, q);
+			const unsigned long long scap = (unsigned long long) na * 96ull + 4096ull;
+			if (m->d_cig_rows.reserve((size_t) na * sstride) || m->d_md_rows.reserve((size_t) na * sstride) || m->d_cigout.reserve(na) || m->d_str.reserve(scap) ||
+					m->p_cigout.reserve(na)) { ngm::pipeline_set_error("out of memory (CIGAR strings)"); return -12; }
+			MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 8, 0, 8, m->st));
+			const bool affine = m->prm.personality == NGM_PERSONALITY_AFFINE;
+			if (affine) hipLaunchKernelGGL(ngm::cigar_strings_kernel<true>, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs_c.p, eng->packed.p, eng->RW, eng->FW,
+					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, sstride, m->d_cig_rows.p, m->d_md_rows.p, m->d_cigout.p);
+			else hipLaunchKernelGGL(ngm::cigar_strings_kernel<false>, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs_c.p, eng->packed.p, eng->RW, eng->FW,
+					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, sstride, m->d_cig_rows.p, m->d_md_rows.p, m->d_cigout.p);
+			hipLaunchKernelGGL(ngm::cigar_compact_kernel, dim3((na + 255) / 256), dim3(256), 0, m->st, na, sstride, m->d_cig_rows.p, m->d_md_rows.p, m->d_cigout.p, m->d_str.p, scap,
+					m->d_total.p + 8);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipMemcpyAsync(m->p_cigout.p, m->d_cigout.p, (size_t) na * sizeof(ngm::CigarDevOut), hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(&n_str_total, m->d_total.p + 8, 8, hipMemcpyDeviceToHost, m->st));
+		}
 		MAP_HIP_TRY(hipMemcpyAsync(h_rec, m->d_records.p, (size_t) na * 8 * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(&n_runs_total, m->d_total.p, 8, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		if (m->p_runs.reserve(n_runs_total + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
 		h_runs = m->p_runs.p;
 		MAP_HIP_TRY(hipMemcpy(h_runs, m->d_runs_c.p, n_runs_total * 2, hipMemcpyDeviceToHost));
+		if (dev_strings) {
+			n_str_total = std::min<unsigned long long>(n_str_total, (unsigned long long) na * 96ull + 4096ull);
+			if (m->p_str.reserve(n_str_total + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+			if (n_str_total) MAP_HIP_TRY(hipMemcpy(m->p_str.p, m->d_str.p, n_str_total, hipMemcpyDeviceToHost));
+		}
 	}
 	stage_align.done();
 
@@ -1107,7 +1143,14 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			ngm_hip_align_out ao{};
 			ao.cigar = cigars + o * str_stride;
 			ao.md = mds + o * str_stride;
-			if (m->prm.personality == NGM_PERSONALITY_AFFINE) {
+			const ngm::CigarDevOut *dv = dev_strings ? &m->p_cigout.p[j] : nullptr;
+			if (dv && (dv->flags & 1)) {  // built on the GPU: copy the two strings and the numbers
+				if (!(dv->flags & 2)) { h.mapped = 0; continue; }  // no alignment could be built
+				memcpy(ao.cigar, m->p_str.p + dv->cig_off, dv->cig_len); ao.cigar[dv->cig_len] = 0;
+				memcpy(ao.md, m->p_str.p + dv->md_off, dv->md_len); ao.md[dv->md_len] = 0;
+				ao.identity = dv->identity; ao.nm = dv->nm; ao.qstart = dv->qstart; ao.qend = dv->qend; ao.position_offset = dv->position_offset;
+				ao.score_token = dv->score_token;
+			} else if (m->prm.personality == NGM_PERSONALITY_AFFINE) {
 				// matches / mismatches were counted by the traceback kernel: no window decode, no reverse complement here.
 				// EndToEndAffine never touches pBuffer2: the SAM record carries AlignmentBuffer's "!!!" (AlignmentBuffer.cpp:109)
 				ngm::build_cigar_affine(&h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], nullptr, nullptr, q, &ao, L);
