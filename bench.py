@@ -477,8 +477,8 @@ def main():
                         tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     except Exception:
                         continue
-                    for k, v in tj.items():  # grid = 64 threads per read
-                        if k.startswith("ngm::cs_fast_kernel") and k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64)):
+                    for k, v in tj.items():  # grid = 128 threads per read (two waves)
+                        if k.startswith("ngm::cs_fast2_kernel") and k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 128)):
                             traffic, traffic_source = v, "profiles/" + fn
                     if traffic is not None:
                         break
@@ -504,7 +504,7 @@ def main():
             "accuracy_rank0_shard": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
             "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries if ref else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "cs_fast_kernel (candidate search)",
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "cs_fast2_kernel (candidate search)",
                          "isolated": {"achieved": (20 * iso_ctr[0] + 4 * iso_ctr[1] + 16 * iso_ctr[2]) / (iso_ms[0] * 1e-3) / 1e9 if iso_ms[0] > 0 else 0.0, "ms": float(iso_ms[0]),
                                       "reads": int(bounds[1] - bounds[0]),
                                       "note": "same kernel, one launch of one mapper instance with nothing else on the GPU (untimed extra pass)"}, "bytes_per_launch": b_cs / W, "launches_per_step": W,

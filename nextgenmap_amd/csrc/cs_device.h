@@ -68,8 +68,11 @@ struct CsArgs {
 	// cursor would make every read of the batch wait on one L2 atomic); compacted afterwards in read order
 	unsigned long long *out_total;  // [kCsRegions * kCsCursorStride]
 	unsigned long long out_capacity;  // entries per region
+	// ... except for reads with at most kCsFixedSlots candidates (nearly all): those have their own slots behind the regions, so
+	// that their workgroup does not wait for a returning L2 atomic.  0: off
+	uint32_t fixed_base;
 	uint32_t *status;       // [0] output overflow flag, [1] number of queued reads
-	unsigned long long *counters;  // per region, stride kCsCursorStride: [0] k-mers looked up, [1] hits voted (algorithmic-bytes accounting)
+	unsigned long long *counters;  // per region, stride kCsCursorStride: [0] k-mers looked up, [1] hits voted (algorithmic-bytes accounting), [2] candidates
 	uint32_t *order_scratch;    // cs_order_kernel: time lines in global memory for reads with more hits than LDS holds
 	uint32_t order_gcap;        // ... entries per workgroup
 	unsigned long long *phase_cycles;  // optional diagnostics (fast path): [0] lists [1] sweep 1 [2] sweep 2 [3] candidates
@@ -92,24 +95,51 @@ __device__ __forceinline__ uint32_t cs_revcomp(uint32_t prefix, int k) {  // Pre
 	return c;
 }
 
+// Cross-lane steps as DPP modifiers (row shifts / mirrors inside the 16-lane rows, row_bcast15 / row_bcast31 across them:
+// gfx9 has both) instead of ds_bpermute round trips through the LDS pipe.  All 64 lanes must be active at the call.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int wave_dpp(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false); }
+constexpr int kDppQuadSwap1 = 0xB1, kDppQuadSwap2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+
 __device__ __forceinline__ int wave_reduce_max(int v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-	return v;
+	v = max(v, wave_dpp<kDppQuadSwap1, 0xf>(v, v));
+	v = max(v, wave_dpp<kDppQuadSwap2, 0xf>(v, v));
+	v = max(v, wave_dpp<kDppRowHalfMirror, 0xf>(v, v));
+	v = max(v, wave_dpp<kDppRowMirror, 0xf>(v, v));       // every lane: maximum of its row
+	v = max(v, wave_dpp<kDppRowBcast15, 0xa>(v, v));      // rows 1, 3: with the row before
+	v = max(v, wave_dpp<kDppRowBcast31, 0xc>(v, v));      // rows 2, 3: with rows 0-1
+	return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_reduce_min(int v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+	v = min(v, wave_dpp<kDppQuadSwap1, 0xf>(v, v));
+	v = min(v, wave_dpp<kDppQuadSwap2, 0xf>(v, v));
+	v = min(v, wave_dpp<kDppRowHalfMirror, 0xf>(v, v));
+	v = min(v, wave_dpp<kDppRowMirror, 0xf>(v, v));
+	v = min(v, wave_dpp<kDppRowBcast15, 0xa>(v, v));
+	v = min(v, wave_dpp<kDppRowBcast31, 0xc>(v, v));
+	return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int) {
+	v += (uint32_t) wave_dpp<kDppRowShr1, 0xf>(0, (int) v);   // lanes without a source inside their row add the identity
+	v += (uint32_t) wave_dpp<kDppRowShr2, 0xf>(0, (int) v);
+	v += (uint32_t) wave_dpp<kDppRowShr4, 0xf>(0, (int) v);
+	v += (uint32_t) wave_dpp<kDppRowShr8, 0xf>(0, (int) v);   // inclusive prefix inside each row
+	v += (uint32_t) wave_dpp<kDppRowBcast15, 0xa>(0, (int) v);
+	v += (uint32_t) wave_dpp<kDppRowBcast31, 0xc>(0, (int) v);
 	return v;
 }
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const uint32_t t = __shfl_up(v, o);
-		if (lane >= o) v += t;
-	}
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v) {
+	v = max(v, (uint32_t) wave_dpp<kDppRowShr1, 0xf>(0, (int) v));
+	v = max(v, (uint32_t) wave_dpp<kDppRowShr2, 0xf>(0, (int) v));
+	v = max(v, (uint32_t) wave_dpp<kDppRowShr4, 0xf>(0, (int) v));
+	v = max(v, (uint32_t) wave_dpp<kDppRowShr8, 0xf>(0, (int) v));
+	v = max(v, (uint32_t) wave_dpp<kDppRowBcast15, 0xa>(0, (int) v));
+	v = max(v, (uint32_t) wave_dpp<kDppRowBcast31, 0xc>(0, (int) v));
 	return v;
 }
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t) __builtin_amdgcn_readlane((int) v, 63); }
+__device__ __forceinline__ uint32_t wave_first(uint32_t v) { return (uint32_t) __builtin_amdgcn_readlane((int) v, 0); }
 
 // exclusive prefix sum over the lanes of a small per-lane count (< 2^BITS), bit-sliced: one ballot + mbcnt per bit, no
 // cross-lane data movement; total = sum over all lanes (wave-uniform)
@@ -197,6 +227,7 @@ template <> struct CsItem<uint16_t> {
 // bucket word 0 (written by fill_buckets_kernel, refindex.cpp)
 constexpr uint32_t kCsHdrCountMask = 0x3FFFu;   // bits 0-13 own list length (<= 9900), bits 14-27 the other strand's
 constexpr uint32_t kCsHdrOverflow = 0x80000000u;
+constexpr int kCsFixedSlots = 4;   // candidate slots every read owns (CsArgs::fixed_base)
 
 // BUCKETS: the lists come from the bucketed index: one 8-byte read of bucket words 0 and 1 per list -- the header (length,
 // "does not fit" flag) and either the first position or, for a list that does not fit, its start in the position table --
@@ -282,9 +313,9 @@ __device__ __forceinline__ CsRead cs_prepare(const CsArgs &A, int read, int lane
 					for (uint32_t sg = 0; sg < nsf; ++sg, ++o) if (o < items_cap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p), sg);
 					for (uint32_t sg = 0; sg < nsr; ++sg, ++o) if (o < items_cap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p + 1), sg);
 				}
-				carry_s += __shfl(incl_s, 63);
+				carry_s += wave_last(incl_s);
 			}
-			carry += __shfl(incl, 63);
+			carry += wave_last(incl);
 		}
 	}
 	if (!ITEMS && lane == 0) l_pref[R.n_lists] = (PrefT) carry;
@@ -336,21 +367,30 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 		}
 	}
 	const uint32_t incl = wave_inclusive_scan(count, lane);
-	uint32_t total = __shfl(incl, 63);
+	uint32_t total = wave_last(incl);
 	if ((int64_t) total >= (int64_t) A.max_cmrs) total = 0;  // "if (index < maxScores) AllocScores" (CS.cpp:308-310)
+	const bool fixed = A.fixed_base != 0u && total <= (uint32_t) kCsFixedSlots;  // wave-uniform
 	unsigned long long base = 0;
 	if (lane == 0) {
-		base = total ? atomicAdd(&A.out_total[region * kCsCursorStride], (unsigned long long) total) : 0ull;
-		if (base + total > A.out_capacity) { atomicExch(&A.status[0], 1u); }
-		A.cand_base[read] = (uint32_t) (region * A.out_capacity + base);
+		if (!fixed) {
+			base = total ? atomicAdd(&A.out_total[region * kCsCursorStride], (unsigned long long) total) : 0ull;
+			if (base + total > A.out_capacity) { atomicExch(&A.status[0], 1u); }
+		}
+		A.cand_base[read] = fixed ? A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots : (uint32_t) (region * A.out_capacity + base);
 		A.cand_count[read] = total;
 		A.max_votes[read] = max_hit;
 		if (A.max_both) A.max_both[read] = (float) mxb;
 		A.read_len[read] = (uint16_t) R.L;
+		if (A.counters && total) atomicAdd(&A.counters[region * kCsCursorStride + 2], (unsigned long long) total);
 	}
-	base = __shfl((uint32_t) base, 0) | ((unsigned long long) __shfl((uint32_t) (base >> 32), 0) << 32);
-	if (total == 0 || base + total > A.out_capacity) return true;
-	uint32_t w = (uint32_t) (region * A.out_capacity + base) + (incl - count);
+	if (total == 0) return true;
+	uint32_t w;
+	if (fixed) w = A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots + (incl - count);
+	else {
+		base = wave_first((uint32_t) base) | ((unsigned long long) wave_first((uint32_t) (base >> 32)) << 32);
+		if (base + total > A.out_capacity) return true;
+		w = (uint32_t) (region * A.out_capacity + base) + (incl - count);
+	}
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
 	for (uint32_t s = lane; s < n_slots; s += 64) {
 		const uint32_t key = cs_tload<MODE>(&t_keys[s]);
@@ -379,6 +419,10 @@ __device__ __forceinline__ bool cs_finish(const CsArgs &A, int read, int lane, c
 // human-size index), 24 -> 1 536 segments (250 bp reads)
 constexpr int kCsFastItemsShort = 12, kCsFastItemsLong = 24;
 constexpr int kCsFastDepth = 2;    // segments in flight per lane
+#ifndef NGM_CS_FAST2_DEPTH
+#define NGM_CS_FAST2_DEPTH 3
+#endif
+constexpr int kCsFast2Depth = NGM_CS_FAST2_DEPTH;  // ... of the two-wave kernel (fewer registers per lane: room for one more)
 // LDS queue: as many entries as the table may hold keys (3/4 of its slots) -- sweep 2 queues at most one hit per key;
 // sweep 1 flushes whenever more than 96 repeats are waiting
 
@@ -583,6 +627,310 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3))) void
 	}
 }
 
+// ---- FAST path, T waves per read --------------------------------------------------------------------------------------
+// The same algorithm as cs_fast_kernel with the read's k-mers and work items dealt to the lanes of T waves (2-4) that share
+// the plane and the table (LDS atomics do not care which wave votes): half the dependent chain per wave and twice the waves
+// per CU for the same LDS footprint -- the kernel is bound by per-read latency x reads in flight.  Each wave has
+// its own half of the repeat queue and inserts it on its own (wave-level ordering only), so sweep 1 runs without block barriers.
+template <int T, int kItems, typename ItemT>
+__global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu((T == 3 && kItems <= 4) ? 8 : 1))) void cs_fast2_kernel(CsArgs A) {
+	constexpr int NT = T * 64;
+	constexpr uint32_t kItemCap = (uint32_t) kItems * (uint32_t) NT;
+	constexpr int RB = T >= 3 ? 1 : 2;  // 64-k-mer chunks per wave per trip of the lists phase (a trip covers T * RB * 64 k-mers)
+	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+	__shared__ uint32_t s_tot[T * RB][3];  // per chunk: hits, segments, k-mers looked up
+	__shared__ int s_len[T];
+	__shared__ uint32_t s_abort, s_nkeys;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int read = blockIdx.x;
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;
+	uint16_t *l_len = (uint16_t *) (cs_lds + A.lists_cap);
+	uint8_t *l_code = (uint8_t *) (l_len + A.lists_cap);
+	ItemT *l_items = (ItemT *) ((uint32_t *) l_code + (A.q + 3) / 4);
+	uint32_t *plane = (uint32_t *) (l_items + kItemCap);
+	const uint32_t plane_words = A.plane_bits >> 5;
+	uint32_t *t_keys = plane + plane_words;
+	const int log2_slots = A.log2_slots;
+	const uint32_t n_slots = 1u << log2_slots;
+	uint32_t *t_votes = t_keys + n_slots;
+	const uint32_t q_cap = ((n_slots * 3u) / 4u) / (uint32_t) T;  // per wave
+	uint32_t *my_queue = t_votes + n_slots + (uint32_t) wv * q_cap;
+	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+	for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
+	if (tid == 0) { s_abort = 0; s_nkeys = 0; }
+	const bool diag = A.phase_cycles && (read & 255) == 0;
+	const unsigned long long c0 = diag ? wall_clock64() : 0ull;
+
+	// 1. codes, k-mers, lists (cs_prepare's steps; the prefix sums cross the two waves through s_tot)
+	CsRead R;
+	{
+		const uint8_t *rp = A.reads + (size_t) read * A.q;
+		int first_nul = A.q;
+		for (int i = tid; i < A.q; i += NT) {
+			const uint32_t ch = rp[i];
+			uint8_t code;
+			if (ch == 0) { code = 255; first_nul = min(first_nul, i); }
+			else if (ch == 'N') code = 4;
+			else code = (uint8_t) ((ch >> 1) & 3u);
+			l_code[i] = code;
+		}
+		first_nul = wave_reduce_min(first_nul);
+		if (lane == 0) s_len[wv] = first_nul;
+		__syncthreads();
+		R.L = s_len[0];
+#pragma unroll
+		for (int w2 = 1; w2 < T; ++w2) R.L = min(R.L, s_len[w2]);
+		const int L = R.L, n_kmers = L - k + 1;
+		R.n_lists = n_kmers > 0 ? 2 * n_kmers : 0;
+		uint32_t carry = 0, carry_s = 0, n_valid = 0;
+		for (int base = 0; base < n_kmers; base += NT * RB) {
+			uint2 hf[RB], hr[RB];
+			uint32_t kf[RB], kr[RB];
+			bool valid[RB];
+#pragma unroll
+			for (int r = 0; r < RB; ++r) {
+				const int p = base + (r * T + wv) * 64 + lane;
+				valid[r] = false;
+				hf[r] = make_uint2(0, 0); hr[r] = make_uint2(0, 0); kf[r] = 0; kr[r] = 0;
+				if (p < n_kmers) {
+					bool v = true;
+					uint32_t kmer = 0;
+					for (int j = 0; j < k; ++j) {
+						const uint32_t c = l_code[p + j];
+						v = v && (c < 4);
+						kmer = (kmer << 2) | (c & 3u);
+					}
+					if (v && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) v = false;  // CSstatic.cpp:30-41, see cs_prepare
+					valid[r] = v;
+					if (v) {
+						kf[r] = kmer; kr[r] = cs_revcomp(kmer, k);
+						hf[r] = *reinterpret_cast<const uint2 *>(A.buckets + ((size_t) kf[r] << A.bucket_log2_words));
+						hr[r] = *reinterpret_cast<const uint2 *>(A.buckets + ((size_t) kr[r] << A.bucket_log2_words));
+					}
+				}
+			}
+			uint32_t cf[RB], cr[RB], sf[RB], sr[RB], ex[RB], ex_s[RB];
+#pragma unroll
+			for (int r = 0; r < RB; ++r) {
+				cf[r] = cr[r] = sf[r] = sr[r] = 0;
+				const uint32_t nf = hf[r].x & kCsHdrCountMask, nr = hr[r].x & kCsHdrCountMask;
+				if (valid[r] && (int) (nf + nr) < A.max_kfreq) {  // CS.cpp:122
+					cf[r] = nf; sf[r] = (hf[r].x & kCsHdrOverflow) ? A.pos_base + hf[r].y : (kf[r] << A.bucket_log2_words) + 1u;
+					cr[r] = nr; sr[r] = (hr[r].x & kCsHdrOverflow) ? A.pos_base + hr[r].y : (kr[r] << A.bucket_log2_words) + 1u;
+				}
+				const uint32_t both = cf[r] + cr[r], segs = (cf[r] + kCsSeg - 1) / kCsSeg + (cr[r] + kCsSeg - 1) / kCsSeg;
+				const uint32_t incl = wave_inclusive_scan(both, lane), incl_s = wave_inclusive_scan(segs, lane);
+				ex[r] = incl - both; ex_s[r] = incl_s - segs;
+				const uint32_t nv = (uint32_t) __popcll(__ballot(valid[r]));
+				if (lane == 63) { s_tot[r * T + wv][0] = incl; s_tot[r * T + wv][1] = incl_s; s_tot[r * T + wv][2] = nv; }
+			}
+			__syncthreads();
+#pragma unroll
+			for (int r = 0; r < RB; ++r) {
+				const int c = r * T + wv, p = base + c * 64 + lane;
+				uint32_t o = carry_s + ex_s[r];
+				for (int c2 = 0; c2 < c; ++c2) o += s_tot[c2][1];
+				if (p < n_kmers) {
+					l_start[2 * p] = sf[r]; l_len[2 * p] = (uint16_t) cf[r];
+					l_start[2 * p + 1] = sr[r]; l_len[2 * p + 1] = (uint16_t) cr[r];
+					const uint32_t nsf = (cf[r] + kCsSeg - 1) / kCsSeg, nsr = (cr[r] + kCsSeg - 1) / kCsSeg;
+					for (uint32_t sg = 0; sg < nsf; ++sg, ++o) if (o < kItemCap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p), sg);
+					for (uint32_t sg = 0; sg < nsr; ++sg, ++o) if (o < kItemCap) l_items[o] = CsItem<ItemT>::make((uint32_t) (2 * p + 1), sg);
+				}
+			}
+#pragma unroll
+			for (int c = 0; c < T * RB; ++c) { carry += s_tot[c][0]; carry_s += s_tot[c][1]; n_valid += s_tot[c][2]; }
+			__syncthreads();
+		}
+		R.H = carry; R.n_valid = n_valid; R.n_items = carry_s;
+	}
+	const uint32_t H = R.H;
+	const int L = R.L;
+	if (H > A.hit_cap || R.n_items > kItemCap) { if (wv == 0) cs_enqueue(A, read, lane, R); return; }
+	const unsigned long long c1 = diag ? wall_clock64() : 0ull;
+
+	const uint32_t pbits = A.plane_bits;
+	const int hs = 32 - log2_slots;
+	const uint32_t n_items = R.n_items;
+	// LDS operations of one wave complete in program order: the queue hand-over inside a wave needs no hardware barrier, only
+	// the compiler kept from moving the accesses
+	auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+	uint32_t q_len = 0;        // this wave's queue (wave-uniform)
+	bool abort_fast = false;
+	auto flush_inserts = [&]() {
+		wave_sync();
+		const uint32_t nq = min(q_len, q_cap);
+		uint32_t fresh = 0;
+		if (!abort_fast) for (uint32_t i = lane; i < nq; i += 64) {
+			const uint32_t e = my_queue[i];
+			const uint32_t bin = e & 0x3FFFFFFFu;
+			uint32_t slot = (bin * 2654435761u) >> hs;
+			for (uint32_t probes = 0;; ++probes) {
+				if (probes >= n_slots) { slot = 0xFFFFFFFFu; break; }  // the other wave filled the table meanwhile
+				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+				if (prev == bin) break;
+				if (prev == 0xFFFFFFFFu) { ++fresh; break; }
+				slot = (slot + 1) & (n_slots - 1);
+			}
+			if (slot != 0xFFFFFFFFu) atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); else s_abort = 1u;
+		}
+		uint32_t total;
+		(void) wave_prefix_small<4>(fresh, total);  // fresh <= q_cap / 64 < 16
+		uint32_t before = 0;
+		if (lane == 0 && total) before = atomicAdd(&s_nkeys, total);
+		before = wave_first(before);
+		if (before + total > (n_slots * 3u) / 4u) { abort_fast = true; if (lane == 0) s_abort = 1u; }  // probing gets slow, the spurious entries too many
+		wave_sync();
+		q_len = 0;
+	};
+	auto fetch = [&](int it, CsU4 (&d)[kCsSeg / 4]) -> uint32_t {
+		const uint32_t idx = (uint32_t) it * (uint32_t) NT + (uint32_t) tid;
+		uint32_t meta = 0;
+		if (idx < n_items) {
+			const uint32_t item = l_items[idx];
+			const uint32_t li = CsItem<ItemT>::list(item), sg = CsItem<ItemT>::seg(item);
+			const uint32_t cnt = min((uint32_t) kCsSeg, (uint32_t) l_len[li] - sg * kCsSeg);
+			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.buckets + l_start[li] + sg * kCsSeg);
+#pragma unroll
+			for (int v = 0; v < kCsSeg / 4; ++v) if ((uint32_t) (4 * v) < cnt) d[v] = src[v];
+			const int p = (int) (li >> 1);
+			meta = (cnt << 16) | ((li & 1u) ? ((uint32_t) (L - (p + k)) | 0x80000000u) : (uint32_t) p);  // CS.cpp:140-142
+		}
+		return meta;
+	};
+
+	// sweep 1 (see cs_fast_kernel)
+	uint32_t bins[kItems * kCsSeg];
+	constexpr int DEPTH = kCsFast2Depth;
+	CsU4 ring[DEPTH][kCsSeg / 4];
+	uint32_t rmeta[DEPTH];
+#pragma unroll
+	for (int d = 0; d < DEPTH - 1; ++d) rmeta[d] = fetch(d, ring[d]);
+#pragma unroll
+	for (int it = 0; it < kItems; ++it) {
+		if ((uint32_t) it * (uint32_t) NT >= n_items) {  // block-uniform
+#pragma unroll
+			for (int j = 0; j < kCsSeg; ++j) bins[it * kCsSeg + j] = 0;
+			continue;
+		}
+		if (it + DEPTH - 1 < kItems) rmeta[(it + DEPTH - 1) % DEPTH] = fetch(it + DEPTH - 1, ring[(it + DEPTH - 1) % DEPTH]);
+		const uint32_t meta = rmeta[it % DEPTH];
+		CsU4 (&cur)[kCsSeg / 4] = ring[it % DEPTH];
+		const uint32_t cnt = (meta >> 16) & 0x1Fu, corr = meta & 0xFFFFu, rev = meta & 0x80000000u;
+		uint32_t old[kCsSeg], msk[kCsSeg], ent[kCsSeg];
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) {
+			const uint32_t pos = (j & 3) == 0 ? cur[j >> 2].x : (j & 3) == 1 ? cur[j >> 2].y : (j & 3) == 2 ? cur[j >> 2].z : cur[j >> 2].w;
+			const bool valid = (uint32_t) j < cnt;
+			const uint32_t bin = ((pos - corr) >> A.bin_shift) & 0x3FFFFFFFu;
+			const uint32_t b = __umulhi(bin * 0x9E3779B1u, pbits);
+			msk[j] = valid ? (1u << (b & 31)) : 0u;
+			old[j] = atomicOr(&plane[b >> 5], msk[j]);
+			ent[j] = bin | rev;
+		}
+		uint32_t ndup = 0;
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
+		uint32_t qb;
+		{ uint32_t total; qb = q_len + wave_prefix_small<4>(ndup, total); q_len += total; }
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) {
+			const bool first = msk[j] != 0u && (old[j] & msk[j]) == 0u;  // valid and first on its bit
+			bins[it * kCsSeg + j] = first ? (ent[j] | 0x40000000u) : 0u;    // repeats vote in sweep 1: nothing left to do for them
+		}
+		// the repeats go through the queue: inserted when a good batch is waiting (a round adds ~40 per wave) and after the last
+		// round; when one round brings more than the queue holds (repetitive reads) it is filled and emptied window by window
+		const bool last_round = (uint32_t) (it + 1) * (uint32_t) NT >= n_items || it + 1 == kItems;
+		uint32_t window = 0;  // queue coordinates [window, window + q_cap) are in the queue right now
+		for (;;) {
+			uint32_t at = qb;
+#pragma unroll
+			for (int j = 0; j < kCsSeg; ++j) if ((old[j] & msk[j]) != 0u) { if (at - window < q_cap) my_queue[at - window] = ent[j]; ++at; }
+			const bool more = q_len - window > q_cap;
+			if (more || q_len - window > (T >= 4 ? 0u : q_cap / 2u) || last_round) {
+				const uint32_t all = q_len;
+				q_len = min(all - window, q_cap);
+				flush_inserts();  // leaves q_len = 0
+				if (!more) break;
+				q_len = all; window += q_cap;
+				continue;
+			}
+			q_len -= window;
+			break;
+		}
+	}
+	__syncthreads();
+	const unsigned long long c2 = diag ? wall_clock64() : 0ull;
+	if (s_abort) { if (wv == 0) cs_enqueue(A, read, lane, R); return; }  // not provably exact here
+
+	// sweep 2
+	for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
+	__syncthreads();
+	for (uint32_t s = tid; s < n_slots; s += NT) {
+		const uint32_t key = t_keys[s];
+		if (key != 0xFFFFFFFFu) {
+			const uint32_t b = __umulhi(key * 0x9E3779B1u, pbits);
+			atomicOr(&plane[b >> 5], 1u << (b & 31));
+		}
+	}
+	__syncthreads();
+	uint32_t nhit = 0;
+	uint32_t wmask[kItems];
+#pragma unroll
+	for (int it = 0; it < kItems; ++it) {
+		wmask[it] = 0;
+		if ((uint32_t) it * (uint32_t) NT >= n_items) continue;
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) {
+			const uint32_t e = bins[it * kCsSeg + j];
+			const uint32_t b = __umulhi((e & 0x3FFFFFFFu) * 0x9E3779B1u, pbits);
+			const uint32_t w = (plane[b >> 5] >> (b & 31)) & (e >> 30) & 1u;
+			wmask[it] |= w << j;
+		}
+		nhit += __popc(wmask[it]);
+	}
+	{
+		// the marked hits go through this wave's queue to be spread over its lanes: add the vote where the bin is in the table (a
+		// set bit may also be a collision).  One hit per table key plus the collisions: more than the per-wave queue holds for the
+		// reads with the fullest tables, so window by window again
+		uint32_t total;
+		const uint32_t qb = wave_prefix_small<8>(nhit, total);  // nhit <= 8 * kItems <= 96
+		for (uint32_t window = 0; window < total; window += q_cap) {
+			uint32_t at = qb;
+#pragma unroll
+			for (int it = 0; it < kItems; ++it) {
+				if (wmask[it])
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) if ((wmask[it] >> j) & 1u) { if (at - window < q_cap) my_queue[at - window] = bins[it * kCsSeg + j]; ++at; }
+			}
+			wave_sync();
+			const uint32_t nq = min(total - window, q_cap);
+			for (uint32_t i = lane; i < nq; i += 64) {
+				const uint32_t e = my_queue[i];
+				const uint32_t bin = e & 0x3FFFFFFFu;
+				uint32_t slot = (bin * 2654435761u) >> hs;
+				for (;;) {  // the table is at most 3/4 full here
+					const uint32_t key = t_keys[slot];
+					if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); break; }
+					if (key == 0xFFFFFFFFu) break;
+					slot = (slot + 1) & (n_slots - 1);
+				}
+			}
+			wave_sync();
+		}
+	}
+	__syncthreads();
+	const unsigned long long c3 = diag ? wall_clock64() : 0ull;
+	if (wv != 0) return;
+	if (s_abort) { cs_enqueue(A, read, lane, R); return; }
+	if (!cs_finish<kCsFast>(A, read, lane, R, t_keys, t_votes, n_slots)) cs_enqueue(A, read, lane, R);
+	if (diag && lane == 0) {
+		atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);
+		atomicAdd(&A.phase_cycles[3], wall_clock64() - c3);
+	}
+}
+
 // ---- EXACT paths: every hit goes into an open-addressing table (LDS, or global memory for very repetitive reads) --
 template <int MODE>
 __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
@@ -655,9 +1003,8 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 // out: cand_rank[c] = 2 * (rList position among the tracked bins) + strand for every candidate c of the read, i.e. its
 // relative order in CollectResultsStd's output (forward before reverse of one bin, src/CS.cpp:289-304).
 constexpr int kCsOrderLog2Slots = 10;       // tracked bins (>= 2 votes, plus bit collisions): 1024 slots
-constexpr uint32_t kCsOrderMaxHits = 6144;  // time line entries in LDS; reads with more hits keep the position order
+constexpr uint32_t kCsOrderMaxHits = 7168;  // time line entries in LDS; reads with more hits use a slice of global memory
 constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
-constexpr uint32_t kCsOrderItemCap = 1280; // 8-hit list segments of such a read
 
 __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
 		uint32_t *__restrict__ cand_rank) {
@@ -680,20 +1027,30 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; t_cand[s] = 0; }
 	if (lane == 0) s_keys = 0;
-	uint32_t *l_items = ev_at + kCsOrderMaxHits;  // [kCsOrderItemCap]
-	const CsRead R = cs_prepare<true, uint32_t>(A, read, lane, l_start, l_pref, l_code, l_items, kCsOrderItemCap);
+	uint32_t *seg_pref = ev_at + kCsOrderMaxHits;  // [lists_cap + 1]: work items (8-hit list segments) in front of each list
+	const CsRead R = cs_prepare<true, uint32_t>(A, read, lane, l_start, l_pref, l_code, (uint32_t *) nullptr, 0);
 	const uint32_t H = R.H;
 	const int L = R.L;
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
 	auto give_up = [&]() { for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown; };
-	// very repetitive reads: the time line moves to global memory and the lists are walked hit by hit (rare, slow, exact);
-	// the 16-bit list offsets of l_pref bound that at 65 535 hits
-	const bool big = H > kCsOrderMaxHits || R.n_items > kCsOrderItemCap;
+	// very repetitive reads: the time line moves to global memory; the 16-bit list offsets of l_pref bound that at 65 535 hits
+	const bool big = H > kCsOrderMaxHits;
 	if (big) {
 		if (!A.order_scratch || H > A.order_gcap || H >= 65536u) { give_up(); return; }
 		ev_at = A.order_scratch + (size_t) blockIdx.x * A.order_gcap;
 	}
 	__syncthreads();
+	{
+		uint32_t carry = 0;
+		for (int base = 0; base < R.n_lists; base += 64) {
+			const int li = base + lane;
+			const uint32_t ns = li < R.n_lists ? ((l_pref[li] & 0xFFFFu) + kCsSeg - 1) / kCsSeg : 0u;
+			const uint32_t incl = wave_inclusive_scan(ns, lane);
+			if (li < R.n_lists) seg_pref[li] = carry + incl - ns;
+			carry += wave_last(incl);
+		}
+		if (lane == 0) seg_pref[R.n_lists] = carry;
+	}
 	// the candidates themselves are tracked whatever their votes: with a final threshold <= 1 (few votes: sensitive settings,
 	// diverged reads) single-vote bins are candidates too, and entered rList at their only hit
 	{
@@ -732,27 +1089,22 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 			}
 		}
 	};
-	if (big) {
+	{
+		// work item = 8 consecutive hits of one list (two 16-byte loads), the next item's loads in flight; item -> (list,
+		// segment) by bisection of seg_pref, so that no item list has to fit anywhere
 		const int n_lists = R.n_lists;
-		for (uint32_t h = (uint32_t) lane; h < H; h += 64) {
-			int lo = 0, hi = n_lists;  // largest list whose first hit is at or before h (empty lists share their successor's offset)
-			while (hi - lo > 1) {
-				const int mid = (lo + hi) >> 1;
-				if ((l_pref[mid] >> 16) <= h) lo = mid; else hi = mid;
-			}
-			while ((l_pref[lo] & 0xFFFFu) == 0u || h - (l_pref[lo] >> 16) >= (l_pref[lo] & 0xFFFFu)) --lo;  // skip empty lists that start at the same offset
-			vote(A.positions[l_start[lo] + (h - (l_pref[lo] >> 16))], lo, h);
-		}
-	} else {
-		// work item = 8 consecutive hits of one list (two 16-byte loads), the next item's loads in flight
 		CsU4 cur[2], nxt[2];
 		auto fetch = [&](uint32_t idx, CsU4 (&d)[2]) -> uint32_t {
 			if (idx >= R.n_items) return 0xFFFFFFFFu;
-			const uint32_t item = l_items[idx];
-			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
+			int lo = 0, hi = n_lists;  // the list with seg_pref[li] <= idx < seg_pref[li + 1] (never an empty one)
+			while (hi - lo > 1) {
+				const int mid = (lo + hi) >> 1;
+				if (seg_pref[mid] <= idx) lo = mid; else hi = mid;
+			}
+			const uint32_t li = (uint32_t) lo, sg = idx - seg_pref[lo];
 			const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_start[li] + sg * kCsSeg);
 			d[0] = src[0]; d[1] = src[1];  // the table is padded by 16 entries
-			return item;
+			return (li << 16) | sg;
 		};
 		uint32_t item = fetch((uint32_t) lane, cur);
 		for (uint32_t idx = (uint32_t) lane; idx < R.n_items; idx += 64) {
@@ -794,10 +1146,11 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		ev_at[t] = out;
 	}
 	__syncthreads();
-	// replay in time order.  A bin with one vote never moves the maximum beyond 1 and is never a candidate: the very
-	// first hit of the read already sets the maximum to 1 (CS.cpp:197-202), so only bins with >= 2 votes are replayed.
-	float max_hit = H > 0 ? 1.0f : 0.0f, thresh = max_hit * A.sensitivity;
-	uint32_t next_rank = 0;
+	// replay in time order.  A bin with one vote never moves the maximum beyond 1 and is never a candidate unless the final
+	// threshold is <= 1 (those are tracked as t_cand): the very first hit of the read already sets the maximum to 1
+	// (CS.cpp:197-202), so only the hits of those bins take part; they are packed to the front of the time line first.
+	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	uint32_t E = 0;
 	for (uint32_t t0 = 0; t0 < H; t0 += 64) {
 		const uint32_t t = t0 + (uint32_t) lane;
 		uint32_t e = (t < H) ? ev_at[t] : 0xFFFFFFFFu;
@@ -805,20 +1158,42 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 			const uint32_t v = t_votes[e & 0x7FFFFFFFu];
 			if ((v & 0xFFFFu) + (v >> 16) < 2u && !t_cand[e & 0x7FFFFFFFu]) e = 0xFFFFFFFFu;
 		}
-		unsigned long long todo = __ballot(e != 0xFFFFFFFFu);
-		while (todo) {
-			const int i = __ffsll((long long) todo) - 1;
-			todo &= todo - 1;
-			const uint32_t ev = (uint32_t) __shfl((int) e, i);
-			const uint32_t slot = ev & 0x7FFFFFFFu;
-			uint32_t run = t_run[slot];
-			uint32_t score;
-			if (ev & 0x80000000u) { run += 0x10000u; score = run >> 16; } else { run += 1u; score = run & 0xFFFFu; }
-			if (lane == 0) t_run[slot] = run;
-			if ((float) score > max_hit) { max_hit = (float) score; thresh = max_hit * A.sensitivity; }      // CS.cpp:197-202
-			if (t_rank[slot] == kCsOrderUnknown && (float) score >= thresh) { if (lane == 0) t_rank[slot] = next_rank; ++next_rank; }  // CS.cpp:205-208
-			__builtin_amdgcn_wave_barrier();  // one wave: LDS operations complete in program order
+		const unsigned long long keep = __ballot(e != 0xFFFFFFFFu);
+		if (e != 0xFFFFFFFFu) ev_at[E + (uint32_t) __popcll(keep & lanes_below)] = e;  // E <= t0: behind everything still to be read
+		E += (uint32_t) __popcll(keep);
+	}
+	// 64 hits per trip instead of one: what the sequential loop of CS::AddLocationStd carries from hit to hit is (a) the
+	// votes of the hit's bin so far -- votes before this trip (t_run) + earlier lanes of the trip with the same bin and
+	// strand -- and (b) the running maximum (CS.cpp:197-202), an inclusive prefix maximum over the lanes.  A bin enters
+	// rList at its first hit with score >= maximum * sensitivity (CS.cpp:205-208); the ranks follow the lane order.
+	uint32_t max_votes = H > 0 ? 1u : 0u, next_rank = 0;
+	for (uint32_t c0 = 0; c0 < E; c0 += 64) {
+		__syncthreads();
+		const bool act = c0 + (uint32_t) lane < E;
+		const uint32_t e = act ? ev_at[c0 + (uint32_t) lane] : 0u;
+		const uint32_t slot = e & 0x7FFFFFFFu;
+		const bool rev = (e >> 31) != 0u;
+		unsigned long long same_bin = __ballot(act);  // lanes of this trip that hit the same bin
+#pragma unroll
+		for (int b = 0; b < kCsOrderLog2Slots; ++b) {
+			const bool bit = (slot >> b) & 1u;
+			const unsigned long long bb = __ballot(act && bit);
+			same_bin &= bit ? bb : ~bb;
 		}
+		const unsigned long long rev_lanes = __ballot(act && rev);
+		const unsigned long long same_key = same_bin & (rev ? rev_lanes : ~rev_lanes);
+		const uint32_t run = act ? t_run[slot] : 0u;
+		const uint32_t score = act ? (rev ? run >> 16 : run & 0xFFFFu) + (uint32_t) __popcll(same_key & lanes_below) + 1u : 0u;
+		if (act && ((same_bin >> lane) >> 1) == 0ull)  // the bin's last lane of this trip
+			t_run[slot] = run + (uint32_t) __popcll(same_bin & ~rev_lanes) + ((uint32_t) __popcll(same_bin & rev_lanes) << 16);
+		const uint32_t mx = max(wave_inclusive_max(score), max_votes);
+		max_votes = wave_last(mx);
+		const bool enters = act && (float) score >= (float) mx * A.sensitivity && t_rank[slot] == kCsOrderUnknown;
+		const unsigned long long entering = __ballot(enters);
+		const bool first = enters && (entering & same_bin & lanes_below) == 0ull;
+		const unsigned long long firsts = __ballot(first);
+		if (first) t_rank[slot] = next_rank + (uint32_t) __popcll(firsts & lanes_below);
+		next_rank += (uint32_t) __popcll(firsts);
 	}
 	__syncthreads();
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;

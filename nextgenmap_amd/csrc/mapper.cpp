@@ -55,12 +55,14 @@ struct ngm_mapper {
 	ngm_hip_ctx *eng = nullptr;
 	hipStream_t st = nullptr;
 	int max_kfreq = 0;
-	int cs_log2_slots = 13;   // large LDS vote table: 2^13 slots * 8 B = 64 KB
+	int cs_log2_slots = 14;   // large LDS vote table: 2^14 slots * 8 B = 128 KB (2^13 when the lists of very long reads need the room)
 	int cs_log2_small = 10;   // fast path: small exact table ...
 	uint32_t cs_plane_bits = 65536;
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
 	int cs_fast_items = ngm::kCsFastItemsShort;
+	size_t cs_region_cap = 0; // candidate slots of all output regions together (grows when a batch overflows)
+	int cs_waves = 3;         // waves per read of the fast path (cs_fast2_kernel; 1: cs_fast_kernel, NGM_HIP_CS_WAVES)
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
@@ -119,7 +121,7 @@ size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
 	if (mode == ngm::kCsFast)  // list starts (32-bit) + lengths (16-bit), codes, plane, items, table, queue
 		w = (size_t) A.lists_cap + (size_t) A.lists_cap / 2 + (A.q + 3) / 4 + ((size_t) A.plane_bits >> 5) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) +
-				((size_t) 3 << A.log2_slots) / 4;
+				((size_t) 3 << A.log2_slots) / 4 + 32;  // + the kernels' static variables (<= 128 bytes): this is what the occupancy math sees
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -137,12 +139,13 @@ int run_cs(ngm_mapper *m, int n) {
 		return -12;
 	}
 	const size_t ctr_words = (size_t) ngm::kCsRegions * ngm::kCsCursorStride;
-	size_t cap = std::max<size_t>(m->d_out_loc.cap, (size_t) n * 8 + 64 * ngm::kCsRegions);
+	size_t cap = std::max<size_t>(m->cs_region_cap, (size_t) n * 4 + 64 * ngm::kCsRegions);
 	cap = (cap + ngm::kCsRegions - 1) / ngm::kCsRegions * ngm::kCsRegions;
+	const size_t fixed_slots = getenv("NGM_HIP_CS_NO_FIXED_SLOTS") ? 0 : (size_t) n * ngm::kCsFixedSlots;
 	for (int attempt = 0; attempt < 8; ++attempt) {
 		// candidate offsets are 32-bit (base = region * capacity + cursor; the prefix sums over the counts)
-		if (cap >= 0xFFFFFFFFull) { ngm::pipeline_set_error("more than 2^32 candidate slots needed for %d reads: use smaller batches or a higher sensitivity", n); return -75; }
-		if (m->d_out_loc.reserve(cap) || m->d_out_sv.reserve(cap) || m->d_out_loc2.reserve(cap) || m->d_out_sv2.reserve(cap)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
+		if (cap + fixed_slots >= 0xFFFFFFFFull) { ngm::pipeline_set_error("more than 2^32 candidate slots needed for %d reads: use smaller batches or a higher sensitivity", n); return -75; }
+		if (m->d_out_loc.reserve(cap + fixed_slots) || m->d_out_sv.reserve(cap + fixed_slots) || m->d_out_loc2.reserve(cap + fixed_slots) || m->d_out_sv2.reserve(cap + fixed_slots)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 16) * 8, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 16) * 8, m->st));
@@ -153,6 +156,7 @@ int run_cs(ngm_mapper *m, int n) {
 		A.lists_cap = 2 * std::max(1, q - r->prm.kmer + 1);
 		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p; A.max_both = m->d_max_both.p;
 		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap / ngm::kCsRegions;
+		A.fixed_base = fixed_slots ? (uint32_t) cap : 0u;
 		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
 		A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + ctr_words : nullptr;
 		uint32_t status[4];
@@ -169,7 +173,21 @@ int run_cs(ngm_mapper *m, int n) {
 		// 16-bit work items when every list index fits 9 bits and no used list can have more than 128 segments
 		A.items16 = (A.lists_cap <= 512 && m->max_kfreq <= 128 * ngm::kCsSeg) ? 1 : 0;
 		if (!A.items16) A.fast_items = ngm::kCsFastItemsLong;  // the 32-bit item list only exists in the large size
-		if (A.fast_items == ngm::kCsFastItemsShort && A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
+		if (m->cs_waves >= 2 && A.items16) {  // T waves per read: the same 768 / 1 536 segments, dealt to T * 64 lanes
+			const bool shrt = A.fast_items == ngm::kCsFastItemsShort;
+			const size_t lds = cs_lds_bytes(A, ngm::kCsFast) - 128;  // the kernel's static variables take the rest
+#define NGM_CS_LAUNCH_T(T) \
+			do { if (shrt) hipLaunchKernelGGL((ngm::cs_fast2_kernel<T, ngm::kCsFastItemsShort / T, uint16_t>), dim3(n), dim3(T * 64), lds, m->st, A); \
+				else hipLaunchKernelGGL((ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>), dim3(n), dim3(T * 64), lds, m->st, A); } while (0)
+			if (m->cs_waves == 2) NGM_CS_LAUNCH_T(2); else if (m->cs_waves == 3) NGM_CS_LAUNCH_T(3); else NGM_CS_LAUNCH_T(4);
+			if (A.phase_cycles && m->cs_waves == 3 && shrt) {  // diagnostics: reads resident per CU
+				int blocks = 0;
+				(void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *) ngm::cs_fast2_kernel<3, ngm::kCsFastItemsShort / 3, uint16_t>, 192, lds);
+				fprintf(stderr, "[ngm-hip] cs fast path: %zu bytes of LDS per read, %d reads resident per CU\n", lds, blocks);
+			}
+#undef NGM_CS_LAUNCH_T
+		}
+		else if (A.fast_items == ngm::kCsFastItemsShort && A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		else if (A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		else hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
@@ -238,6 +256,7 @@ int run_cs(ngm_mapper *m, int n) {
 			MAP_HIP_TRY(hipGetLastError());
 			std::swap(m->d_out_loc, m->d_out_loc2); std::swap(m->d_out_sv, m->d_out_sv2); std::swap(m->d_cand_base, m->d_new_base);
 			m->last_cs = A;
+			m->cs_region_cap = cap;
 			m->n_reads = n;
 			std::vector<unsigned long long> ctr(ctr_words + 16);
 			MAP_HIP_TRY(hipMemcpyAsync(ctr.data(), m->d_counters.p, ctr.size() * 8, hipMemcpyDeviceToHost, m->st));
@@ -248,11 +267,9 @@ int run_cs(ngm_mapper *m, int n) {
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 			m->n_cand = n > 0 ? (uint64_t) m->h_base[n - 1] + m->h_count[n - 1] : 0;
 			{
-				// the 32-bit prefix sums wrap silently: cross-check the total against the 64-bit region cursors
-				std::vector<unsigned long long> tot(ctr_words);
-				MAP_HIP_TRY(hipMemcpy(tot.data(), m->d_total.p, ctr_words * 8, hipMemcpyDeviceToHost));
+				// the 32-bit prefix sums wrap silently: cross-check the total against the 64-bit candidate counters
 				unsigned long long sum = 0;
-				for (int g = 0; g < ngm::kCsRegions; ++g) sum += tot[(size_t) g * ngm::kCsCursorStride];
+				for (int g = 0; g < ngm::kCsRegions; ++g) sum += ctr[(size_t) g * ngm::kCsCursorStride + 2];
 				if (sum != m->n_cand) { ngm::pipeline_set_error("%llu candidates in one batch of %d reads exceed the 32-bit candidate index: use smaller batches", sum, n); return -75; }
 			}
 			m->cs_kmers = m->cs_hits = 0;
@@ -405,34 +422,48 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		const double segs = hexp / 8.0 + 0.44 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
 		m->cs_fast_items = segs * 1.10 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
 		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
-		// The kernel is bound by reads in flight per CU, and those by LDS: when trimming the plane by a few
-		// per cent (it is sized to 12 bits per expected hit; 11 still keep the spurious table entries in bounds) lets one
-		// more read fit the 160 KB of a CU, do it.
+		// The kernel is bound by reads in flight per CU, and those by LDS, which gfx950 hands out in granules of
+		// 1 280 bytes (160 KB / 128: hipOccupancyMaxActiveBlocksPerMultiprocessor reports 9 workgroups of 16 328 bytes per CU and 10
+		// of 15 360).  The plane is sized generously (12 bits per expected hit): when giving up at most a fifth of it (never below
+		// 10 bits per hit -- the spurious table entries H^2 / 2P stay far from the table's capacity) lets one more read in, do it.
 		{
 			ngm::CsArgs G{};
 			G.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); G.q = p->qry_max_len; G.log2_slots = m->cs_log2_small;
 			G.fast_items = m->cs_fast_items; G.items16 = (G.lists_cap <= 512) ? 1 : 0; G.plane_bits = m->cs_plane_bits;
-			const size_t bytes = cs_lds_bytes(G, ngm::kCsFast), lds = 160 * 1024;
+			const size_t granule = 1280, lds = 160 * 1024;
+			const size_t bytes = (cs_lds_bytes(G, ngm::kCsFast) + granule - 1) / granule * granule;
 			const size_t per_cu = lds / std::max<size_t>(bytes, 1);
-			if (per_cu >= 1 && per_cu < 12) {
-				const size_t target = lds / (per_cu + 1);  // bytes that would let one more read in
-				if (bytes > target && (bytes - target) * 8 <= (size_t) m->cs_plane_bits / 12) {  // at most a twelfth of the plane
-					const uint32_t cut_bits = (uint32_t) (((bytes - target) * 8 + 31) / 32 * 32);
-					m->cs_plane_bits -= cut_bits;
+			if (per_cu >= 1 && per_cu < 10) {
+				const size_t target = lds / (per_cu + 1) / granule * granule;  // bytes that would let one more read in
+				const size_t have = cs_lds_bytes(G, ngm::kCsFast);
+				if (have > target) {
+					const uint32_t cut_bits = (uint32_t) (((have - target) * 8 + 31) / 32 * 32);
+					if (cut_bits <= m->cs_plane_bits / 5 && (double) (m->cs_plane_bits - cut_bits) >= 10.0 * hexp) m->cs_plane_bits -= cut_bits;
 				}
 			}
 		}
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
-	A.log2_slots = m->cs_log2_slots; A.log2_bits = 17; A.plane_bits = 131072;
+	A.log2_slots = m->cs_log2_slots;
+	if (cs_lds_bytes(A, ngm::kCsExactLds) > 158 * 1024) { m->cs_log2_slots = 13; A.log2_slots = 13; } A.log2_bits = 17; A.plane_bits = 131072;
 	A.fast_items = ngm::kCsFastItemsLong;
 	A.items16 = 0;
+	const int log2_exact = A.log2_slots;
+	A.log2_slots = 12;  // the largest table the fast path picks (above)
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
+#define NGM_CS_ATTR_T(T) \
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsShort / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast)); \
+	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast))
+	NGM_CS_ATTR_T(2); NGM_CS_ATTR_T(3); NGM_CS_ATTR_T(4);
+#undef NGM_CS_ATTR_T
+	if (const char *e = getenv("NGM_HIP_CS_WAVES")) m->cs_waves = std::min(4, std::max(1, atoi(e)));
+	A.log2_slots = log2_exact;
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
+	(void) hipGetLastError();  // a refused attribute shows up as a launch failure where it matters, not as a stale error at the next check
 	return m;
 }
 
@@ -511,7 +542,7 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	A.read_list = m->d_order_list.p;
 	A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p;
 	A.counters = nullptr; A.phase_cycles = nullptr;
-	const size_t lds = ((size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits + ngm::kCsOrderItemCap) * 4;
+	const size_t lds = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits) * 4;
 	// reads with more hits than the LDS time line holds use a slice of a global scratch: launches of at most 4096 reads
 	constexpr uint32_t kChunk = 4096, kGcap = 49152;
 	if (m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap)) { A.order_scratch = nullptr; A.order_gcap = 0; }
