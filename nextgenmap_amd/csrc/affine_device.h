@@ -345,6 +345,157 @@ __global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t 
 	if (hasB && pairB < n) { if (lenVB < 1 || lenHB < 1) bestB = 0; scores[pairB] = (float) bestB; }
 }
 
+// Align variant, packed 16-bit, local mode: two pairs per lane like the score kernel above, plus what the traceback needs.
+// * Trace: 4 bits per cell instead of SeqAn's 7-bit value in a byte -- "gap opened here" for the horizontal and the vertical
+//   gap (bits 0, 1) and which of {none, diagonal, horizontal maximum, vertical maximum} the cell took (bits 2-3); the Hori /
+//   Vert presence bits depend on the band column alone and are put back by affine_traceback_kernel (aff_trace_from_nibble).
+//   The flags come out of the packed arithmetic without compares: a = max(x, y) opened / switched exactly where a - x > 0,
+//   i.e. min(a - x, 1).
+// * End cell: SeqAn's scout keeps the first strict maximum in column-major order; per row the packed unsigned maximum of
+//   (score << 5 | 31 - d) finds the row's best score and its smallest column, the rule across rows is applied per pair as
+//   in sw_affine_kernel.  Needs score < 2048 and CP <= 32 (checked by the host).
+// * _correctTraceValue's "Ev == S" / "Eh == S" flags at the end cell are always clear here: with negative gap penalties a
+//   gap state is strictly below some earlier S, and the end cell holds the maximum of all S (the host takes this kernel only
+//   then; end-to-end alignments -- which may end in a gap -- stay with sw_affine_kernel).
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr int aff_nib_words(int CP) { return (CP + 7) / 8; }
+__device__ __forceinline__ v2s pk_min(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+
+template <int CP>
+__global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t *__restrict__ packed, const uint16_t *__restrict__ lens,
+		const uint16_t *__restrict__ blk_rows, uint32_t *__restrict__ dirs, int32_t *__restrict__ records, int n, int n_blocks, int RW, int q, AffConst K) {
+	static_assert(CP <= 32, "the row key keeps the band column in 5 bits");
+	__shared__ uint2 s_tab[8];
+	if (threadIdx.x < 8) s_tab[threadIdx.x] = aff_row_table(threadIdx.x, K);
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const int blkA = 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));
+	if (blkA >= n_blocks) return;
+	const bool hasB = blkA + 1 < n_blocks;
+	const int blkB = hasB ? blkA + 1 : blkA;
+	constexpr int NRG = sel_regs(CP);
+	constexpr int DW = aff_nib_words(CP);
+	const int FW = RW + NRG / 2;
+	const uint32_t *rdA = packed + (size_t) blkA * (RW + FW) * kSlots + lane, *rdB = packed + (size_t) blkB * (RW + FW) * kSlots + lane;
+	const uint32_t *fdA = rdA + (size_t) RW * kSlots, *fdB = rdB + (size_t) RW * kSlots;
+	uint32_t *doutA = dirs + (size_t) blkA * q * DW * kSlots + lane, *doutB = dirs + (size_t) blkB * q * DW * kSlots + lane;
+	const int pairA = blkA * kSlots + lane, pairB = blkB * kSlots + lane;
+	const int lenVA = (pairA < n) ? (int) lens[pairA] : 0, lenVB = (pairB < n) ? (int) lens[pairB] : 0;
+	const int rows = max(__builtin_amdgcn_readfirstlane((int) blk_rows[blkA]), __builtin_amdgcn_readfirstlane((int) blk_rows[blkB]));
+	const int ngroups = (rows + 7) >> 3;
+
+	v2s S[CP], Ev[CP];
+#pragma unroll
+	for (int d = 0; d < CP; ++d) { S[d] = pk_splat(0); Ev[d] = pk_splat(0); }
+	uint32_t RGA[NRG], RGB[NRG];
+#pragma unroll
+	for (int r = 0; r < NRG / 2; ++r) {
+		const uint32_t xa = fdA[(size_t) r * kSlots], xb = fdB[(size_t) r * kSlots];
+		RGA[2 * r] = xa & 0x0F0F0F0Fu; RGA[2 * r + 1] = (xa >> 4) & 0x0F0F0F0Fu;
+		RGB[2 * r] = xb & 0x0F0F0F0Fu; RGB[2 * r + 1] = (xb >> 4) & 0x0F0F0F0Fu;
+	}
+	int fl = K.tZ;
+	int bestA = 0, bhA = 0, bvA = 0, bestB = 0, bhB = 0, bvB = 0;
+	const v2s ext2 = pk_splat(K.ext), open2 = pk_splat(K.open), vext2 = pk_splat(K.vext), vopen2 = pk_splat(K.vopen);
+	const v2s neg2 = pk_splat(kAffNeg16), one2 = pk_splat(1), zero2 = pk_splat(0), two2 = pk_splat(2), four2 = pk_splat(4), k32 = pk_splat(32);
+	uint32_t rnA = (ngroups > 0) ? rdA[0] : 0x66666666u, rnB = (ngroups > 0) ? rdB[0] : 0x66666666u;
+
+	for (int g = 0; g < ngroups; ++g) {
+		const uint32_t rxA = rnA, rxB = rnB;
+		rnA = (g + 1 < ngroups) ? rdA[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		rnB = (g + 1 < ngroups) ? rdB[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		const uint32_t fxA = fdA[(size_t) (g + NRG / 2) * kSlots], fxB = fdB[(size_t) (g + NRG / 2) * kSlots];
+		const uint32_t rsA[2] = {rxA & 0x0F0F0F0Fu, (rxA >> 4) & 0x0F0F0F0Fu}, rsB[2] = {rxB & 0x0F0F0F0Fu, (rxB >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {
+			const int i = g * 8 + s;
+			uint32_t rcA = (rsA[s >> 2] >> (8 * (s & 3))) & 0xFFu, rcB = (rsB[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+			rcA = (i < lenVA) ? rcA : 6u;
+			rcB = (i < lenVB) ? rcB : 6u;
+			const uint2 TA = s_tab[rcA], TB = s_tab[rcB];
+			uint32_t PA[NRG], PB[NRG];
+#pragma unroll
+			for (int r = 0; r < NRG; ++r) {
+				const bool used = (s + CP - 1) / 4 >= r && s / 4 <= r;
+				PA[r] = used ? __builtin_amdgcn_perm(TA.y, TA.x, RGA[r]) : 0u;
+				PB[r] = used ? __builtin_amdgcn_perm(TB.y, TB.x, RGB[r]) : 0u;
+			}
+			const v2s fl2 = pk_splat(fl);
+			v2s leftS = neg2, leftEh = neg2;  // column d = 0 has no horizontal predecessor
+			v2u rowkey = __builtin_bit_cast(v2u, zero2);
+			uint32_t acc[2] = {0u, 0u};       // 4 trace nibbles per pair each: low halves pair A, high halves pair B
+#pragma unroll
+			for (int d = 0; d < CP; ++d) {
+				const int bi = s + d, kb = bi & 3;
+				const uint32_t sel = 0x0C000C00u | (uint32_t) kb | ((uint32_t) (4 + kb) << 16);
+				const v2s t = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(PB[bi >> 2], PA[bi >> 2], sel));
+				const v2s dg = S[d] + t;
+				v2s eh = neg2, ho = zero2;   // ho / vo: 1 where the gap was opened in this cell (strictly better than extending)
+				if (d > 0) { const v2s e = leftEh + ext2; eh = pk_max(e, leftS + open2); ho = pk_min(eh - e, one2); }
+				v2s ev = neg2, vo = zero2;
+				if (d < CP - 1) { const v2s e = Ev[d + 1] + vext2; ev = pk_max(e, S[d + 1] + vopen2); vo = pk_min(ev - e, one2); }
+				// gap maximum: vertical unless horizontal is strictly greater (fh); the diagonal wins ties against it (nd = 0)
+				v2s gm, fh;
+				if (d == 0) { gm = ev; fh = zero2; } else if (d == CP - 1) { gm = eh; fh = one2; } else { gm = pk_max(ev, eh); fh = pk_min(gm - ev, one2); }
+				v2s sc = pk_max(gm, dg);
+				const v2s nd = pk_min(sc - dg, one2);
+				const v2s pos = pk_max(sc - fl2, zero2);     // the cell's score; 0: clamped (S = Eh = Ev = 0, no trace)
+				const v2s nz = pk_min(pos, one2);
+				sc = pk_max(sc, fl2);
+				eh = fl2 + (eh - fl2) * nz;
+				ev = fl2 + (ev - fl2) * nz;
+				const v2s took = nz * (one2 + nd * (two2 - fh));  // 0 none, 1 diagonal, 2 horizontal maximum, 3 vertical maximum
+				const v2s nib = took * four2 + vo * two2 + ho;
+				acc[(d >> 2) & 1] |= __builtin_bit_cast(uint32_t, nib) << (4 * (d & 3));
+				rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pos * k32 + pk_splat(31 - d)));
+				S[d] = sc;
+				Ev[d] = ev;
+				leftS = sc;
+				leftEh = eh;
+				if ((d & 7) == 7 || d == CP - 1) {
+					if (i < q) {
+						doutA[((size_t) i * DW + (d >> 3)) * kSlots] = (acc[0] & 0xFFFFu) | (acc[1] << 16);
+						if (hasB) doutB[((size_t) i * DW + (d >> 3)) * kSlots] = (acc[0] >> 16) | (acc[1] & 0xFFFF0000u);
+					}
+					acc[0] = acc[1] = 0u;
+				}
+			}
+			{
+				// column-major first maximum: strictly greater, or equal with a smaller h
+				const int ka = (int) rowkey.x, kb2 = (int) rowkey.y;
+				const int rsa = ka >> 5, rha = i + 1 + (31 - (ka & 31)), rsb = kb2 >> 5, rhb = i + 1 + (31 - (kb2 & 31));
+				if (i < lenVA && (rsa > bestA || (rsa == bestA && rsa > 0 && rha < bhA))) { bestA = rsa; bhA = rha; bvA = i + 1; }
+				if (i < lenVB && (rsb > bestB || (rsb == bestB && rsb > 0 && rhb < bhB))) { bestB = rsb; bhB = rhb; bvB = i + 1; }
+			}
+			fl += K.tZ;
+		}
+#pragma unroll
+		for (int r = 0; r + 2 < NRG; ++r) { RGA[r] = RGA[r + 2]; RGB[r] = RGB[r + 2]; }
+		RGA[NRG - 2] = fxA & 0x0F0F0F0Fu; RGA[NRG - 1] = (fxA >> 4) & 0x0F0F0F0Fu;
+		RGB[NRG - 2] = fxB & 0x0F0F0F0Fu; RGB[NRG - 1] = (fxB >> 4) & 0x0F0F0F0Fu;
+	}
+	if (pairA < n) {
+		if (lenVA < 1) { bestA = 0; bhA = bvA = 0; }
+		int32_t *rec = records + (size_t) pairA * 8;
+		rec[0] = 0; rec[1] = 0; rec[2] = 0; rec[3] = 0; rec[4] = 0; rec[5] = bestA; rec[6] = bhA; rec[7] = bvA;
+	}
+	if (hasB && pairB < n) {
+		if (lenVB < 1) { bestB = 0; bhB = bvB = 0; }
+		int32_t *rec = records + (size_t) pairB * 8;
+		rec[0] = 0; rec[1] = 0; rec[2] = 0; rec[3] = 0; rec[4] = 0; rec[5] = bestB; rec[6] = bhB; rec[7] = bvB;
+	}
+}
+
+// 4-bit trace of sw_affine_align_pk_kernel -> SeqAn's trace value of the cell in band column d
+__device__ __forceinline__ uint32_t aff_trace_from_nibble(uint32_t nib, int d, int CP) {
+	const uint32_t took = nib >> 2;
+	if (took == 0u) return 0u;
+	uint32_t tg = 0;
+	if (d > 0) tg |= (nib & 1u) ? (uint32_t) kTHoriOpen : (uint32_t) kTHori;
+	if (d < CP - 1) tg |= (nib & 2u) ? (uint32_t) kTVertOpen : (uint32_t) kTVert;
+	return took == 1u ? (tg | (uint32_t) kTDiag) : (tg | (took == 2u ? (uint32_t) kTMaxH : (uint32_t) kTMaxV));
+}
+
 #ifdef NGM_ENGINE_KERNELS
 // SeqAn's single-trace, gaps-left traceback (dp_traceback_impl.h:184-470) over the stored trace bytes.
 // Emits the same compact runs as the linear traceback: (len << 2) | op, op 1 = M, 2 = I, 3 = D, in traceback order.
@@ -352,19 +503,20 @@ __global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t 
 // (rec[3] = matches, rec[7] = mismatches: characters compare like symbol classes on NextGenMap's alphabet), so the host
 // needs neither the window nor the read to finish NM and identity.
 __global__ __launch_bounds__(256) void affine_traceback_kernel(const uint32_t *__restrict__ dirs, int32_t *__restrict__ records,
-		uint16_t *__restrict__ runs, int n, int q, int CP, int run_stride, const uint32_t *__restrict__ packed, int RW, int FW) {
+		uint16_t *__restrict__ runs, int n, int q, int CP, int run_stride, const uint32_t *__restrict__ packed, int RW, int FW, int nibbles) {
 	const int pair = blockIdx.x * blockDim.x + threadIdx.x;
 	if (pair >= n) return;
 	int32_t *rec = records + (size_t) pair * 8;
 	int h = rec[6], v = rec[7];
 	const int flags = rec[3];
-	const int DW = aff_dir_words(CP);
+	const int DW = nibbles ? aff_nib_words(CP) : aff_dir_words(CP);  // nibbles: the trace of sw_affine_align_pk_kernel
 	const uint32_t *dp = dirs + (size_t) (pair >> 6) * q * DW * kSlots + (pair & 63);
 	uint16_t *out = runs + (size_t) pair * run_stride;
 	auto tv_at = [&](int hh, int vv) -> uint32_t {
 		if (vv <= 0 || hh <= 0) return 0u;  // initialisation row / column: NONE
 		const int d = hh - vv;
 		if (d < 0 || d >= CP) return 0u;
+		if (nibbles) return aff_trace_from_nibble((dp[((size_t) (vv - 1) * DW + (d >> 3)) * kSlots] >> (4 * (d & 7))) & 15u, d, CP);
 		const uint32_t w = dp[((size_t) (vv - 1) * DW + (d >> 2)) * kSlots];
 		return (w >> (8 * (d & 3))) & 0xFFu;
 	};

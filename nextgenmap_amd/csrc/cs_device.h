@@ -656,6 +656,8 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu((T == 3 
 	uint32_t *t_votes = t_keys + n_slots;
 	const uint32_t q_cap = ((n_slots * 3u) / 4u) / (uint32_t) T;  // per wave
 	uint32_t *my_queue = t_votes + n_slots + (uint32_t) wv * q_cap;
+	const uint8_t *rp = A.reads + (size_t) read * A.q;
+	const uint32_t ch0 = tid < A.q ? (uint32_t) rp[tid] : 0u;  // on its way while the table is cleared
 	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 	for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
 	if (tid == 0) { s_abort = 0; s_nkeys = 0; }
@@ -665,10 +667,9 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu((T == 3 
 	// 1. codes, k-mers, lists (cs_prepare's steps; the prefix sums cross the two waves through s_tot)
 	CsRead R;
 	{
-		const uint8_t *rp = A.reads + (size_t) read * A.q;
 		int first_nul = A.q;
 		for (int i = tid; i < A.q; i += NT) {
-			const uint32_t ch = rp[i];
+			const uint32_t ch = i == tid ? ch0 : (uint32_t) rp[i];
 			uint8_t code;
 			if (ch == 0) { code = 255; first_nul = min(first_nul, i); }
 			else if (ch == 'N') code = 4;

@@ -91,6 +91,16 @@ const void *find_pk_affine_score_kernel(int c, bool endfree) {
 	return nullptr;
 }
 
+template <int CP> const void *pk_affine_align_ptr() {
+	if constexpr (CP <= 32) return (const void *) ngm::sw_affine_align_pk_kernel<CP>; else return nullptr;
+}
+const void *find_pk_affine_align_kernel(int c) {
+#define X(C) if (c == C) return pk_affine_align_ptr<C + 1>();
+	NGM_CORRIDORS(X)
+#undef X
+	return nullptr;
+}
+
 KernelRef find_kernel(ngm_hip_ctx *ctx, int kind) {
 	KernelRef k;
 	k.aot = find_aot_kernel(ctx->c, kind);
@@ -160,12 +170,25 @@ int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, u
 	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
 		const int CP = ctx->c + 1, ADW = ngm::aff_dir_words(CP);
 		if (ctx->dirs.reserve((size_t) nb * ctx->q * ADW * ngm::kSlots)) { set_error(ctx, "out of device memory for the trace matrix"); return -12; }
-		const KernelRef ka = find_kernel(ctx, 6 + (am == NGM_MODE_END_TO_END ? 1 : 0));
-		HIP_TRY(ctx, launch_kernel(ka, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
-				(const uint16_t *) ctx->blk_rows.p, (float *) nullptr, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->KA));
+		// local alignments of short reads: two pairs per lane in 16-bit halves, 4-bit trace (see sw_affine_align_pk_kernel for the
+		// conditions: scores below 2 048, at most 32 band columns, negative gap penalties, the 16-bit range of the score kernel)
+		static const bool force32 = getenv("NGM_HIP_ALIGN_32BIT") != nullptr;
+		const void *pk = nullptr;
+		if (!force32 && am != NGM_MODE_END_TO_END && (long) ctx->q * ctx->prm.match_bonus < 2048 && ctx->KA.open < 0 && ctx->KA.ext < 0 && (long) ctx->q * ctx->KA.tM < 30000 &&
+				ctx->prm.gap_read_penalty + (long) ctx->q * (ctx->prm.gap_extend_penalty + ctx->KA.tZ) < 19000)
+			pk = find_pk_affine_align_kernel(ctx->c);
+		if (pk) {
+			KernelRef kp; kp.aot = pk;
+			HIP_TRY(ctx, launch_kernel(kp, dim3((nb + 7) / 8), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+					(const uint16_t *) ctx->blk_rows.p, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->KA));
+		} else {
+			const KernelRef ka = find_kernel(ctx, 6 + (am == NGM_MODE_END_TO_END ? 1 : 0));
+			HIP_TRY(ctx, launch_kernel(ka, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+					(const uint16_t *) ctx->blk_rows.p, (float *) nullptr, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->KA));
+		}
 		if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
 		hipLaunchKernelGGL(ngm::affine_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, d_records, d_runs, n,
-				ctx->q, CP, run_stride, (const uint32_t *) ctx->packed.p, ctx->RW, ctx->FW);
+				ctx->q, CP, run_stride, (const uint32_t *) ctx->packed.p, ctx->RW, ctx->FW, pk ? 1 : 0);
 		HIP_TRY(ctx, hipGetLastError());
 		return 0;
 	}
