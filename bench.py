@@ -477,8 +477,8 @@ def main():
                         tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     except Exception:
                         continue
-                    for k, v in tj.items():  # grid = 128 threads per read (two waves)
-                        if k.startswith("ngm::cs_fast2_kernel") and k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 128)):
+                    for k, v in tj.items():  # grid = 64 threads per wave x 2-4 waves per read
+                        if k.startswith("ngm::cs_fast2_kernel") and any(k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64 * t)) for t in (2, 3, 4)):
                             traffic, traffic_source = v, "profiles/" + fn
                     if traffic is not None:
                         break

@@ -511,7 +511,10 @@ int main(int argc, char **argv) {
 
 	// ---- output ------------------------------------------------------------------------------------------------------
 	// the output is written with pwrite at offsets the writer thread hands out in input order, by pool threads: copying 400+
-	// bytes per read into the page cache from ONE thread would bound the whole program at a few million reads per second
+	// bytes per read into the page cache from ONE thread would bound the whole program at a few million reads per second.
+	// (Measured alternative, round 2: extending the file with ftruncate and filling a shared mapping of each batch's range from
+	// the pool -- 1.6 M reads/s against 3.5 M with pwrite: the page faults of a shared file mapping cost more than the inode
+	// lock that serialises the pwrite calls.)
 	const int out_fd = ::open(o.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
 	if (out_fd < 0) die("cannot write " + o.out);
 	uint64_t out_off = 0;
@@ -836,7 +839,12 @@ int main(int argc, char **argv) {
 		q_in.close();
 	});
 
-	std::atomic<long long> t_wait_us{0}, t_parse_us{0}, t_map_us{0}, t_format_us{0};
+	// The formatted text of a batch (~100 MB in MB-sized pieces) and its record views are recycled instead of freed: fresh memory
+	// means page faults from 64 threads at once, and those serialise on the address-space lock.
+	std::mutex spare_mu;
+	std::vector<std::vector<std::string>> spare_chunks;
+	std::vector<std::vector<Rec>> spare_recs;
+	std::atomic<long long> t_wait_us{0}, t_parse_us{0}, t_map_us{0}, t_format_us{0}, t_format_cpu_us{0}, t_parse_cpu_us{0}, t_write_us{0}, t_write_cpu_us{0};
 	auto us_since = [](std::chrono::steady_clock::time_point t0) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
 	auto worker_main = [&](Worker &w) {
 		std::unique_ptr<Batch> b;
@@ -852,6 +860,11 @@ int main(int argc, char **argv) {
 				w.rows_cap = (size_t) std::max(n, batch_reads) * q;
 				w.rows = (char *) ngm_host_alloc(w.rows_cap);
 				if (!w.rows) { fail(ngm_pipeline_last_error()); w.rows_cap = 0; }
+			}
+			{
+				std::lock_guard<std::mutex> lk(spare_mu);
+				if (!spare_recs.empty()) { b->recs = std::move(spare_recs.back()); spare_recs.pop_back(); }
+				if (!spare_chunks.empty()) { b->chunks = std::move(spare_chunks.back()); spare_chunks.pop_back(); }
 			}
 			b->recs.resize(n);
 			std::atomic<bool> bad{false};
@@ -871,6 +884,8 @@ int main(int argc, char **argv) {
 				const bool two = b->n1 > 0;
 				const int nsub0 = (int) b->sub0.size() - 1, nsub1 = two ? (int) b->sub1.size() - 1 : 0;
 				pool.parallel_for(nsub0 + nsub1, [&](int lo, int hi) {
+					const auto t_cpu = std::chrono::steady_clock::now();
+					struct Acc { std::atomic<long long> &a; std::chrono::steady_clock::time_point t; ~Acc() { a += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{t_parse_cpu_us, t_cpu};
 					for (int sidx = lo; sidx < hi; ++sidx) {
 						const int f = sidx < nsub0 ? 0 : 1, sl = f ? sidx - nsub0 : sidx;
 						const MappedFile &mf = f ? mf1 : mf0;
@@ -892,12 +907,20 @@ int main(int argc, char **argv) {
 			}
 			if (bad) fail(bad_msg);
 			if (!failed && o.paired) {
-				for (int i = 0; i + 1 < n; i += 2) {
-					const Rec &a = b->recs[i], &c = b->recs[i + 1];
-					if (a.name_len != c.name_len || memcmp(a.name, c.name, a.name_len) != 0) {
-						fail("Error while reading paired end reads. Names of mates don't match: " + std::string(a.name, a.name_len) + " and " + std::string(c.name, c.name_len) + ".");
-						break;
+				std::atomic<int> first_bad{n};
+				pool.parallel_for(n / 2, [&](int lo, int hi) {
+					for (int pi = lo; pi < hi; ++pi) {
+						const Rec &a = b->recs[2 * pi], &c = b->recs[2 * pi + 1];
+						if (a.name_len != c.name_len || memcmp(a.name, c.name, a.name_len) != 0) {
+							int seen = first_bad.load();
+							while (2 * pi < seen && !first_bad.compare_exchange_weak(seen, 2 * pi)) {}
+							return;
+						}
 					}
+				}, 8192);
+				if (first_bad.load() < n) {
+					const Rec &a = b->recs[first_bad.load()], &c = b->recs[first_bad.load() + 1];
+					fail("Error while reading paired end reads. Names of mates don't match: " + std::string(a.name, a.name_len) + " and " + std::string(c.name, c.name_len) + ".");
 				}
 			}
 			ngm_mapper_set_batch_seq(w.m, b->seq);
@@ -913,12 +936,17 @@ int main(int argc, char **argv) {
 			// format: chunks of whole pairs
 			const int units = o.paired ? n / 2 : n, per = o.paired ? 2 : 1;
 			const int n_chunks = std::max(1, std::min(units / 2048 + 1, pool.size() * 2));
-			b->chunks.assign(n_chunks, std::string());
+			b->chunks.resize(n_chunks);
+			for (std::string &c : b->chunks) c.clear();  // (keeps the capacity of the batch this vector served before)
 			std::vector<size_t> ct(n_chunks, 0), cm(n_chunks, 0), cw(n_chunks, 0);
 			pool.parallel_for(n_chunks, [&](int lo, int hi) {
+				const auto t_cpu = std::chrono::steady_clock::now();
+				struct Acc { std::atomic<long long> &a; std::chrono::steady_clock::time_point t; ~Acc() { a += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{t_format_cpu_us, t_cpu};
 				for (int c = lo; c < hi; ++c) {
 					const int u0 = (int) ((long long) units * c / n_chunks), u1 = (int) ((long long) units * (c + 1) / n_chunks);
-					format_range(*b, w, u0 * per, u1 * per, b->chunks[c], ct[c], cm[c], cw[c]);
+					size_t t_loc = 0, m_loc = 0, w_loc = 0;  // (not ct[c] & co. directly: neighbouring chunks share cache lines, and these are bumped per record)
+					format_range(*b, w, u0 * per, u1 * per, b->chunks[c], t_loc, m_loc, w_loc);
+					ct[c] = t_loc; cm[c] = m_loc; cw[c] = w_loc;
 					if (o.bam && !b->chunks[c].empty()) {  // every chunk becomes whole BGZF blocks: they concatenate into one valid file
 						std::string z;
 						z.reserve(b->chunks[c].size() / 3 + 64);
@@ -928,7 +956,12 @@ int main(int argc, char **argv) {
 				}
 			}, 1);
 			for (int c = 0; c < n_chunks; ++c) { b->n_total += ct[c]; b->n_mapped += cm[c]; b->n_written += cw[c]; }
-			b->recs.clear(); b->recs.shrink_to_fit(); b->owned.clear(); b->owned.shrink_to_fit();
+			{
+				std::lock_guard<std::mutex> lk(spare_mu);
+				b->recs.clear();
+				spare_recs.push_back(std::move(b->recs));
+			}
+			b->owned.clear(); b->owned.shrink_to_fit();
 			t_format_us += us_since(tf);
 			{
 				std::lock_guard<std::mutex> lk(out_mu);
@@ -952,9 +985,17 @@ int main(int argc, char **argv) {
 			}
 			std::vector<uint64_t> offs(b->chunks.size());
 			for (size_t c = 0; c < b->chunks.size(); ++c) { offs[c] = out_off; out_off += b->chunks[c].size(); }
+			const auto t_wr = std::chrono::steady_clock::now();
 			pool.parallel_for((int) b->chunks.size(), [&](int lo, int hi) {
+				const auto t_cpu = std::chrono::steady_clock::now();
+				struct Acc { std::atomic<long long> &a; std::chrono::steady_clock::time_point t; ~Acc() { a += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{t_write_cpu_us, t_cpu};
 				for (int c = lo; c < hi; ++c) if (!b->chunks[c].empty() && !put_all(b->chunks[c].data(), b->chunks[c].size(), offs[c])) fail("write error on " + o.out);
 			}, 1);
+			t_write_us += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wr).count();
+			{
+				std::lock_guard<std::mutex> lk(spare_mu);
+				spare_chunks.push_back(std::move(b->chunks));
+			}
 			n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written;
 			++next;
 		}
@@ -984,6 +1025,9 @@ int main(int argc, char **argv) {
 	if (getenv("NGM_HIP_HOST_TIMING")) {
 		snprintf(msg, sizeof(msg), "Worker time summed over %zu workers, s: waiting for input %.3f | parse + pack %.3f | map (GPU + library host stages) %.3f | format %.3f",
 				workers.size(), t_wait_us / 1e6, t_parse_us / 1e6, t_map_us / 1e6, t_format_us / 1e6);
+		info("MAIN", msg);
+		snprintf(msg, sizeof(msg), "Pool thread time inside the stages, s: parse + pack %.3f | format %.3f | output copies %.3f (writer wall %.3f)",
+				t_parse_cpu_us / 1e6, t_format_cpu_us / 1e6, t_write_cpu_us / 1e6, t_write_us / 1e6);
 		info("MAIN", msg);
 	}
 	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); }
