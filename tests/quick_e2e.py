@@ -21,15 +21,15 @@ rows, _, _ = B.make_reads(contigs, n, seed=5, paired=True)
 f1, f2 = os.path.join(wd, "a_1.fq"), os.path.join(wd, "a_2.fq")
 B.write_fastq_pair(rows, f1, f2)
 del rows, contigs
-for extra in (["--workers", "2", "-o", "/dev/null"], ["--workers", "3", "-o", "/dev/null"]):
+for extra, prefix in ((["--workers", "2", "-o", "/dev/null"], []), (["--workers", "2", "-o", "/dev/null"], ["taskset", "-c", "0-63"]), (["--workers", "2", "-o", "/dev/null"], ["taskset", "-c", "0-31"]), (["--workers", "2", "-o", "/dev/null"], ["taskset", "-c", "64-127"]), (["--workers", "2"], ["taskset", "-c", "0-63"])):
     out = os.path.join(wd, "o.sam")
     t = time.time()
-    r = subprocess.run([build.CLI, "-r", fa, "-1", f1, "-2", f2, "--affine", "-s", "0.5", "--no-progress"] + (extra if "-o" in extra else extra + ["-o", out]), capture_output=True, text=True,
+    r = subprocess.run(prefix + [build.CLI, "-r", fa, "-1", f1, "-2", f2, "--affine", "-s", "0.5", "--no-progress"] + (extra if "-o" in extra else extra + ["-o", out]), capture_output=True, text=True,
                        env=dict(os.environ, NGM_HIP_HOST_TIMING="1"))
     log = r.stdout + r.stderr
     m = re.findall(r"(Mapping pass: [0-9.]+ s, [0-9]+ reads/s|Input to output: [0-9.]+ s)", log)
-    print("\n".join([l for l in log.splitlines() if "Worker time" in l or "host wall" in l][-5:]))
-    print(extra, "wall %.1f s" % (time.time() - t), m, "bytes", os.path.getsize(out) if os.path.exists(out) else None, flush=True)
+    print("\n".join([l for l in log.splitlines() if "Worker time" in l or "Pool thread" in l][-5:]))
+    print(extra, prefix, "wall %.1f s" % (time.time() - t), m, "bytes", os.path.getsize(out) if os.path.exists(out) else None, flush=True)
     if r.returncode != 0:
         print(log[-800:])
 try:
