@@ -310,11 +310,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    pinned_cpus = 0
     if stub:
         dev = torch.device("cpu")
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+        # host threads (this one, the mapper instances', the library's pool) on the socket this rank's GPU hangs on
+        from nextgenmap_amd.engine import load_library
+        pinned_cpus = int(load_library().ngm_host_pin_to_device_node(local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if stub:
@@ -493,7 +497,7 @@ def main():
                        % (R, READ_LEN, "PE (insert ~N(350,35), FR)" if paired else "SE", 100 * args.subs,
                           ", %.0f %% indel bases" % (100 * args.indel_bases) if args.indel_bases else "", args.genome_mbp, sens,
                           "pair selection (top1PE)" if paired else "top-1"),
-                       "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R, "mapper_instances_per_gpu": W,
+                       "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R, "mapper_instances_per_gpu": W, "host_cpus_per_rank_numa_pinned": pinned_cpus,
                        "parallelism": "reads sharded x%d (nextgenmap_amd.sharding.shard_range), genome+index replicated per GPU (built by rank 0, loaded from NextGenMap cache files by the others)" % world},
             "sw_gcells_per_s": {"score_kernel": score_cells / (kms[2] * 1e-3) / 1e9 if kms[2] > 0 else None,
                                 "align_kernel": align_cells / (kms[5] * 1e-3) / 1e9 if kms[5] > 0 else None},

@@ -165,6 +165,14 @@ int ngm_mapper_set_batch_seq(ngm_mapper *m, uint64_t seq);
 void *ngm_host_alloc(size_t bytes);
 void ngm_host_free(void *p);
 
+/* Host threads next to the GPU.  A two-socket host runs the host stages (read parsing, pair selection, SAM text) at half the
+ * rate when their threads and buffers are spread over both sockets (measured with ngm-hip).  This pins the
+ * CALLING thread -- and with it every thread it creates afterwards, the library's thread pool included -- to the CPUs of
+ * the NUMA node the device hangs on (/sys/bus/pci/devices/<bdf>/numa_node, .../node<N>/cpulist).  Call it first thing, before
+ * any other entry point.  Returns the number of CPUs in the set, 0 when nothing was changed (no NUMA information, or
+ * NGM_HIP_NO_NUMA_PIN is set), < 0 on error.  (NextGenMap itself leaves placement to the OS; this replaces nothing there.) */
+int ngm_host_pin_to_device_node(int device);
+
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted
  * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */
 int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]);

@@ -17,6 +17,8 @@
 #include <vector>
 
 #include <string.h>
+#include <ctype.h>
+#include <sched.h>
 #include <rocprim/rocprim.hpp>
 
 #include "refindex.h"
@@ -1236,6 +1238,40 @@ void *ngm_host_alloc(size_t bytes) {
 	return p;
 }
 void ngm_host_free(void *p) { if (p) (void) hipHostFree(p); }
+
+int ngm_host_pin_to_device_node(int device) {
+	if (getenv("NGM_HIP_NO_NUMA_PIN")) return 0;
+	char bdf[64] = {0};
+	if (hipDeviceGetPCIBusId(bdf, (int) sizeof(bdf), device) != hipSuccess) { ngm::pipeline_set_error("no PCI bus id for device %d", device); return -19; }
+	for (char *c = bdf; *c; ++c) *c = (char) tolower((unsigned char) *c);
+	char path[256], line[4096] = {0};
+	snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+	int node = -1;
+	if (FILE *f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+	if (node < 0) return 0;
+	snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+	FILE *f = fopen(path, "r");
+	if (!f) return 0;
+	const bool got = fgets(line, sizeof(line), f) != nullptr;
+	fclose(f);
+	if (!got) return 0;
+	cpu_set_t set;
+	CPU_ZERO(&set);
+	int n = 0;
+	for (const char *c = line; *c;) {  // "0-63,128-191"
+		char *end = nullptr;
+		const long a = strtol(c, &end, 10);
+		if (end == c) break;
+		long b = a;
+		c = end;
+		if (*c == '-') { b = strtol(c + 1, &end, 10); if (end == c + 1) break; c = end; }
+		for (long x = a; x <= b && x < CPU_SETSIZE; ++x) if (x >= 0) { CPU_SET((int) x, &set); ++n; }
+		if (*c == ',') ++c; else break;
+	}
+	if (n == 0) return 0;
+	if (sched_setaffinity(0, sizeof(set), &set) != 0) return 0;  // (a container may forbid it: not an error)
+	return n;
+}
 
 int ngm_mapper_cs_max_combined(ngm_mapper *m, float *out) {
 	if (!m) return -22;

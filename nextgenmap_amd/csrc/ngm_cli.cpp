@@ -389,6 +389,12 @@ int main(int argc, char **argv) {
 	Opts o = parse(argc, argv);
 	ngm_ref_params rp{o.kmer, o.kmer_skip, o.bin_size};
 	info("MAIN", "NextGenMap-compatible HIP backend (gfx950)");
+	// one GPU: keep every host thread (this one, the workers, the pool) on the socket the GPU hangs on -- the parse / select /
+	// format stages run twice as fast there as spread over both sockets of the host
+	if (o.devices.size() == 1) {
+		const int cpus = ngm_host_pin_to_device_node(o.device);
+		if (cpus > 0) info("MAIN", "Host threads pinned to the " + std::to_string(cpus) + " CPUs of the GPU's NUMA node");
+	}
 	// an index cache next to the FASTA is loaded instead of rebuilding; a fresh build is saved for the next run unless
 	// --skip-save (src/PrefixTable.cpp:232-262, SequenceProvider.cpp:264-330)
 	const std::string ht_cache = o.ref + "-ht-" + std::to_string(o.kmer) + "-" + std::to_string(o.kmer_skip) + ".3.ngm";

@@ -21,7 +21,7 @@ rows, _, _ = B.make_reads(contigs, n, seed=5, paired=True)
 f1, f2 = os.path.join(wd, "a_1.fq"), os.path.join(wd, "a_2.fq")
 B.write_fastq_pair(rows, f1, f2)
 del rows, contigs
-for extra, prefix in ((["--workers", "2", "-o", "/dev/null"], []), (["--workers", "2", "-o", "/dev/null"], ["taskset", "-c", "0-63"]), (["--workers", "2", "-o", "/dev/null"], ["taskset", "-c", "0-31"]), (["--workers", "2", "-o", "/dev/null"], ["taskset", "-c", "64-127"]), (["--workers", "2"], ["taskset", "-c", "0-63"])):
+for extra, prefix in ((["--workers", "2"], []), (["--workers", "4"], []), (["--workers", "2", "-o", "/dev/null"], []), (["--workers", "2"], ["taskset", "-c", "0-63"])):
     out = os.path.join(wd, "o.sam")
     t = time.time()
     r = subprocess.run(prefix + [build.CLI, "-r", fa, "-1", f1, "-2", f2, "--affine", "-s", "0.5", "--no-progress"] + (extra if "-o" in extra else extra + ["-o", out]), capture_output=True, text=True,
