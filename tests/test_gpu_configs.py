@@ -124,6 +124,38 @@ def test_pipeline_output_independent_of_workers_and_batches(tmp_path):
     assert se0 == se1
 
 
+def test_kernel_variants_give_identical_sam(tmp_path):
+    """The run-time selectable kernel variants are implementations of ONE result: candidate search on 1 / 2 / 3 (default) / 4
+    waves per read, the 32-bit score / align kernels instead of the packed 16-bit ones, CIGAR / MD strings built on the host
+    instead of the GPU, candidate slots through the region cursors only.  Paired-end on a repeat-rich genome (ties, repeat
+    families: the reads that overflow the per-wave queues), both personalities: byte-identical SAM bodies."""
+    from nextgenmap_amd import build
+    build.build()
+    contigs = S.make_genome([1_500_000, 900_001], seed=611, repeat_families=40, repeat_len=800, copies=14, divergence=0.01)
+    fa = str(tmp_path / "ref.fa")
+    _write_fasta(fa, contigs)
+    r1, r2 = S.make_reads(contigs, 20000, 150, seed=612, sub_rate=0.015, indel_rate=0.002, paired=True)
+    f1, f2 = str(tmp_path / "pe_1.fq"), str(tmp_path / "pe_2.fq")
+    S.write_fastq(f1, r1)
+    S.write_fastq(f2, r2)
+
+    def run(tag, personality, env):
+        out = str(tmp_path / (tag + ".sam"))
+        e = dict(os.environ)
+        e.update(env)
+        c = subprocess.run([CLI, "-r", fa, "-o", out, "-1", f1, "-2", f2] + personality, capture_output=True, text=True, env=e)
+        assert c.returncode == 0, c.stderr[-2000:]
+        return [l for l in open(out, "rb") if not l.startswith(b"@PG")]
+    for personality in (["--affine"], []):
+        base = run("base", personality, {})
+        assert len(base) > 40000
+        for tag, env in (("w1", {"NGM_HIP_CS_WAVES": "1"}), ("w2", {"NGM_HIP_CS_WAVES": "2"}), ("w4", {"NGM_HIP_CS_WAVES": "4"}),
+                         ("dp32", {"NGM_HIP_ALIGN_32BIT": "1", "NGM_HIP_SCORE_32BIT": "1"}), ("hostcigar", {"NGM_HIP_HOST_CIGAR": "1"}),
+                         ("noslots", {"NGM_HIP_CS_NO_FIXED_SLOTS": "1"})):
+            other = run(tag, personality, env)
+            assert other == base, "%s %s: %d of %d lines differ" % (tag, personality, sum(a != b for a, b in zip(other, base)), len(base))
+
+
 @needs_ref
 def test_big_parity_60mbp(tmp_path):
     """tests/big_parity.py ('not collected by pytest'): 0 differing records in every mode."""
