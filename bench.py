@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--indel-bases", type=float, default=0.0, help="extra share of read bases in indels (config #5: 0.03)")
     ap.add_argument("--sensitive", action="store_true", help="config #5: sensitivity 0.5 - 0.35 * 0.5 (what --sensitive does to an estimate of 0.5)")
     ap.add_argument("--no-end-to-end", action="store_true")
-    ap.add_argument("--e2e-reads", type=int, default=4_000_000, help="reads of the end-to-end ngm-hip run (BASELINE config #3: 10 000 000)")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end ngm-hip run (BASELINE config #3: 10 000 000)")
     ap.add_argument("--stub-mapper", action="store_true", help="CPU-only control-path run (tests)")
     args = ap.parse_args()
     global Q, C, READ_LEN

@@ -85,7 +85,7 @@ CLI = os.path.join(HERE, "ngm-hip")
 
 def build_cli(verbose=False):
     """The NextGenMap-compatible command line: plain g++ host program over the C ABI of the library."""
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", os.path.join(CSRC, "ngm_cli.cpp"), LIB, "-lz",
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-g1", "-std=c++17", os.path.join(CSRC, "ngm_cli.cpp"), LIB, "-lz", "-ldl",
            "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-o", CLI]
     if verbose:
         print(" ".join(cmd))

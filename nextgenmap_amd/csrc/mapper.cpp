@@ -710,12 +710,15 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			m->pair_dist_sum = m->ps->dist_sum; m->pair_dist_count = m->ps->dist_count;
 			held = true;
 		}
-		~PairTurn() {
-			if (!active) return;
+		void release() {  // the running mean is final for this batch: the next batch may read it (align + CIGAR of this one go on)
+			if (!active || released) return;
 			acquire();
 			{ std::lock_guard<std::mutex> lk(m->ps->mu); m->ps->dist_sum = m->pair_dist_sum; m->ps->dist_count = m->pair_dist_count; m->ps->next = m->batch_seq + 1; }
 			m->ps->cv.notify_all();
+			released = true;
 		}
+		bool released = false;
+		~PairTurn() { release(); }
 	} pair_turn{m, paired && m->ps != nullptr};
 	if (n == 0) return 0;
 	const ngm_ref *r = m->ref;
@@ -999,6 +1002,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					}
 					m->pair_dist_sum += carry_sum; m->pair_dist_count += carry_cnt;
 					for (uint32_t i : se_tied) { if (m->h_count[i ^ 1u] > 0) first_sorted(i); else first_best(i); }
+					pair_turn.release();
 					qlap(3);
 					if (host_timing) fprintf(stderr, "[ngm-hip] pair selection ms: pass 1 %.2f | pass 2 %.2f | order %.2f | pass 3+4 %.2f\n", tq[0], tq[1], tq[2], tq[3]);
 				}

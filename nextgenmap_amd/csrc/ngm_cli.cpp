@@ -23,7 +23,12 @@
 //   writer (1 thread)     batches in input order, large writes.
 // Paired-end tie-breaks see the same running mean insert size as `ngm -t 1` (ngm_pair_state: batches take turns for that
 // part only), so the output does not depend on the number of workers or GPUs.
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <signal.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+#include <ucontext.h>
 #include <malloc.h>
 #include <getopt.h>
 #include <sys/mman.h>
@@ -326,7 +331,7 @@ struct Batch {
 	std::vector<std::string> chunks;    // formatted output, in order
 	size_t n_total = 0, n_mapped = 0, n_written = 0;
 };
-constexpr int kSub = 4096;
+constexpr int kSub = 1024;
 
 template <typename T>
 class BoundedQueue {
@@ -377,9 +382,49 @@ inline void put_identity(std::string &s, float identity) {
 	s.append(b, k);
 }
 
+// NGM_HIP_PROFILE=file: a sampling profile of the host side without any tool installed -- ITIMER_PROF ticks (1 kHz of process
+// CPU time, delivered to whichever thread is running), the interrupted instruction's address per tick, written as
+// "module offset count" lines at exit (resolve with addr2line -e <module> -f -C -i <offset>).
+namespace prof {
+constexpr int kSlots = 1 << 16;
+std::atomic<uintptr_t> g_ip[kSlots];
+std::atomic<unsigned> g_n{0};
+void on_tick(int, siginfo_t *, void *uc) {
+	const unsigned at = g_n.fetch_add(1, std::memory_order_relaxed);
+	if (at < (unsigned) kSlots) g_ip[at].store((uintptr_t) ((ucontext_t *) uc)->uc_mcontext.gregs[REG_RIP], std::memory_order_relaxed);
+}
+void start() {
+	struct sigaction sa;
+	memset(&sa, 0, sizeof(sa));
+	sa.sa_sigaction = on_tick;
+	sa.sa_flags = SA_SIGINFO | SA_RESTART;
+	sigaction(SIGPROF, &sa, nullptr);
+	struct itimerval tv = {{0, 1000}, {0, 1000}};
+	setitimer(ITIMER_PROF, &tv, nullptr);
+}
+void dump(const char *path) {
+	struct itimerval off = {{0, 0}, {0, 0}};
+	setitimer(ITIMER_PROF, &off, nullptr);
+	const unsigned n = std::min(g_n.load(), (unsigned) kSlots);
+	std::map<std::pair<std::string, uintptr_t>, unsigned> hist;
+	for (unsigned i = 0; i < n; ++i) {
+		const uintptr_t ip = g_ip[i].load();
+		Dl_info di;
+		if (dladdr((void *) ip, &di) && di.dli_fname) hist[{di.dli_fname, ip - (uintptr_t) di.dli_fbase}] += 1;
+		else hist[{"?", ip}] += 1;
+	}
+	if (FILE *f = fopen(path, "w")) {
+		fprintf(f, "# %u samples (1 ms of process CPU time each)\n", g_n.load());
+		for (const auto &e : hist) fprintf(f, "%s 0x%lx %u\n", e.first.first.c_str(), (unsigned long) e.first.second, e.second);
+		fclose(f);
+	}
+}
+}  // namespace prof
+
 }  // namespace
 
 int main(int argc, char **argv) {
+
 	// every batch allocates and frees a few hundred MB in MB-sized pieces from ~64 threads (output chunks, record views): with
 	// glibc's defaults each of them is an mmap / page-fault / munmap cycle, and the kernel's address-space lock serialises the
 	// formatter threads (measured: 55 ms per 256 k reads instead of ~2).  Keep that memory in the heap.
@@ -516,11 +561,10 @@ int main(int argc, char **argv) {
 
 
 	// ---- output ------------------------------------------------------------------------------------------------------
-	// the output is written with pwrite at offsets the writer thread hands out in input order, by pool threads: copying 400+
-	// bytes per read into the page cache from ONE thread would bound the whole program at a few million reads per second.
-	// (Measured alternative, round 2: extending the file with ftruncate and filling a shared mapping of each batch's range from
-	// the pool -- 1.6 M reads/s against 3.5 M with pwrite: the page faults of a shared file mapping cost more than the inode
-	// lock that serialises the pwrite calls.)
+	// the output is written by the writer thread alone, in input order.  Measured alternatives (round 2, 10 M reads, 4.2 GB of
+	// SAM): pwrite from the pool threads -- the writes serialise on the file's inode lock and the threads queueing there are
+	// missing from the pool (3.5 M reads/s with 65 chunks per batch, 2.8 M and 32 s of system time with 500); a shared file
+	// mapping of each batch's range filled by the pool -- 1.6 M reads/s, the page faults cost more than the lock.
 	const int out_fd = ::open(o.out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
 	if (out_fd < 0) die("cannot write " + o.out);
 	uint64_t out_off = 0;
@@ -941,7 +985,7 @@ int main(int argc, char **argv) {
 			auto tf = std::chrono::steady_clock::now();
 			// format: chunks of whole pairs
 			const int units = o.paired ? n / 2 : n, per = o.paired ? 2 : 1;
-			const int n_chunks = std::max(1, std::min(units / 2048 + 1, pool.size() * 2));
+			const int n_chunks = std::max(1, std::min(units / 256 + 1, pool.size() * 8));  // many more chunks than threads: the slowest thread decides when the batch is done
 			b->chunks.resize(n_chunks);
 			for (std::string &c : b->chunks) c.clear();  // (keeps the capacity of the batch this vector served before)
 			std::vector<size_t> ct(n_chunks, 0), cm(n_chunks, 0), cw(n_chunks, 0);
@@ -992,11 +1036,9 @@ int main(int argc, char **argv) {
 			std::vector<uint64_t> offs(b->chunks.size());
 			for (size_t c = 0; c < b->chunks.size(); ++c) { offs[c] = out_off; out_off += b->chunks[c].size(); }
 			const auto t_wr = std::chrono::steady_clock::now();
-			pool.parallel_for((int) b->chunks.size(), [&](int lo, int hi) {
-				const auto t_cpu = std::chrono::steady_clock::now();
-				struct Acc { std::atomic<long long> &a; std::chrono::steady_clock::time_point t; ~Acc() { a += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{t_write_cpu_us, t_cpu};
-				for (int c = lo; c < hi; ++c) if (!b->chunks[c].empty() && !put_all(b->chunks[c].data(), b->chunks[c].size(), offs[c])) fail("write error on " + o.out);
-			}, 1);
+			// one writer: buffered writes to one file serialise on its inode lock anyway, and pool threads queueing there (64 of
+			// them, 500 chunks per batch) burn more system time than the copies take (measured: 32 s of it for 4.2 GB)
+			for (size_t c = 0; c < b->chunks.size(); ++c) if (!b->chunks[c].empty() && !put_all(b->chunks[c].data(), b->chunks[c].size(), offs[c])) fail("write error on " + o.out);
 			t_write_us += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wr).count();
 			{
 				std::lock_guard<std::mutex> lk(spare_mu);
@@ -1006,6 +1048,11 @@ int main(int argc, char **argv) {
 			++next;
 		}
 	});
+	if (getenv("NGM_HIP_PROFILE")) prof::start();  // the mapping pass only
+	struct timespec cpu0;
+	clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu0);
+	struct rusage ru0;
+	getrusage(RUSAGE_SELF, &ru0);
 	{
 		std::vector<std::thread> th;
 		for (Worker &w : workers) th.emplace_back([&, pw = &w] { worker_main(*pw); });
@@ -1032,10 +1079,22 @@ int main(int argc, char **argv) {
 		snprintf(msg, sizeof(msg), "Worker time summed over %zu workers, s: waiting for input %.3f | parse + pack %.3f | map (GPU + library host stages) %.3f | format %.3f",
 				workers.size(), t_wait_us / 1e6, t_parse_us / 1e6, t_map_us / 1e6, t_format_us / 1e6);
 		info("MAIN", msg);
+		{
+			struct timespec cpu1;
+			clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu1);
+			struct rusage ru1;
+			getrusage(RUSAGE_SELF, &ru1);
+			auto tv = [](const timeval &a, const timeval &b) { return (double) (b.tv_sec - a.tv_sec) + 1e-6 * (double) (b.tv_usec - a.tv_usec); };
+			snprintf(msg, sizeof(msg), "Mapping pass, process totals: CPU %.2f s (user %.2f, system %.2f), page faults %ld minor / %ld major, context switches %ld voluntary / %ld involuntary",
+					(double) (cpu1.tv_sec - cpu0.tv_sec) + 1e-9 * (double) (cpu1.tv_nsec - cpu0.tv_nsec), tv(ru0.ru_utime, ru1.ru_utime), tv(ru0.ru_stime, ru1.ru_stime),
+					ru1.ru_minflt - ru0.ru_minflt, ru1.ru_majflt - ru0.ru_majflt, ru1.ru_nvcsw - ru0.ru_nvcsw, ru1.ru_nivcsw - ru0.ru_nivcsw);
+			info("MAIN", msg);
+		}
 		snprintf(msg, sizeof(msg), "Pool thread time inside the stages, s: parse + pack %.3f | format %.3f | output copies %.3f (writer wall %.3f)",
 				t_parse_cpu_us / 1e6, t_format_cpu_us / 1e6, t_write_cpu_us / 1e6, t_write_us / 1e6);
 		info("MAIN", msg);
 	}
+	if (const char *pf = getenv("NGM_HIP_PROFILE")) prof::dump(pf);
 	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); }
 	ngm_pair_state_destroy(pair_state);
 	for (ngm_ref *r2 : refs) ngm_ref_destroy(r2);
