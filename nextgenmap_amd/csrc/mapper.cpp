@@ -1010,7 +1010,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		}
 	}
 	if (paired && np > 0 && m->prm.strata)  // mates selected single-end (top1SE): several equally best candidates -> unmapped
-		for (int i = 0; i < n; ++i) if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] > 1) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; }
+		parallel_for(n, [&](int lo, int hi) { for (int i = lo; i < hi; ++i) if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] > 1) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; } }, 16384);
 	const int topn = (!paired && m->prm.topn > 1) ? m->prm.topn : 1;
 	std::vector<uint32_t> tn_pairs;  // topn > 1: per output entry the candidate (pair index) to align, or none
 	if (!paired && np > 0 && (topn > 1 || m->prm.strata)) {
@@ -1077,7 +1077,28 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	std::vector<uint32_t> a_read((size_t) n * topn), a_loc((size_t) n * topn), a_sv((size_t) n * topn), a_out((size_t) n * topn), a_pair((size_t) n * topn);
 	int na = 0;
 	if (topn == 1 || np == 0) {
-		for (int i = 0; i < n; ++i) if (h_winner[i] != 0xFFFFFFFFu) { a_read[na] = i; a_out[na] = i; a_pair[na] = h_winner[i]; a_loc[na] = h_loc[h_winner[i]]; a_sv[na] = h_sv[h_winner[i]]; ++na; }
+		// winners, compacted in read order: count per slice, prefix, fill (the gathers through h_winner miss the caches)
+		const int slices = std::max(1, std::min(256, n / 4096));
+		std::vector<int> first(slices + 1, 0);
+		parallel_for(slices, [&](int lo, int hi) {
+			for (int s2 = lo; s2 < hi; ++s2) {
+				const int i0 = (int) ((long long) n * s2 / slices), i1 = (int) ((long long) n * (s2 + 1) / slices);
+				int cnt = 0;
+				for (int i = i0; i < i1; ++i) cnt += h_winner[i] != 0xFFFFFFFFu;
+				first[s2 + 1] = cnt;
+			}
+		}, 1);
+		for (int s2 = 0; s2 < slices; ++s2) first[s2 + 1] += first[s2];
+		na = first[slices];
+		parallel_for(slices, [&](int lo, int hi) {
+			for (int s2 = lo; s2 < hi; ++s2) {
+				const int i0 = (int) ((long long) n * s2 / slices), i1 = (int) ((long long) n * (s2 + 1) / slices);
+				int at = first[s2];
+				for (int i = i0; i < i1; ++i) if (h_winner[i] != 0xFFFFFFFFu) {
+					a_read[at] = (uint32_t) i; a_out[at] = (uint32_t) i; a_pair[at] = h_winner[i]; a_loc[at] = h_loc[h_winner[i]]; a_sv[at] = h_sv[h_winner[i]]; ++at;
+				}
+			}
+		}, 1);
 	} else {
 		for (int i = 0; i < n; ++i) for (int t = 0; t < topn; ++t) {
 			const uint32_t w = tn_pairs[(size_t) i * topn + t];

@@ -33,6 +33,11 @@ def test_library_exports_every_declared_symbol():
     assert declared <= syms, "missing: %s" % sorted(declared - syms)
     plugin = {"SetLog", "SetConfig", "Cookie", "IsAvailable", "CreateAlignment", "DeleteAlignment", "ExternalDeleteString"}
     assert plugin <= syms
+    # ... and the pipeline ABI (reference index, candidate search, mapping): include/ngm_pipeline.h
+    hdr2 = re.sub(r"/\*.*?\*/", "", open(os.path.join(INC, "ngm_pipeline.h")).read(), flags=re.S)
+    declared2 = set(re.findall(r"\b(ngm_(?:ref|mapper|pair_state|host|pipeline)_\w+)\s*\(", hdr2))
+    assert len(declared2) >= 25, sorted(declared2)
+    assert declared2 <= syms, "missing: %s" % sorted(declared2 - syms)
 
 
 def test_library_loads_and_fails_loudly_without_gpu():
