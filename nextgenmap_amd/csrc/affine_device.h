@@ -361,10 +361,15 @@ typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int aff_nib_words(int CP) { return (CP + 7) / 8; }
 __device__ __forceinline__ v2s pk_min(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
 
-template <int CP>
+// WINDOW: for bands of more than 32 columns or scores of 2 048 and more the row key is (score - base) << 7 | 127 - d with a
+// per-pair base that follows the running row maximum: a row's maximum is at least the previous row's minus one mismatch (the
+// diagonal successor of that cell is in the band) and at most one match above it, so the scores that can be the row maximum
+// lie in a window of mismatch + match + 1 values (<= 63: host-checked) above base = max(previous row maximum - mismatch - 1, 0);
+// cells below the window clamp to 0 and cannot win.
+template <int CP, bool WINDOW>
 __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t *__restrict__ packed, const uint16_t *__restrict__ lens,
 		const uint16_t *__restrict__ blk_rows, uint32_t *__restrict__ dirs, int32_t *__restrict__ records, int n, int n_blocks, int RW, int q, AffConst K) {
-	static_assert(CP <= 32, "the row key keeps the band column in 5 bits");
+	static_assert(WINDOW ? CP <= 128 : CP <= 32, "the row key keeps the band column in 7 / 5 bits");
 	__shared__ uint2 s_tab[8];
 	if (threadIdx.x < 8) s_tab[threadIdx.x] = aff_row_table(threadIdx.x, K);
 	__syncthreads();
@@ -397,7 +402,9 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 	int fl = K.tZ;
 	int bestA = 0, bhA = 0, bvA = 0, bestB = 0, bhB = 0, bvB = 0;
 	const v2s ext2 = pk_splat(K.ext), open2 = pk_splat(K.open), vext2 = pk_splat(K.vext), vopen2 = pk_splat(K.vopen);
-	const v2s neg2 = pk_splat(kAffNeg16), one2 = pk_splat(1), zero2 = pk_splat(0), two2 = pk_splat(2), four2 = pk_splat(4), k32 = pk_splat(32);
+	const v2s neg2 = pk_splat(kAffNeg16), one2 = pk_splat(1), zero2 = pk_splat(0), two2 = pk_splat(2), four2 = pk_splat(4), k32 = pk_splat(WINDOW ? 128 : 32);
+	const v2s win_lo2 = pk_splat(K.tZ + 1), win_max2 = pk_splat(63);  // K.tZ = -mismatch
+	v2s prevmax2 = pk_splat(0);  // WINDOW: the previous row's maximum of both pairs
 	uint32_t rnA = (ngroups > 0) ? rdA[0] : 0x66666666u, rnB = (ngroups > 0) ? rdB[0] : 0x66666666u;
 
 	for (int g = 0; g < ngroups; ++g) {
@@ -423,6 +430,7 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 			const v2s fl2 = pk_splat(fl);
 			v2s leftS = neg2, leftEh = neg2;  // column d = 0 has no horizontal predecessor
 			v2u rowkey = __builtin_bit_cast(v2u, zero2);
+			const v2s base2 = WINDOW ? pk_max(prevmax2 - win_lo2, zero2) : zero2;
 			uint32_t acc[2] = {0u, 0u};       // 4 trace nibbles per pair each: low halves pair A, high halves pair B
 #pragma unroll
 			for (int d = 0; d < CP; ++d) {
@@ -447,7 +455,8 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 				const v2s took = nz * (one2 + nd * (two2 - fh));  // 0 none, 1 diagonal, 2 horizontal maximum, 3 vertical maximum
 				const v2s nib = took * four2 + vo * two2 + ho;
 				acc[(d >> 2) & 1] |= __builtin_bit_cast(uint32_t, nib) << (4 * (d & 3));
-				rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pos * k32 + pk_splat(31 - d)));
+				if (WINDOW) rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_min(pk_max(pos - base2, zero2), win_max2) * k32 + pk_splat(127 - d)));
+				else rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pos * k32 + pk_splat(31 - d)));
 				S[d] = sc;
 				Ev[d] = ev;
 				leftS = sc;
@@ -463,7 +472,9 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 			{
 				// column-major first maximum: strictly greater, or equal with a smaller h
 				const int ka = (int) rowkey.x, kb2 = (int) rowkey.y;
-				const int rsa = ka >> 5, rha = i + 1 + (31 - (ka & 31)), rsb = kb2 >> 5, rhb = i + 1 + (31 - (kb2 & 31));
+				constexpr int SH = WINDOW ? 7 : 5, DM = WINDOW ? 127 : 31;
+				const int rsa = (ka >> SH) + (int) base2.x, rha = i + 1 + (DM - (ka & DM)), rsb = (kb2 >> SH) + (int) base2.y, rhb = i + 1 + (DM - (kb2 & DM));
+				if (WINDOW) { prevmax2.x = (short) rsa; prevmax2.y = (short) rsb; }
 				if (i < lenVA && (rsa > bestA || (rsa == bestA && rsa > 0 && rha < bhA))) { bestA = rsa; bhA = rha; bvA = i + 1; }
 				if (i < lenVB && (rsb > bestB || (rsb == bestB && rsb > 0 && rhb < bhB))) { bestB = rsb; bhB = rhb; bvB = i + 1; }
 			}

@@ -91,11 +91,13 @@ const void *find_pk_affine_score_kernel(int c, bool endfree) {
 	return nullptr;
 }
 
-template <int CP> const void *pk_affine_align_ptr() {
-	if constexpr (CP <= 32) return (const void *) ngm::sw_affine_align_pk_kernel<CP>; else return nullptr;
+// window = false: the plain row key (<= 32 band columns, scores below 2 048); true: the windowed one (<= 128 columns)
+template <int CP> const void *pk_affine_align_ptr(bool window) {
+	if (!window) { if constexpr (CP <= 32) return (const void *) ngm::sw_affine_align_pk_kernel<CP, false>; else return nullptr; }
+	if constexpr (CP <= 128) return (const void *) ngm::sw_affine_align_pk_kernel<CP, true>; else return nullptr;
 }
-const void *find_pk_affine_align_kernel(int c) {
-#define X(C) if (c == C) return pk_affine_align_ptr<C + 1>();
+const void *find_pk_affine_align_kernel(int c, bool window) {
+#define X(C) if (c == C) return pk_affine_align_ptr<C + 1>(window);
 	NGM_CORRIDORS(X)
 #undef X
 	return nullptr;
@@ -174,9 +176,12 @@ int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, u
 		// conditions: scores below 2 048, at most 32 band columns, negative gap penalties, the 16-bit range of the score kernel)
 		static const bool force32 = getenv("NGM_HIP_ALIGN_32BIT") != nullptr;
 		const void *pk = nullptr;
-		if (!force32 && am != NGM_MODE_END_TO_END && (long) ctx->q * ctx->prm.match_bonus < 2048 && ctx->KA.open < 0 && ctx->KA.ext < 0 && (long) ctx->q * ctx->KA.tM < 30000 &&
-				ctx->prm.gap_read_penalty + (long) ctx->q * (ctx->prm.gap_extend_penalty + ctx->KA.tZ) < 19000)
-			pk = find_pk_affine_align_kernel(ctx->c);
+		if (!force32 && am != NGM_MODE_END_TO_END && ctx->KA.open < 0 && ctx->KA.ext < 0 && (long) ctx->q * ctx->KA.tM < 30000 &&
+				ctx->prm.gap_read_penalty + (long) ctx->q * (ctx->prm.gap_extend_penalty + ctx->KA.tZ) < 19000) {
+			const bool plain_key = (long) ctx->q * ctx->prm.match_bonus < 2048 && ctx->c + 1 <= 32;
+			if (plain_key) pk = find_pk_affine_align_kernel(ctx->c, false);
+			else if (ctx->KA.tZ > 0 && ctx->KA.tM > 0 && ctx->KA.tM + 1 <= 63) pk = find_pk_affine_align_kernel(ctx->c, true);  // window: mismatch + match + 1 values
+		}
 		if (pk) {
 			KernelRef kp; kp.aot = pk;
 			HIP_TRY(ctx, launch_kernel(kp, dim3((nb + 7) / 8), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
