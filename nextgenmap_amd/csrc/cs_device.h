@@ -75,6 +75,7 @@ struct CsArgs {
 	unsigned long long *counters;  // per region, stride kCsCursorStride: [0] k-mers looked up, [1] hits voted (algorithmic-bytes accounting), [2] candidates
 	uint32_t *order_scratch;    // cs_order_kernel: time lines in global memory for reads with more hits than LDS holds
 	uint32_t order_gcap;        // ... entries per workgroup
+	uint32_t order_max_hits;    // cs_order_kernel: time line entries in LDS (sized by the host from the expected hits per read)
 	unsigned long long *phase_cycles;  // optional diagnostics (fast path): [0] lists [1] sweep 1 [2] sweep 2 [3] candidates
 	uint32_t *ovf_read;     // [n] queue written by this pass
 	uint32_t *ovf_hits;     // [n]
@@ -1004,13 +1005,14 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 // out: cand_rank[c] = 2 * (rList position among the tracked bins) + strand for every candidate c of the read, i.e. its
 // relative order in CollectResultsStd's output (forward before reverse of one bin, src/CS.cpp:289-304).
 constexpr int kCsOrderLog2Slots = 10;       // tracked bins (>= 2 votes, plus bit collisions): 1024 slots
-constexpr uint32_t kCsOrderMaxHits = 7168;  // time line entries in LDS; reads with more hits use a slice of global memory
+constexpr uint32_t kCsOrderMaxHits = 7168;  // least time line entries in LDS (CsArgs::order_max_hits); reads with more hits use a slice of global memory
 constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
 		uint32_t *__restrict__ cand_rank) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	__shared__ uint32_t s_keys;  // distinct tracked bins
+	const unsigned long long t_block = A.phase_cycles ? wall_clock64() : 0ull;
 	const int lane = threadIdx.x;
 	const int read = (int) A.read_list[blockIdx.x];
 	const int k = A.k;
@@ -1028,14 +1030,18 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
 	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; t_cand[s] = 0; }
 	if (lane == 0) s_keys = 0;
-	uint32_t *seg_pref = ev_at + kCsOrderMaxHits;  // [lists_cap + 1]: work items (8-hit list segments) in front of each list
+	uint32_t *seg_pref = ev_at + A.order_max_hits;
+	const bool diag = A.phase_cycles && (blockIdx.x & 63) == 0;
+	unsigned long long ck[6] = {0, 0, 0, 0, 0, 0};
+	if (diag) ck[0] = wall_clock64();  // [lists_cap + 1]: work items (8-hit list segments) in front of each list
 	const CsRead R = cs_prepare<true, uint32_t>(A, read, lane, l_start, l_pref, l_code, (uint32_t *) nullptr, 0);
 	const uint32_t H = R.H;
 	const int L = R.L;
+	if (diag) ck[1] = wall_clock64();
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
 	auto give_up = [&]() { for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown; };
 	// very repetitive reads: the time line moves to global memory; the 16-bit list offsets of l_pref bound that at 65 535 hits
-	const bool big = H > kCsOrderMaxHits;
+	const bool big = H > A.order_max_hits;
 	if (big) {
 		if (!A.order_scratch || H > A.order_gcap || H >= 65536u) { give_up(); return; }
 		ev_at = A.order_scratch + (size_t) blockIdx.x * A.order_gcap;
@@ -1081,6 +1087,10 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
 		const uint32_t msk = 1u << (b & 31);
 		if (atomicOr(&plane[b >> 5], msk) & msk) {
+			// (a read whose repeated bins outgrow the table is given up below: stop inserting as soon as that is certain -- with
+			// the table nearly full every further hit would walk hundreds of slots, and one such read per launch of 4 096 kept
+			// the launch alive for 25 ms: 1.7 s instead of 0.1 s for config 5's 256 k tied reads)
+			if (*(volatile uint32_t *) &s_keys > (n_slots * 3u) / 4u) return;
 			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
 			for (uint32_t probes = 0; probes < n_slots; ++probes) {
 				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
@@ -1120,7 +1130,8 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		}
 	}
 	__syncthreads();
-	if (s_keys > (n_slots * 3u) / 4u) { give_up(); return; }
+	if (diag) ck[2] = wall_clock64();
+	if (s_keys > (n_slots * 3u) / 4u) { give_up(); if (diag && lane == 0) atomicAdd(&A.phase_cycles[13], 1ull); return; }
 	// sweep B (LDS only): exact votes of the tracked bins; their time line entries become slot | strand << 31, all others
 	// empty.  The plane is rebuilt as a bit set of the tracked keys first, so that the ~90 % untracked hits cost one read.
 	for (uint32_t s2 = lane; s2 < plane_words; s2 += 64) plane[s2] = 0;
@@ -1147,6 +1158,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		ev_at[t] = out;
 	}
 	__syncthreads();
+	if (diag) ck[3] = wall_clock64();
 	// replay in time order.  A bin with one vote never moves the maximum beyond 1 and is never a candidate unless the final
 	// threshold is <= 1 (those are tracked as t_cand): the very first hit of the read already sets the maximum to 1
 	// (CS.cpp:197-202), so only the hits of those bins take part; they are packed to the front of the time line first.
@@ -1197,6 +1209,12 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		next_rank += (uint32_t) __popcll(firsts);
 	}
 	__syncthreads();
+	if (diag) ck[4] = wall_clock64();
+	if (diag && lane == 0) {  // 100 MHz ticks: lists, sweep A, sweep B, compaction + replay; sampled reads, big ones, hits, replayed hits
+		atomicAdd(&A.phase_cycles[8], ck[1] - ck[0]); atomicAdd(&A.phase_cycles[9], ck[2] - ck[1]); atomicAdd(&A.phase_cycles[10], ck[3] - ck[2]);
+		atomicAdd(&A.phase_cycles[11], ck[4] - ck[3]); atomicAdd(&A.phase_cycles[12], 1ull); 
+		atomicAdd(&A.phase_cycles[14], (unsigned long long) H); atomicAdd(&A.phase_cycles[15], (unsigned long long) E);
+	}
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
 	for (uint32_t c = lane; c < cn; c += 64) {
 		const uint32_t bin = ((cand_loc[cb + c] - centre) >> A.bin_shift) & 0x3FFFFFFFu;
@@ -1209,6 +1227,12 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 			slot = (slot + 1) & (n_slots - 1);
 		}
 		cand_rank[cb + c] = rank;
+	}
+	if (A.phase_cycles && threadIdx.x == 0) {
+		const unsigned long long dt = wall_clock64() - t_block;
+		atomicAdd(&A.phase_cycles[13], dt << 8);  // whole-block time of every workgroup (ticks << 8 above the give-up count)
+		atomicMax(&A.phase_cycles[16], dt);
+		if (dt > 100000ull) { atomicAdd(&A.phase_cycles[17], 1ull); atomicMax(&A.phase_cycles[18], (unsigned long long) H); atomicMax(&A.phase_cycles[19], (unsigned long long) s_keys); }  // > 1 ms
 	}
 }
 

@@ -64,6 +64,7 @@ struct ngm_mapper {
 	uint32_t cs_queued_exact = 0;
 	int cs_fast_items = ngm::kCsFastItemsShort;
 	size_t cs_region_cap = 0; // candidate slots of all output regions together (grows when a batch overflows)
+	double cs_hexp = 4096;    // expected index hits per read
 	int cs_waves = 3;         // waves per read of the fast path (cs_fast2_kernel; 1: cs_fast_kernel, NGM_HIP_CS_WAVES)
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
@@ -135,7 +136,7 @@ int run_cs(ngm_mapper *m, int n) {
 	const int q = m->prm.qry_max_len;
 	if (n <= 0) { m->n_reads = 0; m->n_cand = 0; return 0; }
 	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) || m->d_max_both.reserve(n) ||
-			m->d_status.reserve(4) || m->d_total.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 16) || m->d_counters.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 16) || m->d_new_base.reserve(n) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
+			m->d_status.reserve(4) || m->d_total.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 16) || m->d_counters.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 32) || m->d_new_base.reserve(n) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
 			m->d_ovf_hits.reserve(n)) {
 		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
 		return -12;
@@ -150,7 +151,7 @@ int run_cs(ngm_mapper *m, int n) {
 		if (m->d_out_loc.reserve(cap + fixed_slots) || m->d_out_sv.reserve(cap + fixed_slots) || m->d_out_loc2.reserve(cap + fixed_slots) || m->d_out_sv2.reserve(cap + fixed_slots)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 16) * 8, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 16) * 8, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 32) * 8, m->st));
 		ngm::CsArgs A{};
 		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
@@ -406,6 +407,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	{
 		const double avg_list = (double) ref->n_entries / (double) (1ull << (2 * ref->prm.kmer));
 		const double hexp = std::max(64.0, 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer) * avg_list);
+		m->cs_hexp = hexp;
 		int lb = 12;
 		while ((double) (1u << lb) < 12.0 * hexp && lb < 17) ++lb;
 		m->cs_log2_bits = lb;
@@ -529,22 +531,35 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 // Reference order of the candidates of the listed reads (cs_order_kernel): h_rank[c] for every candidate c of those
 // reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
 static int candidate_order_wait(ngm_mapper *m, uint32_t **h_rank) {
-	MAP_HIP_TRY(hipStreamSynchronize(m->st_hi ? m->st_hi : m->st));
+	static const bool order_on_main = getenv("NGM_HIP_ORDER_ON_MAIN_STREAM") != nullptr;
+	MAP_HIP_TRY(hipStreamSynchronize((m->st_hi && !order_on_main) ? m->st_hi : m->st));
 	*h_rank = m->p_rank.p;
 	return 0;
 }
 // wait = false: only enqueue (the list must stay alive until candidate_order_wait)
 static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank, bool wait = true) {
 	const uint32_t nl = (uint32_t) list.size();
-	hipStream_t ost = m->st_hi ? m->st_hi : m->st;  // everything this depends on has been synchronised by the caller
+	static const bool order_on_main = getenv("NGM_HIP_ORDER_ON_MAIN_STREAM") != nullptr;  // diagnostics
+	hipStream_t ost = (m->st_hi && !order_on_main) ? m->st_hi : m->st;  // everything this depends on has been synchronised by the caller
 	const auto t_begin = std::chrono::steady_clock::now();
 	if (m->d_order_list.reserve(nl) || m->d_cand_rank.reserve(np + 1) || m->p_rank.reserve(np + 1)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
 	MAP_HIP_TRY(hipMemcpyAsync(m->d_order_list.p, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ost));
 	ngm::CsArgs A = m->last_cs;
 	A.read_list = m->d_order_list.p;
 	A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p;
-	A.counters = nullptr; A.phase_cycles = nullptr;
-	const size_t lds = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + ngm::kCsOrderMaxHits) * 4;
+	A.counters = nullptr;
+	const size_t ctr_words_o = (size_t) ngm::kCsRegions * ngm::kCsCursorStride;
+	A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + ctr_words_o : nullptr;
+	if (A.phase_cycles) MAP_HIP_TRY(hipMemsetAsync(A.phase_cycles + 8, 0, 12 * 8, ost));
+	// the time line in LDS holds 1.7 x the expected hits per read (reads beyond it walk a slice of global memory, ~10 x slower),
+	// within what lets TWO workgroups share a CU (80 KB each): measured on MI355X, this kernel with 88 KB of LDS has 26
+	// workgroups in flight instead of 232 (NGM_HIP_CS_PHASES=1 prints the summed workgroup time; a plain spinning kernel of the
+	// same LDS size does reach 232, profiles/tools/lds_occupancy_calib.hip) -- 1.7 s instead of 0.1 s for config 5's 256 k tied reads
+	const size_t lds_budget = std::max<size_t>(80 * 1024, 0);
+	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots)) * 4;
+	const size_t hits_room = lds_fixed + 4 * (size_t) ngm::kCsOrderMaxHits < lds_budget ? (lds_budget - 64 - lds_fixed) / 4 : (size_t) ngm::kCsOrderMaxHits;
+	A.order_max_hits = (uint32_t) std::min<size_t>(hits_room, std::max<size_t>(ngm::kCsOrderMaxHits, ((size_t) (1.7 * m->cs_hexp) + 1023) / 1024 * 1024));
+	const size_t lds = lds_fixed + (size_t) A.order_max_hits * 4;
 	// reads with more hits than the LDS time line holds use a slice of a global scratch: launches of at most 4096 reads
 	constexpr uint32_t kChunk = 4096, kGcap = 49152;
 	if (m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap)) { A.order_scratch = nullptr; A.order_gcap = 0; }
@@ -558,6 +573,15 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	if (!wait) return 0;
 	MAP_HIP_TRY(hipStreamSynchronize(ost));
 	*h_rank = m->p_rank.p;
+	if (A.phase_cycles) {
+		unsigned long long ph[12];
+		MAP_HIP_TRY(hipMemcpy(ph, A.phase_cycles + 8, sizeof(ph), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[ngm-hip] order replay: slowest workgroup %.1f us; %llu workgroups above 1 ms (most hits among them %llu, most tracked bins %llu)\n", ph[8] / 100.0, ph[9], ph[10], ph[11]);
+		const double ns = (double) std::max(1ull, ph[4]);
+		fprintf(stderr, "[ngm-hip] order replay, us per sampled read: lists %.1f | sweep A %.1f | sweep B %.1f | compaction + replay %.1f; %llu sampled, %llu gave up, %llu on the global time line; hits %.0f, replayed %.0f per read\n",
+				ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[4], ph[5] & 0xFFull, 0ull, ph[6] / ns, ph[7] / ns);
+		fprintf(stderr, "[ngm-hip] order replay: %.1f us per workgroup start to end, summed %.1f ms over %u workgroups\n", (double) (ph[5] >> 8) / 100.0 / std::max(1u, nl), (double) (ph[5] >> 8) / 1e5, nl);
+	}
 	if (getenv("NGM_HIP_HOST_TIMING"))
 		fprintf(stderr, "[ngm-hip] candidate order replay: %u reads, %.2f ms\n", nl, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
 	return 0;
