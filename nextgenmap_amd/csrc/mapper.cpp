@@ -555,7 +555,8 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	// within what lets TWO workgroups share a CU (80 KB each): measured on MI355X, this kernel with 88 KB of LDS has 26
 	// workgroups in flight instead of 232 (NGM_HIP_CS_PHASES=1 prints the summed workgroup time; a plain spinning kernel of the
 	// same LDS size does reach 232, profiles/tools/lds_occupancy_calib.hip) -- 1.7 s instead of 0.1 s for config 5's 256 k tied reads
-	const size_t lds_budget = std::max<size_t>(80 * 1024, 0);
+	static const size_t lds_budget_kb = getenv("NGM_HIP_ORDER_LDS_KB") ? (size_t) atoi(getenv("NGM_HIP_ORDER_LDS_KB")) : 80;  // (tuning)
+	const size_t lds_budget = lds_budget_kb * 1024;
 	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots)) * 4;
 	const size_t hits_room = lds_fixed + 4 * (size_t) ngm::kCsOrderMaxHits < lds_budget ? (lds_budget - 64 - lds_fixed) / 4 : (size_t) ngm::kCsOrderMaxHits;
 	A.order_max_hits = (uint32_t) std::min<size_t>(hits_room, std::max<size_t>(ngm::kCsOrderMaxHits, ((size_t) (1.7 * m->cs_hexp) + 1023) / 1024 * 1024));
