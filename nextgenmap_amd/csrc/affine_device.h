@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t 
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int aff_nib_words(int CP) { return (CP + 7) / 8; }
 __device__ __forceinline__ v2s pk_min(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s pk_sub_sat(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }  // v_pk_sub_i16 ... clamp
 
 // WINDOW: for bands of more than 32 columns or scores of 2 048 and more the row key is (score - base) << 7 | 127 - d with a
 // per-pair base that follows the running row maximum: a row's maximum is at least the previous row's minus one mismatch (the
@@ -439,14 +440,15 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 				const v2s t = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(PB[bi >> 2], PA[bi >> 2], sel));
 				const v2s dg = S[d] + t;
 				v2s eh = neg2, ho = zero2;   // ho / vo: 1 where the gap was opened in this cell (strictly better than extending)
-				if (d > 0) { const v2s e = leftEh + ext2; eh = pk_max(e, leftS + open2); ho = pk_min(eh - e, one2); }
+				// (the flag differences saturate: "unreachable" is -20 000, and with long reads the re-based scores pass +12 767)
+				if (d > 0) { const v2s e = leftEh + ext2; eh = pk_max(e, leftS + open2); ho = pk_min(pk_sub_sat(eh, e), one2); }
 				v2s ev = neg2, vo = zero2;
-				if (d < CP - 1) { const v2s e = Ev[d + 1] + vext2; ev = pk_max(e, S[d + 1] + vopen2); vo = pk_min(ev - e, one2); }
+				if (d < CP - 1) { const v2s e = Ev[d + 1] + vext2; ev = pk_max(e, S[d + 1] + vopen2); vo = pk_min(pk_sub_sat(ev, e), one2); }
 				// gap maximum: vertical unless horizontal is strictly greater (fh); the diagonal wins ties against it (nd = 0)
 				v2s gm, fh;
-				if (d == 0) { gm = ev; fh = zero2; } else if (d == CP - 1) { gm = eh; fh = one2; } else { gm = pk_max(ev, eh); fh = pk_min(gm - ev, one2); }
+				if (d == 0) { gm = ev; fh = zero2; } else if (d == CP - 1) { gm = eh; fh = one2; } else { gm = pk_max(ev, eh); fh = pk_min(pk_sub_sat(gm, ev), one2); }
 				v2s sc = pk_max(gm, dg);
-				const v2s nd = pk_min(sc - dg, one2);
+				const v2s nd = pk_min(pk_sub_sat(sc, dg), one2);
 				const v2s pos = pk_max(sc - fl2, zero2);     // the cell's score; 0: clamped (S = Eh = Ev = 0, no trace)
 				const v2s nz = pk_min(pos, one2);
 				sc = pk_max(sc, fl2);

@@ -1007,13 +1007,17 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 constexpr int kCsOrderLog2Slots = 10;       // tracked bins (>= 2 votes, plus bit collisions): 1024 slots
 constexpr uint32_t kCsOrderMaxHits = 7168;  // least time line entries in LDS (CsArgs::order_max_hits); reads with more hits use a slice of global memory
 constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
+constexpr int kCsOrderThreads = 256;
 
-__global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
+__global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
 		uint32_t *__restrict__ cand_rank) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	__shared__ uint32_t s_keys;  // distinct tracked bins
 	const unsigned long long t_block = A.phase_cycles ? wall_clock64() : 0ull;
-	const int lane = threadIdx.x;
+	// four waves: the sweeps over the hits (most of the time) are spread over all of them, the sequential parts -- the time-ordered
+	// compaction and the replay -- stay with wave 0; cs_prepare is run by every wave (same values, its barrier is the block's)
+	constexpr int NT = kCsOrderThreads;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int read = (int) A.read_list[blockIdx.x];
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;
@@ -1027,9 +1031,9 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	uint32_t *t_rank = t_run + n_slots;
 	uint32_t *t_cand = t_rank + n_slots;    // 1: the bin is one of the read's candidates (tracked even with a single vote)
 	uint32_t *ev_at = t_cand + n_slots;     // [kCsOrderMaxHits]: slot | strand << 31 of the hit at that time, or empty (reads with more hits: global memory)
-	for (uint32_t s = lane; s < plane_words; s += 64) plane[s] = 0;
-	for (uint32_t s = lane; s < n_slots; s += 64) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; t_cand[s] = 0; }
-	if (lane == 0) s_keys = 0;
+	for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
+	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; t_cand[s] = 0; }
+	if (tid == 0) s_keys = 0;
 	uint32_t *seg_pref = ev_at + A.order_max_hits;
 	const bool diag = A.phase_cycles && (blockIdx.x & 63) == 0;
 	unsigned long long ck[6] = {0, 0, 0, 0, 0, 0};
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	const int L = R.L;
 	if (diag) ck[1] = wall_clock64();
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
-	auto give_up = [&]() { for (uint32_t c = lane; c < cn; c += 64) cand_rank[cb + c] = kCsOrderUnknown; };
+	auto give_up = [&]() { for (uint32_t c = tid; c < cn; c += NT) cand_rank[cb + c] = kCsOrderUnknown; };
 	// very repetitive reads: the time line moves to global memory; the 16-bit list offsets of l_pref bound that at 65 535 hits
 	const bool big = H > A.order_max_hits;
 	if (big) {
@@ -1047,7 +1051,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		ev_at = A.order_scratch + (size_t) blockIdx.x * A.order_gcap;
 	}
 	__syncthreads();
-	{
+	if (wv == 0) {
 		uint32_t carry = 0;
 		for (int base = 0; base < R.n_lists; base += 64) {
 			const int li = base + lane;
@@ -1062,7 +1066,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	// diverged reads) single-vote bins are candidates too, and entered rList at their only hit
 	{
 		const uint32_t centre0 = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
-		for (uint32_t c = lane; c < cn; c += 64) {
+		for (uint32_t c = tid; c < cn; c += NT) {
 			const uint32_t bin = ((cand_loc[cb + c] - centre0) >> A.bin_shift) & 0x3FFFFFFFu;
 			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
 			for (uint32_t probes = 0; probes < n_slots; ++probes) {
@@ -1117,9 +1121,9 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 			d[0] = src[0]; d[1] = src[1];  // the table is padded by 16 entries
 			return (li << 16) | sg;
 		};
-		uint32_t item = fetch((uint32_t) lane, cur);
-		for (uint32_t idx = (uint32_t) lane; idx < R.n_items; idx += 64) {
-			const uint32_t item_n = fetch(idx + 64, nxt);
+		uint32_t item = fetch((uint32_t) tid, cur);
+		for (uint32_t idx = (uint32_t) tid; idx < R.n_items; idx += NT) {
+			const uint32_t item_n = fetch(idx + NT, nxt);
 			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
 			const uint32_t meta = l_pref[li];
 			const uint32_t cnt = min((uint32_t) kCsSeg, (meta & 0xFFFFu) - sg * kCsSeg), t0 = (meta >> 16) + sg * kCsSeg;
@@ -1131,17 +1135,17 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	}
 	__syncthreads();
 	if (diag) ck[2] = wall_clock64();
-	if (s_keys > (n_slots * 3u) / 4u) { give_up(); if (diag && lane == 0) atomicAdd(&A.phase_cycles[13], 1ull); return; }
+	if (s_keys > (n_slots * 3u) / 4u) { give_up(); if (diag && tid == 0) atomicAdd(&A.phase_cycles[13], 1ull); return; }
 	// sweep B (LDS only): exact votes of the tracked bins; their time line entries become slot | strand << 31, all others
 	// empty.  The plane is rebuilt as a bit set of the tracked keys first, so that the ~90 % untracked hits cost one read.
-	for (uint32_t s2 = lane; s2 < plane_words; s2 += 64) plane[s2] = 0;
+	for (uint32_t s2 = tid; s2 < plane_words; s2 += NT) plane[s2] = 0;
 	__syncthreads();
-	for (uint32_t s2 = lane; s2 < n_slots; s2 += 64) {
+	for (uint32_t s2 = tid; s2 < n_slots; s2 += NT) {
 		const uint32_t key = t_keys[s2];
 		if (key != 0xFFFFFFFFu) { const uint32_t b = (key * 0x9E3779B1u) >> 16; atomicOr(&plane[b >> 5], 1u << (b & 31)); }
 	}
 	__syncthreads();
-	for (uint32_t t = lane; t < H; t += 64) {
+	for (uint32_t t = tid; t < H; t += NT) {
 		const uint32_t e = ev_at[t];
 		const uint32_t bin = e & 0x3FFFFFFFu;
 		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
@@ -1164,6 +1168,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	// (CS.cpp:197-202), so only the hits of those bins take part; they are packed to the front of the time line first.
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 	uint32_t E = 0;
+	if (wv == 0) {
 	for (uint32_t t0 = 0; t0 < H; t0 += 64) {
 		const uint32_t t = t0 + (uint32_t) lane;
 		uint32_t e = (t < H) ? ev_at[t] : 0xFFFFFFFFu;
@@ -1181,7 +1186,7 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 	// rList at its first hit with score >= maximum * sensitivity (CS.cpp:205-208); the ranks follow the lane order.
 	uint32_t max_votes = H > 0 ? 1u : 0u, next_rank = 0;
 	for (uint32_t c0 = 0; c0 < E; c0 += 64) {
-		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // one wave: LDS operations complete in program order
 		const bool act = c0 + (uint32_t) lane < E;
 		const uint32_t e = act ? ev_at[c0 + (uint32_t) lane] : 0u;
 		const uint32_t slot = e & 0x7FFFFFFFu;
@@ -1208,15 +1213,16 @@ __global__ __launch_bounds__(64) void cs_order_kernel(CsArgs A, const uint32_t *
 		if (first) t_rank[slot] = next_rank + (uint32_t) __popcll(firsts & lanes_below);
 		next_rank += (uint32_t) __popcll(firsts);
 	}
+	}  // wave 0
 	__syncthreads();
 	if (diag) ck[4] = wall_clock64();
-	if (diag && lane == 0) {  // 100 MHz ticks: lists, sweep A, sweep B, compaction + replay; sampled reads, big ones, hits, replayed hits
+	if (diag && tid == 0) {  // 100 MHz ticks: lists, sweep A, sweep B, compaction + replay; sampled reads, big ones, hits, replayed hits
 		atomicAdd(&A.phase_cycles[8], ck[1] - ck[0]); atomicAdd(&A.phase_cycles[9], ck[2] - ck[1]); atomicAdd(&A.phase_cycles[10], ck[3] - ck[2]);
 		atomicAdd(&A.phase_cycles[11], ck[4] - ck[3]); atomicAdd(&A.phase_cycles[12], 1ull); 
 		atomicAdd(&A.phase_cycles[14], (unsigned long long) H); atomicAdd(&A.phase_cycles[15], (unsigned long long) E);
 	}
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
-	for (uint32_t c = lane; c < cn; c += 64) {
+	for (uint32_t c = tid; c < cn; c += NT) {
 		const uint32_t bin = ((cand_loc[cb + c] - centre) >> A.bin_shift) & 0x3FFFFFFFu;
 		uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
 		uint32_t rank = kCsOrderUnknown;

@@ -567,7 +567,7 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	else { A.order_scratch = m->d_order_scratch.p; A.order_gcap = kGcap; }
 	for (uint32_t off = 0; off < nl; off += kChunk) {
 		A.read_list = m->d_order_list.p + off;
-		hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(std::min(kChunk, nl - off)), dim3(64), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
+		hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(std::min(kChunk, nl - off)), dim3(ngm::kCsOrderThreads), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
 		MAP_HIP_TRY(hipGetLastError());
 	}
 	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
