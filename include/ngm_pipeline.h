@@ -173,6 +173,13 @@ void ngm_host_free(void *p);
  * NGM_HIP_NO_NUMA_PIN is set), < 0 on error.  (NextGenMap itself leaves placement to the OS; this replaces nothing there.) */
 int ngm_host_pin_to_device_node(int device);
 
+/* A reference artefact that is NOT mirrored: NextGenMap hands a read to its ScoreBuffer right after the search
+ * (src/CS.cpp:436); when the scores of a pair's first mate end exactly on a multiple of the 1 024-entry score buffer
+ * (src/seqan/EndToEndAffine.h:44-46), top1SE runs on that mate alone before its partner has scores
+ * (src/ScoreBuffer.cpp:196-209) and narrows the pairing to that winner.  out[0] = pairs of this mapper's batches where that
+ * would have happened, out[1] = those of them whose first mate has several candidates (only there can the outcome differ). */
+int ngm_mapper_early_top1se_counts(ngm_mapper *m, uint64_t out[2]);
+
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted
  * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */
 int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]);

@@ -47,6 +47,7 @@ struct ngm_pair_state {
 	std::condition_variable cv;
 	uint64_t next = 0;                 // sequence number of the batch whose turn it is
 	long dist_count = 1, dist_sum = 0;
+	uint64_t scores_so_far = 0;        // candidates of all pairs so far: where the reference's score buffer would stand
 };
 
 struct ngm_mapper {
@@ -67,6 +68,8 @@ struct ngm_mapper {
 	double cs_hexp = 4096;    // expected index hits per read
 	int cs_waves = 3;         // waves per read of the fast path (cs_fast2_kernel; 1: cs_fast_kernel, NGM_HIP_CS_WAVES)
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
+	uint64_t scores_so_far = 0;       // see ngm_pair_state
+	uint64_t early_se_pairs = 0, early_se_ambiguous = 0;  // ngm_mapper_early_top1se_counts
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
 	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank, d_order_scratch;
@@ -732,13 +735,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			if (!active || held) return;
 			std::unique_lock<std::mutex> lk(m->ps->mu);
 			m->ps->cv.wait(lk, [&] { return m->ps->next == m->batch_seq; });
-			m->pair_dist_sum = m->ps->dist_sum; m->pair_dist_count = m->ps->dist_count;
+			m->pair_dist_sum = m->ps->dist_sum; m->pair_dist_count = m->ps->dist_count; m->scores_so_far = m->ps->scores_so_far;
 			held = true;
 		}
 		void release() {  // the running mean is final for this batch: the next batch may read it (align + CIGAR of this one go on)
 			if (!active || released) return;
 			acquire();
-			{ std::lock_guard<std::mutex> lk(m->ps->mu); m->ps->dist_sum = m->pair_dist_sum; m->ps->dist_count = m->pair_dist_count; m->ps->next = m->batch_seq + 1; }
+			{ std::lock_guard<std::mutex> lk(m->ps->mu); m->ps->dist_sum = m->pair_dist_sum; m->ps->dist_count = m->pair_dist_count; m->ps->scores_so_far = m->scores_so_far; m->ps->next = m->batch_seq + 1; }
 			m->ps->cv.notify_all();
 			released = true;
 		}
@@ -918,6 +921,21 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// every mean in between, and its insert size keeps the bounds exact.  (With --strata a tied pair may contribute
 			// nothing at all; then every tied pair simply waits for pass 4.)
 			pair_turn.acquire();
+			{
+				// Diagnostics only: the reference hands a read to its ScoreBuffer right after the search (CS.cpp:436); when
+				// the scores of a pair's first mate end exactly on a multiple of the 1 024-entry buffer (EndToEndAffine.h:44-46),
+				// DoRun runs top1SE on that mate alone before its partner has scores (ScoreBuffer.cpp:196-209).  That artefact is not
+				// mirrored; count where it would have struck, and where it could have changed something (several
+				// candidates for that mate).  Sequential like the running mean: part of the batch's turn.
+				uint64_t tot = m->scores_so_far;
+				for (int pi = 0; pi < n / 2; ++pi) {
+					const uint32_t c1 = m->h_count[2 * pi], c2 = m->h_count[2 * pi + 1];
+					tot += c1;
+					if (c1 > 0 && c2 > 0 && (tot & 1023u) == 0) { ++m->early_se_pairs; if (c1 > 1) ++m->early_se_ambiguous; }
+					tot += c2;
+				}
+				m->scores_so_far = tot;
+			}
 			if (!pe_strata) {
 				long sum_lo = m->pair_dist_sum, sum_hi = m->pair_dist_sum, cnt = m->pair_dist_count;
 				for (Tied &t : tied) {
@@ -1327,6 +1345,12 @@ int ngm_mapper_cs_max_combined(ngm_mapper *m, float *out) {
 	if (!m) return -22;
 	DevGuard g(m->ref->device);
 	if (m->n_reads > 0) MAP_HIP_TRY(hipMemcpy(out, m->d_max_both.p, (size_t) m->n_reads * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int ngm_mapper_early_top1se_counts(ngm_mapper *m, uint64_t out[2]) {
+	if (!m || !out) return -22;
+	out[0] = m->early_se_pairs; out[1] = m->early_se_ambiguous;
 	return 0;
 }
 

@@ -497,7 +497,7 @@ int main(int argc, char **argv) {
 	const int avg_len = (int) (sum_len / count);
 	if (q > 1000) q = 1000;
 	const int corridor = o.corridor > 0 ? o.corridor : (int) (5 + avg_len * 0.15);
-	char msg[256];
+	char msg[512];
 	snprintf(msg, sizeof(msg), "Average read length: %d (min: %zu, max: %d)", avg_len, min_len, q);
 	info("INPUT", msg);
 	info("INPUT", "Corridor width: " + std::to_string(corridor));
@@ -1092,6 +1092,13 @@ int main(int argc, char **argv) {
 		}
 		snprintf(msg, sizeof(msg), "Pool thread time inside the stages, s: parse + pack %.3f | format %.3f | output copies %.3f (writer wall %.3f)",
 				t_parse_cpu_us / 1e6, t_format_cpu_us / 1e6, t_write_cpu_us / 1e6, t_write_us / 1e6);
+		info("MAIN", msg);
+	}
+	if (o.paired) {
+		uint64_t hit = 0, amb = 0;
+		for (Worker &w : workers) { uint64_t c2[2] = {0, 0}; if (ngm_mapper_early_top1se_counts(w.m, c2) == 0) { hit += c2[0]; amb += c2[1]; } }
+		snprintf(msg, sizeof(msg), "Pairs whose first mate would have filled NextGenMap's score buffer exactly (early top1SE there, src/CS.cpp:436; not mirrored): %llu, %llu of them with several candidates for that mate",
+				(unsigned long long) hit, (unsigned long long) amb);
 		info("MAIN", msg);
 	}
 	if (const char *pf = getenv("NGM_HIP_PROFILE")) prof::dump(pf);
