@@ -117,8 +117,8 @@ def test_pipeline_output_independent_of_workers_and_batches(tmp_path):
     # the diagnostics counter of the reference artefact that is not mirrored (early top1SE) is reported, and is the
     # same sequential count whatever the workers / batches
     import re
-    c0 = re.search(r"early top1SE there[^:]*: (\d+), (\d+) of them", log0)
-    c1 = re.search(r"early top1SE there[^:]*: (\d+), (\d+) of them", log1)
+    c0 = re.search(r"not mirrored\): (\d+), (\d+) of them", log0)
+    c1 = re.search(r"not mirrored\): (\d+), (\d+) of them", log1)
     assert c0 and c1 and c0.groups() == c1.groups(), (log0[-600:], log1[-600:])
     assert len(base) == len(piped) and base == piped
     gz, log2 = run("gz", ["--workers", "2", "--batch-size", "10000"], ["-1", f1 + ".gz", "-2", f2 + ".gz"])
