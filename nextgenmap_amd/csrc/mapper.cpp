@@ -554,15 +554,15 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	const size_t ctr_words_o = (size_t) ngm::kCsRegions * ngm::kCsCursorStride;
 	A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + ctr_words_o : nullptr;
 	if (A.phase_cycles) MAP_HIP_TRY(hipMemsetAsync(A.phase_cycles + 8, 0, 12 * 8, ost));
-	// the time line in LDS holds 1.7 x the expected hits per read (reads beyond it walk a slice of global memory, ~10 x slower),
-	// within what lets TWO workgroups share a CU (80 KB each): measured on MI355X, this kernel with 88 KB of LDS has 26
+	// the time line takes what is left of 80 KB of LDS (reads with more hits walk a slice of global memory, ~10 x slower): the
+	// size that lets TWO workgroups share a CU: measured on MI355X, this kernel with 88 KB of LDS has 26
 	// workgroups in flight instead of 232 (NGM_HIP_CS_PHASES=1 prints the summed workgroup time; a plain spinning kernel of the
 	// same LDS size does reach 232, profiles/tools/lds_occupancy_calib.hip) -- 1.7 s instead of 0.1 s for config 5's 256 k tied reads
 	static const size_t lds_budget_kb = getenv("NGM_HIP_ORDER_LDS_KB") ? (size_t) atoi(getenv("NGM_HIP_ORDER_LDS_KB")) : 80;  // (tuning)
 	const size_t lds_budget = lds_budget_kb * 1024;
 	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots)) * 4;
 	const size_t hits_room = lds_fixed + 4 * (size_t) ngm::kCsOrderMaxHits < lds_budget ? (lds_budget - 64 - lds_fixed) / 4 : (size_t) ngm::kCsOrderMaxHits;
-	A.order_max_hits = (uint32_t) std::min<size_t>(hits_room, std::max<size_t>(ngm::kCsOrderMaxHits, ((size_t) (1.7 * m->cs_hexp) + 1023) / 1024 * 1024));
+	A.order_max_hits = (uint32_t) std::max<size_t>(ngm::kCsOrderMaxHits, std::min<size_t>(hits_room, 65535));  // (all of the budget: two workgroups per CU either way)
 	const size_t lds = lds_fixed + (size_t) A.order_max_hits * 4;
 	// reads with more hits than the LDS time line holds use a slice of a global scratch: launches of at most 4096 reads
 	constexpr uint32_t kChunk = 4096, kGcap = 49152;

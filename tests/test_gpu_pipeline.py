@@ -170,3 +170,24 @@ def test_map_se_matches_oracle_composition(tmp_path, mode):
             near += 1
     assert near > 0.93 * (len(reads) - 41)
     mp.close(); ref.close()
+
+
+def test_host_threads_are_pinned_to_the_gpus_numa_node():
+    """ngm_host_pin_to_device_node: 0 (no NUMA information / not permitted) or the size of the CPU set the calling thread now has."""
+    import ctypes as C
+    import os
+    import threading
+    from nextgenmap_amd.engine import load_library
+    lib = load_library()
+    lib.ngm_host_pin_to_device_node.restype = C.c_int
+    out = {}
+
+    def probe():  # (in a thread of its own: the affinity of the test runner stays what it was)
+        out["n"] = lib.ngm_host_pin_to_device_node(0)
+        out["cpus"] = len(os.sched_getaffinity(0))
+    t = threading.Thread(target=probe)
+    t.start()
+    t.join()
+    assert out["n"] >= 0
+    if out["n"] > 0:
+        assert out["cpus"] == out["n"]
