@@ -465,6 +465,9 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast))
 	NGM_CS_ATTR_T(2); NGM_CS_ATTR_T(3); NGM_CS_ATTR_T(4);
 #undef NGM_CS_ATTR_T
+	// three waves per read for the 768-segment size (150 bp reads), four for the 1 536-segment one (250 bp: 12.3 instead of 14.7 ms
+	// per 524 288 reads -- with twice the work items per read the fourth wave pays for the seventh-of-a-CU it costs)
+	m->cs_waves = m->cs_fast_items == ngm::kCsFastItemsLong ? 4 : 3;
 	if (const char *e = getenv("NGM_HIP_CS_WAVES")) m->cs_waves = std::min(4, std::max(1, atoi(e)));
 	A.log2_slots = log2_exact;
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
