@@ -98,3 +98,16 @@ def test_bam_writer_produces_a_valid_file(driver, tmp_path):
 def test_thread_pool_covers_every_index_once_also_with_concurrent_and_nested_callers(driver):
     r = subprocess.run([driver, "pool"], capture_output=True, text=True, timeout=300, env=dict(os.environ, NGM_HIP_HOST_THREADS="8"))
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_cli_rejects_what_it_does_not_support_before_touching_a_gpu():
+    """`ngm-hip` takes NextGenMap's option names (src/config/Options.h); options of modes that are not built (bisulfite, SLAM-seq,
+    fast pairing, argos, vcf) are refused loudly instead of being ignored, and so are unknown ones."""
+    from nextgenmap_amd import build
+    build.build()
+    for bad in (["--bs-mapping"], ["--slam-seq", "2"], ["--frobnicate"]):
+        r = subprocess.run([build.CLI, "-r", "x.fa", "-q", "y.fq", "-o", "/dev/null"] + bad, capture_output=True, text=True)
+        assert r.returncode != 0, bad
+        assert "[ngm-hip] error" in r.stderr, (bad, r.stderr)
+    r = subprocess.run([build.CLI, "-r", "/nonexistent/ref.fa", "-q", "y.fq", "-o", "/dev/null"], capture_output=True, text=True)
+    assert r.returncode != 0 and "cannot open reference" in (r.stdout + r.stderr)
