@@ -205,11 +205,14 @@ def end_to_end(ref, contigs, workdir, args, paired, affine):
     import re
     m = re.search(r"Input to output: ([0-9.]+) s", log)
     t_io = float(m.group(1)) if m else t_wall
+    mg = re.search(r"GPU kernels: ([0-9.]+) s of the ([0-9.]+) s mapping pass", log)
     out = {"reads": n, "seconds_first_input_byte_to_sam_closed": t_io, "value": n / t_io, "unit": "reads/s",
            "process_wall_s_incl_index_load_from_cache": t_wall, "sam_bytes": os.path.getsize(sam), "fastq_bytes": 2 * (n // 2) * rec,
-           "command": " ".join(["ngm-hip"] + cmd[1:]), "cli_log_tail": [l for l in log.splitlines() if "MAIN" in l][-3:],
+           "command": " ".join(["ngm-hip"] + cmd[1:]), "cli_log_tail": [l for l in log.splitlines() if "MAIN" in l][-4:],
            "input": "two plain FASTQ files (%d x %d bp pairs, fixed-width names), page cache warm; index from NextGenMap cache files" % (n // 2, READ_LEN),
-           "make_input_s": t_make}
+           "make_input_s": t_make,
+           "gpu_kernel_s": float(mg.group(1)) if mg else None, "mapping_pass_s": float(mg.group(2)) if mg else None,
+           "gpu_busy_fraction_of_mapping_pass": (float(mg.group(1)) / float(mg.group(2))) if mg and float(mg.group(2)) > 0 else None}
     base = None
     if not args.no_cpu_baseline and RF.have_reference_binary() and affine:
         ns = min(args.cpu_sample_reads, n) & ~1

@@ -894,6 +894,7 @@ int main(int argc, char **argv) {
 	std::mutex spare_mu;
 	std::vector<std::vector<std::string>> spare_chunks;
 	std::vector<std::vector<Rec>> spare_recs;
+	std::atomic<long long> t_gpu_us{0};  // HIP-event time of the mapping kernels, summed over the batches
 	std::atomic<long long> t_wait_us{0}, t_parse_us{0}, t_map_us{0}, t_format_us{0}, t_format_cpu_us{0}, t_parse_cpu_us{0}, t_write_us{0}, t_write_cpu_us{0};
 	auto us_since = [](std::chrono::steady_clock::time_point t0) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
 	auto worker_main = [&](Worker &w) {
@@ -982,6 +983,7 @@ int main(int argc, char **argv) {
 			                        : ngm_mapper_map_se(w.m, n, w.rows, w.hits.data(), w.cig.data(), w.md.data());
 			if (rc < 0) { fail(ngm_pipeline_last_error()); continue; }
 			t_map_us += us_since(tm);
+			{ float kms[8] = {0}; if (ngm_mapper_last_kernel_ms(w.m, kms) == 0) { double sum = 0; for (int k2 = 0; k2 < 7; ++k2) sum += kms[k2]; t_gpu_us += (long long) (sum * 1000.0); } }
 			auto tf = std::chrono::steady_clock::now();
 			// format: chunks of whole pairs
 			const int units = o.paired ? n / 2 : n, per = o.paired ? 2 : 1;
@@ -1071,6 +1073,9 @@ int main(int argc, char **argv) {
 	info("MAIN", msg);
 	snprintf(msg, sizeof(msg), "Mapping pass: %.3f s, %.0f reads/s (%zu GPU(s) x %d worker(s), %d host threads, %s input)", secs, n_total / std::max(1e-9, secs),
 			o.devices.size(), o.workers, pool.size(), plain ? "memory-mapped plain FASTQ" : "serial reader");
+	info("MAIN", msg);
+	snprintf(msg, sizeof(msg), "GPU kernels: %.3f s of the %.3f s mapping pass (%.0f %%; candidate search, gathers, score, select, align, traceback by HIP events)",
+			t_gpu_us / 1e6, secs, 100.0 * (t_gpu_us / 1e6) / std::max(1e-9, secs));
 	info("MAIN", msg);
 	snprintf(msg, sizeof(msg), "Input to output: %.3f s (estimation pass + mapping pass, first input byte to output closed)",
 			std::chrono::duration<double>(std::chrono::steady_clock::now() - t_input).count());
