@@ -14,7 +14,7 @@
 //
 // Pass 2 is a pipeline, not a loop:
 //   splitter (1 thread)   cuts the input into batches: for plain 4-line FASTQ it only counts line ends in the mapped file
-//                         (record boundaries every 4 096 reads), for gz / FASTA / multi-line input it is the serial kseq-style
+//                         (record boundaries every 1 024 reads), for gz / FASTA / multi-line input it is the serial kseq-style
 //                         reader (inflate is one stream; that is the bound of such input, as in the reference);
 //   workers               `--workers` per GPU (default 2), each owning an ngm_mapper like a NextGenMap CS thread owns its
 //                         IAlignment: parse its batch into a page-locked row buffer (pool threads, zero-copy names / qualities),
