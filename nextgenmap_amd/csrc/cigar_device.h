@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 				else if (silent_clip != 1) { co += dev_put_num(cg + co, lead); cg[co++] = 'S'; }
 				o.qstart = lead;
 			}
+			// symbol classes of read position j / window position j: eight per dword, the dword kept while it lasts
+			uint32_t rw_at = 0xFFFFFFFFu, rw = 0, fw_at = 0xFFFFFFFFu, fw = 0;
+			auto nib = [](uint32_t w, int b) -> uint32_t { return (b < 4) ? (w >> (8 * b)) & 15u : (w >> (8 * (b - 4) + 4)) & 15u; };
+			auto rclass = [&](int j) -> uint32_t { const uint32_t wi = (uint32_t) j >> 3; if (wi != rw_at) { rw = pb[(size_t) wi * kSlots]; rw_at = wi; } return nib(rw, j & 7); };
+			auto fclass = [&](int j) -> uint32_t { const uint32_t wi = (uint32_t) j >> 3; if (wi != fw_at) { fw = pb[(size_t) (RW + wi) * kSlots]; fw_at = wi; } return nib(fw, j & 7); };
 			int match = 0, mismatch = 0, total = 0, m_len = 0, md_eq = 0, ref_i = 0, read_i = o.qstart;
 			bool in_x_run = false, odd_symbol = false;
 			for (int k = nruns - 1; k >= 0 && fits; --k) {
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 				if (co > lim || mo > lim) { fits = false; break; }
 				if (op == 1 || op == 0) {
 					for (int t = 0; t < len; ++t) {
-						const uint32_t rc = packed_class(pb, 0, read_i), fc = packed_class(pb, RW, ref0 + ref_i);
+						const uint32_t rc = rclass(read_i), fc = fclass(ref0 + ref_i);
 						if (rc == 4u) odd_symbol = true;  // a read symbol outside ACGTN: characters and classes may disagree -> host
 						const bool eq = (op == 1) && (variant_cpu ? (rc <= 3u && rc == fc) : (rc == fc));
 						if (eq) { match += 1; md_eq += 1; in_x_run = false; }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 					co += dev_put_num(cg + co, len); cg[co++] = 'D';
 					mo += dev_put_num(mdp + mo, md_eq); md_eq = 0;
 					mdp[mo++] = '^';
-					for (int t = 0; t < len; ++t) { if (mo > lim) { fits = false; break; } mdp[mo++] = class_to_char(packed_class(pb, RW, ref0 + ref_i)); ref_i += 1; }
+					for (int t = 0; t < len; ++t) { if (mo > lim) { fits = false; break; } mdp[mo++] = class_to_char(fclass(ref0 + ref_i)); ref_i += 1; }
 					mismatch += len;
 				} else {
 					in_x_run = false;
