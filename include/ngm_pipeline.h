@@ -179,6 +179,9 @@ int ngm_host_pin_to_device_node(int device);
  * (src/ScoreBuffer.cpp:196-209) and narrows the pairing to that winner.  out[0] = pairs of this mapper's batches where that
  * would have happened, out[1] = those of them whose first mate has several candidates (only there can the outcome differ). */
 int ngm_mapper_early_top1se_counts(ngm_mapper *m, uint64_t out[2]);
+/* ... the reference flushes that buffer at the end of every CS batch of 1 800 000 / qry_avg_len reads (src/CS.cpp:26, :542-543,
+ * even for paired input: src/NGM.cpp:238-243); tell the mapper that number (0: never flushed) so that the count follows it */
+int ngm_mapper_set_reference_cs_batch(ngm_mapper *m, int reads);
 
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted
  * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */

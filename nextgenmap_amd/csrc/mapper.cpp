@@ -47,7 +47,8 @@ struct ngm_pair_state {
 	std::condition_variable cv;
 	uint64_t next = 0;                 // sequence number of the batch whose turn it is
 	long dist_count = 1, dist_sum = 0;
-	uint64_t scores_so_far = 0;        // candidates of all pairs so far: where the reference's score buffer would stand
+	uint64_t scores_so_far = 0;        // candidates of the pairs of the reference's current CS batch: where its score buffer would stand
+	uint64_t reads_so_far = 0;         // reads of all batches so far (position inside the reference's CS batches)
 };
 
 struct ngm_mapper {
@@ -68,7 +69,8 @@ struct ngm_mapper {
 	double cs_hexp = 4096;    // expected index hits per read
 	int cs_waves = 3;         // waves per read of the fast path (cs_fast2_kernel; 1: cs_fast_kernel, NGM_HIP_CS_WAVES)
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
-	uint64_t scores_so_far = 0;       // see ngm_pair_state
+	uint64_t scores_so_far = 0, reads_so_far = 0;  // see ngm_pair_state
+	int ref_cs_batch = 0;             // reads per CS batch of the reference (1 800 000 / average read length, CS.cpp:26, :542): its score buffer is flushed there
 	uint64_t early_se_pairs = 0, early_se_ambiguous = 0;  // ngm_mapper_early_top1se_counts
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
@@ -738,13 +740,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			if (!active || held) return;
 			std::unique_lock<std::mutex> lk(m->ps->mu);
 			m->ps->cv.wait(lk, [&] { return m->ps->next == m->batch_seq; });
-			m->pair_dist_sum = m->ps->dist_sum; m->pair_dist_count = m->ps->dist_count; m->scores_so_far = m->ps->scores_so_far;
+			m->pair_dist_sum = m->ps->dist_sum; m->pair_dist_count = m->ps->dist_count; m->scores_so_far = m->ps->scores_so_far; m->reads_so_far = m->ps->reads_so_far;
 			held = true;
 		}
 		void release() {  // the running mean is final for this batch: the next batch may read it (align + CIGAR of this one go on)
 			if (!active || released) return;
 			acquire();
-			{ std::lock_guard<std::mutex> lk(m->ps->mu); m->ps->dist_sum = m->pair_dist_sum; m->ps->dist_count = m->pair_dist_count; m->ps->scores_so_far = m->scores_so_far; m->ps->next = m->batch_seq + 1; }
+			{ std::lock_guard<std::mutex> lk(m->ps->mu); m->ps->dist_sum = m->pair_dist_sum; m->ps->dist_count = m->pair_dist_count; m->ps->scores_so_far = m->scores_so_far; m->ps->reads_so_far = m->reads_so_far; m->ps->next = m->batch_seq + 1; }
 			m->ps->cv.notify_all();
 			released = true;
 		}
@@ -930,14 +932,15 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				// DoRun runs top1SE on that mate alone before its partner has scores (ScoreBuffer.cpp:196-209).  That artefact is not
 				// mirrored; count where it would have struck, and where it could have changed something (several
 				// candidates for that mate).  Sequential like the running mean: part of the batch's turn.
-				uint64_t tot = m->scores_so_far;
-				for (int pi = 0; pi < n / 2; ++pi) {
+				uint64_t tot = m->scores_so_far, at = m->reads_so_far;
+				for (int pi = 0; pi < n / 2; ++pi, at += 2) {
+					if (m->ref_cs_batch > 0 && at % (uint64_t) m->ref_cs_batch == 0) tot = 0;  // the reference flushes its score buffer at the end of a CS batch (CS.cpp:488-500)
 					const uint32_t c1 = m->h_count[2 * pi], c2 = m->h_count[2 * pi + 1];
 					tot += c1;
 					if (c1 > 0 && c2 > 0 && (tot & 1023u) == 0) { ++m->early_se_pairs; if (c1 > 1) ++m->early_se_ambiguous; }
 					tot += c2;
 				}
-				m->scores_so_far = tot;
+				m->scores_so_far = tot; m->reads_so_far = at;
 			}
 			if (!pe_strata) {
 				long sum_lo = m->pair_dist_sum, sum_hi = m->pair_dist_sum, cnt = m->pair_dist_count;
@@ -1348,6 +1351,12 @@ int ngm_mapper_cs_max_combined(ngm_mapper *m, float *out) {
 	if (!m) return -22;
 	DevGuard g(m->ref->device);
 	if (m->n_reads > 0) MAP_HIP_TRY(hipMemcpy(out, m->d_max_both.p, (size_t) m->n_reads * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int ngm_mapper_set_reference_cs_batch(ngm_mapper *m, int reads) {
+	if (!m || reads < 0) return -22;
+	m->ref_cs_batch = reads & ~1;
 	return 0;
 }
 

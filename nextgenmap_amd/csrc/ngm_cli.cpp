@@ -626,6 +626,7 @@ int main(int argc, char **argv) {
 		workers[w].m = ngm_mapper_create(refs[w % refs.size()], &mp);
 		if (!workers[w].m) die(ngm_pipeline_last_error());
 		ngm_mapper_set_pair_state(workers[w].m, pair_state);
+		ngm_mapper_set_reference_cs_batch(workers[w].m, 1800000 / std::max(1, avg_len));
 	}
 
 	// ---- the record -> SAM line code (SAMWriter::DoWriteReadGeneric, SAMWriter.cpp:98-228) -----------------------------
