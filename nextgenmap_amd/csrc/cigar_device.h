@@ -15,7 +15,7 @@
 namespace ngm {
 
 struct CigarDevOut {   // per alignment
-	uint32_t cig_off, md_off;     // into the compact byte stream (after cigar_compact_kernel)
+	uint32_t cig_off, md_off;     // into the compact byte stream
 	uint16_t cig_len, md_len;     // bytes, without the terminating NUL
 	int32_t position_offset, qstart, qend, nm;
 	float identity, score_token;
@@ -41,18 +41,28 @@ __device__ __forceinline__ int dev_put_num(char *dst, int v) {
 }
 
 // cig / md: scratch rows of `stride` bytes per alignment.  read_len: per READ (affine: QEnd); a_read: read of alignment j.
+// The strings are built in LDS rows (kCigarRow bytes for the CIGAR, as many for MD -- byte stores to 608-byte-strided global rows
+// cost one cache line per lane and store) and leave the workgroup as one contiguous piece of the compact byte stream: block
+// prefix sum of the lengths, ONE atomic on the stream cursor per workgroup.
+constexpr int kCigarRow = 96;
+
 template <bool AFFINE>
 __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t *__restrict__ records, const uint16_t *__restrict__ runs_c,
 		const uint32_t *__restrict__ packed, int RW, int FW, const uint16_t *__restrict__ read_len, const uint32_t *__restrict__ a_read, int variant_cpu,
-		int hard_clip, int silent_clip, int stride, char *__restrict__ cig, char *__restrict__ md, CigarDevOut *__restrict__ out) {
+		int hard_clip, int silent_clip, CigarDevOut *__restrict__ out, char *__restrict__ bytes, unsigned long long capacity, unsigned long long *__restrict__ cursor) {
+	__shared__ char s_rows[256 * 2 * kCigarRow];
+	__shared__ uint32_t s_wave[4];
+	__shared__ unsigned long long s_base;
 	const int j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= n) return;
-	const int32_t *rec = records + (size_t) j * 8;
+	const bool live = j < n;
+	constexpr int stride = kCigarRow;
 	CigarDevOut o{};
-	char *cg = cig + (size_t) j * stride, *mdp = md + (size_t) j * stride;
+	char *cg = s_rows + (size_t) threadIdx.x * 2 * kCigarRow, *mdp = cg + kCigarRow;
 	const int lim = stride - 16;  // room for one more element; longer strings go to the host fall-back
 	bool fits = true;
 	int co = 0, mo = 0;
+	if (live) {
+	const int32_t *rec = records + (size_t) j * 8;
 	const uint16_t *runs = runs_c + (uint32_t) rec[6];
 	if (AFFINE) {
 		int h = rec[1], v = rec[2], total = 0, pattern_chars = 0;
@@ -142,25 +152,33 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 			o.flags = ((fits && !odd_symbol) ? 1 : 0) | 2;
 		}
 	}
+	}  // live
 	o.cig_len = (uint16_t) co; o.md_len = (uint16_t) mo;
+	// this workgroup's piece of the stream
+	const uint32_t need = (live && (o.flags & 1)) ? (uint32_t) (co + mo) : 0u;
+	uint32_t incl = need;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+	if (lane == 63) s_wave[wv] = incl;
+	__syncthreads();
+	uint32_t before = incl - need, total = 0;
+#pragma unroll
+	for (int w2 = 0; w2 < 4; ++w2) { if (w2 < wv) before += s_wave[w2]; total += s_wave[w2]; }
+	if (threadIdx.x == 0) s_base = total ? atomicAdd(cursor, (unsigned long long) total) : 0ull;
+	__syncthreads();
+	const unsigned long long base = s_base;
+	if (!live) return;
+	if (need) {
+		if (base + total > capacity) o.flags &= ~1;  // stream full: built on the host
+		else {
+			const unsigned long long off = base + before;
+			o.cig_off = (uint32_t) off; o.md_off = (uint32_t) off + o.cig_len;
+			for (int t = 0; t < co; ++t) bytes[off + t] = cg[t];
+			for (int t = 0; t < mo; ++t) bytes[off + co + t] = mdp[t];
+		}
+	}
 	out[j] = o;
-}
-
-// strings of the scratch rows -> one compact byte stream (cursor: one atomic per alignment; the order does not matter)
-__global__ __launch_bounds__(256) void cigar_compact_kernel(int n, int stride, const char *__restrict__ cig, const char *__restrict__ md, CigarDevOut *__restrict__ out,
-		char *__restrict__ bytes, unsigned long long capacity, unsigned long long *__restrict__ cursor) {
-	const int j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= n) return;
-	CigarDevOut o = out[j];
-	if (!(o.flags & 1)) return;
-	const unsigned need = (unsigned) o.cig_len + (unsigned) o.md_len;
-	const unsigned long long off = need ? atomicAdd(cursor, (unsigned long long) need) : 0ull;
-	if (off + need > capacity) { out[j].flags = o.flags & ~1; return; }  // stream full: this one is built on the host
-	o.cig_off = (uint32_t) off; o.md_off = (uint32_t) off + o.cig_len;
-	const char *c = cig + (size_t) j * stride, *m = md + (size_t) j * stride;
-	for (unsigned t = 0; t < o.cig_len; ++t) bytes[off + t] = c[t];
-	for (unsigned t = 0; t < o.md_len; ++t) bytes[off + o.cig_len + t] = m[t];
-	out[j].cig_off = o.cig_off; out[j].md_off = o.md_off;
 }
 
 }  // namespace ngm

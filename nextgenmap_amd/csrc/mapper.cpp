@@ -97,7 +97,7 @@ struct ngm_mapper {
 	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
 	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records;
 	ngm::DevBuf<uint16_t> d_runs, d_runs_c;
-	ngm::DevBuf<char> d_cig_rows, d_md_rows, d_str;   // CIGAR / MD on the device: scratch rows and the compact stream
+	ngm::DevBuf<char> d_str;   // CIGAR / MD on the device: the compact byte stream
 	ngm::DevBuf<ngm::CigarDevOut> d_cigout;
 	ngm::PinnedBuf<ngm::CigarDevOut> p_cigout;
 	ngm::PinnedBuf<char> p_str;
@@ -495,7 +495,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
-	m->d_cig_rows.release(); m->d_md_rows.release(); m->d_str.release(); m->d_cigout.release(); m->p_cigout.release(); m->p_str.release();
+	m->d_str.release(); m->d_cigout.release(); m->p_cigout.release(); m->p_str.release();
 	ngm_hip_destroy(m->eng);
 	delete m;
 }
@@ -1188,18 +1188,16 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		unsigned long long n_runs_total = 0, n_str_total = 0;
 		// CIGAR / MD / NM / identity on the GPU (cigar_device.h); NGM_HIP_HOST_CIGAR=1 keeps the host builders (tests)
 		if (dev_strings) {
-			const int sstride = 4 * std::max(1, q);
 			const unsigned long long scap = (unsigned long long) na * 96ull + 4096ull;
-			if (m->d_cig_rows.reserve((size_t) na * sstride) || m->d_md_rows.reserve((size_t) na * sstride) || m->d_cigout.reserve(na) || m->d_str.reserve(scap) ||
-					m->p_cigout.reserve(na)) { ngm::pipeline_set_error("out of memory (CIGAR strings)"); return -12; }
+			if (m->d_cigout.reserve(na) || m->d_str.reserve(scap) || m->p_cigout.reserve(na)) { ngm::pipeline_set_error("out of memory (CIGAR strings)"); return -12; }
 			MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 8, 0, 8, m->st));
 			const bool affine = m->prm.personality == NGM_PERSONALITY_AFFINE;
 			if (affine) hipLaunchKernelGGL(ngm::cigar_strings_kernel<true>, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs_c.p, eng->packed.p, eng->RW, eng->FW,
-					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, sstride, m->d_cig_rows.p, m->d_md_rows.p, m->d_cigout.p);
+					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, m->d_cigout.p, m->d_str.p, scap,
+					(unsigned long long *) (m->d_total.p + 8));
 			else hipLaunchKernelGGL(ngm::cigar_strings_kernel<false>, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs_c.p, eng->packed.p, eng->RW, eng->FW,
-					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, sstride, m->d_cig_rows.p, m->d_md_rows.p, m->d_cigout.p);
-			hipLaunchKernelGGL(ngm::cigar_compact_kernel, dim3((na + 255) / 256), dim3(256), 0, m->st, na, sstride, m->d_cig_rows.p, m->d_md_rows.p, m->d_cigout.p, m->d_str.p, scap,
-					m->d_total.p + 8);
+					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, m->d_cigout.p, m->d_str.p, scap,
+					(unsigned long long *) (m->d_total.p + 8));
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_cigout.p, m->d_cigout.p, (size_t) na * sizeof(ngm::CigarDevOut), hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(&n_str_total, m->d_total.p + 8, 8, hipMemcpyDeviceToHost, m->st));
