@@ -148,22 +148,28 @@ def _sam_records(path, paired=False):
     return recs
 
 
-def write_fastq_pair(rows, path1, path2):
-    """rows 2i / 2i+1 -> two plain 4-line FASTQ files with fixed-width names r<8 digits>/1 and /2 (numpy, no Python loop).
-    Returns the bytes per record."""
-    n = rows.shape[0] // 2
+def write_fastq(rows, paths):
+    """rows -> plain 4-line FASTQ with fixed-width names (numpy, no Python loop).  Two paths: rows 2i / 2i+1 are mates and go to
+    paths[0] / paths[1] as r<8 digits>/1 and /2; one path: single-end reads r<8 digits>.  Returns the bytes per record."""
+    two = len(paths) == 2
+    n = rows.shape[0] // 2 if two else rows.shape[0]
     idx = np.arange(n, dtype=np.int64)
-    for mate, path in ((0, path1), (1, path2)):
-        hdr = np.empty((n, 12), np.uint8)
+    rec = 0
+    for mate, path in enumerate(paths):
+        w = 12 if two else 10
+        hdr = np.empty((n, w), np.uint8)
         hdr[:, 0] = ord("@"); hdr[:, 1] = ord("r")
         for d in range(8):
             hdr[:, 2 + d] = ord("0") + (idx // 10 ** (7 - d)) % 10
-        hdr[:, 10] = ord("/"); hdr[:, 11] = ord("1") + mate
+        if two:
+            hdr[:, 10] = ord("/"); hdr[:, 11] = ord("1") + mate
         nl = np.full((n, 1), ord("\n"), np.uint8)
-        a = np.concatenate([hdr, nl, rows[mate::2, :READ_LEN], np.frombuffer(b"\n+\n", np.uint8)[None, :].repeat(n, 0),
+        body = rows[mate::2, :READ_LEN] if two else rows[:, :READ_LEN]
+        a = np.concatenate([hdr, nl, body, np.frombuffer(b"\n+\n", np.uint8)[None, :].repeat(n, 0),
                             np.full((n, READ_LEN), ord("I"), np.uint8), nl], axis=1)
         a.tofile(path)
-    return 12 + 1 + READ_LEN + 3 + READ_LEN + 1
+        rec = a.shape[1]
+    return rec
 
 
 def _sam_body(path):
@@ -177,8 +183,35 @@ def _sam_body(path):
     return out
 
 
-def end_to_end(ref, contigs, workdir, args, paired, affine):
-    """The drop-in, measured: `ngm-hip` from the first input byte to the closed SAM file, and NextGenMap itself on a slice."""
+SAM_FIELDS = ["QNAME", "FLAG", "RNAME", "POS", "MAPQ", "CIGAR", "RNEXT", "PNEXT", "TLEN", "SEQ", "QUAL"]
+
+
+def _sam_diff(theirs, ours, limit=4):
+    """(identical lines, the first differing records as {name, field: [reference, ours]})"""
+    same, diffs = 0, []
+    for k, v in theirs.items():
+        o = ours.get(k)
+        if o == v:
+            same += 1
+            continue
+        if len(diffs) < limit:
+            if o is None:
+                diffs.append({"name": k[0].decode(), "missing_in_ours": True})
+                continue
+            fa, fb = v.decode().rstrip("\n").split("\t"), o.decode().rstrip("\n").split("\t")
+            d = {"name": k[0].decode(), "mapq_reference": fa[4], "mapq_ours": fb[4]}
+            for i in range(max(len(fa), len(fb))):
+                x, y = (fa[i] if i < len(fa) else None), (fb[i] if i < len(fb) else None)
+                if x != y:
+                    d[SAM_FIELDS[i] if i < len(SAM_FIELDS) else (x or y)[:2]] = [x, y]
+            diffs.append(d)
+    return same, diffs
+
+
+def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
+    """The drop-in, measured: `ngm-hip` from the first input byte to the closed SAM file (plain FASTQ, .fastq.gz and --bam), and
+    NextGenMap itself (-t cores and -t 1) on slices of the same input with the SAM records compared field by field."""
+    import re
     import ref_files as RF
     from nextgenmap_amd import build as B
     cores = os.cpu_count() or 1
@@ -189,62 +222,112 @@ def end_to_end(ref, contigs, workdir, args, paired, affine):
         ref.write_ngm_cache(fa)
     n = args.e2e_reads & ~1
     t0 = time.perf_counter()
-    rows, _, _ = make_reads(contigs, n, seed=20240602 + 3, paired=True, subs=args.subs, indel_bases=args.indel_bases)  # config #3's seed
-    f1, f2 = os.path.join(workdir, "e2e_1.fq"), os.path.join(workdir, "e2e_2.fq")
-    rec = write_fastq_pair(rows, f1, f2)
+    rows, _, _ = make_reads(contigs, n, seed=20240602 + 3, paired=paired, subs=args.subs, indel_bases=args.indel_bases)  # config #3's seed
+    files = [os.path.join(workdir, "e2e_1.fq"), os.path.join(workdir, "e2e_2.fq")] if paired else [os.path.join(workdir, "e2e.fq")]
+    rec = write_fastq(rows, files)
     t_make = time.perf_counter() - t0
+    common = ["-s", "%.6f" % sens, "--no-progress", "--max-read-length", str(READ_LEN)] + (["--affine"] if affine else [])
+    if args.corridor > 0:
+        common += ["-C", str(args.corridor // 2)]
+
+    def inputs(fs):
+        return ["-1", fs[0], "-2", fs[1]] if paired else ["-q", fs[0]]
+
+    def run_hip(fs, outp, extra=()):
+        cmd = [B.CLI, "-r", fa] + inputs(fs) + ["-o", outp] + common + list(extra)
+        t = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        wall = time.perf_counter() - t
+        log = r.stdout + r.stderr
+        if r.returncode != 0 or "Done" not in log:
+            raise RuntimeError("ngm-hip failed: " + log[-600:])
+        m = re.search(r"Input to output: ([0-9.]+) s", log)
+        mi = re.search(r"Reference and index ready: ([0-9.]+) s", log)
+        mg = re.search(r"GPU kernels: ([0-9.]+) s of the ([0-9.]+) s mapping pass", log)
+        return {"cmd": cmd, "log": log, "wall": wall, "io": float(m.group(1)) if m else wall, "index": float(mi.group(1)) if mi else None,
+                "gpu": float(mg.group(1)) if mg else None, "pass": float(mg.group(2)) if mg else None}
+
     sam = os.path.join(workdir, "e2e.sam")
-    pers = ["--affine"] if affine else []
-    cmd = [B.CLI, "-r", fa, "-1", f1, "-2", f2, "-o", sam, "-s", "0.5", "--no-progress"] + pers
-    t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    t_wall = time.perf_counter() - t0
-    log = r.stdout + r.stderr
-    if r.returncode != 0 or "Done" not in log:
-        raise RuntimeError("ngm-hip failed: " + log[-600:])
-    import re
-    m = re.search(r"Input to output: ([0-9.]+) s", log)
-    t_io = float(m.group(1)) if m else t_wall
-    mg = re.search(r"GPU kernels: ([0-9.]+) s of the ([0-9.]+) s mapping pass", log)
-    out = {"reads": n, "seconds_first_input_byte_to_sam_closed": t_io, "value": n / t_io, "unit": "reads/s",
-           "process_wall_s_incl_index_load_from_cache": t_wall, "sam_bytes": os.path.getsize(sam), "fastq_bytes": 2 * (n // 2) * rec,
-           "command": " ".join(["ngm-hip"] + cmd[1:]), "cli_log_tail": [l for l in log.splitlines() if "MAIN" in l][-4:],
-           "input": "two plain FASTQ files (%d x %d bp pairs, fixed-width names), page cache warm; index from NextGenMap cache files" % (n // 2, READ_LEN),
-           "make_input_s": t_make,
-           "gpu_kernel_s": float(mg.group(1)) if mg else None, "mapping_pass_s": float(mg.group(2)) if mg else None,
-           "gpu_busy_fraction_of_mapping_pass": (float(mg.group(1)) / float(mg.group(2))) if mg and float(mg.group(2)) > 0 else None}
+    h = run_hip(files, sam)
+    out = {"reads": n, "seconds_first_input_byte_to_sam_closed": h["io"], "value": n / h["io"], "unit": "reads/s",
+           "index_load_s": h["index"], "process_wall_s": h["wall"], "reads_per_s_of_process_wall": n / h["wall"],
+           "sam_bytes": os.path.getsize(sam), "fastq_bytes": len(files) * (n // len(files)) * rec,
+           "command": " ".join(["ngm-hip"] + h["cmd"][1:]), "cli_log_tail": [l for l in h["log"].splitlines() if "MAIN" in l][-4:],
+           "input": "%s plain FASTQ (%d x %d bp %s, fixed-width names), page cache warm; index from NextGenMap cache files"
+                    % ("two" if paired else "one", n // 2 if paired else n, READ_LEN, "pairs" if paired else "reads"),
+           "make_input_s": t_make, "gpu_kernel_s": h["gpu"], "mapping_pass_s": h["pass"],
+           "gpu_busy_fraction_of_mapping_pass": (h["gpu"] / h["pass"]) if h["gpu"] and h["pass"] else None}
+    # the same program on what real input looks like (.fastq.gz: the serial reader) and with --bam, on a slice
+    ng = min(n, args.e2e_gz_reads) & ~1
+    if ng > 0:
+        try:
+            cnt = ng // len(files)
+            slices = []
+            for i, src in enumerate(files):
+                dst = os.path.join(workdir, "gz_%d.fq" % i)
+                with open(src, "rb") as fi, open(dst, "wb") as fo:
+                    fo.write(fi.read(cnt * rec))
+                slices.append(dst)
+            hb = run_hip(slices, os.path.join(workdir, "e2e.bam"), ["--bam"])
+            out["bam_output"] = {"reads": ng, "value": ng / hb["io"], "unit": "reads/s", "seconds": hb["io"], "bam_bytes": os.path.getsize(os.path.join(workdir, "e2e.bam"))}
+            t = time.perf_counter()
+            for dst in slices:
+                subprocess.run(["gzip", "-1", "-f", dst], check=True)
+            t_gz = time.perf_counter() - t
+            hz = run_hip([d + ".gz" for d in slices], os.path.join(workdir, "e2e_gz.sam"))
+            out["fastq_gz_input"] = {"reads": ng, "value": ng / hz["io"], "unit": "reads/s", "seconds": hz["io"], "gzip_1_of_the_input_s": t_gz,
+                                     "same_sam_as_plain_input": None}
+            for fn in [d + ".gz" for d in slices] + [os.path.join(workdir, "e2e.bam"), os.path.join(workdir, "e2e_gz.sam")]:
+                os.remove(fn)
+        except Exception as e:
+            out["variants_error"] = str(e)[:300]
     base = None
     if not args.no_cpu_baseline and RF.have_reference_binary() and affine:
-        ns = min(args.cpu_sample_reads, n) & ~1
-        s1, s2, o1 = os.path.join(workdir, "s_1.fq"), os.path.join(workdir, "s_2.fq"), os.path.join(workdir, "one_1.fq")
-        o2 = os.path.join(workdir, "one_2.fq")
-        for src, dst, cnt in ((f1, s1, ns // 2), (f2, s2, ns // 2), (f1, o1, 1), (f2, o2, 1)):
-            with open(src, "rb") as fi, open(dst, "wb") as fo:
-                fo.write(fi.read(cnt * rec))
         threads = min(cores, 64)
 
-        def run(q1, q2, outp):
-            c = [RF.NGM_CORE, "-r", fa, "-1", q1, "-2", q2, "-o", outp, "--affine", "-t", str(threads), "--no-progress", "-s", "0.5"]
-            t = time.perf_counter()
+        def slice_to(cnt_reads, tag):
+            cnt = cnt_reads // len(files)
+            dsts = []
+            for i, src in enumerate(files):
+                dst = os.path.join(workdir, "%s_%d.fq" % (tag, i))
+                with open(src, "rb") as fi, open(dst, "wb") as fo:
+                    fo.write(fi.read(cnt * rec))
+                dsts.append(dst)
+            return dsts
+
+        def run_ref(fs, outp, t):
+            c = [RF.NGM_CORE, "-r", fa] + inputs(fs) + ["-o", outp, "-t", str(t)] + common
+            t0_ = time.perf_counter()
             rr = subprocess.run(c, capture_output=True, text=True, cwd=workdir)
-            dt = time.perf_counter() - t
+            dt = time.perf_counter() - t0_
             if "Done" not in (rr.stdout + rr.stderr):
                 raise RuntimeError("reference run failed: " + (rr.stdout + rr.stderr)[-400:])
             return dt
+        t_load = run_ref(slice_to(2, "one"), os.path.join(workdir, "one.sam"), threads)
+        # the sample: what the reference maps in ~25 s on this host (a pilot of 20 000 reads gives the rate), at most --cpu-sample-reads
+        pilot = min(20000, n) & ~1
+        t_pilot = max(run_ref(slice_to(pilot, "pilot"), os.path.join(workdir, "pilot.sam"), threads) - t_load, 1e-3)
+        ns = int(min(args.cpu_sample_reads, n, max(pilot, 25.0 * pilot / t_pilot))) & ~1
         ref_sam = os.path.join(workdir, "ref.sam")
-        t_load = run(o1, o2, os.path.join(workdir, "one.sam"))
-        t_all = run(s1, s2, ref_sam)
+        t_all = run_ref(slice_to(ns, "s"), ref_sam, threads)
         t_map = max(t_all - t_load, 1e-3)
-        ours, theirs = _sam_body(sam), _sam_body(ref_sam)
-        same = sum(1 for k, v in theirs.items() if ours.get(k) == v)
-        diffs = [(theirs[k].decode()[:160], ours.get(k, b"").decode()[:160]) for k in theirs if ours.get(k) != theirs[k]][:2]
+        ours = _sam_body(sam)
+        same, diffs = _sam_diff(_sam_body(ref_sam), ours)
+        # ... and -t 1, the run whose output this library reproduces exactly (one CS thread: one running mean insert size)
+        n1 = min(args.cpu_t1_reads, ns) & ~1
+        t1_sam = os.path.join(workdir, "ref_t1.sam")
+        t_t1 = run_ref(slice_to(n1, "t1"), t1_sam, 1)
+        th1 = _sam_body(t1_sam)
+        same1, diffs1 = _sam_diff(th1, ours)
         base = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
                 "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d on the first %d reads of the end-to-end input vs the same genome (index loaded "
                           "from the same cache files): %.1f s total minus %.1f s index load/start-up measured with a 1-pair run" % (threads, ns, t_all, t_load),
-                "parity_vs_reference_sam": {"records_compared": len(theirs), "identical_lines": same, "first_differences": diffs,
-                                            "note": "whole SAM lines; the reference runs %d CS threads, each with its own running mean insert size "
-                                                    "(ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output, which is what ngm-hip reproduces" % threads}}
-    for fn in (sam, f1, f2):
+                "parity_vs_reference_sam": {"records_compared": ns, "identical_lines": same, "first_differences": diffs,
+                                            "note": "whole SAM lines, differing fields listed; the reference runs %d CS threads, each with its own running mean insert "
+                                                    "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads},
+                "parity_vs_reference_sam_t1": {"records_compared": len(th1), "identical_lines": same1, "first_differences": diffs1, "seconds": t_t1,
+                                               "note": "ngm-core --affine -t 1 on the first %d reads: the run ngm-hip reproduces" % n1}}
+    for fn in [sam] + files:
         try:
             os.remove(fn)
         except OSError:
@@ -290,6 +373,8 @@ def main():
     ap.add_argument("--sensitive", action="store_true", help="config #5: sensitivity 0.5 - 0.35 * 0.5 (what --sensitive does to an estimate of 0.5)")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end ngm-hip run (BASELINE config #3: 10 000 000)")
+    ap.add_argument("--e2e-gz-reads", type=int, default=2_000_000, help="reads of the .fastq.gz-input and --bam-output runs of ngm-hip (0: skip)")
+    ap.add_argument("--cpu-t1-reads", type=int, default=200_000, help="reads of the reference's -t 1 run (SAM cross-check)")
     ap.add_argument("--stub-mapper", action="store_true", help="CPU-only control-path run (tests)")
     args = ap.parse_args()
     global Q, C, READ_LEN
@@ -467,26 +552,36 @@ def main():
         ins = np.abs(hits["pos"][0::2].astype(np.int64) - hits["pos"][1::2].astype(np.int64)) + READ_LEN
         local.update(pairs_total=R // 2, pairs_broken=int(((hits["pair_flags"][0::2] & 2) != 0).sum()), insert_sum=int(ins[sel].sum()), insert_cnt=int(sel.sum()))
     stats = sharding.reduce_stats(local, device=dev)
+    # the collective saw every rank: the summed read count is R per rank
+    assert stats["reads"] == R * world, "stats all-reduce: %r reads, expected %d x %d" % (stats["reads"], R, world)
+    stats["ranks_seen"] = stats["reads"] // R
 
     if rank == 0:
         value = R * world * args.steps / elapsed
         score_cells = n_cand * READ_LEN * band
         align_cells = int(mapped.sum()) * READ_LEN * band
         b_cs = 20 * kmers + 4 * hits_voted + 16 * n_cand
-        achieved = b_cs / (kms[0] * 1e-3) / 1e9 if kms[0] > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel: NOT measured in this run -- taken from the committed PMC passes
+        n_aln = int(mapped.sum())
+        # the dominant kernel of THIS workload (largest GPU time per step) and its algorithmic bytes
+        kernels = {"candidate_search": (kms[0], b_cs, "cs_canon_kernel / cs_fast2_kernel (candidate search): 20 B/k-mer + 4 B/index hit + 16 B/candidate"),
+                   "sw_score": (kms[2], n_cand * (Q + Q + C + 4), "sw_*score*_kernel (BatchScore): B_score = q + (q + c) + 4 bytes per pair"),
+                   "sw_align": (kms[5] + kms[6], n_aln * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)), "sw_*align*_kernel + traceback (BatchAlign): B_align = q + (q + c) + 8 + 4 (2q + c + 1) bytes per pair")}
+        dom = max(kernels, key=lambda k_: kernels[k_][0])
+        dom_ms, dom_bytes, dom_note = kernels[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch of the candidate search: NOT measured in this run -- taken from the committed PMC passes
         # (profiles/*_pmc_traffic.json, keyed by kernel name and grid size; collected with this default workload)
         traffic = traffic_source = None
-        if int(args.genome_mbp) == 3100 and READ_LEN == 150 and not stub:
+        if dom == "candidate_search" and int(args.genome_mbp) == 3100 and READ_LEN == 150 and not stub:
             for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
                 if fn.endswith("_pmc_traffic.json"):
                     try:
                         tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     except Exception:
                         continue
-                    for k, v in tj.items():  # grid = 64 threads per wave x 2-4 waves per read
-                        if k.startswith("ngm::cs_fast2_kernel") and any(k.endswith("|grid=%d" % ((bounds[1] - bounds[0]) * 64 * t)) for t in (2, 3, 4)):
-                            traffic, traffic_source = v, "profiles/" + fn
+                    for k, v in tj.items():
+                        if k.startswith("ngm::cs_canon_kernel") or (traffic is None and k.startswith("ngm::cs_fast2_kernel") and fn.startswith("r02")):
+                            traffic, traffic_source = v, "profiles/" + fn + " [" + k + "]"
                     if traffic is not None:
                         break
         line = {
@@ -511,15 +606,17 @@ def main():
             "accuracy_rank0_shard": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
             "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries if ref else 0},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": "cs_fast2_kernel (candidate search)",
-                         "isolated": {"achieved": (20 * iso_ctr[0] + 4 * iso_ctr[1] + 16 * iso_ctr[2]) / (iso_ms[0] * 1e-3) / 1e9 if iso_ms[0] > 0 else 0.0, "ms": float(iso_ms[0]),
-                                      "reads": int(bounds[1] - bounds[0]),
-                                      "note": "same kernel, one launch of one mapper instance with nothing else on the GPU (untimed extra pass)"}, "bytes_per_launch": b_cs / W, "launches_per_step": W,
-                         "note": "algorithmic bytes = 20 B/k-mer + 4 B/index hit + 16 B/candidate (SURVEY.md 8d); lists gathered from the bucketed "
-                                 "index (8-byte header + 32-byte segments); random gathers on MI355X are bound by ~50 G requests/s "
-                                 "(profiles/r02_gather_calibration.txt); the kernel is bound by per-read latency x reads in flight (DESIGN.md 4); "
-                                 "`traffic` = FETCH_SIZE x 1 (calibrated for <= 64-byte gathers) + WRITE_SIZE from the committed rocprofv3 PMC pass "
-                                 "named in traffic_source -- it is not measured in this run; the SW kernels are VALU-bound, see sw_gcells_per_s"},
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "kernel_note": dom_note, "kernel_ms_per_step": float(dom_ms),
+                         "candidate_search": {"achieved": b_cs / (kms[0] * 1e-3) / 1e9 if kms[0] > 0 else 0.0, "frac": (b_cs / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if kms[0] > 0 else 0.0,
+                                              "bytes_per_launch": b_cs / W, "launches_per_step": W, "ms_per_launch": float(kms[0] / W),
+                                              "isolated": {"achieved": (20 * iso_ctr[0] + 4 * iso_ctr[1] + 16 * iso_ctr[2]) / (iso_ms[0] * 1e-3) / 1e9 if iso_ms[0] > 0 else 0.0, "ms": float(iso_ms[0]),
+                                                           "reads": int(bounds[1] - bounds[0]),
+                                                           "note": "one launch of one mapper instance with nothing else on the GPU (untimed extra pass)"}},
+                         "note": "`kernel` = the kernel with the largest GPU time per step of this workload; achieved = its algorithmic bytes (SURVEY.md 8d) / its "
+                                 "HIP-event time on the launch stream.  Candidate search gathers from the canonical pair buckets (one 128-byte line per k-mer pair + "
+                                 "16-byte chunks beyond 31 positions); random gathers on MI355X are bound by ~50 G requests/s "
+                                 "(profiles/r02_gather_calibration.txt).  `traffic` = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC pass "
+                                 "named in traffic_source -- not measured in this run.  The SW kernels are VALU-bound, see sw_gcells_per_s"},
             # SURVEY.md 8d's whole-path figure: (pairs * B_score + alignments * B_align + B_cs) per second of wall time
             "path_algorithmic_gbs": (n_cand * (Q + Q + C + 4) + int(mapped.sum()) * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)) + b_cs) * world
                                     / (elapsed / args.steps) / 1e9,
@@ -530,23 +627,19 @@ def main():
             line["end_to_end"] = None
         else:
             e2e_base = None
-            if not args.no_end_to_end and paired and READ_LEN == 150:
+            if not args.no_end_to_end:
                 try:
-                    line["end_to_end"], e2e_base = end_to_end(ref, contigs, workdir, args, paired, affine)
+                    line["end_to_end"], e2e_base = end_to_end(ref, contigs, workdir, args, paired, affine, sens)
                 except Exception as e:
                     line["end_to_end"] = {"error": str(e)[:400]}
             if e2e_base is not None:
                 line["cpu_baseline"] = e2e_base
             elif not args.no_cpu_baseline:
-                try:
-                    import ref_files as RF
-                    if not RF.have_reference_binary():
-                        raise RuntimeError("oracle/_ref/ngm/ngm-core not built")
-                    ours = (hits, out[1], [c[0] for c in ref.contigs]) if affine else None
-                    line["cpu_baseline"] = cpu_baseline_reference(ref, rows, min(args.cpu_sample_reads, 200000), workdir, ours, paired)
-                except Exception as e:  # the port of the score stage only
-                    line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
-                    line["cpu_baseline"]["note"] = "reference program unavailable: %s" % str(e)[:200]
+                # no reference program (not built, or the linear personality, which needs an OpenCL CPU device it does not have here):
+                # the oracle's C restatement of the score stage only
+                line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
+                line["cpu_baseline"]["note"] = ("reference program not run: " + ("ngm-core only runs --affine on this host" if not affine else
+                                                "oracle/_ref/ngm/ngm-core not built or --no-end-to-end given"))
         print(json.dumps(line))
     for m_ in mps:
         m_.close()

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 		}
 		const int len_v = (int) read_len[a_read[j]];
 		o.qend = len_v - (pattern_chars + o.qstart);
-		if (o.qend > 0) { co += dev_put_num(cg + co, o.qend); cg[co++] = 'S'; }
+		if (co > lim) fits = false;
+		if (fits && o.qend > 0) { co += dev_put_num(cg + co, o.qend); cg[co++] = 'S'; }
 		o.identity = (float) rec[3] * 1.0f / (float) total;
 		o.nm = rec[7];
 		o.score_token = 0.f;
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 					mismatch += len;
 				}
 			}
+			if (co > lim || mo > lim) fits = false;  // the last run may have used the head room the tail below needs: host fall-back
 			if (fits) {
 				mo += dev_put_num(mdp + mo, md_eq);
 				if (m_len > 0) { co += dev_put_num(cg + co, m_len); cg[co++] = 'M'; }

@@ -27,6 +27,7 @@
 #include "cigar_md.h"
 #include "cigar_device.h"
 #include "cs_device.h"
+#include "cs_canon_device.h"
 #include "gather_device.h"
 #include "thread_pool.h"
 
@@ -62,12 +63,16 @@ struct ngm_mapper {
 	int cs_log2_slots = 14;   // large LDS vote table: 2^14 slots * 8 B = 128 KB (2^13 when the lists of very long reads need the room)
 	int cs_log2_small = 10;   // fast path: small exact table ...
 	uint32_t cs_plane_bits = 65536;
+	uint32_t cs_plane_bits0 = 65536;  // ... before it was trimmed to the LDS granule
 	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
 	uint32_t cs_queued_exact = 0;
 	int cs_fast_items = ngm::kCsFastItemsShort;
 	size_t cs_region_cap = 0; // candidate slots of all output regions together (grows when a batch overflows)
 	double cs_hexp = 4096;    // expected index hits per read
 	int cs_waves = 3;         // waves per read of the fast path (cs_fast2_kernel; 1: cs_fast_kernel, NGM_HIP_CS_WAVES)
+	int cs_canon_wpe = 7;      // 72 VGPRs: with 64 the sweeps spill (scratch round trips inside the vote loop cost more than the tenth read per CU brings)
+	int cs_canon_ch = 1;      // canonical path, shape 2: chunk loads issued after this vote step (NGM_HIP_CS_CANON_CH: 0, 1, 3)
+	int cs_canon = 0;         // 0: fast path over one bucket per k-mer (cs_fast2_kernel); 1-3: over canonical pair buckets, cs_canon_kernel<3,4,2> / <3,6,2> / <4,8,4>
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	uint64_t scores_so_far = 0, reads_so_far = 0;  // see ngm_pair_state
 	int ref_cs_batch = 0;             // reads per CS batch of the reference (1 800 000 / average read length, CS.cpp:26, :542): its score buffer is flushed there
@@ -125,6 +130,24 @@ struct DevGuard {
 	~DevGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
 };
 
+// canonical fast path: waves per read and chunk-item rounds of the kernel shapes (cs_canon_device.h)
+constexpr int kCanonT[4] = {0, 3, 3, 4}, kCanonR1[4] = {0, 4, 6, 8}, kCanonR2[4] = {0, 2, 2, 4};
+constexpr int kCsCanonMode = 3;
+size_t cs_canon_lds_bytes(const ngm::CsArgs &A, int shape) {  // k-mer info + headers, codes, chunk items (16-bit), plane, table, queue (+ the kernel's static variables)
+	const size_t w = (size_t) A.lists_cap + (A.q + 3) / 4 + (size_t) kCanonR2[shape] * kCanonT[shape] * 64 / 2 + ((size_t) A.plane_bits >> 5) + ((size_t) 2 << A.log2_slots) +
+			((size_t) 3 << A.log2_slots) / 4 + 64;
+	return w * 4;
+}
+
+// shape 1-3; shape 2 exists in variants (experiments: NGM_HIP_CS_CANON_CH = the vote step after which the chunk loads are issued,
+// NGM_HIP_CS_CANON_WPE = waves per SIMD the register allocation aims at)
+const void *cs_canon_fn(int shape, int ch, int wpe) {
+	if (shape == 1) return (const void *) ngm::cs_canon_kernel<3, 4, 2, 1>;
+	if (shape == 3) return (const void *) ngm::cs_canon_kernel<4, 8, 4, 1>;
+	if (wpe <= 7) return ch == 0 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 0, 7> : (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 7>;
+	return ch == 0 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 0> : ch >= 3 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 3> : (const void *) ngm::cs_canon_kernel<3, 6, 2, 1>;
+}
+
 size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
 	if (mode == ngm::kCsFast)  // list starts (32-bit) + lengths (16-bit), codes, plane, items, table, queue
@@ -181,7 +204,22 @@ int run_cs(ngm_mapper *m, int n) {
 		// 16-bit work items when every list index fits 9 bits and no used list can have more than 128 segments
 		A.items16 = (A.lists_cap <= 512 && m->max_kfreq <= 128 * ngm::kCsSeg) ? 1 : 0;
 		if (!A.items16) A.fast_items = ngm::kCsFastItemsLong;  // the 32-bit item list only exists in the large size
-		if (m->cs_waves >= 2 && A.items16) {  // T waves per read: the same 768 / 1 536 segments, dealt to T * 64 lanes
+		if (m->cs_canon) {
+			A.buckets = r->d_cbuckets; A.bucket_log2_words = r->cbucket_log2_words; A.pos_base = r->cbucket_pos_base;
+			const size_t lds = cs_canon_lds_bytes(A, m->cs_canon) - 256;  // the kernel's static variables take the rest
+			// persistent workgroups: as many as the GPU holds at once, each walking the reads with that stride
+			const void *fn = cs_canon_fn(m->cs_canon, m->cs_canon_ch, m->cs_canon_wpe);
+			int per_cu = 0, cus = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kCanonT[m->cs_canon] * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+			if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
+			int grid = std::min(n, per_cu * cus);
+			if (const char *e = getenv("NGM_HIP_CS_GRID_PER_CU")) grid = std::min(n, std::max(1, atoi(e)) * cus);  // experiments
+			void *kargs[] = {(void *) &A};
+			(void) hipLaunchKernel(fn, dim3(grid), dim3(kCanonT[m->cs_canon] * 64), kargs, lds, m->st);
+			if (A.phase_cycles)
+				fprintf(stderr, "[ngm-hip] cs canonical path (shape %d): %zu bytes of LDS per read, %d reads resident per CU (grid %d), bucket 2^%d words\n", m->cs_canon, lds, per_cu, grid, A.bucket_log2_words);
+		}
+		else if (m->cs_waves >= 2 && A.items16) {  // T waves per read: the same 768 / 1 536 segments, dealt to T * 64 lanes
 			const bool shrt = A.fast_items == ngm::kCsFastItemsShort;
 			const size_t lds = cs_lds_bytes(A, ngm::kCsFast) - 128;  // the kernel's static variables take the rest
 #define NGM_CS_LAUNCH_T(T) \
@@ -431,6 +469,8 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		const double segs = hexp / 8.0 + 0.44 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
 		m->cs_fast_items = segs * 1.10 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
 		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
+		const uint32_t plane_untrimmed = m->cs_plane_bits;
+		m->cs_plane_bits0 = plane_untrimmed;
 		// The kernel is bound by reads in flight per CU, and those by LDS, which gfx950 hands out in granules of
 		// 1 280 bytes (160 KB / 128: hipOccupancyMaxActiveBlocksPerMultiprocessor reports 9 workgroups of 16 328 bytes per CU and 10
 		// of 15 360).  The plane is sized generously (12 bits per expected hit): when giving up at most a fifth of it (never below
@@ -452,6 +492,37 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 			}
 		}
 	}
+	// which index layout the fast path gathers from: canonical pair buckets (odd k, up to 256 k-mers per read, k-mer pairs in
+	// use shorter than 1 000 hits: the chunk items are 16-bit) unless NGM_HIP_CS_PLAIN_BUCKETS asks for one bucket per k-mer
+	{
+		const int n_kmers = std::max(1, p->qry_max_len - ref->prm.kmer + 1);
+		const bool canon_ok = (ref->prm.kmer & 1) && n_kmers <= 256 && m->max_kfreq <= 1000 && !getenv("NGM_HIP_CS_PLAIN_BUCKETS");
+		if (ngm_ref_ensure_buckets(ref, canon_ok ? 1 : 0) != 0) { ngm_mapper_destroy(m); return nullptr; }
+		if (canon_ok) {
+			const int glog = std::min(ref->cbucket_log2_words, 5) - 2;
+			int shape = 1;
+			while (shape < 3 && (n_kmers > kCanonT[shape] * 64 || n_kmers > kCanonR1[shape] * ((kCanonT[shape] * 64) >> glog))) ++shape;
+			if (const char *e = getenv("NGM_HIP_CS_CANON_SHAPE")) shape = std::max(shape, std::min(3, atoi(e)));  // tests: a larger shape than needed
+			m->cs_canon = shape;
+			if (const char *e = getenv("NGM_HIP_CS_CANON_CH")) m->cs_canon_ch = atoi(e);
+			if (const char *e = getenv("NGM_HIP_CS_CANON_WPE")) m->cs_canon_wpe = atoi(e);
+			m->cs_plane_bits = m->cs_plane_bits0;
+			// one more read per CU where trimming the plane a little allows it (see above; the canonical kernel keeps less per read in LDS)
+			ngm::CsArgs G{};
+			G.lists_cap = 2 * n_kmers; G.q = p->qry_max_len; G.log2_slots = m->cs_log2_small; G.plane_bits = m->cs_plane_bits;
+			const size_t granule = 1280, lds = 160 * 1024;
+			const size_t have = cs_canon_lds_bytes(G, shape);
+			const size_t per_cu = lds / std::max<size_t>((have + granule - 1) / granule * granule, 1);
+			const size_t wave_limit = (size_t) (shape == 2 ? m->cs_canon_wpe * 4 : 32) / kCanonT[shape];
+			if (per_cu >= 1 && per_cu < wave_limit) {
+				const size_t target = lds / (per_cu + 1) / granule * granule;
+				if (have > target) {
+					const uint32_t cut_bits = (uint32_t) (((have - target) * 8 + 31) / 32 * 32);
+					if (cut_bits <= m->cs_plane_bits / 5 && (double) (m->cs_plane_bits - cut_bits) >= 10.0 * m->cs_hexp) m->cs_plane_bits -= cut_bits;
+				}
+			}
+		}
+	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
 	A.log2_slots = m->cs_log2_slots;
 	if (cs_lds_bytes(A, ngm::kCsExactLds) > 158 * 1024) { m->cs_log2_slots = 13; A.log2_slots = 13; } A.log2_bits = 17; A.plane_bits = 131072;
@@ -467,6 +538,8 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast))
 	NGM_CS_ATTR_T(2); NGM_CS_ATTR_T(3); NGM_CS_ATTR_T(4);
 #undef NGM_CS_ATTR_T
+	for (int shape = 1; shape <= 3; ++shape) for (int ch : {0, 1, 3}) for (int wpe : {7, 8})
+		(void) hipFuncSetAttribute(cs_canon_fn(shape, ch, wpe), hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_canon_lds_bytes(A, shape));
 	// three waves per read for the 768-segment size (150 bp reads), four for the 1 536-segment one (250 bp: 12.3 instead of 14.7 ms
 	// per 524 288 reads -- with twice the work items per read the fourth wave pays for the seventh-of-a-CU it costs)
 	m->cs_waves = m->cs_fast_items == ngm::kCsFastItemsLong ? 4 : 3;
@@ -729,11 +802,10 @@ static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_coun
 }
 
 static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired) {
-	if (!m || n < 0) return -22;
-	if (paired && m->prm.topn > 1) { ngm::pipeline_set_error("Paired end mode with topn > 1 not yet supported."); return -38; }  // ScoreBuffer::topNPE
-	if (paired && (n & 1)) { ngm::pipeline_set_error("paired-end batches need an even number of reads"); return -22; }
+	if (!m) return -22;
 	// shared paired-end state: wait for this batch's turn before the running mean is read, pass it on when the batch is
-	// done with it (also on every early return)
+	// done with it (also on EVERY early return, the argument checks below included: with a shared ngm_pair_state a batch that
+	// never passes its turn on would block all later ones)
 	struct PairTurn {
 		ngm_mapper *m; bool active, held = false;
 		void acquire() {
@@ -753,6 +825,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		bool released = false;
 		~PairTurn() { release(); }
 	} pair_turn{m, paired && m->ps != nullptr};
+	if (n < 0) return -22;
+	if (paired && m->prm.topn > 1) { ngm::pipeline_set_error("Paired end mode with topn > 1 not yet supported."); return -38; }  // ScoreBuffer::topNPE
+	if (paired && (n & 1)) { ngm::pipeline_set_error("paired-end batches need an even number of reads"); return -22; }
 	if (n == 0) return 0;
 	const ngm_ref *r = m->ref;
 	DevGuard g(r->device);

@@ -254,21 +254,22 @@ void pack_row(const Read &r, int q, char *row) { pack_row_view(r.seq.data(), r.s
 // a whole file mapped read-only; plain() = not gzip and made of 4-line FASTQ records (checked on the first records)
 struct MappedFile {
 	const char *p = nullptr;
-	size_t n = 0;
+	size_t n = 0, map_len = 0;   // n: the bytes that hold records (white space at the end of the file is not a record: kseq skips it too)
 	int fd = -1;
 	bool open(const char *path) {
 		fd = ::open(path, O_RDONLY);
 		if (fd < 0) return false;
 		struct stat st;
 		if (fstat(fd, &st) != 0 || st.st_size == 0) return false;
-		n = (size_t) st.st_size;
-		void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+		n = map_len = (size_t) st.st_size;
+		void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
 		if (m == MAP_FAILED) { p = nullptr; return false; }
 		p = (const char *) m;
-		madvise(m, n, MADV_SEQUENTIAL);
-		return true;
+		madvise(m, map_len, MADV_SEQUENTIAL);
+		while (n > 0 && (p[n - 1] == '\n' || p[n - 1] == '\r' || p[n - 1] == ' ' || p[n - 1] == '\t')) --n;
+		return n > 0;
 	}
-	~MappedFile() { if (p) munmap((void *) p, n); if (fd >= 0) close(fd); }
+	~MappedFile() { if (p) munmap((void *) p, map_len); if (fd >= 0) close(fd); }
 	// touch every page from the pool threads: the page-table entries of a multi-GB input are then set up in parallel instead
 	// of one minor fault at a time under the (single) splitter thread
 	void prefault() const {
@@ -431,6 +432,7 @@ int main(int argc, char **argv) {
 	mallopt(M_MMAP_THRESHOLD, 32 << 20);
 	mallopt(M_TRIM_THRESHOLD, 1 << 30);
 	mallopt(M_TOP_PAD, 64 << 20);
+	const auto t_process = std::chrono::steady_clock::now();
 	Opts o = parse(argc, argv);
 	ngm_ref_params rp{o.kmer, o.kmer_skip, o.bin_size};
 	info("MAIN", "NextGenMap-compatible HIP backend (gfx950)");
@@ -453,6 +455,12 @@ int main(int argc, char **argv) {
 	}
 	info("PREPROCESS", "index entries: " + std::to_string(ngm_ref_index_entries(ref)) + ", max. k-mer frequency " +
 			std::to_string(o.max_kfreq > 0 ? o.max_kfreq : ngm_ref_auto_max_kfreq(ref)));
+	{
+		char tmsg[160];
+		snprintf(tmsg, sizeof(tmsg), "Reference and index ready: %.3f s (%s)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_process).count(),
+				had_cache ? "loaded from the cache files" : "built");
+		info("PREPROCESS", tmsg);
+	}
 	const std::string first_input = o.qry1.empty() ? o.qry : o.qry1;  // parser1: what the estimation pass reads (ReadProvider.cpp:201)
 	if (first_input.empty()) { ngm_ref_destroy(ref); return 0; }  // index only, like `ngm -r ref.fa`
 	if (o.out.empty()) die("no output file given (-o/--output)");
@@ -474,17 +482,25 @@ int main(int argc, char **argv) {
 			return false;
 		};
 		MappedFile pf;
-		if (!o.serial_reader && pf.open(first_input.c_str()) && pf.plain_fastq()) {
+		bool plain_ok = !o.serial_reader && pf.open(first_input.c_str()) && pf.plain_fastq();
+		if (plain_ok) {
 			pf.prefault();
 			Rec rec;
 			for (size_t at = 0; !finish && at < pf.n;) {
 				const size_t nx = pf.record(at, rec);
-				if (!nx) die("malformed FASTQ record at byte " + std::to_string(at) + " of " + first_input + " (--serial-reader reads multi-line input)");
+				if (!nx) {
+					// not a strict 4-line record (multi-line sequences, stray blank lines): kseq reads those, so does the serial reader
+					info("INPUT", "Record at byte " + std::to_string(at) + " of " + first_input + " is not a 4-line FASTQ record: using the serial reader");
+					plain_ok = false; o.serial_reader = 1;
+					max_len = 0; min_len = 9999999; sum_len = 0; count = 0; finish = false; sample.clear();
+					break;
+				}
 				if (rec.qual_len != rec.seq_len) die("Error while parsing read: sequence and quality lengths differ (" + std::string(rec.name, rec.name_len) + ")");
 				at = nx;
 				if (account(rec.seq_len)) sample.push_back(Read{std::string(rec.name, rec.name_len), std::string(rec.seq, rec.seq_len), std::string()});
 			}
-		} else {
+		}
+		if (!plain_ok) {
 			SeqReader in(first_input.c_str());
 			if (!in.ok()) die("cannot open " + first_input);
 			Read r;

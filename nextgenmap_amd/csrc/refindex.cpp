@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string.h>
 
 #include "refindex.h"
@@ -217,7 +219,11 @@ int gpu_kmer_walk(ngm_ref *r, uint32_t **d_keys_out, uint32_t **d_vals_out, uint
 	uint8_t *d_flag = nullptr;
 	uint64_t *d_count = nullptr;
 	void *d_tmp = nullptr;
-	auto cleanup = [&]() { (void) hipFree(d_cs); (void) hipFree(d_ce); (void) hipFree(d_run); (void) hipFree(d_flag); (void) hipFree(d_count); (void) hipFree(d_tmp); };
+	auto cleanup = [&]() { (void) hipFree(d_cs); (void) hipFree(d_ce); (void) hipFree(d_run); (void) hipFree(d_flag); (void) hipFree(d_count); (void) hipFree(d_tmp);
+		d_cs = d_ce = nullptr; d_run = nullptr; d_flag = nullptr; d_count = nullptr; d_tmp = nullptr; };
+	// every error return below frees what the walk holds (up to ~12 GB of scratch for a human-size genome)
+	bool done = false;
+	struct Guard { std::function<void()> f; bool *done; ~Guard() { if (!*done) f(); } } guard{[&]() { cleanup(); (void) hipFree(d_pos); (void) hipFree(d_keys); (void) hipFree(d_keys2); (void) hipFree(d_pos2); }, &done};
 	REF_HIP_TRY(hipMalloc(&d_cs, std::max(1, nc) * 8)); REF_HIP_TRY(hipMalloc(&d_ce, std::max(1, nc) * 8));
 	REF_HIP_TRY(hipMemcpy(d_cs, hs.data(), nc * 8, hipMemcpyHostToDevice)); REF_HIP_TRY(hipMemcpy(d_ce, he.data(), nc * 8, hipMemcpyHostToDevice));
 	REF_HIP_TRY(hipMalloc(&d_run, std::max<uint64_t>(n, 1) * 4)); REF_HIP_TRY(hipMalloc(&d_flag, std::max<uint64_t>(n, 1))); REF_HIP_TRY(hipMalloc(&d_count, 8));
@@ -240,7 +246,7 @@ int gpu_kmer_walk(ngm_ref *r, uint32_t **d_keys_out, uint32_t **d_vals_out, uint
 	REF_HIP_TRY(rocprim::select(d_tmp, tb, rocprim::counting_iterator<uint32_t>(0), d_flag, d_pos, d_count, (size_t) n));
 	uint64_t m = 0;
 	REF_HIP_TRY(hipMemcpy(&m, d_count, 8, hipMemcpyDeviceToHost));
-	if (m > cap) { cleanup(); (void) hipFree(d_pos); ngm::pipeline_set_error("k-mer walk: more visited k-mers than expected"); return -75; }
+	if (m > cap) { ngm::pipeline_set_error("k-mer walk: more visited k-mers than expected"); return -75; }
 	(void) hipFree(d_run); d_run = nullptr;
 	REF_HIP_TRY(hipMalloc(&d_keys, std::max<uint64_t>(m, 1) * 4)); REF_HIP_TRY(hipMalloc(&d_keys2, std::max<uint64_t>(m, 1) * 4)); REF_HIP_TRY(hipMalloc(&d_pos2, std::max<uint64_t>(m, 1) * 4));
 	uint64_t kept = 0;
@@ -255,6 +261,7 @@ int gpu_kmer_walk(ngm_ref *r, uint32_t **d_keys_out, uint32_t **d_vals_out, uint
 	}
 	cleanup();
 	(void) hipFree(d_pos); (void) hipFree(d_keys);
+	done = true;
 	*d_keys_out = d_keys2; *d_vals_out = d_pos2; *n_out = kept;
 	return 0;
 }
@@ -278,9 +285,51 @@ __global__ void fill_buckets_kernel(uint32_t n_kmers, int k, int log2_w, const u
 	buckets[g] = v;
 }
 
-int build_buckets(ngm_ref *r) {
+// canonical bucket c (refindex.h): the pair {X = kmer_of_canon_id(c), revcomp(X)}
+__global__ void fill_cbuckets_kernel(uint32_t n_pairs, int k, int log2_w, const uint2 *__restrict__ index, const uint32_t *__restrict__ positions,
+		uint32_t *__restrict__ buckets) {
+	const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t c = (uint32_t) (g >> log2_w), w = (uint32_t) g & ((1u << log2_w) - 1u);
+	if (c >= n_pairs) return;
+	const int b = 2 * (k / 2) + 1;
+	const uint32_t x = ((c >> b) << (b + 1)) | (c & ((1u << b) - 1u));
+	const uint2 ea = index[x], eb = index[d_revcomp(x, k)];
+	const uint32_t na = ea.y, nb = eb.y;
+	const bool inl = na + nb < (1u << log2_w);
+	uint32_t v = 0;
+	if (w == 0) v = na | (nb << 14) | (inl ? 0u : 0x80000000u);
+	else if (inl) v = (w <= na) ? positions[ea.x + (w - 1)] : (w <= na + nb) ? positions[eb.x + (w - 1 - na)] : 0u;
+	else if (w == 1) v = ea.x;
+	else if (w == 2) v = eb.x;
+	buckets[g] = v;
+}
+
+std::mutex g_bucket_mu;
+
+int build_buckets_kind(ngm_ref *r, int kind) {
 	const int k = r->prm.kmer;
 	const uint32_t n_kmers = 1u << (2 * k);
+	if (kind == 1) {
+		if (r->d_cbuckets) return 0;
+		if ((k & 1) == 0) { ngm::pipeline_set_error("canonical buckets need an odd k-mer length"); return -22; }
+		const uint32_t n_pairs = n_kmers / 2;
+		const double mu = (double) r->n_entries / (double) n_pairs;
+		int lw = 2;
+		while (lw < 6 && (double) ((1 << lw) - 1) < mu + 4.0 * sqrt(mu) + 0.5) ++lw;
+		if (const char *e = getenv("NGM_HIP_CBUCKET_LOG2_WORDS")) lw = std::max(2, std::min(6, atoi(e)));  // tests
+		while (lw > 2 && ((uint64_t) n_pairs << lw) + r->n_entries + 16 >= 0xFFFFFFFFull) --lw;
+		const uint64_t words = (uint64_t) n_pairs << lw;
+		uint32_t *d = nullptr;
+		REF_HIP_TRY(hipMalloc(&d, (words + r->n_entries + 16) * 4));
+		hipLaunchKernelGGL(fill_cbuckets_kernel, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, 0, n_pairs, k, lw, r->d_index, r->d_positions, d);
+		if (hipGetLastError() != hipSuccess || hipMemcpy(d + words, r->d_positions, (r->n_entries + 16) * 4, hipMemcpyDeviceToDevice) != hipSuccess ||
+				hipDeviceSynchronize() != hipSuccess) { (void) hipFree(d); ngm::pipeline_set_error("building the canonical buckets failed"); return -5; }
+		r->cbucket_log2_words = lw;
+		r->cbucket_pos_base = (uint32_t) words;
+		r->d_cbuckets = d;
+		return 0;
+	}
+	if (r->d_buckets) return 0;
 	// W - 1 >= mean + 4 standard deviations of a Poisson list length (real genomes have a heavy tail on top: those
 	// lists overflow into d_positions, which costs them one more request)
 	const double mu = (double) r->n_entries / (double) n_kmers;
@@ -290,15 +339,22 @@ int build_buckets(ngm_ref *r) {
 	// the buckets are followed by a copy of the position table, so that one 32-bit word offset addresses an inline list and a
 	// list that did not fit alike; both must stay below 2^32 words
 	while (lw > 2 && (((uint64_t) n_kmers + 1) << lw) + r->n_entries + 16 >= 0xFFFFFFFFull) --lw;
-	r->bucket_log2_words = lw;
 	const uint64_t words = ((uint64_t) n_kmers + 1) << lw;
+	uint32_t *d = nullptr;
+	REF_HIP_TRY(hipMalloc(&d, (words + r->n_entries + 16) * 4));
+	hipLaunchKernelGGL(fill_buckets_kernel, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, 0, n_kmers, k, lw, r->d_index, r->d_positions, d);
+	if (hipGetLastError() != hipSuccess || hipMemcpy(d + words, r->d_positions, (r->n_entries + 16) * 4, hipMemcpyDeviceToDevice) != hipSuccess ||
+			hipDeviceSynchronize() != hipSuccess) { (void) hipFree(d); ngm::pipeline_set_error("building the buckets failed"); return -5; }
+	r->bucket_log2_words = lw;
 	r->bucket_pos_base = (uint32_t) words;
-	REF_HIP_TRY(hipMalloc(&r->d_buckets, (words + r->n_entries + 16) * 4));
-	hipLaunchKernelGGL(fill_buckets_kernel, dim3((unsigned) ((words + 255) / 256)), dim3(256), 0, 0, n_kmers, k, lw, r->d_index, r->d_positions, r->d_buckets);
-	REF_HIP_TRY(hipGetLastError());
-	REF_HIP_TRY(hipMemcpy(r->d_buckets + words, r->d_positions, (r->n_entries + 16) * 4, hipMemcpyDeviceToDevice));
-	REF_HIP_TRY(hipDeviceSynchronize());
+	r->d_buckets = d;
 	return 0;
+}
+
+// the layout the default search kernel reads: canonical pairs for odd k (NextGenMap's default 13), one bucket per k-mer otherwise
+int build_buckets(ngm_ref *r) {
+	const bool canon = (r->prm.kmer & 1) && !getenv("NGM_HIP_CS_PLAIN_BUCKETS");
+	return build_buckets_kind(r, canon ? 1 : 0);
 }
 
 int build_index(ngm_ref *r) {
@@ -309,8 +365,9 @@ int build_index(ngm_ref *r) {
 	if (!getenv("NGM_HIP_HOST_KMER_WALK")) {
 		// the walk on the GPU (CountKmerFreq decodes a contig with bufferLength = len and DecodeRefSequence emits len - 2 bases,
 		// 'x' / NUL after that, which encode() maps to 0: the last two bases of a contig act as 'A' -- handled in the kernels)
-		if (int rc = gpu_kmer_walk(r, &d_keys, &d_vals, &n)) return rc;
-	} else {
+		if (gpu_kmer_walk(r, &d_keys, &d_vals, &n) != 0) { d_keys = d_vals = nullptr; n = 0; (void) hipGetLastError(); }  // e.g. out of memory on a shared GPU: the host walk needs no scratch
+	}
+	if (!d_keys) {
 		std::vector<uint32_t> keys, vals;
 		keys.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
 		vals.reserve(r->n_bases / (r->prm.kmer_skip + 1) + 16);
@@ -630,8 +687,23 @@ void ngm_ref_destroy(ngm_ref *r) {
 	if (r->d_raw_counts) (void) hipFree(r->d_raw_counts);
 	if (r->d_positions) (void) hipFree(r->d_positions);
 	if (r->d_buckets) (void) hipFree(r->d_buckets);
+	if (r->d_cbuckets) (void) hipFree(r->d_cbuckets);
 	delete r;
 }
+
+}  // extern "C"
+
+int ngm_ref_ensure_buckets(const ngm_ref *r, int kind) {
+	std::lock_guard<std::mutex> lk(g_bucket_mu);
+	int prev = -1;
+	(void) hipGetDevice(&prev);
+	(void) hipSetDevice(r->device);
+	const int rc = build_buckets_kind(const_cast<ngm_ref *>(r), kind);
+	if (prev >= 0 && prev != r->device) (void) hipSetDevice(prev);
+	return rc;
+}
+
+extern "C" {
 
 int ngm_ref_contig_count(const ngm_ref *r) { return (int) r->contigs.size(); }
 const char *ngm_ref_contig_name(const ngm_ref *r, int i) { return r->contigs[i].name.c_str(); }

@@ -54,13 +54,33 @@ struct ngm_ref {
 	int bucket_log2_words = 2;        // W = 1 << bucket_log2_words dwords per k-mer bucket
 	uint32_t bucket_pos_base = 0;     // word offset of the position table copy that follows the buckets in d_buckets
 	double overflow_hit_share = 0.0;  // share of all index entries that live in lists longer than W-1
+	// canonical buckets (round 3, odd k): ONE bucket per {k-mer, reverse complement} pair -- the search always needs both lists
+	// (CS.cpp:116-160), so they live side by side: word 0 = length of the canonical k-mer's list | the other one's << 14 | 1 << 31
+	// when the two do not fit, words 1.. = the canonical k-mer's positions followed by its reverse complement's (a pair that does
+	// not fit keeps the two list starts in the position table in words 1 and 2).  The canonical one of a pair is the k-mer whose
+	// MIDDLE base is A or C (bit 1 of its 2-bit code clear: complementing flips exactly that bit, and the middle base of an odd
+	// k-mer stays in the middle), its bucket number the k-mer with that bit removed: a bijection onto [0, 4^k / 2), no table.
+	// W = 4..64 dwords from the mean length of both lists (GRCh38 size: 30.8 -> 64 dwords = two 128-byte lines, the second one
+	// only read for the ~45 % of the pairs with more than 31 positions).  Same allocation scheme: a copy of the position table
+	// follows the buckets.
+	uint32_t *d_cbuckets = nullptr;
+	int cbucket_log2_words = 2;
+	uint32_t cbucket_pos_base = 0;
 };
+
+// builds the bucket layout `kind` (0: one bucket per k-mer, 1: canonical pairs; odd k only) if it does not exist yet; 0 or -errno
+int ngm_ref_ensure_buckets(const ngm_ref *r, int kind);
 
 namespace ngm {
 void pipeline_set_error(const char *fmt, ...);
 // k-mer integer as the reference builds it: 2 bits per base, A0 C1 T2 G3 ((c >> 1) & 3, CSstatic.cpp:20-22)
 inline uint32_t kmer_code_of_class(uint32_t cls) { return cls == 2 ? 3u : (cls == 3 ? 2u : cls); }
 // reverse complement of a k-mer integer (PrefixTable.cpp:94-108), valid for 2k <= 32
+inline uint32_t kmer_revcomp(uint32_t prefix, int k);
+// canonical pairs (odd k): bit 2*(k/2)+1 of a k-mer -- the high bit of its middle base -- tells the two k-mers of a pair apart
+inline int kmer_canon_bit(int k) { return 2 * (k / 2) + 1; }
+inline uint32_t kmer_canon_id(uint32_t canon_kmer, int k) { const int b = kmer_canon_bit(k); return ((canon_kmer >> (b + 1)) << b) | (canon_kmer & ((1u << b) - 1u)); }
+inline uint32_t kmer_of_canon_id(uint32_t id, int k) { const int b = kmer_canon_bit(k); return ((id >> b) << (b + 1)) | (id & ((1u << b) - 1u)); }
 inline uint32_t kmer_revcomp(uint32_t prefix, int k) {
 	const int shift = 32 - 2 * k;
 	uint32_t c = (prefix ^ 0xAAAAAAAAu) << shift;

@@ -1,14 +1,14 @@
 """Debug helper (not a test): the config-5 reads whose SAM record differs from the reference program's; prints the candidate
 list (location, strand, votes, affine score) next to what each side reported."""
 import os, re, subprocess, sys, tempfile
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import simulate as S, ref_files as RF
 import nextgenmap_amd as N
 from nextgenmap_amd.pipeline import Mapper, Reference
 from test_gpu_cli import _sam
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CLI = os.path.join(ROOT, "nextgenmap_amd", "ngm-hip")
 d = tempfile.mkdtemp()
 contigs = S.make_genome([3_000_000, 2_000_001], seed=501, repeat_families=40, repeat_len=800, copies=12, divergence=0.01)

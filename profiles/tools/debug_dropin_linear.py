@@ -3,10 +3,10 @@ Lists the candidates of those reads and their linear scores through three routes
 from ngm_ref_decode (what the plugin sees), the C oracle on the same windows, and what the device pipeline reported."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import simulate as S
 import oracle_lib as O
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import nextgenmap_amd as N
 from nextgenmap_amd.pipeline import Mapper, Reference
 
