@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NGM_HIP_ABI_VERSION 2
+#define NGM_HIP_ABI_VERSION 3
 
 /* mode argument of batch_score / batch_align: include/IAlignment.h:33-48 */
 #define NGM_MODE_LOCAL 0      /* Smith-Waterman, kernels oclSW / oclSW_Score        */
@@ -74,7 +74,16 @@ typedef struct ngm_hip_params {
 	int max_batch;     /* largest n the caller will pass (0 = default 1<<20); sizes the HBM workspace */
 	int personality;   /* NGM_PERSONALITY_* */
 	int gap_extend_penalty; /* Config "gap_extend_penalty" (affine personality only), src/config/Config.cpp:444 */
+	/* ABI 3: the strand-specific score tables of `--bs-mapping` / `--slam-seq` (the reference builds its kernels with
+	 * -D__ALT_SCORING__, lib/mason/opencl/SWOcl.cpp:225-242, oclDefines.cl:94-128); linear personality only, like the reference
+	 * (src/config/Config.cpp:448-460).  The per-pair table choice arrives through the `dir` argument of batch_score / batch_align. */
+	int alt_scoring;        /* NGM_ALT_* */
+	int match_bonus_tt;     /* Config MATCH_BONUS_TT (-D matchALT) */
+	int match_bonus_tc;     /* Config MATCH_BONUS_TC (-D mismatchALT; SLAM-seq: its negation) */
 } ngm_hip_params;
+#define NGM_ALT_NONE 0
+#define NGM_ALT_BISULFITE 1   /* Config "bs_mapping" == 1: tables scoresBsFWD / scoresBsREV, bsFrom/bsTo T>C (dir 0), A>G (dir 1) */
+#define NGM_ALT_SLAMSEQ 2     /* Config "slam_seq" & 2: tables scoresSlamSeqFWD / REV, C>T (dir 0), G>A (dir 1) */
 
 /* Mirrors struct Align (include/IAlignment.h:14-29); buffers are caller-owned. */
 typedef struct ngm_hip_align_out {
@@ -100,8 +109,9 @@ int ngm_hip_score_batch_size(const ngm_hip_ctx *ctx);
 int ngm_hip_align_batch_size(const ngm_hip_ctx *ctx);
 
 /* Host-pointer drop-in.  ref[i] -> qry_max_len + corridor readable bytes, qry[i] -> qry_max_len
- * bytes (NUL padded); scores[i] receives the integer score as float.  dir (strand flags for
- * bisulfite/SLAM scoring) must be NULL in this version. */
+ * bytes (NUL padded); scores[i] receives the integer score as float.  dir: with alt_scoring, n bytes -- 0 selects the FWD
+ * score table for the pair, anything else the REV one (what ScoreBuffer / AlignmentBuffer pass as extData,
+ * src/ScoreBuffer.cpp:93-127); NULL = all 0; ignored without alt_scoring. */
 int ngm_hip_batch_score(ngm_hip_ctx *ctx, int mode, int n, const char *const *ref, const char *const *qry,
 		float *scores, const char *dir);
 int ngm_hip_batch_align(ngm_hip_ctx *ctx, int mode, int n, const char *const *ref, const char *const *qry,
@@ -112,6 +122,9 @@ int ngm_hip_batch_align(ngm_hip_ctx *ctx, int mode, int n, const char *const *re
  * (a hipStream_t, NULL = the context's own stream) and is asynchronous. */
 int ngm_hip_score_device(ngm_hip_ctx *ctx, int mode, int n, const void *d_ref, const void *d_qry,
 		float *d_scores, void *stream);
+
+/* alt_scoring with device-resident batches: d_dir = n bytes in HBM (0: FWD table), read by the next *_device call; NULL: all 0. */
+int ngm_hip_set_pair_directions(ngm_hip_ctx *ctx, const void *d_dir);
 
 /* Raw per-pair traceback record produced on the device (8 ints):
  *   [0] valid  [1] position_offset  [2] qstart  [3] qend  [4] n_runs  [5] best_score

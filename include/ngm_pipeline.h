@@ -148,6 +148,34 @@ int ngm_mapper_map_pe(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, ch
 int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads, ngm_hit *hits, char *cigars,
 		char *mds);
 
+/* The SAM text of a batch, assembled on the GPU (csrc/sam_device.h): what GenericReadWriter::WriteRead / WritePair
+ * (src/writer/GenericReadWriter.h:190-304: min_identity / min_residues / min_mq filters), AlignmentBuffer::WriteRead's
+ * proper-pair check (src/AlignmentBuffer.cpp:175-199) and SAMWriter::DoWriteReadGeneric / DoWriteUnmappedReadGeneric /
+ * DoWritePair (src/writer/SAMWriter.cpp:98-372) produce for the reads of one ngm_mapper_map_* call, records in input order
+ * (the two records of a pair: mate 2 first, as the reference writes them).  Single alignments per read (topn <= 1). */
+typedef struct ngm_sam_options {
+	int paired;                 /* the calls map pairs (reads 2i, 2i + 1) */
+	int min_insert_size, max_insert_size;   /* the writer's proper-pair window (max <= 0: unlimited) */
+	int min_mq;                 /* Config "min_mq" */
+	float min_identity, min_residues;       /* Config "min_identity" (0.65), "min_residues" (0.5; <= 1: share of the read length) */
+	int no_unal;                /* Config "no_unal": unmapped reads are not written */
+	const char *rg_id;          /* read group id for the RG:Z tag, or NULL */
+} ngm_sam_options;
+int ngm_mapper_set_sam_options(ngm_mapper *m, const ngm_sam_options *o);
+typedef struct ngm_sam_read {   /* per read: where its name is, how long its quality string is */
+	uint32_t name_off;          /* into `names` */
+	uint16_t name_len;
+	uint16_t qual_len;          /* bytes of the quality string the parser holds (the row holds the first qry_max_len - 1 of them); 0: none ('*');
+	                             * bit 15 set: the read has no sequence and is discarded (NGMNames::Empty, GenericReadWriter.h:245-252) */
+} ngm_sam_read;
+/* Maps the batch like ngm_mapper_map_se / _pe and formats it.  reads, quals: n rows of qry_max_len bytes (page-locked memory
+ * makes the copies asynchronous); names: names_bytes bytes; out: out_cap bytes for the text.  Returns the length of the text
+ * (> out_cap: nothing was copied -- call ngm_mapper_sam_fetch with a larger buffer), or < 0.  stats: reads counted, reads
+ * mapped, lines written.  kernel_ms (optional): GPU time of the formatting kernels. */
+long long ngm_mapper_map_sam(ngm_mapper *m, int n, const char *reads, const char *quals, const char *names, size_t names_bytes,
+		const ngm_sam_read *meta, char *out, size_t out_cap, uint64_t stats[3], float *kernel_ms);
+int ngm_mapper_sam_fetch(ngm_mapper *m, char *out, size_t out_cap);
+
 /* Several mappers on ONE input (ngm-hip hands batches to a mapper per worker thread / per GPU, like NextGenMap hands them to
  * its CS threads, src/NGM.cpp:232-279, src/CS.cpp:440-456).  top1PE's tie-break reads the running mean insert size of the
  * pairs selected so far (ScoreBuffer.h:90, ScoreBuffer.cpp:420-422, :487-488) -- sequential state.  Mappers that share an

@@ -33,8 +33,8 @@ template <int C, bool ENDFREE>
 __global__ __launch_bounds__(256) void sw_align_kernel(const uint32_t *__restrict__ packed,
 		const uint16_t *__restrict__ lens, const uint16_t *__restrict__ blk_rows, uint32_t *__restrict__ dirs,
 		int32_t *__restrict__ records, int n, int n_blocks, int RW, int q, SwConst K) {
-	__shared__ uint2 s_tab[8];
-	if (threadIdx.x < 8) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
+	__shared__ uint2 s_tab[16];
+	if (threadIdx.x < 16) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -49,7 +49,7 @@ constexpr int kCigarRow = 96;
 template <bool AFFINE>
 __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t *__restrict__ records, const uint16_t *__restrict__ runs_c,
 		const uint32_t *__restrict__ packed, int RW, int FW, const uint16_t *__restrict__ read_len, const uint32_t *__restrict__ a_read, int variant_cpu,
-		int hard_clip, int silent_clip, CigarDevOut *__restrict__ out, char *__restrict__ bytes, unsigned long long capacity, unsigned long long *__restrict__ cursor) {
+		int hard_clip, int silent_clip, CigarDevOut *__restrict__ out, char *__restrict__ bytes, unsigned long long capacity, unsigned long long *__restrict__ cursor, int alt = 0) {
 	__shared__ char s_rows[256 * 2 * kCigarRow];
 	__shared__ uint32_t s_wave[4];
 	__shared__ unsigned long long s_base;
@@ -99,7 +99,11 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 			// symbol classes of read position j / window position j: eight per dword, the dword kept while it lasts
 			uint32_t rw_at = 0xFFFFFFFFu, rw = 0, fw_at = 0xFFFFFFFFu, fw = 0;
 			auto nib = [](uint32_t w, int b) -> uint32_t { return (b < 4) ? (w >> (8 * b)) & 15u : (w >> (8 * (b - 4) + 4)) & 15u; };
-			auto rclass = [&](int j) -> uint32_t { const uint32_t wi = (uint32_t) j >> 3; if (wi != rw_at) { rw = pb[(size_t) wi * kSlots]; rw_at = wi; } return nib(rw, j & 7); };
+			// (bit 3 of a read class = the pair's score table, SwConst::alt)
+			auto rclass = [&](int j) -> uint32_t { const uint32_t wi = (uint32_t) j >> 3; if (wi != rw_at) { rw = pb[(size_t) wi * kSlots]; rw_at = wi; } return nib(rw, j & 7) & 7u; };
+			const uint32_t dir = alt ? ((pb[0] >> 3) & 1u) : 0u;
+			// bs_mapping / slam_seq: the conversion that counts as a match (SWOclCigar.cpp:300-317), as symbol classes A0 C1 G2 T3
+			const uint32_t bs_from = alt == 1 ? (dir ? 0u : 3u) : (dir ? 2u : 1u), bs_to = alt == 1 ? (dir ? 2u : 1u) : (dir ? 0u : 3u);
 			auto fclass = [&](int j) -> uint32_t { const uint32_t wi = (uint32_t) j >> 3; if (wi != fw_at) { fw = pb[(size_t) (RW + wi) * kSlots]; fw_at = wi; } return nib(fw, j & 7); };
 			int match = 0, mismatch = 0, total = 0, m_len = 0, md_eq = 0, ref_i = 0, read_i = o.qstart;
 			bool in_x_run = false, odd_symbol = false;
@@ -111,10 +115,10 @@ __global__ __launch_bounds__(256) void cigar_strings_kernel(int n, const int32_t
 					for (int t = 0; t < len; ++t) {
 						const uint32_t rc = rclass(read_i), fc = fclass(ref0 + ref_i);
 						if (rc == 4u) odd_symbol = true;  // a read symbol outside ACGTN: characters and classes may disagree -> host
-						const bool eq = (op == 1) && (variant_cpu ? (rc <= 3u && rc == fc) : (rc == fc));
+						const bool eq = (op == 1) && ((variant_cpu && !alt) ? (rc <= 3u && rc == fc) : (rc == fc));
 						if (eq) { match += 1; md_eq += 1; in_x_run = false; }
 						else {
-							mismatch += 1;
+							if (alt && rc == bs_from && fc == bs_to) match += 1; else mismatch += 1;   // SWOclCigar.cpp:507-514
 							if (mo > lim) { fits = false; break; }
 							if (!in_x_run) { mo += dev_put_num(mdp + mo, md_eq); md_eq = 0; in_x_run = true; }
 							mdp[mo++] = class_to_char(fc);

@@ -18,6 +18,7 @@ struct CigarParams {
 	int variant;   // NGM_VARIANT_*
 	int hard_clip;
 	int silent_clip;
+	int alt = 0;   // NGM_ALT_*: bs_mapping / slam_seq (SWOclCigar.cpp:300-317, :496-520)
 };
 
 // symbol classes of the reference's kernels (oclDefines.cl:64-80)
@@ -38,6 +39,7 @@ inline int host_sym_class(unsigned char ch) {
 inline bool column_is_eq(const CigarParams &p, unsigned char r, unsigned char f) {
 	if (p.variant == NGM_VARIANT_OCL_GPU) return r == f;
 	const int rc = host_sym_class(r), fc = host_sym_class(f);
+	if (p.alt) return rc == fc;   // the __ALT_SCORING__ build of the float4 kernels compares the classes (oclSwScore.cl:69)
 	return rc <= 3 && rc == fc;
 }
 
@@ -55,8 +57,12 @@ inline int put_num(char *dst, int v) {
 inline int put_op(char *dst, int v, char op) { const int n = put_num(dst, v); dst[n] = op; dst[n + 1] = 0; return n + 1; }
 
 // rec: the 8-int record, runs: rec[4] entries in traceback order.
+// dir: the pair's entry of extData (bs_mapping / slam_seq: which conversion counts as a match)
 inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint16_t *runs, const char *ref,
-		const char *qry, ngm_hip_align_out *out) {
+		const char *qry, ngm_hip_align_out *out, int dir = 0) {
+	char bs_from = '0', bs_to = '0';  // SWOclCigar.cpp:300-317
+	if (p.alt == NGM_ALT_BISULFITE) { bs_from = dir ? 'A' : 'T'; bs_to = dir ? 'G' : 'C'; }
+	if (p.alt == NGM_ALT_SLAMSEQ) { bs_from = dir ? 'G' : 'C'; bs_to = dir ? 'A' : 'T'; }
 	out->position_offset = 0;
 	out->qstart = 0;
 	out->qend = 0;
@@ -86,7 +92,8 @@ inline void build_cigar_md(const CigarParams &p, const int32_t *rec, const uint1
 				if (eq) {
 					match += 1; md_eq += 1; in_x_run = false;
 				} else {
-					mismatch += 1;
+					// bs_mapping / slam_seq: the conversion is a match for identity and NM, not for CIGAR / MD (SWOclCigar.cpp:507-514)
+					if (p.alt && qry[read_i] == bs_from && refseq[ref_i] == bs_to) match += 1; else mismatch += 1;
 					if (!in_x_run) { mo += put_num(md + mo, md_eq); md_eq = 0; in_x_run = true; }
 					md[mo++] = refseq[ref_i];
 				}

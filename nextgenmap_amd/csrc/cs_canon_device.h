@@ -167,6 +167,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		}
 		if (tid == 0) s_next_read = drawn;   // (the atomic was issued before the loads above: it has returned with them)
 		__syncthreads();
+		const unsigned long long c1a = diag ? wall_clock64() : 0ull;
 
 		// 2. chunk items: the part of a pair's lists beyond the first line (16-byte chunks of the bucket's further words), or both
 		// lists of a pair that does not fit its bucket (16-byte chunks of the position table copy behind the buckets)
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			R.H = H; R.n_valid = n_valid; R.n_items = n_items;
 			__syncthreads();
 		}
+		const unsigned long long c1b = diag ? wall_clock64() : 0ull;
 		const uint32_t H = R.H;
 		const uint32_t n_items = R.n_items;
 		if (H > A.hit_cap || n_items > kItemCap || n_kmers > NT || n_kmers > R1 * bpr) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			}
 			vote_step(s, pos, valid, corr, rev, n_items == 0u && ((uint32_t) (2 * s + 2) * (uint32_t) bpr >= (uint32_t) n_kmers || s + 1 == S1));
 		}
+		const unsigned long long c1c = diag ? wall_clock64() : 0ull;
 		if (CH >= S1) issue_chunks();
 		// votes of the chunks
 #pragma unroll
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				if (diag && lane == 0) {
 					atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);
 					atomicAdd(&A.phase_cycles[3], wall_clock64() - c3);
+					atomicAdd(&A.phase_cycles[4], c1a - c1); atomicAdd(&A.phase_cycles[5], c1b - c1a); atomicAdd(&A.phase_cycles[6], c1c - c1b); atomicAdd(&A.phase_cycles[7], c2 - c1c);
 				}
 			}
 			__syncthreads();   // the table is reused by the next read

@@ -80,6 +80,14 @@ struct CsArgs {
 	uint32_t *ovf_read;     // [n] queue written by this pass
 	uint32_t *ovf_hits;     // [n]
 	// kCsExactGlobal
+	// bisulfite mapping (CS::PrefixMutateSearch, src/CS.cpp:54-112): every T (second mate of a pair: A) of a read k-mer may be a
+	// converted C (G): all 2^m combinations are looked up when the k-mer has at most bs_cutoff of them, none otherwise; the read is
+	// walked with bs_read_skip (the "kmer_skip" of a --bs-mapping run applies to the READ, src/CS.cpp:556-560, the index is built
+	// with skip 0, src/PrefixTable.cpp:199-207).  Exact paths only.
+	int bs;                 // 0 off, 1 on
+	int bs_cutoff;          // Config "bs_cutoff" (6)
+	int bs_read_skip;       // k-mers skipped between two looked-up ones inside an N-free stretch of the read
+	int bs_paired;          // reads 2i + 1 are second mates: A -> G instead of T -> C (src/CS.cpp:356-376)
 	const uint64_t *ovf_table_off;  // per queued read: offset (in slots) into gtable_*
 	const uint32_t *ovf_log2;       // per queued read: log2 slots
 	uint32_t *gtable_keys;
@@ -333,6 +341,132 @@ __device__ __forceinline__ void cs_enqueue(const CsArgs &A, int read, int lane, 
 		A.ovf_hits[slot] = R.H;
 		A.read_len[read] = (uint16_t) R.L;
 	}
+}
+
+// ---- bisulfite mapping: which k-mers of the read are looked up, and as which variants ---------------------------------
+// One wave.  Codes as in cs_prepare; l_vbase[p] = number of k-mer variants in front of k-mer p (l_vbase[n_kmers] = all of them):
+// a k-mer contributes 2^m variants (m = its bases equal to `from`, m <= bs_cutoff), 0 when it is not looked up at all -- N inside,
+// more than bs_cutoff convertible bases, or not on the read-side stride: PrefixIteration visits the first k-mer of every N-free
+// stretch and then every (skip + 1)-th (CSstatic.cpp:57-75; a stretch begins after an N, the counter restarts with it).
+struct CsBsRead { int L; int n_kmers; uint32_t V; uint32_t n_valid; uint32_t from, to; };
+constexpr int kCsBsChunk = 1024;   // variants whose lists are held in LDS at a time
+
+__device__ __forceinline__ CsBsRead cs_bs_scan(const CsArgs &A, int read, int lane, uint8_t *l_code, uint32_t *l_vbase) {
+	const int k = A.k;
+	const uint8_t *rp = A.reads + (size_t) read * A.q;
+	int first_nul = A.q;
+	for (int i = lane; i < A.q; i += 64) {
+		const uint32_t ch = rp[i];
+		uint8_t code;
+		if (ch == 0) { code = 255; first_nul = min(first_nul, i); }
+		else if (ch == 'N') code = 4;
+		else code = (uint8_t) ((ch >> 1) & 3u);
+		l_code[i] = code;
+	}
+	CsBsRead R;
+	R.L = wave_reduce_min(first_nul);
+	__syncthreads();
+	const int L = R.L;
+	R.n_kmers = max(L - k + 1, 0);
+	const bool second = A.bs_paired && (read & 1);
+	R.from = second ? 0u : 2u;   // A -> G for the second mate, T -> C otherwise (codes A0 C1 T2 G3, CS.cpp:356-376)
+	R.to = second ? 3u : 1u;
+	uint32_t carry = 0, n_valid = 0;
+	int last_n = -1;   // position of the last N in front of the current round (wave-uniform)
+	if (lane == 0) l_vbase[0] = 0;
+	for (int base = 0; base < R.n_kmers; base += 64) {
+		const int p = base + lane;
+		// the N-free stretch k-mer p lies in starts behind the last N at or before p: prefix maximum over the positions of the round
+		const int here = (p < L && l_code[p] == 4) ? p : -1;
+		const int seg_n = max((int) wave_inclusive_max((uint32_t) (here + 1)) - 1, last_n);   // last N at or before p (-1: none)
+		uint32_t nvar = 0;
+		bool looked = false;
+		if (p < R.n_kmers) {
+			bool v = true;
+			uint32_t m = 0;
+			for (int j = 0; j < k; ++j) {
+				const uint32_t c = l_code[p + j];
+				v = v && (c < 4);
+				m += (c == R.from) ? 1u : 0u;
+			}
+			if (v && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) v = false;  // CSstatic.cpp:30-41, see cs_prepare
+			// (a valid k-mer holds no N: the last N at or before p lies in front of it)
+			if (v && ((p - (seg_n + 1)) % (A.bs_read_skip + 1)) == 0) { looked = true; if ((int) m <= A.bs_cutoff) nvar = 1u << m; }
+		}
+		n_valid += (uint32_t) __popcll(__ballot(looked));
+		const uint32_t incl = wave_inclusive_scan(nvar, lane);
+		if (p < R.n_kmers) l_vbase[p + 1] = carry + incl;
+		carry += wave_last(incl);
+		last_n = max(last_n, (int) wave_last((uint32_t) (seg_n + 1)) - 1);
+	}
+	R.V = carry; R.n_valid = n_valid;
+	__syncthreads();
+	return R;
+}
+
+// The variants [v0, v1) of the read, in the reference's order: k-mers left to right; per k-mer the recursion of
+// CS::PrefixMutateSearchEx (src/CS.cpp:97-112) -- the k-mer itself, then for every convertible base i (from the LAST base of the
+// k-mer towards the first) the k-mer with base i converted followed by all further conversions of bases beyond i -- i.e. the
+// subsets of the convertible bases in lexicographic order of their sorted element lists.  Per variant two lists (forward k-mer,
+// reverse complement), dropped together when they hold max_kfreq hits or more (CS.cpp:122).
+// l_start[2j], l_start[2j + 1]: position-table offsets of variant v0 + j; l_pref: prefix sums of the list lengths (TIMES: length |
+// time of the list's first hit << 16, times counted from t_base); l_vpos[j]: the k-mer's position in the read.
+// Returns the hits of the chunk; *segments (optional) += their 8-hit segments.  One wave.
+template <bool TIMES>
+__device__ __forceinline__ uint32_t cs_bs_chunk(const CsArgs &A, const CsBsRead &R, int lane, const uint8_t *l_code, const uint32_t *l_vbase, uint32_t v0, uint32_t v1,
+		uint32_t t_base, uint32_t *l_start, uint32_t *l_pref, uint16_t *l_vpos, uint32_t *segments = nullptr) {
+	const int k = A.k;
+	uint32_t carry = 0, carry_s = 0;
+	for (uint32_t vb = v0; vb < v1; vb += 64) {
+		const uint32_t v = vb + (uint32_t) lane;
+		uint32_t cf = 0, cr = 0, sf = 0, sr = 0;
+		int p = 0;
+		if (v < v1) {
+			int lo = 0, hi = R.n_kmers;  // the k-mer with l_vbase[p] <= v < l_vbase[p + 1]
+			while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (l_vbase[mid] <= v) lo = mid; else hi = mid; }
+			p = lo;
+			uint32_t r = v - l_vbase[p];
+			uint32_t kmer = 0, conv = 0;   // conv: bit i set = base i (counted from the k-mer's last base) is convertible
+			for (int j = 0; j < k; ++j) {
+				const uint32_t c = l_code[p + j] & 3u;
+				kmer = (kmer << 2) | c;
+				conv = (conv << 1) | (c == R.from ? 1u : 0u);
+			}
+			// unrank r in the recursion order: rank 0 = nothing converted; below a node whose last converted base is the e-th convertible one
+			// lie 2^(m - 1 - e) nodes
+			const int m = __popc(conv);
+			uint32_t chosen = 0;   // bit e: the e-th convertible base (in increasing i) is converted
+			int e = 0;
+			while (r > 0) {
+				r -= 1;
+				for (;; ++e) {
+					const uint32_t size = 1u << (m - 1 - e);
+					if (r < size) { chosen |= 1u << e; ++e; break; }
+					r -= size;
+				}
+			}
+			int idx = 0;
+			for (int i = 0; i < k; ++i) if ((conv >> i) & 1u) { if ((chosen >> idx) & 1u) kmer = (kmer & ~(3u << (2 * i))) | (R.to << (2 * i)); ++idx; }
+			const uint2 ef = A.index[kmer], er = A.index[cs_revcomp(kmer, k)];
+			if ((int) (ef.y + er.y) < A.max_kfreq) { cf = ef.y; sf = ef.x; cr = er.y; sr = er.x; }  // CS.cpp:122
+		}
+		const uint32_t both = cf + cr;
+		const uint32_t incl = wave_inclusive_scan(both, lane);
+		const uint32_t nseg = (cf + kCsSeg - 1) / kCsSeg + (cr + kCsSeg - 1) / kCsSeg;
+		const uint32_t incl_s = wave_inclusive_scan(nseg, lane);
+		if (v < v1) {
+			const uint32_t j = v - v0, b0 = carry + incl - both;
+			l_start[2 * j] = sf; l_start[2 * j + 1] = sr;
+			if (TIMES) { l_pref[2 * j] = (cf & 0xFFFFu) | ((t_base + b0) << 16); l_pref[2 * j + 1] = (cr & 0xFFFFu) | ((t_base + b0 + cf) << 16); }
+			else { l_pref[2 * j] = b0; l_pref[2 * j + 1] = b0 + cf; }
+			l_vpos[j] = (uint16_t) p;
+		}
+		carry += wave_last(incl);
+		carry_s += wave_last(incl_s);
+	}
+	if (!TIMES && lane == 0) l_pref[2 * (v1 - v0)] = carry;
+	if (segments) *segments += carry_s;
+	return carry;
 }
 
 // 4. threshold and candidates (CS.cpp:201-205, :263-313).  Returns false when the FAST path cannot certify the
@@ -957,7 +1091,25 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	}
 	uint32_t n_slots = 1u << log2_slots;
 
-	const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
+	// bisulfite mapping: the lists of the k-mer VARIANTS, kCsBsChunk variants at a time (votes commute); behind the codes in LDS:
+	// l_vbase [q + 1], l_vpos [kCsBsChunk]
+	uint32_t *l_vbase = nullptr;
+	uint16_t *l_vpos = nullptr;
+	CsBsRead B{};
+	CsRead R;
+	if (A.bs) {
+		l_vbase = (uint32_t *) l_code + (A.q + 3) / 4;
+		l_vpos = (uint16_t *) (l_vbase + A.q + 1);
+		uint32_t *after = (uint32_t *) (l_vpos + kCsBsChunk);
+		if (MODE != kCsExactGlobal) { t_keys = after; t_votes = t_keys + (1u << log2_slots); }
+		B = cs_bs_scan(A, read, lane, l_code, l_vbase);
+		uint32_t Hs = 0;   // counting pass: the table is sized from the read's hits
+		for (uint32_t v0 = 0; v0 < B.V; v0 += kCsBsChunk) {
+			Hs += cs_bs_chunk<false>(A, B, lane, l_code, l_vbase, v0, min(B.V, v0 + (uint32_t) kCsBsChunk), 0u, l_start, l_pref, l_vpos);
+			__syncthreads();
+		}
+		R.L = B.L; R.n_lists = 0; R.H = Hs; R.n_valid = B.n_valid; R.n_items = 0;
+	} else R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
 	const uint32_t H = R.H;
 	const int L = R.L;
 	if (MODE != kCsExactGlobal && H > A.hit_cap) { cs_enqueue(A, read, lane, R); return; }
@@ -975,9 +1127,8 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	__syncthreads();
 	if (MODE == kCsExactGlobal) __threadfence_block();
 
-	cs_for_each_hit(A.positions, l_start, l_pref, R.n_lists, H, lane, [&](uint32_t pos, int li, uint32_t) {
-		const int p = li >> 1;
-		const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
+	auto vote = [&](uint32_t pos, int p, bool rev) {
+		const uint32_t correction = rev ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
 		const uint32_t bin = (pos - correction) >> A.bin_shift;
 		uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
 		for (;;) {
@@ -985,8 +1136,19 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 			if (prev == bin || prev == 0xFFFFFFFFu) break;
 			slot = (slot + 1) & (n_slots - 1);
 		}
-		atomicAdd(&t_votes[slot], (li & 1) ? 0x10000u : 1u);
-	});
+		atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
+	};
+	if (A.bs) {
+		for (uint32_t v0 = 0; v0 < B.V; v0 += kCsBsChunk) {
+			const uint32_t v1 = min(B.V, v0 + (uint32_t) kCsBsChunk);
+			const uint32_t hc = cs_bs_chunk<false>(A, B, lane, l_code, l_vbase, v0, v1, 0u, l_start, l_pref, l_vpos);
+			__syncthreads();
+			cs_for_each_hit(A.positions, l_start, l_pref, (int) (2 * (v1 - v0)), hc, lane, [&](uint32_t pos, int li, uint32_t) { vote(pos, (int) l_vpos[li >> 1], (li & 1) != 0); });
+			__syncthreads();
+		}
+	} else {
+		cs_for_each_hit(A.positions, l_start, l_pref, R.n_lists, H, lane, [&](uint32_t pos, int li, uint32_t) { vote(pos, li >> 1, (li & 1) != 0); });
+	}
 	__syncthreads();
 	if (MODE == kCsExactGlobal) __threadfence_block();
 	(void) cs_finish<MODE>(A, read, lane, R, t_keys, t_votes, n_slots);

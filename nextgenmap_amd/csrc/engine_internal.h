@@ -59,7 +59,8 @@ struct ngm_hip_ctx {
 	// HBM workspace
 	ngm::DevBuf<uint32_t> packed;
 	ngm::DevBuf<uint16_t> lens, blk_rows;
-	ngm::DevBuf<uint8_t> d_ref, d_qry;
+	ngm::DevBuf<uint8_t> d_ref, d_qry, d_pair_dir;   // d_pair_dir: the `dir` bytes of the host-pointer entry points (alt_scoring)
+	const uint8_t *pair_dir = nullptr;               // ... what the next pack reads: a device array of n bytes, or null (all 0)
 	ngm::DevBuf<float> d_scores;
 	ngm::DevBuf<uint32_t> dirs;
 	ngm::DevBuf<int32_t> d_records;

@@ -24,7 +24,7 @@ void log_msg(int lvl, const char *msg) {
 
 class HipAlignment : public IAlignment {
 public:
-	explicit HipAlignment(ngm_hip_ctx *ctx) : ctx_(ctx) {}
+	HipAlignment(ngm_hip_ctx *ctx, bool alt) : ctx_(ctx), alt_(alt) {}
 	~HipAlignment() override { ngm_hip_destroy(ctx_); }
 
 	int GetScoreBatchSize() const override { return ngm_hip_score_batch_size(ctx_); }
@@ -34,7 +34,9 @@ public:
 			char const *const *const qrySeqList, char const *const *const /*qalSeqList*/, float *const results,
 			void *extData) override {
 		if (batchSize <= 0) { log_msg(1, "Score for batchSize <= 0"); return 0; }  // SWOcl.cpp:39-42
-		const char *dir = (mode & 0x10000) ? static_cast<const char *>(extData) : nullptr;
+		// bisulfite mapping: ScoreBuffer passes its direction bytes as extData (src/ScoreBuffer.cpp:93-127); the "BSMappingActive"
+		// bit of include/IAlignment.h:37 is never set by the 0.5.5 callers (ScoreBuffer.h:90, AlignmentBuffer.cpp:114)
+		const char *dir = (alt_ || (mode & 0x10000)) ? static_cast<const char *>(extData) : nullptr;
 		int r = ngm_hip_batch_score(ctx_, mode, batchSize, refSeqList, qrySeqList, results, dir);
 		if (r < 0) { log_msg(2, ngm_hip_last_error(ctx_)); return 0; }
 		return r;
@@ -44,7 +46,7 @@ public:
 			char const *const *const qrySeqList, char const *const *const /*qalSeqList*/, Align *const results,
 			void *extData) override {
 		if (batchSize <= 0) { log_msg(1, "Align for batchSize <= 0"); return 0; }  // SWOclCigar.cpp:109-112
-		const char *dir = (mode & 0x10000) ? static_cast<const char *>(extData) : nullptr;
+		const char *dir = (alt_ || (mode & 0x10000)) ? static_cast<const char *>(extData) : nullptr;
 		std::vector<ngm_hip_align_out> out(static_cast<size_t>(batchSize));
 		for (int i = 0; i < batchSize; ++i) { out[i].cigar = results[i].pBuffer1; out[i].md = results[i].pBuffer2; }
 		int r = ngm_hip_batch_align(ctx_, mode, batchSize, refSeqList, qrySeqList, out.data(), dir);
@@ -62,6 +64,7 @@ public:
 
 private:
 	ngm_hip_ctx *ctx_;
+	bool alt_;
 };
 
 bool integral(float v, int *out) {
@@ -86,10 +89,13 @@ IAlignment *CreateAlignment(int const mode) {
 	const int report = (mode >> 8) & 0xFF;
 	if (report != 1) { log_msg(2, "Unsupported report type (only CIGAR + MD output is implemented)"); return nullptr; }
 	IConfig &cfg = *g_config;
-	if ((cfg.Exists("bs_mapping") && cfg.GetInt("bs_mapping") == 1) || (cfg.Exists("slam_seq") && cfg.GetInt("slam_seq") != 0)) {
-		log_msg(2, "bisulfite / SLAM-seq scoring is not implemented in the HIP backend");
+	// SLAM-seq needs the per-base records behind Align::ExtendedData (SWOclCigar.cpp:442-447, :484-540) for the TC / RA / MP
+	// tags (src/writer/GenericReadWriter.h:87-180): not produced here yet, so that mode is refused rather than written without them
+	if (cfg.Exists("slam_seq") && cfg.GetInt("slam_seq") != 0) {
+		log_msg(2, "SLAM-seq (--slam-seq) is not implemented in the HIP backend");
 		return nullptr;
 	}
+	const bool bs = cfg.Exists("bs_mapping") && cfg.GetInt("bs_mapping") == 1;
 	ngm_hip_params p{};
 	p.abi_version = NGM_HIP_ABI_VERSION;
 	p.qry_max_len = cfg.GetInt("qry_max_len");
@@ -110,9 +116,16 @@ IAlignment *CreateAlignment(int const mode) {
 		log_msg(2, "the HIP backend needs an integer gap_extend_penalty");
 		return nullptr;
 	}
+	if (bs) {  // lib/mason/opencl/SWOcl.cpp:228-232
+		p.alt_scoring = NGM_ALT_BISULFITE;
+		if (!integral(cfg.GetFloat("match_bonus_tt"), &p.match_bonus_tt) || !integral(cfg.GetFloat("match_bonus_tc"), &p.match_bonus_tc)) {
+			log_msg(2, "the HIP backend needs integer scores (match_bonus_tt, match_bonus_tc)");
+			return nullptr;
+		}
+	}
 	ngm_hip_ctx *ctx = ngm_hip_create(mode & 0xFF, &p);
 	if (!ctx) { log_msg(2, ngm_hip_last_error(nullptr)); return nullptr; }
-	return new HipAlignment(ctx);
+	return new HipAlignment(ctx, bs);
 }
 
 void DeleteAlignment(IAlignment *instance) { delete instance; }

@@ -28,6 +28,8 @@
 #include "cigar_device.h"
 #include "cs_device.h"
 #include "cs_canon_device.h"
+#define NGM_SAM_KERNELS
+#include "sam_device.h"
 #include "gather_device.h"
 #include "thread_pool.h"
 
@@ -106,6 +108,20 @@ struct ngm_mapper {
 	ngm::DevBuf<ngm::CigarDevOut> d_cigout;
 	ngm::PinnedBuf<ngm::CigarDevOut> p_cigout;
 	ngm::PinnedBuf<char> p_str;
+	// SAM text on the GPU (sam_device.h)
+	ngm_sam_options sam_opt{};
+	bool sam_ready = false;
+	std::string sam_rg;
+	ngm::DevBuf<char> d_sam_contig_names, d_sam_rg, d_sam_names, d_sam_text;
+	ngm::DevBuf<uint32_t> d_sam_contig_off, d_sam_len, d_sam_off;
+	ngm::DevBuf<uint8_t> d_sam_quals;
+	ngm::DevBuf<ngm::SamMeta> d_sam_meta;
+	ngm::DevBuf<ngm::SamRef> d_sam_refs;
+	ngm::DevBuf<ngm_hit> d_sam_hits;
+	ngm::PinnedBuf<ngm_hit> p_sam_hits;
+	ngm::PinnedBuf<ngm::SamRef> p_sam_refs;
+	ngm::PinnedBuf<char> p_sam_extra;
+	uint64_t sam_text_bytes = 0;      // of the last batch (still in d_sam_text)
 	// last CS result on the host
 	int n_reads = 0;
 	// per-read candidate offsets / counts / best vote counts of the last search, downloaded into pinned memory
@@ -135,7 +151,7 @@ constexpr int kCanonT[4] = {0, 3, 3, 4}, kCanonR1[4] = {0, 4, 6, 8}, kCanonR2[4]
 constexpr int kCsCanonMode = 3;
 size_t cs_canon_lds_bytes(const ngm::CsArgs &A, int shape) {  // k-mer info + headers, codes, chunk items (16-bit), plane, table, queue (+ the kernel's static variables)
 	const size_t w = (size_t) A.lists_cap + (A.q + 3) / 4 + (size_t) kCanonR2[shape] * kCanonT[shape] * 64 / 2 + ((size_t) A.plane_bits >> 5) + ((size_t) 2 << A.log2_slots) +
-			((size_t) 3 << A.log2_slots) / 4 + 64;
+			((size_t) 3 << A.log2_slots) / 4 + 96;  // (+ slack: the per-wave k-mer rows round up, the static variables)
 	return w * 4;
 }
 
@@ -324,6 +340,9 @@ int run_cs(ngm_mapper *m, int n) {
 			if (A.phase_cycles)
 				fprintf(stderr, "[ngm-hip] cs fast path, 100 MHz ticks per read: lists %.1f sweep1 %.1f sweep2 %.1f candidates %.1f; %u of %d reads re-run by the exact path; kernels %.2f + %.2f + %.2f ms\n",
 						(double) ph[0] * 256 / n, (double) ph[1] * 256 / n, (double) ph[2] * 256 / n, (double) ph[3] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
+			if (A.phase_cycles && m->cs_canon)
+				fprintf(stderr, "[ngm-hip] cs canonical path, inside sweep 1: first lines arrived %.1f | chunk items %.1f | first-line votes %.1f | chunk votes %.1f\n",
+						(double) ph[4] * 256 / n, (double) ph[5] * 256 / n, (double) ph[6] * 256 / n, (double) ph[7] * 256 / n);
 			return 0;
 		}
 		cap *= 4;  // candidate buffer too small: grow and redo the batch
@@ -563,6 +582,8 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
+	m->d_sam_contig_names.release(); m->d_sam_rg.release(); m->d_sam_names.release(); m->d_sam_text.release(); m->d_sam_contig_off.release(); m->d_sam_len.release(); m->d_sam_off.release();
+	m->d_sam_quals.release(); m->d_sam_meta.release(); m->d_sam_refs.release(); m->d_sam_hits.release(); m->p_sam_hits.release(); m->p_sam_refs.release(); m->p_sam_extra.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
 	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
@@ -607,7 +628,9 @@ int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *vo
 	return 0;
 }
 
-static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired);
+// the SAM stage of a call (ngm_mapper_map_sam): inputs the records need beyond the reads, where the text goes
+struct SamCall { const char *quals; const char *names; size_t names_bytes; const ngm::SamMeta *meta; char *out; size_t out_cap; uint64_t *stats; long long text_bytes; float kernel_ms; };
+static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired, SamCall *sam = nullptr);
 
 // Reference order of the candidates of the listed reads (cs_order_kernel): h_rank[c] for every candidate c of those
 // reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
@@ -680,6 +703,45 @@ int ngm_mapper_map_pe(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, ch
 }
 int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds) {
 	return map_impl(m, n, reads, d_reads_ext, hits, cigars, mds, true);
+}
+
+int ngm_mapper_set_sam_options(ngm_mapper *m, const ngm_sam_options *o) {
+	if (!m || !o) return -22;
+	DevGuard g(m->ref->device);
+	m->sam_opt = *o;
+	m->sam_opt.rg_id = nullptr;
+	m->sam_rg = o->rg_id ? o->rg_id : "";
+	const ngm_ref *r = m->ref;
+	std::string names;
+	std::vector<uint32_t> off(r->contigs.size() + 1, 0);
+	for (size_t i = 0; i < r->contigs.size(); ++i) { off[i] = (uint32_t) names.size(); names += r->contigs[i].name; }
+	off[r->contigs.size()] = (uint32_t) names.size();
+	if (m->d_sam_contig_names.reserve(names.size() + 16) || m->d_sam_contig_off.reserve(off.size()) || m->d_sam_rg.reserve(m->sam_rg.size() + 16)) { ngm::pipeline_set_error("out of device memory (SAM options)"); return -12; }
+	MAP_HIP_TRY(hipMemcpy(m->d_sam_contig_names.p, names.data(), names.size(), hipMemcpyHostToDevice));
+	MAP_HIP_TRY(hipMemcpy(m->d_sam_contig_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+	if (!m->sam_rg.empty()) MAP_HIP_TRY(hipMemcpy(m->d_sam_rg.p, m->sam_rg.data(), m->sam_rg.size(), hipMemcpyHostToDevice));
+	m->sam_ready = true;
+	return 0;
+}
+
+static_assert(sizeof(ngm_sam_read) == sizeof(ngm::SamMeta) && sizeof(ngm_sam_read) == 8, "ngm_sam_read is the device's per-read record");
+
+long long ngm_mapper_map_sam(ngm_mapper *m, int n, const char *reads, const char *quals, const char *names, size_t names_bytes, const ngm_sam_read *meta,
+		char *out, size_t out_cap, uint64_t stats[3], float *kernel_ms) {
+	if (!m || n < 0 || (n > 0 && (!reads || !quals || !meta))) return -22;
+	SamCall sc{quals, names, names_bytes, reinterpret_cast<const ngm::SamMeta *>(meta), out, out_cap, stats, 0, 0.f};
+	const int rc = map_impl(m, n, reads, nullptr, nullptr, nullptr, nullptr, m->sam_opt.paired != 0, &sc);
+	if (rc < 0) return rc;
+	if (kernel_ms) *kernel_ms = sc.kernel_ms;
+	if (n == 0 && stats) stats[0] = stats[1] = stats[2] = 0;
+	return sc.text_bytes;
+}
+
+int ngm_mapper_sam_fetch(ngm_mapper *m, char *out, size_t out_cap) {
+	if (!m || !out || out_cap < m->sam_text_bytes) return -22;
+	DevGuard g(m->ref->device);
+	if (m->sam_text_bytes) MAP_HIP_TRY(hipMemcpy(out, m->d_sam_text.p, (size_t) m->sam_text_bytes, hipMemcpyDeviceToHost));
+	return 0;
 }
 
 // ScoreBuffer::top1PE's std::sort(Scores, sortLocationScore) (src/ScoreBuffer.cpp:373-376) over one read's candidates.
@@ -801,7 +863,7 @@ static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_coun
 	}
 }
 
-static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired) {
+static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired, SamCall *sam) {
 	if (!m) return -22;
 	// shared paired-end state: wait for this batch's turn before the running mean is read, pass it on when the batch is
 	// done with it (also on EVERY early return, the argument checks below included: with a shared ngm_pair_state a batch that
@@ -847,6 +909,17 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	auto lap = [&](int k) { auto t = now(); t_stage[k] += std::chrono::duration<double, std::milli>(t - tp0).count(); tp0 = t; };
 	MAP_HIP_TRY(hipEventRecord(m->ev[0], m->st));
 	if (!d_reads_ext) if (int rc = upload_reads(m, n, reads)) return rc;
+	if (sam) {
+		// what the SAM records need beyond the reads: qualities, names (travel while the search runs)
+		if (!m->sam_ready || (!paired) != (!m->sam_opt.paired) || m->prm.topn > 1) { ngm::pipeline_set_error("ngm_mapper_map_sam: call ngm_mapper_set_sam_options first (single alignments only; paired as configured)"); return -22; }
+		if ((unsigned long long) n * (unsigned long long) (2 * q + 1024) + sam->names_bytes >= 0xFFFFFFFFull) { ngm::pipeline_set_error("ngm_mapper_map_sam: the text of %d reads may exceed the 32-bit offsets of a batch: use smaller batches", n); return -75; }
+		if (m->d_sam_quals.reserve((size_t) n * q) || m->d_sam_names.reserve(sam->names_bytes + 16) || m->d_sam_meta.reserve(n) || m->p_sam_hits.reserve(n) || m->p_sam_refs.reserve(n) ||
+				m->d_sam_hits.reserve(n) || m->d_sam_refs.reserve(n)) { ngm::pipeline_set_error("out of memory (SAM stage)"); return -12; }
+		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_quals.p, sam->quals, (size_t) n * q, hipMemcpyHostToDevice, m->st));
+		if (sam->names_bytes) MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_names.p, sam->names, sam->names_bytes, hipMemcpyHostToDevice, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_meta.p, sam->meta, (size_t) n * sizeof(ngm::SamMeta), hipMemcpyHostToDevice, m->st));
+		hits = m->p_sam_hits.p;
+	}
 	GpuStage stage_cs;
 	if (int rc = run_cs(m, n)) return rc;
 	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
@@ -1236,6 +1309,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	uint16_t *h_runs = nullptr;
 	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
 	static const bool dev_strings = !getenv("NGM_HIP_HOST_CIGAR");
+	uint64_t str_base = 0;   // bytes of the device's CIGAR / MD stream (host-built strings of the SAM stage go behind them)
 	GpuStage stage_align(1);
 	if (na > 0) {
 		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
@@ -1285,14 +1359,20 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipMemcpy(h_runs, m->d_runs_c.p, n_runs_total * 2, hipMemcpyDeviceToHost));
 		if (dev_strings) {
 			n_str_total = std::min<unsigned long long>(n_str_total, (unsigned long long) na * 96ull + 4096ull);
+			str_base = n_str_total;
 			if (m->p_str.reserve(n_str_total + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
-			if (n_str_total) MAP_HIP_TRY(hipMemcpy(m->p_str.p, m->d_str.p, n_str_total, hipMemcpyDeviceToHost));
+			if (n_str_total && !sam) MAP_HIP_TRY(hipMemcpy(m->p_str.p, m->d_str.p, n_str_total, hipMemcpyDeviceToHost));
 		}
 	}
 	stage_align.done();
 
 	lap(3);
 	// ---- host: CIGAR / MD, final positions --------------------------------------------------------------
+	// (SAM stage: the strings stay in the device's byte stream and the records point into it; only strings the device could
+	// not build are made here and appended to that stream)
+	ngm::SamRef *sam_refs = sam ? m->p_sam_refs.p : nullptr;
+	std::mutex extra_mu;
+	std::vector<char> extra;
 	parallel_for(n, [&](int lo, int hi) {
 		for (int i = lo; i < hi; ++i) for (int t = 0; t < topn; ++t) {
 			const size_t o = (size_t) i * topn + t;
@@ -1304,13 +1384,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			h.n_best = h_nbest[i];
 			h.score = h_best[i];
 			h.pair_flags = pair_flags[i];
-			cigars[o * str_stride] = 0;
-			mds[o * str_stride] = 0;
+			if (!sam) { cigars[o * str_stride] = 0; mds[o * str_stride] = 0; }
+			else sam_refs[o] = ngm::SamRef{0, 0, 0, 0};
 		}
 	});
 	ngm::CigarParams cp{m->prm.match_bonus, -m->prm.mismatch_penalty, m->prm.variant, m->prm.hard_clip, m->prm.silent_clip};
 	parallel_for(na, [&](int lo, int hi) {
-		std::vector<char> win((size_t) q + c + 8), qry((size_t) q + 8);
+		std::vector<char> win((size_t) q + c + 8), qry((size_t) q + 8), scr(sam ? 2 * str_stride : 0);
 		for (int j = lo; j < hi; ++j) {
 			const int i = (int) a_read[j];
 			const size_t o = a_out[j];
@@ -1321,13 +1401,17 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			const char *rd = reads + (size_t) i * q;
 			const int L = (int) strnlen(rd, q);
 			ngm_hip_align_out ao{};
-			ao.cigar = cigars + o * str_stride;
-			ao.md = mds + o * str_stride;
+			ao.cigar = sam ? scr.data() : cigars + o * str_stride;
+			ao.md = sam ? scr.data() + str_stride : mds + o * str_stride;
+			bool host_strings = true;
 			const ngm::CigarDevOut *dv = dev_strings ? &m->p_cigout.p[j] : nullptr;
 			if (dv && (dv->flags & 1)) {  // built on the GPU: copy the two strings and the numbers
 				if (!(dv->flags & 2)) { h.mapped = 0; continue; }  // no alignment could be built
-				memcpy(ao.cigar, m->p_str.p + dv->cig_off, dv->cig_len); ao.cigar[dv->cig_len] = 0;
-				memcpy(ao.md, m->p_str.p + dv->md_off, dv->md_len); ao.md[dv->md_len] = 0;
+				if (sam) { sam_refs[o] = ngm::SamRef{dv->cig_off, dv->md_off, dv->cig_len, dv->md_len}; host_strings = false; }
+				else {
+					memcpy(ao.cigar, m->p_str.p + dv->cig_off, dv->cig_len); ao.cigar[dv->cig_len] = 0;
+					memcpy(ao.md, m->p_str.p + dv->md_off, dv->md_len); ao.md[dv->md_len] = 0;
+				}
 				ao.identity = dv->identity; ao.nm = dv->nm; ao.qstart = dv->qstart; ao.qend = dv->qend; ao.position_offset = dv->position_offset;
 				ao.score_token = dv->score_token;
 			} else if (m->prm.personality == NGM_PERSONALITY_AFFINE) {
@@ -1347,6 +1431,14 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), &ao);
 				if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
 			}
+			if (sam && host_strings) {
+				const size_t cl = strlen(ao.cigar), ml = strlen(ao.md);
+				std::lock_guard<std::mutex> lk(extra_mu);
+				const size_t at = extra.size();
+				extra.insert(extra.end(), ao.cigar, ao.cigar + cl);
+				extra.insert(extra.end(), ao.md, ao.md + ml);
+				sam_refs[o] = ngm::SamRef{(uint32_t) (str_base + at), (uint32_t) (str_base + at + cl), (uint16_t) cl, (uint16_t) ml};
+			}
 			h.identity = ao.identity; h.nm = ao.nm; h.qstart = ao.qstart; h.qend = ao.qend;
 			// AlignmentBuffer.cpp:129 then SequenceProvider.convert (AlignmentBuffer.cpp:173)
 			const uint64_t final_loc = (uint64_t) a_loc[j] + (uint64_t) (int64_t) ao.position_offset - (uint64_t) (c >> 1);
@@ -1357,6 +1449,71 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	});
 
 	lap(4);
+	if (sam) {
+		// ---- SAM text on the GPU: lengths per unit, exclusive prefix sum, bytes (sam_device.h) ------------------------------
+		GpuStage stage_sam(1);
+		const int units = paired ? n / 2 : n;
+		if (!extra.empty()) {
+			// the byte stream grows by the host-built strings (rare: strings beyond the device's scratch rows)
+			const size_t need = (size_t) str_base + extra.size();
+			if (need > m->d_str.cap) {
+				ngm::DevBuf<char> bigger;
+				if (bigger.reserve(need + 4096)) { ngm::pipeline_set_error("out of device memory (SAM strings)"); return -12; }
+				if (str_base) MAP_HIP_TRY(hipMemcpyAsync(bigger.p, m->d_str.p, (size_t) str_base, hipMemcpyDeviceToDevice, m->st));
+				MAP_HIP_TRY(hipStreamSynchronize(m->st));
+				std::swap(bigger, m->d_str);
+				bigger.release();
+			}
+			if (m->p_sam_extra.reserve(extra.size())) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+			memcpy(m->p_sam_extra.p, extra.data(), extra.size());
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_str.p + str_base, m->p_sam_extra.p, extra.size(), hipMemcpyHostToDevice, m->st));
+		}
+		if (m->d_sam_len.reserve((size_t) units + 1) || m->d_sam_off.reserve((size_t) units + 1)) { ngm::pipeline_set_error("out of device memory (SAM stage)"); return -12; }
+		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_hits.p, hits, (size_t) n * sizeof(ngm_hit), hipMemcpyHostToDevice, m->st));
+		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_refs.p, sam_refs, (size_t) n * sizeof(ngm::SamRef), hipMemcpyHostToDevice, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 16, 0, 24, m->st));
+		ngm::SamArgs S{};
+		S.n = n; S.q = q; S.paired = paired ? 1 : 0;
+		S.reads = m->d_reads.p; S.quals = m->d_sam_quals.p; S.names = m->d_sam_names.p; S.meta = m->d_sam_meta.p; S.hits = m->d_sam_hits.p; S.refs = m->d_sam_refs.p;
+		S.str = m->d_str.p; S.contig_names = m->d_sam_contig_names.p; S.contig_name_off = m->d_sam_contig_off.p;
+		S.min_insert = m->sam_opt.min_insert_size; S.max_insert = m->sam_opt.max_insert_size > 0 ? m->sam_opt.max_insert_size : 2147483647;
+		S.min_mq = m->sam_opt.min_mq; S.no_unal = m->sam_opt.no_unal; S.hard_clip = m->prm.hard_clip; S.silent_clip = m->prm.silent_clip;
+		S.min_identity = m->sam_opt.min_identity; S.min_residues = m->sam_opt.min_residues;
+		S.rg = m->sam_rg.empty() ? nullptr : m->d_sam_rg.p; S.rg_len = (int) m->sam_rg.size();
+		S.unit_len = m->d_sam_len.p; S.unit_off = m->d_sam_off.p; S.counters = m->d_total.p + 16;
+		hipEvent_t e0 = m->cev[0], e1 = m->cev[1];
+		MAP_HIP_TRY(hipEventRecord(e0, m->st));
+		unsigned long long total = 0;
+		if (units > 0) {
+			hipLaunchKernelGGL(ngm::sam_lengths_kernel, dim3((units + 255) / 256), dim3(256), 0, m->st, S, units);
+			MAP_HIP_TRY(hipGetLastError());
+			size_t tmp_bytes = 0;
+			(void) rocprim::exclusive_scan(nullptr, tmp_bytes, m->d_sam_len.p, m->d_sam_off.p, 0u, (size_t) units + 1, rocprim::plus<uint32_t>(), m->st);
+			if (m->d_scan_tmp.reserve(tmp_bytes + 16)) { ngm::pipeline_set_error("out of device memory (scan)"); return -12; }
+			MAP_HIP_TRY(hipMemsetAsync(m->d_sam_len.p + units, 0, 4, m->st));
+			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_sam_len.p, m->d_sam_off.p, 0u, (size_t) units + 1, rocprim::plus<uint32_t>(), m->st));
+			uint32_t total32 = 0;
+			MAP_HIP_TRY(hipMemcpyAsync(&total32, m->d_sam_off.p + units, 4, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+			total = total32;
+			if (m->d_sam_text.reserve((size_t) total + 16)) { ngm::pipeline_set_error("out of device memory (SAM text)"); return -12; }
+			S.out = m->d_sam_text.p;
+			hipLaunchKernelGGL(ngm::sam_write_kernel, dim3((units + 255) / 256), dim3(256), 0, m->st, S, units);
+			MAP_HIP_TRY(hipGetLastError());
+		}
+		MAP_HIP_TRY(hipEventRecord(e1, m->st));
+		unsigned long long ctr[3] = {0, 0, 0};
+		MAP_HIP_TRY(hipMemcpyAsync(ctr, m->d_total.p + 16, 24, hipMemcpyDeviceToHost, m->st));
+		m->sam_text_bytes = total;
+		if (total <= sam->out_cap && total > 0) MAP_HIP_TRY(hipMemcpyAsync(sam->out, m->d_sam_text.p, (size_t) total, hipMemcpyDeviceToHost, m->st));
+		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		stage_sam.done();
+		sam->text_bytes = (long long) total;
+		if (sam->stats) { sam->stats[0] = ctr[0]; sam->stats[1] = ctr[1]; sam->stats[2] = ctr[2]; }
+		float t = 0;
+		sam->kernel_ms = hipEventElapsedTime(&t, e0, e1) == hipSuccess ? t : 0.f;
+		lap(5);
+	}
 	if (host_timing)
 		fprintf(stderr, "[ngm-hip] host wall ms: candidate search %.1f | score stage + downloads %.1f | pair selection %.1f | align stage + downloads %.1f | CIGAR/positions %.1f\n",
 				t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4]);

@@ -330,6 +330,8 @@ struct Batch {
 	std::vector<Read> owned;            // serial reader: the records themselves
 	std::vector<Rec> recs;
 	std::vector<std::string> chunks;    // formatted output, in order
+	char *text = nullptr;               // ... or, formatted on the GPU: one piece in a page-locked buffer of the pool
+	size_t text_len = 0, text_cap = 0;
 	size_t n_total = 0, n_mapped = 0, n_written = 0;
 };
 constexpr int kSub = 1024;
@@ -636,12 +638,21 @@ int main(int argc, char **argv) {
 		refs.push_back(r2);
 	}
 	ngm_pair_state *pair_state = ngm_pair_state_create();
-	struct Worker { ngm_mapper *m = nullptr; char *rows = nullptr; size_t rows_cap = 0; std::vector<ngm_hit> hits; std::vector<char> cig, md; };
+	// SAM text on the GPU (csrc/sam_device.h) for plain SAM output with one alignment per read; BAM and -n > 1 are formatted here
+	const bool gpu_sam = !o.bam && topn == 1 && !getenv("NGM_HIP_HOST_SAM");
+	struct Worker { ngm_mapper *m = nullptr; char *rows = nullptr; size_t rows_cap = 0; std::vector<ngm_hit> hits; std::vector<char> cig, md;
+		char *qrows = nullptr, *names = nullptr; size_t names_cap = 0; ngm_sam_read *meta = nullptr; };
 	std::vector<Worker> workers(o.devices.size() * (size_t) o.workers);
 	for (size_t w = 0; w < workers.size(); ++w) {
 		workers[w].m = ngm_mapper_create(refs[w % refs.size()], &mp);
 		if (!workers[w].m) die(ngm_pipeline_last_error());
 		ngm_mapper_set_pair_state(workers[w].m, pair_state);
+		if (gpu_sam) {
+			ngm_sam_options so{};
+			so.paired = o.paired; so.min_insert_size = o.min_insert; so.max_insert_size = o.max_insert; so.min_mq = o.min_mq;
+			so.min_identity = o.min_identity; so.min_residues = o.min_residues; so.no_unal = o.no_unal; so.rg_id = o.rg[0].empty() ? nullptr : o.rg[0].c_str();
+			if (ngm_mapper_set_sam_options(workers[w].m, &so) < 0) die(ngm_pipeline_last_error());
+		}
 		ngm_mapper_set_reference_cs_batch(workers[w].m, 1800000 / std::max(1, avg_len));
 	}
 
@@ -818,12 +829,12 @@ int main(int argc, char **argv) {
 	};
 
 	// ---- the pipeline ---------------------------------------------------------------------------------------------
-	const auto t_start = std::chrono::steady_clock::now();
 	ngm::ThreadPool &pool = ngm::ThreadPool::instance();
 	BoundedQueue<std::unique_ptr<Batch>> q_in(workers.size() + 2);
 	std::mutex out_mu;
 	std::condition_variable out_cv;
 	std::map<uint64_t, std::unique_ptr<Batch>> out_ready;
+	uint64_t next_write = 0;   // the batch the writer waits for (under out_mu)
 	bool workers_done = false;
 	std::atomic<bool> failed{false};
 	std::string fail_msg;
@@ -914,6 +925,30 @@ int main(int argc, char **argv) {
 	std::atomic<long long> t_gpu_us{0};  // HIP-event time of the mapping kernels, summed over the batches
 	std::atomic<long long> t_wait_us{0}, t_parse_us{0}, t_map_us{0}, t_format_us{0}, t_format_cpu_us{0}, t_parse_cpu_us{0}, t_write_us{0}, t_write_cpu_us{0};
 	auto us_since = [](std::chrono::steady_clock::time_point t0) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
+	// GPU-formatted text: page-locked buffers that travel worker -> writer -> pool.  Their number bounds the formatted text in
+	// flight (a slow output file then stalls the workers instead of piling the output up in memory)
+	struct TextBuf { char *p; size_t cap; };
+	std::mutex text_mu;
+	std::condition_variable text_cv;
+	std::vector<TextBuf> text_free;
+	const size_t text_cap0 = (size_t) batch_reads * ((size_t) 2 * q + 288) + (1u << 20);
+	if (gpu_sam) {
+		// page-locked memory is slow to get (~0.1 s per 150 MB): everything a worker needs, and the text pool, at once and in parallel
+		std::vector<std::thread> alloc;
+		text_free.resize(workers.size() + 2);
+		for (TextBuf &t : text_free) alloc.emplace_back([&t, text_cap0] { t.p = (char *) ngm_host_alloc(text_cap0); t.cap = text_cap0; });
+		for (Worker &w : workers) alloc.emplace_back([&w, batch_reads, q] {
+			w.rows_cap = (size_t) batch_reads * q;
+			w.rows = (char *) ngm_host_alloc(w.rows_cap); w.qrows = (char *) ngm_host_alloc(w.rows_cap);
+			w.meta = (ngm_sam_read *) ngm_host_alloc((size_t) batch_reads * sizeof(ngm_sam_read));
+			w.names_cap = (size_t) batch_reads * 32; w.names = (char *) ngm_host_alloc(w.names_cap);
+		});
+		for (auto &t : alloc) t.join();
+		for (const TextBuf &t : text_free) if (!t.p) die(ngm_pipeline_last_error());
+		for (const Worker &w : workers) if (!w.rows || !w.qrows || !w.meta || !w.names) die(ngm_pipeline_last_error());
+	}
+	std::atomic<long long> t_sam_gpu_us{0};
+	const auto t_start = std::chrono::steady_clock::now();   // the mapping pass: mappers and page-locked buffers exist, the splitter has begun to cut batches
 	auto worker_main = [&](Worker &w) {
 		std::unique_ptr<Batch> b;
 		for (;;) {
@@ -928,6 +963,12 @@ int main(int argc, char **argv) {
 				w.rows_cap = (size_t) std::max(n, batch_reads) * q;
 				w.rows = (char *) ngm_host_alloc(w.rows_cap);
 				if (!w.rows) { fail(ngm_pipeline_last_error()); w.rows_cap = 0; }
+				if (gpu_sam && w.rows) {
+					ngm_host_free(w.qrows); ngm_host_free(w.meta);
+					w.qrows = (char *) ngm_host_alloc(w.rows_cap);
+					w.meta = (ngm_sam_read *) ngm_host_alloc((size_t) std::max(n, batch_reads) * sizeof(ngm_sam_read));
+					if (!w.qrows || !w.meta) { fail(ngm_pipeline_last_error()); ngm_host_free(w.rows); w.rows = nullptr; w.rows_cap = 0; }
+				}
 			}
 			{
 				std::lock_guard<std::mutex> lk(spare_mu);
@@ -944,6 +985,7 @@ int main(int argc, char **argv) {
 						b->recs[i] = Rec{r.name.data(), r.seq.data(), r.qual.data(), (uint32_t) r.name.size(), (uint32_t) r.seq.size(), (uint32_t) r.qual.size()};
 						if (o.paired) strip_mate(b->recs[i].name, b->recs[i].name_len);
 						pack_row_view(r.seq.data(), r.seq.size(), q, w.rows + (size_t) i * q);
+						if (gpu_sam) memcpy(w.qrows + (size_t) i * q, r.qual.data(), std::min<size_t>(r.qual.size(), (size_t) q - 1));
 					}
 				}, 4096);
 			} else if (w.rows) {
@@ -969,6 +1011,7 @@ int main(int argc, char **argv) {
 							at = nx;
 							if (o.paired) strip_mate(r.name, r.name_len);
 							pack_row_view(r.seq, r.seq_len, q, w.rows + (size_t) i * q);
+							if (gpu_sam) memcpy(w.qrows + (size_t) i * q, r.qual, std::min<size_t>(r.qual_len, (size_t) q - 1));
 						}
 					}
 				}, 1);
@@ -993,6 +1036,58 @@ int main(int argc, char **argv) {
 			}
 			ngm_mapper_set_batch_seq(w.m, b->seq);
 			if (failed) { if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
+			if (gpu_sam) {
+				// names: one block of bytes per batch (offsets by a prefix sum over the records), plus what the record printer needs per read
+				size_t total = 0;
+				for (int i = 0; i < n; ++i) {
+					const Rec &r = b->recs[i];
+					w.meta[i].name_off = (uint32_t) total; w.meta[i].name_len = (uint16_t) std::min<uint32_t>(r.name_len, 65535u);
+					w.meta[i].qual_len = (uint16_t) (std::min<uint32_t>(r.qual_len, 0x7FFFu) | (r.seq_len == 0 ? 0x8000u : 0u));
+					total += w.meta[i].name_len;
+				}
+				if (total + 16 > w.names_cap) {
+					ngm_host_free(w.names);
+					w.names_cap = std::max(total + 16, (size_t) batch_reads * 32);
+					w.names = (char *) ngm_host_alloc(w.names_cap);
+					if (!w.names) { fail(ngm_pipeline_last_error()); w.names_cap = 0; if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
+				}
+				pool.parallel_for(n, [&](int lo, int hi) { for (int i = lo; i < hi; ++i) memcpy(w.names + w.meta[i].name_off, b->recs[i].name, w.meta[i].name_len); }, 8192);
+				t_parse_us += us_since(tp);
+				auto tm = std::chrono::steady_clock::now();
+				TextBuf tb{nullptr, 0};
+				{
+					std::unique_lock<std::mutex> lk(text_mu);
+					text_cv.wait(lk, [&] { return !text_free.empty(); });
+					tb = text_free.back(); text_free.pop_back();
+				}
+				uint64_t st[3] = {0, 0, 0};
+				float sam_ms = 0.f;
+				long long len = ngm_mapper_map_sam(w.m, n, w.rows, w.qrows, w.names, total, w.meta, tb.p, tb.cap, st, &sam_ms);
+				if (len > (long long) tb.cap) {  // (long CIGAR / MD strings: a larger buffer for this batch)
+					ngm_host_free(tb.p);
+					tb.cap = (size_t) len + (1u << 20);
+					tb.p = (char *) ngm_host_alloc(tb.cap);
+					if (!tb.p || ngm_mapper_sam_fetch(w.m, tb.p, tb.cap) < 0) len = -1;
+				}
+				if (len < 0) { fail(ngm_pipeline_last_error()); std::lock_guard<std::mutex> lk(text_mu); if (tb.p) text_free.push_back(tb); text_cv.notify_one(); continue; }
+				t_map_us += us_since(tm);
+				{ float kms[8] = {0}; if (ngm_mapper_last_kernel_ms(w.m, kms) == 0) { double sum = sam_ms; for (int k2 = 0; k2 < 7; ++k2) sum += kms[k2]; t_gpu_us += (long long) (sum * 1000.0); } }
+				t_sam_gpu_us += (long long) (sam_ms * 1000.0);
+				b->text = tb.p; b->text_cap = tb.cap; b->text_len = (size_t) len;
+				b->n_total = st[0]; b->n_mapped = st[1]; b->n_written = st[2];
+				{
+					std::lock_guard<std::mutex> lk(spare_mu);
+					b->recs.clear();
+					spare_recs.push_back(std::move(b->recs));
+				}
+				b->owned.clear(); b->owned.shrink_to_fit();
+				{
+					std::lock_guard<std::mutex> lk(out_mu);
+					out_ready[b->seq] = std::move(b);
+				}
+				out_cv.notify_all();
+				continue;
+			}
 			t_parse_us += us_since(tp);
 			auto tm = std::chrono::steady_clock::now();
 			w.hits.resize((size_t) n * topn); w.cig.resize((size_t) n * topn * stride); w.md.resize((size_t) n * topn * stride);
@@ -1033,7 +1128,9 @@ int main(int argc, char **argv) {
 			b->owned.clear(); b->owned.shrink_to_fit();
 			t_format_us += us_since(tf);
 			{
-				std::lock_guard<std::mutex> lk(out_mu);
+				// back-pressure: formatted batches wait here while the writer is behind -- except the one it is waiting for
+				std::unique_lock<std::mutex> lk(out_mu);
+				out_cv.wait(lk, [&] { return out_ready.size() < workers.size() + 2 || b->seq == next_write || failed.load(); });
 				out_ready[b->seq] = std::move(b);
 			}
 			out_cv.notify_all();
@@ -1046,11 +1143,25 @@ int main(int argc, char **argv) {
 			std::unique_ptr<Batch> b;
 			{
 				std::unique_lock<std::mutex> lk(out_mu);
+				next_write = next;
+				out_cv.notify_all();
 				out_cv.wait(lk, [&] { return out_ready.count(next) || workers_done; });
 				auto it = out_ready.find(next);
 				if (it == out_ready.end()) return;  // workers are done and the next batch never came (failure) or everything is written
 				b = std::move(it->second);
 				out_ready.erase(it);
+			}
+			out_cv.notify_all();
+			if (b->text) {
+				const auto t_wr = std::chrono::steady_clock::now();
+				if (b->text_len && !put_all(b->text, b->text_len, out_off)) fail("write error on " + o.out);
+				out_off += b->text_len;
+				t_write_us += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wr).count();
+				{ std::lock_guard<std::mutex> lk(text_mu); text_free.push_back(TextBuf{b->text, b->text_cap}); }
+				text_cv.notify_one();
+				n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written;
+				++next;
+				continue;
 			}
 			std::vector<uint64_t> offs(b->chunks.size());
 			for (size_t c = 0; c < b->chunks.size(); ++c) { offs[c] = out_off; out_off += b->chunks[c].size(); }
@@ -1094,6 +1205,7 @@ int main(int argc, char **argv) {
 	snprintf(msg, sizeof(msg), "GPU kernels: %.3f s of the %.3f s mapping pass (%.0f %%; candidate search, gathers, score, select, align, traceback by HIP events)",
 			t_gpu_us / 1e6, secs, 100.0 * (t_gpu_us / 1e6) / std::max(1e-9, secs));
 	info("MAIN", msg);
+	if (gpu_sam) { snprintf(msg, sizeof(msg), "SAM text assembled on the GPU: %.3f s of kernels (included above)", t_sam_gpu_us / 1e6); info("MAIN", msg); }
 	snprintf(msg, sizeof(msg), "Input to output: %.3f s (estimation pass + mapping pass, first input byte to output closed)",
 			std::chrono::duration<double>(std::chrono::steady_clock::now() - t_input).count());
 	info("MAIN", msg);
@@ -1124,7 +1236,8 @@ int main(int argc, char **argv) {
 		info("MAIN", msg);
 	}
 	if (const char *pf = getenv("NGM_HIP_PROFILE")) prof::dump(pf);
-	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); }
+	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); ngm_host_free(w.qrows); ngm_host_free(w.names); ngm_host_free(w.meta); }
+	for (TextBuf &t : text_free) ngm_host_free(t.p);
 	ngm_pair_state_destroy(pair_state);
 	for (ngm_ref *r2 : refs) ngm_ref_destroy(r2);
 	return 0;

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -152,7 +154,7 @@ int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipS
 	const bool endfree = (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END;
 	// two pairs per lane in 16-bit halves while every re-based value fits (rows * (match - mismatch) and the end-to-end
 	// sentinel stay inside int16)
-	if (!force32 && (long) ctx->q * ctx->K.tM < 30000 && (long) ctx->q * ctx->K.tZ < 14000) {
+	if (!force32 && (long) ctx->q * std::max(ctx->K.tM, ctx->K.alt ? std::max(ctx->K.tMA, ctx->K.tXA) : 0) < 30000 && (long) ctx->q * ctx->K.tZ < 14000) {
 		if (const void *pk = find_pk_score_kernel(ctx->c, endfree)) {
 			KernelRef kp; kp.aot = pk;
 			HIP_TRY(ctx, launch_kernel(kp, dim3((nb + 7) / 8), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
@@ -223,8 +225,18 @@ int launch_pack(ngm_hip_ctx *ctx, int n, const void *d_ref, const void *d_qry, h
 	const size_t lds = (size_t) ngm::kSlots * (ctx->rl + ctx->q);
 	hipLaunchKernelGGL(ngm::pack_pairs_kernel, dim3(nb), dim3(256), lds, st, (const uint8_t *) d_ref,
 			(const uint8_t *) d_qry, n, ctx->q, ctx->rl, ctx->RW, ctx->FW, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p,
-			ctx->prm.personality == NGM_PERSONALITY_AFFINE ? 1 : 0);
+			ctx->prm.personality == NGM_PERSONALITY_AFFINE ? 1 : 0, ctx->K.alt ? ctx->pair_dir : nullptr);
 	HIP_TRY(ctx, hipGetLastError());
+	return 0;
+}
+
+// the `dir` bytes of a host-pointer call -> device (null: all pairs use the FWD table)
+int stage_dirs(ngm_hip_ctx *ctx, int n, const char *dir) {
+	ctx->pair_dir = nullptr;
+	if (!ctx->K.alt || !dir) return 0;
+	if (ctx->d_pair_dir.reserve(n)) { set_error(ctx, "out of memory staging %d pairs", n); return -12; }
+	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pair_dir.p, dir, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+	ctx->pair_dir = ctx->d_pair_dir.p;
 	return 0;
 }
 
@@ -251,6 +263,16 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 	if (p->personality == NGM_PERSONALITY_AFFINE && p->gap_extend_penalty <= 0) { set_error(nullptr, "ngm_hip_create: gap_extend_penalty must be a positive integer"); return nullptr; }
 	if (p->match_bonus + p->mismatch_penalty > 255) { set_error(nullptr, "ngm_hip_create: match_bonus + mismatch_penalty must be <= 255"); return nullptr; }
 	if (p->corridor > 200) { set_error(nullptr, "ngm_hip_create: corridor %d too wide (the band row lives in registers)", p->corridor); return nullptr; }
+	if (p->alt_scoring != NGM_ALT_NONE) {
+		// Config.cpp:448-460: bs-mapping and affine exclude each other; the tables hold (score - mismatch) as unsigned bytes
+		if (p->alt_scoring != NGM_ALT_BISULFITE && p->alt_scoring != NGM_ALT_SLAMSEQ) { set_error(nullptr, "ngm_hip_create: unknown alt_scoring %d", p->alt_scoring); return nullptr; }
+		if (p->personality != NGM_PERSONALITY_LINEAR) { set_error(nullptr, "ngm_hip_create: bisulfite / SLAM-seq scoring and the affine personality can't be used at the same time"); return nullptr; }
+		const int m_alt = p->match_bonus_tt, x_alt = p->alt_scoring == NGM_ALT_SLAMSEQ ? -p->match_bonus_tc : p->match_bonus_tc;
+		if (m_alt + p->mismatch_penalty < 0 || m_alt + p->mismatch_penalty > 255 || x_alt + p->mismatch_penalty < 0 || x_alt + p->mismatch_penalty > 255) {
+			set_error(nullptr, "ngm_hip_create: match_bonus_tt %d / match_bonus_tc %d out of range for mismatch_penalty %d", p->match_bonus_tt, p->match_bonus_tc, p->mismatch_penalty);
+			return nullptr;
+		}
+	}
 	int ndev = ngm_hip_device_count();
 	if (ndev <= 0) { set_error(nullptr, "ngm_hip_create: no HIP device available (this library has no CPU fallback)"); return nullptr; }
 	if (device < 0 || device >= ndev) { set_error(nullptr, "ngm_hip_create: device %d out of range (%d devices)", device, ndev); return nullptr; }
@@ -278,6 +300,9 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 	ctx->K.gu = gap_read - mismatch;
 	ctx->K.gap_read = gap_read;
 	ctx->K.variant = p->variant;
+	ctx->K.alt = p->alt_scoring;
+	ctx->K.tMA = p->match_bonus_tt - mismatch;                                                            // SWOcl.cpp:230-237
+	ctx->K.tXA = (p->alt_scoring == NGM_ALT_SLAMSEQ ? -p->match_bonus_tc : p->match_bonus_tc) - mismatch;
 	// Score<float, Simple>(match, -mismatch, -gap_extend, -gap_read): extend = gap_extend, open = gap_read (EndToEndAffine.h:37)
 	ctx->KA.tM = match - mismatch;
 	ctx->KA.tZ = -mismatch;
@@ -299,7 +324,7 @@ void ngm_hip_destroy(ngm_hip_ctx *ctx) {
 	ScopedDevice sd(ctx->device);
 	if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
 	ctx->packed.release(); ctx->lens.release(); ctx->blk_rows.release(); ctx->d_ref.release(); ctx->d_qry.release();
-	ctx->d_scores.release(); ctx->dirs.release(); ctx->d_records.release(); ctx->d_runs.release();
+	ctx->d_scores.release(); ctx->dirs.release(); ctx->d_pair_dir.release(); ctx->d_records.release(); ctx->d_runs.release();
 	ctx->h_ref.release(); ctx->h_qry.release(); ctx->h_scores.release(); ctx->h_records.release(); ctx->h_runs.release();
 	for (auto &e : ctx->ev) if (e) (void) hipEventDestroy(e);
 	if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
@@ -349,8 +374,8 @@ int ngm_hip_batch_score(ngm_hip_ctx *ctx, int mode, int n, const char *const *re
 		float *scores, const char *dir) {
 	if (!ctx) return -22;
 	if (n <= 0) return 0;  // SWOcl.cpp:39-42
-	if (dir) { set_error(ctx, "bisulfite / SLAM-seq strand-specific scoring is not implemented"); return -38; }
 	ScopedDevice sd(ctx->device);
+	if (int r0 = stage_dirs(ctx, n, dir)) return r0;
 	const size_t rl = ctx->rl, q = ctx->q;
 	if (ctx->h_ref.reserve((size_t) n * rl) || ctx->h_qry.reserve((size_t) n * q) || ctx->h_scores.reserve(n) ||
 			ctx->d_ref.reserve((size_t) n * rl) || ctx->d_qry.reserve((size_t) n * q) || ctx->d_scores.reserve(n)) {
@@ -370,6 +395,12 @@ int ngm_hip_batch_score(ngm_hip_ctx *ctx, int mode, int n, const char *const *re
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	memcpy(scores, ctx->h_scores.p, sizeof(float) * (size_t) n);
 	return n;
+}
+
+int ngm_hip_set_pair_directions(ngm_hip_ctx *ctx, const void *d_dir) {
+	if (!ctx) return -22;
+	ctx->pair_dir = (const uint8_t *) d_dir;
+	return 0;
 }
 
 int ngm_hip_align_run_stride(const ngm_hip_ctx *ctx) { return ctx ? ngm::run_stride(ctx->q, ctx->c) : 0; }
@@ -398,8 +429,8 @@ int ngm_hip_batch_align(ngm_hip_ctx *ctx, int mode, int n, const char *const *re
 		ngm_hip_align_out *out, const char *dir) {
 	if (!ctx) return -22;
 	if (n <= 0) return 0;  // SWOclCigar.cpp:109-112
-	if (dir) { set_error(ctx, "bisulfite / SLAM-seq strand-specific scoring is not implemented"); return -38; }
 	ScopedDevice sd(ctx->device);
+	if (int r0 = stage_dirs(ctx, n, dir)) return r0;
 	const size_t rl = ctx->rl, q = ctx->q;
 	const int rs = ngm::run_stride(ctx->q, ctx->c);
 	if (ctx->h_ref.reserve((size_t) n * rl) || ctx->h_qry.reserve((size_t) n * q) || ctx->d_ref.reserve((size_t) n * rl) ||
@@ -425,13 +456,14 @@ int ngm_hip_batch_align(ngm_hip_ctx *ctx, int mode, int n, const char *const *re
 	cp.variant = ctx->prm.variant;
 	cp.hard_clip = ctx->prm.hard_clip;
 	cp.silent_clip = ctx->prm.silent_clip;
+	cp.alt = ctx->prm.alt_scoring;
 	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
 		for (int i = 0; i < n; ++i)
 			ngm::build_cigar_affine(ctx->h_records.p + (size_t) i * 8, ctx->h_runs.p + (size_t) i * rs, ref[i], qry[i], ctx->q, &out[i]);
 		return n;
 	}
 	for (int i = 0; i < n; ++i) {
-		ngm::build_cigar_md(cp, ctx->h_records.p + (size_t) i * 8, ctx->h_runs.p + (size_t) i * rs, ref[i], qry[i], &out[i]);
+		ngm::build_cigar_md(cp, ctx->h_records.p + (size_t) i * 8, ctx->h_runs.p + (size_t) i * rs, ref[i], qry[i], &out[i], (cp.alt && dir && dir[i]) ? 1 : 0);
 	}
 	return n;
 }

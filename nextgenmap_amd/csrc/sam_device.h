@@ -1,0 +1,248 @@
+// sam_device.h -- the SAM text of a batch, assembled on the GPU.
+//
+// Replaces, for the plain-SAM output of `ngm-hip`, the host formatter that mirrors GenericReadWriter::WriteRead / WritePair
+// (src/writer/GenericReadWriter.h:190-304: the filters), AlignmentBuffer::WriteRead's proper-pair check
+// (src/AlignmentBuffer.cpp:175-199), SAMWriter::DoWriteReadGeneric / DoWriteUnmappedReadGeneric / DoWritePair
+// (src/writer/SAMWriter.cpp:98-372).  Everything a record needs is in HBM after the align stage -- the read rows, the CIGAR / MD
+// byte stream, the per-read results -- or cheap to upload (names, qualities): formatting 422 bytes per read costs the host
+// 2.2 us of CPU time per read on 64 threads (22 of the 20 CPU-seconds of a 10 M read run); the GPU does it in two passes
+// over the batch: lengths per unit (a read, or a pair: the two records of a pair are written together, mate 2 first),
+// exclusive prefix sum, bytes.  The host only copies the finished text to the output file.
+// The host formatter in ngm_cli.cpp stays: BAM output, -n > 1, and as the twin the tests compare this one with.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ngm_pipeline.h"
+
+namespace ngm {
+
+struct SamMeta {            // per read
+	uint32_t name_off;      // into the batch's name bytes
+	uint16_t name_len;
+	uint16_t qual_len;      // bytes of the quality string as the parser holds it (0: none, the record prints '*'); bit 15: the read has no sequence (discarded)
+};
+struct SamRef { uint32_t cig_off, md_off; uint16_t cig_len, md_len; };   // the read's CIGAR / MD in the byte stream
+
+struct SamArgs {
+	int n, q, paired;
+	const uint8_t *reads;       // n rows of q bytes
+	const uint8_t *quals;       // n rows of q bytes
+	const char *names;
+	const SamMeta *meta;
+	const ngm_hit *hits;
+	const SamRef *refs;
+	const char *str;            // CIGAR / MD byte stream
+	const char *contig_names;   // concatenated
+	const uint32_t *contig_name_off;  // [contigs + 1]
+	int min_insert, max_insert, min_mq, no_unal, hard_clip, silent_clip;
+	float min_identity, min_residues;
+	const char *rg;             // read group id (rg_len bytes) or null
+	int rg_len;
+	uint32_t *unit_len;         // [units] pass 1
+	const uint32_t *unit_off;   // [units] exclusive prefix sums
+	char *out;
+	unsigned long long *counters;  // [0] reads counted [1] reads mapped [2] lines written
+};
+
+struct SamCountSink {
+	uint32_t n = 0;
+	__device__ __forceinline__ void put(char) { ++n; }
+	__device__ __forceinline__ void bytes(const char *, uint32_t len) { n += len; }
+	__device__ __forceinline__ void seq_fwd(const uint8_t *, int len) { n += (uint32_t) len; }
+	__device__ __forceinline__ void seq_rc(const uint8_t *, int, int len) { n += (uint32_t) len; }
+	__device__ __forceinline__ void rev(const uint8_t *, int, int len) { n += (uint32_t) len; }
+};
+struct SamWriteSink {
+	char *p;
+	__device__ __forceinline__ void put(char c) { *p++ = c; }
+	__device__ __forceinline__ void bytes(const char *s, uint32_t len) { for (uint32_t i = 0; i < len; ++i) p[i] = s[i]; p += len; }
+	__device__ __forceinline__ void seq_fwd(const uint8_t *s, int len) { for (int i = 0; i < len; ++i) p[i] = (char) s[i]; p += len; }
+	// len characters: complement of s[last], s[last - 1], ...
+	__device__ __forceinline__ void seq_rc(const uint8_t *s, int last, int len) {
+		for (int t = 0; t < len; ++t) { const char ch = (char) s[last - t]; p[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch; }
+		p += len;
+	}
+	__device__ __forceinline__ void rev(const uint8_t *s, int last, int len) { for (int t = 0; t < len; ++t) p[t] = (char) s[last - t]; p += len; }
+};
+
+template <typename Sink> __device__ __forceinline__ void sam_u64(Sink &s, unsigned long long v) {
+	char b[24];
+	int i = 24;
+	do { b[--i] = (char) ('0' + (int) (v % 10ull)); v /= 10ull; } while (v);
+	for (; i < 24; ++i) s.put(b[i]);
+}
+template <typename Sink> __device__ __forceinline__ void sam_i64(Sink &s, long long v) {
+	if (v < 0) { s.put('-'); sam_u64(s, (unsigned long long) (-(v + 1)) + 1ull); } else sam_u64(s, (unsigned long long) v);
+}
+template <typename Sink> __device__ __forceinline__ void sam_lit(Sink &s, const char *lit) { for (; *lit; ++lit) s.put(*lit); }
+// printf("%g") of roundf(identity * 10000) / 10000 (SAMWriter.cpp:163): at most four decimals, trailing zeros dropped
+template <typename Sink> __device__ __forceinline__ void sam_identity(Sink &s, float identity) {
+	const float r = roundf(identity * 10000.0f);
+	if (!(r >= 0.0f && r <= 10000.0f)) {  // not a ratio of counts: what glibc prints for the non-finite values (never seen from an alignment)
+		if (r != r) { if (__float_as_uint(r) >> 31) s.put('-'); sam_lit(s, "nan"); }
+		else if (r < 0.0f && r < -3.0e38f) sam_lit(s, "-inf");
+		else if (r > 3.0e38f) sam_lit(s, "inf");
+		else sam_lit(s, "0");
+		return;
+	}
+	const int iv = (int) r;
+	if (iv == 10000) { s.put('1'); return; }
+	if (iv == 0) { s.put('0'); return; }
+	const char b[6] = {'0', '.', (char) ('0' + iv / 1000), (char) ('0' + iv / 100 % 10), (char) ('0' + iv / 10 % 10), (char) ('0' + iv % 10)};
+	int k = 6;
+	while (b[k - 1] == '0') --k;
+	for (int i = 0; i < k; ++i) s.put(b[i]);
+}
+
+struct SamView { int i; const ngm_hit *h; const uint8_t *row, *qual; int L; SamMeta m; };
+
+__device__ __forceinline__ SamView sam_view(const SamArgs &A, int i) {
+	SamView v;
+	v.i = i; v.h = A.hits + i; v.row = A.reads + (size_t) i * A.q; v.qual = A.quals + (size_t) i * A.q; v.m = A.meta[i];
+	int L = 0;
+	while (L < A.q && v.row[L] != 0) ++L;
+	v.L = L;
+	return v;
+}
+__device__ __forceinline__ bool sam_passes(const SamArgs &A, const SamView &v) {  // GenericReadWriter.h:205-215, :262-273
+	float min_res = A.min_residues;
+	if (min_res <= 1.0f) min_res = v.L * min_res;
+	return v.h->mapped && v.h->mapq >= A.min_mq && v.h->identity >= A.min_identity && (float) (v.L - v.h->qstart - v.h->qend) >= min_res;
+}
+template <typename Sink> __device__ __forceinline__ void sam_contig(const SamArgs &A, Sink &s, int contig) {
+	const uint32_t o = A.contig_name_off[contig];
+	s.bytes(A.contig_names + o, A.contig_name_off[contig + 1] - o);
+}
+
+// SAMWriter::DoWriteReadGeneric (SAMWriter.cpp:98-228).  rnext: 0 '*', 1 '=', 2 the name of contig rnext_contig
+template <typename Sink>
+__device__ __forceinline__ void sam_mapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int rnext, int rnext_contig, unsigned long long pnext, long long tlen) {
+	const ngm_hit &h = *v.h;
+	const int L = v.L;
+	const int qlen = v.m.qual_len & 0x7FFF;
+	const bool noq = qlen == 0;
+	if (h.reverse) flags |= 0x10;
+	const bool clip = A.hard_clip || A.silent_clip;
+	const int s0 = clip ? h.qstart : 0, sl = clip ? L - h.qstart - h.qend : L;
+	s.bytes(A.names + v.m.name_off, v.m.name_len); s.put('\t'); sam_u64(s, (unsigned) flags); s.put('\t');
+	sam_contig(A, s, h.contig); s.put('\t'); sam_u64(s, (unsigned long long) h.pos + 1ull); s.put('\t'); sam_i64(s, h.mapq); s.put('\t');
+	const SamRef rf = A.refs[v.i];
+	s.bytes(A.str + rf.cig_off, rf.cig_len); s.put('\t');
+	if (rnext == 0) s.put('*'); else if (rnext == 1) s.put('='); else sam_contig(A, s, rnext_contig);
+	s.put('\t'); sam_u64(s, pnext); s.put('\t'); sam_i64(s, tlen); s.put('\t');
+	if (sl > 0) { if (!h.reverse) s.seq_fwd(v.row + s0, sl); else s.seq_rc(v.row, L - 1 - s0, sl); }
+	s.put('\t');
+	if (noq) s.put('*');
+	else if (sl > 0) {
+		// the quality string as the reference holds it: the first L characters (IParser.h copies qry_max_len - 1 at most)
+		const int QL = min(qlen, L);
+		const int take = max(0, min(sl, QL - s0));
+		if (!h.reverse) s.seq_fwd(v.qual + s0, take); else s.rev(v.qual, QL - 1 - s0, take);
+	}
+	s.put('\t');
+	if (A.rg_len > 0) { sam_lit(s, "RG:Z:"); s.bytes(A.rg, (uint32_t) A.rg_len); s.put('\t'); }
+	sam_lit(s, "AS:i:"); sam_i64(s, (int) h.score); sam_lit(s, "\tNM:i:"); sam_i64(s, h.nm); sam_lit(s, "\tNH:i:"); sam_i64(s, h.n_best);
+	sam_lit(s, "\tXI:f:"); sam_identity(s, h.identity);
+	sam_lit(s, "\tX0:i:"); sam_i64(s, h.n_best); sam_lit(s, "\tXE:i:"); sam_i64(s, (int) h.max_votes); sam_lit(s, "\tXR:i:"); sam_i64(s, L - h.qstart - h.qend);
+	sam_lit(s, "\tMD:Z:"); s.bytes(A.str + rf.md_off, rf.md_len);
+	s.put('\n');
+}
+// SAMWriter::DoWriteUnmappedReadGeneric (SAMWriter.cpp:311-372): contig < 0 prints '*'
+template <typename Sink>
+__device__ __forceinline__ void sam_unmapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int contig, unsigned long long pos1, char rnext, unsigned long long pnext1) {
+	const int qlen = v.m.qual_len & 0x7FFF;
+	s.bytes(A.names + v.m.name_off, v.m.name_len); s.put('\t'); sam_u64(s, (unsigned) (flags | 0x4)); s.put('\t');
+	if (contig >= 0) sam_contig(A, s, contig); else s.put('*');
+	s.put('\t'); sam_u64(s, pos1); sam_lit(s, "\t0\t*\t"); s.put(rnext); s.put('\t'); sam_u64(s, pnext1); sam_lit(s, "\t0\t");
+	s.seq_fwd(v.row, v.L); s.put('\t');
+	if (qlen == 0) s.put('*'); else s.seq_fwd(v.qual, min(qlen, v.L));
+	if (A.rg_len > 0) { sam_lit(s, "\tRG:Z:"); s.bytes(A.rg, (uint32_t) A.rg_len); }
+	s.put('\n');
+}
+
+// one unit: read `unit` (single-end) or reads 2 * unit, 2 * unit + 1 (paired).  cnt: reads counted / mapped, lines written
+template <typename Sink>
+__device__ __forceinline__ void sam_unit(const SamArgs &A, int unit, Sink &s, uint32_t (&cnt)[3]) {
+	if (!A.paired) {
+		const SamView v = sam_view(A, unit);
+		if (v.m.qual_len & 0x8000u) return;  // NGMNames::Empty reads are discarded (GenericReadWriter.h:245-247)
+		++cnt[0];
+		if (!sam_passes(A, v)) { if (!A.no_unal) { sam_unmapped(A, s, v, 0, -1, 0, '*', 0); ++cnt[2]; } return; }
+		++cnt[1];
+		sam_mapped(A, s, v, 0, 0, 0, 0, 0); ++cnt[2];
+		return;
+	}
+	// read1 = the first mate (even ReadId), written second by AlignmentBuffer::WriteRead; read2 = its mate
+	const SamView v1 = sam_view(A, 2 * unit), v2 = sam_view(A, 2 * unit + 1);
+	if ((v1.m.qual_len & 0x8000u) || (v2.m.qual_len & 0x8000u)) return;  // GenericReadWriter.h:250-252
+	cnt[0] += 2;
+	const ngm_hit &h1 = *v1.h, &h2 = *v2.h;
+	// AlignmentBuffer::WriteRead (AlignmentBuffer.cpp:175-199): is the pair consistent?
+	bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
+	if (h1.mapped && h2.mapped) {
+		const long long distance = (h2.pos > h1.pos) ? (long long) (h2.pos - h1.pos) + v1.L : (long long) (h1.pos - h2.pos) + v2.L;
+		if (h1.contig != h2.contig || distance < A.min_insert || distance > A.max_insert || h1.reverse == h2.reverse) paired_fail = true;
+	}
+	const bool m1 = sam_passes(A, v1), m2 = sam_passes(A, v2);  // GenericReadWriter::WritePair
+	cnt[1] += (m1 ? 1u : 0u) + (m2 ? 1u : 0u);
+	const int f1 = 0x1 | 0x40, f2 = 0x1 | 0x80;  // SAMWriter::DoWritePair (SAMWriter.cpp:230-310)
+	const unsigned long long p1 = h1.pos + 1, p2 = h2.pos + 1;
+	const uint32_t unal = A.no_unal ? 0u : 1u;
+	if (!m1 && !m2) {
+		if (unal) { sam_unmapped(A, s, v2, f2 | 0x8, -1, 0, '*', 0); sam_unmapped(A, s, v1, f1 | 0x8, -1, 0, '*', 0); }
+		cnt[2] += 2 * unal;
+	} else if (!m1) {
+		sam_mapped(A, s, v2, f2 | 0x8, 1, 0, p2, 0);
+		if (unal) sam_unmapped(A, s, v1, f1, h2.contig, p2, '=', p2);
+		cnt[2] += 1 + unal;
+	} else if (!m2) {
+		if (unal) sam_unmapped(A, s, v2, f2, h1.contig, p1, '=', p1);
+		sam_mapped(A, s, v1, f1 | 0x8, 1, 0, p1, 0);
+		cnt[2] += 1 + unal;
+	} else if (!paired_fail) {
+		if (!h1.reverse) {
+			const long long d = ((long long) h2.pos + v2.L - h2.qstart - h2.qend) - (long long) h1.pos;
+			sam_mapped(A, s, v2, f2 | 0x2, 1, 0, p1, -d);
+			sam_mapped(A, s, v1, f1 | 0x2 | 0x20, 1, 0, p2, d);
+			cnt[2] += 2;
+		} else if (!h2.reverse) {
+			const long long d = ((long long) h1.pos + v1.L - h1.qstart - h1.qend) - (long long) h2.pos;
+			sam_mapped(A, s, v2, f2 | 0x2 | 0x20, 1, 0, p1, d);
+			sam_mapped(A, s, v1, f1 | 0x2, 1, 0, p2, -d);
+			cnt[2] += 2;
+		}
+	} else {
+		sam_mapped(A, s, v2, f2 | (h1.reverse ? 0x20 : 0), 2, h1.contig, p1, 0);
+		sam_mapped(A, s, v1, f1 | (h2.reverse ? 0x20 : 0), 2, h2.contig, p2, 0);
+		cnt[2] += 2;
+	}
+}
+
+#ifdef NGM_SAM_KERNELS
+__global__ __launch_bounds__(256) void sam_lengths_kernel(SamArgs A, int units) {
+	const int u = blockIdx.x * blockDim.x + threadIdx.x;
+	if (u >= units) return;
+	SamCountSink s;
+	uint32_t cnt[3] = {0, 0, 0};
+	sam_unit(A, u, s, cnt);
+	A.unit_len[u] = s.n;
+}
+__global__ __launch_bounds__(256) void sam_write_kernel(SamArgs A, int units) {
+	__shared__ uint32_t s_cnt[3];
+	if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const int u = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t cnt[3] = {0, 0, 0};
+	if (u < units) {
+		SamWriteSink s{A.out + A.unit_off[u]};
+		sam_unit(A, u, s, cnt);
+	}
+	for (int k = 0; k < 3; ++k) if (cnt[k]) atomicAdd(&s_cnt[k], cnt[k]);
+	__syncthreads();
+	if (threadIdx.x < 3 && s_cnt[threadIdx.x]) atomicAdd(&A.counters[threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
+}
+#endif
+
+}  // namespace ngm

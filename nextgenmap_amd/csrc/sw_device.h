@@ -45,6 +45,12 @@ struct SwConst {
 	int gu;        // gap_read - mismatch
 	int gap_read;  // raw
 	int variant;   // NGM_VARIANT_*
+	// strand-specific tables of the reference's __ALT_SCORING__ builds (oclDefines.cl:94-128): 0 off, 1 bisulfite, 2 SLAM-seq.
+	// The pair's table (FWD / REV, the kernels' `direction` argument) travels in bit 3 of its packed READ classes, so the DP
+	// kernels just index a 16-row table with the class nibble.
+	int alt;
+	int tMA;       // matchALT - mismatch
+	int tXA;       // mismatchALT - mismatch
 };
 
 // Symbol class of a byte. oclDefines.cl:64-80: A/a 0, C/c 1, G/g 2, T/t 3, N/n 5, NUL 6, other 4.
@@ -60,8 +66,10 @@ __device__ __forceinline__ uint32_t sym_class(uint32_t ch) {
 	return k;
 }
 
-// Row table for read class rc: byte fc = t(rc, fc) = score(rc, fc) - mismatch. oclDefines.cl:85-91.
-__device__ __forceinline__ uint2 make_row_table(int rc, const SwConst &K) {
+// Row table for read class nibble rc16 = class | table << 3: byte fc = t(rc, fc) = score(rc, fc) - mismatch.
+// oclDefines.cl:85-91 ("scores"), :94-109 (bisulfite), :113-128 (SLAM-seq).
+__device__ __forceinline__ uint2 make_row_table(int rc16, const SwConst &K) {
+	const int rc = rc16 & 7, rev = (rc16 >> 3) & 1;
 	uint32_t b[8];
 	for (int fc = 0; fc < 8; ++fc) {
 		uint32_t t;
@@ -70,6 +78,13 @@ __device__ __forceinline__ uint2 make_row_table(int rc, const SwConst &K) {
 		else if (fc == 6) t = K.tZ;                              // ref NUL: 0
 		else if (rc == 4) t = 0;                                 // read "other": mismatch
 		else t = (fc == rc) ? K.tM : 0;                          // read ACGT
+		if (K.alt == 1) {          // bisulfite: read T vs C / T (FWD), read A vs A / G (REV); the REV tables' read-N row is all zero
+			if (!rev) { if (rc == 3 && fc == 1) t = K.tXA; if (rc == 3 && fc == 3) t = K.tMA; }
+			else { if (rc == 0 && fc == 0) t = K.tMA; if (rc == 0 && fc == 2) t = K.tXA; if (rc == 5) t = K.tZ; }
+		} else if (K.alt == 2) {   // SLAM-seq: read C vs T, read T vs T (FWD); read A vs A, read G vs A (REV)
+			if (!rev) { if (rc == 1 && fc == 3) t = K.tXA; if (rc == 3 && fc == 3) t = K.tMA; }
+			else { if (rc == 0 && fc == 0) t = K.tMA; if (rc == 2 && fc == 0) t = K.tXA; if (rc == 5) t = K.tZ; }
+		}
 		b[fc] = t & 0xFF;
 	}
 	uint2 r;
@@ -95,7 +110,7 @@ __device__ __forceinline__ uint32_t pack8(const uint32_t k[8]) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restrict__ ref,
 		const uint8_t *__restrict__ qry, int n, int q, int rl, int RW, int FW,
-		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows, int cstr_ref) {
+		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows, int cstr_ref, const uint8_t *__restrict__ dirs) {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ int s_first_nul[kSlots];
 	__shared__ int s_rows[kSlots];
@@ -151,6 +166,7 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restri
 		__syncthreads();
 	}
 	uint32_t *ob = out + (size_t) blk * (RW + FW) * kSlots + slot;
+	const uint32_t dbit = (dirs && p0 + slot < n && dirs[p0 + slot]) ? 8u : 0u;   // the pair's score table (SwConst::alt)
 	{
 		const uint8_t *row = lqry + slot * q;
 		int first_nul = q, rows = 0;
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const uint8_t *__restri
 			for (int j = 0; j < 8; ++j) {
 				const int i = m * 8 + j;
 				const uint32_t ch = (i < q) ? row[i] : 0u;
-				k[j] = s_trans[ch];
+				k[j] = s_trans[ch] | dbit;
 				if (ch == 0) first_nul = min(first_nul, i); else rows = max(rows, i + 1);
 			}
 			ob[(size_t) m * kSlots] = pack8(k);
@@ -199,8 +215,8 @@ template <int C, bool ENDFREE>
 __global__ __launch_bounds__(256) void sw_score_kernel(const uint32_t *__restrict__ packed,
 		const uint16_t *__restrict__ lens, const uint16_t *__restrict__ blk_rows,
 		float *__restrict__ scores, int n, int n_blocks, int RW, SwConst K) {
-	__shared__ uint2 s_tab[8];
-	if (threadIdx.x < 8) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
+	__shared__ uint2 s_tab[16];
+	if (threadIdx.x < 16) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int blk = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -309,8 +325,8 @@ template <int C, bool ENDFREE>
 __global__ __launch_bounds__(256) void sw_score_pk_kernel(const uint32_t *__restrict__ packed,
 		const uint16_t *__restrict__ lens, const uint16_t *__restrict__ blk_rows,
 		float *__restrict__ scores, int n, int n_blocks, int RW, SwConst K) {
-	__shared__ uint2 s_tab[8];
-	if (threadIdx.x < 8) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
+	__shared__ uint2 s_tab[16];
+	if (threadIdx.x < 16) s_tab[threadIdx.x] = make_row_table(threadIdx.x, K);
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const int blkA = 2 * (blockIdx.x * 4 + (threadIdx.x >> 6));

@@ -15,7 +15,7 @@ VARIANT_OCL_GPU = 0
 VARIANT_OCL_CPU = 1
 PERSONALITY_LINEAR = 0   # the OpenCL plugin (default)
 PERSONALITY_AFFINE = 1   # `ngm --affine`: EndToEndAffine over SeqAn's banded Gotoh alignment
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -29,7 +29,7 @@ class Params(C.Structure):
                 ("match_bonus", C.c_int), ("mismatch_penalty", C.c_int), ("gap_read_penalty", C.c_int),
                 ("gap_ref_penalty", C.c_int), ("variant", C.c_int), ("hard_clip", C.c_int),
                 ("silent_clip", C.c_int), ("max_batch", C.c_int), ("personality", C.c_int),
-                ("gap_extend_penalty", C.c_int)]
+                ("gap_extend_penalty", C.c_int), ("alt_scoring", C.c_int), ("match_bonus_tt", C.c_int), ("match_bonus_tc", C.c_int)]
 
 
 class AlignOut(C.Structure):
@@ -93,12 +93,12 @@ class Engine:
 
     def __init__(self, qry_max_len, corridor, match=10, mismatch=15, gap_read=20, gap_ref=20, device=0,
                  variant=VARIANT_OCL_GPU, hard_clip=0, silent_clip=0, max_batch=0, personality=PERSONALITY_LINEAR,
-                 gap_extend=0):
+                 gap_extend=0, alt_scoring=0, match_bonus_tt=0, match_bonus_tc=0):
         self.lib = load_library()
         self.q, self.c = int(qry_max_len), int(corridor)
         self.personality = int(personality)
         p = Params(ABI_VERSION, self.q, self.c, match, mismatch, gap_read, gap_ref, variant, hard_clip, silent_clip, max_batch,
-                   self.personality, gap_extend)
+                   self.personality, gap_extend, alt_scoring, match_bonus_tt, match_bonus_tc)
         self.h = self.lib.ngm_hip_create(device, C.byref(p))
         if not self.h:
             raise NgmHipError(self.lib.ngm_hip_last_error(None).decode())
@@ -135,15 +135,16 @@ class Engine:
         qp = (C.c_void_p * n)(*[qry.ctypes.data + i * qry.strides[0] for i in range(n)])
         return n, ref, qry, rp, qp
 
-    def BatchScore(self, mode, ref, qry):
-        """ref [n, >=q+c] uint8 rows, qry [n, >=q] uint8 rows (NUL padded) -> float32[n]."""
+    def BatchScore(self, mode, ref, qry, dirs=None):
+        """ref [n, >=q+c] uint8 rows, qry [n, >=q] uint8 rows (NUL padded) -> float32[n].  dirs: extData (alt_scoring)."""
         n, ref, qry, rp, qp = self._ptr_lists(ref, qry)
         out = np.full(n, -1.0, dtype=np.float32)  # ScoreBuffer.cpp:120
-        r = self._check(self.lib.ngm_hip_batch_score(self.h, mode, n, rp, qp, out.ctypes.data, None), n)
+        d = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.uint8)
+        r = self._check(self.lib.ngm_hip_batch_score(self.h, mode, n, rp, qp, out.ctypes.data, None if d is None else d.ctypes.data), n)
         assert r == n
         return out
 
-    def BatchAlign(self, mode, ref, qry):
+    def BatchAlign(self, mode, ref, qry, dirs=None):
         """-> list of dicts(cigar, md, position_offset, qstart, qend, score_token, identity, nm)."""
         n, ref, qry, rp, qp = self._ptr_lists(ref, qry)
         stride = 4 * max(1, self.q)  # AlignmentBuffer.cpp:106-109
@@ -155,7 +156,8 @@ class Engine:
         for i in range(n):
             outs[i].cigar = cig.ctypes.data + i * stride
             outs[i].md = md.ctypes.data + i * stride
-        r = self._check(self.lib.ngm_hip_batch_align(self.h, mode, n, rp, qp, outs, None), n)
+        d = None if dirs is None else np.ascontiguousarray(dirs, dtype=np.uint8)
+        r = self._check(self.lib.ngm_hip_batch_align(self.h, mode, n, rp, qp, outs, None if d is None else d.ctypes.data), n)
         assert r == n
         res = []
         for i in range(n):

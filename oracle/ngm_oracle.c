@@ -35,8 +35,17 @@ int ngm_oracle_sym_class(unsigned char ch) {
 	}
 }
 
-/* oclDefines.cl:85-91, table "scores": rows = read class, columns = ref class. */
+/* oclDefines.cl:85-91, table "scores": rows = read class, columns = ref class; with sc->alt the tables of the
+ * __ALT_SCORING__ builds (oclDefines.cl:94-128), which differ from "scores" in two rows each -- and in the read-N row of the
+ * REV tables, which is all zero there (oclDefines.cl:108, :127). */
 int ngm_oracle_pair_score(const ngm_oracle_scoring *sc, int rc, int fc) {
+	if (sc->alt == 1) {          /* bisulfite */
+		if (sc->dir == 0) { if (rc == 3 && fc == 1) return sc->mismatch_alt; if (rc == 3 && fc == 3) return sc->match_alt; }  /* read T vs C / T */
+		else { if (rc == 0 && fc == 0) return sc->match_alt; if (rc == 0 && fc == 2) return sc->mismatch_alt; if (rc == 5) return 0; }  /* read A vs A / G */
+	} else if (sc->alt == 2) {   /* SLAM-seq */
+		if (sc->dir == 0) { if (rc == 1 && fc == 3) return sc->mismatch_alt; if (rc == 3 && fc == 3) return sc->match_alt; }  /* read C vs T, read T vs T */
+		else { if (rc == 0 && fc == 0) return sc->match_alt; if (rc == 2 && fc == 0) return sc->mismatch_alt; if (rc == 5) return 0; }  /* read A vs A, read G vs A */
+	}
 	if (rc == 6) return 0;                       /* read NUL: every column 0 */
 	if (rc == 5) return fc <= 3 ? 0 : sc->mismatch; /* read N: free vs ACGT, else mismatch */
 	if (fc == 6) return 0;                       /* ref NUL vs read ACGT/other: 0 */
@@ -128,7 +137,9 @@ void ngm_oracle_align_trace(int mode, const char *ref, const char *qry, int q, i
 			int m = local ? imax(0, left) : left;
 			m = imax(diag, m);
 			m = imax(up, m);
-			const int is_eq = (variant == NGM_ORACLE_VARIANT_CPU) ? (s == sc->match) : (qry[i] == ref[i + d]);
+			/* '=' / 'X': __GPU__ by character equality; __CPU__ by score == match, or -- __ALT_SCORING__ -- by class equality
+			 * (oclSwScore.cl:65 / :69, oclEndFreeScore.cl alike) */
+			const int is_eq = (variant == NGM_ORACLE_VARIANT_CPU) ? (sc->alt ? (rc == ngm_oracle_sym_class((unsigned char) ref[i + d])) : (s == sc->match)) : (qry[i] == ref[i + d]);
 			unsigned char ptr;
 			if (local && m <= 0) ptr = NGM_OP_STOP;
 			else if (m == diag || m == prev + sc->mismatch) ptr = is_eq ? NGM_OP_EQ : NGM_OP_X;
@@ -179,15 +190,24 @@ void ngm_oracle_align_trace(int mode, const char *ref, const char *qry, int q, i
 	free(M);
 }
 
-/* computeCigarMD: lib/mason/opencl/SWOclCigar.cpp:430-615, bs_mapping and slam_seq off. */
+/* computeCigarMD: lib/mason/opencl/SWOclCigar.cpp:430-615. */
 void ngm_oracle_cigar_md(const ngm_oracle_trace *tr, const short *rle, const char *ref,
 		const char *qry, int q, int c, int hard_clip, int silent_clip,
 		ngm_oracle_align *out, char *cigar, char *md) {
+	ngm_oracle_cigar_md_alt(tr, rle, ref, qry, q, c, hard_clip, silent_clip, 0, 0, out, cigar, md);
+}
+
+void ngm_oracle_cigar_md_alt(const ngm_oracle_trace *tr, const short *rle, const char *ref,
+		const char *qry, int q, int c, int hard_clip, int silent_clip, int alt, int dir,
+		ngm_oracle_align *out, char *cigar, char *md) {
+	/* SWOclCigar.cpp:300-317 */
+	char bs_from = '0', bs_to = '0';
+	if (alt == 1) { if (dir == 1) { bs_from = 'A'; bs_to = 'G'; } else { bs_from = 'T'; bs_to = 'C'; } }
+	if (alt == 2) { if (dir == 1) { bs_from = 'G'; bs_to = 'A'; } else { bs_from = 'C'; bs_to = 'T'; } }
 	const int alignment_length = 2 * q + c + 1;
 	memset(out, 0, sizeof(*out));
 	cigar[0] = 0;
 	md[0] = 0;
-	(void) qry;
 	if (!tr->valid) return;
 	const char *refseq = ref + tr->ref_position; /* SWOclCigar.cpp:324 */
 	int co = 0, mo = 0;
@@ -206,9 +226,12 @@ void ngm_oracle_cigar_md(const ngm_oracle_trace *tr, const short *rle, const cha
 		switch (op) {
 		case NGM_OP_X:
 			m_len += len;
-			mismatch += len;
+			if (!alt) mismatch += len;
 			mo += sprintf(md + mo, "%d", md_eq);
-			for (int k = 0; k < len; ++k) { md[mo++] = refseq[ref_i++]; read_i += 1; }
+			for (int k = 0; k < len; ++k) {
+				if (alt) { if (qry[read_i] == bs_from && refseq[ref_i] == bs_to) match += 1; else mismatch += 1; }  /* :507-514 */
+				md[mo++] = refseq[ref_i++]; read_i += 1;
+			}
 			md_eq = 0;
 			break;
 		case NGM_OP_EQ:
@@ -258,7 +281,7 @@ void ngm_oracle_align_pair(int mode, const char *ref, const char *qry, int q, in
 	ngm_oracle_trace tr;
 	short *rle = (short *) malloc(sizeof(short) * 2 * (size_t) (2 * q + c + 1));
 	ngm_oracle_align_trace(mode, ref, qry, q, c, sc, variant, &tr, rle);
-	ngm_oracle_cigar_md(&tr, rle, ref, qry, q, c, hard_clip, silent_clip, out, cigar, md);
+	ngm_oracle_cigar_md_alt(&tr, rle, ref, qry, q, c, hard_clip, silent_clip, sc->alt, sc->dir, out, cigar, md);
 	free(rle);
 }
 
@@ -287,6 +310,39 @@ void ngm_oracle_batch_align(int mode, int n, const char *ref, long ref_stride, c
 	for (int i = 0; i < n; ++i) {
 		ngm_oracle_align_pair(mode & 0xFF, ref + (long) i * ref_stride, qry + (long) i * qry_stride,
 				q, c, sc, variant, hard_clip, silent_clip, out + i, cigars + (long) i * str_stride,
+				mds + (long) i * str_stride);
+	}
+}
+
+void ngm_oracle_batch_score_alt(int mode, int n, const char *ref, long ref_stride, const char *qry,
+		long qry_stride, int q, int c, const ngm_oracle_scoring *sc, int variant, const char *dirs,
+		float *scores, int nthreads) {
+	(void) nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+	for (int i = 0; i < n; ++i) {
+		ngm_oracle_scoring s1 = *sc;
+		s1.dir = dirs ? (dirs[i] != 0) : 0;
+		const char *r = ref + (long) i * ref_stride, *s = qry + (long) i * qry_stride;
+		scores[i] = (float) ((mode & 0xFF) == 0 ? ngm_oracle_score_local(r, s, q, c, &s1, variant)
+				: ngm_oracle_score_endfree(r, s, q, c, &s1, variant));
+	}
+}
+
+void ngm_oracle_batch_align_alt(int mode, int n, const char *ref, long ref_stride, const char *qry,
+		long qry_stride, int q, int c, const ngm_oracle_scoring *sc, int variant, const char *dirs,
+		int hard_clip, int silent_clip, ngm_oracle_align *out, char *cigars, char *mds,
+		long str_stride, int nthreads) {
+	(void) nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+	for (int i = 0; i < n; ++i) {
+		ngm_oracle_scoring s1 = *sc;
+		s1.dir = dirs ? (dirs[i] != 0) : 0;
+		ngm_oracle_align_pair(mode & 0xFF, ref + (long) i * ref_stride, qry + (long) i * qry_stride,
+				q, c, &s1, variant, hard_clip, silent_clip, out + i, cigars + (long) i * str_stride,
 				mds + (long) i * str_stride);
 	}
 }

@@ -25,6 +25,12 @@ typedef struct ngm_oracle_scoring {
 	int mismatch;  /* < 0 */
 	int gap_read;  /* < 0, charged per read base consumed without a ref base (CIGAR I) */
 	int gap_ref;   /* < 0, charged per ref base consumed without a read base (CIGAR D) */
+	/* -D__ALT_SCORING__ builds (lib/mason/opencl/SWOcl.cpp:225-242): 0 = off (tables "scores"), 1 = bisulfite
+	 * (scoresBsFWD / scoresBsREV, oclDefines.cl:94-109), 2 = SLAM-seq (scoresSlamSeqFWD / REV, oclDefines.cl:113-128) */
+	int alt;
+	int match_alt;     /* -D matchALT    = Config MATCH_BONUS_TT */
+	int mismatch_alt;  /* -D mismatchALT = Config MATCH_BONUS_TC (bisulfite) or its negation (SLAM-seq) */
+	int dir;           /* the pair's entry of the kernels' `direction` argument (extData, src/ScoreBuffer.cpp:93-110): 0 = FWD table */
 } ngm_oracle_scoring;
 
 /* Which build of the reference kernels is being restated where they differ
@@ -90,6 +96,13 @@ void ngm_oracle_cigar_md(const ngm_oracle_trace *tr, const short *rle, const cha
 		const char *qry, int q, int c, int hard_clip, int silent_clip,
 		ngm_oracle_align *out, char *cigar, char *md);
 
+/* ... with bs_mapping (alt 1) / slam_seq (alt 2) on: a mismatch column whose read base is bsFrom and whose reference base is
+ * bsTo counts as a match, every other one as a mismatch (NM) -- SWOclCigar.cpp:300-317 (bsFrom / bsTo from the pair's
+ * direction), :496-520. */
+void ngm_oracle_cigar_md_alt(const ngm_oracle_trace *tr, const short *rle, const char *ref,
+		const char *qry, int q, int c, int hard_clip, int silent_clip, int alt, int dir,
+		ngm_oracle_align *out, char *cigar, char *md);
+
 /* Convenience: full BatchAlign for one pair (trace + cigar/md). */
 void ngm_oracle_align_pair(int mode, const char *ref, const char *qry, int q, int c,
 		const ngm_oracle_scoring *sc, int variant, int hard_clip, int silent_clip,
@@ -101,6 +114,15 @@ void ngm_oracle_batch_score(int mode, int n, const char *ref, long ref_stride, c
 		float *scores, int nthreads);
 void ngm_oracle_batch_align(int mode, int n, const char *ref, long ref_stride, const char *qry,
 		long qry_stride, int q, int c, const ngm_oracle_scoring *sc, int variant,
+		int hard_clip, int silent_clip, ngm_oracle_align *out, char *cigars, char *mds,
+		long str_stride, int nthreads);
+
+/* the same with the per-pair `direction` bytes of the __ALT_SCORING__ builds (dirs == NULL: all 0) */
+void ngm_oracle_batch_score_alt(int mode, int n, const char *ref, long ref_stride, const char *qry,
+		long qry_stride, int q, int c, const ngm_oracle_scoring *sc, int variant, const char *dirs,
+		float *scores, int nthreads);
+void ngm_oracle_batch_align_alt(int mode, int n, const char *ref, long ref_stride, const char *qry,
+		long qry_stride, int q, int c, const ngm_oracle_scoring *sc, int variant, const char *dirs,
 		int hard_clip, int silent_clip, ngm_oracle_align *out, char *cigars, char *mds,
 		long str_stride, int nthreads);
 

@@ -11,7 +11,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 
 class Scoring(C.Structure):
-    _fields_ = [("match", C.c_int), ("mismatch", C.c_int), ("gap_read", C.c_int), ("gap_ref", C.c_int)]
+    _fields_ = [("match", C.c_int), ("mismatch", C.c_int), ("gap_read", C.c_int), ("gap_ref", C.c_int),
+                ("alt", C.c_int), ("match_alt", C.c_int), ("mismatch_alt", C.c_int), ("dir", C.c_int)]
 
 
 class Trace(C.Structure):
@@ -28,6 +29,10 @@ ALIGN_DTYPE = np.dtype([("ok", "i4"), ("position_offset", "i4"), ("qstart", "i4"
                         ("nm", "i4"), ("identity", "f4"), ("score_token", "f4")])
 
 DEFAULT_SCORING = dict(match=10, mismatch=-15, gap_read=-20, gap_ref=-20)
+# `ngm --bs-mapping` (src/config/Config.cpp:461-467; matchALT = MATCH_BONUS_TT, mismatchALT = MATCH_BONUS_TC) and the
+# scores of a `--slam-seq 2` run (Config.cpp:433-447; mismatchALT = -MATCH_BONUS_TC, lib/mason/opencl/SWOcl.cpp:233-238)
+BS_SCORING = dict(match=4, mismatch=-2, gap_read=-10, gap_ref=-10, alt=1, match_alt=4, mismatch_alt=4)
+SLAM_SCORING = dict(match=10, mismatch=-15, gap_read=-20, gap_ref=-20, alt=2, match_alt=10, mismatch_alt=-2)
 
 
 def _build(target):
@@ -49,6 +54,11 @@ def oracle():
         lib.ngm_oracle_batch_align.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
                                                C.c_int, C.c_int, C.POINTER(Scoring), C.c_int, C.c_int, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]
+        lib.ngm_oracle_batch_score_alt.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                                   C.c_int, C.c_int, C.POINTER(Scoring), C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        lib.ngm_oracle_batch_align_alt.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                                   C.c_int, C.c_int, C.POINTER(Scoring), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int]
         lib.ngm_oracle_align_trace.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                C.POINTER(Scoring), C.c_int, C.POINTER(Trace), C.c_void_p]
         _oracle = lib
@@ -62,20 +72,29 @@ def _sc(scoring):
     return Scoring(**s)
 
 
-def oracle_score(mode, ref, qry, c, scoring=None, variant=0, nthreads=1):
-    """ref [n, q+c] uint8, qry [n, q] uint8 -> float32[n]"""
+def _dirs(dirs, n):
+    if dirs is None:
+        return None, None
+    d = np.ascontiguousarray(dirs, dtype=np.uint8)
+    assert d.shape == (n,)
+    return d, d.ctypes.data
+
+
+def oracle_score(mode, ref, qry, c, scoring=None, variant=0, nthreads=1, dirs=None):
+    """ref [n, q+c] uint8, qry [n, q] uint8 -> float32[n]; dirs: the per-pair direction bytes of the ALT scoring modes"""
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     qry = np.ascontiguousarray(qry, dtype=np.uint8)
     n, q = qry.shape
     assert ref.shape == (n, q + c)
     out = np.empty(n, dtype=np.float32)
     sc = _sc(scoring)
-    oracle().ngm_oracle_batch_score(mode, n, ref.ctypes.data, ref.strides[0], qry.ctypes.data, qry.strides[0],
-                                    q, c, C.byref(sc), variant, out.ctypes.data, nthreads)
+    d, dp = _dirs(dirs, n)
+    oracle().ngm_oracle_batch_score_alt(mode, n, ref.ctypes.data, ref.strides[0], qry.ctypes.data, qry.strides[0],
+                                        q, c, C.byref(sc), variant, dp, out.ctypes.data, nthreads)
     return out
 
 
-def oracle_align(mode, ref, qry, c, scoring=None, variant=0, hard_clip=0, silent_clip=0, nthreads=1):
+def oracle_align(mode, ref, qry, c, scoring=None, variant=0, hard_clip=0, silent_clip=0, nthreads=1, dirs=None):
     """-> (structured array ALIGN_DTYPE [n], cigars list[bytes], mds list[bytes])"""
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     qry = np.ascontiguousarray(qry, dtype=np.uint8)
@@ -85,15 +104,16 @@ def oracle_align(mode, ref, qry, c, scoring=None, variant=0, hard_clip=0, silent
     cig = np.zeros((n, stride), dtype=np.uint8)
     md = np.zeros((n, stride), dtype=np.uint8)
     sc = _sc(scoring)
-    oracle().ngm_oracle_batch_align(mode, n, ref.ctypes.data, ref.strides[0], qry.ctypes.data, qry.strides[0],
-                                    q, c, C.byref(sc), variant, hard_clip, silent_clip, res.ctypes.data,
-                                    cig.ctypes.data, md.ctypes.data, stride, nthreads)
+    d, dp = _dirs(dirs, n)
+    oracle().ngm_oracle_batch_align_alt(mode, n, ref.ctypes.data, ref.strides[0], qry.ctypes.data, qry.strides[0],
+                                        q, c, C.byref(sc), variant, dp, hard_clip, silent_clip, res.ctypes.data,
+                                        cig.ctypes.data, md.ctypes.data, stride, nthreads)
     cigs = [bytes(r).split(b"\0", 1)[0] for r in cig]
     mds = [bytes(r).split(b"\0", 1)[0] for r in md]
     return res, cigs, mds
 
 
-def oracle_trace(mode, ref, qry, c, scoring=None, variant=0):
+def oracle_trace(mode, ref, qry, c, scoring=None, variant=0, dirs=None):
     """Raw kernel-level outputs: (results4 int16 [n,4] as the reference leaves them, rle int16 [n, 2*AL],
     valid bool[n], best_score int32[n])."""
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
@@ -108,6 +128,7 @@ def oracle_trace(mode, ref, qry, c, scoring=None, variant=0):
     tr = Trace()
     lib = oracle()
     for i in range(n):
+        sc.dir = int(dirs[i] != 0) if dirs is not None else 0
         lib.ngm_oracle_align_trace(mode, ref[i].ctypes.data, qry[i].ctypes.data, q, c, C.byref(sc), variant,
                                    C.byref(tr), rle[i].ctypes.data)
         valid[i] = bool(tr.valid)

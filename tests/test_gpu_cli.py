@@ -318,3 +318,86 @@ def test_cli_paired_end_repeat_rich_genome(tmp_path):
     print("records differing:", len(diff), "of", len(a), "; records with NH > 1:", multi)
     assert multi > 50  # the case really has pairs of equal score and insert size
     assert len(diff) == 0, (len(diff), diff[:3])
+
+
+def _body(path):
+    return b"".join(l for l in open(path, "rb") if not l.startswith(b"@PG"))
+
+
+@pytest.mark.parametrize("case", ["se", "se-linear-hardclip-rg", "se-silentclip-nounal-filters", "se-fasta-gz", "pe", "pe-linear-nounal-rg", "pe-small-batches"])
+def test_sam_assembled_on_the_gpu_equals_the_host_formatter(tmp_path, case):
+    """csrc/sam_device.h vs the host formatter of ngm_cli.cpp (NGM_HIP_HOST_SAM=1; the one every reference comparison above was
+    written against): the files must be byte-identical -- names, flags, mate fields, TLEN, clipped / reverse-complemented
+    sequences and qualities, tags, unmapped records, the filters, read groups."""
+    from nextgenmap_amd import build
+    build.build()
+    contigs = S.make_genome([300000, 200001], seed=71, repeat_families=6, repeat_len=400, copies=5)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    rng = np.random.default_rng(9)
+    extra = []
+    if case.startswith("se"):
+        reads = S.make_reads(contigs, 5000, 100, seed=72, sub_rate=0.03, indel_rate=0.004)
+        reads[5] = (reads[5][0], np.full(100, ord("N"), np.uint8), reads[5][2])
+        for k in range(10, 400, 7):   # junk reads (unmapped records) and reads with a junk tail (clipping)
+            reads[k] = (reads[k][0], S.ACGT[rng.integers(0, 4, 100)], reads[k][2])
+        for k in range(11, 800, 5):
+            s = reads[k][1].copy(); s[70:] = S.ACGT[rng.integers(0, 4, 30)]
+            reads[k] = (reads[k][0], s, reads[k][2])
+        # varied qualities and lengths, so that reversed / clipped quality strings are told apart
+        reads = [(n, s[:100 - (i % 9)], (33 + (np.arange(len(s[:100 - (i % 9)])) * 7 + i) % 40).astype(np.uint8).tobytes()) for i, (n, s, q) in enumerate(reads)]
+        if case == "se-fasta-gz":
+            import gzip
+            fq = str(tmp_path / "reads.fa.gz")
+            with gzip.open(fq, "wb") as f:
+                for n, s, q in reads:
+                    f.write(b">" + n.encode() + b" comment\n" + s.tobytes() + b"\n")
+        else:
+            fq = str(tmp_path / "reads.fq")
+            S.write_fastq(fq, reads)
+        inp = ["-q", fq]
+        if case == "se-linear-hardclip-rg":
+            extra = ["--hard-clip", "--rg-id", "grp1", "--rg-sm", "sample"]
+        elif case == "se-silentclip-nounal-filters":
+            extra = ["--affine", "--silent-clip", "--no-unal", "-i", "0.9", "-R", "0.8", "-Q", "10"]
+        else:
+            extra = ["--affine"]
+    else:
+        r1, r2 = S.make_reads(contigs, 3000, 100, seed=73, sub_rate=0.02, indel_rate=0.003, paired=True)
+        for k in range(0, 90, 3):
+            r2[k] = (r2[k][0], S.ACGT[rng.integers(0, 4, 100)], r2[k][2])
+        for k in range(1, 90, 3):
+            r2[k] = (r2[k][0], r2[k + 300][1], r2[k][2])
+        for k in range(2, 60, 3):
+            r1[k] = (r1[k][0], S.ACGT[rng.integers(0, 4, 100)], r1[k][2])
+        for k in range(100, 130):   # both mates junk
+            r1[k] = (r1[k][0], S.ACGT[rng.integers(0, 4, 100)], r1[k][2]); r2[k] = (r2[k][0], S.ACGT[rng.integers(0, 4, 100)], r2[k][2])
+        r1 = [(n, s, (33 + (np.arange(len(s)) * 3 + i) % 40).astype(np.uint8).tobytes()) for i, (n, s, q) in enumerate(r1)]
+        r2 = [(n, s, (33 + (np.arange(len(s)) * 5 + i) % 40).astype(np.uint8).tobytes()) for i, (n, s, q) in enumerate(r2)]
+        f1, f2 = str(tmp_path / "pe_1.fq"), str(tmp_path / "pe_2.fq")
+        S.write_fastq(f1, r1)
+        S.write_fastq(f2, r2)
+        inp = ["-1", f1, "-2", f2]
+        extra = {"pe": ["--affine"], "pe-linear-nounal-rg": ["--no-unal", "--rg-id", "x", "-X", "420"], "pe-small-batches": ["--affine", "--batch-size", "1024", "--workers", "3"]}[case]
+    outs = []
+    for host in (0, 1):
+        out = str(tmp_path / ("host.sam" if host else "gpu.sam"))
+        env = dict(os.environ)
+        if host:
+            env["NGM_HIP_HOST_SAM"] = "1"
+        c = subprocess.run([CLI, "-r", fa, "-o", out] + inp + extra, capture_output=True, text=True, env=env)
+        assert c.returncode == 0, c.stderr[-2000:]
+        assert ("SAM text assembled on the GPU" in c.stderr) == (not host)
+        outs.append((out, re.search(r"Done \((.*)\)", c.stderr).group(1)))
+    assert outs[0][1] == outs[1][1]            # reads mapped / not mapped / lines written
+    a, b = _body(outs[0][0]), _body(outs[1][0])
+    assert len(b) > 100000
+    if a != b:
+        la, lb = a.split(b"\n"), b.split(b"\n")
+        bad = [(x, y) for x, y in zip(la, lb) if x != y][:3]
+        raise AssertionError("GPU-assembled SAM differs from the host formatter: %d vs %d lines; first: %r" % (len(la), len(lb), bad))
