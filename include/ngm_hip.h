@@ -80,6 +80,8 @@ typedef struct ngm_hip_params {
 	int alt_scoring;        /* NGM_ALT_* */
 	int match_bonus_tt;     /* Config MATCH_BONUS_TT (-D matchALT) */
 	int match_bonus_tc;     /* Config MATCH_BONUS_TC (-D mismatchALT; SLAM-seq: its negation) */
+	int alt_cigar;          /* NGM_ALT_*: computeCigarMD counts the strand's conversion as a match for NM / Identity (SWOclCigar.cpp:300-317,
+	                         * :496-520): bs_mapping, or ANY slam_seq value -- also one that leaves the score tables alone (slam_seq & 2 == 0) */
 } ngm_hip_params;
 #define NGM_ALT_NONE 0
 #define NGM_ALT_BISULFITE 1   /* Config "bs_mapping" == 1: tables scoresBsFWD / scoresBsREV, bsFrom/bsTo T>C (dir 0), A>G (dir 1) */

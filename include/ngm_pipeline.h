@@ -67,6 +67,10 @@ int ngm_ref_decode(const ngm_ref *r, uint64_t offset, int buffer_len, char *out)
  * position lies in a spacer (reported unmapped), 1 otherwise. */
 int ngm_ref_convert(const ngm_ref *r, uint64_t pos, int *contig, uint64_t *contig_pos);
 
+/* n symbol classes (A0 C1 G2 T3 x4 N5) of the encoded genome from concatenated position `pos` on, from the host copy (what a
+ * record formatter needs to label the columns of an alignment, e.g. for the SLAM-seq tags); returns the number copied. */
+int ngm_ref_host_classes(const ngm_ref *r, uint64_t pos, int n, uint8_t *out);
+
 /* Write NextGenMap's own cache files next to `fasta_path` so that the reference program loads this encoded
  * genome and index instead of rebuilding them: <fasta_path>-enc.2.ngm (src/SequenceProvider.cpp:189-208) and
  * <fasta_path>-ht-<k>-<skip>.3.ngm (src/PrefixTable.cpp:819-855).  Content is what NGM itself would write. */
@@ -92,6 +96,17 @@ typedef struct ngm_mapper_params {
 	/* ScoreBuffer::topNSE (src/ScoreBuffer.cpp:279-327), single-end only as in the reference */
 	int topn;              /* Config "topn" (-n): alignments reported per read; <= 1: one */
 	int strata;            /* Config "strata": only the equally best ones, none if there are more than topn */
+	/* `--bs-mapping` (src/CS.cpp:54-112, :340-376, :553-560; lib/mason/opencl/SWOcl.cpp:225-232): candidate search looks every read
+	 * k-mer up in all its T>C (second mates: A>G) conversions, scoring uses the strand-specific tables.  The reference index must
+	 * have been built with kmer_skip 0 (src/PrefixTable.cpp:199-207); the run's "kmer_skip" applies to the read instead. */
+	int bs_mapping;        /* Config "bs_mapping" */
+	int bs_cutoff;         /* Config "bs_cutoff" (6): k-mers with more convertible bases are not looked up */
+	int bs_read_skip;      /* Config "kmer_skip" of the run (2) */
+	int match_bonus_tt, match_bonus_tc;   /* Config MATCH_BONUS_TT / MATCH_BONUS_TC (4 / 4) */
+	/* `--slam-seq <n>` (Config SLAM_SEQ): any value makes computeCigarMD count T>C (reverse strand: A>G) columns as matches and the
+	 * writer add TC / RA / MP tags; bit 1 (2) also switches the score tables (scoresSlamSeqFWD / REV, match_bonus_tt / -match_bonus_tc);
+	 * bit 2 (4) -- the weighted k-mer mutation search (src/CS.cpp:69-75, :133-138) -- is not implemented: refused. */
+	int slam_seq;
 } ngm_mapper_params;
 
 ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p);
@@ -160,6 +175,8 @@ typedef struct ngm_sam_options {
 	float min_identity, min_residues;       /* Config "min_identity" (0.65), "min_residues" (0.5; <= 1: share of the read length) */
 	int no_unal;                /* Config "no_unal": unmapped reads are not written */
 	const char *rg_id;          /* read group id for the RG:Z tag, or NULL */
+	int bs_mapping;             /* Config "bs_mapping": the ZS:Z tag (src/writer/SAMWriter.cpp:173-187) */
+	int slam_seq;               /* Config SLAM_SEQ != 0: the TC:i / RA:Z / MP:Z tags (src/writer/SAMWriter.cpp:203-221, GenericReadWriter.h:87-186) */
 } ngm_sam_options;
 int ngm_mapper_set_sam_options(ngm_mapper *m, const ngm_sam_options *o);
 typedef struct ngm_sam_read {   /* per read: where its name is, how long its quality string is */

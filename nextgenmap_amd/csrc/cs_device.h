@@ -1200,12 +1200,26 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	const bool diag = A.phase_cycles && (blockIdx.x & 63) == 0;
 	unsigned long long ck[6] = {0, 0, 0, 0, 0, 0};
 	if (diag) ck[0] = wall_clock64();  // [lists_cap + 1]: work items (8-hit list segments) in front of each list
-	const CsRead R = cs_prepare<true, uint32_t>(A, read, lane, l_start, l_pref, l_code, (uint32_t *) nullptr, 0);
+	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
+	auto give_up = [&]() { for (uint32_t c = tid; c < cn; c += NT) cand_rank[cb + c] = kCsOrderUnknown; };
+	CsRead R;
+	const uint16_t *l_vpos = nullptr;   // bisulfite mapping: the read position of the k-mer behind list pair j
+	if (A.bs) {
+		// the lists of ALL k-mer variants at once, in the reference's order (their hits form one time line); every wave computes
+		// the same values.  Reads with more variants than the LDS rows hold keep the position order.
+		uint32_t *l_vbase = seg_pref + A.lists_cap + 1;
+		uint16_t *vp = (uint16_t *) (l_vbase + A.q + 1);
+		const CsBsRead B = cs_bs_scan(A, read, lane, l_code, l_vbase);
+		if (2u * B.V > (uint32_t) A.lists_cap) { give_up(); return; }   // (block-uniform)
+		uint32_t segs = 0;
+		const uint32_t Hb = cs_bs_chunk<true>(A, B, lane, l_code, l_vbase, 0u, B.V, 0u, l_start, l_pref, vp, &segs);
+		R.L = B.L; R.n_lists = (int) (2u * B.V); R.H = Hb; R.n_valid = B.n_valid; R.n_items = segs;
+		l_vpos = vp;
+		__syncthreads();
+	} else R = cs_prepare<true, uint32_t>(A, read, lane, l_start, l_pref, l_code, (uint32_t *) nullptr, 0);
 	const uint32_t H = R.H;
 	const int L = R.L;
 	if (diag) ck[1] = wall_clock64();
-	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
-	auto give_up = [&]() { for (uint32_t c = tid; c < cn; c += NT) cand_rank[cb + c] = kCsOrderUnknown; };
 	// very repetitive reads: the time line moves to global memory; the 16-bit list offsets of l_pref bound that at 65 535 hits
 	const bool big = H > A.order_max_hits;
 	if (big) {
@@ -1241,7 +1255,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	}
 	__syncthreads();
 	auto bin_of = [&](uint32_t pos, int li) -> uint32_t {
-		const int p = li >> 1;
+		const int p = l_vpos ? (int) l_vpos[li >> 1] : li >> 1;
 		const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
 		return ((pos - correction) >> A.bin_shift) & 0x3FFFFFFFu;
 	};

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t read_class_fwd(uint32_t ch) {
 __global__ __launch_bounds__(256) void gather_pairs_kernel(const uint8_t *__restrict__ reads, const uint16_t *__restrict__ read_len,
 		int q, const uint32_t *__restrict__ genome, WindowGeom G, const uint32_t *__restrict__ pair_read,
 		const uint32_t *__restrict__ pair_loc, const uint32_t *__restrict__ pair_sv, int n_pairs, int RW, int FW,
-		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows) {
+		uint32_t *__restrict__ out, uint16_t *__restrict__ lens, uint16_t *__restrict__ blk_rows, int alt_dir = 0) {
 	__shared__ int s_rows;
 	const int tid = threadIdx.x;
 	const int blk = blockIdx.x;
@@ -65,6 +65,10 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(const uint8_t *__rest
 	const bool rev = live ? (pair_sv[pair] & 1u) : false;
 	const int L = live ? (int) read_len[ridx] : 0;
 	const uint8_t *rp = reads + (size_t) ridx * q;
+	// bisulfite / SLAM-seq: the pair's score table (the m_DirBuffer of src/ScoreBuffer.cpp:93-110, src/AlignmentBuffer.cpp:80-98) rides
+	// in bit 3 of the read classes (SwConst::alt).  alt_dir: 0 off, 1 single-end (reverse strand -> 1), 2 paired (second mates flip)
+	uint32_t dbit = 0;
+	if (alt_dir && live) { const bool second = alt_dir == 2 && (ridx & 1u); dbit = (rev ? !second : second) ? 8u : 0u; }
 	struct __attribute__((packed, aligned(1))) U32 { uint32_t v; };
 	for (int m = part; m < RW; m += 4) {
 		uint32_t k[8];
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(const uint8_t *__rest
 				c = read_class_fwd(ch);
 				if (rev) c = (c <= 3u) ? 3u - c : c;  // reverse complement: A<->T, C<->G, N stays (MappedRead.cpp:32-43, :53-68)
 			}
-			k[j] = c;
+			k[j] = c | dbit;
 		}
 		ob[(size_t) m * kSlots] = pack8(k);
 	}
@@ -162,6 +166,27 @@ __global__ void select_top1_kernel(int n_reads, const uint32_t *__restrict__ can
 	mapq[r] = mq;
 	n_best[r] = num;
 	best_score[r] = best > 0 ? best : scores[bi];
+}
+
+// Paired-end selection, the common case on the GPU: both mates have exactly ONE candidate.  ScoreBuffer::top1PE / CheckPairs
+// (src/ScoreBuffer.cpp:368-502) then has nothing to choose: the pair is taken when its insert size lies inside the window and
+// its score is positive (MAPQ 60 for both mates, no equally good pair), otherwise the single-end selection of
+// select_top1_kernel stands and the pair is flagged as failed.  info[pair] = -1: more candidates, left to the host;
+// else bit 0 = pair taken, bits 1.. = its insert size (the host only sums those for the running mean, ScoreBuffer.h:90).
+__global__ void pair_simple_kernel(int n_pairs, const uint32_t *__restrict__ cand_base, const uint32_t *__restrict__ cand_count,
+		const float *__restrict__ scores, const uint32_t *__restrict__ pair_loc, const uint16_t *__restrict__ read_len, int min_d, int max_d,
+		int32_t *__restrict__ mapq, int32_t *__restrict__ n_best, int32_t *__restrict__ info) {
+	const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pi >= n_pairs) return;
+	const int rb = 2 * pi, ra = 2 * pi + 1;   // `a` = the mate whose scores arrive last in the reference (the odd read id)
+	if (cand_count[ra] != 1u || cand_count[rb] != 1u) { info[pi] = -1; return; }
+	const uint32_t ba = cand_base[ra], bb = cand_base[rb];
+	const uint64_t l1 = pair_loc[ba], l2 = pair_loc[bb];
+	const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) read_len[rb] : l1 - l2 + (uint64_t) read_len[ra]);
+	const float ps = scores[ba] + scores[bb];
+	const bool found = cur > min_d && cur < max_d && ps > 0.0f;
+	if (found) { mapq[ra] = 60; mapq[rb] = 60; n_best[ra] = 0; n_best[rb] = 0; }
+	info[pi] = found ? ((cur << 1) | 1) : 0;
 }
 
 // expands per-read candidate lists into pair arrays: pair j of read r gets pair_read[j] = r

@@ -72,6 +72,7 @@ struct ngm_mapper {
 	size_t cs_region_cap = 0; // candidate slots of all output regions together (grows when a batch overflows)
 	double cs_hexp = 4096;    // expected index hits per read
 	int cs_waves = 3;         // waves per read of the fast path (cs_fast2_kernel; 1: cs_fast_kernel, NGM_HIP_CS_WAVES)
+	bool cs_paired = false;   // the batch being searched holds pairs (bisulfite mapping: second mates are searched A>G)
 	int cs_canon_wpe = 7;      // 72 VGPRs: with 64 the sweeps spill (scratch round trips inside the vote loop cost more than the tenth read per CU brings)
 	int cs_canon_ch = 1;      // canonical path, shape 2: chunk loads issued after this vote step (NGM_HIP_CS_CANON_CH: 0, 1, 3)
 	int cs_canon = 0;         // 0: fast path over one bucket per k-mer (cs_fast2_kernel); 1-3: over canonical pair buckets, cs_canon_kernel<3,4,2> / <3,6,2> / <4,8,4>
@@ -102,7 +103,8 @@ struct ngm_mapper {
 	float cs_kernel_ms = 0.f;
 	hipEvent_t cev[6] = {};
 	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
-	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records;
+	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records, d_pair_info;
+	ngm::PinnedBuf<int32_t> p_pair_info;
 	ngm::DevBuf<uint16_t> d_runs, d_runs_c;
 	ngm::DevBuf<char> d_str;   // CIGAR / MD on the device: the compact byte stream
 	ngm::DevBuf<ngm::CigarDevOut> d_cigout;
@@ -114,6 +116,7 @@ struct ngm_mapper {
 	std::string sam_rg;
 	ngm::DevBuf<char> d_sam_contig_names, d_sam_rg, d_sam_names, d_sam_text;
 	ngm::DevBuf<uint32_t> d_sam_contig_off, d_sam_len, d_sam_off;
+	ngm::DevBuf<uint64_t> d_sam_contig_start;
 	ngm::DevBuf<uint8_t> d_sam_quals;
 	ngm::DevBuf<ngm::SamMeta> d_sam_meta;
 	ngm::DevBuf<ngm::SamRef> d_sam_refs;
@@ -169,6 +172,7 @@ size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	if (mode == ngm::kCsFast)  // list starts (32-bit) + lengths (16-bit), codes, plane, items, table, queue
 		w = (size_t) A.lists_cap + (size_t) A.lists_cap / 2 + (A.q + 3) / 4 + ((size_t) A.plane_bits >> 5) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) +
 				((size_t) 3 << A.log2_slots) / 4 + 32;  // + the kernels' static variables (<= 128 bytes): this is what the occupancy math sees
+	if (mode != ngm::kCsFast && A.bs) w += (size_t) A.q + 1 + ngm::kCsBsChunk / 2;  // l_vbase, l_vpos
 	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
 	return w * 4;
 }
@@ -211,12 +215,20 @@ int run_cs(ngm_mapper *m, int n) {
 		float pass_ms[3] = {0, 0, 0};
 		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) { m->cs_kernel_ms += t; pass_ms[e / 2] = t; } };
 
+		const bool bs = m->prm.bs_mapping != 0;
+		A.bs = bs ? 1 : 0; A.bs_cutoff = m->prm.bs_cutoff; A.bs_read_skip = std::max(0, m->prm.bs_read_skip); A.bs_paired = m->cs_paired ? 1 : 0;
+		if (bs) A.lists_cap = 2 * ngm::kCsBsChunk;  // the exact kernels hold the lists of kCsBsChunk k-mer variants at a time
 		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
 		A.log2_bits = m->cs_log2_bits; A.plane_bits = m->cs_plane_bits; A.log2_slots = m->cs_log2_small; A.fast_items = m->cs_fast_items;
 		A.buckets = r->d_buckets; A.bucket_log2_words = r->bucket_log2_words; A.pos_base = r->bucket_pos_base;
 		A.hit_cap = m->cs_plane_bits / 6u;
 		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
+		if (bs) {
+			// bisulfite mapping: no fast path (a read looks up ~10 variants of every k-mer: exact tables only); every read starts in pass 2
+			MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
+			status[0] = 0; status[1] = (uint32_t) n; status[2] = status[3] = 0;
+		} else {
 		// 16-bit work items when every list index fits 9 bits and no used list can have more than 128 segments
 		A.items16 = (A.lists_cap <= 512 && m->max_kfreq <= 128 * ngm::kCsSeg) ? 1 : 0;
 		if (!A.items16) A.fast_items = ngm::kCsFastItemsLong;  // the 32-bit item list only exists in the large size
@@ -257,16 +269,17 @@ int run_cs(ngm_mapper *m, int n) {
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		timed(0);
+		}
 		m->cs_queued_exact = status[1];
 		if (status[1] > 0) {
 			// pass 2 -- EXACT path, table in LDS, for the reads the fast path could not certify
 			const uint32_t no = status[1];
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
+			if (!bs) MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
 			MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
 			ngm::CsArgs B = A;
-			B.log2_slots = m->cs_log2_slots;
+			B.log2_slots = bs ? std::min(m->cs_log2_slots, 13) : m->cs_log2_slots;
 			B.hit_cap = (uint32_t) ((1u << B.log2_slots) * 0.66f);
-			B.read_list = m->d_ovf_read2.p;
+			B.read_list = bs ? nullptr : m->d_ovf_read2.p;
 			MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
 			hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactLds>, dim3(no), dim3(64), cs_lds_bytes(B, ngm::kCsExactLds), m->st, B);
 			MAP_HIP_TRY(hipGetLastError());
@@ -450,6 +463,18 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	ep.match_bonus = p->match_bonus; ep.mismatch_penalty = p->mismatch_penalty; ep.gap_read_penalty = p->gap_read_penalty; ep.gap_ref_penalty = p->gap_ref_penalty;
 	ep.variant = p->variant; ep.hard_clip = p->hard_clip; ep.silent_clip = p->silent_clip; ep.max_batch = 0;
 	ep.personality = p->personality; ep.gap_extend_penalty = p->gap_extend_penalty;
+	if (p->bs_mapping) {
+		if (ref->prm.kmer_skip != 0) { ngm::pipeline_set_error("ngm_mapper_create: bisulfite mapping needs a reference index built with kmer_skip 0 (src/PrefixTable.cpp:199-207)"); return nullptr; }
+		if (p->mode != 0 || p->topn > 1) { ngm::pipeline_set_error("ngm_mapper_create: '--bs-mapping' and '--end-to-end' / '-n' can't be used at the same time"); return nullptr; }
+		ep.alt_scoring = ep.alt_cigar = NGM_ALT_BISULFITE; ep.match_bonus_tt = p->match_bonus_tt; ep.match_bonus_tc = p->match_bonus_tc;
+	}
+	if (p->slam_seq) {
+		if (p->bs_mapping) { ngm::pipeline_set_error("ngm_mapper_create: '--bs-mapping' and '--slam-seq' can't be used at the same time!"); return nullptr; }  // Config.cpp:454-457
+		if (p->slam_seq & 4) { ngm::pipeline_set_error("ngm_mapper_create: --slam-seq with bit 2 set (the weighted k-mer mutation search, src/CS.cpp:69-75) is not implemented"); return nullptr; }
+		if (p->personality != NGM_PERSONALITY_LINEAR) { ngm::pipeline_set_error("ngm_mapper_create: '--slam-seq' needs the default (linear-gap) personality: EndToEndAffine produces no per-base records (Align::ExtendedData)"); return nullptr; }
+		ep.alt_cigar = NGM_ALT_SLAMSEQ;
+		if (p->slam_seq & 2) { ep.alt_scoring = NGM_ALT_SLAMSEQ; ep.match_bonus_tt = p->match_bonus_tt; ep.match_bonus_tc = p->match_bonus_tc; }
+	}
 	ngm_hip_ctx *eng = ngm_hip_create(ref->device, &ep);
 	if (!eng) { ngm::pipeline_set_error("%s", ngm_hip_last_error(nullptr)); return nullptr; }
 	ngm_mapper *m = new ngm_mapper();
@@ -515,8 +540,8 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	// use shorter than 1 000 hits: the chunk items are 16-bit) unless NGM_HIP_CS_PLAIN_BUCKETS asks for one bucket per k-mer
 	{
 		const int n_kmers = std::max(1, p->qry_max_len - ref->prm.kmer + 1);
-		const bool canon_ok = (ref->prm.kmer & 1) && n_kmers <= 256 && m->max_kfreq <= 1000 && !getenv("NGM_HIP_CS_PLAIN_BUCKETS");
-		if (ngm_ref_ensure_buckets(ref, canon_ok ? 1 : 0) != 0) { ngm_mapper_destroy(m); return nullptr; }
+		const bool canon_ok = (ref->prm.kmer & 1) && n_kmers <= 256 && m->max_kfreq <= 1000 && !getenv("NGM_HIP_CS_PLAIN_BUCKETS") && !p->bs_mapping;
+		if (!p->bs_mapping && ngm_ref_ensure_buckets(ref, canon_ok ? 1 : 0) != 0) { ngm_mapper_destroy(m); return nullptr; }   // (bisulfite mapping: exact paths only, no buckets)
 		if (canon_ok) {
 			const int glog = std::min(ref->cbucket_log2_words, 5) - 2;
 			int shape = 1;
@@ -565,6 +590,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	if (const char *e = getenv("NGM_HIP_CS_WAVES")) m->cs_waves = std::min(4, std::max(1, atoi(e)));
 	A.log2_slots = log2_exact;
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
+	if (p->bs_mapping) { A.bs = 1; A.lists_cap = 2 * ngm::kCsBsChunk; A.log2_slots = std::min(A.log2_slots, 13); }
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
 	(void) hipGetLastError();  // a refused attribute shows up as a launch failure where it matters, not as a stale error at the next check
@@ -582,6 +608,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
+	m->d_pair_info.release(); m->p_pair_info.release(); m->d_sam_contig_start.release();
 	m->d_sam_contig_names.release(); m->d_sam_rg.release(); m->d_sam_names.release(); m->d_sam_text.release(); m->d_sam_contig_off.release(); m->d_sam_len.release(); m->d_sam_off.release();
 	m->d_sam_quals.release(); m->d_sam_meta.release(); m->d_sam_refs.release(); m->d_sam_hits.release(); m->p_sam_hits.release(); m->p_sam_refs.release(); m->p_sam_extra.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
@@ -599,6 +626,7 @@ int ngm_mapper_cs(ngm_mapper *m, int n, const char *reads, uint32_t *cand_offset
 	DevGuard g(m->ref->device);
 	if (n == 0) { cand_offsets[0] = 0; m->n_reads = 0; m->n_cand = 0; return 0; }
 	if (int r = upload_reads(m, n, reads)) return r;
+	m->cs_paired = false;
 	if (int r = run_cs(m, n)) return r;
 	uint32_t acc = 0;
 	for (int i = 0; i < n; ++i) { cand_offsets[i] = acc; acc += m->h_count[i]; max_votes[i] = m->h_maxv[i]; }
@@ -661,7 +689,8 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	// same LDS size does reach 232, profiles/tools/lds_occupancy_calib.hip) -- 1.7 s instead of 0.1 s for config 5's 256 k tied reads
 	static const size_t lds_budget_kb = getenv("NGM_HIP_ORDER_LDS_KB") ? (size_t) atoi(getenv("NGM_HIP_ORDER_LDS_KB")) : 80;  // (tuning)
 	const size_t lds_budget = lds_budget_kb * 1024;
-	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots)) * 4;
+	if (A.bs) A.lists_cap = 2 * 3072;   // bisulfite mapping: the lists of all k-mer variants of a read (more: that read keeps the position order)
+	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + (A.bs ? (size_t) A.q + 1 + A.lists_cap / 4 + 1 : 0)) * 4;
 	const size_t hits_room = lds_fixed + 4 * (size_t) ngm::kCsOrderMaxHits < lds_budget ? (lds_budget - 64 - lds_fixed) / 4 : (size_t) ngm::kCsOrderMaxHits;
 	A.order_max_hits = (uint32_t) std::max<size_t>(ngm::kCsOrderMaxHits, std::min<size_t>(hits_room, 65535));  // (all of the budget: two workgroups per CU either way)
 	const size_t lds = lds_fixed + (size_t) A.order_max_hits * 4;
@@ -720,6 +749,12 @@ int ngm_mapper_set_sam_options(ngm_mapper *m, const ngm_sam_options *o) {
 	MAP_HIP_TRY(hipMemcpy(m->d_sam_contig_names.p, names.data(), names.size(), hipMemcpyHostToDevice));
 	MAP_HIP_TRY(hipMemcpy(m->d_sam_contig_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
 	if (!m->sam_rg.empty()) MAP_HIP_TRY(hipMemcpy(m->d_sam_rg.p, m->sam_rg.data(), m->sam_rg.size(), hipMemcpyHostToDevice));
+	{
+		std::vector<uint64_t> starts(r->contigs.size() + 1, 0);
+		for (size_t i = 0; i < r->contigs.size(); ++i) starts[i] = r->contigs[i].start;
+		if (m->d_sam_contig_start.reserve(starts.size())) { ngm::pipeline_set_error("out of device memory (SAM options)"); return -12; }
+		MAP_HIP_TRY(hipMemcpy(m->d_sam_contig_start.p, starts.data(), starts.size() * 8, hipMemcpyHostToDevice));
+	}
 	m->sam_ready = true;
 	return 0;
 }
@@ -903,6 +938,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	struct Restore { ngm_mapper *m; ngm::DevBuf<uint8_t> own; bool on; ~Restore() { if (on) m->d_reads = own; } } restore{m, own, d_reads_ext != nullptr};
 	if (d_reads_ext) { m->d_reads.p = (uint8_t *) d_reads_ext; m->d_reads.cap = (size_t) n * q; }
 	const bool host_timing = getenv("NGM_HIP_HOST_TIMING") != nullptr;
+	const int alt_cigar = m->prm.bs_mapping ? NGM_ALT_BISULFITE : (m->prm.slam_seq ? NGM_ALT_SLAMSEQ : NGM_ALT_NONE);
+	const int alt_dir = alt_cigar ? (paired ? 2 : 1) : 0;   // the pairs' direction bits (gather_pairs_kernel): score tables, conversion rule
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	auto tp0 = now();
 	double t_stage[6] = {0, 0, 0, 0, 0, 0};
@@ -921,6 +958,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		hits = m->p_sam_hits.p;
 	}
 	GpuStage stage_cs;
+	m->cs_paired = paired;
 	if (int rc = run_cs(m, n)) return rc;
 	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
 	const uint64_t np = m->n_cand;
@@ -945,7 +983,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		const int nb = (int) ((np + ngm::kSlots - 1) / ngm::kSlots);
 		ngm::WindowGeom Gs{r->n_bases - 1, ((q + c) | 1) + 1, c >> 1};  // refMaxLen of ScoreBuffer.h:112
 		hipLaunchKernelGGL(ngm::gather_pairs_kernel, dim3(nb), dim3(256), 0, m->st, m->d_reads.p, m->d_read_len.p, q, r->d_genome, Gs,
-				m->d_pair_read.p, m->d_out_loc.p, m->d_out_sv.p, (int) np, eng->RW, eng->FW, eng->packed.p, eng->lens.p, eng->blk_rows.p);
+				m->d_pair_read.p, m->d_out_loc.p, m->d_out_sv.p, (int) np, eng->RW, eng->FW, eng->packed.p, eng->lens.p, eng->blk_rows.p, alt_dir);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->ev[2], m->st));
 		if (int rc = ngm::engine_score_packed(eng, mode, (int) np, m->d_scores.p, m->st)) { ngm::pipeline_set_error("%s", ngm_hip_last_error(eng)); return rc; }
@@ -953,6 +991,16 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		hipLaunchKernelGGL(ngm::select_top1_kernel, dim3((n + 255) / 256), dim3(256), 0, m->st, n, m->d_cand_base.p, m->d_cand_count.p,
 				m->d_scores.p, m->d_out_loc.p, m->d_out_sv.p, m->d_winner.p, m->d_mapq.p, m->d_nbest.p, m->d_best.p);
 		MAP_HIP_TRY(hipGetLastError());
+		static const bool pair_gpu = !getenv("NGM_HIP_HOST_PAIR_PASS1");
+		const bool simple_on_gpu = paired && pair_gpu && m->prm.strata == 0;   // (--strata touches NH of every pair: host)
+		if (simple_on_gpu) {
+			// pairs whose mates have one candidate each (most): settled here, the host only sums their insert sizes
+			if (m->d_pair_info.reserve(n / 2 + 1) || m->p_pair_info.reserve(n / 2 + 1)) { ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
+			hipLaunchKernelGGL(ngm::pair_simple_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, m->st, n / 2, m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p,
+					m->d_out_loc.p, m->d_read_len.p, m->prm.min_insert_size, m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX, m->d_mapq.p, m->d_nbest.p, m->d_pair_info.p);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_info.p, m->d_pair_info.p, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost, m->st));
+		}
 		MAP_HIP_TRY(hipEventRecord(m->ev[4], m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_winner, m->d_winner.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_mapq, m->d_mapq.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
@@ -1034,6 +1082,12 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				long gsum = 0, gcnt = 0;
 				for (int pi = plo; pi < phi; ++pi) {
 					const int rb = 2 * pi, ra = 2 * pi + 1;
+					if (simple_on_gpu && m->p_pair_info.p[pi] >= 0) {   // one candidate per mate: pair_simple_kernel has settled it
+						const int info = m->p_pair_info.p[pi];
+						if (info & 1) { pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED; gsum += info >> 1; ++gcnt; }
+						else pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;
+						continue;
+					}
 					if (m->h_count[ra] == 0 || m->h_count[rb] == 0) { se_check(local_se, rb); se_check(local_se, ra); continue; }  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
 					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0, dist = 0;
 					bool found = false;
@@ -1321,7 +1375,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipEventRecord(m->ev[5], m->st));
 		ngm::WindowGeom Ga{r->n_bases - 1, align_buf_len, c >> 1};
 		hipLaunchKernelGGL(ngm::gather_pairs_kernel, dim3((na + ngm::kSlots - 1) / ngm::kSlots), dim3(256), 0, m->st, m->d_reads.p, m->d_read_len.p, q,
-				r->d_genome, Ga, m->d_a_read.p, m->d_a_loc.p, m->d_a_sv.p, na, eng->RW, eng->FW, eng->packed.p, eng->lens.p, eng->blk_rows.p);
+				r->d_genome, Ga, m->d_a_read.p, m->d_a_loc.p, m->d_a_sv.p, na, eng->RW, eng->FW, eng->packed.p, eng->lens.p, eng->blk_rows.p, alt_dir);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->ev[6], m->st));
 		const bool was_prof = eng->profiling;
@@ -1343,10 +1397,10 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			const bool affine = m->prm.personality == NGM_PERSONALITY_AFFINE;
 			if (affine) hipLaunchKernelGGL(ngm::cigar_strings_kernel<true>, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs_c.p, eng->packed.p, eng->RW, eng->FW,
 					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, m->d_cigout.p, m->d_str.p, scap,
-					(unsigned long long *) (m->d_total.p + 8));
+					(unsigned long long *) (m->d_total.p + 8), 0);
 			else hipLaunchKernelGGL(ngm::cigar_strings_kernel<false>, dim3((na + 255) / 256), dim3(256), 0, m->st, na, m->d_records.p, m->d_runs_c.p, eng->packed.p, eng->RW, eng->FW,
 					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, m->d_cigout.p, m->d_str.p, scap,
-					(unsigned long long *) (m->d_total.p + 8));
+					(unsigned long long *) (m->d_total.p + 8), alt_cigar);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_cigout.p, m->d_cigout.p, (size_t) na * sizeof(ngm::CigarDevOut), hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(&n_str_total, m->d_total.p + 8, 8, hipMemcpyDeviceToHost, m->st));
@@ -1388,7 +1442,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			else sam_refs[o] = ngm::SamRef{0, 0, 0, 0};
 		}
 	});
-	ngm::CigarParams cp{m->prm.match_bonus, -m->prm.mismatch_penalty, m->prm.variant, m->prm.hard_clip, m->prm.silent_clip};
+	ngm::CigarParams cp{m->prm.match_bonus, -m->prm.mismatch_penalty, m->prm.variant, m->prm.hard_clip, m->prm.silent_clip, alt_cigar};
 	parallel_for(na, [&](int lo, int hi) {
 		std::vector<char> win((size_t) q + c + 8), qry((size_t) q + 8), scr(sam ? 2 * str_stride : 0);
 		for (int j = lo; j < hi; ++j) {
@@ -1428,7 +1482,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					const char ch = rd[L - 1 - t];
 					qry[t] = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
 				}
-				ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), &ao);
+				const bool second = paired && (i & 1);
+				ngm::build_cigar_md(cp, &h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], win.data(), qry.data(), &ao, cp.alt ? ((rev ? !second : second) ? 1 : 0) : 0);
 				if (ao.score_token < 0) { h.mapped = 0; continue; }  // no alignment could be built
 			}
 			if (sam && host_strings) {
@@ -1479,7 +1534,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		S.min_insert = m->sam_opt.min_insert_size; S.max_insert = m->sam_opt.max_insert_size > 0 ? m->sam_opt.max_insert_size : 2147483647;
 		S.min_mq = m->sam_opt.min_mq; S.no_unal = m->sam_opt.no_unal; S.hard_clip = m->prm.hard_clip; S.silent_clip = m->prm.silent_clip;
 		S.min_identity = m->sam_opt.min_identity; S.min_residues = m->sam_opt.min_residues;
-		S.rg = m->sam_rg.empty() ? nullptr : m->d_sam_rg.p; S.rg_len = (int) m->sam_rg.size();
+		S.rg = m->sam_rg.empty() ? nullptr : m->d_sam_rg.p; S.rg_len = (int) m->sam_rg.size(); S.bs_mapping = m->sam_opt.bs_mapping;
+		S.slam_seq = m->sam_opt.slam_seq; S.variant_cpu = m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0; S.alt_scoring = (m->prm.bs_mapping || (m->prm.slam_seq & 2)) ? 1 : 0;
+		S.genome = r->d_genome; S.contig_start = m->d_sam_contig_start.p;
 		S.unit_len = m->d_sam_len.p; S.unit_off = m->d_sam_off.p; S.counters = m->d_total.p + 16;
 		hipEvent_t e0 = m->cev[0], e1 = m->cev[1];
 		MAP_HIP_TRY(hipEventRecord(e0, m->st));

@@ -118,6 +118,7 @@ struct Opts {
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
 	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
 	int skip_save = 0, bam = 0, workers = 2, serial_reader = 0;
+	int bs_mapping = 0, bs_cutoff = 6, match_tt = -1, match_tc = -1, match_set = 0, mismatch_set = 0, slam_seq = 0;
 	std::vector<int> devices;
 	std::string rg[12];  // read group: ID CN DS DT FO KS LB PG PI PL PU SM (SAMWriter.cpp:46-80)
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
@@ -133,7 +134,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -154,8 +155,9 @@ Opts parse(int argc, char **argv) {
 		{"rg-lb", required_argument, 0, RG0 + 6}, {"rg-pg", required_argument, 0, RG0 + 7}, {"rg-pi", required_argument, 0, RG0 + 8},
 		{"rg-pl", required_argument, 0, RG0 + 9}, {"rg-pu", required_argument, 0, RG0 + 10}, {"rg-sm", required_argument, 0, RG0 + 11},
 		{"fast-pairing", no_argument, 0, UNSUPPORTED}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
-		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, BAMOUT}, {"workers", required_argument, 0, WORKERS}, {"serial-reader", no_argument, 0, SERIAL}, {"bs-mapping", no_argument, 0, UNSUPPORTED},
-		{"slam-seq", required_argument, 0, UNSUPPORTED}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
+		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, BAMOUT}, {"workers", required_argument, 0, WORKERS}, {"serial-reader", no_argument, 0, SERIAL}, {"bs-mapping", no_argument, 0, BSMAP},
+		{"bs-cutoff", required_argument, 0, BSCUT}, {"match-bonus-tt", required_argument, 0, MBTT}, {"match-bonus-tc", required_argument, 0, MBTC},
+		{"slam-seq", required_argument, 0, SLAM}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
 		{"argos", no_argument, 0, UNSUPPORTED}, {"vcf", required_argument, 0, UNSUPPORTED}, {"config", required_argument, 0, UNSUPPORTED},
 		{0, 0, 0, 0}};
 	int c, idx = 0;
@@ -192,8 +194,13 @@ Opts parse(int argc, char **argv) {
 		case HARD: o.hard_clip = 1; break;
 		case SILENT: o.silent_clip = 1; break;
 		case KMIN: o.kmer_min = (float) atof(optarg); break;
-		case MB: o.match = atoi(optarg); break;
-		case MMP: o.mismatch = atoi(optarg); break;
+		case MB: o.match = atoi(optarg); o.match_set = 1; break;
+		case MMP: o.mismatch = atoi(optarg); o.mismatch_set = 1; break;
+		case BSMAP: o.bs_mapping = 1; break;
+		case SLAM: o.slam_seq = atoi(optarg); break;
+		case BSCUT: o.bs_cutoff = atoi(optarg); break;
+		case MBTT: o.match_tt = atoi(optarg); break;
+		case MBTC: o.match_tc = atoi(optarg); break;
 		case GRP: o.gap_read = atoi(optarg); break;
 		case GFP: o.gap_ref = atoi(optarg); break;
 		case AFFINE: o.affine = 1; break;
@@ -226,7 +233,28 @@ Opts parse(int argc, char **argv) {
 	else if (!o.qry1.empty() || !o.qry2.empty()) die("--qry1 and --qry2 must be given together");
 	if (o.paired && o.topn > 1) die("Paired end mode with topn > 1 not yet supported.");  // ScoreBuffer::topNPE
 	if (o.paired && o.qry.empty() && o.qry1.empty()) die("-p/--paired needs -q (interleaved mates) or --qry1/--qry2");
-	// scoring defaults depend on the personality (Config.cpp:433-446)
+	// scoring defaults depend on the personality (Config.cpp:433-470)
+	if (o.bs_mapping) {
+		info("MAIN", "Using bs-mapping scoring scheme");
+		if (o.affine) die("'--bs-mapping' and '--affine' can't be used at the same time!");
+		if (o.mode == 1) die("'--bs-mapping' and '--e/--end-to-end' can't be used at the same time!");
+		if (o.topn > 1) die("'--bs-mapping' and '-n/--topn' can't be used at the same time (HIP backend)");
+		if (!o.match_set) o.match = 4;
+		if (!o.mismatch_set) o.mismatch = 2;
+		if (o.gap_read < 0) o.gap_read = 10;
+		if (o.gap_ref < 0) o.gap_ref = 10;
+		if (o.gap_extend < 0) o.gap_extend = 2;
+		if (o.match_tt < 0) o.match_tt = 4;
+		if (o.match_tc < 0) o.match_tc = 4;
+	}
+	if (o.slam_seq) {
+		if (o.bs_mapping) die("'--bs-mapping' and '--slam-seq' can't be used at the same time!");   // Config.cpp:454-457
+		if (o.affine) die("'--slam-seq' needs the default (linear-gap) scoring: the affine backend produces no per-base records");
+		if (o.slam_seq & 4) die("--slam-seq " + std::to_string(o.slam_seq) + ": the weighted k-mer mutation search (bit 2) is not supported by the HIP backend yet");
+		if (o.topn > 1 || o.bam) die("'--slam-seq' with -n / --bam is not supported by the HIP backend yet");
+	}
+	if (o.match_tt < 0) o.match_tt = 10;
+	if (o.match_tc < 0) o.match_tc = 2;
 	if (o.gap_read < 0) o.gap_read = o.affine ? 33 : 20;
 	if (o.gap_ref < 0) o.gap_ref = o.affine ? 33 : 20;
 	if (o.gap_extend < 0) o.gap_extend = o.affine ? 3 : 5;
@@ -436,8 +464,10 @@ int main(int argc, char **argv) {
 	mallopt(M_TOP_PAD, 64 << 20);
 	const auto t_process = std::chrono::steady_clock::now();
 	Opts o = parse(argc, argv);
-	ngm_ref_params rp{o.kmer, o.kmer_skip, o.bin_size};
+	// bisulfite mapping: the index holds every reference k-mer, the run's kmer_skip applies to the reads (src/PrefixTable.cpp:199-207, src/CS.cpp:556-560)
+	ngm_ref_params rp{o.kmer, o.bs_mapping ? 0 : o.kmer_skip, o.bin_size};
 	info("MAIN", "NextGenMap-compatible HIP backend (gfx950)");
+	if (o.bs_mapping) info("MAIN", "BS mapping enabled. Max. number of A/T per k-mer set to " + std::to_string(o.bs_cutoff));
 	// one GPU: keep every host thread (this one, the workers, the pool) on the socket the GPU hangs on -- the parse / select /
 	// format stages run twice as fast there as spread over both sockets of the host
 	if (o.devices.size() == 1) {
@@ -446,7 +476,7 @@ int main(int argc, char **argv) {
 	}
 	// an index cache next to the FASTA is loaded instead of rebuilding; a fresh build is saved for the next run unless
 	// --skip-save (src/PrefixTable.cpp:232-262, SequenceProvider.cpp:264-330)
-	const std::string ht_cache = o.ref + "-ht-" + std::to_string(o.kmer) + "-" + std::to_string(o.kmer_skip) + ".3.ngm";
+	const std::string ht_cache = o.ref + "-ht-" + std::to_string(o.kmer) + "-" + std::to_string(rp.kmer_skip) + ".3.ngm";
 	ngm_ref *ref = ngm_ref_create_from_fasta(o.device, &rp, o.ref.c_str());
 	if (!ref) die(ngm_pipeline_last_error());
 	const bool had_cache = ngm_ref_loaded_from_cache(ref) != 0;  // (an unreadable or corrupt cache was rebuilt and is rewritten below)
@@ -528,12 +558,16 @@ int main(int argc, char **argv) {
 	mp.personality = o.affine ? NGM_PERSONALITY_AFFINE : NGM_PERSONALITY_LINEAR; mp.gap_extend_penalty = o.gap_extend;
 	mp.min_insert_size = o.min_insert; mp.max_insert_size = o.max_insert; mp.pair_score_cutoff = 0.9f;
 	mp.topn = o.topn; mp.strata = o.strata;
+	mp.bs_mapping = o.bs_mapping; mp.bs_cutoff = o.bs_cutoff; mp.bs_read_skip = o.kmer_skip; mp.match_bonus_tt = o.match_tt; mp.match_bonus_tc = o.match_tc; mp.slam_seq = o.slam_seq;
 	if (o.paired) info("INPUT", "Input is paired end data.");
 
 	// ---- sensitivity (ReadProvider.cpp:310-385) -----------------------------------------------------------
 	float sens = 0.5f;
 	bool estimated = false;
-	if (count >= 1000 && !sample.empty()) {
+	if (o.bs_mapping) {
+		if (o.sensitivity < 0) info("INPUT", "Sensitivity parameter set to 0.5");   // ReadProvider.cpp:317, :378-386: no estimate in this mode
+		estimated = true;
+	} else if (count >= 1000 && !sample.empty()) {
 		ngm_mapper_params ep = mp;
 		ep.sensitivity = 0.0f;
 		ngm_mapper *em = ngm_mapper_create(ref, &ep);
@@ -650,7 +684,7 @@ int main(int argc, char **argv) {
 		if (gpu_sam) {
 			ngm_sam_options so{};
 			so.paired = o.paired; so.min_insert_size = o.min_insert; so.max_insert_size = o.max_insert; so.min_mq = o.min_mq;
-			so.min_identity = o.min_identity; so.min_residues = o.min_residues; so.no_unal = o.no_unal; so.rg_id = o.rg[0].empty() ? nullptr : o.rg[0].c_str();
+			so.min_identity = o.min_identity; so.min_residues = o.min_residues; so.no_unal = o.no_unal; so.rg_id = o.rg[0].empty() ? nullptr : o.rg[0].c_str(); so.bs_mapping = o.bs_mapping; so.slam_seq = o.slam_seq;
 			if (ngm_mapper_set_sam_options(workers[w].m, &so) < 0) die(ngm_pipeline_last_error());
 		}
 		ngm_mapper_set_reference_cs_batch(workers[w].m, 1800000 / std::max(1, avg_len));
@@ -662,6 +696,50 @@ int main(int argc, char **argv) {
 		float min_res = o.min_residues;
 		if (min_res <= 1.0f) min_res = v.L * min_res;
 		return v.h->mapped && v.h->mapq >= o.min_mq && v.h->identity >= o.min_identity && (float) (v.L - v.h->qstart - v.h->qend) >= min_res;
+	};
+	// SLAM-seq tags (SAMWriter.cpp:203-221, GenericReadWriter::computeSlaSeqTags over the per-column records of computeCigarMD,
+	// SWOclCigar.cpp:484-540); the device twin is sam_slam_tags (csrc/sam_device.h)
+	auto slam_tags = [&](std::string &s, const View &v) {
+		const ngm_hit &h = *v.h;
+		const int L = v.L;
+		auto read_char = [&](int i) -> char {
+			if (!h.reverse) return v.row[i];
+			const char ch = v.row[L - 1 - i];
+			return ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+		};
+		auto read_class = [](char ch) -> unsigned { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 5u : 4u; };
+		int span = 0;
+		for (const char *c = v.cigar, *e = c + strlen(c); c < e;) { int num = 0; while (c < e && *c >= '0' && *c <= '9') num = num * 10 + (*c++ - '0'); if (c < e) { if (*c == 'M' || *c == 'D') span += num; ++c; } }
+		std::vector<uint8_t> refc((size_t) span + 1, 5);
+		(void) ngm_ref_host_classes(ref, ngm_ref_contig_start(ref, h.contig) + h.pos, span, refc.data());
+		int rates[25] = {0};
+		std::string mp;
+		int read_i = h.qstart, ref_i = 0;
+		const bool variant_cpu = o.variant == NGM_VARIANT_OCL_CPU, alt_tables = (o.slam_seq & 2) != 0;
+		for (const char *c = v.cigar, *e = c + strlen(c); c < e;) {
+			int num = 0;
+			while (c < e && *c >= '0' && *c <= '9') num = num * 10 + (*c++ - '0');
+			if (c >= e) break;
+			const char op = *c++;
+			if (op == 'M') {
+				for (int k2 = 0; k2 < num; ++k2) {
+					const unsigned fc = refc[ref_i + k2];
+					const char rch = read_char(read_i + k2);
+					const unsigned rc = read_class(rch);
+					const int type = 5 * (int) (fc <= 3u ? fc : 4u) + (int) (rc <= 3u ? rc : 4u);
+					rates[type] += 1;
+					const char fch = fc == 0u ? 'A' : fc == 1u ? 'C' : fc == 2u ? 'G' : fc == 3u ? 'T' : fc == 4u ? 'x' : 'N';
+					const bool eq = !variant_cpu ? (rch == fch) : (alt_tables ? rc == fc : (rc <= 3u && rc == fc));
+					if (!eq) { if (!mp.empty()) mp.push_back(','); put_i64(mp, type); mp.push_back(':'); put_i64(mp, read_i + k2 + 1); mp.push_back(':'); put_i64(mp, ref_i + k2 + 1); }
+				}
+				read_i += num; ref_i += num;
+			} else if (op == 'I') read_i += num;
+			else if (op == 'D') ref_i += num;
+		}
+		s += "\tTC:i:"; put_i64(s, h.reverse ? rates[0 * 5 + 2] : rates[3 * 5 + 1]);
+		s += "\tRA:Z:";
+		for (int i = 0; i < 25; ++i) { if (i) s.push_back(','); put_i64(s, rates[i]); }
+		if (!mp.empty()) { s += "\tMP:Z:"; s += mp; }
 	};
 	struct BamMate { int ref; long long pos0; long long tlen; };  // what BAMWriter::DoWritePair passes on (0-based, -1 = none; its own TLEN rule)
 	auto write_mapped = [&](std::string &s, size_t &n_written, const View &v, int flags, const char *rnext, unsigned long long pnext, long long tlen, const BamMate &bm) {
@@ -685,6 +763,7 @@ int main(int argc, char **argv) {
 			}
 			ngm::bam::Tags tg;
 			tg.add_int("AS", (int) h.score); tg.add_int("NM", h.nm); tg.add_int("NH", h.n_best);
+			if (o.bs_mapping) { const bool second = o.paired && (flags & 0x80); const char *zs = second ? (h.reverse ? "+-" : "--") : (h.reverse ? "-+" : "++"); tg.add_string("ZS", zs, 2); }  // BAMWriter.cpp:240-254
 			tg.add_float("XI", roundf(h.identity * 10000.0f) / 10000.0f);
 			tg.add_int("X0", h.n_best); tg.add_int("XE", (int) h.max_votes); tg.add_int("XR", L - h.qstart - h.qend);
 			tg.add_string("MD", v.md, strlen(v.md));
@@ -716,8 +795,14 @@ int main(int argc, char **argv) {
 		}
 		s.push_back('\t');
 		s += rg_mapped;
-		s += "AS:i:"; put_i64(s, (int) h.score); s += "\tNM:i:"; put_i64(s, h.nm); s += "\tNH:i:"; put_i64(s, h.n_best); s += "\tXI:f:"; put_identity(s, h.identity);
+		s += "AS:i:"; put_i64(s, (int) h.score); s += "\tNM:i:"; put_i64(s, h.nm); s += "\tNH:i:"; put_i64(s, h.n_best);
+		if (o.bs_mapping) {  // SAMWriter.cpp:173-187: first mates / single reads "++" or "-+", second mates "--" or "+-"
+			const bool second = o.paired && (flags & 0x80);
+			s += second ? (h.reverse ? "\tZS:Z:+-" : "\tZS:Z:--") : (h.reverse ? "\tZS:Z:-+" : "\tZS:Z:++");
+		}
+		s += "\tXI:f:"; put_identity(s, h.identity);
 		s += "\tX0:i:"; put_i64(s, h.n_best); s += "\tXE:i:"; put_i64(s, (int) h.max_votes); s += "\tXR:i:"; put_i64(s, L - h.qstart - h.qend); s += "\tMD:Z:"; s += v.md;
+		if (o.slam_seq) slam_tags(s, v);
 		s.push_back('\n');
 		++n_written;
 	};

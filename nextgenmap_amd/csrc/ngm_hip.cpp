@@ -225,7 +225,7 @@ int launch_pack(ngm_hip_ctx *ctx, int n, const void *d_ref, const void *d_qry, h
 	const size_t lds = (size_t) ngm::kSlots * (ctx->rl + ctx->q);
 	hipLaunchKernelGGL(ngm::pack_pairs_kernel, dim3(nb), dim3(256), lds, st, (const uint8_t *) d_ref,
 			(const uint8_t *) d_qry, n, ctx->q, ctx->rl, ctx->RW, ctx->FW, ctx->packed.p, ctx->lens.p, ctx->blk_rows.p,
-			ctx->prm.personality == NGM_PERSONALITY_AFFINE ? 1 : 0, ctx->K.alt ? ctx->pair_dir : nullptr);
+			ctx->prm.personality == NGM_PERSONALITY_AFFINE ? 1 : 0, (ctx->K.alt || ctx->prm.alt_cigar) ? ctx->pair_dir : nullptr);
 	HIP_TRY(ctx, hipGetLastError());
 	return 0;
 }
@@ -233,7 +233,7 @@ int launch_pack(ngm_hip_ctx *ctx, int n, const void *d_ref, const void *d_qry, h
 // the `dir` bytes of a host-pointer call -> device (null: all pairs use the FWD table)
 int stage_dirs(ngm_hip_ctx *ctx, int n, const char *dir) {
 	ctx->pair_dir = nullptr;
-	if (!ctx->K.alt || !dir) return 0;
+	if ((!ctx->K.alt && !ctx->prm.alt_cigar) || !dir) return 0;
 	if (ctx->d_pair_dir.reserve(n)) { set_error(ctx, "out of memory staging %d pairs", n); return -12; }
 	HIP_TRY(ctx, hipMemcpyAsync(ctx->d_pair_dir.p, dir, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
 	ctx->pair_dir = ctx->d_pair_dir.p;
@@ -263,6 +263,8 @@ ngm_hip_ctx *ngm_hip_create(int device, const ngm_hip_params *p) {
 	if (p->personality == NGM_PERSONALITY_AFFINE && p->gap_extend_penalty <= 0) { set_error(nullptr, "ngm_hip_create: gap_extend_penalty must be a positive integer"); return nullptr; }
 	if (p->match_bonus + p->mismatch_penalty > 255) { set_error(nullptr, "ngm_hip_create: match_bonus + mismatch_penalty must be <= 255"); return nullptr; }
 	if (p->corridor > 200) { set_error(nullptr, "ngm_hip_create: corridor %d too wide (the band row lives in registers)", p->corridor); return nullptr; }
+	if (p->alt_cigar != NGM_ALT_NONE && p->alt_cigar != NGM_ALT_BISULFITE && p->alt_cigar != NGM_ALT_SLAMSEQ) { set_error(nullptr, "ngm_hip_create: unknown alt_cigar %d", p->alt_cigar); return nullptr; }
+	if (p->alt_cigar != NGM_ALT_NONE && p->personality != NGM_PERSONALITY_LINEAR) { set_error(nullptr, "ngm_hip_create: bisulfite / SLAM-seq and the affine personality can't be used at the same time"); return nullptr; }
 	if (p->alt_scoring != NGM_ALT_NONE) {
 		// Config.cpp:448-460: bs-mapping and affine exclude each other; the tables hold (score - mismatch) as unsigned bytes
 		if (p->alt_scoring != NGM_ALT_BISULFITE && p->alt_scoring != NGM_ALT_SLAMSEQ) { set_error(nullptr, "ngm_hip_create: unknown alt_scoring %d", p->alt_scoring); return nullptr; }
@@ -456,7 +458,7 @@ int ngm_hip_batch_align(ngm_hip_ctx *ctx, int mode, int n, const char *const *re
 	cp.variant = ctx->prm.variant;
 	cp.hard_clip = ctx->prm.hard_clip;
 	cp.silent_clip = ctx->prm.silent_clip;
-	cp.alt = ctx->prm.alt_scoring;
+	cp.alt = ctx->prm.alt_cigar;
 	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
 		for (int i = 0; i < n; ++i)
 			ngm::build_cigar_affine(ctx->h_records.p + (size_t) i * 8, ctx->h_runs.p + (size_t) i * rs, ref[i], qry[i], ctx->q, &out[i]);

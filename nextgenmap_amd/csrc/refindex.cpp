@@ -351,12 +351,6 @@ int build_buckets_kind(ngm_ref *r, int kind) {
 	return 0;
 }
 
-// the layout the default search kernel reads: canonical pairs for odd k (NextGenMap's default 13), one bucket per k-mer otherwise
-int build_buckets(ngm_ref *r) {
-	const bool canon = (r->prm.kmer & 1) && !getenv("NGM_HIP_CS_PLAIN_BUCKETS");
-	return build_buckets_kind(r, canon ? 1 : 0);
-}
-
 int build_index(ngm_ref *r) {
 	const int k = r->prm.kmer;
 	const uint32_t n_kmers = 1u << (2 * k);
@@ -420,7 +414,7 @@ int build_index(ngm_ref *r) {
 	std::vector<uint32_t> raw(n_kmers);
 	REF_HIP_TRY(hipMemcpy(raw.data(), r->d_raw_counts, (size_t) n_kmers * 4, hipMemcpyDeviceToHost));
 	index_stats(r, raw);
-	return build_buckets(r);
+	return 0;   // the bucket layouts are built when the first mapper asks for one (ngm_ref_ensure_buckets): a bisulfite run needs none
 }
 
 // CompactPrefixTable::stats (PrefixTable.cpp:150-194): integer sums are exact in double, order-free
@@ -630,7 +624,6 @@ ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *p, const ch
 		return nullptr;
 	}
 	index_stats(r, raw);
-	if (build_buckets(r) != 0) { ngm_ref_destroy(r); return nullptr; }
 	r->from_cache = true;
 	return r;
 }
@@ -704,6 +697,13 @@ int ngm_ref_ensure_buckets(const ngm_ref *r, int kind) {
 }
 
 extern "C" {
+
+int ngm_ref_host_classes(const ngm_ref *r, uint64_t pos, int n, uint8_t *out) {
+	if (!r || !out || n < 0) return -22;
+	int k = 0;
+	for (; k < n && pos + (uint64_t) k < r->host_cls.size(); ++k) out[k] = r->host_cls[pos + (uint64_t) k];
+	return k;
+}
 
 int ngm_ref_contig_count(const ngm_ref *r) { return (int) r->contigs.size(); }
 const char *ngm_ref_contig_name(const ngm_ref *r, int i) { return r->contigs[i].name.c_str(); }

@@ -40,6 +40,11 @@ struct SamArgs {
 	float min_identity, min_residues;
 	const char *rg;             // read group id (rg_len bytes) or null
 	int rg_len;
+	int bs_mapping;             // ZS:Z tag
+	int slam_seq;               // TC:i / RA:Z / MP:Z tags
+	int variant_cpu, alt_scoring;   // how a column was labelled '=' (SwConst::variant, ::alt)
+	const uint32_t *genome;     // 4-bit symbol classes, 8 per dword (refindex.h)
+	const uint64_t *contig_start;
 	uint32_t *unit_len;         // [units] pass 1
 	const uint32_t *unit_off;   // [units] exclusive prefix sums
 	char *out;
@@ -116,6 +121,59 @@ template <typename Sink> __device__ __forceinline__ void sam_contig(const SamArg
 	s.bytes(A.contig_names + o, A.contig_name_off[contig + 1] - o);
 }
 
+
+// SLAM-seq tags (src/writer/SAMWriter.cpp:203-221 over GenericReadWriter::computeSlaSeqTags, GenericReadWriter.h:87-186, fed by the
+// per-column records computeCigarMD leaves in Align::ExtendedData, SWOclCigar.cpp:484-540): every aligned column has a type
+// 5 * ref + read (A0 C1 G2 T3 other 4); RA = the 25 type counts, MP = "type:read position:ref position" (1-based, from the start of
+// the aligned read / of the alignment) of the columns the kernel labelled 'X', TC = the T>C columns (reverse strand: A>G).
+template <typename Sink>
+__device__ __forceinline__ void sam_slam_tags(const SamArgs &A, Sink &s, const SamView &v, const SamRef &rf) {
+	const ngm_hit &h = *v.h;
+	const int L = v.L;
+	const uint64_t g0 = A.contig_start[h.contig] + h.pos;
+	auto ref_class = [&](int i) -> uint32_t { const uint64_t p = g0 + (uint64_t) i; return (A.genome[p >> 3] >> (4 * (p & 7))) & 15u; };   // A0 C1 G2 T3 x4 N5
+	auto read_char = [&](int i) -> char {
+		if (!h.reverse) return (char) v.row[i];
+		const char ch = (char) v.row[L - 1 - i];
+		return ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+	};
+	auto read_class = [](char ch) -> uint32_t { return ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : ch == 'N' ? 5u : 4u; };
+	int rates[25];
+	for (int i = 0; i < 25; ++i) rates[i] = 0;
+	for (int pass = 0; pass < 2; ++pass) {   // pass 0: counts (TC and RA come first in the record), pass 1: the MP list
+		if (pass == 1) {
+			const int tc = h.reverse ? rates[0 * 5 + 2] : rates[3 * 5 + 1];
+			sam_lit(s, "\tTC:i:"); sam_i64(s, tc); sam_lit(s, "\tRA:Z:");
+			for (int i = 0; i < 25; ++i) { if (i) s.put(','); sam_i64(s, rates[i]); }
+		}
+		int read_i = h.qstart, ref_i = 0, num = 0;
+		bool any = false;
+		for (uint32_t c = 0; c < rf.cig_len; ++c) {
+			const char ch = A.str[rf.cig_off + c];
+			if (ch >= '0' && ch <= '9') { num = num * 10 + (ch - '0'); continue; }
+			if (ch == 'M') {
+				for (int k2 = 0; k2 < num; ++k2) {
+					const uint32_t fc = ref_class(ref_i + k2);
+					const char rch = read_char(read_i + k2);
+					const uint32_t rc = read_class(rch);
+					const int type = 5 * (int) (fc <= 3u ? fc : 4u) + (int) (rc <= 3u ? rc : 4u);
+					if (pass == 0) { rates[type] += 1; continue; }
+					// '=' as the kernel labelled it: the __GPU__ build compares the characters, the float4 build the score / the classes
+					const char fch = fc == 0u ? 'A' : fc == 1u ? 'C' : fc == 2u ? 'G' : fc == 3u ? 'T' : fc == 4u ? 'x' : 'N';
+					const bool eq = !A.variant_cpu ? (rch == fch) : (A.alt_scoring ? rc == fc : (rc <= 3u && rc == fc));
+					if (!eq) {
+						sam_lit(s, any ? "," : "\tMP:Z:"); any = true;
+						sam_i64(s, type); s.put(':'); sam_i64(s, read_i + k2 + 1); s.put(':'); sam_i64(s, ref_i + k2 + 1);
+					}
+				}
+				read_i += num; ref_i += num;
+			} else if (ch == 'I') read_i += num;
+			else if (ch == 'D') ref_i += num;
+			num = 0;   // (S / H: the clipped bases are not columns; the leading ones are h.qstart)
+		}
+	}
+}
+
 // SAMWriter::DoWriteReadGeneric (SAMWriter.cpp:98-228).  rnext: 0 '*', 1 '=', 2 the name of contig rnext_contig
 template <typename Sink>
 __device__ __forceinline__ void sam_mapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int rnext, int rnext_contig, unsigned long long pnext, long long tlen) {
@@ -144,9 +202,14 @@ __device__ __forceinline__ void sam_mapped(const SamArgs &A, Sink &s, const SamV
 	s.put('\t');
 	if (A.rg_len > 0) { sam_lit(s, "RG:Z:"); s.bytes(A.rg, (uint32_t) A.rg_len); s.put('\t'); }
 	sam_lit(s, "AS:i:"); sam_i64(s, (int) h.score); sam_lit(s, "\tNM:i:"); sam_i64(s, h.nm); sam_lit(s, "\tNH:i:"); sam_i64(s, h.n_best);
+	if (A.bs_mapping) {  // SAMWriter.cpp:173-187
+		const bool second = A.paired && (flags & 0x80);
+		sam_lit(s, second ? (h.reverse ? "\tZS:Z:+-" : "\tZS:Z:--") : (h.reverse ? "\tZS:Z:-+" : "\tZS:Z:++"));
+	}
 	sam_lit(s, "\tXI:f:"); sam_identity(s, h.identity);
 	sam_lit(s, "\tX0:i:"); sam_i64(s, h.n_best); sam_lit(s, "\tXE:i:"); sam_i64(s, (int) h.max_votes); sam_lit(s, "\tXR:i:"); sam_i64(s, L - h.qstart - h.qend);
 	sam_lit(s, "\tMD:Z:"); s.bytes(A.str + rf.md_off, rf.md_len);
+	if (A.slam_seq) sam_slam_tags(A, s, v, rf);
 	s.put('\n');
 }
 // SAMWriter::DoWriteUnmappedReadGeneric (SAMWriter.cpp:311-372): contig < 0 prints '*'

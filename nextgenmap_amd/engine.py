@@ -29,7 +29,7 @@ class Params(C.Structure):
                 ("match_bonus", C.c_int), ("mismatch_penalty", C.c_int), ("gap_read_penalty", C.c_int),
                 ("gap_ref_penalty", C.c_int), ("variant", C.c_int), ("hard_clip", C.c_int),
                 ("silent_clip", C.c_int), ("max_batch", C.c_int), ("personality", C.c_int),
-                ("gap_extend_penalty", C.c_int), ("alt_scoring", C.c_int), ("match_bonus_tt", C.c_int), ("match_bonus_tc", C.c_int)]
+                ("gap_extend_penalty", C.c_int), ("alt_scoring", C.c_int), ("match_bonus_tt", C.c_int), ("match_bonus_tc", C.c_int), ("alt_cigar", C.c_int)]
 
 
 class AlignOut(C.Structure):
@@ -93,12 +93,12 @@ class Engine:
 
     def __init__(self, qry_max_len, corridor, match=10, mismatch=15, gap_read=20, gap_ref=20, device=0,
                  variant=VARIANT_OCL_GPU, hard_clip=0, silent_clip=0, max_batch=0, personality=PERSONALITY_LINEAR,
-                 gap_extend=0, alt_scoring=0, match_bonus_tt=0, match_bonus_tc=0):
+                 gap_extend=0, alt_scoring=0, match_bonus_tt=0, match_bonus_tc=0, alt_cigar=None):
         self.lib = load_library()
         self.q, self.c = int(qry_max_len), int(corridor)
         self.personality = int(personality)
         p = Params(ABI_VERSION, self.q, self.c, match, mismatch, gap_read, gap_ref, variant, hard_clip, silent_clip, max_batch,
-                   self.personality, gap_extend, alt_scoring, match_bonus_tt, match_bonus_tc)
+                   self.personality, gap_extend, alt_scoring, match_bonus_tt, match_bonus_tc, alt_scoring if alt_cigar is None else alt_cigar)
         self.h = self.lib.ngm_hip_create(device, C.byref(p))
         if not self.h:
             raise NgmHipError(self.lib.ngm_hip_last_error(None).decode())

@@ -17,7 +17,8 @@ class MapperParams(C.Structure):
                 ("sensitivity", C.c_float), ("kmer_min", C.c_float), ("max_cmrs", C.c_int), ("max_kfreq", C.c_int),
                 ("hard_clip", C.c_int), ("silent_clip", C.c_int), ("personality", C.c_int), ("gap_extend_penalty", C.c_int),
                 ("min_insert_size", C.c_int), ("max_insert_size", C.c_int), ("pair_score_cutoff", C.c_float),
-                ("topn", C.c_int), ("strata", C.c_int)]
+                ("topn", C.c_int), ("strata", C.c_int), ("bs_mapping", C.c_int), ("bs_cutoff", C.c_int), ("bs_read_skip", C.c_int),
+                ("match_bonus_tt", C.c_int), ("match_bonus_tc", C.c_int), ("slam_seq", C.c_int)]
 
 
 HIT_DTYPE = np.dtype([("mapped", "i4"), ("contig", "i4"), ("pos", "u8"), ("reverse", "i4"), ("mapq", "i4"),
@@ -177,13 +178,13 @@ class Mapper:
     def __init__(self, ref, qry_max_len, corridor, sensitivity=0.5, match=10, mismatch=15, gap_read=20, gap_ref=20,
                  mode=0, variant=0, kmer_min=0.0, max_cmrs=2 ** 31 - 1, max_kfreq=0, hard_clip=0, silent_clip=0, personality=0,
                  gap_extend=0, min_insert_size=0, max_insert_size=1000, pair_score_cutoff=0.9, topn=1,
-                 strata=0):
+                 strata=0, bs_mapping=0, bs_cutoff=6, bs_read_skip=2, match_bonus_tt=4, match_bonus_tc=4, slam_seq=0):
         self.lib = _lib()
         self.ref = ref
         self.q, self.c = qry_max_len, corridor
         p = MapperParams(qry_max_len, corridor, match, mismatch, gap_read, gap_ref, mode, variant, sensitivity, kmer_min,
                          max_cmrs, max_kfreq, hard_clip, silent_clip, personality, gap_extend, min_insert_size, max_insert_size,
-                         pair_score_cutoff, topn, strata)
+                         pair_score_cutoff, topn, strata, bs_mapping, bs_cutoff, bs_read_skip, match_bonus_tt, match_bonus_tc, slam_seq)
         self.topn = max(1, topn)
         self.h = self.lib.ngm_mapper_create(ref.h, C.byref(p))
         if not self.h:

@@ -8,11 +8,14 @@
 # The -D options are the ones NGM's host passes at JIT time
 # (lib/mason/opencl/SWOcl.cpp:206-242, lib/mason/opencl/SWOclCigar.cpp:35).
 #
-# usage: build_ref.sh <gpu|gpu1|cpu> <qry_max_len> <corridor> [match mismatch gap_read gap_ref]
+# usage: build_ref.sh <gpu|gpu1|cpu> <qry_max_len> <corridor> [match mismatch gap_read gap_ref [bs|slam match_bonus_tt match_bonus_tc]]
 #   (penalties positive, as in NGM's config; they are negated exactly as SWOcl.cpp:211-213 does)
+#   bs / slam: the -D__ALT_SCORING__ builds of `--bs-mapping` / `--slam-seq 2` (SWOcl.cpp:225-242); their kernels take one more
+#   argument, the per-pair `direction` bytes
 set -euo pipefail
 variant=${1:?variant gpu|cpu}; q=${2:?qry_max_len}; c=${3:?corridor}
 match=${4:-10}; mismatch=${5:-15}; gap_read=${6:-20}; gap_ref=${7:-20}
+alt=${8:-none}; tt=${9:-0}; tc=${10:-0}
 REF=${NGM_REFERENCE:-/root/reference}
 SRC=$REF/lib/mason/opencl/opencl
 here=$(cd "$(dirname "$0")" && pwd)
@@ -32,6 +35,12 @@ else
 	tpb=1;   vdef=-D__CPU__     # float4 lanes, 4 pairs per work-item; run with local size 1
 fi
 name=ngm_ocl_${variant}_q${q}_c${c}_m${match}_x${mismatch}_gr${gap_read}_gf${gap_ref}
+altdef="-DmatchALT=0 -DmismatchALT=0 -DscoresFWD=scores -DscoresREV=scores"
+if [ "$alt" = bs ]; then
+	altdef="-D__ALT_SCORING__ -DmatchALT=$tt -DmismatchALT=$tc -DscoresFWD=scoresBsFWD -DscoresREV=scoresBsREV"; name=${name}_bs_tt${tt}_tc${tc}
+elif [ "$alt" = slam ]; then
+	altdef="-D__ALT_SCORING__ -DmatchALT=$tt -DmismatchALT=-$tc -DscoresFWD=scoresSlamSeqFWD -DscoresREV=scoresSlamSeqREV"; name=${name}_slam_tt${tt}_tc${tc}
+fi
 # program text = oclDefines + oclSwScore + oclEndFreeScore + oclSwCigar (SWOcl.cpp:250-251, SWOclCigar.cpp:33-36)
 tmp=$(mktemp -d)
 trap 'rm -rf "$tmp"' EXIT
@@ -44,6 +53,6 @@ cat "$SRC/oclDefines.cl" "$SRC/oclSwScore.cl" "$SRC/oclEndFreeScore.cl" "$SRC/oc
 	-Dalignment_length=$(( 2 * q + c + 1 )) \
 	-Dresult_number=4 -DCIGAR_M=0 -DCIGAR_I=1 -DCIGAR_D=2 -DCIGAR_N=3 -DCIGAR_S=4 -DCIGAR_H=5 \
 	-DCIGAR_P=6 -DCIGAR_EQ=7 -DCIGAR_X=8 $vdef \
-	-DmatchALT=0 -DmismatchALT=0 -DscoresFWD=scores -DscoresREV=scores \
+	$altdef \
 	"$tmp/program.cl" -o "$out/$name.co"
 echo "$out/$name.co"

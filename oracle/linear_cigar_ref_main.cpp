@@ -7,8 +7,10 @@
 // Only this main() is ours.  The method is private: this translation unit (and only this one) is compiled with
 // -fno-access-control; the object is raw zeroed storage with the two data members set, because SWOcl's constructor
 // needs an OpenCL device (lib/mason/opencl/SWOcl.cpp:163-200).
-//   usage: ngm_linear_cigar_ref <in.bin> <out.txt> <clip>      clip: 0 soft (default), 1 --hard-clip, 2 --silent-clip
-//   in.bin: int32 n, q, c; then per pair: (q+c) window bytes, q read bytes, 4 int16 results, (2q+c+1) int16 RLE
+//   usage: ngm_linear_cigar_ref <in.bin> <out.txt> <clip> [alt]   clip: 0 soft (default), 1 --hard-clip, 2 --silent-clip
+//                                                                alt: 1 = --bs-mapping, 2 = --slam-seq (bsFrom / bsTo per pair as
+//                                                                SWOclCigar::BatchAlign derives them from extData, SWOclCigar.cpp:300-317)
+//   in.bin: int32 n, q, c; then per pair: (q+c) window bytes, q read bytes, 4 int16 results, (2q+c+1) int16 RLE [, alt: 1 direction byte]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,7 +42,9 @@ uloc const FileSize(char const *const filename) {
 int main(int argc, char **argv) {
 	if (argc < 4) return 2;
 	const int clip = atoi(argv[3]);
+	const int alt = argc > 4 ? atoi(argv[4]) : 0;
 	std::vector<std::string> args = {"ngm", "-t", "1"};  // (a bare command line makes the parser print the help and throw)
+	if (alt == 1) args.push_back("--bs-mapping");   // computeCigarMD reads Config "bs_mapping" (SWOclCigar.cpp:435)
 	if (clip == 1) args.push_back("--hard-clip");
 	if (clip == 2) args.push_back("--silent-clip");
 	std::vector<char *> cfg_argv;
@@ -61,7 +65,7 @@ int main(int argc, char **argv) {
 	void *raw = calloc(1, sizeof(SWOclCigar));
 	SWOclCigar *obj = reinterpret_cast<SWOclCigar *>(raw);
 	obj->alignment_length = al;
-	*const_cast<int *>(&obj->slamSeq) = 0;
+	*const_cast<int *>(&obj->slamSeq) = alt == 2 ? 2 : 0;   // (SWOcl.cpp:165-166: Config SLAM_SEQ)
 	FILE *o = fopen(argv[2], "w");
 	if (!o) return 2;
 	std::vector<char> ref(q + c + 1), qry(q + 1), cigar(4 * (q + c) + 64), md(4 * (q + c) + 64);
@@ -71,12 +75,18 @@ int main(int argc, char **argv) {
 		memset(ref.data(), 0, ref.size()); memset(qry.data(), 0, qry.size());
 		if (fread(ref.data(), 1, q + c, f) != (size_t) (q + c) || fread(qry.data(), 1, q, f) != (size_t) q || fread(res, 2, 4, f) != 4 ||
 				fread(rle.data(), 2, al, f) != (size_t) al) return 2;
+		char dir = 0, bs_from = '0', bs_to = '0';
+		if (alt) {
+			if (fread(&dir, 1, 1, f) != 1) return 2;
+			if (alt == 1) { if (dir == 1) { bs_from = 'A'; bs_to = 'G'; } else { bs_from = 'T'; bs_to = 'C'; } }   // SWOclCigar.cpp:302-310
+			if (alt == 2) { if (dir == 1) { bs_from = 'G'; bs_to = 'A'; } else { bs_from = 'C'; bs_to = 'T'; } }   // :311-318
+		}
 		Align a;
 		a.pBuffer1 = cigar.data(); a.pBuffer2 = md.data();
 		strcpy(a.pBuffer1, "!!!"); strcpy(a.pBuffer2, "!!!");
 		// the call of SWOclCigar::BatchAlign (SWOclCigar.cpp:322-328) with alignments_per_thread = 1:
 		//   offset = results[3], refSeq = window + results[0], PositionOffset = results[0]
-		const bool ok = obj->computeCigarMD(a, res[3], rle.data(), ref.data() + res[0], qry.data(), 0, '0', '0');
+		const bool ok = obj->computeCigarMD(a, res[3], rle.data(), ref.data() + res[0], qry.data(), 0, bs_from, bs_to);
 		a.PositionOffset = res[0];
 		fprintf(o, "%d\t%d\t%s\t%s\t%d\t%.9g\t%d\t%d\t%d\t%.9g\n", i, ok ? 1 : 0, a.pBuffer1, a.pBuffer2, a.NM, a.Identity, a.QStart, a.QEnd,
 				a.PositionOffset, ok ? a.Score : -1.0f);

@@ -24,7 +24,7 @@ DRIVER = os.path.join(ROOT, "oracle", "_ref", "ngm", "ngm_linear_cigar_ref")
 CLIPS = ("soft", "hard", "silent")
 
 
-def run_reference(ref, qry, c, res, rle, rows, clip):
+def run_reference(ref, qry, c, res, rle, rows, clip, alt=0, dirs=None):
     """-> dict of arrays over `rows` as the reference's computeCigarMD returns them"""
     n, q = len(rows), qry.shape[1]
     al = 2 * q + c + 1
@@ -35,7 +35,9 @@ def run_reference(ref, qry, c, res, rle, rows, clip):
             for i in rows:
                 f.write(ref[i, :q + c].tobytes()); f.write(qry[i].tobytes())
                 f.write(res[i].astype(np.int16).tobytes()); f.write(rle[i, :al].astype(np.int16).tobytes())
-        subprocess.check_call([DRIVER, fin, fout, str(clip)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                if alt:
+                    f.write(bytes([int(dirs[i])]))
+        subprocess.check_call([DRIVER, fin, fout, str(clip)] + ([str(alt)] if alt else []), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         lines = open(fout, "rb").read().split(b"\n")[:n]
     out = dict(ok=np.zeros(n, np.int8), cigar=[], md=[], nm=np.zeros(n, np.int32), identity=np.zeros(n, np.float32),
                qstart=np.zeros(n, np.int32), qend=np.zeros(n, np.int32), position_offset=np.zeros(n, np.int32),
@@ -59,16 +61,19 @@ def main():
             continue
         g = np.load(path)
         ref, qry, c, variant = g["ref"], g["qry"], int(g["c"]), int(g["variant"])
+        alt = int(g["alt"]) if "alt" in g.files else 0
+        dirs = g["dirs"] if alt else None
+        scoring = dict(zip(("match", "mismatch", "gap_read", "gap_ref", "alt", "match_alt", "mismatch_alt"), (int(x) for x in g["scoring"]))) if alt else None
         out = {}
         for mode, mn in ((0, "local"), (1, "endfree")):
             rows = np.nonzero(g[mn + "_valid"])[0]
             out[mn + "_rows"] = rows.astype(np.int32)
             for clip, cn in enumerate(CLIPS):
-                r = run_reference(ref, qry, c, g[mn + "_res"], g[mn + "_rle"], rows, clip)
+                r = run_reference(ref, qry, c, g[mn + "_res"], g[mn + "_rle"], rows, clip, alt, dirs)
                 for k, v in r.items():
                     out["%s_%s_%s" % (mn, cn, k)] = v
                 # the C restatement on the same pairs (it recomputes the DP: its RLE equals the golden RLE, test_oracle_golden.py)
-                res, cig, md = O.oracle_align(mode, ref, qry, c, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2), nthreads=8)
+                res, cig, md = O.oracle_align(mode, ref, qry, c, scoring, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2), nthreads=8, dirs=dirs)
                 bad = 0
                 for j, i in enumerate(rows):
                     have = (bool(res["ok"][i]), cig[i], md[i], int(res["nm"][i]), np.float32(res["identity"][i]).tobytes(), int(res["qstart"][i]),

@@ -161,7 +161,9 @@ void ngm_oracle_align_trace(int mode, const char *ref, const char *qry, int q, i
 	out->best_read_index = bri;
 	out->best_ref_index = bci;
 	out->best_score = best;
-	out->qend = local ? (L - bri - 1) : 0;
+	/* (an empty read: the float4 build never enters its DP and stores qend = 0, oclSwScore.cl:38, :101-106; the __GPU__ build computes
+	 * read_index - best_read_index - 1 = -1, :325) */
+	out->qend = local ? ((variant == NGM_ORACLE_VARIANT_CPU && L == 0) ? 0 : (L - bri - 1)) : 0;
 
 	/* pass 2 -- skipped by the reference when best_read_index <= 0, leaving its outputs
 	 * undefined; the oracle reports that as valid = 0. */

@@ -44,8 +44,16 @@ struct Launch {
 // variant 1 = __CPU__ build (4 pairs per work-item, local size 1, no interleave),
 // variant 2 = __GPU__ build with threads_per_block = interleave_number = 1 (local size 1, flat refs).
 // ref_flat: n rows of (q+c) bytes, qry_flat: n rows of q bytes (NUL padded).
+// dirs != null: a code object built with -D__ALT_SCORING__ (build_ref.sh ... bs|slam): the score / align kernels take the per-pair
+// `direction` bytes as one more argument (SWOcl.cpp:123-137, SWOclCigar.cpp:252-267)
+extern "C" int ngm_ref_run_score_alt(const char *co_path, int variant, int mode, int n, const char *ref_flat,
+		const char *qry_flat, int q, int c, const char *dirs, float *scores, float *kernel_ms);
 extern "C" int ngm_ref_run_score(const char *co_path, int variant, int mode, int n, const char *ref_flat,
 		const char *qry_flat, int q, int c, float *scores, float *kernel_ms) {
+	return ngm_ref_run_score_alt(co_path, variant, mode, n, ref_flat, qry_flat, q, c, nullptr, scores, kernel_ms);
+}
+extern "C" int ngm_ref_run_score_alt(const char *co_path, int variant, int mode, int n, const char *ref_flat,
+		const char *qry_flat, int q, int c, const char *dirs, float *scores, float *kernel_ms) {
 	const int rl = q + c;
 	const int group = variant == 0 ? 256 : (variant == 1 ? 4 : 1);
 	const int np = (n + group - 1) / group * group;
@@ -62,16 +70,25 @@ extern "C" int ngm_ref_run_score(const char *co_path, int variant, int mode, int
 	CK(hipMemcpy(dref, href.data(), href.size(), hipMemcpyHostToDevice));
 	CK(hipMemcpy(dqry, hqry.data(), hqry.size(), hipMemcpyHostToDevice));
 	CK(hipMemset(dres, 0, sizeof(float) * np));
+	char *ddir = nullptr;
+	if (dirs) {
+		std::vector<char> hd(np, 0);
+		memcpy(hd.data(), dirs, n);
+		CK(hipMalloc(&ddir, np));
+		CK(hipMemcpy(ddir, hd.data(), np, hipMemcpyHostToDevice));
+	}
+	auto with_dir = [&](std::vector<void *> v) { if (ddir) v.push_back(ddir); return v; };
 	float ms = 0;
 	const char *kname = (mode & 0xFF) == 0 ? "oclSW" : "oclSW_Global";
 	if (variant == 0) {
 		if (L.run("interleaveSeq", np, 256, {dref, dref_il}, nullptr)) return -1;
-		if (L.run(kname, np, 256, {dref_il, dqry, dres}, &ms)) return -1;
+		if (L.run(kname, np, 256, with_dir({dref_il, dqry, dres}), &ms)) return -1;
 	} else if (variant == 1) {
-		if (L.run(kname, np / 4, 1, {dref, dqry, dres}, &ms)) return -1;
+		if (L.run(kname, np / 4, 1, with_dir({dref, dqry, dres}), &ms)) return -1;
 	} else {
-		if (L.run(kname, np, 1, {dref, dqry, dres}, &ms)) return -1;
+		if (L.run(kname, np, 1, with_dir({dref, dqry, dres}), &ms)) return -1;
 	}
+	if (ddir) (void) hipFree(ddir);
 	std::vector<float> h(np);
 	CK(hipMemcpy(h.data(), dres, sizeof(float) * np, hipMemcpyDeviceToHost));
 	memcpy(scores, h.data(), sizeof(float) * n);
@@ -83,8 +100,14 @@ extern "C" int ngm_ref_run_score(const char *co_path, int variant, int mode, int
 // results4: n x 4 shorts  (ref_position, qstart, qend, alignment_offset after backtracking;
 //                          best_read_index, best_ref_index in [0],[1] when backtracking was skipped)
 // rle     : n x 2*(2q+c+1) shorts, device buffer pre-filled with 0
+extern "C" int ngm_ref_run_align_alt(const char *co_path, int variant, int mode, int n, const char *ref_flat,
+		const char *qry_flat, int q, int c, const char *dirs, short *results4, short *rle, float *kernel_ms);
 extern "C" int ngm_ref_run_align(const char *co_path, int variant, int mode, int n, const char *ref_flat,
 		const char *qry_flat, int q, int c, short *results4, short *rle, float *kernel_ms) {
+	return ngm_ref_run_align_alt(co_path, variant, mode, n, ref_flat, qry_flat, q, c, nullptr, results4, rle, kernel_ms);
+}
+extern "C" int ngm_ref_run_align_alt(const char *co_path, int variant, int mode, int n, const char *ref_flat,
+		const char *qry_flat, int q, int c, const char *dirs, short *results4, short *rle, float *kernel_ms) {
 	const int rl = q + c;
 	const int al = 2 * q + c + 1;
 	const int group = variant == 0 ? 256 : (variant == 1 ? 4 : 1);
@@ -106,19 +129,28 @@ extern "C" int ngm_ref_run_align(const char *co_path, int variant, int mode, int
 	CK(hipMemset(dres, 0, sizeof(short) * 4 * np));
 	CK(hipMemset(drle, 0, sizeof(short) * 2 * al * (size_t) np));
 	CK(hipMemset(dmat, 0, matrix_bytes));
+	char *ddir = nullptr;
+	if (dirs) {
+		std::vector<char> hd(np, 0);
+		memcpy(hd.data(), dirs, n);
+		CK(hipMalloc(&ddir, np));
+		CK(hipMemcpy(ddir, hd.data(), np, hipMemcpyHostToDevice));
+	}
+	auto with_dir = [&](std::vector<void *> v) { if (ddir) v.push_back(ddir); return v; };
 	float ms = 0;
 	const char *kname = (mode & 0xFF) == 0 ? "oclSW_Score" : "oclSW_ScoreGlobal";
 	if (variant == 0) {
 		if (L.run("interleaveSeq", np, 256, {dref, dref_il}, nullptr)) return -1;
-		if (L.run(kname, np, 256, {dref_il, dqry, dres, dmat}, &ms)) return -1;
+		if (L.run(kname, np, 256, with_dir({dref_il, dqry, dres, dmat}), &ms)) return -1;
 		if (L.run("oclSW_Backtracking", np, 256, {dref_il, dqry, dres, dmat, drle}, &ms)) return -1;
 	} else if (variant == 1) {
-		if (L.run(kname, np / 4, 1, {dref, dqry, dres, dmat}, &ms)) return -1;
+		if (L.run(kname, np / 4, 1, with_dir({dref, dqry, dres, dmat}), &ms)) return -1;
 		if (L.run("oclSW_Backtracking", np / 4, 1, {dref, dqry, dres, dmat, drle}, &ms)) return -1;
 	} else {
-		if (L.run(kname, np, 1, {dref, dqry, dres, dmat}, &ms)) return -1;
+		if (L.run(kname, np, 1, with_dir({dref, dqry, dres, dmat}), &ms)) return -1;
 		if (L.run("oclSW_Backtracking", np, 1, {dref, dqry, dres, dmat, drle}, &ms)) return -1;
 	}
+	if (ddir) (void) hipFree(ddir);
 	std::vector<short> hres((size_t) 4 * np), hrle((size_t) 2 * al * np);
 	CK(hipMemcpy(hres.data(), dres, sizeof(short) * hres.size(), hipMemcpyDeviceToHost));
 	CK(hipMemcpy(hrle.data(), drle, sizeof(short) * hrle.size(), hipMemcpyDeviceToHost));

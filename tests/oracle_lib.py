@@ -80,6 +80,19 @@ def _dirs(dirs, n):
     return d, d.ctypes.data
 
 
+
+def golden_case(g):
+    """(oracle scoring dict or None, direction bytes or None, Engine keyword arguments) of a golden file written by
+    oracle/make_goldens.py: the -D__ALT_SCORING__ cases carry `alt`, `scoring` and `dirs`."""
+    if "alt" not in g.files:
+        return None, None, {}
+    v = [int(x) for x in g["scoring"]]
+    sc = dict(zip(("match", "mismatch", "gap_read", "gap_ref", "alt", "match_alt", "mismatch_alt"), v))
+    kw = dict(match=sc["match"], mismatch=-sc["mismatch"], gap_read=-sc["gap_read"], gap_ref=-sc["gap_ref"], alt_scoring=sc["alt"],
+              match_bonus_tt=sc["match_alt"], match_bonus_tc=abs(sc["mismatch_alt"]))
+    return sc, g["dirs"], kw
+
+
 def oracle_score(mode, ref, qry, c, scoring=None, variant=0, nthreads=1, dirs=None):
     """ref [n, q+c] uint8, qry [n, q] uint8 -> float32[n]; dirs: the per-pair direction bytes of the ALT scoring modes"""
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
@@ -212,9 +225,13 @@ def ref_co_path(variant, q, c, scoring=None):
     s = dict(DEFAULT_SCORING)
     if scoring:
         s.update(scoring)
-    name = "ngm_ocl_%s_q%d_c%d_m%d_x%d_gr%d_gf%d.co" % (("gpu", "cpu", "gpu1")[variant], q, c, s["match"],
-                                                         -s["mismatch"], -s["gap_read"], -s["gap_ref"])
-    return os.path.join(ORACLE_DIR, "_ref", name)
+    name = "ngm_ocl_%s_q%d_c%d_m%d_x%d_gr%d_gf%d" % (("gpu", "cpu", "gpu1")[variant], q, c, s["match"],
+                                                      -s["mismatch"], -s["gap_read"], -s["gap_ref"])
+    if s.get("alt") == 1:     # oracle/build_ref.sh ... bs <tt> <tc>
+        name += "_bs_tt%d_tc%d" % (s["match_alt"], s["mismatch_alt"])
+    elif s.get("alt") == 2:   # ... slam <tt> <tc>  (mismatchALT = -tc)
+        name += "_slam_tt%d_tc%d" % (s["match_alt"], -s["mismatch_alt"])
+    return os.path.join(ORACLE_DIR, "_ref", name + ".co")
 
 
 _runner = None
@@ -229,25 +246,34 @@ def ref_runner():
                                           C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         lib.ngm_ref_run_align.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        lib.ngm_ref_run_score_alt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        lib.ngm_ref_run_align_alt.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         _runner = lib
     return _runner
 
 
-def ref_score(variant, mode, ref, qry, c, scoring=None):
+def ref_score(variant, mode, ref, qry, c, scoring=None, dirs=None):
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     qry = np.ascontiguousarray(qry, dtype=np.uint8)
     n, q = qry.shape
     out = np.empty(n, dtype=np.float32)
     ms = C.c_float(0)
     co = ref_co_path(variant, q, c, scoring)
-    r = ref_runner().ngm_ref_run_score(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c,
-                                       out.ctypes.data, C.byref(ms))
+    if scoring and scoring.get("alt"):   # a -D__ALT_SCORING__ build: its kernels take the direction bytes
+        d = np.zeros(n, np.uint8) if dirs is None else np.ascontiguousarray(dirs, dtype=np.uint8)
+        r = ref_runner().ngm_ref_run_score_alt(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c, d.ctypes.data,
+                                               out.ctypes.data, C.byref(ms))
+    else:
+        r = ref_runner().ngm_ref_run_score(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c,
+                                           out.ctypes.data, C.byref(ms))
     if r != n:
         raise RuntimeError("reference kernel run failed (%s)" % co)
     return out, ms.value
 
 
-def ref_align(variant, mode, ref, qry, c, scoring=None):
+def ref_align(variant, mode, ref, qry, c, scoring=None, dirs=None):
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     qry = np.ascontiguousarray(qry, dtype=np.uint8)
     n, q = qry.shape
@@ -256,8 +282,13 @@ def ref_align(variant, mode, ref, qry, c, scoring=None):
     rle = np.zeros((n, 2 * al), dtype=np.int16)
     ms = C.c_float(0)
     co = ref_co_path(variant, q, c, scoring)
-    r = ref_runner().ngm_ref_run_align(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c,
-                                       res.ctypes.data, rle.ctypes.data, C.byref(ms))
+    if scoring and scoring.get("alt"):
+        d = np.zeros(n, np.uint8) if dirs is None else np.ascontiguousarray(dirs, dtype=np.uint8)
+        r = ref_runner().ngm_ref_run_align_alt(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c, d.ctypes.data,
+                                               res.ctypes.data, rle.ctypes.data, C.byref(ms))
+    else:
+        r = ref_runner().ngm_ref_run_align(co.encode(), variant, mode, n, ref.ctypes.data, qry.ctypes.data, q, c,
+                                           res.ctypes.data, rle.ctypes.data, C.byref(ms))
     if r != n:
         raise RuntimeError("reference kernel run failed (%s)" % co)
     return res, rle, ms.value

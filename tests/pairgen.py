@@ -97,3 +97,23 @@ def make_pairs(n, q, c, seed=1, read_len=None, sub_rate=0.02, indel_rate=0.004,
         ref[i] = win
         qry[i, :len(read)] = read
     return ref, qry
+
+
+def make_alt_pairs(n, q, c, seed=1, read_len=None, alt=1, conv_rate=0.6):
+    """Pairs for the strand-specific score tables of `--bs-mapping` (alt 1) / `--slam-seq` (alt 2): make_pairs plus a random table
+    choice per pair (the `direction` byte) and reads converted the way the protocol converts them on that strand --
+    bisulfite: read C -> T (direction 0) or G -> A (direction 1); SLAM-seq: read T -> C or A -> G -- so that the ALT rows of the
+    tables (oclDefines.cl:94-128) and the conversion branch of computeCigarMD (SWOclCigar.cpp:507-514) carry weight.
+    Returns (ref, qry, dirs uint8[n])."""
+    ref, qry = make_pairs(n, q, c, seed=seed, read_len=read_len)
+    rng = np.random.default_rng(seed + 7919)
+    dirs = (rng.random(n) < 0.5).astype(np.uint8)
+    frm = {(1, 0): b"C", (1, 1): b"G", (2, 0): b"T", (2, 1): b"A"}
+    to = {(1, 0): b"T", (1, 1): b"A", (2, 0): b"C", (2, 1): b"G"}
+    for d in (0, 1):
+        rows = np.nonzero(dirs == d)[0]
+        sub = qry[rows]
+        m = (sub == frm[(alt, d)][0]) & (rng.random(sub.shape) < conv_rate)
+        sub[m] = to[(alt, d)][0]
+        qry[rows] = sub
+    return ref, qry, dirs

@@ -112,3 +112,67 @@ def test_two_device_entries_on_one_gpu_give_the_same_output(tmp_path):
             assert "2 GPU(s)" in c.stderr
         outs.append([l for l in open(out) if not l.startswith("@PG")])
     assert outs[0] == outs[1] and len([l for l in outs[0] if not l.startswith("@")]) == n
+
+
+def _bs_reads(contigs, n, paired, seed):
+    """Bisulfite-converted reads of a directional library: a first mate (or single read) shows most unmethylated C of the strand it
+    was sequenced from as T, a second mate -- the reverse complement of that strand -- shows G as A, whichever strand of the
+    genome the fragment came from (that is what CS::RunBatch's mutateFrom / mutateTo assume, src/CS.cpp:356-376)."""
+    rng = np.random.default_rng(seed)
+
+    def convert(reads, second):
+        out = []
+        frm, to = (ord("G"), ord("A")) if second else (ord("C"), ord("T"))
+        for name, seq, qual in reads:
+            s = seq.copy()
+            m = (s == frm) & (rng.random(len(s)) < 0.9)
+            s[m] = to
+            out.append((name, s, qual))
+        return out
+    if paired:
+        r1, r2 = S.make_reads(contigs, n, 100, seed=seed, sub_rate=0.01, indel_rate=0.002, paired=True)
+        return convert(r1, False), convert(r2, True)
+    return convert(S.make_reads(contigs, n, 100, seed=seed, sub_rate=0.01, indel_rate=0.002), False), None
+
+
+@needs
+@pytest.mark.parametrize("layout", ["single-end", "paired-end"])
+def test_bisulfite_mapping_real_program_with_plugin_vs_ngm_hip(tmp_path, layout):
+    """`--bs-mapping`.  The stock program cannot run this mode here (it excludes --affine, and the OpenCL
+    backend has no device), so the oracle is the REAL program with this library behind IAlignment: its own CS::PrefixMutateSearch
+    (src/CS.cpp:54-112), skip-0 index, ScoreBuffer direction bytes, computeCigarMD callers and SAMWriter (ZS tag) drive BatchScore /
+    BatchAlign -- against ngm-hip, whose k-mer mutation search, direction bits and ZS tag are this repository's own."""
+    contigs = S.make_genome([300000, 200001], seed=911, repeat_families=6, repeat_len=400, copies=4)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    paired = layout == "paired-end"
+    r1, r2 = _bs_reads(contigs, 1500 if paired else 2500, paired, 912)
+    fq = str(tmp_path / "reads.fq")
+    if paired:
+        S.write_fastq(fq, [x for pair in zip(r1, r2) for x in pair])
+        inp, n = ["-p", "-q", fq], 2 * len(r1)
+    else:
+        S.write_fastq(fq, r1)
+        inp, n = ["-q", fq], len(r1)
+    d1 = tmp_path / "plug"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    plug, ours = str(d1 / "plugin.sam"), str(tmp_path / "ours.sam")
+    log = _run(DROPIN, fa1, inp + ["--bs-mapping"], plug, str(d1))
+    c = subprocess.run([CLI, "-r", fa, "-o", ours, "--bs-mapping"] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    rec = lambda p: {(l.split("\t", 2)[0], int(l.split("\t", 2)[1]) & 0xC0): l for l in open(p) if not l.startswith("@")}
+    a, b = rec(plug), rec(ours)
+    assert set(a) == set(b) and len(a) == n
+    mapped = sum(1 for v in a.values() if not int(v.split("\t")[1]) & 4)
+    assert mapped > 0.8 * n, "the converted reads must map (%d of %d)" % (mapped, n)
+    assert all("\tZS:Z:" in v for v in a.values() if not int(v.split("\t")[1]) & 4)
+    diff = [(a[k], b[k]) for k in a if a[k] != b[k]]
+    print("records differing:", len(diff), "of", len(a))
+    assert not diff, str(diff[:2])[:1500]

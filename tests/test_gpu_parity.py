@@ -87,8 +87,9 @@ def test_batch_align_matches_reference_cigar_goldens(path, mode, clip):
     g = np.load(path.replace("_cigar.npz", ".npz"))
     ref, qry, c, variant = g["ref"], g["qry"], int(g["c"]), int(g["variant"])
     rows, want = cigar_golden_rows(path, mode, clip)
-    eng = _engine(qry.shape[1], c, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2))
-    got = eng.BatchAlign(mode, ref, qry)
+    _, dirs, kw = O.golden_case(g)
+    eng = _engine(qry.shape[1], c, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2), **kw)
+    got = eng.BatchAlign(mode, ref, qry, dirs)
     for j, i in enumerate(rows):
         a = got[i]
         have = (True, a["cigar"], a["md"], a["nm"], np.float32(a["identity"]).tobytes(), a["qstart"], a["qend"], a["position_offset"],
@@ -102,9 +103,10 @@ def test_scores_match_reference_goldens(path):
     """Scores straight against what NextGenMap's own kernels produced on the MI355X."""
     g = np.load(path)
     ref, qry, c, variant = g["ref"], g["qry"], int(g["c"]), int(g["variant"])
-    eng = _engine(qry.shape[1], c, variant=variant)
-    assert np.array_equal(eng.BatchScore(0, ref, qry), g["local_score"])
-    assert np.array_equal(eng.BatchScore(1, ref, qry), g["endfree_score"])
+    _, dirs, kw = O.golden_case(g)
+    eng = _engine(qry.shape[1], c, variant=variant, **kw)
+    assert np.array_equal(eng.BatchScore(0, ref, qry, dirs), g["local_score"])
+    assert np.array_equal(eng.BatchScore(1, ref, qry, dirs), g["endfree_score"])
     eng.close()
 
 
@@ -194,4 +196,43 @@ def test_long_reads_at_the_limits_of_the_packed_16_bit_kernels(q, c, rl):
         assert np.array_equal(eng.BatchScore(mode, ref, qry), sc)
         al = eng.BatchAlign(mode, ref, qry)
         assert [a["cigar"] for a in al] == cig
+    eng.close()
+
+
+# ---- strand-specific score tables: `--bs-mapping` / `--slam-seq 2` -------------------------------------------
+ALT_CASES = {"bs": (O.BS_SCORING, dict(match=4, mismatch=2, gap_read=10, gap_ref=10, alt_scoring=1, match_bonus_tt=4, match_bonus_tc=4)),
+             "slam": (O.SLAM_SCORING, dict(match=10, mismatch=15, gap_read=20, gap_ref=20, alt_scoring=2, match_bonus_tt=10, match_bonus_tc=2)),
+             "bs-custom": (dict(match=5, mismatch=-3, gap_read=-9, gap_ref=-11, alt=1, match_alt=6, mismatch_alt=2),
+                           dict(match=5, mismatch=3, gap_read=9, gap_ref=11, alt_scoring=1, match_bonus_tt=6, match_bonus_tc=2))}
+
+
+@pytest.mark.parametrize("kind", sorted(ALT_CASES))
+@pytest.mark.parametrize("q,c,rl", [(102, 20, 100), (152, 27, 150), (252, 42, 250), (52, 11, 50)])
+@pytest.mark.parametrize("variant", [0, 1], ids=["oclgpu", "oclcpu"])
+def test_alt_scoring_matches_oracle(kind, q, c, rl, variant):
+    """BatchScore / BatchAlign with per-pair direction bytes (extData) against the restatement of the -D__ALT_SCORING__ kernels
+    and of computeCigarMD's conversion branch (lib/mason/opencl/opencl/oclDefines.cl:94-128, SWOclCigar.cpp:300-317, :496-520)."""
+    from pairgen import make_alt_pairs
+    scoring, eng_kw = ALT_CASES[kind]
+    n = 1200 if q <= 152 else 300
+    ref, qry, dirs = make_alt_pairs(n, q, c, seed=300 + q + c, read_len=rl, alt=scoring["alt"])
+    eng = _engine(q, c, variant=variant, **eng_kw)
+    for mode in (0, 1):
+        got = eng.BatchScore(mode, ref, qry, dirs)
+        want = O.oracle_score(mode, ref, qry, c, scoring, variant=variant, nthreads=8, dirs=dirs)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "mode %d first mismatches: %s" % (mode, [(int(i), int(dirs[i]), float(got[i]), float(want[i])) for i in bad[:5]])
+        # the direction must matter (else the test proves nothing)
+        assert np.any(O.oracle_score(mode, ref, qry, c, scoring, variant=variant, nthreads=8, dirs=1 - dirs) != want)
+        al = eng.BatchAlign(mode, ref, qry, dirs)
+        res, cig, md = O.oracle_align(mode, ref, qry, c, scoring, variant=variant, nthreads=8, dirs=dirs)
+        for i in range(n):
+            g = al[i]
+            if not res["ok"][i]:
+                assert g["score_token"] == -1.0
+                continue
+            exp = (cig[i], md[i], int(res["position_offset"][i]), int(res["qstart"][i]), int(res["qend"][i]), int(res["nm"][i]),
+                   np.float32(res["identity"][i]).tobytes(), float(res["score_token"][i]))
+            have = (g["cigar"], g["md"], g["position_offset"], g["qstart"], g["qend"], g["nm"], np.float32(g["identity"]).tobytes(), float(g["score_token"]))
+            assert have == exp, "mode %d pair %d dir %d: %r != %r" % (mode, i, int(dirs[i]), have, exp)
     eng.close()

@@ -25,10 +25,11 @@ def test_oracle_matches_reference_kernels(path, mode):
     al = 2 * q + c + 1
     mn = "local" if mode == 0 else "endfree"
     # BatchScore kernels (oclSW / oclSW_Global): bit-exact
-    sc = O.oracle_score(mode, ref, qry, c, variant=variant)
+    scoring, dirs, _ = O.golden_case(g)
+    sc = O.oracle_score(mode, ref, qry, c, scoring, variant=variant, dirs=dirs)
     assert np.array_equal(sc, g[mn + "_score"])
     # BatchAlign kernels (oclSW_Score[Global] + oclSW_Backtracking): raw outputs, bit-exact
-    res, rle, valid, _ = O.oracle_trace(mode, ref, qry, c, variant=variant)
+    res, rle, valid, _ = O.oracle_trace(mode, ref, qry, c, scoring, variant=variant, dirs=dirs)
     assert np.array_equal(valid, g[mn + "_valid"])
     assert np.array_equal(res[:, :3], g[mn + "_res"][:, :3])
     assert np.array_equal(res[valid, 3], g[mn + "_res"][valid, 3])
@@ -93,7 +94,8 @@ def test_oracle_cigar_md_matches_reference_function(path, mode, clip):
     if clip and qry.shape[1] > 152:
         pytest.skip("clipping modes only change the string conversion: covered on the shapes up to 150 bp (CPU-suite time)")
     rows, want = cigar_golden_rows(path, mode, clip)
-    res, cig, md = O.oracle_align(mode, ref, qry, c, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2), nthreads=8)
+    scoring, dirs, _ = O.golden_case(g)
+    res, cig, md = O.oracle_align(mode, ref, qry, c, scoring, variant=variant, hard_clip=int(clip == 1), silent_clip=int(clip == 2), nthreads=8, dirs=dirs)
     for j, i in enumerate(rows):
         have = (bool(res["ok"][i]), cig[i], md[i], int(res["nm"][i]), np.float32(res["identity"][i]).tobytes(), int(res["qstart"][i]),
                 int(res["qend"][i]), int(res["position_offset"][i]), float(res["score_token"][i]))

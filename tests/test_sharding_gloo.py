@@ -75,7 +75,7 @@ def test_bench_control_path_two_ranks(tmp_path):
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["unit"] == "reads/s"
     st = j["stats_allreduce"]
     from nextgenmap_amd.sharding import STAT_NAMES
-    assert tuple(st.keys()) == STAT_NAMES
+    assert tuple(st.keys()) == STAT_NAMES + ("ranks_seen",) and st["ranks_seen"] == 2
     # 40 000 reads over both ranks; the stub leaves global reads 999, 1999, ... unmapped
     assert st["reads"] == 40000 and st["unmapped"] == 40 and st["mapped"] == 40000 - 40 and st["written"] == 40000
     assert st["pairs_total"] == 20000 and st["insert_cnt"] == 20000 - 40
