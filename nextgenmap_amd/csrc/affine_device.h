@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void sw_affine_kernel(const uint32_t *__restri
 
 // Score-only variant, packed 16-bit: two pairs per lane (blocks 2w and 2w+1), S / Eh / Ev in the 16-bit halves of one
 // VGPR, v_pk_add_i16 / v_pk_max_i16 on both pairs at once.  Only the maximum is needed here (no end cell), so SeqAn's
-// tie rules drop out; the local clamp "S <= 0 -> S = Eh = Ev = 0" is the only select and is done arithmetically:
-// nz = min(max(S' - floor, 0), 1) is 1 exactly where the cell survives, X' = floor + (X' - floor) * nz.
+// tie rules drop out.  Of the local clamp "S <= 0 -> S = Eh = Ev = 0" only S = max(S, 0) is executed: where a cell is clamped
+// Eh, Ev <= S <= 0 already, a gap state <= 0 only produces gap states < 0 (extension costs), and a value <= 0 never wins the
+// maximum of a cell whose clamped score is > 0 -- so every positive S, Eh, Ev equals SeqAn's and the non-positive ones, which
+// may differ from SeqAn's 0, are never read into a result (12 packed operations per cell pair instead of 21).
 // Valid while the re-based values fit 16 bits (checked by the host, which otherwise uses the 32-bit kernel).
 constexpr int kAffNeg16 = -20000;
 
@@ -306,10 +308,8 @@ __global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t 
 				v2s ev = (d < CP - 1) ? pk_max(Ev[d + 1] + vext2, S[d + 1] + vopen2) : neg2;
 				v2s sc = pk_max(pk_max(ev, eh), dg);
 				if (!ENDFREE) {
-					const v2s nz = __builtin_elementwise_min(pk_max(sc - fl2, zero2), one2);  // 1 where the cell is not clamped
+					// local clamp: only S is clamped (see the note above the kernel)
 					sc = pk_max(sc, fl2);
-					eh = fl2 + (eh - fl2) * nz;
-					ev = fl2 + (ev - fl2) * nz;
 					rowmax = pk_max(rowmax, sc);
 				}
 				S[d] = sc;
@@ -360,6 +360,21 @@ __global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t 
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int aff_nib_words(int CP) { return (CP + 7) / 8; }
 __device__ __forceinline__ v2s pk_min(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s pk_min_op(v2s a, v2s b) {  // (opaque to the optimizer, see took4 below)
+	v2s r;
+	asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ v2s pk_mul(v2s a, v2s b) {
+	v2s r;
+	asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ v2s pk_mad(v2s a, v2s b, v2s c) {  // a * b + c per 16-bit half, one instruction
+	v2s r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
 __device__ __forceinline__ v2s pk_sub_sat(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }  // v_pk_sub_i16 ... clamp
 
 // WINDOW: for bands of more than 32 columns or scores of 2 048 and more the row key is (score - base) << 7 | 127 - d with a
@@ -449,16 +464,19 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 				if (d == 0) { gm = ev; fh = zero2; } else if (d == CP - 1) { gm = eh; fh = one2; } else { gm = pk_max(ev, eh); fh = pk_min(pk_sub_sat(gm, ev), one2); }
 				v2s sc = pk_max(gm, dg);
 				const v2s nd = pk_min(pk_sub_sat(sc, dg), one2);
-				const v2s pos = pk_max(sc - fl2, zero2);     // the cell's score; 0: clamped (S = Eh = Ev = 0, no trace)
-				const v2s nz = pk_min(pos, one2);
+				const v2s pos = pk_max(sc - fl2, zero2);     // the cell's score; 0: clamped (S = 0, no trace)
+				const v2s nz = pk_min_op(pos, one2);
 				sc = pk_max(sc, fl2);
-				eh = fl2 + (eh - fl2) * nz;
-				ev = fl2 + (ev - fl2) * nz;
-				const v2s took = nz * (one2 + nd * (two2 - fh));  // 0 none, 1 diagonal, 2 horizontal maximum, 3 vertical maximum
-				const v2s nib = took * four2 + vo * two2 + ho;
+				// Eh / Ev are left as they are where the cell is clamped (SeqAn: 0): they are <= 0 there, and gap states <= 0 never reach a
+				// cell of the path -- along it every S, and every gap state it walks through, is > 0 and equals SeqAn's, and "opened
+				// here" compares such a value with the extension of a predecessor that is either equal to SeqAn's or, in both, below it
+				// 0 none, 1 diagonal, 2 horizontal maximum, 3 vertical maximum -- times 4; (as instructions: the compiler turns a product
+				// with a 0 / 1 factor into two compares and two selects per cell pair)
+				const v2s took4 = pk_mul(pk_mad(nd, two2 - fh, one2), pk_mad(nz, four2, zero2));
+				const v2s nib = took4 + pk_mad(vo, two2, ho);
 				acc[(d >> 2) & 1] |= __builtin_bit_cast(uint32_t, nib) << (4 * (d & 3));
-				if (WINDOW) rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_min(pk_max(pos - base2, zero2), win_max2) * k32 + pk_splat(127 - d)));
-				else rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pos * k32 + pk_splat(31 - d)));
+				if (WINDOW) rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_mad(pk_min(pk_max(pos - base2, zero2), win_max2), k32, pk_splat(127 - d))));
+				else rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_mad(pos, k32, pk_splat(31 - d))));
 				S[d] = sc;
 				Ev[d] = ev;
 				leftS = sc;

@@ -24,7 +24,7 @@ void log_msg(int lvl, const char *msg) {
 
 class HipAlignment : public IAlignment {
 public:
-	HipAlignment(ngm_hip_ctx *ctx, bool alt) : ctx_(ctx), alt_(alt) {}
+	HipAlignment(ngm_hip_ctx *ctx, bool alt, bool slam) : ctx_(ctx), alt_(alt), slam_(slam) {}
 	~HipAlignment() override { ngm_hip_destroy(ctx_); }
 
 	int GetScoreBatchSize() const override { return ngm_hip_score_batch_size(ctx_); }
@@ -58,13 +58,61 @@ public:
 			results[i].Score = out[i].score_token;
 			results[i].Identity = out[i].identity;
 			results[i].NM = out[i].nm;
+			if (slam_ && out[i].score_token != -1.0f) results[i].ExtendedData = slam_records(refSeqList[i] + out[i].position_offset, qrySeqList[i], out[i]);
 		}
 		return r;
 	}
 
 private:
+	// SLAM-seq: the per-column records computeCigarMD leaves behind Align::ExtendedData (lib/mason/opencl/SWOclCigar.cpp:442-447,
+	// :484-497, :523-536) for the TC / RA / MP tags of the writers (src/writer/GenericReadWriter.h:87-187): one per '=' / 'X'
+	// column -- type = 5 * class(ref) + class(read), read and alignment-relative reference position, match -- closed by the default
+	// record (type -1).  The columns come from the CIGAR, '=' or 'X' from the MD string (a letter outside '^' runs is an 'X'
+	// column of the device's element list).  Freed by the caller with delete[] (src/MappedRead.cpp:97-99).
+	static void *slam_records(const char *ref, const char *qry, const ngm_hip_align_out &o) {
+		static const auto cls = [](char ch) -> int {
+			switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+		};
+		size_t cols = 0;
+		for (const char *c = o.cigar; *c;) { int n = 0; while (*c >= '0' && *c <= '9') n = n * 10 + (*c++ - '0'); if (!*c) break; if (*c == 'M') cols += (size_t) n; ++c; }
+		AlignmentPosition *rec = new AlignmentPosition[cols + 1], *w = rec;
+		const char *md = o.md;
+		long eq_left = 0;
+		int read_i = o.qstart, ref_i = 0;
+		for (const char *c = o.cigar; *c;) {
+			int n = 0;
+			while (*c >= '0' && *c <= '9') n = n * 10 + (*c++ - '0');
+			if (!*c) break;
+			const char op = *c++;
+			if (op == 'M') {
+				for (int k = 0; k < n; ++k, ++w) {
+					bool match = true;
+					for (;;) {
+						if (eq_left > 0) { --eq_left; break; }
+						if (*md >= '0' && *md <= '9') { while (*md >= '0' && *md <= '9') eq_left = eq_left * 10 + (*md++ - '0'); if (eq_left == 0 && !(*md >= 'A' && *md <= 'Z') && !(*md >= 'a' && *md <= 'z')) break; continue; }
+						if (*md && *md != '^') { ++md; match = false; }
+						break;
+					}
+					w->type = 5 * cls(ref[ref_i + k]) + cls(qry[read_i + k]);
+					w->readPosition = read_i + k;
+					w->refPosition = ref_i + k;
+					w->match = match;
+				}
+				read_i += n; ref_i += n;
+			} else if (op == 'I') {
+				read_i += n;
+			} else if (op == 'D') {
+				while (*md >= '0' && *md <= '9') ++md;   // the "0" (or the matches already consumed) in front of '^'
+				eq_left = 0;
+				if (*md == '^') { ++md; for (int k = 0; k < n && *md; ++k) ++md; }
+				ref_i += n;
+			}
+		}
+		return rec;
+	}
+
 	ngm_hip_ctx *ctx_;
-	bool alt_;
+	bool alt_, slam_;
 };
 
 bool integral(float v, int *out) {
@@ -89,13 +137,8 @@ IAlignment *CreateAlignment(int const mode) {
 	const int report = (mode >> 8) & 0xFF;
 	if (report != 1) { log_msg(2, "Unsupported report type (only CIGAR + MD output is implemented)"); return nullptr; }
 	IConfig &cfg = *g_config;
-	// SLAM-seq needs the per-base records behind Align::ExtendedData (SWOclCigar.cpp:442-447, :484-540) for the TC / RA / MP
-	// tags (src/writer/GenericReadWriter.h:87-180): not produced here yet, so that mode is refused rather than written without them
-	if (cfg.Exists("slam_seq") && cfg.GetInt("slam_seq") != 0) {
-		log_msg(2, "SLAM-seq (--slam-seq) is not implemented in the HIP backend");
-		return nullptr;
-	}
 	const bool bs = cfg.Exists("bs_mapping") && cfg.GetInt("bs_mapping") == 1;
+	const int slam = cfg.Exists("slam_seq") ? cfg.GetInt("slam_seq") : 0;
 	ngm_hip_params p{};
 	p.abi_version = NGM_HIP_ABI_VERSION;
 	p.qry_max_len = cfg.GetInt("qry_max_len");
@@ -116,16 +159,18 @@ IAlignment *CreateAlignment(int const mode) {
 		log_msg(2, "the HIP backend needs an integer gap_extend_penalty");
 		return nullptr;
 	}
-	if (bs) {  // lib/mason/opencl/SWOcl.cpp:228-232
-		p.alt_scoring = NGM_ALT_BISULFITE;
+	if (bs || (slam & 2)) {  // lib/mason/opencl/SWOcl.cpp:225-242 (SLAM-seq negates match_bonus_tc itself, :237: the engine does the same)
+		p.alt_scoring = bs ? NGM_ALT_BISULFITE : NGM_ALT_SLAMSEQ;
 		if (!integral(cfg.GetFloat("match_bonus_tt"), &p.match_bonus_tt) || !integral(cfg.GetFloat("match_bonus_tc"), &p.match_bonus_tc)) {
 			log_msg(2, "the HIP backend needs integer scores (match_bonus_tt, match_bonus_tc)");
 			return nullptr;
 		}
 	}
+	// computeCigarMD's conversion rule (SWOclCigar.cpp:301-320): slam_seq, any value, wins over bs_mapping
+	p.alt_cigar = slam ? NGM_ALT_SLAMSEQ : (bs ? NGM_ALT_BISULFITE : NGM_ALT_NONE);
 	ngm_hip_ctx *ctx = ngm_hip_create(mode & 0xFF, &p);
 	if (!ctx) { log_msg(2, ngm_hip_last_error(nullptr)); return nullptr; }
-	return new HipAlignment(ctx, bs);
+	return new HipAlignment(ctx, bs || slam != 0, slam != 0);
 }
 
 void DeleteAlignment(IAlignment *instance) { delete instance; }

@@ -176,3 +176,66 @@ def test_bisulfite_mapping_real_program_with_plugin_vs_ngm_hip(tmp_path, layout)
     diff = [(a[k], b[k]) for k in a if a[k] != b[k]]
     print("records differing:", len(diff), "of", len(a))
     assert not diff, str(diff[:2])[:1500]
+
+
+@needs
+@pytest.mark.parametrize("layout", ["single-end", "paired-end"])
+@pytest.mark.parametrize("slam", [1, 2])
+def test_slam_seq_real_program_with_plugin_vs_ngm_hip(tmp_path, layout, slam):
+    """`--slam-seq 1|2`: 1 = conversion-aware NM / identity plus the TC / RA / MP tags, 2 = the strand-specific
+    SLAM-seq score tables as well.  As for bisulfite the oracle is the REAL program with this library behind IAlignment: its
+    ScoreBuffer / AlignmentBuffer direction bytes and SAMWriter::computeSlaSeqTags (src/writer/GenericReadWriter.h:87-187) over the
+    adapter's Align::ExtendedData records -- against ngm-hip, which builds the three tags on the GPU (csrc/sam_device.h)."""
+    contigs = S.make_genome([300000, 200001], seed=921, repeat_families=6, repeat_len=400, copies=4)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    paired = layout == "paired-end"
+    rng = np.random.default_rng(922)
+
+    def convert(reads, second):   # 4-thiouridine: T read as C on the sequenced strand (second mates: A as G)
+        out = []
+        frm, to = (ord("A"), ord("G")) if second else (ord("T"), ord("C"))
+        for name, seq, qual in reads:
+            s = seq.copy()
+            s[(s == frm) & (rng.random(len(s)) < 0.08)] = to
+            out.append((name, s, qual))
+        return out
+    fq = str(tmp_path / "reads.fq")
+    if paired:
+        r1, r2 = S.make_reads(contigs, 1500, 100, seed=923, sub_rate=0.01, indel_rate=0.002, paired=True)
+        r1, r2 = convert(r1, False), convert(r2, True)
+        S.write_fastq(fq, [x for pair in zip(r1, r2) for x in pair])
+        inp, n = ["-p", "-q", fq], 2 * len(r1)
+    else:
+        r1 = convert(S.make_reads(contigs, 2500, 100, seed=923, sub_rate=0.01, indel_rate=0.002), False)
+        S.write_fastq(fq, r1)
+        inp, n = ["-q", fq], len(r1)
+    d1 = tmp_path / "plug"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    plug, ours = str(d1 / "plugin.sam"), str(tmp_path / "ours.sam")
+    _run(DROPIN, fa1, inp + ["--slam-seq", str(slam)], plug, str(d1))
+    c = subprocess.run([CLI, "-r", fa, "-o", ours, "--slam-seq", str(slam)] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    rec = lambda p: {(l.split("\t", 2)[0], int(l.split("\t", 2)[1]) & 0xC0): l for l in open(p) if not l.startswith("@")}
+    a, b = rec(plug), rec(ours)
+    assert set(a) == set(b) and len(a) == n
+    mapped = [v for v in a.values() if not int(v.split("\t")[1]) & 4]
+    assert len(mapped) > 0.9 * n
+    assert all("\tTC:i:" in v and "\tRA:Z:" in v for v in mapped)
+    assert sum(int(v.split("\tTC:i:")[1].split("\t")[0]) for v in mapped) > n, "the conversions must be counted"
+    diff = [(a[k], b[k]) for k in a if a[k] != b[k]]
+    print("records differing:", len(diff), "of", len(a))
+    assert not diff, str(diff[:2])[:1500]
+    # the host formatter (NGM_HIP_HOST_SAM=1) writes the same tags
+    host = str(tmp_path / "host.sam")
+    c = subprocess.run([CLI, "-r", fa, "-o", host, "--slam-seq", str(slam)] + inp, capture_output=True, text=True, env=dict(os.environ, NGM_HIP_HOST_SAM="1"))
+    assert c.returncode == 0, c.stderr[-2000:]
+    strip = lambda p: [l for l in open(p) if not l.startswith("@PG")]
+    assert strip(host) == strip(ours)
