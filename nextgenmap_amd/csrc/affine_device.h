@@ -357,25 +357,7 @@ __global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t 
 // * _correctTraceValue's "Ev == S" / "Eh == S" flags at the end cell are always clear here: with negative gap penalties a
 //   gap state is strictly below some earlier S, and the end cell holds the maximum of all S (the host takes this kernel only
 //   then; end-to-end alignments -- which may end in a gap -- stay with sw_affine_kernel).
-typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int aff_nib_words(int CP) { return (CP + 7) / 8; }
-__device__ __forceinline__ v2s pk_min(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ v2s pk_min_op(v2s a, v2s b) {  // (opaque to the optimizer, see took4 below)
-	v2s r;
-	asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-	return r;
-}
-__device__ __forceinline__ v2s pk_mul(v2s a, v2s b) {
-	v2s r;
-	asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-	return r;
-}
-__device__ __forceinline__ v2s pk_mad(v2s a, v2s b, v2s c) {  // a * b + c per 16-bit half, one instruction
-	v2s r;
-	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-	return r;
-}
-__device__ __forceinline__ v2s pk_sub_sat(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }  // v_pk_sub_i16 ... clamp
 
 // WINDOW: for bands of more than 32 columns or scores of 2 048 and more the row key is (score - base) << 7 | 127 - d with a
 // per-pair base that follows the running row maximum: a row's maximum is at least the previous row's minus one mismatch (the
@@ -465,7 +447,7 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 				v2s sc = pk_max(gm, dg);
 				const v2s nd = pk_min(pk_sub_sat(sc, dg), one2);
 				const v2s pos = pk_max(sc - fl2, zero2);     // the cell's score; 0: clamped (S = 0, no trace)
-				const v2s nz = pk_min_op(pos, one2);
+				const v2s nz = pk_min1_op(pos);
 				sc = pk_max(sc, fl2);
 				// Eh / Ev are left as they are where the cell is clamped (SeqAn: 0): they are <= 0 there, and gap states <= 0 never reach a
 				// cell of the path -- along it every S, and every gap state it walks through, is > 0 and equals SeqAn's, and "opened
@@ -475,8 +457,8 @@ __global__ __launch_bounds__(256) void sw_affine_align_pk_kernel(const uint32_t 
 				const v2s took4 = pk_mul(pk_mad(nd, two2 - fh, one2), pk_mad(nz, four2, zero2));
 				const v2s nib = took4 + pk_mad(vo, two2, ho);
 				acc[(d >> 2) & 1] |= __builtin_bit_cast(uint32_t, nib) << (4 * (d & 3));
-				if (WINDOW) rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_mad(pk_min(pk_max(pos - base2, zero2), win_max2), k32, pk_splat(127 - d))));
-				else rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_mad(pos, k32, pk_splat(31 - d))));
+				if (WINDOW) rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_mad_k(pk_min(pk_max(pos - base2, zero2), win_max2), k32, 127 - d)));
+				else rowkey = __builtin_elementwise_max(rowkey, __builtin_bit_cast(v2u, pk_mad_k(pos, k32, 31 - d)));
 				S[d] = sc;
 				Ev[d] = ev;
 				leftS = sc;

@@ -364,6 +364,96 @@ struct Batch {
 };
 constexpr int kSub = 1024;
 
+// ---- record index of a plain FASTQ file, built by all pool threads ----------------------------------------------------
+// The file is cut into byte ranges; every range finds its first record (a line that starts with '@' whose second-next line
+// starts with '+': in 4-line FASTQ only header lines have that -- a quality line that starts with '@' is followed by a header and a
+// sequence), counts its records, and after a prefix sum over the ranges walks them again to note the byte offset of every
+// `step`-th record of the FILE and, for the first input file, what ReadProvider's estimation pass collects (read lengths of the
+// first 10 000 001 non-empty reads, every 1 000-th of the first 10 000 000 for the sensitivity sample; src/ReadProvider.cpp:201-305).
+struct FastqIndex {
+	bool ok = false;
+	size_t bad_at = 0;                 // !ok: offset of the record that is not a 4-line FASTQ record
+	std::string length_error;          // the first read whose sequence and quality lengths differ (IParser.h copyToRead), if any
+	int step = kSub;
+	std::vector<size_t> sub;           // offset of record 0, step, 2 step, ...; one more entry: the end of the last record
+	size_t n_records = 0, n_nonempty = 0;
+	size_t max_len = 0, min_len = 9999999, sum_len = 0, count = 0;   // the estimation pass's numbers
+	std::vector<Read> sample;
+};
+
+void build_fastq_index(const MappedFile &f, int step, bool stats, FastqIndex &ix) {
+	ngm::ThreadPool &pool = ngm::ThreadPool::instance();
+	const int T = (int) std::max<size_t>(1, std::min<size_t>((size_t) pool.size() * 4, f.n >> 20));
+	struct Range { size_t start = 0, n_rec = 0, n_ne = 0, bad_at = 0, rec_base = 0, ne_base = 0, max_len = 0, min_len = 9999999, sum_len = 0; bool bad = false; std::string len_err; std::vector<Read> sample; };
+	std::vector<Range> rg((size_t) T + 1);
+	rg[T].start = f.n;
+	auto line_start_after = [&](size_t o) -> size_t {  // first line start at or after o
+		if (o == 0 || f.p[o - 1] == '\n') return o;
+		const char *c = (const char *) memchr(f.p + o, '\n', f.n - o);
+		return c ? (size_t) (c + 1 - f.p) : f.n;
+	};
+	auto next_line = [&](size_t o) -> size_t { const char *c = o < f.n ? (const char *) memchr(f.p + o, '\n', f.n - o) : nullptr; return c ? (size_t) (c + 1 - f.p) : f.n; };
+	pool.parallel_for(T, [&](int lo, int hi) {
+		for (int r = lo; r < hi; ++r) {
+			size_t at = r == 0 ? 0 : line_start_after(f.n / T * r);
+			if (r > 0) {
+				// a header line: '@' here and '+' two lines on
+				for (; at < f.n; at = next_line(at)) {
+					if (f.p[at] != '@') continue;
+					const size_t l2 = next_line(next_line(at));
+					if (l2 < f.n && f.p[l2] == '+') break;
+				}
+			}
+			rg[r].start = at;
+		}
+	}, 1);
+	for (int r = 1; r <= T; ++r) if (rg[r].start < rg[r - 1].start) rg[r].start = rg[r - 1].start;  // (ranges shorter than a record)
+	auto walk = [&](int r, bool second) {
+		Range &R = rg[r];
+		Rec rec;
+		size_t at = R.start, g = R.rec_base, c = R.ne_base;
+		const size_t end = rg[r + 1].start;
+		while (at < end) {
+			const size_t nx = f.record(at, rec);
+			if (!nx) { R.bad = true; R.bad_at = at; return; }
+			if (!second) {
+				if (rec.qual_len != rec.seq_len && R.len_err.empty()) R.len_err.assign(rec.name, rec.name_len);
+				++R.n_rec;
+				if (rec.seq_len) ++R.n_ne;
+			} else {
+				if (g % (size_t) step == 0) ix.sub[g / (size_t) step] = at;
+				++g;
+				if (stats && rec.seq_len) {   // reads without a sequence are not counted (ReadProvider.cpp:236)
+					++c;
+					if (c <= 10000001) {
+						const size_t len = std::min<size_t>(rec.seq_len, 9999);
+						R.max_len = std::max(R.max_len, len); R.min_len = std::min(R.min_len, len); R.sum_len += len;
+						if (c % 1000 == 0 && c < 10000000) R.sample.push_back(Read{std::string(rec.name, rec.name_len), std::string(rec.seq, rec.seq_len), std::string()});
+					}
+				}
+			}
+			at = nx;
+		}
+		if (at != end) { R.bad = true; R.bad_at = at; }
+	};
+	pool.parallel_for(T, [&](int lo, int hi) { for (int r = lo; r < hi; ++r) walk(r, false); }, 1);
+	for (int r = 0; r < T; ++r) {
+		if (rg[r].bad) { ix.ok = false; ix.bad_at = rg[r].bad_at; return; }
+		if (!rg[r].len_err.empty() && ix.length_error.empty()) ix.length_error = rg[r].len_err;
+		rg[r].rec_base = ix.n_records; rg[r].ne_base = ix.n_nonempty;
+		ix.n_records += rg[r].n_rec; ix.n_nonempty += rg[r].n_ne;
+	}
+	ix.step = step;
+	ix.sub.assign((ix.n_records + (size_t) step - 1) / (size_t) step + 1, f.n);
+	pool.parallel_for(T, [&](int lo, int hi) { for (int r = lo; r < hi; ++r) walk(r, true); }, 1);
+	for (int r = 0; r < T; ++r) {
+		ix.max_len = std::max(ix.max_len, rg[r].max_len); ix.min_len = std::min(ix.min_len, rg[r].min_len); ix.sum_len += rg[r].sum_len;
+		for (Read &x : rg[r].sample) ix.sample.push_back(std::move(x));
+	}
+	ix.count = std::min<size_t>(ix.n_nonempty, 10000001);
+	ix.ok = true;
+}
+
 template <typename T>
 class BoundedQueue {
 public:
@@ -499,6 +589,17 @@ int main(int argc, char **argv) {
 
 	// ---- pass 1: read lengths + the sample for the sensitivity estimate (ReadProvider.cpp:201-305) ----------
 	const auto t_input = std::chrono::steady_clock::now();  // the first input byte is read below
+	const bool interleaved = o.paired && !o.qry.empty();  // ReadProvider::GenerateRead (ReadProvider.cpp:526-584)
+	const std::string path0 = o.paired ? (interleaved ? o.qry : o.qry1) : o.qry, path1 = (o.paired && !interleaved) ? o.qry2 : std::string();
+	MappedFile mf0, mf1;
+	bool plain = !o.serial_reader && mf0.open(path0.c_str()) && mf0.plain_fastq();
+	if (plain && !path1.empty()) plain = mf1.open(path1.c_str()) && mf1.plain_fastq();
+	const int batch_reads = o.paired ? (o.batch & ~1) : o.batch;
+	// the splitter hands out whole sub-ranges of sub_step records (per file): the largest power of two up to kSub that divides a batch's share
+	const int per_file_reads = path1.empty() ? batch_reads : batch_reads / 2;
+	int sub_step = kSub;
+	while (sub_step > 1 && per_file_reads % sub_step != 0) sub_step >>= 1;
+	FastqIndex ix0, ix1;
 	size_t max_len = 0, min_len = 9999999, sum_len = 0, count = 0;
 	std::vector<Read> sample;
 	{
@@ -513,23 +614,22 @@ int main(int argc, char **argv) {
 			if (count == 10000001) { if (max_len - min_len >= 10) max_len = (size_t) (max_len * 1.1f); finish = true; }
 			return false;
 		};
-		MappedFile pf;
-		bool plain_ok = !o.serial_reader && pf.open(first_input.c_str()) && pf.plain_fastq();
+		bool plain_ok = plain;
 		if (plain_ok) {
-			pf.prefault();
-			Rec rec;
-			for (size_t at = 0; !finish && at < pf.n;) {
-				const size_t nx = pf.record(at, rec);
-				if (!nx) {
-					// not a strict 4-line record (multi-line sequences, stray blank lines): kseq reads those, so does the serial reader
-					info("INPUT", "Record at byte " + std::to_string(at) + " of " + first_input + " is not a 4-line FASTQ record: using the serial reader");
-					plain_ok = false; o.serial_reader = 1;
-					max_len = 0; min_len = 9999999; sum_len = 0; count = 0; finish = false; sample.clear();
-					break;
-				}
-				if (rec.qual_len != rec.seq_len) die("Error while parsing read: sequence and quality lengths differ (" + std::string(rec.name, rec.name_len) + ")");
-				at = nx;
-				if (account(rec.seq_len)) sample.push_back(Read{std::string(rec.name, rec.name_len), std::string(rec.seq, rec.seq_len), std::string()});
+			// both passes over a plain input are one parallel scan: record offsets for the splitter, lengths and the sample for the estimates
+			mf0.prefault(); mf1.prefault();
+			build_fastq_index(mf0, sub_step, true, ix0);
+			if (ix0.ok && mf1.p) build_fastq_index(mf1, sub_step, false, ix1);
+			if (!ix0.ok || (mf1.p && !ix1.ok)) {
+				// not a strict 4-line record (multi-line sequences, stray blank lines): kseq reads those, so does the serial reader
+				info("INPUT", "Record at byte " + std::to_string(!ix0.ok ? ix0.bad_at : ix1.bad_at) + " of " + (!ix0.ok ? path0 : path1) + " is not a 4-line FASTQ record: using the serial reader");
+				plain_ok = plain = false; o.serial_reader = 1;
+			} else {
+				const std::string &le = !ix0.length_error.empty() ? ix0.length_error : ix1.length_error;
+				if (!le.empty()) die("Error while parsing read: sequence and quality lengths differ (" + le + ")");
+				max_len = ix0.max_len; min_len = ix0.min_len; sum_len = ix0.sum_len; count = ix0.count;
+				if (ix0.n_nonempty >= 10000001 && max_len - min_len >= 10) max_len = (size_t) (max_len * 1.1f);
+				sample = std::move(ix0.sample);
 			}
 		}
 		if (!plain_ok) {
@@ -926,14 +1026,6 @@ int main(int argc, char **argv) {
 	std::mutex fail_mu;
 	auto fail = [&](const std::string &m2) { std::lock_guard<std::mutex> lk(fail_mu); if (!failed.exchange(true)) fail_msg = m2; };
 
-	const bool interleaved = o.paired && !o.qry.empty();  // ReadProvider::GenerateRead (ReadProvider.cpp:526-584)
-	const std::string path0 = o.paired ? (interleaved ? o.qry : o.qry1) : o.qry, path1 = (o.paired && !interleaved) ? o.qry2 : std::string();
-	MappedFile mf0, mf1;
-	bool plain = !o.serial_reader && mf0.open(path0.c_str()) && mf0.plain_fastq();
-	if (plain && !path1.empty()) plain = mf1.open(path1.c_str()) && mf1.plain_fastq();
-	if (plain) { mf0.prefault(); mf1.prefault(); }
-	const int batch_reads = o.paired ? (o.batch & ~1) : o.batch;
-
 	auto strip_mate = [&](const char *name, uint32_t &len) {  // ReadProvider::NextRead (ReadProvider.cpp:419-422)
 		if (len >= 2 && name[len - 2] == o.pe_delimiter) len -= 2;
 	};
@@ -941,43 +1033,23 @@ int main(int argc, char **argv) {
 	std::thread splitter([&] {
 		uint64_t seq = 0;
 		if (plain) {
-			// record boundaries by counting line ends; every kSub-th record offset is kept so that the batch can be parsed in parallel
-			size_t at0 = 0, at1 = 0;
+			// record boundaries: the index of the estimation pass (every sub_step-th record offset per file, so that a batch is parsed in parallel)
 			const bool two = !path1.empty();
-			const int per_file = two ? batch_reads / 2 : batch_reads;
-			auto skip = [&](const MappedFile &f, size_t &at, int want, std::vector<size_t> &sub) -> int {
-				int got = 0;
-				const char *end = f.p + f.n;
-				while (got < want && at < f.n) {
-					if ((got % kSub) == 0) sub.push_back(at);
-					const char *c = f.p + at;
-					if (*c != '@') { fail("malformed FASTQ record at byte " + std::to_string(at) + " (4-line records expected; --serial-reader reads multi-line input)"); return -1; }
-					for (int l = 0; l < 4 && c; ++l) { c = (const char *) memchr(c, '\n', end - c); if (c) ++c; else if (l == 3) c = end; }
-					if (!c) { fail("truncated FASTQ record at byte " + std::to_string(at)); return -1; }
-					at = (size_t) (c - f.p);
-					++got;
-				}
-				sub.push_back(at);  // end of the last sub-range
-				return got;
+			const char *uneven = "Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode.";
+			if (two ? ix0.n_records != ix1.n_records : (o.paired && (ix0.n_records & 1))) fail(uneven);
+			auto take = [&](const FastqIndex &ix, size_t r0, int cnt, std::vector<size_t> &sub) {
+				const size_t s0 = r0 / (size_t) sub_step, s1 = (r0 + (size_t) cnt + (size_t) sub_step - 1) / (size_t) sub_step;
+				sub.assign(ix.sub.begin() + (long) s0, ix.sub.begin() + (long) s1 + 1);
 			};
-			while (!failed && (at0 < mf0.n)) {
+			for (size_t r0 = 0; !failed && r0 < ix0.n_records; r0 += (size_t) per_file_reads) {
 				auto b = std::make_unique<Batch>();
 				b->seq = seq++;
-				std::thread other;  // two files: the second one is scanned by a helper thread at the same time
-				int n1 = 0;
-				if (two) other = std::thread([&] { n1 = skip(mf1, at1, per_file, b->sub1); });
-				b->n0 = skip(mf0, at0, per_file, b->sub0);
-				if (two) other.join();
-				if (b->n0 < 0 || n1 < 0) break;
-				if (two) {
-					b->n1 = n1;
-					if (b->n1 != b->n0) { fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode."); break; }
-				}
+				b->n0 = (int) std::min<size_t>((size_t) per_file_reads, ix0.n_records - r0);
+				take(ix0, r0, b->n0, b->sub0);
+				if (two) { b->n1 = b->n0; take(ix1, r0, b->n1, b->sub1); }
 				b->n = b->n0 + b->n1;
-				if (o.paired && (b->n & 1)) { fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode."); break; }
 				q_in.push(std::move(b));
 			}
-			if (!failed && two && at1 < mf1.n) fail("Error in input file. Number of reads in input not even. Please check the input or mapped in single-end mode.");
 		} else {
 			SeqReader in1(path0.c_str());
 			std::unique_ptr<SeqReader> in2(path1.empty() ? nullptr : new SeqReader(path1.c_str()));
@@ -1074,7 +1146,7 @@ int main(int argc, char **argv) {
 					}
 				}, 4096);
 			} else if (w.rows) {
-				// plain input: sub-range s of file f holds records [s kSub, ...) of that file; record j of file f is batch record
+				// plain input: sub-range s of file f holds records [s sub_step, ...) of that file's share of the batch; record j of file f is batch record
 				// j (one file) or 2 j + f (two files)
 				const bool two = b->n1 > 0;
 				const int nsub0 = (int) b->sub0.size() - 1, nsub1 = two ? (int) b->sub1.size() - 1 : 0;
@@ -1085,10 +1157,10 @@ int main(int argc, char **argv) {
 						const int f = sidx < nsub0 ? 0 : 1, sl = f ? sidx - nsub0 : sidx;
 						const MappedFile &mf = f ? mf1 : mf0;
 						const std::vector<size_t> &sub = f ? b->sub1 : b->sub0;
-						const int cnt = std::min(kSub, (f ? b->n1 : b->n0) - sl * kSub);
+						const int cnt = std::min(sub_step, (f ? b->n1 : b->n0) - sl * sub_step);
 						size_t at = sub[sl];
 						for (int j = 0; j < cnt; ++j) {
-							const int i = two ? 2 * (sl * kSub + j) + f : sl * kSub + j;
+							const int i = two ? 2 * (sl * sub_step + j) + f : sl * sub_step + j;
 							Rec &r = b->recs[i];
 							const size_t nx = mf.record(at, r);
 							if (!nx) { if (!bad.exchange(true)) bad_msg = "malformed FASTQ record at byte " + std::to_string(at); return; }

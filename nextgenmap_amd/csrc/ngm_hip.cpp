@@ -105,6 +105,18 @@ const void *find_pk_affine_align_kernel(int c, bool window) {
 	return nullptr;
 }
 
+// packed 16-bit linear align kernels (local mode): plain row key (<= 32 band columns, scores below 2 048) or the windowed one
+template <int C> const void *pk_align_ptr(bool window) {
+	if (!window) { if constexpr (C <= 32) return (const void *) ngm::sw_align_pk_kernel<C, false>; else return nullptr; }
+	if constexpr (C <= 128) return (const void *) ngm::sw_align_pk_kernel<C, true>; else return nullptr;
+}
+const void *find_pk_align_kernel(int c, bool window) {
+#define X(C) if (c == C) return pk_align_ptr<C>(window);
+	NGM_CORRIDORS(X)
+#undef X
+	return nullptr;
+}
+
 KernelRef find_kernel(ngm_hip_ctx *ctx, int kind) {
 	KernelRef k;
 	k.aot = find_aot_kernel(ctx->c, kind);
@@ -201,9 +213,24 @@ int engine_align_packed(ngm_hip_ctx *ctx, int mode, int n, int32_t *d_records, u
 	}
 	const int DW = ngm::dir_words(ctx->c);
 	if (ctx->dirs.reserve((size_t) nb * ctx->q * DW * ngm::kSlots)) { set_error(ctx, "out of device memory for the direction matrix"); return -12; }
-	const KernelRef k = find_kernel(ctx, 2 + (am == NGM_MODE_END_TO_END ? 1 : 0));
-	HIP_TRY(ctx, launch_kernel(k, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
-			(const uint16_t *) ctx->blk_rows.p, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->K));
+	// local alignments whose re-based values fit 16 bits (the score kernel's condition): two pairs per lane, see sw_align_pk_kernel
+	static const bool force32 = getenv("NGM_HIP_ALIGN_32BIT") != nullptr;
+	const void *pk = nullptr;
+	const int max_gain = std::max(ctx->K.tM, ctx->K.alt ? std::max(ctx->K.tMA, ctx->K.tXA) : 0);  // largest table byte: best column score - mismatch
+	if (!force32 && am != NGM_MODE_END_TO_END && (long) ctx->q * max_gain < 30000 && (long) ctx->q * ctx->K.tZ < 14000 && ctx->K.gl < 0 && ctx->K.gap_read < 0) {
+		const bool plain_key = (long) ctx->q * (max_gain - ctx->K.tZ) < 2048 && ctx->c <= 32;
+		if (plain_key) pk = find_pk_align_kernel(ctx->c, false);
+		else if (ctx->K.tZ > 0 && max_gain + 1 <= 63) pk = find_pk_align_kernel(ctx->c, true);  // window: mismatch + best column score + 1 values
+	}
+	if (pk) {
+		KernelRef kp; kp.aot = pk;
+		HIP_TRY(ctx, launch_kernel(kp, dim3((nb + 7) / 8), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+				(const uint16_t *) ctx->blk_rows.p, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->K));
+	} else {
+		const KernelRef k = find_kernel(ctx, 2 + (am == NGM_MODE_END_TO_END ? 1 : 0));
+		HIP_TRY(ctx, launch_kernel(k, dim3((nb + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+				(const uint16_t *) ctx->blk_rows.p, ctx->dirs.p, d_records, n, nb, ctx->RW, ctx->q, ctx->K));
+	}
 	if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
 	hipLaunchKernelGGL(ngm::sw_traceback_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ctx->dirs.p, ctx->lens.p, d_records,
 			d_runs, n, ctx->q, ctx->c, run_stride, am == NGM_MODE_END_TO_END ? 1 : 0);

@@ -320,6 +320,45 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2s pk_splat(int x) { v2s r; r.x = (short) x; r.y = (short) x; return r; }
 __device__ __forceinline__ v2s pk_max(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s pk_min(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ v2s pk_min_op(v2s a, v2s b) {  // (opaque to the optimizer, see took4 below)
+	v2s r;
+	asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ v2s pk_mul(v2s a, v2s b) {
+	v2s r;
+	asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+__device__ __forceinline__ v2s pk_mad(v2s a, v2s b, v2s c) {  // a * b + c per 16-bit half, one instruction
+	v2s r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+__device__ __forceinline__ v2s pk_mad_k(v2s a, v2s b, int k) {  // a * b + k, k a uniform value (kept in an SGPR: no VGPR per constant)
+	v2s r;
+	const uint32_t kk = ((uint32_t) k & 0xFFFFu) * 0x10001u;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(kk));
+	return r;
+}
+__device__ __forceinline__ v2s pk_min1_op(v2s a) {  // min(a, 1), signed, opaque to the optimizer
+	v2s r;
+	asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+	return r;
+}
+__device__ __forceinline__ v2s pk_min1_u_op(v2s a) {  // min(a, 1), unsigned
+	v2s r;
+	asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+	return r;
+}
+__device__ __forceinline__ v2s pk_sub_sat(v2s a, v2s b) { return __builtin_elementwise_sub_sat(a, b); }  // v_pk_sub_i16 ... clamp
+__device__ __forceinline__ v2s pk_min_u_op(v2s a, v2s b) {  // unsigned, opaque
+	v2s r;
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
 
 template <int C, bool ENDFREE>
 __global__ __launch_bounds__(256) void sw_score_pk_kernel(const uint32_t *__restrict__ packed,
