@@ -51,13 +51,14 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	const int tid0 = threadIdx.x;
 	const int k = A.k;
 	const int kcap = A.lists_cap >> 1;                      // k-mers a read can have
-	uint32_t *l_kinfo = cs_lds;                              // [kcap] bucket number | pair member << 30 | valid << 31
+	// (the bit plane first: its word addresses are then a constant away from the hash -- one add less per vote)
+	uint32_t *plane = cs_lds;
+	const uint32_t plane_words = A.plane_bits >> 5;
+	uint32_t *l_kinfo = plane + plane_words;                 // [kcap] bucket number | pair member << 30 | valid << 31
 	uint32_t *l_hdr = l_kinfo + kcap;                        // [kcap] bucket header of the k-mers in use, else 0
 	uint8_t *l_code = (uint8_t *) (l_hdr + kcap);
 	uint16_t *l_items = (uint16_t *) ((uint32_t *) l_code + (A.q + 3) / 4);   // [kItemCap] k-mer << 8 | chunk
-	uint32_t *plane = (uint32_t *) (l_items + kItemCap);
-	const uint32_t plane_words = A.plane_bits >> 5;
-	uint32_t *t_keys = plane + plane_words;
+	uint32_t *t_keys = (uint32_t *) (l_items + kItemCap);
 	const int log2_slots = A.log2_slots;
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
@@ -247,33 +248,31 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 
 		uint32_t bins[NS * kCsSeg];   // bin | first-on-its-bit << 30 | reverse strand << 31 ; 0 = empty slot
 		// one step: 8 slots per lane vote (sweep 1 of cs_fast2_kernel): positions, validity, diagonal correction and strand per slot
-		auto vote_step = [&](const int step, const uint32_t (&pos)[kCsSeg], const bool (&valid)[kCsSeg], const uint32_t (&corr)[kCsSeg], const uint32_t (&rev)[kCsSeg], const bool last_step) {
-			uint32_t old[kCsSeg], msk[kCsSeg], ent[kCsSeg];
+		// (revf: the hit's strand in bit 31 and the "first on its bit" flag, bit 30, that the entries kept in `bins` carry; the queue ignores bit 30)
+		auto vote_step = [&](const int step, const uint32_t (&pos)[kCsSeg], const bool (&valid)[kCsSeg], const uint32_t (&corr)[kCsSeg], const uint32_t (&revf)[kCsSeg], const bool last_step) {
+			uint32_t dup[kCsSeg], msk[kCsSeg], ent[kCsSeg];
 #pragma unroll
 			for (int j = 0; j < kCsSeg; ++j) {
 				const uint32_t bin = ((pos[j] - corr[j]) >> A.bin_shift) & 0x3FFFFFFFu;
 				const uint32_t b = __umulhi(bin * 0x9E3779B1u, pbits);
 				msk[j] = valid[j] ? (1u << (b & 31)) : 0u;      // empty slots vote with an all-zero mask: branch-free
-				old[j] = atomicOr(&plane[b >> 5], msk[j]);
-				ent[j] = bin | (rev[j] << 31);
+				dup[j] = atomicOr(&plane[b >> 5], msk[j]) & msk[j];   // != 0: a repeat on its bit
+				ent[j] = bin | revf[j];
 			}
 			uint32_t ndup = 0;
 #pragma unroll
-			for (int j = 0; j < kCsSeg; ++j) ndup += (old[j] & msk[j]) ? 1u : 0u;
+			for (int j = 0; j < kCsSeg; ++j) ndup += dup[j] ? 1u : 0u;
 			uint32_t qb;
 			{ uint32_t total; qb = q_len + wave_prefix_small<4>(ndup, total); q_len += total; }
 #pragma unroll
-			for (int j = 0; j < kCsSeg; ++j) {
-				const bool first = msk[j] != 0u && (old[j] & msk[j]) == 0u;  // valid and first on its bit
-				bins[step * kCsSeg + j] = first ? (ent[j] | 0x40000000u) : 0u;  // repeats vote in sweep 1: nothing left to do for them
-			}
+			for (int j = 0; j < kCsSeg; ++j) bins[step * kCsSeg + j] = (msk[j] ^ dup[j]) ? ent[j] : 0u;  // valid and first on its bit; repeats vote in sweep 1: nothing left to do for them
 			// the repeats go through this wave's queue: inserted when a good batch is waiting and after the last step; when one step
 			// brings more than the queue holds (repetitive reads) it is filled and emptied window by window
 			uint32_t window = 0;
 			for (;;) {
 				uint32_t at = qb;
 #pragma unroll
-				for (int j = 0; j < kCsSeg; ++j) if ((old[j] & msk[j]) != 0u) { if (at - window < q_cap) my_queue[at - window] = ent[j]; ++at; }
+				for (int j = 0; j < kCsSeg; ++j) if (dup[j] != 0u) { if (at - window < q_cap) my_queue[at - window] = ent[j]; ++at; }
 				const bool more = q_len - window > q_cap;
 				if (more || q_len - window > (T >= 4 ? 0u : q_cap / 2u) || last_step) {
 					const uint32_t all = q_len;
@@ -319,17 +318,19 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				const uint32_t info = b < n_kmers ? l_kinfo[b] : 0u;
 				const uint32_t hdr = b < n_kmers ? l_hdr[b] : 0u;          // 0 for k-mers that are not in use
 				const uint32_t na = hdr & kCsHdrCountMask, ntot = na + ((hdr >> 14) & kCsHdrCountMask);
-				const uint32_t member = (info >> 30) & 1u;
+				const bool member = ((info >> 30) & 1u) != 0u;
 				const uint32_t lim = (hdr & kCsHdrOverflow) ? 0u : ntot;
 				const uint32_t cf = (uint32_t) b, cr = (uint32_t) (L - (b + k));   // CS.cpp:140-142
+				// first list of the bucket = the canonical k-mer's, second = its reverse complement's; `member` says which of the two the read has
+				const uint32_t c1 = member ? cr : cf, c2 = member ? cf : cr, f1 = member ? 0xC0000000u : 0x40000000u, f2 = member ? 0x40000000u : 0xC0000000u;
 				const uint32_t w4[4] = {d[r].x, d[r].y, d[r].z, d[r].w};
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
 					const uint32_t idx = sub * 4u + (uint32_t) e - 1u;    // position index inside the bucket (word 0 is the header: wraps to "invalid")
-					const uint32_t rv = (idx >= na ? 1u : 0u) ^ member;   // second list of the bucket = the pair's reverse complement
+					const bool second = idx >= na;
 					valid[h * 4 + e] = idx < lim;
-					rev[h * 4 + e] = rv;
-					corr[h * 4 + e] = rv ? cr : cf;
+					rev[h * 4 + e] = second ? f2 : f1;
+					corr[h * 4 + e] = second ? c2 : c1;
 					pos[h * 4 + e] = w4[e];
 				}
 			}
@@ -351,17 +352,19 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			for (int h = 0; h < 2; ++h) {
 				const int r = 2 * s + h;
 				const uint32_t idx = (uint32_t) r * (uint32_t) NT + (uint32_t) tid;
-				uint32_t p = 0, first = 0, lim = 0, na = 0, member = 0;
-				if (idx < n_items) { (void) item_meta(idx, p, first, lim, na); member = (l_kinfo[p] >> 30) & 1u; }
+				uint32_t p = 0, first = 0, lim = 0, na = 0;
+				bool member = false;
+				if (idx < n_items) { (void) item_meta(idx, p, first, lim, na); member = ((l_kinfo[p] >> 30) & 1u) != 0u; }
 				const uint32_t cf = p, cr = (uint32_t) (L - ((int) p + k));
+				const uint32_t c1 = member ? cr : cf, c2 = member ? cf : cr, f1 = member ? 0xC0000000u : 0x40000000u, f2 = member ? 0x40000000u : 0xC0000000u;
 				const uint32_t w4[4] = {d2[r].x, d2[r].y, d2[r].z, d2[r].w};
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
 					const uint32_t i2 = first + (uint32_t) e;
-					const uint32_t rv = (i2 >= na ? 1u : 0u) ^ member;
+					const bool second = i2 >= na;
 					valid[h * 4 + e] = i2 < lim;
-					rev[h * 4 + e] = rv;
-					corr[h * 4 + e] = rv ? cr : cf;
+					rev[h * 4 + e] = second ? f2 : f1;
+					corr[h * 4 + e] = second ? c2 : c1;
 					pos[h * 4 + e] = w4[e];
 				}
 			}
@@ -388,13 +391,15 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 #pragma unroll
 		for (int w2 = 0; w2 < T; ++w2) { mx_lo = max(mx_lo, s_mx[w2][0]); mxb_lo = max(mxb_lo, s_mx[w2][1]); }
 		{
-			const float reach = (float) mx_lo * A.sensitivity;
+			// count + 1 >= m * sensitivity, in integers: the left side is one (counts are below 65 536: exact in a float)
+			const uint32_t reach = (uint32_t) ceilf((float) mx_lo * A.sensitivity);
+			const bool both = A.max_both != nullptr;
 			for (uint32_t s = tid; s < n_slots; s += NT) {
 				const uint32_t key = t_keys[s];
 				if (key == 0xFFFFFFFFu) continue;
 				const uint32_t v = t_votes[s];
 				const uint32_t f = v & 0xFFFFu, r = v >> 16;
-				if ((float) (max(f, r) + 1u) >= reach || (A.max_both && f + r + 1u >= mxb_lo)) {
+				if (max(f, r) + 1u >= reach || (both && f + r + 1u >= mxb_lo)) {
 					const uint32_t at = atomicAdd(&s_nrel, 1u);
 					if (at < (uint32_t) kCsCanonRel) { s_rel_key[at] = key | 0x40000000u; s_rel_slot[at] = s; }
 				}
@@ -405,14 +410,13 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		if (n_rel <= (uint32_t) kCsCanonRel) {
 			for (uint32_t j = 0; j < n_rel; ++j) {   // (typically one or two entries: the keys stay scalar)
 				const uint32_t key = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_rel_key[j]);
-				bool hit = false;
-				uint32_t inc = 0;
+				uint32_t hit = 0;   // bin | first-on-its-bit flag (| strand << 31): at most one such hit per bin in the whole workgroup; empty slots are 0, keys are not
 #pragma unroll
 				for (int i = 0; i < NS * kCsSeg; ++i) {
 					const uint32_t e = bins[i];
-					if ((e & 0x7FFFFFFFu) == key) { hit = true; inc = (e >> 31) ? 0x10000u : 1u; }   // bin | first-on-its-bit flag: at most one such hit per bin in the whole workgroup
+					hit = ((e ^ key) << 1) == 0u ? e : hit;
 				}
-				if (hit) atomicAdd(&t_votes[s_rel_slot[j]], inc);
+				if (hit) atomicAdd(&t_votes[s_rel_slot[j]], (hit >> 31) ? 0x10000u : 1u);
 			}
 			__syncthreads();
 			const unsigned long long c3 = diag ? wall_clock64() : 0ull;

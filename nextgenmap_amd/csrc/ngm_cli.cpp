@@ -33,6 +33,8 @@
 #include <getopt.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/sendfile.h>
+#include <sys/wait.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -120,6 +122,7 @@ struct Opts {
 	int skip_save = 0, bam = 0, workers = 2, serial_reader = 0;
 	int bs_mapping = 0, bs_cutoff = 6, match_tt = -1, match_tc = -1, match_set = 0, mismatch_set = 0, slam_seq = 0;
 	std::vector<int> devices;
+	int shard_i = 0, shard_n = 1, shard_output = 0, keep_shards = 0;
 	std::string rg[12];  // read group: ID CN DS DT FO KS LB PG PI PL PU SM (SAMWriter.cpp:46-80)
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
 	float sensitivity = -1.f, kmer_min = 0.f, min_identity = 0.65f, min_residues = 0.5f;
@@ -134,7 +137,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, SHARD, SHARDOUT, KEEPSHARDS, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -147,7 +150,8 @@ Opts parse(int argc, char **argv) {
 		{"max-read-length", required_argument, 0, MAXRL}, {"bin-size", required_argument, 0, BINSZ}, {"max-kfreq", required_argument, 0, MAXKF},
 		{"very-fast", no_argument, 0, VFAST}, {"fast", no_argument, 0, FAST}, {"sensitive", no_argument, 0, SENS}, {"very-sensitive", no_argument, 0, VSENS},
 		{"device", required_argument, 0, DEVICE}, {"skip-save", no_argument, 0, SKIPSAVE}, {"batch-size", required_argument, 0, BATCH},
-		{"kernel-variant", required_argument, 0, VARIANT},
+		{"kernel-variant", required_argument, 0, VARIANT}, {"shard", required_argument, 0, SHARD}, {"shard-output", no_argument, 0, SHARDOUT},
+		{"keep-shards", no_argument, 0, KEEPSHARDS},
 		{"qry1", required_argument, 0, '1'}, {"qry2", required_argument, 0, '2'}, {"paired", no_argument, 0, 'p'},
 		{"min-insert-size", required_argument, 0, 'I'}, {"max-insert-size", required_argument, 0, 'X'}, {"pe-delimiter", required_argument, 0, PEDELIM},
 		{"rg-id", required_argument, 0, RG0}, {"rg-cn", required_argument, 0, RG0 + 1}, {"rg-ds", required_argument, 0, RG0 + 2},
@@ -224,6 +228,14 @@ Opts parse(int argc, char **argv) {
 		case SERIAL: o.serial_reader = 1; break;
 		case BATCH: o.batch = std::max(1024, atoi(optarg)); break;
 		case VARIANT: o.variant = atoi(optarg) ? NGM_VARIANT_OCL_CPU : NGM_VARIANT_OCL_GPU; break;
+		case SHARD: {  // "i/N": this process maps the i-th of N contiguous ranges of the input and writes their records (the header with shard 0)
+			const char *sl = strchr(optarg, '/');
+			o.shard_i = atoi(optarg); o.shard_n = sl ? atoi(sl + 1) : 0;
+			if (!sl || o.shard_n < 1 || o.shard_i < 0 || o.shard_i >= o.shard_n) die("--shard expects i/N with 0 <= i < N");
+			break;
+		}
+		case SHARDOUT: o.shard_output = 1; break;
+		case KEEPSHARDS: o.keep_shards = 1; break;
 		case UNSUPPORTED: die(std::string("option --") + lo[idx].name + " is not supported by the HIP backend yet");
 		default: die("unknown option (see src/config/Options.h of NextGenMap for the option set)");
 		}
@@ -544,6 +556,59 @@ void dump(const char *path) {
 
 }  // namespace
 
+// `-g a,b,... --shard-output`: one process per GPU.  Child k runs this program again with `--device <k-th GPU> --shard
+// k/N -o <out>.shard<k>`: its own reference copy in that GPU's HBM, its own reader, workers, paired-end state and writer -- nothing is
+// shared, so N GPUs write N files at once instead of queueing behind one writer.  Shard 0 carries the header; the pieces are
+// appended to <out> in shard order (in-kernel copies) unless --keep-shards asks for `cat <out>.shard*` to be left to the caller.
+int run_sharded(int argc, char **argv, const Opts &o) {
+	const int N = (int) o.devices.size();
+	std::vector<pid_t> kids;
+	std::vector<std::string> parts;
+	for (int k = 0; k < N; ++k) parts.push_back(o.out + ".shard" + std::to_string(k));
+	for (int k = 0; k < N; ++k) {
+		const pid_t pid = fork();
+		if (pid < 0) die("fork failed");
+		if (pid == 0) {
+			std::vector<std::string> a(argv, argv + argc);
+			a.push_back("--device"); a.push_back(std::to_string(o.devices[k]));
+			a.push_back("--shard"); a.push_back(std::to_string(k) + "/" + std::to_string(N));
+			a.push_back("-o"); a.push_back(parts[k]);
+			std::vector<char *> av;
+			for (std::string &x : a) av.push_back(&x[0]);
+			av.push_back(nullptr);
+			execv("/proc/self/exe", av.data());
+			_exit(127);
+		}
+		kids.push_back(pid);
+	}
+	bool ok = true;
+	for (pid_t pid : kids) { int st = 0; if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
+	if (!ok) die("a shard process failed (its messages are above)");
+	if (o.keep_shards) { info("MAIN", "Shards written: " + parts[0] + " .. " + parts.back() + " (concatenate in this order)"); return 0; }
+	const auto t0 = std::chrono::steady_clock::now();
+	if (rename(parts[0].c_str(), o.out.c_str()) != 0) die("cannot rename " + parts[0]);
+	const int out_fd = ::open(o.out.c_str(), O_WRONLY | O_APPEND);
+	if (out_fd < 0) die("cannot append to " + o.out);
+	for (int k = 1; k < N; ++k) {
+		const int in_fd = ::open(parts[k].c_str(), O_RDONLY);
+		struct stat st;
+		if (in_fd < 0 || fstat(in_fd, &st) != 0) die("cannot read " + parts[k]);
+		off_t left = st.st_size;
+		while (left > 0) {
+			const ssize_t w = sendfile(out_fd, in_fd, nullptr, (size_t) std::min<off_t>(left, (off_t) 1 << 30));
+			if (w <= 0) die("write error on " + o.out);
+			left -= w;
+		}
+		close(in_fd);
+		unlink(parts[k].c_str());
+	}
+	if (close(out_fd) != 0) die("write error on " + o.out);
+	char msg[200];
+	snprintf(msg, sizeof(msg), "%d shards appended to the output in %.3f s", N, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+	info("MAIN", msg);
+	return 0;
+}
+
 int main(int argc, char **argv) {
 
 	// every batch allocates and frees a few hundred MB in MB-sized pieces from ~64 threads (output chunks, record views): with
@@ -554,6 +619,7 @@ int main(int argc, char **argv) {
 	mallopt(M_TOP_PAD, 64 << 20);
 	const auto t_process = std::chrono::steady_clock::now();
 	Opts o = parse(argc, argv);
+	if (o.shard_output && o.devices.size() > 1 && o.shard_n == 1 && !o.out.empty() && !(o.qry.empty() && o.qry1.empty())) return run_sharded(argc, argv, o);
 	// bisulfite mapping: the index holds every reference k-mer, the run's kmer_skip applies to the reads (src/PrefixTable.cpp:199-207, src/CS.cpp:556-560)
 	ngm_ref_params rp{o.kmer, o.bs_mapping ? 0 : o.kmer_skip, o.bin_size};
 	info("MAIN", "NextGenMap-compatible HIP backend (gfx950)");
@@ -744,8 +810,10 @@ int main(int argc, char **argv) {
 			for (size_t i = 0; i < contig_names.size(); ++i) { h += "@SQ\tSN:" + contig_names[i] + "\tLN:"; put_u64(h, contig_lens[i]); h += "\n"; }
 			h += "@PG\tID:ngm\tPN:ngm\tVN:0.5.5-hip\tCL:\"" + o.cmdline + "\"\n";
 			h += rg;
-			if (!put_all(h.data(), h.size(), out_off)) die("write error on " + o.out);
-			out_off += h.size();
+			if (o.shard_i == 0) {   // (--shard i/N: the header travels with the first shard)
+				if (!put_all(h.data(), h.size(), out_off)) die("write error on " + o.out);
+				out_off += h.size();
+			}
 		} else {
 			// BAMWriter::DoWriteProlog (BAMWriter.cpp:18-110) through bamtools' SamFormatPrinter: @HD, @RG, @PG (ID PN CL VN); the
 			// contigs only in the binary dictionary
@@ -754,8 +822,10 @@ int main(int argc, char **argv) {
 			std::string raw, z;
 			ngm::bam::put_header(raw, h, contig_names, contig_lens);
 			if (!ngm::bam::bgzf_compress(raw.data(), raw.size(), z)) die("BGZF compression failed");
-			if (!put_all(z.data(), z.size(), out_off)) die("write error on " + o.out);
-			out_off += z.size();
+			if (o.shard_i == 0) {
+				if (!put_all(z.data(), z.size(), out_off)) die("write error on " + o.out);
+				out_off += z.size();
+			}
 		}
 	}
 	const std::string rg_mapped = o.rg[0].empty() ? std::string() : "RG:Z:" + o.rg[0] + "\t";
@@ -1041,15 +1111,21 @@ int main(int argc, char **argv) {
 				const size_t s0 = r0 / (size_t) sub_step, s1 = (r0 + (size_t) cnt + (size_t) sub_step - 1) / (size_t) sub_step;
 				sub.assign(ix.sub.begin() + (long) s0, ix.sub.begin() + (long) s1 + 1);
 			};
-			for (size_t r0 = 0; !failed && r0 < ix0.n_records; r0 += (size_t) per_file_reads) {
+			// --shard i/N: records [lo, hi) of each file, the boundaries on whole sub-ranges (and whole pairs of an interleaved file)
+			const size_t gran = (size_t) std::max(sub_step, (o.paired && !two) ? 2 : 1);
+			auto bound = [&](int i) -> size_t { return i >= o.shard_n ? ix0.n_records : (size_t) ((unsigned __int128) ix0.n_records * (unsigned) i / (unsigned) o.shard_n) / gran * gran; };
+			const size_t rec_lo = bound(o.shard_i), rec_hi = bound(o.shard_i + 1);
+			for (size_t r0 = rec_lo; !failed && r0 < rec_hi; r0 += (size_t) per_file_reads) {
 				auto b = std::make_unique<Batch>();
 				b->seq = seq++;
-				b->n0 = (int) std::min<size_t>((size_t) per_file_reads, ix0.n_records - r0);
+				b->n0 = (int) std::min<size_t>((size_t) per_file_reads, rec_hi - r0);
 				take(ix0, r0, b->n0, b->sub0);
 				if (two) { b->n1 = b->n0; take(ix1, r0, b->n1, b->sub1); }
 				b->n = b->n0 + b->n1;
 				q_in.push(std::move(b));
 			}
+		} else if (o.shard_n > 1) {
+			fail("--shard needs plain (uncompressed, 4-line) FASTQ input: the shard boundaries come from the record index");
 		} else {
 			SeqReader in1(path0.c_str());
 			std::unique_ptr<SeqReader> in2(path1.empty() ? nullptr : new SeqReader(path1.c_str()));

@@ -1,6 +1,8 @@
 // refindex.cpp -- reference encoding and k-mer index construction (host walk + GPU sort).
 // See refindex.h for what it replaces and for the HBM layout.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -8,6 +10,10 @@
 #include <functional>
 #include <mutex>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "refindex.h"
 #include "thread_pool.h"
@@ -131,7 +137,8 @@ __global__ void apply_usage_rule_kernel(uint32_t n_kmers, int k, const uint32_t 
 	if (total > 9900u) index[p].y = 0;
 }
 
-void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw);
+void index_stats(ngm_ref *r, const uint32_t *raw, uint32_t n_kmers);
+int upload_staged(void *dst, const void *src, size_t bytes);
 
 // ---- the same enumeration on the GPU ------------------------------------------------------------------------
 // KmerWalker above, position-parallel.  Which k-mers the reference visits (CS::PrefixIteration, src/CSstatic.cpp:26-76, with
@@ -413,21 +420,61 @@ int build_index(ngm_ref *r) {
 
 	std::vector<uint32_t> raw(n_kmers);
 	REF_HIP_TRY(hipMemcpy(raw.data(), r->d_raw_counts, (size_t) n_kmers * 4, hipMemcpyDeviceToHost));
-	index_stats(r, raw);
+	index_stats(r, raw.data(), (uint32_t) raw.size());
 	return 0;   // the bucket layouts are built when the first mapper asks for one (ngm_ref_ensure_buckets): a bisulfite run needs none
 }
 
 // CompactPrefixTable::stats (PrefixTable.cpp:150-194): integer sums are exact in double, order-free
-void index_stats(ngm_ref *r, const std::vector<uint32_t> &raw) {
-	const uint32_t n_kmers = (uint32_t) raw.size();
+void index_stats(ngm_ref *r, const uint32_t *raw, uint32_t n_kmers) {
+	// (sums of integers below 2^53: exact in doubles whatever the order, so the pool threads may split them)
+	std::mutex mu;
 	double sum = 0.0, sum2 = 0.0;
-	for (uint32_t j = 0; j < n_kmers; ++j) { sum += raw[j]; sum2 += (double) raw[j] * (double) raw[j]; }
+	ngm::ThreadPool::instance().parallel_for((int) ((n_kmers + (1u << 18) - 1) >> 18), [&](int lo, int hi) {
+		double s1 = 0.0, s2 = 0.0;
+		for (uint32_t j = (uint32_t) lo << 18, e = (uint32_t) std::min<uint64_t>(n_kmers, (uint64_t) hi << 18); j < e; ++j) { s1 += raw[j]; s2 += (double) raw[j] * (double) raw[j]; }
+		std::lock_guard<std::mutex> lk(mu);
+		sum += s1; sum2 += s2;
+	}, 1);
 	const double len = (double) n_kmers;
 	const double avg = sum / len;
 	const double stdev = sqrt(sum2 / (len - 1) - 2.0 * avg * (sum / (len - 1)) + ((len * avg * avg) / (len - 1)));
 	r->auto_max_kfreq = (int) ceil(std::max(100.0, avg + 5 * stdev));
 }
 
+
+// host -> device for the multi-GB arrays of the reference (pageable or file-mapped memory): the pool threads copy 32 MB pieces
+// into two page-locked buffers, each piece travels while the next is copied
+int upload_staged(void *dst, const void *src, size_t bytes) {
+	constexpr size_t kPiece = (size_t) 32 << 20;
+	if (bytes <= kPiece) { REF_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+	void *stage[2] = {nullptr, nullptr};
+	hipEvent_t done[2] = {nullptr, nullptr};
+	hipStream_t st = nullptr;
+	int rc = 0;
+	auto cleanup = [&] { for (int i = 0; i < 2; ++i) { if (stage[i]) (void) hipHostFree(stage[i]); if (done[i]) (void) hipEventDestroy(done[i]); } if (st) (void) hipStreamDestroy(st); };
+	if (hipHostMalloc(&stage[0], kPiece, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&stage[1], kPiece, hipHostMallocDefault) != hipSuccess ||
+			hipEventCreateWithFlags(&done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done[1], hipEventDisableTiming) != hipSuccess ||
+			hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+		cleanup();
+		REF_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));   // (no page-locked memory left: the plain copy)
+		return 0;
+	}
+	ngm::ThreadPool &pool = ngm::ThreadPool::instance();
+	int turn = 0;
+	for (size_t off = 0; off < bytes && rc == 0; off += kPiece, turn ^= 1) {
+		const size_t nb = std::min(kPiece, bytes - off);
+		if (off >= 2 * kPiece && hipEventSynchronize(done[turn]) != hipSuccess) { rc = -5; break; }
+		const char *from = (const char *) src + off;
+		char *to = (char *) stage[turn];
+		const int parts = (int) ((nb + (1u << 20) - 1) >> 20);
+		pool.parallel_for(parts, [&](int lo, int hi) { const size_t a = (size_t) lo << 20, b = std::min(nb, (size_t) hi << 20); memcpy(to + a, from + a, b - a); }, 1);
+		if (hipMemcpyAsync((char *) dst + off, to, nb, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(done[turn], st) != hipSuccess) rc = -5;
+	}
+	if (hipStreamSynchronize(st) != hipSuccess) rc = -5;
+	cleanup();
+	if (rc) ngm::pipeline_set_error("copying the reference to the GPU failed");
+	return rc;
+}
 
 int upload_genome(ngm_ref *r) {
 	// artificial upper bound for positions on the last contig (SequenceProvider.cpp:378)
@@ -436,9 +483,10 @@ int upload_genome(ngm_ref *r) {
 	if (!r->contigs.empty()) r->start_pos.push_back(r->contigs.back().start + r->contigs.back().len + 1000);
 	// upload the genome as packed nibbles (+ one guard word so window reads never run off the end)
 	r->genome_words = (r->n_bases + 7) / 8 + 64;
-	std::vector<uint32_t> packed(r->genome_words, 0x66666666u);  // NUL class beyond the end
+	std::vector<uint32_t, ngm::default_init_allocator<uint32_t>> packed(r->genome_words);
 	{
 		const uint64_t nb = r->n_bases, nw = (nb + 7) / 8;
+		for (uint64_t wi = nw; wi < r->genome_words; ++wi) packed[wi] = 0x66666666u;  // NUL class beyond the end
 		const uint8_t *cls = r->host_cls.data();
 		uint32_t *out = packed.data();
 		const int blocks = (int) ((nw + (1u << 17) - 1) >> 17);  // 128 Kword blocks on the pool threads
@@ -454,8 +502,7 @@ int upload_genome(ngm_ref *r) {
 		}, 1);
 	}
 	REF_HIP_TRY(hipMalloc(&r->d_genome, r->genome_words * 4));
-	REF_HIP_TRY(hipMemcpy(r->d_genome, packed.data(), r->genome_words * 4, hipMemcpyHostToDevice));
-	return 0;
+	return upload_staged(r->d_genome, packed.data(), r->genome_words * 4);
 }
 
 int finish_ref(ngm_ref *r) {
@@ -463,7 +510,7 @@ int finish_ref(ngm_ref *r) {
 	return build_index(r);
 }
 
-void append_spacer(std::vector<uint8_t> &g) { g.insert(g.end(), 1000, (uint8_t) 5); }
+void append_spacer(ngm::ByteVec &g) { g.insert(g.end(), 1000, (uint8_t) 5); }
 
 void append_contig(ngm_ref *r, const std::string &name, const uint8_t *seq, uint64_t len) {
 	if (len <= 10) return;  // minRefSeqLen, SequenceProvider.h:71 / .cpp:300
@@ -541,89 +588,140 @@ ngm_ref *ngm_ref_create(int device, const ngm_ref_params *p, int n_contigs, cons
 // NextGenMap's own cache files next to the FASTA: <ref>-enc.2.ngm (SequenceProvider.cpp:189-208, :228-262) and
 // <ref>-ht-<k>-<skip>.3.ngm (PrefixTable.cpp:819-855, :857-930).  nullptr (with the reason as last error) when they are
 // absent, were written with other parameters or are not single-unit indexes.
+namespace {
+// a cache file mapped read-only (the kernel's page cache is the only copy of its bytes on the host)
+struct MappedCache {
+	const uint8_t *p = nullptr;
+	size_t n = 0;
+	int fd = -1;
+	bool open(const char *path) {
+		fd = ::open(path, O_RDONLY);
+		if (fd < 0) return false;
+		struct stat st;
+		if (fstat(fd, &st) != 0 || st.st_size <= 0) return false;
+		n = (size_t) st.st_size;
+		void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (m == MAP_FAILED) return false;
+		p = (const uint8_t *) m;
+		return true;
+	}
+	~MappedCache() { if (p) munmap((void *) p, n); if (fd >= 0) close(fd); }
+};
+}  // namespace
+
+// NextGenMap's cache files next to the FASTA: <fasta>-enc.2.ngm (SequenceProvider.cpp:189-208, :264-330) and
+// <fasta>-ht-<k>-<skip>.3.ngm (PrefixTable.cpp:819-903).  Both files are mapped; everything that touches the 1.5 + 4.4 GB of a
+// GRCh38-size reference (decoding, checks, the copies to the GPU) runs on all pool threads.
 ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *p, const char *fasta_path) {
 	if (!p || !fasta_path) { ngm::pipeline_set_error("ngm_ref_create_from_cache: null argument"); return nullptr; }
 	const std::string enc_fn = std::string(fasta_path) + "-enc.2.ngm";
 	const std::string ht_fn = std::string(fasta_path) + "-ht-" + std::to_string(p->kmer) + "-" + std::to_string(p->kmer_skip) + ".3.ngm";
-	FILE *fe = fopen(enc_fn.c_str(), "rb");
-	FILE *fh = fe ? fopen(ht_fn.c_str(), "rb") : nullptr;
-	if (!fe || !fh) { if (fe) fclose(fe); ngm::pipeline_set_error("no index cache next to %s", fasta_path); return nullptr; }
+	MappedCache fe, fh;
+	if (!fe.open(enc_fn.c_str()) || !fh.open(ht_fn.c_str())) { ngm::pipeline_set_error("no index cache next to %s", fasta_path); return nullptr; }
+	const bool timing = getenv("NGM_HIP_LOAD_TIMING") != nullptr;
+	auto t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!timing) return;
+		const auto t1 = std::chrono::steady_clock::now();
+		fprintf(stderr, "[ngm-hip] index cache: %s %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+		t0 = t1;
+	};
 	ngm_ref *r = new_ref(device, p);
-	if (!r) { fclose(fe); fclose(fh); return nullptr; }
-	auto fail = [&](const char *why) -> ngm_ref * { ngm::pipeline_set_error("index cache of %s: %s", fasta_path, why); fclose(fe); fclose(fh); ngm_ref_destroy(r); return nullptr; };
+	if (!r) return nullptr;
+	auto fail = [&](const char *why) -> ngm_ref * { ngm::pipeline_set_error("index cache of %s: %s", fasta_path, why); ngm_ref_destroy(r); return nullptr; };
+	ngm::ThreadPool &pool = ngm::ThreadPool::instance();
 	struct RefIdx { uint32_t SeqId, Flags; uint64_t SeqStart; uint32_t SeqLen, NameLen; char name[100]; uint32_t pad; };
 	static_assert(sizeof(RefIdx) == 128, "RefIdx layout");
+	size_t at = 0;
+	auto take = [](const MappedCache &f, size_t &o, void *dst, size_t bytes) -> bool { if (o + bytes > f.n) return false; memcpy(dst, f.p + o, bytes); o += bytes; return true; };
 	uint32_t cookie = 0, ref_count = 0;
 	uint64_t bin_ref_index = 0, enc_size = 0;
-	if (fread(&cookie, 4, 1, fe) != 1 || fread(&ref_count, 4, 1, fe) != 1 || fread(&bin_ref_index, 8, 1, fe) != 1 || fread(&enc_size, 8, 1, fe) != 1 ||
+	if (!take(fe, at, &cookie, 4) || !take(fe, at, &ref_count, 4) || !take(fe, at, &bin_ref_index, 8) || !take(fe, at, &enc_size, 8) ||
 			cookie != 0x74656 || ref_count == 0 || bin_ref_index >= 0xFFFFFFFFull || enc_size < bin_ref_index / 2) return fail("bad header of the encoded reference");
 	for (uint32_t i = 0; i < ref_count; ++i) {
 		RefIdx x;
-		if (fread(&x, sizeof(x), 1, fe) != 1) return fail("truncated contig table");
+		if (!take(fe, at, &x, sizeof(x))) return fail("truncated contig table");
 		NgmContig c;
 		c.name.assign(x.name, std::min<uint32_t>(x.NameLen, 100));
 		c.start = x.SeqStart; c.len = x.SeqLen;
 		r->contigs.push_back(c);
 	}
+	if (at + enc_size > fe.n) return fail("truncated sequence data");
 	{
-		std::vector<uint8_t> data(enc_size);
-		if (fread(data.data(), 1, enc_size, fe) != enc_size) return fail("truncated sequence data");
 		// 4 bits per base, first base in the high nibble, A0 T1 G2 C3 N4 (SequenceProvider.cpp:72-85) -> classes A0 C1 G2 T3 N5
-		static const uint8_t dec[16] = {0, 3, 2, 1, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
+		const uint8_t *data = fe.p + at;
 		r->host_cls.resize(bin_ref_index);
-		for (uint64_t i = 0; i < bin_ref_index; ++i) r->host_cls[i] = dec[(i & 1) ? (data[i >> 1] & 15) : (data[i >> 1] >> 4)];
+		uint8_t *cls = r->host_cls.data();
+		const uint64_t n_bytes = (bin_ref_index + 1) / 2;
+		pool.parallel_for((int) ((n_bytes + (1u << 20) - 1) >> 20), [&](int lo, int hi) {
+			static const uint8_t dec[16] = {0, 3, 2, 1, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
+			for (uint64_t b = (uint64_t) lo << 20, e = std::min<uint64_t>(n_bytes, (uint64_t) hi << 20); b < e; ++b) {
+				const uint8_t x = data[b];
+				cls[2 * b] = dec[x >> 4];
+				if (2 * b + 1 < bin_ref_index) cls[2 * b + 1] = dec[x & 15];
+			}
+		}, 1);
 	}
 	r->n_bases = bin_ref_index;
+	lap("sequence decoded");
 	uint32_t kk = 0, skip = 0, units = 0, index_size = 0, table_len = 0;
 	cookie = 0;
-	if (fread(&cookie, 4, 1, fh) != 1 || fread(&kk, 4, 1, fh) != 1 || fread(&skip, 4, 1, fh) != 1 || fread(&units, 4, 1, fh) != 1 ||
-			fread(&index_size, 4, 1, fh) != 1 || fread(&table_len, 4, 1, fh) != 1 || cookie != 0x74656) return fail("bad header of the k-mer table");
+	at = 0;
+	if (!take(fh, at, &cookie, 4) || !take(fh, at, &kk, 4) || !take(fh, at, &skip, 4) || !take(fh, at, &units, 4) || !take(fh, at, &index_size, 4) ||
+			!take(fh, at, &table_len, 4) || cookie != 0x74656) return fail("bad header of the k-mer table");
 	const uint32_t n_kmers = 1u << (2 * p->kmer);
 	if ((int) kk != p->kmer || (int) skip != p->kmer_skip || index_size != n_kmers + 1) return fail("k-mer table was built with other parameters");
 	if (units != 1) return fail("multi-unit k-mer tables (references >= 4 Gbp) are not supported yet");
-	std::vector<uint8_t> ib((size_t) index_size * 5);
-	std::vector<uint32_t> pos((size_t) table_len + 16, 0);
-	if (fread(ib.data(), 1, ib.size(), fh) != ib.size() || fread(pos.data(), 4, table_len, fh) != table_len) return fail("truncated k-mer table");
+	const size_t ib_bytes = (size_t) index_size * 5, pos_bytes = (size_t) table_len * 4;
+	if (at + ib_bytes + pos_bytes + 12 > fh.n) return fail("truncated k-mer table");
+	const uint8_t *ib = fh.p + at;
+	const uint8_t *pos = ib + ib_bytes;
 	{
 		// trailer: offset of the unit + signature (PrefixTable.cpp:838-846, checked by the reference at :892-903)
+		size_t o = at + ib_bytes + pos_bytes;
 		uint64_t unit_offset = 0;
 		uint32_t signature = 0;
-		if (fread(&unit_offset, 8, 1, fh) != 1 || fread(&signature, 4, 1, fh) != 1 || signature != cookie + kk + skip + units + index_size)
+		if (!take(fh, o, &unit_offset, 8) || !take(fh, o, &signature, 4) || signature != cookie + kk + skip + units + index_size)
 			return fail("k-mer table without a valid signature (truncated or written by another version)");
 	}
 	// a corrupt file must not turn into out-of-bounds reads on the GPU: contigs inside the encoded genome, index offsets
 	// monotonic and inside the position table
 	for (const NgmContig &c : r->contigs) if (c.start + c.len > bin_ref_index || c.len == 0) return fail("contig table does not match the sequence data");
+	std::vector<uint32_t, ngm::default_init_allocator<uint32_t>> raw(n_kmers);
+	std::vector<uint2, ngm::default_init_allocator<uint2>> idx(n_kmers);
 	{
-		uint32_t prev = 1;
-		for (uint32_t q = 0; q <= n_kmers; ++q) {
-			uint32_t t;
-			memcpy(&t, &ib[(size_t) q * 5], 4);
-			if (t < prev || t > table_len + 1) return fail("corrupt k-mer table index");
-			prev = t;
-		}
-	}
-	fclose(fe); fclose(fh);
-	std::vector<uint32_t> raw(n_kmers);
-	std::vector<uint2> idx(n_kmers);
-	for (uint32_t q = 0; q < n_kmers; ++q) {
-		uint32_t t0, t1;
-		memcpy(&t0, &ib[(size_t) q * 5], 4);
-		memcpy(&t1, &ib[(size_t) (q + 1) * 5], 4);
-		raw[q] = t1 - t0;
-		// the usage byte doubles as "skip this k-mer" (PrefixTable.cpp:468-478, :771-775)
-		idx[q] = make_uint2(t0 - 1, ib[(size_t) q * 5 + 4] ? raw[q] : 0u);
+		std::atomic<bool> corrupt{false};
+		auto entry = [&](uint32_t q) { uint32_t t; memcpy(&t, ib + (size_t) q * 5, 4); return t; };
+		pool.parallel_for((int) ((n_kmers + (1u << 16) - 1) >> 16), [&](int lo, int hi) {
+			const uint32_t a = (uint32_t) lo << 16, e = (uint32_t) std::min<uint64_t>(n_kmers, (uint64_t) hi << 16);
+			uint32_t t0 = entry(a);
+			if (t0 < 1u) { corrupt = true; return; }
+			for (uint32_t q = a; q < e; ++q) {
+				const uint32_t t1 = entry(q + 1);
+				if (t1 < t0 || t1 > table_len + 1) { corrupt = true; return; }
+				raw[q] = t1 - t0;
+				// the usage byte doubles as "skip this k-mer" (PrefixTable.cpp:468-478, :771-775)
+				idx[q] = make_uint2(t0 - 1, ib[(size_t) q * 5 + 4] ? t1 - t0 : 0u);
+				t0 = t1;
+			}
+		}, 1);
+		if (corrupt) return fail("corrupt k-mer table index");
 	}
 	r->n_entries = table_len;
+	lap("index entries checked");
 	if (upload_genome(r) != 0) { ngm_ref_destroy(r); return nullptr; }
-	auto up = [&](void **d, const void *h, size_t bytes, size_t alloc) { return hipMalloc(d, alloc) == hipSuccess && hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess; };
-	if (!up((void **) &r->d_index, idx.data(), (size_t) n_kmers * 8, (size_t) n_kmers * 8) || !up((void **) &r->d_raw_counts, raw.data(), (size_t) n_kmers * 4, (size_t) n_kmers * 4) ||
-			!up((void **) &r->d_positions, pos.data(), pos.size() * 4, pos.size() * 4)) {
+	lap("sequence packed and copied");
+	const size_t pos_alloc = ((size_t) table_len + 16) * 4;
+	if (hipMalloc((void **) &r->d_index, (size_t) n_kmers * 8) != hipSuccess || hipMalloc((void **) &r->d_raw_counts, (size_t) n_kmers * 4) != hipSuccess ||
+			hipMalloc((void **) &r->d_positions, pos_alloc) != hipSuccess || hipMemset((char *) r->d_positions + pos_bytes, 0, pos_alloc - pos_bytes) != hipSuccess) {
 		ngm::pipeline_set_error("out of device memory loading the index cache");
 		ngm_ref_destroy(r);
 		return nullptr;
 	}
-	index_stats(r, raw);
+	if (upload_staged(r->d_index, idx.data(), (size_t) n_kmers * 8) != 0 || upload_staged(r->d_raw_counts, raw.data(), (size_t) n_kmers * 4) != 0 ||
+			upload_staged(r->d_positions, pos, pos_bytes) != 0) { ngm_ref_destroy(r); return nullptr; }
+	lap("k-mer table copied");
+	index_stats(r, raw.data(), n_kmers);
 	r->from_cache = true;
 	return r;
 }

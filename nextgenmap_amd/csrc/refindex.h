@@ -23,10 +23,23 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/ngm_pipeline.h"
+
+namespace ngm {
+// std::vector whose resize() leaves new elements uninitialised: the multi-GB host arrays of the reference are filled by all pool
+// threads right after they are sized -- value-initialising them first is a second, single-threaded pass over the same memory
+template <class T> struct default_init_allocator : std::allocator<T> {
+	template <class U> struct rebind { using other = default_init_allocator<U>; };
+	template <class U, class... A> void construct(U *p, A &&...a) {
+		if constexpr (sizeof...(A) == 0) ::new ((void *) p) U; else ::new ((void *) p) U(std::forward<A>(a)...);
+	}
+};
+using ByteVec = std::vector<uint8_t, default_init_allocator<uint8_t>>;
+}  // namespace ngm
 
 struct NgmContig {
 	std::string name;
@@ -40,7 +53,7 @@ struct ngm_ref {
 	std::vector<NgmContig> contigs;
 	std::vector<uint64_t> start_pos;  // contig starts + one artificial upper bound (SequenceProvider.cpp:370-378)
 	uint64_t n_bases = 0;             // nibbles in the encoded genome (binRefIndex after doubling)
-	std::vector<uint8_t> host_cls;    // one class per base (kept for the host-side helpers)
+	ngm::ByteVec host_cls;            // one class per base (kept for the host-side helpers)
 	uint64_t n_entries = 0;
 	int auto_max_kfreq = 100;
 	bool from_cache = false;          // loaded from NextGenMap's cache files instead of being built

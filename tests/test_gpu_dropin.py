@@ -114,6 +114,42 @@ def test_two_device_entries_on_one_gpu_give_the_same_output(tmp_path):
     assert outs[0] == outs[1] and len([l for l in outs[0] if not l.startswith("@")]) == n
 
 
+@pytest.mark.parametrize("layout", ["single-end", "paired-end"])
+def test_shards_concatenate_to_the_single_run(tmp_path, layout):
+    """SURVEY.md 8(e): `--shard i/N` maps the i-th contiguous range of the input and writes its records (shard 0: with the header);
+    `-g a,b --shard-output` runs one such process per listed GPU and appends the pieces in shard order.  Single-end output must
+    equal the unsharded run byte for byte; paired-end shards restart the running mean insert size (ScoreBuffer.cpp:420-422 -- the
+    documented tolerance: only equal-score pair ties may differ), so there the records are compared one by one."""
+    paired = layout == "paired-end"
+    fa, inp, n = _case(tmp_path, paired)
+    one = str(tmp_path / "one.sam")
+    c = subprocess.run([CLI, "-r", fa, "-o", one, "--batch-size", "1024"] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    parts = []
+    for i in range(3):
+        out = str(tmp_path / ("part%d.sam" % i))
+        c = subprocess.run([CLI, "-r", fa, "-o", out, "--batch-size", "1024", "--shard", "%d/3" % i] + inp, capture_output=True, text=True)
+        assert c.returncode == 0, c.stderr[-2000:]
+        parts.append(open(out).read())
+    assert parts[0].startswith("@HD") and not parts[1].startswith("@") and not parts[2].startswith("@")
+    assert all(p.count("\n") > n // 4 for p in parts), "every shard maps its share"
+    cat = str(tmp_path / "cat.sam")
+    open(cat, "w").write("".join(parts))
+    multi = str(tmp_path / "multi.sam")
+    c = subprocess.run([CLI, "-r", fa, "-o", multi, "--batch-size", "1024", "-g", "0,0", "--shard-output"] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    assert "2 shards appended" in c.stderr and not os.path.exists(multi + ".shard1")
+    a, b, m = _body(one), _body(cat), _body(multi)
+    assert len(a) == len(b) == len(m) and len([l for l in a if not l.startswith("@")]) == n
+    if not paired:
+        assert a == b and a == m
+    else:
+        for other in (b, m):
+            diff = [(x, y) for x, y in zip(a, other) if x != y]
+            assert len(diff) <= n // 200, diff[:2]
+            assert all(x.split("\t")[0] == y.split("\t")[0] for x, y in diff)
+
+
 def _bs_reads(contigs, n, paired, seed):
     """Bisulfite-converted reads of a directional library: a first mate (or single read) shows most unmethylated C of the strand it
     was sequenced from as T, a second mate -- the reverse complement of that strand -- shows G as A, whichever strand of the
