@@ -252,7 +252,7 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
     out = {"reads": n, "seconds_first_input_byte_to_sam_closed": h["io"], "value": n / h["io"], "unit": "reads/s",
            "index_load_s": h["index"], "process_wall_s": h["wall"], "reads_per_s_of_process_wall": n / h["wall"],
            "sam_bytes": os.path.getsize(sam), "fastq_bytes": len(files) * (n // len(files)) * rec,
-           "command": " ".join(["ngm-hip"] + h["cmd"][1:]), "cli_log_tail": [l for l in h["log"].splitlines() if "MAIN" in l][-4:],
+           "command": " ".join(["ngm-hip"] + h["cmd"][1:]), "cli_log_tail": [l for l in h["log"].splitlines() if "Before the mapping pass" in l or "Sensitivity estimate, s" in l] + [l for l in h["log"].splitlines() if "MAIN" in l][-4:],
            "input": "%s plain FASTQ (%d x %d bp %s, fixed-width names), page cache warm; index from NextGenMap cache files"
                     % ("two" if paired else "one", n // 2 if paired else n, READ_LEN, "pairs" if paired else "reads"),
            "make_input_s": t_make, "gpu_kernel_s": h["gpu"], "mapping_pass_s": h["pass"],
@@ -275,8 +275,15 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
                 subprocess.run(["gzip", "-1", "-f", dst], check=True)
             t_gz = time.perf_counter() - t
             hz = run_hip([d + ".gz" for d in slices], os.path.join(workdir, "e2e_gz.sam"))
+            same = None
+            plain_sam = os.path.join(workdir, "e2e.sam")
+            if os.path.exists(plain_sam):  # the first ng records of the plain run (same order, same batches) against the .gz run's
+                with open(plain_sam) as fa_, open(os.path.join(workdir, "e2e_gz.sam")) as fb_:
+                    ra = (l for l in fa_ if not l.startswith("@"))
+                    rb = [l for l in fb_ if not l.startswith("@")]
+                    same = len(rb) == ng and all(x == y for x, y in zip(ra, rb))
             out["fastq_gz_input"] = {"reads": ng, "value": ng / hz["io"], "unit": "reads/s", "seconds": hz["io"], "gzip_1_of_the_input_s": t_gz,
-                                     "same_sam_as_plain_input": None}
+                                     "same_sam_as_plain_input": same}
             for fn in [d + ".gz" for d in slices] + [os.path.join(workdir, "e2e.bam"), os.path.join(workdir, "e2e_gz.sam")]:
                 os.remove(fn)
         except Exception as e:
@@ -314,18 +321,27 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
         ours = _sam_body(sam)
         same, diffs = _sam_diff(_sam_body(ref_sam), ours)
         # ... and -t 1, the run whose output this library reproduces exactly (one CS thread: one running mean insert size)
-        n1 = min(args.cpu_t1_reads, ns) & ~1
-        t1_sam = os.path.join(workdir, "ref_t1.sam")
-        t_t1 = run_ref(slice_to(n1, "t1"), t1_sam, 1)
-        th1 = _sam_body(t1_sam)
-        same1, diffs1 = _sam_diff(th1, ours)
+        n1 = min(args.cpu_t1_reads, n) & ~1
+        th1, same1, diffs1, t_t1, early = {}, 0, [], 0.0, None
+        if n1 > 0:
+            t1_sam = os.path.join(workdir, "ref_t1.sam")
+            t1_files = slice_to(n1, "t1")
+            t_t1 = run_ref(t1_files, t1_sam, 1)
+            th1 = _sam_body(t1_sam)
+            same1, diffs1 = _sam_diff(th1, ours)
+            # ngm-hip on the same slice: how many of its pairs sit where the reference's score buffer would have filled exactly
+            try:
+                early = [l for l in run_hip(t1_files, os.path.join(workdir, "ours_t1.sam"))["log"].splitlines() if "not mirrored" in l][-1:]
+                os.remove(os.path.join(workdir, "ours_t1.sam"))
+            except Exception as e:
+                early = [str(e)[:200]]
         base = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
                 "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d on the first %d reads of the end-to-end input vs the same genome (index loaded "
                           "from the same cache files): %.1f s total minus %.1f s index load/start-up measured with a 1-pair run" % (threads, ns, t_all, t_load),
                 "parity_vs_reference_sam": {"records_compared": ns, "identical_lines": same, "first_differences": diffs,
                                             "note": "whole SAM lines, differing fields listed; the reference runs %d CS threads, each with its own running mean insert "
                                                     "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads},
-                "parity_vs_reference_sam_t1": {"records_compared": len(th1), "identical_lines": same1, "first_differences": diffs1, "seconds": t_t1,
+                "parity_vs_reference_sam_t1": {"records_compared": len(th1), "identical_lines": same1, "first_differences": diffs1, "seconds": t_t1, "ngm_hip_on_the_same_slice": early,
                                                "note": "ngm-core --affine -t 1 on the first %d reads: the run ngm-hip reproduces" % n1}}
     for fn in [sam] + files:
         try:
@@ -580,7 +596,7 @@ def main():
                     except Exception:
                         continue
                     for k, v in tj.items():
-                        if k.startswith("ngm::cs_canon_kernel") or (traffic is None and k.startswith("ngm::cs_fast2_kernel") and fn.startswith("r02")):
+                        if k.startswith("ngm::cs_canon_kernel"):
                             traffic, traffic_source = v, "profiles/" + fn + " [" + k + "]"
                     if traffic is not None:
                         break
@@ -615,8 +631,11 @@ def main():
                          "note": "`kernel` = the kernel with the largest GPU time per step of this workload; achieved = its algorithmic bytes (SURVEY.md 8d) / its "
                                  "HIP-event time on the launch stream.  Candidate search gathers from the canonical pair buckets (one 128-byte line per k-mer pair + "
                                  "16-byte chunks beyond 31 positions); random gathers on MI355X are bound by ~50 G requests/s "
-                                 "(profiles/r02_gather_calibration.txt).  `traffic` = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC pass "
-                                 "named in traffic_source -- not measured in this run.  The SW kernels are VALU-bound, see sw_gcells_per_s"},
+                                 "(profiles/r02_gather_calibration.txt) -- and the kernel itself issues VALU instructions 77-85 % of the time "
+                                 "(profiles/r03_sq_counters_cs_and_dp_kernels.txt, profiles/r03_valu_lds_issue_rate_calibration.txt: 4.3 cycles per wave "
+                                 "instruction).  `traffic` = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC pass named in traffic_source -- not "
+                                 "measured in this run; FETCH_SIZE tallies a request as 64 bytes, the 128-byte first lines too, so the bytes moved are "
+                                 "up to 64 B x k-mers per read more.  The SW kernels are VALU-bound, see sw_gcells_per_s"},
             # SURVEY.md 8d's whole-path figure: (pairs * B_score + alignments * B_align + B_cs) per second of wall time
             "path_algorithmic_gbs": (n_cand * (Q + Q + C + 4) + int(mapped.sum()) * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)) + b_cs) * world
                                     / (elapsed / args.steps) / 1e9,

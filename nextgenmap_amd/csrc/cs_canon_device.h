@@ -25,6 +25,8 @@
 // registers, which adds the missing first votes exactly; reads with more such entries take the general sweep 2.
 #pragma once
 
+#include <type_traits>
+
 #include "cs_device.h"
 
 namespace ngm {
@@ -249,10 +251,11 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		uint32_t bins[NS * kCsSeg];   // bin | first-on-its-bit << 30 | reverse strand << 31 ; 0 = empty slot
 		// one step: 8 slots per lane vote (sweep 1 of cs_fast2_kernel): positions, validity, diagonal correction and strand per slot
 		// (revf: the hit's strand in bit 31 and the "first on its bit" flag, bit 30, that the entries kept in `bins` carry; the queue ignores bit 30)
-		auto vote_step = [&](const int step, const uint32_t (&pos)[kCsSeg], const bool (&valid)[kCsSeg], const uint32_t (&corr)[kCsSeg], const uint32_t (&revf)[kCsSeg], const bool last_step) {
+		auto vote_step = [&](auto nslots, const int step, const uint32_t (&pos)[kCsSeg], const bool (&valid)[kCsSeg], const uint32_t (&corr)[kCsSeg], const uint32_t (&revf)[kCsSeg], const bool last_step) {
+			constexpr int NSL = decltype(nslots)::value;   // 8, or 4 when the step's second round is empty for the whole workgroup
 			uint32_t dup[kCsSeg], msk[kCsSeg], ent[kCsSeg];
 #pragma unroll
-			for (int j = 0; j < kCsSeg; ++j) {
+			for (int j = 0; j < NSL; ++j) {
 				const uint32_t bin = ((pos[j] - corr[j]) >> A.bin_shift) & 0x3FFFFFFFu;
 				const uint32_t b = __umulhi(bin * 0x9E3779B1u, pbits);
 				msk[j] = valid[j] ? (1u << (b & 31)) : 0u;      // empty slots vote with an all-zero mask: branch-free
@@ -261,18 +264,18 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			}
 			uint32_t ndup = 0;
 #pragma unroll
-			for (int j = 0; j < kCsSeg; ++j) ndup += dup[j] ? 1u : 0u;
+			for (int j = 0; j < NSL; ++j) ndup += dup[j] ? 1u : 0u;
 			uint32_t qb;
 			{ uint32_t total; qb = q_len + wave_prefix_small<4>(ndup, total); q_len += total; }
 #pragma unroll
-			for (int j = 0; j < kCsSeg; ++j) bins[step * kCsSeg + j] = (msk[j] ^ dup[j]) ? ent[j] : 0u;  // valid and first on its bit; repeats vote in sweep 1: nothing left to do for them
+			for (int j = 0; j < kCsSeg; ++j) bins[step * kCsSeg + j] = (j < NSL && (msk[j] ^ dup[j])) ? ent[j] : 0u;  // valid and first on its bit; repeats vote in sweep 1: nothing left to do for them
 			// the repeats go through this wave's queue: inserted when a good batch is waiting and after the last step; when one step
 			// brings more than the queue holds (repetitive reads) it is filled and emptied window by window
 			uint32_t window = 0;
 			for (;;) {
 				uint32_t at = qb;
 #pragma unroll
-				for (int j = 0; j < kCsSeg; ++j) if (dup[j] != 0u) { if (at - window < q_cap) my_queue[at - window] = ent[j]; ++at; }
+				for (int j = 0; j < NSL; ++j) if (dup[j] != 0u) { if (at - window < q_cap) my_queue[at - window] = ent[j]; ++at; }
 				const bool more = q_len - window > q_cap;
 				if (more || q_len - window > (T >= 4 ? 0u : q_cap / 2u) || last_step) {
 					const uint32_t all = q_len;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 					pos[h * 4 + e] = w4[e];
 				}
 			}
-			vote_step(s, pos, valid, corr, rev, n_items == 0u && ((uint32_t) (2 * s + 2) * (uint32_t) bpr >= (uint32_t) n_kmers || s + 1 == S1));
+			vote_step(std::integral_constant<int, kCsSeg>{}, s, pos, valid, corr, rev, n_items == 0u && ((uint32_t) (2 * s + 2) * (uint32_t) bpr >= (uint32_t) n_kmers || s + 1 == S1));
 		}
 		const unsigned long long c1c = diag ? wall_clock64() : 0ull;
 		if (CH >= S1) issue_chunks();
@@ -368,7 +371,9 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 					pos[h * 4 + e] = w4[e];
 				}
 			}
-			vote_step(S1 + s, pos, valid, corr, rev, (uint32_t) (2 * s + 2) * (uint32_t) NT >= n_items || s + 1 == S2);
+			// (most reads have fewer chunk items than lanes: the step's second round is then empty for every lane, and half a step is saved)
+			if ((uint32_t) (2 * s + 1) * (uint32_t) NT >= n_items) vote_step(std::integral_constant<int, kCsSeg / 2>{}, S1 + s, pos, valid, corr, rev, true);
+			else vote_step(std::integral_constant<int, kCsSeg>{}, S1 + s, pos, valid, corr, rev, (uint32_t) (2 * s + 2) * (uint32_t) NT >= n_items || s + 1 == S2);
 		}
 		__syncthreads();
 		const unsigned long long c2 = diag ? wall_clock64() : 0ull;

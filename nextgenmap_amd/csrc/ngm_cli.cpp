@@ -296,20 +296,56 @@ struct MappedFile {
 	const char *p = nullptr;
 	size_t n = 0, map_len = 0;   // n: the bytes that hold records (white space at the end of the file is not a record: kseq skips it too)
 	int fd = -1;
+	char *owned = nullptr;        // gzip input: the inflated text lives here instead of in a file mapping
 	bool open(const char *path) {
 		fd = ::open(path, O_RDONLY);
 		if (fd < 0) return false;
 		struct stat st;
 		if (fstat(fd, &st) != 0 || st.st_size == 0) return false;
+		unsigned char magic[2] = {0, 0};
+		if (st.st_size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) return inflate_all(path);
 		n = map_len = (size_t) st.st_size;
 		void *m = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE, fd, 0);
 		if (m == MAP_FAILED) { p = nullptr; return false; }
 		p = (const char *) m;
 		madvise(m, map_len, MADV_SEQUENTIAL);
-		while (n > 0 && (p[n - 1] == '\n' || p[n - 1] == '\r' || p[n - 1] == ' ' || p[n - 1] == '\t')) --n;
+		trim();
 		return n > 0;
 	}
-	~MappedFile() { if (p) munmap((void *) p, map_len); if (fd >= 0) close(fd); }
+	void trim() { while (n > 0 && (p[n - 1] == '\n' || p[n - 1] == '\r' || p[n - 1] == ' ' || p[n - 1] == '\t')) --n; }
+	// .gz input: inflated ONCE into memory (zlib, one thread per file -- the two files of a pair at the same time) and then read
+	// like a mapped plain file by all pool threads, instead of twice through a line-by-line reader (estimation pass, mapping pass).
+	// Inputs that inflate to more than NGM_HIP_GZ_MEMORY_GB (default 64) per file go through the serial reader.
+	bool inflate_all(const char *path) {
+		const char *e = getenv("NGM_HIP_GZ_MEMORY_GB");
+		const size_t cap_max = (size_t) std::max(1, e ? atoi(e) : 64) << 30;
+		gzFile g = gzopen(path, "rb");
+		if (!g) return false;
+		gzbuffer(g, 1 << 20);
+		size_t cap = (size_t) 256 << 20, len = 0;
+		char *buf = (char *) malloc(cap);
+		bool ok = buf != nullptr;
+		while (ok) {
+			if (cap - len < ((size_t) 16 << 20)) {
+				if (cap >= cap_max) { ok = false; break; }
+				cap = std::min(cap_max, cap * 2);
+				char *nb = (char *) realloc(buf, cap);
+				if (!nb) { ok = false; break; }
+				buf = nb;
+			}
+			const int got = gzread(g, buf + len, (unsigned) std::min<size_t>(cap - len, (size_t) 1 << 30));
+			if (got < 0) { ok = false; break; }
+			if (got == 0) break;
+			len += (size_t) got;
+		}
+		gzclose(g);
+		if (!ok || len == 0) { free(buf); return false; }
+		owned = buf; p = buf; n = len; map_len = 0;
+		trim();
+		return n > 0;
+	}
+	void release() { if (owned) { free(owned); owned = nullptr; p = nullptr; n = 0; } }
+	~MappedFile() { if (owned) free(owned); else if (p) munmap((void *) p, map_len); if (fd >= 0) close(fd); }
 	// touch every page from the pool threads: the page-table entries of a multi-GB input are then set up in parallel instead
 	// of one minor fault at a time under the (single) splitter thread
 	void prefault() const {
@@ -587,8 +623,8 @@ int run_sharded(int argc, char **argv, const Opts &o) {
 	if (o.keep_shards) { info("MAIN", "Shards written: " + parts[0] + " .. " + parts.back() + " (concatenate in this order)"); return 0; }
 	const auto t0 = std::chrono::steady_clock::now();
 	if (rename(parts[0].c_str(), o.out.c_str()) != 0) die("cannot rename " + parts[0]);
-	const int out_fd = ::open(o.out.c_str(), O_WRONLY | O_APPEND);
-	if (out_fd < 0) die("cannot append to " + o.out);
+	const int out_fd = ::open(o.out.c_str(), O_WRONLY);   // (not O_APPEND: sendfile refuses such a target)
+	if (out_fd < 0 || lseek(out_fd, 0, SEEK_END) < 0) die("cannot append to " + o.out);
 	for (int k = 1; k < N; ++k) {
 		const int in_fd = ::open(parts[k].c_str(), O_RDONLY);
 		struct stat st;
@@ -658,8 +694,16 @@ int main(int argc, char **argv) {
 	const bool interleaved = o.paired && !o.qry.empty();  // ReadProvider::GenerateRead (ReadProvider.cpp:526-584)
 	const std::string path0 = o.paired ? (interleaved ? o.qry : o.qry1) : o.qry, path1 = (o.paired && !interleaved) ? o.qry2 : std::string();
 	MappedFile mf0, mf1;
-	bool plain = !o.serial_reader && mf0.open(path0.c_str()) && mf0.plain_fastq();
-	if (plain && !path1.empty()) plain = mf1.open(path1.c_str()) && mf1.plain_fastq();
+	bool plain = false;
+	if (!o.serial_reader) {
+		bool ok1 = true;
+		std::thread second;   // (a .gz pair inflates both files at the same time)
+		if (!path1.empty()) second = std::thread([&] { ok1 = mf1.open(path1.c_str()) && mf1.plain_fastq(); });
+		plain = mf0.open(path0.c_str()) && mf0.plain_fastq();
+		if (second.joinable()) second.join();
+		plain = plain && ok1;
+		if (!plain) { mf0.release(); mf1.release(); }   // (an inflated copy the serial reader has no use for)
+	}
 	const int batch_reads = o.paired ? (o.batch & ~1) : o.batch;
 	// the splitter hands out whole sub-ranges of sub_step records (per file): the largest power of two up to kSub that divides a batch's share
 	const int per_file_reads = path1.empty() ? batch_reads : batch_reads / 2;
@@ -690,6 +734,7 @@ int main(int argc, char **argv) {
 				// not a strict 4-line record (multi-line sequences, stray blank lines): kseq reads those, so does the serial reader
 				info("INPUT", "Record at byte " + std::to_string(!ix0.ok ? ix0.bad_at : ix1.bad_at) + " of " + (!ix0.ok ? path0 : path1) + " is not a 4-line FASTQ record: using the serial reader");
 				plain_ok = plain = false; o.serial_reader = 1;
+				mf0.release(); mf1.release();
 			} else {
 				const std::string &le = !ix0.length_error.empty() ? ix0.length_error : ix1.length_error;
 				if (!le.empty()) die("Error while parsing read: sequence and quality lengths differ (" + le + ")");
@@ -727,6 +772,7 @@ int main(int argc, char **argv) {
 	mp.bs_mapping = o.bs_mapping; mp.bs_cutoff = o.bs_cutoff; mp.bs_read_skip = o.kmer_skip; mp.match_bonus_tt = o.match_tt; mp.match_bonus_tc = o.match_tc; mp.slam_seq = o.slam_seq;
 	if (o.paired) info("INPUT", "Input is paired end data.");
 
+	const auto t_indexed = std::chrono::steady_clock::now();
 	// ---- sensitivity (ReadProvider.cpp:310-385) -----------------------------------------------------------
 	float sens = 0.5f;
 	bool estimated = false;
@@ -736,8 +782,10 @@ int main(int argc, char **argv) {
 	} else if (count >= 1000 && !sample.empty()) {
 		ngm_mapper_params ep = mp;
 		ep.sensitivity = 0.0f;
+		const auto te0 = std::chrono::steady_clock::now();
 		ngm_mapper *em = ngm_mapper_create(ref, &ep);
 		if (!em) die(ngm_pipeline_last_error());
+		const auto te1 = std::chrono::steady_clock::now();
 		const int ns = (int) sample.size();
 		std::vector<char> rows((size_t) ns * q);
 		for (int i = 0; i < ns; ++i) pack_row(sample[i], q, &rows[(size_t) i * q]);
@@ -752,7 +800,14 @@ int main(int argc, char **argv) {
 			const int mx = (int) ceil((L - o.kmer + 1) / skip * 1.0);
 			if (mx > 1.0f && both[i] <= mx) { sum += both[i] / mx; ++n_used; }
 		}
+		const auto te2 = std::chrono::steady_clock::now();
 		ngm_mapper_destroy(em);
+		if (getenv("NGM_HIP_HOST_TIMING")) {
+			char tm[200];
+			snprintf(tm, sizeof(tm), "Sensitivity estimate, s: mapper (+ search layout of the index) %.3f | candidate search of %d reads %.3f | mapper released %.3f",
+					std::chrono::duration<double>(te1 - te0).count(), ns, std::chrono::duration<double>(te2 - te1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - te2).count());
+			info("INPUT", tm);
+		}
 		{
 			// ReadProvider.cpp:324-352; with no usable sample read the average is 0/0 = NaN and std::max(0.3f, NaN) is 0.3
 			const float avg = sum / n_used * 1.0f;
@@ -778,6 +833,7 @@ int main(int argc, char **argv) {
 	mp.sensitivity = sens;
 
 
+	const auto t_estimated = std::chrono::steady_clock::now();
 	// ---- output ------------------------------------------------------------------------------------------------------
 	// the output is written by the writer thread alone, in input order.  Measured alternatives (round 2, 10 M reads, 4.2 GB of
 	// SAM): pwrite from the pool threads -- the writes serialise on the file's inode lock and the threads queueing there are
@@ -1433,7 +1489,7 @@ int main(int argc, char **argv) {
 			n_total ? 100.0 * n_mapped / n_total : 0.0, n_total - n_mapped, n_written);
 	info("MAIN", msg);
 	snprintf(msg, sizeof(msg), "Mapping pass: %.3f s, %.0f reads/s (%zu GPU(s) x %d worker(s), %d host threads, %s input)", secs, n_total / std::max(1e-9, secs),
-			o.devices.size(), o.workers, pool.size(), plain ? "memory-mapped plain FASTQ" : "serial reader");
+			o.devices.size(), o.workers, pool.size(), plain ? (mf0.owned ? "gzip FASTQ inflated to memory" : "memory-mapped plain FASTQ") : "serial reader");
 	info("MAIN", msg);
 	snprintf(msg, sizeof(msg), "GPU kernels: %.3f s of the %.3f s mapping pass (%.0f %%; candidate search, gathers, score, select, align, traceback by HIP events)",
 			t_gpu_us / 1e6, secs, 100.0 * (t_gpu_us / 1e6) / std::max(1e-9, secs));
@@ -1443,6 +1499,10 @@ int main(int argc, char **argv) {
 			std::chrono::duration<double>(std::chrono::steady_clock::now() - t_input).count());
 	info("MAIN", msg);
 	if (getenv("NGM_HIP_HOST_TIMING")) {
+		auto span = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+		snprintf(msg, sizeof(msg), "Before the mapping pass, s: input mapped + record index + read lengths %.3f | sensitivity estimate %.3f | header, mappers, page-locked buffers %.3f",
+				span(t_input, t_indexed), span(t_indexed, t_estimated), span(t_estimated, t_start));
+		info("MAIN", msg);
 		snprintf(msg, sizeof(msg), "Worker time summed over %zu workers, s: waiting for input %.3f | parse + pack %.3f | map (GPU + library host stages) %.3f | format %.3f",
 				workers.size(), t_wait_us / 1e6, t_parse_us / 1e6, t_map_us / 1e6, t_format_us / 1e6);
 		info("MAIN", msg);

@@ -122,8 +122,10 @@ def test_pipeline_output_independent_of_workers_and_batches(tmp_path):
     assert c0 and c1 and c0.groups() == c1.groups(), (log0[-600:], log1[-600:])
     assert len(base) == len(piped) and base == piped
     gz, log2 = run("gz", ["--workers", "2", "--batch-size", "10000"], ["-1", f1 + ".gz", "-2", f2 + ".gz"])
-    assert "serial reader" in log2
+    assert "gzip FASTQ inflated to memory" in log2
     assert gz == base
+    gz1, log3 = run("gz-serial", ["--workers", "2", "--serial-reader"], ["-1", f1 + ".gz", "-2", f2 + ".gz"])
+    assert "serial reader" in log3 and gz1 == base
     # single-end, odd batch size
     se0, _ = run("se0", ["--workers", "1", "--serial-reader"], ["-q", f1])
     se1, _ = run("se1", ["--workers", "3", "--batch-size", "5001"], ["-q", f1])
