@@ -71,6 +71,11 @@ int ngm_ref_convert(const ngm_ref *r, uint64_t pos, int *contig, uint64_t *conti
  * record formatter needs to label the columns of an alignment, e.g. for the SLAM-seq tags); returns the number copied. */
 int ngm_ref_host_classes(const ngm_ref *r, uint64_t pos, int n, uint8_t *out);
 
+/* Builds the index layout the candidate search gathers from (one bucket per k-mer pair for odd k) now instead
+ * of when the first mapper is created: part of preparing the reference, like loading NextGenMap's cache files
+ * (src/PrefixTable.cpp:232-262).  bs_mapping != 0: nothing to build (that mode runs the exact search).  0, or -errno. */
+int ngm_ref_prepare_search(ngm_ref *ref, int bs_mapping);
+
 /* Write NextGenMap's own cache files next to `fasta_path` so that the reference program loads this encoded
  * genome and index instead of rebuilding them: <fasta_path>-enc.2.ngm (src/SequenceProvider.cpp:189-208) and
  * <fasta_path>-ht-<k>-<skip>.3.ngm (src/PrefixTable.cpp:819-855).  Content is what NGM itself would write. */

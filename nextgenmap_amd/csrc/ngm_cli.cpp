@@ -38,6 +38,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -677,6 +678,8 @@ int main(int argc, char **argv) {
 		if (ngm_ref_write_ngm_cache(ref, o.ref.c_str()) < 0) info("PREPROCESS", std::string("could not save the index: ") + ngm_pipeline_last_error());
 		else info("PREPROCESS", "Writing reference index to " + ht_cache);
 	}
+	// the layout the candidate search gathers from (canonical pair buckets) belongs to the preparation of the reference, not to the first batch
+	if (ngm_ref_prepare_search(ref, o.bs_mapping) < 0) die(ngm_pipeline_last_error());
 	info("PREPROCESS", "index entries: " + std::to_string(ngm_ref_index_entries(ref)) + ", max. k-mer frequency " +
 			std::to_string(o.max_kfreq > 0 ? o.max_kfreq : ngm_ref_auto_max_kfreq(ref)));
 	{
@@ -844,7 +847,8 @@ int main(int argc, char **argv) {
 	uint64_t out_off = 0;
 	auto put_all = [&](const char *p, size_t n, uint64_t off) -> bool {
 		while (n) {
-			const ssize_t w = pwrite(out_fd, p, n, (off_t) off);
+			// (4 MB pieces: 13.9 GB/s into the page cache against 9-11 GB/s for one call per 32 MB and more, profiles/r03_write_calibration.txt)
+			const ssize_t w = pwrite(out_fd, p, std::min<size_t>(n, (size_t) 4 << 20), (off_t) off);
 			if (w <= 0) return false;
 			p += w; n -= (size_t) w; off += (uint64_t) w;
 		}
@@ -894,7 +898,7 @@ int main(int argc, char **argv) {
 	std::vector<ngm_ref *> refs(1, ref);
 	for (size_t d = 1; d < o.devices.size(); ++d) {
 		ngm_ref *r2 = ngm_ref_create_from_fasta(o.devices[d], &rp, o.ref.c_str());  // the cache written above loads in seconds
-		if (!r2) die(ngm_pipeline_last_error());
+		if (!r2 || ngm_ref_prepare_search(r2, o.bs_mapping) < 0) die(ngm_pipeline_last_error());
 		refs.push_back(r2);
 	}
 	ngm_pair_state *pair_state = ngm_pair_state_create();
@@ -1171,10 +1175,15 @@ int main(int argc, char **argv) {
 			const size_t gran = (size_t) std::max(sub_step, (o.paired && !two) ? 2 : 1);
 			auto bound = [&](int i) -> size_t { return i >= o.shard_n ? ix0.n_records : (size_t) ((unsigned __int128) ix0.n_records * (unsigned) i / (unsigned) o.shard_n) / gran * gran; };
 			const size_t rec_lo = bound(o.shard_i), rec_hi = bound(o.shard_i + 1);
-			for (size_t r0 = rec_lo; !failed && r0 < rec_hi; r0 += (size_t) per_file_reads) {
+			// the first batch of every worker is a quarter batch: their results reach the writer -- the stage that bounds a run into one
+			// file -- that much earlier
+			const int first_div = std::max(1, getenv("NGM_HIP_FIRST_BATCH_DIV") ? atoi(getenv("NGM_HIP_FIRST_BATCH_DIV")) : 4);
+			const size_t first_share = std::max<size_t>((size_t) sub_step, (size_t) per_file_reads / (size_t) first_div / (size_t) sub_step * (size_t) sub_step);
+			for (size_t r0 = rec_lo, step = 0; !failed && r0 < rec_hi; r0 += step) {
 				auto b = std::make_unique<Batch>();
+				step = seq < workers.size() ? first_share : (size_t) per_file_reads;
 				b->seq = seq++;
-				b->n0 = (int) std::min<size_t>((size_t) per_file_reads, rec_hi - r0);
+				b->n0 = (int) std::min<size_t>(step, rec_hi - r0);
 				take(ix0, r0, b->n0, b->sub0);
 				if (two) { b->n1 = b->n0; take(ix1, r0, b->n1, b->sub1); }
 				b->n = b->n0 + b->n1;
@@ -1223,6 +1232,7 @@ int main(int argc, char **argv) {
 	const size_t text_cap0 = (size_t) batch_reads * ((size_t) 2 * q + 288) + (1u << 20);
 	if (gpu_sam) {
 		// page-locked memory is slow to get (~0.1 s per 150 MB): everything a worker needs, and the text pool, at once and in parallel
+		// (measured: requesting it earlier, under the sensitivity estimate, slows the driver calls of that estimate down by more than it saves)
 		std::vector<std::thread> alloc;
 		text_free.resize(workers.size() + 2);
 		for (TextBuf &t : text_free) alloc.emplace_back([&t, text_cap0] { t.p = (char *) ngm_host_alloc(text_cap0); t.cap = text_cap0; });

@@ -796,6 +796,13 @@ int ngm_ref_ensure_buckets(const ngm_ref *r, int kind) {
 
 extern "C" {
 
+int ngm_ref_prepare_search(ngm_ref *r, int bs_mapping) {
+	if (!r) return -22;
+	if (bs_mapping) return 0;
+	const bool canon = (r->prm.kmer & 1) && !getenv("NGM_HIP_CS_PLAIN_BUCKETS");   // (mapper.cpp: reads of more than 256 k-mers fall back to one bucket per k-mer)
+	return ngm_ref_ensure_buckets(r, canon ? 1 : 0);
+}
+
 int ngm_ref_host_classes(const ngm_ref *r, uint64_t pos, int n, uint8_t *out) {
 	if (!r || !out || n < 0) return -22;
 	int k = 0;

@@ -1,23 +1,27 @@
+# The committed measurements of a round: bench lines (affine = default, linear, single-end, config 5) and the rocprofv3 passes of the
+# default command (kernel statistics; FETCH_SIZE and WRITE_SIZE in separate --pmc passes with the kernel trace only).
+# usage (on an MI355X box, from the repository root): bash profiles/run_profile.sh [tag]      outputs: gpurun_out/profiles/<tag>_*
 set -x
-mkdir -p gpurun_out
-timeout 900 python bench.py > gpurun_out/bench_affine.log 2>&1; tail -1 gpurun_out/bench_affine.log | cut -c1-400
-timeout 600 python bench.py --personality linear --no-cpu-baseline --no-end-to-end --steps 5 > gpurun_out/bench_linear.log 2>&1
-timeout 600 python bench.py --layout se --no-cpu-baseline --no-end-to-end --steps 5 > gpurun_out/bench_se.log 2>&1
+TAG=${1:-r03}
+mkdir -p gpurun_out/profiles
+timeout 1500 python bench.py > gpurun_out/profiles/${TAG}_bench_mapping_pe_affine.log 2> gpurun_out/profiles/${TAG}_bench_mapping_pe_affine.err; tail -1 gpurun_out/profiles/${TAG}_bench_mapping_pe_affine.log | cut -c1-400
+timeout 600 python bench.py --personality linear --no-cpu-baseline --no-end-to-end --steps 5 > gpurun_out/profiles/${TAG}_bench_mapping_pe_linear.log 2>&1
+timeout 600 python bench.py --layout se --no-cpu-baseline --no-end-to-end --steps 5 > gpurun_out/profiles/${TAG}_bench_mapping_se_affine.log 2>&1
+timeout 1200 python bench.py --read-len 250 --corridor 80 --layout se --subs 0.12 --indel-bases 0.03 --sensitive --workers 4 --steps 3 --no-end-to-end --no-cpu-baseline > gpurun_out/profiles/${TAG}_bench_config5_250bp_se_c80_sensitive.log 2>&1
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $R/gpurun_out/prof_stats.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats_lin -o stats -- python $R/bench.py --personality linear --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $R/gpurun_out/prof_stats_lin.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_fetch -o fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $R/gpurun_out/prof_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof_write -o write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end > $R/gpurun_out/prof_write.log 2>&1
 cd $R
-find gpurun_out -name "*.db" | head
-S=$(find gpurun_out/prof_stats -name "*.db" | head -1); F=$(find gpurun_out/prof_fetch -name "*.db" | head -1); W=$(find gpurun_out/prof_write -name "*.db" | head -1)
-cp profiles/summarize_rocprof.py gpurun_out/summ.py
+S=$(find gpurun_out/prof_stats -name "*.db" | head -1); L=$(find gpurun_out/prof_stats_lin -name "*.db" | head -1); F=$(find gpurun_out/prof_fetch -name "*.db" | head -1); W=$(find gpurun_out/prof_write -name "*.db" | head -1)
 python - <<PY
-import shutil,subprocess,sys,os
-os.makedirs("gpurun_out/profiles", exist_ok=True)
-src=open("profiles/summarize_rocprof.py").read().replace('HERE = os.path.dirname(os.path.abspath(__file__))','HERE = "gpurun_out/profiles"')
-open("gpurun_out/summ.py","w").write(src)
-subprocess.run([sys.executable,"gpurun_out/summ.py","r02_mapping_pe_affine","$S","$F","$W"])
+import subprocess, sys
+src = open("profiles/summarize_rocprof.py").read().replace('HERE = os.path.dirname(os.path.abspath(__file__))', 'HERE = "gpurun_out/profiles"')
+open("gpurun_out/summ.py", "w").write(src)
+subprocess.run([sys.executable, "gpurun_out/summ.py", "${TAG}_mapping_pe_affine", "$S", "$F", "$W"])
+subprocess.run([sys.executable, "gpurun_out/summ.py", "${TAG}_mapping_pe_linear", "$L"])
 PY
 ls -la gpurun_out/profiles
-rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write
+rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_lin gpurun_out/prof_fetch gpurun_out/prof_write

@@ -22,7 +22,7 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/linear_stats -o stats -- py
 cd $R
 python - <<'PY' | tee gpurun_out/r3_pmc/summary.txt
 import sqlite3, glob, os
-want = ("cs_canon_kernel", "cs_fast2_kernel", "sw_affine_score_pk_kernel", "sw_affine_align_pk_kernel", "sw_score_pk_kernel", "sw_align_kernel", "sam_write_kernel", "sam_lengths_kernel", "gather_pairs_kernel")
+want = ("cs_canon_kernel", "cs_fast2_kernel", "sw_affine_score_pk_kernel", "sw_affine_align_pk_kernel", "sw_score_pk_kernel", "sw_align_pk_kernel", "sw_align_kernel", "sam_write_kernel", "sam_lengths_kernel", "gather_pairs_kernel")
 for db in sorted(glob.glob("gpurun_out/r3_pmc/*/*.db") + glob.glob("gpurun_out/r3_pmc/*/*/*.db")):
     c = sqlite3.connect(db).cursor()
     tag = db.split("/")[2]
