@@ -84,6 +84,8 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	for (; read < A.n; read = read_next, read_next = s_next_read) {
 		// everything derived from the thread index is recomputed per read from a value the compiler cannot see through: hoisted out
 		// of this loop those values would each hold a register for the whole kernel (78 spilled registers instead of 7)
+		const bool diag = A.phase_cycles && (read & 255) == 0;
+		const unsigned long long c_top = diag ? wall_clock64() : 0ull;
 		int tid = tid0;
 		asm volatile("" : "+v"(tid));
 		const int lane = tid & 63, wv = tid >> 6;
@@ -99,7 +101,6 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		if (tid == 0) drawn = (int) (2u * gridDim.x + atomicAdd(&A.status[2], 1u));
 		for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 		for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
-		const bool diag = A.phase_cycles && (read & 255) == 0;
 		const unsigned long long c0 = diag ? wall_clock64() : 0ull;
 
 		// 0. codes (A0 C1 T2 G3, CSstatic.cpp:20-22; N = 4; past the end = 255), read length
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				if (diag && lane == 0) {
 					atomicAdd(&A.phase_cycles[0], c1 - c0); atomicAdd(&A.phase_cycles[1], c2 - c1); atomicAdd(&A.phase_cycles[2], c3 - c2);
 					atomicAdd(&A.phase_cycles[3], wall_clock64() - c3);
+					atomicAdd(&A.phase_cycles[8], c0 - c_top);   // the resets and the prefetch in front of the timed phases
 					atomicAdd(&A.phase_cycles[4], c1a - c1); atomicAdd(&A.phase_cycles[5], c1b - c1a); atomicAdd(&A.phase_cycles[6], c1c - c1b); atomicAdd(&A.phase_cycles[7], c2 - c1c);
 				}
 			}

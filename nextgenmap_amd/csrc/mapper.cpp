@@ -163,6 +163,8 @@ size_t cs_canon_lds_bytes(const ngm::CsArgs &A, int shape) {  // k-mer info + he
 const void *cs_canon_fn(int shape, int ch, int wpe) {
 	if (shape == 1) return (const void *) ngm::cs_canon_kernel<3, 4, 2, 1>;
 	if (shape == 3) return (const void *) ngm::cs_canon_kernel<4, 8, 4, 1>;
+	if (wpe <= 5) return (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 5>;   // experiments: 86 VGPRs, no scratch, 5 waves per SIMD
+	if (wpe == 6) return (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 6>;   // 80 VGPRs, 5 spilled dwords
 	if (wpe <= 7) return ch == 0 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 0, 7> : (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 7>;
 	return ch == 0 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 0> : ch >= 3 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 3> : (const void *) ngm::cs_canon_kernel<3, 6, 2, 1>;
 }
@@ -354,8 +356,8 @@ int run_cs(ngm_mapper *m, int n) {
 				fprintf(stderr, "[ngm-hip] cs fast path, 100 MHz ticks per read: lists %.1f sweep1 %.1f sweep2 %.1f candidates %.1f; %u of %d reads re-run by the exact path; kernels %.2f + %.2f + %.2f ms\n",
 						(double) ph[0] * 256 / n, (double) ph[1] * 256 / n, (double) ph[2] * 256 / n, (double) ph[3] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
 			if (A.phase_cycles && m->cs_canon)
-				fprintf(stderr, "[ngm-hip] cs canonical path, inside sweep 1: first lines arrived %.1f | chunk items %.1f | first-line votes %.1f | chunk votes %.1f\n",
-						(double) ph[4] * 256 / n, (double) ph[5] * 256 / n, (double) ph[6] * 256 / n, (double) ph[7] * 256 / n);
+				fprintf(stderr, "[ngm-hip] cs canonical path, inside sweep 1: first lines arrived %.1f | chunk items %.1f | first-line votes %.1f | chunk votes %.1f; in front of the phases (resets, prefetch) %.1f\n",
+						(double) ph[4] * 256 / n, (double) ph[5] * 256 / n, (double) ph[6] * 256 / n, (double) ph[7] * 256 / n, (double) ph[8] * 256 / n);
 			return 0;
 		}
 		cap *= 4;  // candidate buffer too small: grow and redo the batch
@@ -582,7 +584,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast))
 	NGM_CS_ATTR_T(2); NGM_CS_ATTR_T(3); NGM_CS_ATTR_T(4);
 #undef NGM_CS_ATTR_T
-	for (int shape = 1; shape <= 3; ++shape) for (int ch : {0, 1, 3}) for (int wpe : {7, 8})
+	for (int shape = 1; shape <= 3; ++shape) for (int ch : {0, 1, 3}) for (int wpe : {5, 6, 7, 8})
 		(void) hipFuncSetAttribute(cs_canon_fn(shape, ch, wpe), hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_canon_lds_bytes(A, shape));
 	// three waves per read for the 768-segment size (150 bp reads), four for the 1 536-segment one (250 bp: 12.3 instead of 14.7 ms
 	// per 524 288 reads -- with twice the work items per read the fourth wave pays for the seventh-of-a-CU it costs)
