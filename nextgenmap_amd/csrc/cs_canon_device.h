@@ -33,6 +33,7 @@ namespace ngm {
 
 constexpr int kCsCanonFirstLineWords = 32;   // words of a bucket fetched blind (one 128-byte line)
 constexpr int kCsCanonRel = 8;               // table entries completed by comparison (more: general sweep 2)
+constexpr int kCsCanonDraw = 4;              // reads a persistent workgroup draws from the launch's read counter at a time
 
 // T waves per read; R1 rounds of blind first-line loads (a round covers T * 64 >> glog buckets, glog = log2 of the lanes per
 // first line: 3 for buckets of 32 words and more); R2 rounds of 16-byte chunk items.  R1 and R2 are even: votes are cast in
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	__shared__ uint32_t s_tot[T][3];   // per wave: chunk items, hits, k-mers looked up
 	__shared__ int s_len[T];
 	__shared__ uint32_t s_abort, s_nkeys, s_nrel;
-	__shared__ int s_next_read;
+	__shared__ int s_next_read, s_draw_next, s_draw_left;
 	__shared__ uint32_t s_mx[T][2];
 	__shared__ uint32_t s_rel_key[kCsCanonRel], s_rel_slot[kCsCanonRel];
 	const int tid0 = threadIdx.x;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	// persistent workgroups: reads b and b + grid are this workgroup's by position, every further one is drawn from a counter
 	// (status[2]) -- a workgroup that only becomes resident when others have finished (the occupancy the API promises is not
 	// always what the hardware admits) then finds little left instead of a full static share, and slow CUs do fewer reads
+	if (tid0 == 0) { s_draw_next = 0; s_draw_left = 0; }   // (only thread 0 reads them)
 	int read = blockIdx.x, read_next = (int) (blockIdx.x + gridDim.x);
 	uint32_t ch_next = (read < A.n && tid0 < A.q) ? (uint32_t) A.reads[(size_t) read * A.q + tid0] : 0u;
 	for (; read < A.n; read = read_next, read_next = s_next_read) {
@@ -97,8 +99,14 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		// this workgroup's next read: its characters travel while this one is processed; the one after that is drawn now (a
 		// returning L2 atomic: its latency hides behind the read, too)
 		ch_next = (read_next < A.n && tid < A.q) ? (uint32_t) A.reads[(size_t) read_next * A.q + tid] : 0u;
+		// (kCsCanonDraw reads per draw: ONE counter for the whole launch serves ~86 M returning atomics per second -- measured with
+		// NGM_HIP_CS_STOP: a launch that leaves every read after its setup phase took as long as the whole kernel, 6.1 ms per
+		// 524 288 reads, because every read drew its successor separately)
 		int drawn = 0;
-		if (tid == 0) drawn = (int) (2u * gridDim.x + atomicAdd(&A.status[2], 1u));
+		if (tid == 0) {
+			if (s_draw_left > 0) { drawn = s_draw_next; s_draw_next = drawn + 1; s_draw_left -= 1; }
+			else { drawn = (int) (2u * gridDim.x + atomicAdd(&A.status[2], (uint32_t) kCsCanonDraw)); s_draw_next = drawn + 1; s_draw_left = kCsCanonDraw - 1; }
+		}
 		for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 		for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
 		const unsigned long long c0 = diag ? wall_clock64() : 0ull;
@@ -200,6 +208,8 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		const unsigned long long c1b = diag ? wall_clock64() : 0ull;
 		const uint32_t H = R.H;
 		const uint32_t n_items = R.n_items;
+		auto stop_here = [&]() { if (tid == 0) { A.cand_base[read] = 0; A.cand_count[read] = 0; A.max_votes[read] = 0.f; A.read_len[read] = (uint16_t) R.L; } };
+		if (A.debug_stop == 1) { stop_here(); continue; }
 		if (H > A.hit_cap || n_items > kItemCap || n_kmers > NT || n_kmers > R1 * bpr) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
 
 		// item -> address of its 16 bytes; its slots are positions [first, first + 4) of the bucket's (or the pair's) hit numbering
@@ -378,6 +388,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		}
 		__syncthreads();
 		const unsigned long long c2 = diag ? wall_clock64() : 0ull;
+		if (A.debug_stop == 2) { stop_here(); continue; }
 		if (s_abort) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }  // not provably exact here
 
 		// 3. complete the entries that can still matter (see the header): largest count, then the entries within reach of it
@@ -425,6 +436,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				if (hit) atomicAdd(&t_votes[s_rel_slot[j]], (hit >> 31) ? 0x10000u : 1u);
 			}
 			__syncthreads();
+			if (A.debug_stop == 3) { stop_here(); continue; }
 			const unsigned long long c3 = diag ? wall_clock64() : 0ull;
 			// 4. threshold and candidates (cs_finish, CS.cpp:201-205, :263-313) over the completed entries -- all others are out of reach
 			if (wv == 0) {

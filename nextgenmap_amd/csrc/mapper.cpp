@@ -212,6 +212,7 @@ int run_cs(ngm_mapper *m, int n) {
 		A.fixed_base = fixed_slots ? (uint32_t) cap : 0u;
 		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
 		A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + ctr_words : nullptr;
+		A.debug_stop = getenv("NGM_HIP_CS_STOP") ? atoi(getenv("NGM_HIP_CS_STOP")) : 0;
 		uint32_t status[4];
 		m->cs_kernel_ms = 0;
 		float pass_ms[3] = {0, 0, 0};
