@@ -70,7 +70,10 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	const int glog = min(lw, 5) - 2;                       // lanes per first line: 1, 2, 4, 8
 	const int bpr = NT >> glog;                            // buckets per round
 	const uint32_t flw = min(1u << lw, (uint32_t) kCsCanonFirstLineWords);
-	const uint32_t pbits = A.plane_bits;
+	// the plane holds a power of two of bits and is indexed by the low bits of the bin itself: genome positions of background hits are
+	// uniform, so no hash is needed (two multiplies less per vote); bins that collide are a multiple of plane_bits x 4 bp apart on the
+	// same diagonal -- rare, and a collision only sends a hit through the exact table
+	const uint32_t pmask = A.plane_bits - 1u;
 	const int hs = 32 - log2_slots;
 	const int cb = 2 * (k >> 1) + 1;  // the bit that tells the two k-mers of a pair apart (refindex.h)
 	// LDS operations of one wave complete in program order: the queue hand-over inside a wave needs no hardware barrier, only
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		const uint32_t ch0 = ch_next;
 		// this workgroup's next read: its characters travel while this one is processed; the one after that is drawn now (a
 		// returning L2 atomic: its latency hides behind the read, too)
-		ch_next = (read_next < A.n && tid < A.q) ? (uint32_t) A.reads[(size_t) read_next * A.q + tid] : 0u;
+		// (requested after the vote phase, not here: across the votes the compiler spills the register, and a spilled load is waited for
+		// where it is issued)
+		auto next_chars = [&]() { ch_next = (read_next < A.n && tid < A.q) ? (uint32_t) A.reads[(size_t) read_next * A.q + tid] : 0u; };
 		// (kCsCanonDraw reads per draw: ONE counter for the whole launch serves ~86 M returning atomics per second -- measured with
 		// NGM_HIP_CS_STOP: a launch that leaves every read after its setup phase took as long as the whole kernel, 6.1 ms per
 		// 524 288 reads, because every read drew its successor separately)
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		const uint32_t H = R.H;
 		const uint32_t n_items = R.n_items;
 		auto stop_here = [&]() { if (tid == 0) { A.cand_base[read] = 0; A.cand_count[read] = 0; A.max_votes[read] = 0.f; A.read_len[read] = (uint16_t) R.L; } };
-		if (A.debug_stop == 1) { stop_here(); continue; }
-		if (H > A.hit_cap || n_items > kItemCap || n_kmers > NT || n_kmers > R1 * bpr) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
+		if (A.debug_stop == 1) { stop_here(); next_chars(); continue; }
+		if (H > A.hit_cap || n_items > kItemCap || n_kmers > NT || n_kmers > R1 * bpr) { if (wv == 0) cs_enqueue(A, read, lane, R); next_chars(); continue; }
 
 		// item -> address of its 16 bytes; its slots are positions [first, first + 4) of the bucket's (or the pair's) hit numbering
 		auto item_meta = [&](uint32_t idx, uint32_t &p, uint32_t &first, uint32_t &lim, uint32_t &na) -> size_t {
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 #pragma unroll
 			for (int j = 0; j < NSL; ++j) {
 				const uint32_t bin = ((pos[j] - corr[j]) >> A.bin_shift) & 0x3FFFFFFFu;
-				const uint32_t b = __umulhi(bin * 0x9E3779B1u, pbits);
+				const uint32_t b = bin & pmask;
 				msk[j] = valid[j] ? (1u << (b & 31)) : 0u;      // empty slots vote with an all-zero mask: branch-free
 				dup[j] = atomicOr(&plane[b >> 5], msk[j]) & msk[j];   // != 0: a repeat on its bit
 				ent[j] = bin | revf[j];
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		}
 		__syncthreads();
 		const unsigned long long c2 = diag ? wall_clock64() : 0ull;
+		next_chars();
 		if (A.debug_stop == 2) { stop_here(); continue; }
 		if (s_abort) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }  // not provably exact here
 
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		for (uint32_t s = tid; s < n_slots; s += NT) {
 			const uint32_t key = t_keys[s];
 			if (key != 0xFFFFFFFFu) {
-				const uint32_t b = __umulhi(key * 0x9E3779B1u, pbits);
+				const uint32_t b = key & pmask;
 				atomicOr(&plane[b >> 5], 1u << (b & 31));
 			}
 		}
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 #pragma unroll
 			for (int i = 0; i < NS * kCsSeg; ++i) {
 				const uint32_t e = bins[i];
-				const uint32_t b = __umulhi((e & 0x3FFFFFFFu) * 0x9E3779B1u, pbits);
+				const uint32_t b = e & 0x3FFFFFFFu & pmask;
 				const uint32_t w = (plane[b >> 5] >> (b & 31)) & (e >> 30) & 1u;
 				wmask |= (unsigned long long) w << i;
 			}

@@ -553,21 +553,11 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 			m->cs_canon = shape;
 			if (const char *e = getenv("NGM_HIP_CS_CANON_CH")) m->cs_canon_ch = atoi(e);
 			if (const char *e = getenv("NGM_HIP_CS_CANON_WPE")) m->cs_canon_wpe = atoi(e);
-			m->cs_plane_bits = m->cs_plane_bits0;
-			// one more read per CU where trimming the plane a little allows it (see above; the canonical kernel keeps less per read in LDS)
-			ngm::CsArgs G{};
-			G.lists_cap = 2 * n_kmers; G.q = p->qry_max_len; G.log2_slots = m->cs_log2_small; G.plane_bits = m->cs_plane_bits;
-			const size_t granule = 1280, lds = 160 * 1024;
-			const size_t have = cs_canon_lds_bytes(G, shape);
-			const size_t per_cu = lds / std::max<size_t>((have + granule - 1) / granule * granule, 1);
-			const size_t wave_limit = (size_t) (shape == 2 ? m->cs_canon_wpe * 4 : 32) / kCanonT[shape];
-			if (per_cu >= 1 && per_cu < wave_limit) {
-				const size_t target = lds / (per_cu + 1) / granule * granule;
-				if (have > target) {
-					const uint32_t cut_bits = (uint32_t) (((have - target) * 8 + 31) / 32 * 32);
-					if (cut_bits <= m->cs_plane_bits / 5 && (double) (m->cs_plane_bits - cut_bits) >= 10.0 * m->cs_hexp) m->cs_plane_bits -= cut_bits;
-				}
-			}
+			// the canonical kernel indexes its plane with the low bits of the bin: a power of two of bits, at least 10 per expected hit
+			// (150 bp reads at GRCh38 size: 65 536 bits; with the rest of a read's LDS 16 KB -> 13 granules of 1 280 bytes, nine reads per CU)
+			uint32_t pb = 4096;
+			while ((double) pb < 10.0 * m->cs_hexp && pb < 131072u) pb <<= 1;
+			m->cs_plane_bits = pb;
 		}
 	}
 	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
