@@ -83,10 +83,15 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	// persistent workgroups: reads b and b + grid are this workgroup's by position, every further one is drawn from a counter
 	// (status[2]) -- a workgroup that only becomes resident when others have finished (the occupancy the API promises is not
 	// always what the hardware admits) then finds little left instead of a full static share, and slow CUs do fewer reads
+	// ... or (reads_per_wg > 0) many short-lived workgroups, each with its run of consecutive reads and the same prefetch inside the
+	// run: no counter at all, the hardware balances the load, and -- unlike workgroups that live as long as the kernel -- a kernel
+	// of another stream (the order replay of the other mapper instance, on a high-priority stream) gets onto the CUs as runs end
 	if (tid0 == 0) { s_draw_next = 0; s_draw_left = 0; }   // (only thread 0 reads them)
-	int read = blockIdx.x, read_next = (int) (blockIdx.x + gridDim.x);
-	uint32_t ch_next = (read < A.n && tid0 < A.q) ? (uint32_t) A.reads[(size_t) read * A.q + tid0] : 0u;
-	for (; read < A.n; read = read_next, read_next = s_next_read) {
+	const int run = A.reads_per_wg;
+	int read = run > 0 ? (int) blockIdx.x * run : (int) blockIdx.x, read_next = run > 0 ? read + 1 : (int) (blockIdx.x + gridDim.x);
+	const int read_end = run > 0 ? min(A.n, read + run) : A.n;
+	uint32_t ch_next = (read < read_end && tid0 < A.q) ? (uint32_t) A.reads[(size_t) read * A.q + tid0] : 0u;
+	for (; read < read_end; read = read_next, read_next = s_next_read) {
 		// everything derived from the thread index is recomputed per read from a value the compiler cannot see through: hoisted out
 		// of this loop those values would each hold a register for the whole kernel (78 spilled registers instead of 7)
 		const bool diag = A.phase_cycles && (read & 255) == 0;
@@ -103,13 +108,14 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		// returning L2 atomic: its latency hides behind the read, too)
 		// (requested after the vote phase, not here: across the votes the compiler spills the register, and a spilled load is waited for
 		// where it is issued)
-		auto next_chars = [&]() { ch_next = (read_next < A.n && tid < A.q) ? (uint32_t) A.reads[(size_t) read_next * A.q + tid] : 0u; };
+		auto next_chars = [&]() { ch_next = (read_next < read_end && tid < A.q) ? (uint32_t) A.reads[(size_t) read_next * A.q + tid] : 0u; };
 		// (kCsCanonDraw reads per draw: ONE counter for the whole launch serves ~86 M returning atomics per second -- measured with
 		// NGM_HIP_CS_STOP: a launch that leaves every read after its setup phase took as long as the whole kernel, 6.1 ms per
 		// 524 288 reads, because every read drew its successor separately)
 		int drawn = 0;
 		if (tid == 0) {
-			if (s_draw_left > 0) { drawn = s_draw_next; s_draw_next = drawn + 1; s_draw_left -= 1; }
+			if (run > 0) drawn = read_next + 1;
+			else if (s_draw_left > 0) { drawn = s_draw_next; s_draw_next = drawn + 1; s_draw_left -= 1; }
 			else { drawn = (int) (2u * gridDim.x + atomicAdd(&A.status[2], (uint32_t) kCsCanonDraw)); s_draw_next = drawn + 1; s_draw_left = kCsCanonDraw - 1; }
 		}
 		for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }

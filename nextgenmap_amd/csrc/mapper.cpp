@@ -245,6 +245,11 @@ int run_cs(ngm_mapper *m, int n) {
 			if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
 			int grid = std::min(n, per_cu * cus);
 			if (const char *e = getenv("NGM_HIP_CS_GRID_PER_CU")) grid = std::min(n, std::max(1, atoi(e)) * cus);  // experiments
+			// (experiment, NGM_HIP_CS_READS_PER_WG=16..128: 5.55 / 5.74 / 6.44 ms per 524 288 reads with runs of 32 / 64 / 128 reads against 5.41 with
+			// persistent workgroups on the same box, and the other instance's order replay waits as long either way: not the default)
+			static const int run_env = getenv("NGM_HIP_CS_READS_PER_WG") ? atoi(getenv("NGM_HIP_CS_READS_PER_WG")) : 0;
+			A.reads_per_wg = std::max(0, run_env);
+			if (A.reads_per_wg > 0) grid = (n + A.reads_per_wg - 1) / A.reads_per_wg;
 			void *kargs[] = {(void *) &A};
 			(void) hipLaunchKernel(fn, dim3(grid), dim3(kCanonT[m->cs_canon] * 64), kargs, lds, m->st);
 			if (A.phase_cycles)
