@@ -88,7 +88,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	// of another stream (the order replay of the other mapper instance, on a high-priority stream) gets onto the CUs as runs end
 	if (tid0 == 0) { s_draw_next = 0; s_draw_left = 0; }   // (only thread 0 reads them)
 	const int run = A.reads_per_wg;
-	int read = run > 0 ? (int) blockIdx.x * run : (int) blockIdx.x, read_next = run > 0 ? read + 1 : (int) (blockIdx.x + gridDim.x);
+	int read = A.read_lo + (run > 0 ? (int) blockIdx.x * run : (int) blockIdx.x), read_next = run > 0 ? read + 1 : read + (int) gridDim.x;
 	const int read_end = run > 0 ? min(A.n, read + run) : A.n;
 	uint32_t ch_next = (read < read_end && tid0 < A.q) ? (uint32_t) A.reads[(size_t) read * A.q + tid0] : 0u;
 	for (; read < read_end; read = read_next, read_next = s_next_read) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		if (tid == 0) {
 			if (run > 0) drawn = read_next + 1;
 			else if (s_draw_left > 0) { drawn = s_draw_next; s_draw_next = drawn + 1; s_draw_left -= 1; }
-			else { drawn = (int) (2u * gridDim.x + atomicAdd(&A.status[2], (uint32_t) kCsCanonDraw)); s_draw_next = drawn + 1; s_draw_left = kCsCanonDraw - 1; }
+			else { drawn = A.read_lo + (int) (2u * gridDim.x + atomicAdd(&A.status[2], (uint32_t) kCsCanonDraw)); s_draw_next = drawn + 1; s_draw_left = kCsCanonDraw - 1; }
 		}
 		for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 		for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;

@@ -77,6 +77,7 @@ struct CsArgs {
 	uint32_t order_gcap;        // ... entries per workgroup
 	uint32_t order_max_hits;    // cs_order_kernel: time line entries in LDS (sized by the host from the expected hits per read)
 	unsigned long long *phase_cycles;  // optional diagnostics (fast path): [0] lists [1] sweep 1 [2] sweep 2 [3] candidates
+	int read_lo;                       // cs_canon_kernel: first read of this launch (a batch may be searched in several launches: reads [read_lo, n))
 	int reads_per_wg;                  // cs_canon_kernel: > 0: workgroup b maps reads [b, b + 1) * reads_per_wg (as many workgroups as that takes); 0: persistent workgroups that draw reads from status[2]
 	int debug_stop;                    // diagnostics (NGM_HIP_CS_STOP, cs_canon_kernel only): 1-3 = leave a read after that phase with no candidates -- instruction counts per phase by difference
 	uint32_t *ovf_read;     // [n] queue written by this pass

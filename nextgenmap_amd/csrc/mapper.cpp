@@ -250,8 +250,21 @@ int run_cs(ngm_mapper *m, int n) {
 			static const int run_env = getenv("NGM_HIP_CS_READS_PER_WG") ? atoi(getenv("NGM_HIP_CS_READS_PER_WG")) : 0;
 			A.reads_per_wg = std::max(0, run_env);
 			if (A.reads_per_wg > 0) grid = (n + A.reads_per_wg - 1) / A.reads_per_wg;
-			void *kargs[] = {(void *) &A};
-			(void) hipLaunchKernel(fn, dim3(grid), dim3(kCanonT[m->cs_canon] * 64), kargs, lds, m->st);
+			// NGM_HIP_CS_SPLIT=k: the batch in k launches -- persistent workgroups hold every CU until their launch ends, and a kernel of
+			// another stream (the other mapper instance's order replay, on a high-priority stream) only gets in between launches
+			static const int split = std::max(1, getenv("NGM_HIP_CS_SPLIT") ? atoi(getenv("NGM_HIP_CS_SPLIT")) : 1);
+			const int n_all = A.n;
+			for (int part = 0; part < split; ++part) {
+				ngm::CsArgs P = A;
+				P.read_lo = (int) ((long long) n_all * part / split);
+				P.n = (int) ((long long) n_all * (part + 1) / split);
+				if (P.n <= P.read_lo) continue;
+				const int cnt = P.n - P.read_lo;
+				const int g = A.reads_per_wg > 0 ? (cnt + A.reads_per_wg - 1) / A.reads_per_wg : std::min(cnt, grid);
+				if (part > 0) (void) hipMemsetAsync(m->d_status.p + 2, 0, 4, m->st);
+				void *kargs[] = {(void *) &P};
+				(void) hipLaunchKernel(fn, dim3(g), dim3(kCanonT[m->cs_canon] * 64), kargs, lds, m->st);
+			}
 			if (A.phase_cycles)
 				fprintf(stderr, "[ngm-hip] cs canonical path (shape %d): %zu bytes of LDS per read, %d reads resident per CU (grid %d), bucket 2^%d words\n", m->cs_canon, lds, per_cu, grid, A.bucket_log2_words);
 		}
