@@ -1146,8 +1146,12 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				// mirrored; count where it would have struck, and where it could have changed something (several
 				// candidates for that mate).  Sequential like the running mean: part of the batch's turn.
 				uint64_t tot = m->scores_so_far, at = m->reads_so_far;
+				// (the next flush position is carried along: a 64-bit remainder per pair made this loop the longest part of the turn)
+				const uint64_t rb = m->ref_cs_batch > 0 ? (uint64_t) m->ref_cs_batch : 0;
+				uint64_t next_flush = rb ? (at + rb - 1) / rb * rb : ~0ull;
 				for (int pi = 0; pi < n / 2; ++pi, at += 2) {
-					if (m->ref_cs_batch > 0 && at % (uint64_t) m->ref_cs_batch == 0) tot = 0;  // the reference flushes its score buffer at the end of a CS batch (CS.cpp:488-500)
+					while (at > next_flush) next_flush += rb;   // (an odd batch size: flush positions between two pairs never match `at`)
+					if (at == next_flush) { tot = 0; next_flush += rb; }  // the reference flushes its score buffer at the end of a CS batch (CS.cpp:488-500)
 					const uint32_t c1 = m->h_count[2 * pi], c2 = m->h_count[2 * pi + 1];
 					tot += c1;
 					if (c1 > 0 && c2 > 0 && (tot & 1023u) == 0) { ++m->early_se_pairs; if (c1 > 1) ++m->early_se_ambiguous; }
