@@ -1491,7 +1491,7 @@ int main(int argc, char **argv) {
 	{ std::lock_guard<std::mutex> lk(out_mu); workers_done = true; }
 	out_cv.notify_all();
 	writer.join();
-	if (o.bam && o.shard_i == o.shard_n - 1) { std::string z; ngm::bam::bgzf_eof(z);   // (--shard: the end-of-file block travels with the last shard) if (!put_all(z.data(), z.size(), out_off)) fail("write error on " + o.out); out_off += z.size(); }
+	if (o.bam && o.shard_i == o.shard_n - 1) { std::string z; ngm::bam::bgzf_eof(z); if (!put_all(z.data(), z.size(), out_off)) fail("write error on " + o.out); out_off += z.size(); }   // (--shard: the end-of-file block travels with the last shard)
 	if (close(out_fd) != 0) fail("write error on " + o.out);
 	if (failed) die(fail_msg);
 	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
