@@ -113,3 +113,26 @@ def test_bam_equals_reference_program(tmp_path, layout, extra):
     for x, y in diff[:3]:
         print([(u, v) for u, v in zip(x[0], y[0]) if u != v])
     assert not diff
+
+
+def test_bam_shards_concatenate(tmp_path):
+    """`--bam --shard i/N`: whole BGZF blocks per shard, the header with shard 0, the end-of-file block with the last one -- the
+    concatenation is one valid BAM file with the records of the unsharded run."""
+    fa, inp = _case(tmp_path, False)
+    one = str(tmp_path / "one.bam")
+    c = subprocess.run([CLI, "-r", fa, "-o", one, "--affine", "--bam", "--batch-size", "1024"] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    parts = b""
+    for i in range(2):
+        out = str(tmp_path / ("part%d.bam" % i))
+        c = subprocess.run([CLI, "-r", fa, "-o", out, "--affine", "--bam", "--batch-size", "1024", "--shard", "%d/2" % i] + inp, capture_output=True, text=True)
+        assert c.returncode == 0, c.stderr[-2000:]
+        parts += open(out, "rb").read()
+    cat = str(tmp_path / "cat.bam")
+    open(cat, "wb").write(parts)
+    ta, ra, a = decode_bam(one)
+    tb, rb, b = decode_bam(cat)
+    assert ra == rb and len(a) == len(b) == 4000
+    strip = lambda t: [l.split("\tCL:")[0] if l.startswith("@PG") else l for l in t.splitlines()]
+    assert strip(ta) == strip(tb)
+    assert a == b
