@@ -76,6 +76,7 @@ struct CsArgs {
 	uint32_t *order_scratch;    // cs_order_kernel: time lines in global memory for reads with more hits than LDS holds
 	uint32_t order_gcap;        // ... entries per workgroup
 	uint32_t order_max_hits;    // cs_order_kernel: time line entries in LDS (sized by the host from the expected hits per read)
+	uint32_t *order_info;       // cs_order_kernel: per listed read {index hits, 0 = replayed | reason it was left to the exact kernel (1 k-mer variants, 2 time line, 3 tracked bins) | tracked bins << 8}
 	unsigned long long *phase_cycles;  // optional diagnostics (fast path): [0] lists [1] sweep 1 [2] sweep 2 [3] candidates
 	int read_lo;                       // cs_canon_kernel: first read of this launch (a batch may be searched in several launches: reads [read_lo, n))
 	int reads_per_wg;                  // cs_canon_kernel: > 0: workgroup b maps reads [b, b + 1) * reads_per_wg (as many workgroups as that takes); 0: persistent workgroups that draw reads from status[2]
@@ -1174,6 +1175,12 @@ constexpr uint32_t kCsOrderMaxHits = 7168;  // least time line entries in LDS (C
 constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
 constexpr int kCsOrderThreads = 256;
 
+// GLOBAL (the exact fall-back for the reads the LDS replay leaves: more hits than its time line, more repeated bins than its
+// 1 024-slot table -- common on a genome with a heavy-tailed k-mer spectrum): the same replay with the time line AND the table of
+// tracked bins in a per-read slice of global memory sized from the read's hits (A.ovf_table_off / A.ovf_log2 / A.gtable_keys), and
+// 32-bit hit times (l_time) instead of the 16-bit ones packed into l_pref.  Nothing is given up but a bisulfite read with more
+// k-mer variants than the list rows hold.
+template <bool GLOBAL>
 __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
 		uint32_t *__restrict__ cand_rank) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
@@ -1183,28 +1190,35 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	// compaction and the replay -- stay with wave 0; cs_prepare is run by every wave (same values, its barrier is the block's)
 	constexpr int NT = kCsOrderThreads;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	auto og = [](const uint32_t *p) -> uint32_t { return GLOBAL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };   // words updated by L2 atomics: not through L1
 	const int read = (int) A.read_list[blockIdx.x];
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;
 	uint32_t *l_pref = cs_lds + A.lists_cap;
 	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);
 	uint32_t *plane = (uint32_t *) l_code + (A.q + 3) / 4;
-	constexpr uint32_t plane_words = 2048, n_slots = 1u << kCsOrderLog2Slots;
-	uint32_t *t_keys = plane + plane_words;
+	constexpr uint32_t plane_words = 2048;
+	const int log2_slots = GLOBAL ? (int) A.ovf_log2[blockIdx.x] : kCsOrderLog2Slots;
+	const uint32_t n_slots = 1u << log2_slots;
+	uint32_t *t_keys = GLOBAL ? A.gtable_keys + A.ovf_table_off[blockIdx.x] : plane + plane_words;
 	uint32_t *t_votes = t_keys + n_slots;   // final votes: forward | reverse << 16
 	uint32_t *t_run = t_votes + n_slots;    // votes so far during the replay
 	uint32_t *t_rank = t_run + n_slots;
 	uint32_t *t_cand = t_rank + n_slots;    // 1: the bin is one of the read's candidates (tracked even with a single vote)
-	uint32_t *ev_at = t_cand + n_slots;     // [kCsOrderMaxHits]: slot | strand << 31 of the hit at that time, or empty (reads with more hits: global memory)
+	uint32_t *ev_at = GLOBAL ? t_cand + n_slots : t_cand + n_slots;     // [order_max_hits]: slot | strand << 31 of the hit at that time, or empty (LDS; reads with more hits: global memory)
 	for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
 	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; t_cand[s] = 0; }
 	if (tid == 0) s_keys = 0;
-	uint32_t *seg_pref = ev_at + A.order_max_hits;
+	uint32_t *seg_pref = GLOBAL ? plane + plane_words : ev_at + A.order_max_hits;
+	uint32_t *l_time = seg_pref + A.lists_cap + 1 + (A.bs ? (size_t) A.q + 1 + A.lists_cap / 4 + 1 : 0);   // GLOBAL: [lists_cap] time of every list's first hit
 	const bool diag = A.phase_cycles && (blockIdx.x & 63) == 0;
 	unsigned long long ck[6] = {0, 0, 0, 0, 0, 0};
 	if (diag) ck[0] = wall_clock64();  // [lists_cap + 1]: work items (8-hit list segments) in front of each list
 	const uint32_t cb = A.cand_base[read], cn = A.cand_count[read];
-	auto give_up = [&]() { for (uint32_t c = tid; c < cn; c += NT) cand_rank[cb + c] = kCsOrderUnknown; };
+	auto give_up = [&](uint32_t why, uint32_t hits, uint32_t keys) {
+		for (uint32_t c = tid; c < cn; c += NT) cand_rank[cb + c] = kCsOrderUnknown;
+		if (tid == 0 && A.order_info) { A.order_info[2 * blockIdx.x] = hits; A.order_info[2 * blockIdx.x + 1] = why | (keys << 8); }
+	};
 	CsRead R;
 	const uint16_t *l_vpos = nullptr;   // bisulfite mapping: the read position of the k-mer behind list pair j
 	if (A.bs) {
@@ -1213,7 +1227,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 		uint32_t *l_vbase = seg_pref + A.lists_cap + 1;
 		uint16_t *vp = (uint16_t *) (l_vbase + A.q + 1);
 		const CsBsRead B = cs_bs_scan(A, read, lane, l_code, l_vbase);
-		if (2u * B.V > (uint32_t) A.lists_cap) { give_up(); return; }   // (block-uniform)
+		if (2u * B.V > (uint32_t) A.lists_cap) { give_up(1u, 0u, 0u); return; }   // (block-uniform)
 		uint32_t segs = 0;
 		const uint32_t Hb = cs_bs_chunk<true>(A, B, lane, l_code, l_vbase, 0u, B.V, 0u, l_start, l_pref, vp, &segs);
 		R.L = B.L; R.n_lists = (int) (2u * B.V); R.H = Hb; R.n_valid = B.n_valid; R.n_items = segs;
@@ -1224,12 +1238,22 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	const int L = R.L;
 	if (diag) ck[1] = wall_clock64();
 	// very repetitive reads: the time line moves to global memory; the 16-bit list offsets of l_pref bound that at 65 535 hits
-	const bool big = H > A.order_max_hits;
+	const bool big = !GLOBAL && H > A.order_max_hits;
 	if (big) {
-		if (!A.order_scratch || H > A.order_gcap || H >= 65536u) { give_up(); return; }
+		if (!A.order_scratch || H > A.order_gcap || H >= 65536u) { give_up(2u, H, 0u); return; }
 		ev_at = A.order_scratch + (size_t) blockIdx.x * A.order_gcap;
 	}
 	__syncthreads();
+	if (GLOBAL && wv == 1) {
+		uint32_t carry = 0;
+		for (int base = 0; base < R.n_lists; base += 64) {
+			const int li = base + lane;
+			const uint32_t cnt = li < R.n_lists ? (l_pref[li] & 0xFFFFu) : 0u;
+			const uint32_t incl = wave_inclusive_scan(cnt, lane);
+			if (li < R.n_lists) l_time[li] = carry + incl - cnt;
+			carry += wave_last(incl);
+		}
+	}
 	if (wv == 0) {
 		uint32_t carry = 0;
 		for (int base = 0; base < R.n_lists; base += 64) {
@@ -1247,7 +1271,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 		const uint32_t centre0 = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
 		for (uint32_t c = tid; c < cn; c += NT) {
 			const uint32_t bin = ((cand_loc[cb + c] - centre0) >> A.bin_shift) & 0x3FFFFFFFu;
-			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+			uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
 			for (uint32_t probes = 0; probes < n_slots; ++probes) {
 				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
 				if (prev == bin) { t_cand[slot] = 1u; break; }
@@ -1273,8 +1297,8 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 			// (a read whose repeated bins outgrow the table is given up below: stop inserting as soon as that is certain -- with
 			// the table nearly full every further hit would walk hundreds of slots, and one such read per launch of 4 096 kept
 			// the launch alive for 25 ms: 1.7 s instead of 0.1 s for config 5's 256 k tied reads)
-			if (*(volatile uint32_t *) &s_keys > (n_slots * 3u) / 4u) return;
-			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+			if (!GLOBAL && *(volatile uint32_t *) &s_keys > (n_slots * 3u) / 4u) return;
+			uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
 			for (uint32_t probes = 0; probes < n_slots; ++probes) {
 				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
 				if (prev == bin) break;
@@ -1305,7 +1329,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 			const uint32_t item_n = fetch(idx + NT, nxt);
 			const uint32_t li = item >> 16, sg = item & 0xFFFFu;
 			const uint32_t meta = l_pref[li];
-			const uint32_t cnt = min((uint32_t) kCsSeg, (meta & 0xFFFFu) - sg * kCsSeg), t0 = (meta >> 16) + sg * kCsSeg;
+			const uint32_t cnt = min((uint32_t) kCsSeg, (meta & 0xFFFFu) - sg * kCsSeg), t0 = (GLOBAL ? l_time[li] : (meta >> 16)) + sg * kCsSeg;
 			const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
 #pragma unroll
 			for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cnt) vote(pos8[j], (int) li, t0 + (uint32_t) j);
@@ -1314,13 +1338,14 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	}
 	__syncthreads();
 	if (diag) ck[2] = wall_clock64();
-	if (s_keys > (n_slots * 3u) / 4u) { give_up(); if (diag && tid == 0) atomicAdd(&A.phase_cycles[13], 1ull); return; }
+	if (GLOBAL) __threadfence();
+	if (!GLOBAL && s_keys > (n_slots * 3u) / 4u) { give_up(3u, H, s_keys); if (diag && tid == 0) atomicAdd(&A.phase_cycles[13], 1ull); return; }
 	// sweep B (LDS only): exact votes of the tracked bins; their time line entries become slot | strand << 31, all others
 	// empty.  The plane is rebuilt as a bit set of the tracked keys first, so that the ~90 % untracked hits cost one read.
 	for (uint32_t s2 = tid; s2 < plane_words; s2 += NT) plane[s2] = 0;
 	__syncthreads();
 	for (uint32_t s2 = tid; s2 < n_slots; s2 += NT) {
-		const uint32_t key = t_keys[s2];
+		const uint32_t key = og(&t_keys[s2]);
 		if (key != 0xFFFFFFFFu) { const uint32_t b = (key * 0x9E3779B1u) >> 16; atomicOr(&plane[b >> 5], 1u << (b & 31)); }
 	}
 	__syncthreads();
@@ -1330,9 +1355,9 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
 		uint32_t out = 0xFFFFFFFFu;
 		if ((plane[b >> 5] >> (b & 31)) & 1u) {
-			uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+			uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
 			for (;;) {
-				const uint32_t key = t_keys[slot];
+				const uint32_t key = og(&t_keys[slot]);
 				if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); out = slot | (e & 0x80000000u); break; }
 				if (key == 0xFFFFFFFFu) break;
 				slot = (slot + 1) & (n_slots - 1);
@@ -1352,7 +1377,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 		const uint32_t t = t0 + (uint32_t) lane;
 		uint32_t e = (t < H) ? ev_at[t] : 0xFFFFFFFFu;
 		if (e != 0xFFFFFFFFu) {
-			const uint32_t v = t_votes[e & 0x7FFFFFFFu];
+			const uint32_t v = og(&t_votes[e & 0x7FFFFFFFu]);
 			if ((v & 0xFFFFu) + (v >> 16) < 2u && !t_cand[e & 0x7FFFFFFFu]) e = 0xFFFFFFFFu;
 		}
 		const unsigned long long keep = __ballot(e != 0xFFFFFFFFu);
@@ -1365,6 +1390,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	// rList at its first hit with score >= maximum * sensitivity (CS.cpp:205-208); the ranks follow the lane order.
 	uint32_t max_votes = H > 0 ? 1u : 0u, next_rank = 0;
 	for (uint32_t c0 = 0; c0 < E; c0 += 64) {
+		if (GLOBAL) __threadfence();   // the trip before wrote t_run / t_rank in global memory
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // one wave: LDS operations complete in program order
 		const bool act = c0 + (uint32_t) lane < E;
 		const uint32_t e = act ? ev_at[c0 + (uint32_t) lane] : 0u;
@@ -1372,7 +1398,8 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 		const bool rev = (e >> 31) != 0u;
 		unsigned long long same_bin = __ballot(act);  // lanes of this trip that hit the same bin
 #pragma unroll
-		for (int b = 0; b < kCsOrderLog2Slots; ++b) {
+		for (int b = 0; b < (GLOBAL ? 30 : kCsOrderLog2Slots); ++b) {
+			if (GLOBAL && b >= log2_slots) break;
 			const bool bit = (slot >> b) & 1u;
 			const unsigned long long bb = __ballot(act && bit);
 			same_bin &= bit ? bb : ~bb;
@@ -1403,16 +1430,17 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
 	for (uint32_t c = tid; c < cn; c += NT) {
 		const uint32_t bin = ((cand_loc[cb + c] - centre) >> A.bin_shift) & 0x3FFFFFFFu;
-		uint32_t slot = (bin * 2654435761u) >> (32 - kCsOrderLog2Slots);
+		uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
 		uint32_t rank = kCsOrderUnknown;
 		for (uint32_t probes = 0; probes < n_slots; ++probes) {
-			const uint32_t key = t_keys[slot];
+			const uint32_t key = og(&t_keys[slot]);
 			if (key == bin) { if (t_rank[slot] != kCsOrderUnknown) rank = 2u * t_rank[slot] + (cand_sv[cb + c] & 1u); break; }
 			if (key == 0xFFFFFFFFu) break;
 			slot = (slot + 1) & (n_slots - 1);
 		}
 		cand_rank[cb + c] = rank;
 	}
+	if (tid == 0 && A.order_info && !GLOBAL) { A.order_info[2 * blockIdx.x] = H; A.order_info[2 * blockIdx.x + 1] = s_keys << 8; }
 	if (A.phase_cycles && threadIdx.x == 0) {
 		const unsigned long long dt = wall_clock64() - t_block;
 		atomicAdd(&A.phase_cycles[13], dt << 8);  // whole-block time of every workgroup (ticks << 8 above the give-up count)

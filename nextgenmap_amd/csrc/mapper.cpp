@@ -80,10 +80,16 @@ struct ngm_mapper {
 	uint64_t scores_so_far = 0, reads_so_far = 0;  // see ngm_pair_state
 	int ref_cs_batch = 0;             // reads per CS batch of the reference (1 800 000 / average read length, CS.cpp:26, :542): its score buffer is flushed there
 	uint64_t early_se_pairs = 0, early_se_ambiguous = 0;  // ngm_mapper_early_top1se_counts
+	// ngm_mapper_path_counters: reads searched, candidates, reads re-run by the exact LDS / exact global-memory search, reads whose
+	// candidate order was replayed, of those beyond the LDS replay's limits (replayed by the exact global-memory kernel), left undetermined
+	uint64_t st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0, st_cmr_dropped = 0;
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
-	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank, d_order_scratch;
-	ngm::PinnedBuf<uint32_t> p_rank;
+	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank, d_order_scratch, d_order_info, d_order_big, d_order_gt, d_order_log2;
+	ngm::DevBuf<uint64_t> d_order_off;
+	ngm::CsArgs order_args{};                       // arguments of the replay in flight
+	ngm::PinnedBuf<uint32_t> p_rank, p_order_info;
+	std::vector<uint32_t> order_pending;            // the reads of the replay in flight (candidate_order_finish accounts for them)
 	// pinned staging for the per-batch downloads
 	ngm::PinnedBuf<uint32_t> p_winner, p_loc, p_sv;
 	ngm::PinnedBuf<int32_t> p_mapq, p_nbest, p_rec;
@@ -292,6 +298,8 @@ int run_cs(ngm_mapper *m, int n) {
 		timed(0);
 		}
 		m->cs_queued_exact = status[1];
+		const uint32_t n_exact_lds = status[1];
+		uint32_t n_exact_global = 0;
 		if (status[1] > 0) {
 			// pass 2 -- EXACT path, table in LDS, for the reads the fast path could not certify
 			const uint32_t no = status[1];
@@ -312,6 +320,7 @@ int run_cs(ngm_mapper *m, int n) {
 		if (status[1] > 0) {
 			// pass 3 -- EXACT path with per-read tables in global memory (reads with more hits than LDS holds)
 			const uint32_t no = status[1];
+			n_exact_global = no;
 			std::vector<uint32_t> hits(no), lg(no);
 			std::vector<uint64_t> off(no);
 			MAP_HIP_TRY(hipMemcpy(hits.data(), m->d_ovf_hits.p, no * 4, hipMemcpyDeviceToHost));
@@ -368,6 +377,7 @@ int run_cs(ngm_mapper *m, int n) {
 				for (int g = 0; g < ngm::kCsRegions; ++g) sum += ctr[(size_t) g * ngm::kCsCursorStride + 2];
 				if (sum != m->n_cand) { ngm::pipeline_set_error("%llu candidates in one batch of %d reads exceed the 32-bit candidate index: use smaller batches", sum, n); return -75; }
 			}
+			m->st_reads += (uint64_t) n; m->st_cands += m->n_cand; m->st_exact_lds += n_exact_lds; m->st_exact_global += n_exact_global;
 			m->cs_kmers = m->cs_hits = 0;
 			for (int g = 0; g < ngm::kCsRegions; ++g) { m->cs_kmers += ctr[(size_t) g * ngm::kCsCursorStride]; m->cs_hits += ctr[(size_t) g * ngm::kCsCursorStride + 1]; }
 			const unsigned long long *ph = ctr.data() + ctr_words;
@@ -600,7 +610,8 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	m->cs_waves = m->cs_fast_items == ngm::kCsFastItemsLong ? 4 : 3;
 	if (const char *e = getenv("NGM_HIP_CS_WAVES")) m->cs_waves = std::min(4, std::max(1, atoi(e)));
 	A.log2_slots = log2_exact;
-	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
+	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
+	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 	if (p->bs_mapping) { A.bs = 1; A.lists_cap = 2 * ngm::kCsBsChunk; A.log2_slots = std::min(A.log2_slots, 13); }
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
 	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
@@ -624,7 +635,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_sam_quals.release(); m->d_sam_meta.release(); m->d_sam_refs.release(); m->d_sam_hits.release(); m->p_sam_hits.release(); m->p_sam_refs.release(); m->p_sam_extra.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
-	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
+	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->d_order_info.release(); m->p_order_info.release(); m->d_order_big.release(); m->d_order_gt.release(); m->d_order_log2.release(); m->d_order_off.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	m->d_str.release(); m->d_cigout.release(); m->p_cigout.release(); m->p_str.release();
@@ -673,10 +684,68 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 
 // Reference order of the candidates of the listed reads (cs_order_kernel): h_rank[c] for every candidate c of those
 // reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
+static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np);
 static int candidate_order_wait(ngm_mapper *m, uint32_t **h_rank) {
 	static const bool order_on_main = getenv("NGM_HIP_ORDER_ON_MAIN_STREAM") != nullptr;
-	MAP_HIP_TRY(hipStreamSynchronize((m->st_hi && !order_on_main) ? m->st_hi : m->st));
+	if (int rc = candidate_order_finish(m, (m->st_hi && !order_on_main) ? m->st_hi : m->st, m->n_cand)) return rc;
 	*h_rank = m->p_rank.p;
+	return 0;
+}
+// After the LDS replay: wait for it, account for the reads it left to the exact kernel (more hits than its time line, more repeated
+// bins than its table: CsArgs::order_info) and replay those exactly in global memory.  No read keeps an undetermined order silently.
+static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
+	MAP_HIP_TRY(hipStreamSynchronize(ost));
+	const uint32_t nl = (uint32_t) m->order_pending.size();
+	m->st_order_reads += nl;
+	std::vector<uint32_t> big;
+	for (uint32_t i = 0; i < nl; ++i) if (m->p_order_info.p[2 * i + 1] & 0xFFu) big.push_back(i);
+	if (const char *hf = getenv("NGM_HIP_ORDER_HIST")) {   // diagnostics: hits / tracked bins / outcome of every replayed read
+		if (FILE *f = fopen(hf, "a")) { for (uint32_t i = 0; i < nl; ++i) fprintf(f, "%u %u %u\n", m->p_order_info.p[2 * i], m->p_order_info.p[2 * i + 1] & 0xFFu, m->p_order_info.p[2 * i + 1] >> 8); fclose(f); }
+	}
+	m->st_order_big += big.size();
+	if (!big.empty()) {
+		// exact replay in global memory (cs_order_kernel<true>): per read a table of 2^l >= 2 (hits + candidates) slots x 5 words and a
+		// time line of `hits` words; launches of as many reads as fit a scratch pool of 1.5 GB
+		const uint32_t nb = (uint32_t) big.size();
+		std::vector<uint32_t> reads(nb), lg(nb);
+		std::vector<uint64_t> off(nb), words(nb);
+		for (uint32_t j = 0; j < nb; ++j) {
+			const uint32_t i = big[j], rd = m->order_pending[i];
+			const uint64_t hits = m->p_order_info.p[2 * i], want = 2ull * (hits + m->h_count[rd]);
+			uint32_t l = 11;
+			while ((1ull << l) < want && l < 30) ++l;
+			reads[j] = rd; lg[j] = l;
+			words[j] = (5ull << l) + hits + 64;
+		}
+		if (m->d_order_big.reserve(nb) || m->d_order_log2.reserve(nb) || m->d_order_off.reserve(nb)) { ngm::pipeline_set_error("out of device memory (exact candidate order)"); return -12; }
+		ngm::CsArgs G = m->order_args;
+		G.order_info = nullptr; G.order_scratch = nullptr; G.order_gcap = 0; G.order_max_hits = 0; G.phase_cycles = nullptr;
+		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
+		constexpr uint64_t kPoolWords = 384ull << 20;
+		for (uint32_t j0 = 0; j0 < nb;) {
+			uint64_t total = 0;
+			uint32_t j1 = j0;
+			while (j1 < nb && (j1 == j0 || total + words[j1] <= kPoolWords)) { off[j1] = total; total += words[j1]; ++j1; }
+			if (m->d_order_gt.reserve(total)) { ngm::pipeline_set_error("out of device memory (exact candidate order, %llu words)", (unsigned long long) total); return -12; }
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_big.p + j0, reads.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, ost));
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_log2.p + j0, lg.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, ost));
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_off.p + j0, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, ost));
+			G.read_list = m->d_order_big.p + j0; G.ovf_log2 = m->d_order_log2.p + j0; G.ovf_table_off = m->d_order_off.p + j0; G.gtable_keys = m->d_order_gt.p;
+			hipLaunchKernelGGL(ngm::cs_order_kernel<true>, dim3(j1 - j0), dim3(ngm::kCsOrderThreads), lds, ost, G, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipStreamSynchronize(ost));   // (reads, lg, off of this launch are consumed; the pool is reused by the next one)
+			j0 = j1;
+		}
+		MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
+		MAP_HIP_TRY(hipStreamSynchronize(ost));
+		for (uint32_t j = 0; j < nb; ++j) {
+			const uint32_t rd = reads[j], b = m->h_base[rd], c = m->h_count[rd];
+			bool unknown = false;
+			for (uint32_t x = 0; x < c && !unknown; ++x) unknown = m->p_rank.p[b + x] == ngm::kCsOrderUnknown;
+			m->st_order_unknown += unknown ? 1 : 0;
+		}
+	}
+	m->order_pending.clear();
 	return 0;
 }
 // wait = false: only enqueue (the list must stay alive until candidate_order_wait)
@@ -685,7 +754,8 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	static const bool order_on_main = getenv("NGM_HIP_ORDER_ON_MAIN_STREAM") != nullptr;  // diagnostics
 	hipStream_t ost = (m->st_hi && !order_on_main) ? m->st_hi : m->st;  // everything this depends on has been synchronised by the caller
 	const auto t_begin = std::chrono::steady_clock::now();
-	if (m->d_order_list.reserve(nl) || m->d_cand_rank.reserve(np + 1) || m->p_rank.reserve(np + 1)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
+	if (m->d_order_list.reserve(nl) || m->d_cand_rank.reserve(np + 1) || m->p_rank.reserve(np + 1) || m->d_order_info.reserve(2 * (size_t) nl) || m->p_order_info.reserve(2 * (size_t) nl)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
+	m->order_pending = list;
 	MAP_HIP_TRY(hipMemcpyAsync(m->d_order_list.p, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ost));
 	ngm::CsArgs A = m->last_cs;
 	A.read_list = m->d_order_list.p;
@@ -711,12 +781,15 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	else { A.order_scratch = m->d_order_scratch.p; A.order_gcap = kGcap; }
 	for (uint32_t off = 0; off < nl; off += kChunk) {
 		A.read_list = m->d_order_list.p + off;
-		hipLaunchKernelGGL(ngm::cs_order_kernel, dim3(std::min(kChunk, nl - off)), dim3(ngm::kCsOrderThreads), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
+		A.order_info = m->d_order_info.p + 2 * (size_t) off;
+		hipLaunchKernelGGL(ngm::cs_order_kernel<false>, dim3(std::min(kChunk, nl - off)), dim3(ngm::kCsOrderThreads), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
 		MAP_HIP_TRY(hipGetLastError());
 	}
 	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
+	MAP_HIP_TRY(hipMemcpyAsync(m->p_order_info.p, m->d_order_info.p, 2 * (size_t) nl * 4, hipMemcpyDeviceToHost, ost));
+	m->order_args = A;
 	if (!wait) return 0;
-	MAP_HIP_TRY(hipStreamSynchronize(ost));
+	if (int rc = candidate_order_finish(m, ost, np)) return rc;
 	*h_rank = m->p_rank.p;
 	if (A.phase_cycles) {
 		unsigned long long ph[12];
@@ -1665,6 +1738,13 @@ int ngm_mapper_set_reference_cs_batch(ngm_mapper *m, int reads) {
 int ngm_mapper_early_top1se_counts(ngm_mapper *m, uint64_t out[2]) {
 	if (!m || !out) return -22;
 	out[0] = m->early_se_pairs; out[1] = m->early_se_ambiguous;
+	return 0;
+}
+
+int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]) {
+	if (!m || !out) return -22;
+	out[0] = m->st_reads; out[1] = m->st_cands; out[2] = m->st_exact_lds; out[3] = m->st_exact_global;
+	out[4] = m->st_order_reads; out[5] = m->st_order_big; out[6] = m->st_order_unknown; out[7] = m->st_cmr_dropped;
 	return 0;
 }
 

@@ -1,0 +1,138 @@
+"""-m gpu: parity on a GRCh38-LIKE k-mer spectrum ("what's weak" 1 / "next" 1).
+
+Every other pipeline test maps against near-Poisson genomes (uniform random + a few small repeat families); there the paths that
+handle long index lists, table / queue overflow, thousands of hits per read and hundreds of candidates serve 0.04 % of the reads.
+tests/humanlike.py builds a genome with a heavy-tailed spectrum (one SINE-like family at ~40 000 copies, LINE-like families,
+satellite arrays, microsatellites, segmental duplications, isochores) on which `max_kfreq`'s automatic rule
+(src/PrefixTable.cpp:150-194) and the "9 901 occurrences => unused" byte (:468-478) both fire, and draws half of the reads FROM the
+repeats.  `ngm-hip --affine` must equal `ngm-core --affine -t 1` in every SAM field; the index files both programs write must be
+identical; and no read may have lost its reference candidate order silently (`Candidate order replay` line of the log)."""
+import filecmp
+import os
+import re
+import subprocess
+
+import pytest
+
+import humanlike as H
+import ref_files as RF
+from test_gpu_cli import _sam
+from test_gpu_cli import _sam_pe
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "nextgenmap_amd", "ngm-hip")
+needs_ref = pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+
+GENOME_BP = int(os.environ.get("NGM_TEST_HUMANLIKE_BP", 120_000_000))
+N_SE = int(os.environ.get("NGM_TEST_HUMANLIKE_SE", 50_000))
+N_PE = int(os.environ.get("NGM_TEST_HUMANLIKE_PE", 50_000))     # pairs
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    from nextgenmap_amd import build
+    build.build()
+    d = tmp_path_factory.mktemp("humanlike")
+    G = H.make_genome(total_bp=GENOME_BP, seed=7)
+    fa = str(d / "ref.fa")
+    H.write_fasta(fa, G)
+    refdir = d / "refrun"
+    refdir.mkdir()
+    os.link(fa, str(refdir / "ref.fa"))
+    se = H.make_reads(G, N_SE, 150, seed=11)
+    H.write_fastq(str(d / "se.fq"), se)
+    r1, r2 = H.make_reads(G, N_PE, 150, seed=12, paired=True)
+    H.write_fastq(str(d / "pe_1.fq"), r1)
+    H.write_fastq(str(d / "pe_2.fq"), r2)
+    return dict(dir=d, fa=fa, ref_fa=str(refdir / "ref.fa"), refdir=refdir)
+
+
+def _both(world, tag, args, hip_extra=()):
+    d = world["dir"]
+    ref_sam, hip_sam = str(world["refdir"] / (tag + ".sam")), str(d / (tag + "_hip.sam"))
+    r = RF.run_ngm(["-r", world["ref_fa"], "-o", ref_sam, "--affine", "-t", "1", "--no-progress"] + args, cwd=str(world["refdir"]), timeout=3000)
+    log_ref = r.stdout + r.stderr
+    assert "Done" in log_ref, log_ref[-1500:]
+    c = subprocess.run([CLI, "-r", world["fa"], "-o", hip_sam, "--affine"] + args + list(hip_extra), capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    return ref_sam, hip_sam, log_ref, c.stderr
+
+
+def _report(tag, a, b, log_hip):
+    diff = [n for n in a if a[n] != b[n]]
+    kinds = {}
+    for n in diff:
+        kind = (n[0] if isinstance(n, tuple) else n).split("_")[-1].split("/")[0]
+        kinds[kind] = kinds.get(kind, 0) + 1
+    print("%s: %d records, %d differ %s" % (tag, len(a), len(diff), kinds))
+    for n in diff[:8]:
+        x, y = a[n], b[n]
+        print("  ", n, {k: (x[k], y[k]) for k in x if x[k] != y[k] and k != "tags"}, {k: (x["tags"].get(k), y["tags"].get(k)) for k in set(x["tags"]) | set(y["tags"]) if x["tags"].get(k) != y["tags"].get(k)})
+    for line in log_hip.splitlines():
+        if "Candidate search" in line or "Candidate order" in line or "candidates per read" in line:
+            print("  ", line)
+    return diff
+
+
+@needs_ref
+def test_index_files_identical_on_a_heavy_tailed_genome(world):
+    """first run of each program builds and saves the index: same bytes (the usage rule, max_kfreq's automatic value)"""
+    ref_sam, hip_sam, log_ref, log_hip = _both(world, "tiny", ["-q", str(world["dir"] / "se.fq")])
+    kf_ref = re.search(r"Max. k-mer frequency set so (\d+)!", log_ref)
+    kf_hip = re.search(r"max. k-mer frequency (\d+)", log_hip)
+    assert kf_ref and kf_hip and kf_ref.group(1) == kf_hip.group(1), (kf_ref, kf_hip)
+    assert int(kf_ref.group(1)) > 100, "the genome should make max_kfreq's automatic rule fire"
+    ign = re.search(r"Number of repetitive k-mers ignored: (\d+)", log_ref)
+    assert ign and int(ign.group(1)) > 0
+    for suffix in ("-enc.2.ngm", "-ht-13-2.3.ngm"):
+        assert filecmp.cmp(world["ref_fa"] + suffix, world["fa"] + suffix, shallow=False), suffix
+    # and since that run mapped the single-end reads: compare them here
+    a, b = _sam(ref_sam), _sam(hip_sam)
+    assert set(a) == set(b) and len(a) == N_SE
+    for pat in (r"Average read length: (\d+) \(min: (\d+), max: (\d+)\)", r"Corridor width: (\d+)", r"Estimated sensitivity: ([0-9.]+)"):
+        assert re.search(pat, log_ref).groups() == re.search(pat, log_hip).groups(), pat
+    diff = _report("single-end", a, b, log_hip)
+    gave_up = re.search(r"Candidate order replay: (\d+) reads, (\d+) of them beyond", log_hip)
+    assert gave_up, log_hip[-3000:]
+    unknown = re.search(r"order left undetermined for (\d+) reads", log_hip)
+    assert unknown and int(unknown.group(1)) == 0, log_hip[-3000:]
+    assert len(diff) == 0, len(diff)
+
+
+@needs_ref
+def test_paired_end_on_a_heavy_tailed_genome(world):
+    d = world["dir"]
+    ref_sam, hip_sam, log_ref, log_hip = _both(world, "pe", ["-1", str(d / "pe_1.fq"), "-2", str(d / "pe_2.fq")])
+    a, b = _sam_pe(ref_sam), _sam_pe(hip_sam)
+    assert set(a) == set(b) and len(a) == 2 * N_PE
+    diff = _report("paired-end", a, b, log_hip)
+    unknown = re.search(r"order left undetermined for (\d+) reads", log_hip)
+    assert unknown and int(unknown.group(1)) == 0, log_hip[-3000:]
+    assert len(diff) == 0, len(diff)
+
+
+def test_single_end_linear_personality_through_the_drop_in(world):
+    """the DEFAULT (linear-gap) personality on the same reads: the reference's own program with this library behind IAlignment
+    (oracle/build_dropin.sh) against ngm-hip"""
+    dropin = os.path.join(ROOT, "oracle", "_ref", "dropin", "ngm-core-hip")
+    if not os.path.exists(dropin):
+        pytest.skip("drop-in build not present (oracle/build_dropin.sh)")
+    d = world["dir"]
+    n = min(N_SE, 20_000) * 4
+    fq = str(d / "se_head.fq")
+    with open(str(d / "se.fq"), "rb") as f, open(fq, "wb") as g:
+        for i, line in enumerate(f):
+            if i >= n:
+                break
+            g.write(line)
+    ref_sam, hip_sam = str(world["refdir"] / "lin.sam"), str(d / "lin_hip.sam")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "nextgenmap_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([dropin, "-r", world["ref_fa"], "-q", fq, "-o", ref_sam, "-t", "1", "--no-progress"], capture_output=True, text=True, cwd=str(world["refdir"]), env=env, timeout=3000)
+    assert "Done" in r.stdout + r.stderr, (r.stdout + r.stderr)[-1500:]
+    c = subprocess.run([CLI, "-r", world["fa"], "-q", fq, "-o", hip_sam], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    a, b = _sam(ref_sam), _sam(hip_sam)
+    assert set(a) == set(b) and len(a) == n // 4
+    diff = _report("linear personality (drop-in)", a, b, c.stderr)
+    assert len(diff) == 0, len(diff)
