@@ -75,7 +75,7 @@ def make_genome(total_bp, seed):
     return contigs
 
 
-def make_reads(contigs, n, seed, paired=False, subs=0.01, indel_bases=0.0):
+def make_reads(contigs, n, seed, paired=False, subs=0.01, indel_bases=0.0, starts=None):
     """uniform positions, 50 % reverse strand, 1 % substitutions, one 1-3 bp indel in 15 % of the reads (0.1 % of the
     bases).  paired: rows 2i / 2i+1 are the two ends of a fragment, insert size ~ N(350, 35), FR orientation, half of
     the fragments from the reverse strand.  Returns ([n, Q] uint8 rows, truth contig, truth pos)."""
@@ -85,7 +85,7 @@ def make_reads(contigs, n, seed, paired=False, subs=0.01, indel_bases=0.0):
     pos = np.zeros(n, np.int64)
     if paired:
         nf = n // 2
-        cf = rng.choice(len(contigs), size=nf, p=lens / lens.sum())
+        cf = rng.choice(len(contigs), size=nf, p=lens / lens.sum()) if starts is None else starts[0]
         ins = np.maximum(READ_LEN + 10, rng.normal(350, 35, nf).astype(np.int64))
         ci = np.repeat(cf, 2)
         flip = rng.random(nf) < 0.5
@@ -93,7 +93,7 @@ def make_reads(contigs, n, seed, paired=False, subs=0.01, indel_bases=0.0):
             sel = np.nonzero(cf == k)[0]
             if sel.size == 0:
                 continue
-            p = rng.integers(0, len(contigs[k]) - 600, sel.size)
+            p = rng.integers(0, len(contigs[k]) - 600, sel.size) if starts is None else np.minimum(starts[1][sel], len(contigs[k]) - 600)
             left = contigs[k][p[:, None] + np.arange(READ_LEN)[None, :]]
             pr = p + ins[sel] - READ_LEN
             right = COMP[contigs[k][pr[:, None] + np.arange(READ_LEN)[None, :]][:, ::-1]]
@@ -103,12 +103,12 @@ def make_reads(contigs, n, seed, paired=False, subs=0.01, indel_bases=0.0):
             pos[2 * sel] = np.where(f, pr, p)
             pos[2 * sel + 1] = np.where(f, p, pr)
     else:
-        ci = rng.choice(len(contigs), size=n, p=lens / lens.sum())
+        ci = rng.choice(len(contigs), size=n, p=lens / lens.sum()) if starts is None else starts[0]
         for k in range(len(contigs)):
             sel = np.nonzero(ci == k)[0]
             if sel.size == 0:
                 continue
-            p = rng.integers(0, len(contigs[k]) - READ_LEN - 8, sel.size)
+            p = rng.integers(0, len(contigs[k]) - READ_LEN - 8, sel.size) if starts is None else np.minimum(starts[1][sel], len(contigs[k]) - READ_LEN - 8)
             pos[sel] = p
             rows[sel, :READ_LEN] = contigs[k][p[:, None] + np.arange(READ_LEN)[None, :]]
     sub = rng.random((n, READ_LEN)) < subs
@@ -351,6 +351,79 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
     return out, base
 
 
+def heavy_tail_leg(args, dev, local_rank, paired, affine, sens):
+    """The same resident mapping path on a genome with a GRCh38-LIKE k-mer spectrum (tests/humanlike.py: one SINE-like family at ~10^5
+    copies per 300 Mbp, LINE-like families, satellite arrays, microsatellites, segmental duplications, isochores), half of the reads
+    drawn FROM the repeats: reads/s, candidates per read and the share of the reads on every fall-back path.  Not the headline: the
+    uniform genome above is the best case (1.2 candidates per read), this is what repeats cost."""
+    import threading
+    import torch
+    import humanlike as HL
+    from nextgenmap_amd.pipeline import HIT_DTYPE, Mapper, Reference
+    t0 = time.perf_counter()
+    G = HL.make_genome(total_bp=int(args.heavy_tail_mbp * 1e6), n_contigs=24, seed=20260929)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = Reference.from_contigs(G.contigs, device=local_rank, kmer=KMER, kmer_skip=2, bin_size=2)
+    t_index = time.perf_counter() - t0
+    R = args.reads_per_step
+    starts = HL.sample_starts(G, R // 2 if paired else R, 400 if paired else READ_LEN, seed=20260930, repeat_share=args.heavy_tail_repeat_share)
+    rows, truth_c, truth_p = make_reads(G.contigs, R, seed=20260931, paired=paired, subs=args.subs, indel_bases=args.indel_bases, starts=starts)
+    d_rows = torch.from_numpy(rows).to(dev)
+    W = max(1, min(args.workers, R // 2048))
+    bounds = [(R * w // W) & ~1 for w in range(W)] + [R]
+    out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
+    kw = dict(gap_read=33, gap_ref=33, gap_extend=3, personality=1) if affine else {}
+    mps = [Mapper(ref, Q, C, sensitivity=sens, **kw) for _ in range(W)]
+    kms = [np.zeros(8) for _ in range(W)]
+
+    def worker(w, steps):
+        lo, hi = bounds[w], bounds[w + 1]
+        for _ in range(steps):
+            (mps[w].map_pe_raw if paired else mps[w].map_se_raw)(rows[lo:hi], d_rows[lo:hi], tuple(o[lo:hi] for o in out))
+            kms[w] += np.array(mps[w].last_kernel_ms())
+
+    def run(steps):
+        ts = [threading.Thread(target=worker, args=(w, steps)) for w in range(W)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    run(1)
+    for k in kms:
+        k[:] = 0
+    before = [m_.path_counters() for m_ in mps]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.heavy_tail_steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    pc = {k: sum(m_.path_counters()[k] - b[k] for m_, b in zip(mps, before)) for k in before[0]}
+    ctr = np.sum([m_.cs_counters() for m_ in mps], axis=0)
+    km = np.sum(kms, axis=0) / args.heavy_tail_steps
+    hits = out[0]
+    mapped = hits["mapped"] == 1
+    correct = mapped & (hits["contig"] == truth_c) & (np.abs(hits["pos"].astype(np.int64) - truth_p) <= C // 2 + 4)
+    nr = max(1, pc["reads"])
+    res = {"value": R * args.heavy_tail_steps / elapsed, "unit": "reads/s", "steps": args.heavy_tail_steps, "ms_per_step": elapsed / args.heavy_tail_steps * 1e3,
+           "genome": "tests/humanlike.py make_genome(%d Mbp, 24 contigs, seed 20260929): %d repeat instances; automatic max. k-mer frequency %d (uniform genome: 100)"
+                     % (args.heavy_tail_mbp, len(G.repeats), ref.auto_max_kfreq),
+           "reads": "%d x %d bp %s per step, %.0f %% of the fragments start inside a repeat instance (kinds equally likely)" % (R, READ_LEN, "PE" if paired else "SE", 100 * args.heavy_tail_repeat_share),
+           "per_read": {"candidates": float(ctr[2]) / R, "index_hits": float(ctr[1]) / R, "kmers": float(ctr[0]) / R},
+           "share_of_reads": {"heavy_read_kernel": pc["heavy"] / nr, "exact_search_lds_table": pc["exact_lds"] / nr, "exact_search_global_table": pc["exact_global"] / nr,
+                              "candidate_order_replayed": pc["order_replayed"] / nr, "candidate_order_exact_global_replay": pc["order_exact_global"] / nr,
+                              "candidate_order_undetermined": pc["order_undetermined"] / nr},
+           "kernel_ms": {"candidate_search": km[0], "gather_score": km[1], "sw_score": km[2], "select": km[3], "gather_align": km[4], "sw_align": km[5], "traceback": km[6],
+                         "all_kernels": float(km[:7].sum()), "candidate_search_stage_incl_host_sync": km[7]},
+           "accuracy": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
+           "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries}}
+    for m_ in mps:
+        m_.close()
+    ref.close()
+    return res
+
+
 def cpu_baseline_port(rows_qry, budget_s=8.0):
     import oracle_lib as O
     cores = os.cpu_count() or 1
@@ -392,6 +465,9 @@ def main():
     ap.add_argument("--e2e-gz-reads", type=int, default=2_000_000, help="reads of the .fastq.gz-input and --bam-output runs of ngm-hip (0: skip)")
     ap.add_argument("--cpu-t1-reads", type=int, default=200_000, help="reads of the reference's -t 1 run (SAM cross-check)")
     ap.add_argument("--stub-mapper", action="store_true", help="CPU-only control-path run (tests)")
+    ap.add_argument("--heavy-tail-mbp", type=float, default=1000.0, help="size of the GRCh38-like (heavy-tailed k-mer spectrum) genome of the second leg; 0: skip")
+    ap.add_argument("--heavy-tail-steps", type=int, default=5)
+    ap.add_argument("--heavy-tail-repeat-share", type=float, default=0.5)
     args = ap.parse_args()
     global Q, C, READ_LEN
     READ_LEN = args.read_len
@@ -659,11 +735,18 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_port(rows[:8192])
                 line["cpu_baseline"]["note"] = ("reference program not run: " + ("ngm-core only runs --affine on this host" if not affine else
                                                 "oracle/_ref/ngm/ngm-core not built or --no-end-to-end given"))
-        print(json.dumps(line))
     for m_ in mps:
         m_.close()
     if ref is not None:
         ref.close()
+    if rank == 0:
+        if world == 1 and not stub and args.heavy_tail_mbp > 0 and READ_LEN == 150:
+            del contigs, rows, d_rows
+            try:
+                line["heavy_tailed_genome"] = heavy_tail_leg(args, dev, local_rank, paired, affine, sens)
+            except Exception as e:
+                line["heavy_tailed_genome"] = {"error": str(e)[:400]}
+        print(json.dumps(line))
     barrier()
     if rank == 0:
         import shutil

@@ -236,7 +236,7 @@ int ngm_mapper_set_reference_cs_batch(ngm_mapper *m, int reads);
 /* which paths the reads took, summed over all batches of this mapper: [0] reads searched, [1] candidates, [2] reads re-run by the exact
  * search with its table in LDS, [3] ... in global memory, [4] reads whose candidate order (rList, src/CS.cpp:196-211) was replayed because
  * it decides a tie, [5] of those beyond the limits of the LDS replay (replayed exactly in global memory), [6] reads whose order was
- * left undetermined (ties then resolve by position; 0 unless NGM_HIP_POSITION_ORDER is set), [7] reserved */
+ * left undetermined (ties then resolve by position), [7] reads searched by the heavy-read kernel (more index hits than the fast path takes) */
 int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]);
 
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted

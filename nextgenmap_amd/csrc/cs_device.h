@@ -1338,7 +1338,9 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	}
 	__syncthreads();
 	if (diag) ck[2] = wall_clock64();
-	if (GLOBAL) __threadfence();
+	// (GLOBAL: every access to the read's slice comes from this workgroup -- one CU, one L1 -- so workgroup scope is enough; an
+	// agent-scope fence writes this XCD's L2 back, and one per replay trip made the kernel 50 x slower)
+	if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	if (!GLOBAL && s_keys > (n_slots * 3u) / 4u) { give_up(3u, H, s_keys); if (diag && tid == 0) atomicAdd(&A.phase_cycles[13], 1ull); return; }
 	// sweep B (LDS only): exact votes of the tracked bins; their time line entries become slot | strand << 31, all others
 	// empty.  The plane is rebuilt as a bit set of the tracked keys first, so that the ~90 % untracked hits cost one read.
@@ -1390,7 +1392,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	// rList at its first hit with score >= maximum * sensitivity (CS.cpp:205-208); the ranks follow the lane order.
 	uint32_t max_votes = H > 0 ? 1u : 0u, next_rank = 0;
 	for (uint32_t c0 = 0; c0 < E; c0 += 64) {
-		if (GLOBAL) __threadfence();   // the trip before wrote t_run / t_rank in global memory
+		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the trip before wrote t_run / t_rank in global memory
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // one wave: LDS operations complete in program order
 		const bool act = c0 + (uint32_t) lane < E;
 		const uint32_t e = act ? ev_at[c0 + (uint32_t) lane] : 0u;

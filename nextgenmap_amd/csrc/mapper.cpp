@@ -28,6 +28,7 @@
 #include "cigar_device.h"
 #include "cs_device.h"
 #include "cs_canon_device.h"
+#include "cs_heavy_device.h"
 #define NGM_SAM_KERNELS
 #include "sam_device.h"
 #include "gather_device.h"
@@ -82,7 +83,7 @@ struct ngm_mapper {
 	uint64_t early_se_pairs = 0, early_se_ambiguous = 0;  // ngm_mapper_early_top1se_counts
 	// ngm_mapper_path_counters: reads searched, candidates, reads re-run by the exact LDS / exact global-memory search, reads whose
 	// candidate order was replayed, of those beyond the LDS replay's limits (replayed by the exact global-memory kernel), left undetermined
-	uint64_t st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0, st_cmr_dropped = 0;
+	uint64_t st_heavy = 0, st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0;
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
 	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank, d_order_scratch, d_order_info, d_order_big, d_order_gt, d_order_log2;
@@ -100,7 +101,7 @@ struct ngm_mapper {
 	ngm::DevBuf<uint16_t> d_read_len;
 	ngm::DevBuf<uint32_t> d_cand_base, d_cand_count, d_out_loc, d_out_sv, d_status, d_ovf_read, d_ovf_read2, d_ovf_hits, d_ovf_log2;
 	ngm::DevBuf<uint64_t> d_ovf_off;
-	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes;
+	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes, d_heavy_list;
 	ngm::DevBuf<float> d_max_votes, d_max_both, d_scores, d_best;
 	ngm::DevBuf<unsigned long long> d_total, d_counters;
 	ngm::DevBuf<uint32_t> d_out_loc2, d_out_sv2, d_new_base;
@@ -297,9 +298,62 @@ int run_cs(ngm_mapper *m, int n) {
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		timed(0);
 		}
+		uint32_t n_heavy = 0;
+		static const bool heavy_on = !getenv("NGM_HIP_CS_NO_HEAVY");
+		if (!bs && heavy_on && status[1] > 0) {
+			// pass 1b -- the reads with more hits than the fast path takes (cs_heavy_device.h): sketch counters + exact table in LDS, by
+			// hit count in three classes of workgroups; pass 1c -- what those cannot certify (more near-threshold bins than their table
+			// holds) and the reads beyond 65 535 hits: the same with 32-bit counters and 8 192 slots; what is left after that is queued
+			// for the exact kernels below
+			struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; bool wide; const void *fn; };
+			static const HeavyClass classes[4] = {{16384u, 13, 11, 256, false, (const void *) ngm::cs_heavy_kernel<256>}, {32768u, 14, 12, 512, false, (const void *) ngm::cs_heavy_kernel<512>},
+					{ngm::kCsHeavyMaxHits16, 15, 12, 1024, false, (const void *) ngm::cs_heavy_kernel<1024>}, {0xFFFFFFFFu, 14, 13, 1024, true, (const void *) ngm::cs_heavy_kernel<1024, true>}};
+			n_heavy = status[1];
+			float t_heavy[2] = {0, 0};
+			uint32_t in_round[2] = {0, 0};
+			for (int round = 0; round < 2 && status[1] > 0; ++round) {
+				const uint32_t no = status[1];
+				in_round[round] = no;
+				std::vector<uint32_t> qr(no), qh(no), lists[4];
+				MAP_HIP_TRY(hipMemcpyAsync(qr.data(), m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
+				MAP_HIP_TRY(hipMemcpyAsync(qh.data(), m->d_ovf_hits.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
+				MAP_HIP_TRY(hipStreamSynchronize(m->st));
+				for (uint32_t i = 0; i < no; ++i) lists[round == 1 ? 3 : qh[i] <= classes[0].max_hits ? 0 : qh[i] <= classes[1].max_hits ? 1 : qh[i] <= classes[2].max_hits ? 2 : 3].push_back(qr[i]);
+				if (m->d_heavy_list.reserve(no)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
+				MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
+				MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
+				uint32_t off = 0;
+				for (int c = 0; c < 4; ++c) {
+					const uint32_t cnt = (uint32_t) lists[c].size();
+					if (cnt == 0) continue;
+					MAP_HIP_TRY(hipMemcpyAsync(m->d_heavy_list.p + off, lists[c].data(), (size_t) cnt * 4, hipMemcpyHostToDevice, m->st));
+					ngm::CsArgs Hv = A;
+					Hv.read_list = m->d_heavy_list.p + off; Hv.log2_bits = classes[c].log2c; Hv.log2_slots = classes[c].log2s;
+					const size_t lds = ngm::cs_heavy_lds_bytes(Hv.lists_cap, Hv.q, Hv.log2_bits, Hv.log2_slots, classes[c].wide);
+					void *kargs[] = {(void *) &Hv};
+					MAP_HIP_TRY(hipLaunchKernel(classes[c].fn, dim3(cnt), dim3(classes[c].nt), kargs, lds, m->st));
+					off += cnt;
+				}
+				MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
+				MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
+				MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the lists live until here)
+				if (hipEventElapsedTime(&t_heavy[round], m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t_heavy[round];
+			}
+			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 1b (heavy reads): %.2f ms for %u reads; pass 1c (32-bit counters, 8 192 slots): %.2f ms for %u reads; %u left for the exact kernels\n",
+					t_heavy[0], in_round[0], t_heavy[1], in_round[1], status[1]);
+		}
 		m->cs_queued_exact = status[1];
 		const uint32_t n_exact_lds = status[1];
 		uint32_t n_exact_global = 0;
+		auto dump_queue = [&](int pass, uint32_t cnt) {   // diagnostics (NGM_HIP_DUMP_OVF=file): index hits of the reads queued for `pass`
+			const char *fn = getenv("NGM_HIP_DUMP_OVF");
+			if (!fn || cnt == 0) return;
+			std::vector<uint32_t> hh(cnt);
+			if (hipMemcpy(hh.data(), m->d_ovf_hits.p, (size_t) cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
+			if (FILE *f = fopen(fn, "a")) { for (uint32_t x : hh) fprintf(f, "%d %u\n", pass, x); fclose(f); }
+		};
+		dump_queue(2, status[1]);
+		if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 1 (fast path): %.2f ms for %d reads, %u queued for the exact path\n", pass_ms[0], n, status[1]);
 		if (status[1] > 0) {
 			// pass 2 -- EXACT path, table in LDS, for the reads the fast path could not certify
 			const uint32_t no = status[1];
@@ -321,6 +375,8 @@ int run_cs(ngm_mapper *m, int n) {
 			// pass 3 -- EXACT path with per-read tables in global memory (reads with more hits than LDS holds)
 			const uint32_t no = status[1];
 			n_exact_global = no;
+			dump_queue(3, no);
+			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 2 (exact, LDS table): %.2f ms for %u reads, %u queued for the global-memory tables\n", pass_ms[1], n_exact_lds, no);
 			std::vector<uint32_t> hits(no), lg(no);
 			std::vector<uint64_t> off(no);
 			MAP_HIP_TRY(hipMemcpy(hits.data(), m->d_ovf_hits.p, no * 4, hipMemcpyDeviceToHost));
@@ -349,6 +405,7 @@ int run_cs(ngm_mapper *m, int n) {
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 			timed(4);
+			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 3 (exact, global-memory tables): %.2f ms for %u reads\n", pass_ms[2], no);
 		}
 		if (status[0] == 0) {
 			// regions -> one dense candidate array in read order
@@ -377,7 +434,7 @@ int run_cs(ngm_mapper *m, int n) {
 				for (int g = 0; g < ngm::kCsRegions; ++g) sum += ctr[(size_t) g * ngm::kCsCursorStride + 2];
 				if (sum != m->n_cand) { ngm::pipeline_set_error("%llu candidates in one batch of %d reads exceed the 32-bit candidate index: use smaller batches", sum, n); return -75; }
 			}
-			m->st_reads += (uint64_t) n; m->st_cands += m->n_cand; m->st_exact_lds += n_exact_lds; m->st_exact_global += n_exact_global;
+			m->st_heavy += n_heavy; m->st_reads += (uint64_t) n; m->st_cands += m->n_cand; m->st_exact_lds += n_exact_lds; m->st_exact_global += n_exact_global;
 			m->cs_kmers = m->cs_hits = 0;
 			for (int g = 0; g < ngm::kCsRegions; ++g) { m->cs_kmers += ctr[(size_t) g * ngm::kCsCursorStride]; m->cs_hits += ctr[(size_t) g * ngm::kCsCursorStride + 1]; }
 			const unsigned long long *ph = ctr.data() + ctr_words;
@@ -610,6 +667,10 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	m->cs_waves = m->cs_fast_items == ngm::kCsFastItemsLong ? 4 : 3;
 	if (const char *e = getenv("NGM_HIP_CS_WAVES")) m->cs_waves = std::min(4, std::max(1, atoi(e)));
 	A.log2_slots = log2_exact;
+	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 	if (p->bs_mapping) { A.bs = 1; A.lists_cap = 2 * ngm::kCsBsChunk; A.log2_slots = std::min(A.log2_slots, 13); }
@@ -627,7 +688,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	if (m->st_hi) { (void) hipStreamSynchronize(m->st_hi); (void) hipStreamDestroy(m->st_hi); }
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
 	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_read2.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
-	m->d_gt_votes.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
+	m->d_gt_votes.release(); m->d_heavy_list.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	m->d_pair_info.release(); m->p_pair_info.release(); m->d_sam_contig_start.release();
@@ -935,8 +996,32 @@ static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_coun
 	float combo_s[64];  // pair score, insert size and candidates of every pair inside the insert-size window
 	int combo_d[64], combo_a[64], combo_b[64];
 	const int avg = (int) (dist_sum / std::max(1L, dist_count));
+	// Mates with hundreds of candidates each (repeat families of a GRCh38-like genome): CheckPairs walks all na x nb combinations,
+	// but only those inside the insert-size window do anything -- B's candidates sorted by position, per candidate of A the ones
+	// within max_d, visited in increasing j like the reference's inner loop: the same sequence of in-window pairs, so every
+	// order-dependent outcome (first best, the equal counter, the recorded combinations) is unchanged.
+	const bool windowed = na * nb > 1024 && max_d < (1 << 28);
+	std::vector<std::pair<uint32_t, uint32_t>> b_by_loc;
+	std::vector<uint32_t> js;
+	if (windowed) {
+		b_by_loc.resize(nb);
+		for (size_t j = 0; j < nb; ++j) b_by_loc[j] = {loc[B[j]], (uint32_t) j};
+		std::sort(b_by_loc.begin(), b_by_loc.end());
+	}
 	for (size_t i = 0; i < na; ++i) {
-		for (size_t j = 0; j < nb; ++j) {
+		size_t n_inner = nb;
+		if (windowed) {
+			const uint64_t l1w = loc[A[i]];
+			const uint32_t lo_loc = l1w > (uint64_t) max_d ? (uint32_t) (l1w - (uint64_t) max_d) : 0u;
+			const uint64_t hi64 = l1w + (uint64_t) max_d;
+			const uint32_t hi_loc = hi64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) hi64;
+			js.clear();
+			for (auto it = std::lower_bound(b_by_loc.begin(), b_by_loc.end(), std::make_pair(lo_loc, 0u)); it != b_by_loc.end() && it->first <= hi_loc; ++it) js.push_back(it->second);
+			std::sort(js.begin(), js.end());
+			n_inner = js.size();
+		}
+		for (size_t jj = 0; jj < n_inner; ++jj) {
+			const size_t j = windowed ? js[jj] : jj;
 			const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
 			const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
 			bool take = false;
@@ -1312,10 +1397,22 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					for (size_t x = 0; x < tied.size(); ++x) if (tied[x].open) open_ix.push_back((int) x);
 					std::vector<Outcome> settled(open_ix.size());
 					std::vector<char> is_settled(open_ix.size(), 0);
+					// (pairs whose bounds are wide -- many open pairs in front of them, each contributing a range -- are evaluated here, in
+					// parallel, at the three values the mean is most likely to have when their turn comes: the mean of thousands of insert
+					// sizes hardly moves inside a batch.  Pass 4 looks the outcome up and only evaluates on the spot when the exact mean is
+					// another one: with hundreds of candidates per mate an evaluation costs ~0.1 ms, and there are thousands of such pairs
+					// per batch on a repeat-rich genome)
+					const long spec_avg = m->pair_dist_sum / std::max(1L, m->pair_dist_count);
+					std::vector<Outcome> spec(open_ix.size() * 3);
+					std::vector<char> has_spec(open_ix.size(), 0);
 					if (!pe_strata) parallel_for((int) open_ix.size(), [&](int lo, int hi) {
 						for (int x = lo; x < hi; ++x) {
 							Tied &t = tied[open_ix[x]];
-							if (t.avg_hi - t.avg_lo > 3) continue;
+							if (t.avg_hi - t.avg_lo > 3) {
+								for (int g = 0; g < 3; ++g) spec[(size_t) x * 3 + g] = outcome_at(t.pi, spec_avg - 1 + g, 1);
+								has_spec[x] = 1;
+								continue;
+							}
 							const Outcome o = outcome_at(t.pi, t.avg_lo, 1);
 							bool same = true;
 							for (long a = t.avg_lo + 1; a <= t.avg_hi && same; ++a) {
@@ -1324,14 +1421,16 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 							}
 							if (same) { settled[x] = o; is_settled[x] = 1; }
 						}
-					}, 128);
+					}, 16);
 					// Pass 4 (sequential): the running mean in input order; the open pairs see exactly the reference's value
 					size_t no = 0;
 					for (const Tied &t : tied) {
 						const int pi = t.pi;
 						m->pair_dist_sum += t.gap_sum; m->pair_dist_count += t.gap_cnt;
 						if (!t.open) { if (t.dist) { m->pair_dist_sum += t.dist; m->pair_dist_count += 1; } continue; }  // closed by pass 2
-						const Outcome o = is_settled[no] ? settled[no] : outcome_at(pi, m->pair_dist_sum, m->pair_dist_count);
+						const long avg_now = m->pair_dist_sum / std::max(1L, m->pair_dist_count);
+						const Outcome o = is_settled[no] ? settled[no] : (has_spec[no] && avg_now >= spec_avg - 1 && avg_now <= spec_avg + 1) ? spec[no * 3 + (size_t) (avg_now - spec_avg + 1)] :
+								outcome_at(pi, m->pair_dist_sum, m->pair_dist_count);
 						++no;
 						const int rb = 2 * pi, ra = 2 * pi + 1;
 						const bool found = o.found;
@@ -1744,7 +1843,7 @@ int ngm_mapper_early_top1se_counts(ngm_mapper *m, uint64_t out[2]) {
 int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]) {
 	if (!m || !out) return -22;
 	out[0] = m->st_reads; out[1] = m->st_cands; out[2] = m->st_exact_lds; out[3] = m->st_exact_global;
-	out[4] = m->st_order_reads; out[5] = m->st_order_big; out[6] = m->st_order_unknown; out[7] = m->st_cmr_dropped;
+	out[4] = m->st_order_reads; out[5] = m->st_order_big; out[6] = m->st_order_unknown; out[7] = m->st_heavy;
 	return 0;
 }
 

@@ -1535,8 +1535,8 @@ int main(int argc, char **argv) {
 		uint64_t pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 		for (Worker &w : workers) { uint64_t c8[8]; if (ngm_mapper_path_counters(w.m, c8) == 0) for (int x = 0; x < 8; ++x) pc[x] += c8[x]; }
 		const double nr = (double) std::max<uint64_t>(1, pc[0]);
-		snprintf(msg, sizeof(msg), "Candidate search: %llu reads, %.2f candidates per read; exact search with the table in LDS for %llu reads (%.3f %%), in global memory for %llu (%.3f %%)",
-				(unsigned long long) pc[0], pc[1] / nr, (unsigned long long) pc[2], 100.0 * pc[2] / nr, (unsigned long long) pc[3], 100.0 * pc[3] / nr);
+		snprintf(msg, sizeof(msg), "Candidate search: %llu reads, %.2f candidates per read; heavy-read kernel for %llu reads (%.3f %%), exact search with the table in LDS for %llu (%.3f %%), in global memory for %llu (%.3f %%)",
+				(unsigned long long) pc[0], pc[1] / nr, (unsigned long long) pc[7], 100.0 * pc[7] / nr, (unsigned long long) pc[2], 100.0 * pc[2] / nr, (unsigned long long) pc[3], 100.0 * pc[3] / nr);
 		info("MAIN", msg);
 		snprintf(msg, sizeof(msg), "Candidate order replay: %llu reads, %llu of them beyond the LDS replay (exact replay in global memory); order left undetermined for %llu reads",
 				(unsigned long long) pc[4], (unsigned long long) pc[5], (unsigned long long) pc[6]);

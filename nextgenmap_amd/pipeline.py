@@ -65,6 +65,7 @@ def _lib():
         lib.ngm_mapper_map_se_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_mapper_map_pe_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ngm_mapper_cs_counters.argtypes = [C.c_void_p, C.c_void_p]
+        lib.ngm_mapper_path_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         _bound = True
     return lib
@@ -263,6 +264,13 @@ class Mapper:
         ms = (C.c_float * 8)()
         self.lib.ngm_mapper_last_kernel_ms(self.h, ms)
         return list(ms)
+
+    def path_counters(self):
+        """summed over all batches: reads searched, candidates, reads re-run by the exact search (LDS table / global-memory table),
+        reads whose candidate order was replayed, of those by the exact global-memory replay, reads left with an undetermined order"""
+        out = np.zeros(8, np.uint64)
+        self.lib.ngm_mapper_path_counters(self.h, out.ctypes.data)
+        return dict(zip(("reads", "candidates", "exact_lds", "exact_global", "order_replayed", "order_exact_global", "order_undetermined", "heavy"), (int(x) for x in out[:8])))
 
     def cs_counters(self):
         """(k-mers looked up, index hits voted, candidates) of the last candidate search."""

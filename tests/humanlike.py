@@ -28,9 +28,14 @@ def revcomp(seq):
     return COMP[seq[::-1]]
 
 
+_AT = np.frombuffer(b"AT", dtype=np.uint8)
+_CG = np.frombuffer(b"CG", dtype=np.uint8)
+
+
 def _random_seq(rng, n, gc=0.5):
-    p = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
-    return ACGT[rng.choice(4, size=n, p=p)]
+    """one random byte per base: bit 0 picks inside the pair (A/T or C/G), bits 1-7 against the GC threshold"""
+    b = rng.integers(0, 256, n, dtype=np.uint8)
+    return np.where((b >> 1) < np.uint8(round(gc * 128)), _CG[b & 1], _AT[b & 1])
 
 
 def _mutate_copies(rng, cons, n, div):
@@ -271,6 +276,30 @@ def make_reads(G, n, read_len, seed=20260930, repeat_share=0.5, sub_rate=0.01, i
                 strand = "-"
             r1.append(("r%d_%d_%d_%s_%s" % (len(r1), c, p, strand, kind), s, b"I" * len(s)))
     return (r1, r2) if paired else r1
+
+
+def sample_starts(G, n, span, seed, repeat_share=0.5, kinds=None):
+    """(contig index, start) of n fragments of `span` bases, vectorised: `repeat_share` of them start inside a repeat instance (kinds
+    equally likely, instances of a kind equally likely), the others anywhere.  For bench.py's heavy-tail leg."""
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(c) for c in G.contigs], dtype=np.int64)
+    ci = rng.choice(len(G.contigs), size=n, p=lens / lens.sum())
+    pos = (rng.random(n) * (lens[ci] - span - 16)).astype(np.int64)
+    reps = [r for r in G.repeats if kinds is None or r[3] in kinds]
+    if reps and repeat_share > 0:
+        names = sorted(set(r[3] for r in reps))
+        tab = {k: np.array([(r[0], r[1], r[2]) for r in reps if r[3] == k], dtype=np.int64) for k in names}
+        from_rep = rng.random(n) < repeat_share
+        kind = rng.integers(0, len(names), n)
+        for ki, k in enumerate(names):
+            sel = np.nonzero(from_rep & (kind == ki))[0]
+            if sel.size == 0:
+                continue
+            inst = tab[k][rng.integers(0, len(tab[k]), sel.size)]
+            p = inst[:, 1] + (rng.random(sel.size) * np.maximum(1, inst[:, 2] - span // 2)).astype(np.int64) - span // 4
+            ci[sel] = inst[:, 0]
+            pos[sel] = np.clip(p, 0, lens[inst[:, 0]] - span - 16)
+    return ci, pos
 
 
 def write_fastq(path, reads):

@@ -2,7 +2,7 @@
 
 Every other pipeline test maps against near-Poisson genomes (uniform random + a few small repeat families); there the paths that
 handle long index lists, table / queue overflow, thousands of hits per read and hundreds of candidates serve 0.04 % of the reads.
-tests/humanlike.py builds a genome with a heavy-tailed spectrum (one SINE-like family at ~40 000 copies, LINE-like families,
+tests/humanlike.py builds a genome with a heavy-tailed spectrum (one SINE-like family at 100 000 copies, LINE-like families,
 satellite arrays, microsatellites, segmental duplications, isochores) on which `max_kfreq`'s automatic rule
 (src/PrefixTable.cpp:150-194) and the "9 901 occurrences => unused" byte (:468-478) both fire, and draws half of the reads FROM the
 repeats.  `ngm-hip --affine` must equal `ngm-core --affine -t 1` in every SAM field; the index files both programs write must be
@@ -27,6 +27,7 @@ needs_ref = pytest.mark.skipif(not RF.have_reference_binary(), reason="reference
 GENOME_BP = int(os.environ.get("NGM_TEST_HUMANLIKE_BP", 120_000_000))
 N_SE = int(os.environ.get("NGM_TEST_HUMANLIKE_SE", 50_000))
 N_PE = int(os.environ.get("NGM_TEST_HUMANLIKE_PE", 50_000))     # pairs
+SINE_COPIES = int(os.environ.get("NGM_TEST_HUMANLIKE_SINE", 100_000))   # one ~300 bp family, 25 % of the bases
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +35,7 @@ def world(tmp_path_factory):
     from nextgenmap_amd import build
     build.build()
     d = tmp_path_factory.mktemp("humanlike")
-    G = H.make_genome(total_bp=GENOME_BP, seed=7)
+    G = H.make_genome(total_bp=GENOME_BP, seed=7, sine_copies=SINE_COPIES)
     fa = str(d / "ref.fa")
     H.write_fasta(fa, G)
     refdir = d / "refrun"
