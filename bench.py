@@ -351,6 +351,54 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
     return out, base
 
 
+def sharded_end_to_end(workdir, contigs, args, paired, affine, sens, world, exe):
+    """BASELINE config #4 as the product runs it (N > 1, rank 0 only, the other ranks wait at a barrier): ONE input of --e2e-reads reads
+    through `ngm-hip -g 0,...,N-1 --shard-output` -- one process per GPU, every shard its own reference copy (from the cache files rank 0
+    wrote), its own slice of the record index, its own output file, appended in shard order -- from the first input byte to the closed,
+    concatenated SAM file.  "strong" scaling: the job is fixed, the GPUs split it."""
+    import re
+    fa = os.path.join(workdir, "bench_ref.fa")
+    n = args.e2e_reads & ~1
+    t0 = time.perf_counter()
+    rows, _, _ = make_reads(contigs, n, seed=20240602 + 3, paired=paired, subs=args.subs, indel_bases=args.indel_bases)
+    files = [os.path.join(workdir, "e2e_1.fq"), os.path.join(workdir, "e2e_2.fq")] if paired else [os.path.join(workdir, "e2e.fq")]
+    write_fastq(rows, files)
+    del rows
+    t_make = time.perf_counter() - t0
+    sam = os.path.join(workdir, "e2e_sharded.sam")
+    cmd = [exe, "-r", fa] + (["-1", files[0], "-2", files[1]] if paired else ["-q", files[0]]) + ["-o", sam, "-s", "%.6f" % sens, "--no-progress",
+           "--max-read-length", str(READ_LEN), "-g", ",".join(str(g) for g in range(world)), "--shard-output"] + (["--affine"] if affine else [])
+    if args.corridor > 0:
+        cmd += ["-C", str(args.corridor // 2)]
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    wall = time.perf_counter() - t0
+    log = r.stdout + r.stderr
+    if r.returncode != 0:
+        raise RuntimeError("sharded ngm-hip failed: " + log[-600:])
+    io = [float(x) for x in re.findall(r"Input to output: ([0-9.]+) s", log)]
+    idx = [float(x) for x in re.findall(r"Reference and index ready: ([0-9.]+) s", log)]
+    done = [(int(a), int(b), int(c)) for a, b, c in re.findall(r"Done \((\d+) reads mapped \([0-9.]+%\), (\d+) reads not mapped, (\d+) lines written\)", log)]
+    app = re.search(r"shards appended to the output in ([0-9.]+) s", log)
+    lines = 0
+    with open(sam, "rb") as f:
+        for l in f:
+            lines += l[:1] != b"@"
+    out = {"reads": n, "shards": world, "scaling": "strong", "unit": "reads/s",
+           "seconds_first_input_byte_to_concatenated_sam_closed": (max(io) if io else wall) + (float(app.group(1)) if app else 0.0),
+           "per_shard_input_to_output_s": io, "per_shard_index_load_s": idx, "append_s": float(app.group(1)) if app else None, "process_wall_s": wall,
+           "stats_summed_over_shards": {"mapped": sum(d[0] for d in done), "unmapped": sum(d[1] for d in done), "written": sum(d[2] for d in done)},
+           "sam_records": lines, "sam_bytes": os.path.getsize(sam), "make_input_s": t_make, "command": " ".join(["ngm-hip"] + cmd[1:])}
+    out["value"] = n / out["seconds_first_input_byte_to_concatenated_sam_closed"]
+    out["reads_per_s_of_process_wall"] = n / wall
+    for fn in [sam] + files:
+        try:
+            os.remove(fn)
+        except OSError:
+            pass
+    return out
+
+
 def heavy_tail_leg(args, dev, local_rank, paired, affine, sens):
     """The same resident mapping path on a genome with a GRCh38-LIKE k-mer spectrum (tests/humanlike.py: one SINE-like family at ~10^5
     copies per 300 Mbp, LINE-like families, satellite arrays, microsatellites, segmental duplications, isochores), half of the reads
@@ -465,6 +513,7 @@ def main():
     ap.add_argument("--e2e-gz-reads", type=int, default=2_000_000, help="reads of the .fastq.gz-input and --bam-output runs of ngm-hip (0: skip)")
     ap.add_argument("--cpu-t1-reads", type=int, default=200_000, help="reads of the reference's -t 1 run (SAM cross-check)")
     ap.add_argument("--stub-mapper", action="store_true", help="CPU-only control-path run (tests)")
+    ap.add_argument("--ngm-hip-exe", default=None, help="the program of the sharded end-to-end leg (default: nextgenmap_amd/ngm-hip; tests pass a stand-in)")
     ap.add_argument("--heavy-tail-mbp", type=float, default=1000.0, help="size of the GRCh38-like (heavy-tailed k-mer spectrum) genome of the second leg; 0: skip")
     ap.add_argument("--heavy-tail-steps", type=int, default=5)
     ap.add_argument("--heavy-tail-repeat-share", type=float, default=0.5)
@@ -720,6 +769,17 @@ def main():
         if world > 1 or stub:
             line["cpu_baseline"] = None  # the host baseline is timed on rank 0 of a 1-GPU run only
             line["end_to_end"] = None
+            if world > 1 and not args.no_end_to_end and (not stub or args.ngm_hip_exe):
+                # the real config 4: one 10 M-read input through the product, one process per GPU (the other ranks wait at the barrier below)
+                try:
+                    if args.ngm_hip_exe:
+                        exe = args.ngm_hip_exe
+                    else:
+                        from nextgenmap_amd import build as B_
+                        exe = B_.CLI
+                    line["end_to_end"] = sharded_end_to_end(workdir, contigs, args, paired, affine, sens, world, exe)
+                except Exception as e:
+                    line["end_to_end"] = {"error": str(e)[:400]}
         else:
             e2e_base = None
             if not args.no_end_to_end:

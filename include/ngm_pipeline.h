@@ -210,6 +210,9 @@ ngm_pair_state *ngm_pair_state_create(void);
 void ngm_pair_state_destroy(ngm_pair_state *ps);
 int ngm_mapper_set_pair_state(ngm_mapper *m, ngm_pair_state *ps);
 int ngm_mapper_set_batch_seq(ngm_mapper *m, uint64_t seq);
+/* Config "fast_pairing" (--fast-pairing, src/ScoreBuffer.cpp:203-216): paired-end batches select both mates with top1SE instead of
+ * top1PE / CheckPairs; whether the two winners form a pair is decided where the records are written (src/AlignmentBuffer.cpp:176-199) */
+int ngm_mapper_set_fast_pairing(ngm_mapper *m, int on);
 
 /* page-locked host memory for read batches (the H2D copy then runs at PCIe rate without a staging copy) */
 void *ngm_host_alloc(size_t bytes);

@@ -110,29 +110,37 @@ inline void put_record(std::string &raw, const char *name, size_t name_len, uint
 	raw += tags.data;
 }
 
-// appends `raw` as complete BGZF blocks (<= 0xFF00 input bytes each, zlib level 6 = Z_DEFAULT_COMPRESSION like bamtools)
+// appends `raw` as complete BGZF blocks (<= 0xFF00 input bytes each, zlib level 6 = Z_DEFAULT_COMPRESSION like bamtools).
+// One deflate state per thread, reset per block: deflateInit2 / deflateEnd allocate and clear ~260 KB per call, and with every pool
+// thread doing that once per 64 KB the allocator, not deflate, set the pace (24 effective threads of 128).
+struct BgzfState {
+	z_stream zs;
+	bool ok = false;
+	unsigned char buf[0x10000 + 1024];
+	BgzfState() { memset(&zs, 0, sizeof(zs)); ok = deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK; }
+	~BgzfState() { if (ok) deflateEnd(&zs); }
+};
 inline bool bgzf_compress(const char *raw, size_t n, std::string &out) {
 	const size_t kIn = 0xFF00;
-	std::vector<unsigned char> buf(0x10000 + 1024);
+	static thread_local BgzfState st;
+	if (!st.ok) return false;
 	for (size_t at = 0; at < n || (n == 0 && at == 0); at += kIn) {
 		const size_t len = n ? std::min(kIn, n - at) : 0;
-		z_stream zs;
-		memset(&zs, 0, sizeof(zs));
-		if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+		z_stream &zs = st.zs;
+		if (deflateReset(&zs) != Z_OK) return false;
 		zs.next_in = (Bytef *) (raw + at);
 		zs.avail_in = (uInt) len;
-		zs.next_out = buf.data();
-		zs.avail_out = (uInt) buf.size();
+		zs.next_out = st.buf;
+		zs.avail_out = (uInt) sizeof(st.buf);
 		const int rc = deflate(&zs, Z_FINISH);
 		const size_t clen = zs.total_out;
-		deflateEnd(&zs);
 		if (rc != Z_STREAM_END || clen + 26 > 0x10000) return false;  // (0xFF00 input bytes always fit)
 		const uint32_t crc = (uint32_t) crc32(crc32(0L, Z_NULL, 0), (const Bytef *) (raw + at), (uInt) len);
 		const uint16_t bsize = (uint16_t) (clen + 25);
 		static const unsigned char head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
 		out.append((const char *) head, 16);
 		out.append((const char *) &bsize, 2);
-		out.append((const char *) buf.data(), clen);
+		out.append((const char *) st.buf, clen);
 		out.append((const char *) &crc, 4);
 		const uint32_t isize = (uint32_t) len;
 		out.append((const char *) &isize, 4);

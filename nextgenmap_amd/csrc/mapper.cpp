@@ -59,6 +59,7 @@ struct ngm_mapper {
 	const ngm_ref *ref = nullptr;
 	ngm_pair_state *ps = nullptr;      // shared paired-end state (null: the mapper's own)
 	uint64_t batch_seq = 0;            // ... and the input-order number of the next paired-end batch
+	int fast_pairing = 0;              // Config "fast_pairing": top1SE for both mates instead of top1PE (src/ScoreBuffer.cpp:203-216)
 	ngm_mapper_params prm{};
 	ngm_hip_ctx *eng = nullptr;
 	hipStream_t st = nullptr;
@@ -1161,7 +1162,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				m->d_scores.p, m->d_out_loc.p, m->d_out_sv.p, m->d_winner.p, m->d_mapq.p, m->d_nbest.p, m->d_best.p);
 		MAP_HIP_TRY(hipGetLastError());
 		static const bool pair_gpu = !getenv("NGM_HIP_HOST_PAIR_PASS1");
-		const bool simple_on_gpu = paired && pair_gpu && m->prm.strata == 0;   // (--strata touches NH of every pair: host)
+		const bool pe_select = paired && !m->fast_pairing;   // --fast-pairing: the mates are selected single-end, the writer checks the pair (AlignmentBuffer.cpp:176-199)
+		const bool simple_on_gpu = pe_select && pair_gpu && m->prm.strata == 0;   // (--strata touches NH of every pair: host)
 		if (simple_on_gpu) {
 			// pairs whose mates have one candidate each (most): settled here, the host only sums their insert sizes
 			if (m->d_pair_info.reserve(n / 2 + 1) || m->p_pair_info.reserve(n / 2 + 1)) { ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
@@ -1182,7 +1184,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		stage_cs.done();
 		lap(1);
 		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
-		if (!paired && m->prm.topn <= 1 && !position_order) {
+		if ((!paired || m->fast_pairing) && m->prm.topn <= 1 && !position_order) {
 			// several candidates share the best score: the reference keeps the first one in ITS candidate order
 			// (ScoreBuffer::top1SE over CollectResultsStd's rList order); replay the votes of just those reads
 			std::vector<uint32_t> tied;
@@ -1207,7 +1209,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				}
 			}
 		}
-		if (paired) {
+		if (pe_select) {
 			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is
 			// sequential state of one CS thread in the reference; here every host thread continues from the value at
 			// the start of the batch and the increments are merged afterwards (NGM_HIP_HOST_THREADS=1: strictly sequential).
@@ -1779,6 +1781,7 @@ ngm_pair_state *ngm_pair_state_create(void) { return new ngm_pair_state(); }
 void ngm_pair_state_destroy(ngm_pair_state *ps) { delete ps; }
 int ngm_mapper_set_pair_state(ngm_mapper *m, ngm_pair_state *ps) { if (!m) return -22; m->ps = ps; return 0; }
 int ngm_mapper_set_batch_seq(ngm_mapper *m, uint64_t seq) { if (!m) return -22; m->batch_seq = seq; return 0; }
+int ngm_mapper_set_fast_pairing(ngm_mapper *m, int on) { if (!m) return -22; m->fast_pairing = on ? 1 : 0; return 0; }
 
 void *ngm_host_alloc(size_t bytes) {
 	void *p = nullptr;

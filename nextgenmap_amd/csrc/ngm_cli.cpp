@@ -119,7 +119,7 @@ struct Opts {
 	int paired = 0, min_insert = 0, max_insert = 1000, topn = 1, strata = 0;
 	char pe_delimiter = '/';
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
-	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, max_cmrs = 2147483647;
+	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, fast_pairing = 0, max_cmrs = 2147483647;
 	int skip_save = 0, bam = 0, workers = 2, serial_reader = 0;
 	int bs_mapping = 0, bs_cutoff = 6, match_tt = -1, match_tc = -1, match_set = 0, mismatch_set = 0, slam_seq = 0;
 	std::vector<int> devices;
@@ -138,7 +138,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, SHARD, SHARDOUT, KEEPSHARDS, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, SHARD, SHARDOUT, KEEPSHARDS, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, FASTPAIR, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -159,7 +159,7 @@ Opts parse(int argc, char **argv) {
 		{"rg-dt", required_argument, 0, RG0 + 3}, {"rg-fo", required_argument, 0, RG0 + 4}, {"rg-ks", required_argument, 0, RG0 + 5},
 		{"rg-lb", required_argument, 0, RG0 + 6}, {"rg-pg", required_argument, 0, RG0 + 7}, {"rg-pi", required_argument, 0, RG0 + 8},
 		{"rg-pl", required_argument, 0, RG0 + 9}, {"rg-pu", required_argument, 0, RG0 + 10}, {"rg-sm", required_argument, 0, RG0 + 11},
-		{"fast-pairing", no_argument, 0, UNSUPPORTED}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
+		{"fast-pairing", no_argument, 0, FASTPAIR}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
 		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, BAMOUT}, {"workers", required_argument, 0, WORKERS}, {"serial-reader", no_argument, 0, SERIAL}, {"bs-mapping", no_argument, 0, BSMAP},
 		{"bs-cutoff", required_argument, 0, BSCUT}, {"match-bonus-tt", required_argument, 0, MBTT}, {"match-bonus-tc", required_argument, 0, MBTC},
 		{"slam-seq", required_argument, 0, SLAM}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
@@ -237,6 +237,7 @@ Opts parse(int argc, char **argv) {
 		}
 		case SHARDOUT: o.shard_output = 1; break;
 		case KEEPSHARDS: o.keep_shards = 1; break;
+		case FASTPAIR: o.fast_pairing = 1; break;
 		case UNSUPPORTED: die(std::string("option --") + lo[idx].name + " is not supported by the HIP backend yet");
 		default: die("unknown option (see src/config/Options.h of NextGenMap for the option set)");
 		}
@@ -911,6 +912,7 @@ int main(int argc, char **argv) {
 		workers[w].m = ngm_mapper_create(refs[w % refs.size()], &mp);
 		if (!workers[w].m) die(ngm_pipeline_last_error());
 		ngm_mapper_set_pair_state(workers[w].m, pair_state);
+		ngm_mapper_set_fast_pairing(workers[w].m, o.fast_pairing);
 		if (gpu_sam) {
 			ngm_sam_options so{};
 			so.paired = o.paired; so.min_insert_size = o.min_insert; so.max_insert_size = o.max_insert; so.min_mq = o.min_mq;
@@ -1149,12 +1151,21 @@ int main(int argc, char **argv) {
 	std::mutex out_mu;
 	std::condition_variable out_cv;
 	std::map<uint64_t, std::unique_ptr<Batch>> out_ready;
-	uint64_t next_write = 0;   // the batch the writer waits for (under out_mu)
+	std::atomic<uint64_t> next_write{0};   // the batch the writer waits for (written under out_mu)
 	bool workers_done = false;
 	std::atomic<bool> failed{false};
 	std::string fail_msg;
 	std::mutex fail_mu;
-	auto fail = [&](const std::string &m2) { std::lock_guard<std::mutex> lk(fail_mu); if (!failed.exchange(true)) fail_msg = m2; };
+	std::mutex text_mu;
+	std::condition_variable text_cv;
+	// (every waiter looks at `failed`: wake them all -- ADVICE r3)
+	auto fail = [&](const std::string &m2) {
+		{ std::lock_guard<std::mutex> lk(fail_mu); if (!failed.exchange(true)) fail_msg = m2; }
+		{ std::lock_guard<std::mutex> lk(out_mu); }
+		out_cv.notify_all();
+		{ std::lock_guard<std::mutex> lk(text_mu); }
+		text_cv.notify_all();
+	};
 
 	auto strip_mate = [&](const char *name, uint32_t &len) {  // ReadProvider::NextRead (ReadProvider.cpp:419-422)
 		if (len >= 2 && name[len - 2] == o.pe_delimiter) len -= 2;
@@ -1226,8 +1237,6 @@ int main(int argc, char **argv) {
 	// GPU-formatted text: page-locked buffers that travel worker -> writer -> pool.  Their number bounds the formatted text in
 	// flight (a slow output file then stalls the workers instead of piling the output up in memory)
 	struct TextBuf { char *p; size_t cap; };
-	std::mutex text_mu;
-	std::condition_variable text_cv;
 	std::vector<TextBuf> text_free;
 	const size_t text_cap0 = (size_t) batch_reads * ((size_t) 2 * q + 288) + (1u << 20);
 	if (gpu_sam) {
@@ -1355,9 +1364,18 @@ int main(int argc, char **argv) {
 				auto tm = std::chrono::steady_clock::now();
 				TextBuf tb{nullptr, 0};
 				{
+					// (buffers go out in no particular order and come back only when the writer has written batch `next_write`; the
+					// worker that holds exactly that batch must never wait for one -- it takes a fresh buffer instead -- and nobody waits
+					// once the run has failed)
 					std::unique_lock<std::mutex> lk(text_mu);
-					text_cv.wait(lk, [&] { return !text_free.empty(); });
-					tb = text_free.back(); text_free.pop_back();
+					text_cv.wait(lk, [&] { return !text_free.empty() || b->seq == next_write.load() || failed.load(); });
+					if (!text_free.empty()) { tb = text_free.back(); text_free.pop_back(); }
+				}
+				if (failed) { if (tb.p) { std::lock_guard<std::mutex> lk(text_mu); text_free.push_back(tb); } if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
+				if (!tb.p) {
+					tb.cap = text_cap0;
+					tb.p = (char *) ngm_host_alloc(tb.cap);
+					if (!tb.p) { fail(ngm_pipeline_last_error()); if (o.paired) (void) ngm_mapper_map_pe(w.m, 0, nullptr, nullptr, nullptr, nullptr); continue; }
 				}
 				uint64_t st[3] = {0, 0, 0};
 				float sam_ms = 0.f;
@@ -1429,7 +1447,7 @@ int main(int argc, char **argv) {
 			{
 				// back-pressure: formatted batches wait here while the writer is behind -- except the one it is waiting for
 				std::unique_lock<std::mutex> lk(out_mu);
-				out_cv.wait(lk, [&] { return out_ready.size() < workers.size() + 2 || b->seq == next_write || failed.load(); });
+				out_cv.wait(lk, [&] { return out_ready.size() < workers.size() + 2 || b->seq == next_write.load() || failed.load(); });
 				out_ready[b->seq] = std::move(b);
 			}
 			out_cv.notify_all();
@@ -1444,6 +1462,8 @@ int main(int argc, char **argv) {
 				std::unique_lock<std::mutex> lk(out_mu);
 				next_write = next;
 				out_cv.notify_all();
+				{ std::lock_guard<std::mutex> lk2(text_mu); }   // (a worker between its predicate and its wait holds text_mu: it sees the new value or the notify)
+				text_cv.notify_all();
 				out_cv.wait(lk, [&] { return out_ready.count(next) || workers_done; });
 				auto it = out_ready.find(next);
 				if (it == out_ready.end()) return;  // workers are done and the next batch never came (failure) or everything is written
@@ -1504,6 +1524,11 @@ int main(int argc, char **argv) {
 	snprintf(msg, sizeof(msg), "GPU kernels: %.3f s of the %.3f s mapping pass (%.0f %%; candidate search, gathers, score, select, align, traceback by HIP events)",
 			t_gpu_us / 1e6, secs, 100.0 * (t_gpu_us / 1e6) / std::max(1e-9, secs));
 	info("MAIN", msg);
+	if (!gpu_sam) {
+		snprintf(msg, sizeof(msg), "Records%s formatted on the host pool: %.3f s of thread time = %.0f %% of %d threads x %.3f s", o.bam ? " + BGZF blocks" : "", t_format_cpu_us / 1e6,
+				100.0 * (t_format_cpu_us / 1e6) / std::max(1e-9, pool.size() * secs), pool.size(), secs);
+		info("MAIN", msg);
+	}
 	if (gpu_sam) { snprintf(msg, sizeof(msg), "SAM text assembled on the GPU: %.3f s of kernels (included above)", t_sam_gpu_us / 1e6); info("MAIN", msg); }
 	snprintf(msg, sizeof(msg), "Input to output: %.3f s (estimation pass + mapping pass, first input byte to output closed)",
 			std::chrono::duration<double>(std::chrono::steady_clock::now() - t_input).count());

@@ -149,10 +149,11 @@ def _sam_pe(path):
 
 
 @pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
-@pytest.mark.parametrize("layout", ["interleaved", "two-files", "interleaved-strata"])
+@pytest.mark.parametrize("layout", ["interleaved", "two-files", "interleaved-strata", "two-files-fastpairing", "interleaved-fastpairing-strata"])
 def test_cli_paired_end_sam_equals_reference_program(tmp_path, layout):
     """Paired-end: top1PE / CheckPairs selection, the proper-pair check and SAMWriter::DoWritePair (flags, RNEXT,
-    PNEXT, TLEN, mate-unmapped records) against `ngm --affine -p` on the same interleaved FASTQ."""
+    PNEXT, TLEN, mate-unmapped records) against `ngm --affine -p` on the same interleaved FASTQ; `--fast-pairing`
+    (top1SE for both mates, src/ScoreBuffer.cpp:203-216) the same way."""
     contigs = S.make_genome([300000, 200001], seed=51, repeat_families=6, repeat_len=400, copies=5)
     fa = str(tmp_path / "ref.fa")
     with open(fa, "wb") as f:
@@ -173,6 +174,8 @@ def test_cli_paired_end_sam_equals_reference_program(tmp_path, layout):
     fa1 = str(d1 / "ref.fa")
     os.link(fa, fa1)
     strata = ["--strata"] if layout.endswith("-strata") else []  # pairs with equally good placements -> both mates unmapped
+    if "fastpairing" in layout:
+        strata = strata + ["--fast-pairing"]
     if layout.startswith("interleaved"):
         fq = str(tmp_path / "pe.fq")
         S.write_fastq(fq, [x for pair in zip(r1, r2) for x in pair])

@@ -81,3 +81,52 @@ def test_bench_control_path_two_ranks(tmp_path):
     assert st["pairs_total"] == 20000 and st["insert_cnt"] == 20000 - 40
     assert abs(j["value"] - 40000 * 2 / (j["ms_per_step"] * 2e-3)) < 1e-6 * j["value"]
     assert j["cpu_baseline"] is None and j["end_to_end"] is None
+
+
+FAKE_NGM_HIP = textwrap.dedent('''\
+    #!%s
+    """stand-in for `ngm-hip -g a,b --shard-output` (no GPU here): what bench.py's config-4 leg reads from the real program -- the
+    per-shard log lines on stderr and one SAM record per input record in the output file"""
+    import sys
+    a = sys.argv[1:]
+    out = a[a.index("-o") + 1]
+    gpus = a[a.index("-g") + 1].split(",")
+    assert "--shard-output" in a
+    files = [a[a.index(f) + 1] for f in ("-1", "-2") if f in a] or [a[a.index("-q") + 1]]
+    n = sum(sum(1 for _ in open(f)) // 4 for f in files)
+    per = n // len(gpus)
+    with open(out, "w") as f:
+        f.write("@HD\\tVN:1.0\\n")
+        for i in range(n):
+            f.write("r%%d\\t4\\t*\\t0\\t0\\t*\\t*\\t0\\t0\\tA\\tI\\n" %% i)
+    for k in range(len(gpus)):
+        sys.stderr.write("[PREPROCESS] Reference and index ready: 0.%%d00 s (cache)\\n" %% (k + 1))
+        sys.stderr.write("[MAIN] Done (%%d reads mapped (99.00%%%%), %%d reads not mapped, %%d lines written)\\n" %% (per - 1, 1, per))
+        sys.stderr.write("[MAIN] Input to output: 0.%%d50 s (estimation pass + mapping pass, first input byte to output closed)\\n" %% (k + 1))
+    sys.stderr.write("[MAIN] %%d shards appended to the output in 0.010 s\\n" %% len(gpus))
+''')
+
+
+def test_bench_config4_leg_two_ranks(tmp_path):
+    """bench.py --gpus 2: after the weak-scaling loop rank 0 runs the product once over ONE input, sharded over both 'GPUs'
+    (`ngm-hip -g 0,1 --shard-output`, here a stand-in program: no GPU), and reports it as `end_to_end` with "scaling": "strong"."""
+    import json
+    fake = tmp_path / "fake-ngm-hip"
+    fake.write_text(FAKE_NGM_HIP % sys.executable)
+    fake.chmod(0o755)
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--stub-mapper", "--genome-mbp", "2", "--reads-per-step", "4096", "--e2e-reads", "10000", "--ngm-hip-exe", str(fake)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert j["scaling"] == "weak" and j["n_gpus"] == 2
+    e = j["end_to_end"]
+    assert "error" not in e, e
+    assert e["scaling"] == "strong" and e["shards"] == 2 and e["reads"] == 10000 and e["sam_records"] == 10000
+    assert e["per_shard_input_to_output_s"] == [0.15, 0.25] and e["per_shard_index_load_s"] == [0.1, 0.2] and e["append_s"] == 0.01
+    assert abs(e["seconds_first_input_byte_to_concatenated_sam_closed"] - 0.26) < 1e-9 and abs(e["value"] - 10000 / 0.26) < 1e-6
+    assert e["stats_summed_over_shards"] == {"mapped": 2 * 4999, "unmapped": 2, "written": 10000}
+    assert "-g 0,1 --shard-output" in e["command"]
