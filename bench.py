@@ -208,13 +208,26 @@ def _sam_diff(theirs, ours, limit=4):
     return same, diffs
 
 
+def usable_cpus():
+    """CPUs this process may use at once: os.cpu_count() capped by the cgroup's CFS quota (the GPU boxes of this pool: 256 hardware
+    threads, cpu.max = 16 CPUs; more runnable threads than the quota get LESS done, profiles/r04_cpu_quota_probe.txt)"""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
     """The drop-in, measured: `ngm-hip` from the first input byte to the closed SAM file (plain FASTQ, .fastq.gz and --bam), and
     NextGenMap itself (-t cores and -t 1) on slices of the same input with the SAM records compared field by field."""
     import re
     import ref_files as RF
     from nextgenmap_amd import build as B
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     fa = os.path.join(workdir, "bench_ref.fa")
     if not os.path.exists(fa):
         with open(fa, "w") as f:
@@ -290,7 +303,7 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
             out["variants_error"] = str(e)[:300]
     base = None
     if not args.no_cpu_baseline and RF.have_reference_binary() and affine:
-        threads = min(cores, 64)
+        threads = min(os.cpu_count() or 1, 64)   # (the reference does best with more threads than the quota allows CPUs: 114 k reads/s at -t 64 against 99 k at -t 16)
 
         def slice_to(cnt_reads, tag):
             cnt = cnt_reads // len(files)
@@ -336,8 +349,9 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
             except Exception as e:
                 early = [str(e)[:200]]
         base = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
-                "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d on the first %d reads of the end-to-end input vs the same genome (index loaded "
-                          "from the same cache files): %.1f s total minus %.1f s index load/start-up measured with a 1-pair run" % (threads, ns, t_all, t_load),
+                "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d (the CPUs this container may use: %d hardware threads, cgroup quota %d) on the first %d reads of the "
+                          "end-to-end input vs the same genome (index loaded from the same cache files): %.1f s total minus %.1f s index load/start-up measured "
+                          "with a 1-pair run" % (threads, os.cpu_count() or 1, cores, ns, t_all, t_load),
                 "parity_vs_reference_sam": {"records_compared": ns, "identical_lines": same, "first_differences": diffs,
                                             "note": "whole SAM lines, differing fields listed; the reference runs %d CS threads, each with its own running mean insert "
                                                     "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads},
@@ -474,7 +488,7 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens):
 
 def cpu_baseline_port(rows_qry, budget_s=8.0):
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     rng = np.random.default_rng(0)
     wins = ACGT[rng.integers(0, 4, (len(rows_qry), Q + C), dtype=np.uint8)]
     n0 = min(len(rows_qry), max(2048, 32 * cores))

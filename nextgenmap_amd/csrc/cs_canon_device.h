@@ -39,23 +39,29 @@ constexpr int kCsCanonDraw = 4;              // reads a persistent workgroup dra
 // first line: 3 for buckets of 32 words and more); R2 rounds of 16-byte chunk items.  R1 and R2 are even: votes are cast in
 // steps of 8 slots (two rounds), the shape the queue bookkeeping of cs_fast2_kernel was tuned for.
 template <int T, int R1, int R2, int CH = 1, int WPE = 8>
-__global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ? WPE : 1))) void cs_canon_kernel(CsArgs A) {
+__global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ? WPE : 1, T == 3 ? WPE : 8))) void cs_canon_kernel(CsArgs A) {
 	static_assert(R1 % 2 == 0 && R2 % 2 == 0, "steps of two rounds");
 	constexpr int NT = T * 64;
 	constexpr int S1 = R1 / 2, S2 = R2 / 2, NS = S1 + S2;
 	constexpr uint32_t kItemCap = (uint32_t) R2 * (uint32_t) NT;
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	__shared__ uint32_t s_tot[T][3];   // per wave: chunk items, hits, k-mers looked up
-	__shared__ int s_len[T];
-	__shared__ uint32_t s_abort, s_nkeys, s_nrel;
-	__shared__ int s_next_read, s_draw_next, s_draw_left;
-	__shared__ uint32_t s_mx[T][2];
-	__shared__ uint32_t s_rel_key[kCsCanonRel], s_rel_slot[kCsCanonRel];
+	// the workgroup's few shared variables live BEHIND the dynamic arrays (no static LDS): the bit plane -- the address every vote
+	// computes -- then starts at LDS address 0, and its word address needs no base added (one VALU instruction less per slot)
+	struct Shared {
+		uint32_t tot[T][3];   // per wave: chunk items, hits, k-mers looked up
+		int len[T];
+		uint32_t abort, nkeys, nrel;
+		int next_read, draw_next, draw_left;
+		uint32_t mx[T][2];
+		uint32_t rel_key[kCsCanonRel], rel_slot[kCsCanonRel];
+	};
 	const int tid0 = threadIdx.x;
 	const int k = A.k;
 	const int kcap = A.lists_cap >> 1;                      // k-mers a read can have
 	// (the bit plane first: its word addresses are then a constant away from the hash -- one add less per vote)
 	uint32_t *plane = cs_lds;
+	typedef __attribute__((address_space(3))) uint32_t lds_u32;
+	lds_u32 *const plane0 = (lds_u32 *) (uint32_t) 0;   // == plane: the kernel has no static LDS, the dynamic array starts at 0
 	const uint32_t plane_words = A.plane_bits >> 5;
 	uint32_t *l_kinfo = plane + plane_words;                 // [kcap] bucket number | pair member << 30 | valid << 31
 	uint32_t *l_hdr = l_kinfo + kcap;                        // [kcap] bucket header of the k-mers in use, else 0
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
 	const uint32_t q_cap = ((n_slots * 3u) / 4u) / (uint32_t) T;  // per wave
+	Shared &S = *reinterpret_cast<Shared *>(t_votes + n_slots + (n_slots * 3u) / 4u);
 	const int lw = A.bucket_log2_words;
 	const int glog = min(lw, 5) - 2;                       // lanes per first line: 1, 2, 4, 8
 	const int bpr = NT >> glog;                            // buckets per round
@@ -86,12 +93,12 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	// ... or (reads_per_wg > 0) many short-lived workgroups, each with its run of consecutive reads and the same prefetch inside the
 	// run: no counter at all, the hardware balances the load, and -- unlike workgroups that live as long as the kernel -- a kernel
 	// of another stream (the order replay of the other mapper instance, on a high-priority stream) gets onto the CUs as runs end
-	if (tid0 == 0) { s_draw_next = 0; s_draw_left = 0; }   // (only thread 0 reads them)
+	if (tid0 == 0) { S.draw_next = 0; S.draw_left = 0; }   // (only thread 0 reads them)
 	const int run = A.reads_per_wg;
 	int read = A.read_lo + (run > 0 ? (int) blockIdx.x * run : (int) blockIdx.x), read_next = run > 0 ? read + 1 : read + (int) gridDim.x;
 	const int read_end = run > 0 ? min(A.n, read + run) : A.n;
 	uint32_t ch_next = (read < read_end && tid0 < A.q) ? (uint32_t) A.reads[(size_t) read * A.q + tid0] : 0u;
-	for (; read < read_end; read = read_next, read_next = s_next_read) {
+	for (; read < read_end; read = read_next, read_next = S.next_read) {
 		// everything derived from the thread index is recomputed per read from a value the compiler cannot see through: hoisted out
 		// of this loop those values would each hold a register for the whole kernel (78 spilled registers instead of 7)
 		const bool diag = A.phase_cycles && (read & 255) == 0;
@@ -115,8 +122,8 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		int drawn = 0;
 		if (tid == 0) {
 			if (run > 0) drawn = read_next + 1;
-			else if (s_draw_left > 0) { drawn = s_draw_next; s_draw_next = drawn + 1; s_draw_left -= 1; }
-			else { drawn = A.read_lo + (int) (2u * gridDim.x + atomicAdd(&A.status[2], (uint32_t) kCsCanonDraw)); s_draw_next = drawn + 1; s_draw_left = kCsCanonDraw - 1; }
+			else if (S.draw_left > 0) { drawn = S.draw_next; S.draw_next = drawn + 1; S.draw_left -= 1; }
+			else { drawn = A.read_lo + (int) (2u * gridDim.x + atomicAdd(&A.status[2], (uint32_t) kCsCanonDraw)); S.draw_next = drawn + 1; S.draw_left = kCsCanonDraw - 1; }
 		}
 		for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
 		for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
@@ -135,13 +142,13 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				l_code[i] = code;
 			}
 			first_nul = wave_reduce_min(first_nul);
-			if (lane == 0) s_len[wv] = first_nul;
+			if (lane == 0) S.len[wv] = first_nul;
 			__syncthreads();
-			// (reset here, not at the top: a wave that is still deciding on the previous read's s_abort has not passed the barrier above)
-			if (tid == 0) { s_abort = 0; s_nkeys = 0; s_nrel = 0; }
-			R.L = s_len[0];
+			// (reset here, not at the top: a wave that is still deciding on the previous read's S.abort has not passed the barrier above)
+			if (tid == 0) { S.abort = 0; S.nkeys = 0; S.nrel = 0; }
+			R.L = S.len[0];
 #pragma unroll
-			for (int w2 = 1; w2 < T; ++w2) R.L = min(R.L, s_len[w2]);
+			for (int w2 = 1; w2 < T; ++w2) R.L = min(R.L, S.len[w2]);
 		}
 		const int L = R.L, n_kmers = max(L - k + 1, 0);
 		R.n_lists = 2 * n_kmers;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				if ((int) ntot < A.max_kfreq) l_hdr[b] = hdr;   // (k-mers without a bucket read 0)
 			}
 		}
-		if (tid == 0) s_next_read = drawn;   // (the atomic was issued before the loads above: it has returned with them)
+		if (tid == 0) S.next_read = drawn;   // (the atomic was issued before the loads above: it has returned with them)
 		__syncthreads();
 		const unsigned long long c1a = diag ? wall_clock64() : 0ull;
 
@@ -207,11 +214,11 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			const uint32_t incl = wave_inclusive_scan(nch, lane);
 			const uint32_t hsum = wave_last(wave_inclusive_scan(hits, lane));
 			const uint32_t nv = (uint32_t) __popcll(__ballot(looked != 0u));
-			if (lane == 63) { s_tot[wv][0] = incl; s_tot[wv][1] = hsum; s_tot[wv][2] = nv; }
+			if (lane == 63) { S.tot[wv][0] = incl; S.tot[wv][1] = hsum; S.tot[wv][2] = nv; }
 			__syncthreads();
 			uint32_t o = incl - nch, n_items = 0, H = 0, n_valid = 0;
 #pragma unroll
-			for (int w2 = 0; w2 < T; ++w2) { if (w2 < wv) o += s_tot[w2][0]; n_items += s_tot[w2][0]; H += s_tot[w2][1]; n_valid += s_tot[w2][2]; }
+			for (int w2 = 0; w2 < T; ++w2) { if (w2 < wv) o += S.tot[w2][0]; n_items += S.tot[w2][0]; H += S.tot[w2][1]; n_valid += S.tot[w2][2]; }
 			for (uint32_t c = 0; c < nch; ++c, ++o) if (o < kItemCap) l_items[o] = (uint16_t) (((uint32_t) tid << 8) | c);
 			R.H = H; R.n_valid = n_valid; R.n_items = n_items;
 			__syncthreads();
@@ -258,14 +265,14 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 					if (prev == 0xFFFFFFFFu) { ++fresh; break; }
 					slot = (slot + 1) & (n_slots - 1);
 				}
-				if (slot != 0xFFFFFFFFu) atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); else s_abort = 1u;
+				if (slot != 0xFFFFFFFFu) atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); else S.abort = 1u;
 			}
 			uint32_t total;
 			(void) wave_prefix_small<4>(fresh, total);  // fresh <= q_cap / 64 < 16
 			uint32_t before = 0;
-			if (lane == 0 && total) before = atomicAdd(&s_nkeys, total);
+			if (lane == 0 && total) before = atomicAdd(&S.nkeys, total);
 			before = wave_first(before);
-			if (before + total > (n_slots * 3u) / 4u) { abort_fast = true; if (lane == 0) s_abort = 1u; }  // probing gets slow, the spurious entries too many
+			if (before + total > (n_slots * 3u) / 4u) { abort_fast = true; if (lane == 0) S.abort = 1u; }  // probing gets slow, the spurious entries too many
 			wave_sync();
 			q_len = 0;
 		};
@@ -281,7 +288,9 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				const uint32_t bin = ((pos[j] - corr[j]) >> A.bin_shift) & 0x3FFFFFFFu;
 				const uint32_t b = bin & pmask;
 				msk[j] = valid[j] ? (1u << (b & 31)) : 0u;      // empty slots vote with an all-zero mask: branch-free
-				dup[j] = atomicOr(&plane[b >> 5], msk[j]) & msk[j];   // != 0: a repeat on its bit
+				// (the plane starts at LDS address 0 -- see Shared above -- and is addressed as such: through the symbol of the dynamic array the
+				// compiler keeps an `add 0` per vote, the symbol's address being a link-time constant)
+				dup[j] = __hip_atomic_fetch_or(&plane0[b >> 5], msk[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & msk[j];   // != 0: a repeat on its bit
 				ent[j] = bin | revf[j];
 			}
 			uint32_t ndup = 0;
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 		const unsigned long long c2 = diag ? wall_clock64() : 0ull;
 		next_chars();
 		if (A.debug_stop == 2) { stop_here(); continue; }
-		if (s_abort) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }  // not provably exact here
+		if (S.abort) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }  // not provably exact here
 
 		// 3. complete the entries that can still matter (see the header): largest count, then the entries within reach of it
 		{
@@ -413,12 +422,12 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			}
 			mx = (uint32_t) wave_reduce_max((int) mx);
 			mxb = (uint32_t) wave_reduce_max((int) mxb);
-			if (lane == 0) { s_mx[wv][0] = mx; s_mx[wv][1] = mxb; }
+			if (lane == 0) { S.mx[wv][0] = mx; S.mx[wv][1] = mxb; }
 		}
 		__syncthreads();
 		uint32_t mx_lo = 0, mxb_lo = 0;
 #pragma unroll
-		for (int w2 = 0; w2 < T; ++w2) { mx_lo = max(mx_lo, s_mx[w2][0]); mxb_lo = max(mxb_lo, s_mx[w2][1]); }
+		for (int w2 = 0; w2 < T; ++w2) { mx_lo = max(mx_lo, S.mx[w2][0]); mxb_lo = max(mxb_lo, S.mx[w2][1]); }
 		{
 			// count + 1 >= m * sensitivity, in integers: the left side is one (counts are below 65 536: exact in a float)
 			const uint32_t reach = (uint32_t) ceilf((float) mx_lo * A.sensitivity);
@@ -429,23 +438,23 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 				const uint32_t v = t_votes[s];
 				const uint32_t f = v & 0xFFFFu, r = v >> 16;
 				if (max(f, r) + 1u >= reach || (both && f + r + 1u >= mxb_lo)) {
-					const uint32_t at = atomicAdd(&s_nrel, 1u);
-					if (at < (uint32_t) kCsCanonRel) { s_rel_key[at] = key | 0x40000000u; s_rel_slot[at] = s; }
+					const uint32_t at = atomicAdd(&S.nrel, 1u);
+					if (at < (uint32_t) kCsCanonRel) { S.rel_key[at] = key | 0x40000000u; S.rel_slot[at] = s; }
 				}
 			}
 		}
 		__syncthreads();
-		const uint32_t n_rel = s_nrel;
+		const uint32_t n_rel = S.nrel;
 		if (n_rel <= (uint32_t) kCsCanonRel) {
 			for (uint32_t j = 0; j < n_rel; ++j) {   // (typically one or two entries: the keys stay scalar)
-				const uint32_t key = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_rel_key[j]);
+				const uint32_t key = (uint32_t) __builtin_amdgcn_readfirstlane((int) S.rel_key[j]);
 				uint32_t hit = 0;   // bin | first-on-its-bit flag (| strand << 31): at most one such hit per bin in the whole workgroup; empty slots are 0, keys are not
 #pragma unroll
 				for (int i = 0; i < NS * kCsSeg; ++i) {
 					const uint32_t e = bins[i];
 					hit = ((e ^ key) << 1) == 0u ? e : hit;
 				}
-				if (hit) atomicAdd(&t_votes[s_rel_slot[j]], (hit >> 31) ? 0x10000u : 1u);
+				if (hit) atomicAdd(&t_votes[S.rel_slot[j]], (hit >> 31) ? 0x10000u : 1u);
 			}
 			__syncthreads();
 			if (A.debug_stop == 3) { stop_here(); continue; }
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			// 4. threshold and candidates (cs_finish, CS.cpp:201-205, :263-313) over the completed entries -- all others are out of reach
 			if (wv == 0) {
 				const bool mine = (uint32_t) lane < n_rel;
-				const uint32_t slot = mine ? s_rel_slot[lane] : 0u;
+				const uint32_t slot = mine ? S.rel_slot[lane] : 0u;
 				const uint32_t v = mine ? t_votes[slot] : 0u;
 				const uint32_t f = v & 0xFFFFu, r = v >> 16;
 				int mxi = wave_reduce_max((int) max(f, r)), mxbi = wave_reduce_max((int) (f + r));

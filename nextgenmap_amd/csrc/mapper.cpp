@@ -145,7 +145,7 @@ struct ngm_mapper {
 	HostArr<uint32_t> h_base, h_count;
 	HostArr<float> h_maxv;
 	uint64_t n_cand = 0;
-	hipEvent_t ev[10] = {};
+	hipEvent_t ev[10] = {};   // [8]: behind the last kernel of the align stage
 	float ms[8] = {};
 };
 
@@ -245,7 +245,7 @@ int run_cs(ngm_mapper *m, int n) {
 		if (!A.items16) A.fast_items = ngm::kCsFastItemsLong;  // the 32-bit item list only exists in the large size
 		if (m->cs_canon) {
 			A.buckets = r->d_cbuckets; A.bucket_log2_words = r->cbucket_log2_words; A.pos_base = r->cbucket_pos_base;
-			const size_t lds = cs_canon_lds_bytes(A, m->cs_canon) - 256;  // the kernel's static variables take the rest
+			const size_t lds = cs_canon_lds_bytes(A, m->cs_canon) - 96;  // (the kernel has no static LDS: its shared variables are the last 160 bytes of this)
 			// persistent workgroups: as many as the GPU holds at once, each walking the reads with that stride
 			const void *fn = cs_canon_fn(m->cs_canon, m->cs_canon_ch, m->cs_canon_wpe);
 			int per_cu = 0, cus = 0;
@@ -469,14 +469,25 @@ std::atomic<int> g_live_mappers{0};  // mapper instances share the host cores
 // NGM_HIP_GPU_STAGE_LOCK=2: one lock per stage KIND -- the align stage of one instance (1 wave per SIMD, hardly any LDS) may then
 // run under the search stage of another (LDS-bound at 10 waves per CU), only stages of the same kind take turns.
 std::mutex g_gpu_stage_mu[2];
+std::atomic<long long> g_stage_hold_us[3], g_stage_wait_us[3];   // diagnostics (NGM_HIP_HOST_TIMING): lock held / waited for, per stage kind (0 search + score, 1 align, 2 SAM text)
 struct GpuStage {
 	std::unique_lock<std::mutex> lk;
-	explicit GpuStage(int kind = 0) {
+	int kind, slot;
+	std::chrono::steady_clock::time_point t_acq;
+	explicit GpuStage(int kind_ = 0, bool now = true, int slot_ = -1) : kind(kind_), slot(slot_ < 0 ? kind_ : slot_) { if (now) acquire(); }
+	void acquire() {
 		static const int mode = getenv("NGM_HIP_GPU_STAGE_LOCK") ? atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) : 1;
-		if (mode == 0) return;
+		if (mode == 0 || lk.owns_lock()) return;
+		const auto t0 = std::chrono::steady_clock::now();
 		lk = std::unique_lock<std::mutex>(g_gpu_stage_mu[mode == 2 ? kind : 0]);
+		t_acq = std::chrono::steady_clock::now();
+		g_stage_wait_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(t_acq - t0).count();
 	}
-	void done() { if (lk.owns_lock()) lk.unlock(); }
+	void done() { if (lk.owns_lock()) { g_stage_hold_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_acq).count(); lk.unlock(); } }
+	// the stage's last KERNEL has been enqueued and `ev` recorded behind it; copies to the host follow on the same stream: the lock is
+	// passed on when the kernels are done, not when the copies are -- the next instance's kernels run under this one's downloads
+	// (round 4: the GPU sat idle for ~2 ms per launch behind 14 MB + 50 MB of result copies)
+	void done_after(hipEvent_t ev) { if (lk.owns_lock()) { (void) hipEventSynchronize(ev); done(); } }
 };
 // per-read host loops run on the process-wide persistent pool (thread_pool.h): shared by the mapper instances, sized
 // to this rank's share of the host cores; no threads are started per call
@@ -683,7 +694,9 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 
 void ngm_mapper_destroy(ngm_mapper *m) {
 	if (!m) return;
-	--g_live_mappers;
+	if (--g_live_mappers == 0 && getenv("NGM_HIP_HOST_TIMING"))
+		fprintf(stderr, "[ngm-hip] GPU stage lock, ms summed over all mappers: search + score held %.1f (waited %.1f) | align held %.1f (waited %.1f) | SAM text held %.1f (waited %.1f)\n",
+				g_stage_hold_us[0] / 1e3, g_stage_wait_us[0] / 1e3, g_stage_hold_us[1] / 1e3, g_stage_wait_us[1] / 1e3, g_stage_hold_us[2] / 1e3, g_stage_wait_us[2] / 1e3);
 	DevGuard g(m->ref->device);
 	(void) hipStreamSynchronize(m->st);
 	if (m->st_hi) { (void) hipStreamSynchronize(m->st_hi); (void) hipStreamDestroy(m->st_hi); }
@@ -1180,8 +1193,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipMemcpyAsync(h_loc, m->d_out_loc.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_sv, m->d_out_sv.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		if (paired) MAP_HIP_TRY(hipMemcpyAsync(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost, m->st));
+		stage_cs.done_after(m->ev[4]);
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
-		stage_cs.done();
 		lap(1);
 		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
 		if ((!paired || m->fast_pairing) && m->prm.topn <= 1 && !position_order) {
@@ -1553,7 +1566,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
 	static const bool dev_strings = !getenv("NGM_HIP_HOST_CIGAR");
 	uint64_t str_base = 0;   // bytes of the device's CIGAR / MD stream (host-built strings of the SAM stage go behind them)
-	GpuStage stage_align(1);
+	GpuStage stage_align(1, false);
 	if (na > 0) {
 		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
 				m->d_runs.reserve((size_t) na * rs)) { ngm::pipeline_set_error("out of device memory (align stage)"); return -12; }
@@ -1561,6 +1574,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_a_read.p, a_read.data(), (size_t) na * 4, hipMemcpyHostToDevice, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_a_loc.p, a_loc.data(), (size_t) na * 4, hipMemcpyHostToDevice, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_a_sv.p, a_sv.data(), (size_t) na * 4, hipMemcpyHostToDevice, m->st));
+		MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the uploads travel outside the stage lock)
+		stage_align.acquire();
 		MAP_HIP_TRY(hipEventRecord(m->ev[5], m->st));
 		ngm::WindowGeom Ga{r->n_bases - 1, align_buf_len, c >> 1};
 		hipLaunchKernelGGL(ngm::gather_pairs_kernel, dim3((na + ngm::kSlots - 1) / ngm::kSlots), dim3(256), 0, m->st, m->d_reads.p, m->d_read_len.p, q,
@@ -1578,6 +1593,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				m->d_runs_c.p, m->d_total.p);
 		MAP_HIP_TRY(hipGetLastError());
 		unsigned long long n_runs_total = 0, n_str_total = 0;
+		if (!dev_strings) MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st));   // (behind the stage's last kernel)
 		// CIGAR / MD / NM / identity on the GPU (cigar_device.h); NGM_HIP_HOST_CIGAR=1 keeps the host builders (tests)
 		if (dev_strings) {
 			const unsigned long long scap = (unsigned long long) na * 96ull + 4096ull;
@@ -1591,11 +1607,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					m->d_read_len.p, m->d_a_read.p, m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0, m->prm.hard_clip, m->prm.silent_clip, m->d_cigout.p, m->d_str.p, scap,
 					(unsigned long long *) (m->d_total.p + 8), alt_cigar);
 			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_cigout.p, m->d_cigout.p, (size_t) na * sizeof(ngm::CigarDevOut), hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(&n_str_total, m->d_total.p + 8, 8, hipMemcpyDeviceToHost, m->st));
 		}
 		MAP_HIP_TRY(hipMemcpyAsync(h_rec, m->d_records.p, (size_t) na * 8 * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(&n_runs_total, m->d_total.p, 8, hipMemcpyDeviceToHost, m->st));
+		stage_align.done_after(m->ev[8]);
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		if (m->p_runs.reserve(n_runs_total + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
 		h_runs = m->p_runs.p;
@@ -1695,7 +1713,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	lap(4);
 	if (sam) {
 		// ---- SAM text on the GPU: lengths per unit, exclusive prefix sum, bytes (sam_device.h) ------------------------------
-		GpuStage stage_sam(1);
+		GpuStage stage_sam(1, false, 2);
 		const int units = paired ? n / 2 : n;
 		if (!extra.empty()) {
 			// the byte stream grows by the host-built strings (rare: strings beyond the device's scratch rows)
@@ -1716,6 +1734,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_hits.p, hits, (size_t) n * sizeof(ngm_hit), hipMemcpyHostToDevice, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_refs.p, sam_refs, (size_t) n * sizeof(ngm::SamRef), hipMemcpyHostToDevice, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 16, 0, 24, m->st));
+		MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the uploads -- 64 bytes per read -- travel outside the stage lock)
+		stage_sam.acquire();
 		ngm::SamArgs S{};
 		S.n = n; S.q = q; S.paired = paired ? 1 : 0;
 		S.reads = m->d_reads.p; S.quals = m->d_sam_quals.p; S.names = m->d_sam_names.p; S.meta = m->d_sam_meta.p; S.hits = m->d_sam_hits.p; S.refs = m->d_sam_refs.p;
@@ -1752,8 +1772,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipMemcpyAsync(ctr, m->d_total.p + 16, 24, hipMemcpyDeviceToHost, m->st));
 		m->sam_text_bytes = total;
 		if (total <= sam->out_cap && total > 0) MAP_HIP_TRY(hipMemcpyAsync(sam->out, m->d_sam_text.p, (size_t) total, hipMemcpyDeviceToHost, m->st));
+		stage_sam.done_after(e1);   // the text (~420 bytes per read) travels while the next instance's kernels run
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
-		stage_sam.done();
 		sam->text_bytes = (long long) total;
 		if (sam->stats) { sam->stats[0] = ctr[0]; sam->stats[1] = ctr[1]; sam->stats[2] = ctr[2]; }
 		float t = 0;
