@@ -110,7 +110,8 @@ typedef struct ngm_mapper_params {
 	int match_bonus_tt, match_bonus_tc;   /* Config MATCH_BONUS_TT / MATCH_BONUS_TC (4 / 4) */
 	/* `--slam-seq <n>` (Config SLAM_SEQ): any value makes computeCigarMD count T>C (reverse strand: A>G) columns as matches and the
 	 * writer add TC / RA / MP tags; bit 1 (2) also switches the score tables (scoresSlamSeqFWD / REV, match_bonus_tt / -match_bonus_tc);
-	 * bit 2 (4) -- the weighted k-mer mutation search (src/CS.cpp:69-75, :133-138) -- is not implemented: refused. */
+	 * bit 2 (4): the weighted k-mer mutation search (src/CS.cpp:57-92, :133-138) -- every read k-mer and its single C > T (second mates
+	 * G > A) conversions, float votes of 1 / (convertible bases + 1) summed in the reference's order (csrc/cs_slam_device.h). */
 	int slam_seq;
 } ngm_mapper_params;
 

@@ -88,7 +88,7 @@ struct CsArgs {
 	// converted C (G): all 2^m combinations are looked up when the k-mer has at most bs_cutoff of them, none otherwise; the read is
 	// walked with bs_read_skip (the "kmer_skip" of a --bs-mapping run applies to the READ, src/CS.cpp:556-560, the index is built
 	// with skip 0, src/PrefixTable.cpp:199-207).  Exact paths only.
-	int bs;                 // 0 off, 1 on
+	int bs;                 // 0 off, 1 on, 2: `--slam-seq` with bit 2 (weighted search, cs_slam_device.h): every read k-mer and its SINGLE C > T (second mates: G > A) conversions, no cut-off, read walked with skip 0 (src/CS.cpp:57-92)
 	int bs_cutoff;          // Config "bs_cutoff" (6)
 	int bs_read_skip;       // k-mers skipped between two looked-up ones inside an N-free stretch of the read
 	int bs_paired;          // reads 2i + 1 are second mates: A -> G instead of T -> C (src/CS.cpp:356-376)
@@ -96,6 +96,9 @@ struct CsArgs {
 	const uint32_t *ovf_log2;       // per queued read: log2 slots
 	uint32_t *gtable_keys;
 	uint32_t *gtable_votes;
+	// cs_slam_kernel: per-workgroup slices of gtable_keys (persistent workgroups: slice blockIdx.x of slam_slice_words words; with a
+	// read_list: ovf_table_off / ovf_log2 per listed read)
+	unsigned long long slam_slice_words;
 };
 
 __device__ __forceinline__ uint32_t cs_revcomp(uint32_t prefix, int k) {  // PrefixTable.cpp:94-108
@@ -373,8 +376,9 @@ __device__ __forceinline__ CsBsRead cs_bs_scan(const CsArgs &A, int read, int la
 	const int L = R.L;
 	R.n_kmers = max(L - k + 1, 0);
 	const bool second = A.bs_paired && (read & 1);
-	R.from = second ? 0u : 2u;   // A -> G for the second mate, T -> C otherwise (codes A0 C1 T2 G3, CS.cpp:356-376)
-	R.to = second ? 3u : 1u;
+	const bool slam = A.bs == 2;
+	R.from = slam ? (second ? 3u : 1u) : (second ? 0u : 2u);   // bisulfite: A -> G for the second mate, T -> C otherwise; SLAM-seq: G -> A / C -> T (codes A0 C1 T2 G3, CS.cpp:356-376)
+	R.to = slam ? (second ? 0u : 2u) : (second ? 3u : 1u);
 	uint32_t carry = 0, n_valid = 0;
 	int last_n = -1;   // position of the last N in front of the current round (wave-uniform)
 	if (lane == 0) l_vbase[0] = 0;
@@ -395,7 +399,8 @@ __device__ __forceinline__ CsBsRead cs_bs_scan(const CsArgs &A, int read, int la
 			}
 			if (v && p + k == L && p >= 1 && l_code[p - 1] == 4 && (p == 1 || l_code[p - 2] == 4)) v = false;  // CSstatic.cpp:30-41, see cs_prepare
 			// (a valid k-mer holds no N: the last N at or before p lies in front of it)
-			if (v && ((p - (seg_n + 1)) % (A.bs_read_skip + 1)) == 0) { looked = true; if ((int) m <= A.bs_cutoff) nvar = 1u << m; }
+			// (SLAM-seq: the k-mer itself and its m single conversions, whatever m -- CS.cpp:69-75, :80-92)
+			if (v && ((p - (seg_n + 1)) % (A.bs_read_skip + 1)) == 0) { looked = true; if (slam) nvar = 1u + m; else if ((int) m <= A.bs_cutoff) nvar = 1u << m; }
 		}
 		n_valid += (uint32_t) __popcll(__ballot(looked));
 		const uint32_t incl = wave_inclusive_scan(nvar, lane);
@@ -423,7 +428,7 @@ __device__ __forceinline__ uint32_t cs_bs_chunk(const CsArgs &A, const CsBsRead 
 	uint32_t carry = 0, carry_s = 0;
 	for (uint32_t vb = v0; vb < v1; vb += 64) {
 		const uint32_t v = vb + (uint32_t) lane;
-		uint32_t cf = 0, cr = 0, sf = 0, sr = 0;
+		uint32_t cf = 0, cr = 0, sf = 0, sr = 0, wdiv_out = 0;
 		int p = 0;
 		if (v < v1) {
 			int lo = 0, hi = R.n_kmers;  // the k-mer with l_vbase[p] <= v < l_vbase[p + 1]
@@ -441,6 +446,11 @@ __device__ __forceinline__ uint32_t cs_bs_chunk(const CsArgs &A, const CsBsRead 
 			const int m = __popc(conv);
 			uint32_t chosen = 0;   // bit e: the e-th convertible base (in increasing i) is converted
 			int e = 0;
+			// SLAM-seq (PrefixMutateSearchSlamSeq, CS.cpp:80-92): variant 0 is the k-mer itself (weight 1), variant r > 0 converts the
+			// (r - 1)-th convertible base counted from the k-mer's last base, alone (weight 1 / (m + 1): the divisor travels in l_vpos)
+			const uint32_t wdiv = (A.bs == 2) ? (r == 0u ? 1u : (uint32_t) m + 1u) : 0u;
+			if (A.bs == 2) { chosen = r ? (1u << (r - 1u)) : 0u; r = 0; }
+			wdiv_out = wdiv;
 			while (r > 0) {
 				r -= 1;
 				for (;; ++e) {
@@ -463,7 +473,7 @@ __device__ __forceinline__ uint32_t cs_bs_chunk(const CsArgs &A, const CsBsRead 
 			l_start[2 * j] = sf; l_start[2 * j + 1] = sr;
 			if (TIMES) { l_pref[2 * j] = (cf & 0xFFFFu) | ((t_base + b0) << 16); l_pref[2 * j + 1] = (cr & 0xFFFFu) | ((t_base + b0 + cf) << 16); }
 			else { l_pref[2 * j] = b0; l_pref[2 * j + 1] = b0 + cf; }
-			l_vpos[j] = (uint16_t) p;
+			l_vpos[j] = (uint16_t) ((uint32_t) p | (wdiv_out << 10));   // (read positions are below 1 024)
 		}
 		carry += wave_last(incl);
 		carry_s += wave_last(incl_s);

@@ -29,6 +29,7 @@
 #include "cs_device.h"
 #include "cs_canon_device.h"
 #include "cs_heavy_device.h"
+#include "cs_slam_device.h"
 #define NGM_SAM_KERNELS
 #include "sam_device.h"
 #include "gather_device.h"
@@ -235,7 +236,52 @@ int run_cs(ngm_mapper *m, int n) {
 		A.hit_cap = m->cs_plane_bits / 6u;
 		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
 		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
-		if (bs) {
+		const bool slamw = (m->prm.slam_seq & 4) != 0;
+		if (slamw) {
+			// `--slam-seq` with bit 2: the weighted search (cs_slam_device.h) -- float votes in the reference's order, one wave per read,
+			// tables in slices of global memory.  Persistent workgroups with a slice each; reads whose hits outgrow it are queued and re-run
+			// with a slice of their own.
+			A.bs = 2; A.bs_cutoff = 0; A.bs_read_skip = 0; A.bs_paired = m->cs_paired ? 1 : 0;
+			A.lists_cap = 2 * ngm::kCsBsChunk;
+			const size_t lds = cs_lds_bytes(A, ngm::kCsExactGlobal);
+			const int grid = std::min(n, 2048);
+			A.slam_slice_words = ngm::cs_slam_words(49152u);
+			if (m->d_gt_keys.reserve((size_t) grid * A.slam_slice_words)) { ngm::pipeline_set_error("out of device memory (weighted SLAM-seq search)"); return -12; }
+			A.gtable_keys = m->d_gt_keys.p;
+			hipLaunchKernelGGL(ngm::cs_slam_kernel, dim3(grid), dim3(64), lds, m->st, A);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+			if (status[1] > 0) {
+				const uint32_t no = status[1];
+				std::vector<uint32_t> qr(no), qh(no), lg(no);
+				std::vector<uint64_t> off(no);
+				MAP_HIP_TRY(hipMemcpy(qr.data(), m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToHost));
+				MAP_HIP_TRY(hipMemcpy(qh.data(), m->d_ovf_hits.p, (size_t) no * 4, hipMemcpyDeviceToHost));
+				if (m->d_ovf_off.reserve(no) || m->d_ovf_log2.reserve(no) || m->d_ovf_read2.reserve(no)) { ngm::pipeline_set_error("out of device memory (weighted SLAM-seq search)"); return -12; }
+				constexpr uint64_t kPoolWords = 1ull << 30;
+				for (uint32_t j0 = 0; j0 < no;) {
+					uint64_t total = 0;
+					uint32_t j1 = j0;
+					while (j1 < no && (j1 == j0 || total + ngm::cs_slam_words(qh[j1]) <= kPoolWords)) { off[j1] = total; lg[j1] = ngm::cs_slam_log2_slots(qh[j1]); total += ngm::cs_slam_words(qh[j1]); ++j1; }
+					if (m->d_gt_keys.reserve(total)) { ngm::pipeline_set_error("out of device memory (weighted SLAM-seq search, %llu words)", (unsigned long long) total); return -12; }
+					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, qr.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, m->st));
+					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, m->st));
+					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, m->st));
+					ngm::CsArgs Q = A;
+					Q.read_list = m->d_ovf_read2.p; Q.ovf_log2 = m->d_ovf_log2.p; Q.ovf_table_off = m->d_ovf_off.p; Q.gtable_keys = m->d_gt_keys.p;
+					hipLaunchKernelGGL(ngm::cs_slam_kernel, dim3(j1 - j0), dim3(64), lds, m->st, Q);
+					MAP_HIP_TRY(hipGetLastError());
+					MAP_HIP_TRY(hipStreamSynchronize(m->st));
+					j0 = j1;
+				}
+				MAP_HIP_TRY(hipMemcpy(status, m->d_status.p, 16, hipMemcpyDeviceToHost));
+			}
+			MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
+			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+			timed(0);
+			status[1] = 0;
+		} else if (bs) {
 			// bisulfite mapping: no fast path (a read looks up ~10 variants of every k-mer: exact tables only); every read starts in pass 2
 			MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
 			status[0] = 0; status[1] = (uint32_t) n; status[2] = status[3] = 0;
@@ -570,7 +616,6 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	}
 	if (p->slam_seq) {
 		if (p->bs_mapping) { ngm::pipeline_set_error("ngm_mapper_create: '--bs-mapping' and '--slam-seq' can't be used at the same time!"); return nullptr; }  // Config.cpp:454-457
-		if (p->slam_seq & 4) { ngm::pipeline_set_error("ngm_mapper_create: --slam-seq with bit 2 set (the weighted k-mer mutation search, src/CS.cpp:69-75) is not implemented"); return nullptr; }
 		if (p->personality != NGM_PERSONALITY_LINEAR) { ngm::pipeline_set_error("ngm_mapper_create: '--slam-seq' needs the default (linear-gap) personality: EndToEndAffine produces no per-base records (Align::ExtendedData)"); return nullptr; }
 		ep.alt_cigar = NGM_ALT_SLAMSEQ;
 		if (p->slam_seq & 2) { ep.alt_scoring = NGM_ALT_SLAMSEQ; ep.match_bonus_tt = p->match_bonus_tt; ep.match_bonus_tc = p->match_bonus_tc; }
@@ -826,6 +871,16 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 // wait = false: only enqueue (the list must stay alive until candidate_order_wait)
 static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank, bool wait = true) {
 	const uint32_t nl = (uint32_t) list.size();
+	if (m->prm.slam_seq & 4) {
+		// the weighted SLAM-seq search replays the votes in the reference's order anyway: its candidates leave in rList order
+		if (m->p_rank.reserve(np + 1)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
+		for (uint32_t rd : list) { const uint32_t b = m->h_base[rd], c = m->h_count[rd]; for (uint32_t x = 0; x < c; ++x) m->p_rank.p[b + x] = x; }
+		m->st_order_reads += nl;
+		m->order_pending.clear();
+		*h_rank = m->p_rank.p;
+		(void) wait;
+		return 0;
+	}
 	static const bool order_on_main = getenv("NGM_HIP_ORDER_ON_MAIN_STREAM") != nullptr;  // diagnostics
 	hipStream_t ost = (m->st_hi && !order_on_main) ? m->st_hi : m->st;  // everything this depends on has been synchronised by the caller
 	const auto t_begin = std::chrono::steady_clock::now();

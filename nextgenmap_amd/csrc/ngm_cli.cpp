@@ -264,7 +264,6 @@ Opts parse(int argc, char **argv) {
 	if (o.slam_seq) {
 		if (o.bs_mapping) die("'--bs-mapping' and '--slam-seq' can't be used at the same time!");   // Config.cpp:454-457
 		if (o.affine) die("'--slam-seq' needs the default (linear-gap) scoring: the affine backend produces no per-base records");
-		if (o.slam_seq & 4) die("--slam-seq " + std::to_string(o.slam_seq) + ": the weighted k-mer mutation search (bit 2) is not supported by the HIP backend yet");
 		if (o.topn > 1 || o.bam) die("'--slam-seq' with -n / --bam is not supported by the HIP backend yet");
 	}
 	if (o.match_tt < 0) o.match_tt = 10;
@@ -786,6 +785,7 @@ int main(int argc, char **argv) {
 	} else if (count >= 1000 && !sample.empty()) {
 		ngm_mapper_params ep = mp;
 		ep.sensitivity = 0.0f;
+		ep.slam_seq &= ~4;   // (the estimate looks the read k-mers up as they are: ReadProvider's own PrefixSearch, src/ReadProvider.cpp:79-124)
 		const auto te0 = std::chrono::steady_clock::now();
 		ngm_mapper *em = ngm_mapper_create(ref, &ep);
 		if (!em) die(ngm_pipeline_last_error());

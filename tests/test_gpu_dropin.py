@@ -216,10 +216,12 @@ def test_bisulfite_mapping_real_program_with_plugin_vs_ngm_hip(tmp_path, layout)
 
 @needs
 @pytest.mark.parametrize("layout", ["single-end", "paired-end"])
-@pytest.mark.parametrize("slam", [1, 2])
+@pytest.mark.parametrize("slam", [1, 2, 4, 5, 6, 7])
 def test_slam_seq_real_program_with_plugin_vs_ngm_hip(tmp_path, layout, slam):
-    """`--slam-seq 1|2`: 1 = conversion-aware NM / identity plus the TC / RA / MP tags, 2 = the strand-specific
-    SLAM-seq score tables as well.  As for bisulfite the oracle is the REAL program with this library behind IAlignment: its
+    """`--slam-seq <n>`: 1 = conversion-aware NM / identity plus the TC / RA / MP tags, 2 = the strand-specific
+    SLAM-seq score tables as well, 4 = the WEIGHTED candidate search (src/CS.cpp:57-92: every read k-mer and its single C > T
+    conversions, float votes of 1 / (convertible bases + 1) -- here csrc/cs_slam_device.h, there the reference's own CS on the host:
+    identical SAM means identical candidate sets, float maxima (XE:i) and candidate order).  As for bisulfite the oracle is the REAL program with this library behind IAlignment: its
     ScoreBuffer / AlignmentBuffer direction bytes and SAMWriter::computeSlaSeqTags (src/writer/GenericReadWriter.h:87-187) over the
     adapter's Align::ExtendedData records -- against ngm-hip, which builds the three tags on the GPU (csrc/sam_device.h)."""
     contigs = S.make_genome([300000, 200001], seed=921, repeat_families=6, repeat_len=400, copies=4)
