@@ -264,7 +264,6 @@ Opts parse(int argc, char **argv) {
 	if (o.slam_seq) {
 		if (o.bs_mapping) die("'--bs-mapping' and '--slam-seq' can't be used at the same time!");   // Config.cpp:454-457
 		if (o.affine) die("'--slam-seq' needs the default (linear-gap) scoring: the affine backend produces no per-base records");
-		if (o.topn > 1 || o.bam) die("'--slam-seq' with -n / --bam is not supported by the HIP backend yet");
 	}
 	if (o.match_tt < 0) o.match_tt = 10;
 	if (o.match_tc < 0) o.match_tc = 2;
@@ -1000,6 +999,17 @@ int main(int argc, char **argv) {
 			tg.add_int("X0", h.n_best); tg.add_int("XE", (int) h.max_votes); tg.add_int("XR", L - h.qstart - h.qend);
 			tg.add_string("MD", v.md, strlen(v.md));
 			if (!o.rg[0].empty()) tg.add_string("RG", o.rg[0].data(), o.rg[0].size());
+			if (o.slam_seq) {
+				// BAMWriter.cpp:273-292: TC:i, RA:Z (the 25 counts, every one followed by a comma -- the SAM writer drops the last comma, this one
+				// does not), MP:Z when there are mismatches
+				std::string t;
+				slam_tags(t, v);   // "\tTC:i:<n>\tRA:Z:<..>[\tMP:Z:<..>]"
+				const size_t a_ra = t.find("\tRA:Z:"), a_mp = t.find("\tMP:Z:");
+				tg.add_int("TC", atoi(t.c_str() + 6));
+				const std::string ra = t.substr(a_ra + 6, (a_mp == std::string::npos ? t.size() : a_mp) - (a_ra + 6)) + ",";
+				tg.add_string("RA", ra.data(), ra.size());
+				if (a_mp != std::string::npos) tg.add_string("MP", t.data() + a_mp + 6, t.size() - (a_mp + 6));
+			}
 			ngm::bam::put_record(s, v.r->name, v.r->name_len, (uint32_t) flags, h.contig, (int) h.pos, h.mapq, v.cigar, seq, (size_t) n, noq ? nullptr : qual,
 					bm.ref, (int) bm.pos0, (int) bm.tlen, tg);
 			++n_written;

@@ -271,6 +271,26 @@ def test_slam_seq_real_program_with_plugin_vs_ngm_hip(tmp_path, layout, slam):
     diff = [(a[k], b[k]) for k in a if a[k] != b[k]]
     print("records differing:", len(diff), "of", len(a))
     assert not diff, str(diff[:2])[:1500]
+    if slam in (1, 6):
+        # ... with -n 3 (several alignments per read, each with its tags; single-end as in the reference) and as BAM (TC / RA / MP in the tag block)
+        if not paired:
+            plug3, ours3 = str(d1 / "plugin3.sam"), str(tmp_path / "ours3.sam")
+            _run(DROPIN, fa1, inp + ["--slam-seq", str(slam), "-n", "3"], plug3, str(d1))
+            c = subprocess.run([CLI, "-r", fa, "-o", ours3, "--slam-seq", str(slam), "-n", "3"] + inp, capture_output=True, text=True)
+            assert c.returncode == 0, c.stderr[-2000:]
+            body = lambda p: sorted(l for l in open(p) if not l.startswith("@"))
+            assert body(plug3) == body(ours3)
+        from test_gpu_bam import decode_bam
+        plugb, oursb = str(d1 / "plugin.bam"), str(tmp_path / "ours.bam")
+        _run(DROPIN, fa1, inp + ["--slam-seq", str(slam), "--bam"], plugb, str(d1))
+        c = subprocess.run([CLI, "-r", fa, "-o", oursb, "--slam-seq", str(slam), "--bam"] + inp, capture_output=True, text=True)
+        assert c.returncode == 0, c.stderr[-2000:]
+        ta, ra, xa = decode_bam(plugb)
+        tb, rb, xb = decode_bam(oursb)
+        assert ra == rb and len(xa) == len(xb) == n
+        bad = [(x, y) for x, y in zip(xa, xb) if x != y]
+        assert not bad, str(bad[:1])[:1500]
+        assert any(b"TCi" in x["tags"] or b"TCC" in x["tags"] or b"TCc" in x["tags"] for x in xa), "the BAM records carry the SLAM-seq tags"
     # the host formatter (NGM_HIP_HOST_SAM=1) writes the same tags
     host = str(tmp_path / "host.sam")
     c = subprocess.run([CLI, "-r", fa, "-o", host, "--slam-seq", str(slam)] + inp, capture_output=True, text=True, env=dict(os.environ, NGM_HIP_HOST_SAM="1"))
