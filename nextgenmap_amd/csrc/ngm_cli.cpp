@@ -63,7 +63,7 @@
 
 namespace {
 
-struct Read { std::string name, seq, qual; };
+struct Read { std::string name, seq, qual; uint8_t unit = 0; };   // unit: --broken-pairs (1 a read without its mate, 2 the placeholder in the mate's row, 4 the pair's 0x40 / 0x80 flags are swapped)
 
 // FASTA / FASTQ reader with kseq semantics: name = header up to the first white space, multi-line records
 class SeqReader {
@@ -119,7 +119,7 @@ struct Opts {
 	int paired = 0, min_insert = 0, max_insert = 1000, topn = 1, strata = 0;
 	char pe_delimiter = '/';
 	int device = 0, kmer = 13, kmer_skip = 2, bin_size = 2, mode = 0, corridor = -1, max_read_length = 0, min_mq = 0, max_kfreq = 0;
-	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, fast_pairing = 0, max_cmrs = 2147483647;
+	int match = 10, mismatch = 15, gap_read = -1, gap_ref = -1, gap_extend = -1, affine = 0, hard_clip = 0, silent_clip = 0, no_unal = 0, fast_pairing = 0, broken_pairs = 0, max_cmrs = 2147483647;
 	int skip_save = 0, bam = 0, workers = 2, serial_reader = 0;
 	int bs_mapping = 0, bs_cutoff = 6, match_tt = -1, match_tc = -1, match_set = 0, mismatch_set = 0, slam_seq = 0;
 	std::vector<int> devices;
@@ -138,7 +138,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, SHARD, SHARDOUT, KEEPSHARDS, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, FASTPAIR, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, SHARD, SHARDOUT, KEEPSHARDS, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, FASTPAIR, BROKENPAIRS, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -159,7 +159,7 @@ Opts parse(int argc, char **argv) {
 		{"rg-dt", required_argument, 0, RG0 + 3}, {"rg-fo", required_argument, 0, RG0 + 4}, {"rg-ks", required_argument, 0, RG0 + 5},
 		{"rg-lb", required_argument, 0, RG0 + 6}, {"rg-pg", required_argument, 0, RG0 + 7}, {"rg-pi", required_argument, 0, RG0 + 8},
 		{"rg-pl", required_argument, 0, RG0 + 9}, {"rg-pu", required_argument, 0, RG0 + 10}, {"rg-sm", required_argument, 0, RG0 + 11},
-		{"fast-pairing", no_argument, 0, FASTPAIR}, {"broken-pairs", no_argument, 0, UNSUPPORTED},
+		{"fast-pairing", no_argument, 0, FASTPAIR}, {"broken-pairs", no_argument, 0, BROKENPAIRS},
 		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, BAMOUT}, {"workers", required_argument, 0, WORKERS}, {"serial-reader", no_argument, 0, SERIAL}, {"bs-mapping", no_argument, 0, BSMAP},
 		{"bs-cutoff", required_argument, 0, BSCUT}, {"match-bonus-tt", required_argument, 0, MBTT}, {"match-bonus-tc", required_argument, 0, MBTC},
 		{"slam-seq", required_argument, 0, SLAM}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
@@ -238,6 +238,7 @@ Opts parse(int argc, char **argv) {
 		case SHARDOUT: o.shard_output = 1; break;
 		case KEEPSHARDS: o.keep_shards = 1; break;
 		case FASTPAIR: o.fast_pairing = 1; break;
+		case BROKENPAIRS: o.broken_pairs = 1; break;
 		case UNSUPPORTED: die(std::string("option --") + lo[idx].name + " is not supported by the HIP backend yet");
 		default: die("unknown option (see src/config/Options.h of NextGenMap for the option set)");
 		}
@@ -274,11 +275,16 @@ Opts parse(int argc, char **argv) {
 	o.device = o.devices[0];
 	if (getenv("NGM_HIP_WORKERS")) o.workers = std::max(1, atoi(getenv("NGM_HIP_WORKERS")));
 	if (getenv("NGM_HIP_SERIAL_READER")) o.serial_reader = 1;
+	if (o.broken_pairs) {
+		if (!(o.paired && !o.qry.empty())) die("--broken-pairs only works with interleaved paired-end files.");   // ReadProvider.cpp:176-179
+		if (o.shard_n > 1 || o.shard_output) die("--broken-pairs cannot be combined with --shard / --shard-output: the pairing of the records is decided while they are read");
+		o.serial_reader = 1;   // which records are mates is decided record by record (ReadProvider.cpp:540-575)
+	}
 	return o;
 }
 
 // ---- input: records as views into the mapped file (plain FASTQ) or into storage owned by the batch (serial reader) ----
-struct Rec { const char *name; const char *seq; const char *qual; uint32_t name_len, seq_len, qual_len; };
+struct Rec { const char *name; const char *seq; const char *qual; uint32_t name_len, seq_len, qual_len; uint8_t unit; };
 
 inline void pack_row_view(const char *seq, size_t len, int q, char *row) {  // IParser.h:59-121
 	memset(row, 0, q);
@@ -903,7 +909,7 @@ int main(int argc, char **argv) {
 	}
 	ngm_pair_state *pair_state = ngm_pair_state_create();
 	// SAM text on the GPU (csrc/sam_device.h) for plain SAM output with one alignment per read; BAM and -n > 1 are formatted here
-	const bool gpu_sam = !o.bam && topn == 1 && !getenv("NGM_HIP_HOST_SAM");
+	const bool gpu_sam = !o.bam && topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
 	struct Worker { ngm_mapper *m = nullptr; char *rows = nullptr; size_t rows_cap = 0; std::vector<ngm_hit> hits; std::vector<char> cig, md;
 		char *qrows = nullptr, *names = nullptr; size_t names_cap = 0; ngm_sam_read *meta = nullptr; };
 	std::vector<Worker> workers(o.devices.size() * (size_t) o.workers);
@@ -1114,6 +1120,15 @@ int main(int argc, char **argv) {
 		for (int i = lo; i + 1 < hi; i += 2) {
 			// read1 = the first mate (even ReadId), written second by AlignmentBuffer::WriteRead; read2 = its mate
 			const View v1 = view(i), v2 = view(i + 1);
+			if (v2.r->unit & 2) {
+				// --broken-pairs: a read without its mate goes out like a single-end read (AlignmentBuffer.cpp:201-203, GenericReadWriter::WriteRead)
+				if (v1.r->seq_len == 0) continue;
+				++n_total;
+				if (!passes(v1)) { write_unmapped(s, n_written, v1, 0, -1, 0, '*', 0); continue; }
+				++n_mapped;
+				write_mapped(s, n_written, v1, 0, "*", 0, 0, BamMate{-1, -1, 0});
+				continue;
+			}
 			if (v1.r->seq_len == 0 || v2.r->seq_len == 0) continue;  // GenericReadWriter.h:250-252
 			n_total += 2;
 			const ngm_hit &h1 = *v1.h, &h2 = *v2.h;
@@ -1125,7 +1140,8 @@ int main(int argc, char **argv) {
 			}
 			const bool m1 = passes(v1), m2 = passes(v2);  // GenericReadWriter::WritePair
 			n_mapped += (m1 ? 1 : 0) + (m2 ? 1 : 0);
-			const int f1 = 0x1 | 0x40, f2 = 0x1 | 0x80;  // SAMWriter::DoWritePair (SAMWriter.cpp:230-310)
+			const bool swp = (v1.r->unit & 4) != 0;   // (--broken-pairs: the reference's read ids have lost their parity, see the reader)
+			const int f1 = 0x1 | (swp ? 0x80 : 0x40), f2 = 0x1 | (swp ? 0x40 : 0x80);  // SAMWriter::DoWritePair (SAMWriter.cpp:230-310)
 			const unsigned long long p1 = h1.pos + 1, p2 = h2.pos + 1;
 			if (!m1 && !m2) {
 				write_unmapped(s, n_written, v2, f2 | 0x8, -1, 0, '*', 0);
@@ -1217,12 +1233,39 @@ int main(int argc, char **argv) {
 			std::unique_ptr<SeqReader> in2(path1.empty() ? nullptr : new SeqReader(path1.c_str()));
 			if (!in1.ok() || (in2 && !in2->ok())) { fail(o.paired ? "cannot open the paired-end input" : "cannot open " + path0); q_in.close(); return; }
 			auto b = std::make_unique<Batch>();
-			Read a, c;
+			Read a, c, spare;
+			bool have_spare = false;
+			const uint64_t bp_units_per_batch = std::max<uint64_t>(1, (uint64_t) ((1800000 / std::max(1, avg_len)) & ~1) / 2);   // CS.cpp:26, :542; NGM.cpp:237-242
+			uint64_t bp_units = 0, bp_reads = 0, bp_cur_start = 0;
 			for (;;) {
 				if (failed) break;
 				if (!o.paired) {
 					if (!in1.next(a)) break;
 					b->owned.push_back(std::move(a));
+				} else if (o.broken_pairs) {
+					// ReadProvider::GenerateRead with acceptBrokenPaired (ReadProvider.cpp:529-575): two consecutive records whose names differ are
+					// not mates -- the first is mapped alone (its mate's row holds a placeholder), the second becomes the first of the next pair;
+					// a record left over at the end is mapped alone too.  Read ids (NGM.cpp:252-267): a batch of the reference's CS thread hands out
+					// ids m_CurStart + 2 j, + 1 to its j-th pair and then advances m_CurStart by the reads it actually got -- after an odd number
+					// the first mates of the following batch carry ODD ids, and SAMWriter::DoWritePair (SAMWriter.cpp:235-244) gives them 0x80
+					if (have_spare) { a = std::move(spare); have_spare = false; }
+					else if (!in1.next(a)) break;
+					const bool hb = in1.next(c);
+					uint32_t la = (uint32_t) a.name.size(), lc = (uint32_t) c.name.size();
+					strip_mate(a.name.data(), la);
+					if (hb) strip_mate(c.name.data(), lc);
+					const bool mates = hb && la == lc && memcmp(a.name.data(), c.name.data(), la) == 0;
+					const uint8_t swp = (bp_cur_start & 1) ? 4 : 0;
+					if (mates) { a.unit = swp; c.unit = swp; b->owned.push_back(std::move(a)); b->owned.push_back(std::move(c)); bp_reads += 2; }
+					else {
+						a.unit = 1;
+						b->owned.push_back(std::move(a));
+						Read ph; ph.unit = 2;
+						b->owned.push_back(std::move(ph));
+						bp_reads += 1;
+						if (hb) { spare = std::move(c); have_spare = true; }
+					}
+					if (++bp_units == bp_units_per_batch) { bp_cur_start += bp_reads; bp_units = 0; bp_reads = 0; }
 				} else {
 					const bool ha = in1.next(a), hb = ha ? (in2 ? in2->next(c) : in1.next(c)) : false;
 					if (!ha) break;
@@ -1300,7 +1343,7 @@ int main(int argc, char **argv) {
 				pool.parallel_for(n, [&](int lo, int hi) {
 					for (int i = lo; i < hi; ++i) {
 						const Read &r = b->owned[i];
-						b->recs[i] = Rec{r.name.data(), r.seq.data(), r.qual.data(), (uint32_t) r.name.size(), (uint32_t) r.seq.size(), (uint32_t) r.qual.size()};
+						b->recs[i] = Rec{r.name.data(), r.seq.data(), r.qual.data(), (uint32_t) r.name.size(), (uint32_t) r.seq.size(), (uint32_t) r.qual.size(), r.unit};
 						if (o.paired) strip_mate(b->recs[i].name, b->recs[i].name_len);
 						pack_row_view(r.seq.data(), r.seq.size(), q, w.rows + (size_t) i * q);
 						if (gpu_sam) memcpy(w.qrows + (size_t) i * q, r.qual.data(), std::min<size_t>(r.qual.size(), (size_t) q - 1));
@@ -1340,6 +1383,7 @@ int main(int argc, char **argv) {
 				pool.parallel_for(n / 2, [&](int lo, int hi) {
 					for (int pi = lo; pi < hi; ++pi) {
 						const Rec &a = b->recs[2 * pi], &c = b->recs[2 * pi + 1];
+						if (c.unit & 2) continue;   // --broken-pairs: a read without its mate
 						if (a.name_len != c.name_len || memcmp(a.name, c.name, a.name_len) != 0) {
 							int seen = first_bad.load();
 							while (2 * pi < seen && !first_bad.compare_exchange_weak(seen, 2 * pi)) {}

@@ -404,3 +404,85 @@ def test_sam_assembled_on_the_gpu_equals_the_host_formatter(tmp_path, case):
         la, lb = a.split(b"\n"), b.split(b"\n")
         bad = [(x, y) for x, y in zip(la, lb) if x != y][:3]
         raise AssertionError("GPU-assembled SAM differs from the host formatter: %d vs %d lines; first: %r" % (len(la), len(lb), bad))
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+def test_broken_pairs_interleaved_equals_reference_program(tmp_path):
+    """`--broken-pairs` (src/ReadProvider.cpp:53, :176-179, :540-575): an interleaved file in which some mates are missing.  Records
+    whose names differ are not paired -- the first is mapped and written like a single-end read, the second opens the next pair.  The
+    input is longer than one batch of the reference's CS thread (18 000 reads of 100 bp), with an odd number of lone reads in the
+    first batch: the reference's read ids then lose their parity and the first mates of the SECOND batch are written with 0x80
+    (SAMWriter.cpp:235-244) -- mirrored, because a drop-in writes what the reference writes."""
+    contigs = S.make_genome([300000, 200001], seed=61, repeat_families=6, repeat_len=400, copies=5)
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "wb") as f:
+        for i, g in enumerate(contigs):
+            f.write(b">chr%d\n" % (i + 1))
+            b = g.tobytes()
+            for o in range(0, len(b), 70):
+                f.write(b[o:o + 70] + b"\n")
+    r1, r2 = S.make_reads(contigs, 11000, 100, seed=62, sub_rate=0.02, indel_rate=0.003, paired=True)
+    rng = np.random.default_rng(6)
+    recs, lone, units = [], 0, []           # units: (reads, index of the pair or -1)
+    for i, (a, b) in enumerate(zip(r1, r2)):
+        x = rng.random()
+        if i == 10 or (x < 0.02 and i != 11):
+            recs.append(a); lone += 1; units.append((1, -1))       # mate 2 missing
+        elif x < 0.04:
+            recs.append(b); lone += 1; units.append((1, -1))       # mate 1 missing
+        else:
+            recs += [a, b]; units.append((2, i))
+    # the reference's CS thread takes (1 800 000 / average read length) / 2 units per batch (CS.cpp:26, :543; NGM.cpp:237-267); pairs of a
+    # batch that starts at an odd read id are flipped
+    all_recs = recs + [r1[0]]
+    per_batch = ((1800000 // (sum(len(x[1]) for x in all_recs) // len(all_recs))) & ~1) // 2
+    start, flipped = 0, set()
+    for b0 in range(0, len(units), per_batch):
+        if start & 1:
+            flipped.update(i for _, i in units[b0:b0 + per_batch] if i >= 0)
+        start += sum(n for n, _ in units[b0:b0 + per_batch])
+    if not flipped:   # (make the first batch odd: drop the second mate of one more pair in front)
+        raise AssertionError("the test input should make the second batch start at an odd read id; change the seed")
+    recs.append(r1[0])                      # a record left over at the end
+    fq = str(tmp_path / "pe.fq")
+    S.write_fastq(fq, recs)
+    d1 = tmp_path / "refrun"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    inp = ["-p", "-q", fq, "--broken-pairs"]
+    r = RF.run_ngm(["-r", fa1, "-o", str(d1 / "out.sam"), "--affine", "-t", "1", "--no-progress"] + inp, cwd=str(d1))
+    assert "Done" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-1500:]
+    c = subprocess.run([CLI, "-r", fa, "-o", str(tmp_path / "hip.sam"), "--affine"] + inp, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    body = lambda p: [l for l in open(p) if not l.startswith("@")]
+    a, b = body(str(d1 / "out.sam")), body(str(tmp_path / "hip.sam"))
+    assert len(a) == len(b) == len(recs)
+    flags = {}
+    for l in a:
+        f = int(l.split("\t")[1])
+        flags[f & 0xC1] = flags.get(f & 0xC1, 0) + 1
+    print("lone reads:", lone + 1, "flag classes of the reference (paired bit | 0x40 | 0x80):", sorted(flags.items()))
+    assert flags.get(0, 0) == lone + 1, "lone reads are written without the paired flag"
+    diff = [(x, y) for x, y in zip(sorted(a), sorted(b)) if x != y]
+    print("records differing:", len(diff), "of", len(a))
+    assert not diff, str(diff[:2])[:1500]
+    # the flip is real: first-in-file mates of the flipped pairs carry 0x80, those of the others 0x40
+    first_seq = {i: (bytes(r1[i][1]), bytes(S.revcomp(r1[i][1]))) for i in range(len(r1))}
+    by_name = {}
+    for l in b:
+        f = l.split("\t")
+        by_name.setdefault(f[0], []).append((int(f[1]), f[9].encode()))
+    seen_flip = seen_plain = 0
+    for i in list(sorted(flipped))[:200] + [j for j in range(len(r1)) if j not in flipped][:200]:
+        name = r1[i][0][:-2]
+        for flag, seq in by_name.get(name, []):
+            if flag & 1 and seq in first_seq[i]:
+                assert bool(flag & 0x80) == (i in flipped), (name, flag, i in flipped)
+                seen_flip += i in flipped
+                seen_plain += i not in flipped
+    print("pairs checked:", seen_flip, "flipped,", seen_plain, "not flipped")
+    assert seen_flip > 50 and seen_plain > 50
+    # the refusal that is left: --broken-pairs needs an interleaved file
+    c = subprocess.run([CLI, "-r", fa, "-o", str(tmp_path / "x.sam"), "-1", fq, "-2", fq, "--broken-pairs"], capture_output=True, text=True)
+    assert c.returncode != 0 and "interleaved" in c.stderr
