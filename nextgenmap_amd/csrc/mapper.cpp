@@ -1788,11 +1788,12 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		if (m->d_sam_len.reserve((size_t) units + 1) || m->d_sam_off.reserve((size_t) units + 1)) { ngm::pipeline_set_error("out of device memory (SAM stage)"); return -12; }
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_hits.p, hits, (size_t) n * sizeof(ngm_hit), hipMemcpyHostToDevice, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_refs.p, sam_refs, (size_t) n * sizeof(ngm::SamRef), hipMemcpyHostToDevice, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 16, 0, 24, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 16, 0, 32, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the uploads -- 64 bytes per read -- travel outside the stage lock)
 		stage_sam.acquire();
 		ngm::SamArgs S{};
 		S.n = n; S.q = q; S.paired = paired ? 1 : 0;
+		S.unit_len_bound = (uint32_t) ((paired ? 2 : 1) * (2 * q + 1024));
 		S.reads = m->d_reads.p; S.quals = m->d_sam_quals.p; S.names = m->d_sam_names.p; S.meta = m->d_sam_meta.p; S.hits = m->d_sam_hits.p; S.refs = m->d_sam_refs.p;
 		S.str = m->d_str.p; S.contig_names = m->d_sam_contig_names.p; S.contig_name_off = m->d_sam_contig_off.p;
 		S.min_insert = m->sam_opt.min_insert_size; S.max_insert = m->sam_opt.max_insert_size > 0 ? m->sam_opt.max_insert_size : 2147483647;
@@ -1814,8 +1815,14 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(hipMemsetAsync(m->d_sam_len.p + units, 0, 4, m->st));
 			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_sam_len.p, m->d_sam_off.p, 0u, (size_t) units + 1, rocprim::plus<uint32_t>(), m->st));
 			uint32_t total32 = 0;
+			unsigned long long longest = 0;
 			MAP_HIP_TRY(hipMemcpyAsync(&total32, m->d_sam_off.p + units, 4, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(&longest, m->d_total.p + 19, 8, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
+			if (longest > 0) {   // a unit longer than the bound the 32-bit check above was made with: the prefix sums may have wrapped
+				ngm::pipeline_set_error("ngm_mapper_map_sam: a record of %llu bytes exceeds the %u bytes per read this batch was sized for (32-bit text offsets): use smaller batches", longest, S.unit_len_bound);
+				return -75;
+			}
 			total = total32;
 			if (m->d_sam_text.reserve((size_t) total + 16)) { ngm::pipeline_set_error("out of device memory (SAM text)"); return -12; }
 			S.out = m->d_sam_text.p;

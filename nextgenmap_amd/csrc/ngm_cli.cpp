@@ -607,6 +607,27 @@ int run_sharded(int argc, char **argv, const Opts &o) {
 	std::vector<pid_t> kids;
 	std::vector<std::string> parts;
 	for (int k = 0; k < N; ++k) parts.push_back(o.out + ".shard" + std::to_string(k));
+	// cold cache: ONE process builds the index and writes the cache files (this program with the reference only), then the shards load
+	// them -- not N builds of the same index, N times the host memory, all writing the same two files
+	{
+		const std::string enc = o.ref + "-enc.2.ngm", ht = o.ref + "-ht-" + std::to_string(o.kmer) + "-" + std::to_string(o.bs_mapping ? 0 : o.kmer_skip) + ".3.ngm";
+		if (!o.skip_save && (access(enc.c_str(), R_OK) != 0 || access(ht.c_str(), R_OK) != 0)) {
+			info("MAIN", "No index cache next to the reference: building it once before the shard processes start");
+			const pid_t pid = fork();
+			if (pid < 0) die("fork failed");
+			if (pid == 0) {
+				std::vector<std::string> a = {argv[0], "-r", o.ref, "-k", std::to_string(o.kmer), "--kmer-skip", std::to_string(o.kmer_skip), "--device", std::to_string(o.devices[0])};
+				if (o.bs_mapping) a.push_back("--bs-mapping");
+				std::vector<char *> av;
+				for (std::string &x : a) av.push_back(&x[0]);
+				av.push_back(nullptr);
+				execv("/proc/self/exe", av.data());
+				_exit(127);
+			}
+			int st = 0;
+			if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0) die("building the index failed (its messages are above)");
+		}
+	}
 	for (int k = 0; k < N; ++k) {
 		const pid_t pid = fork();
 		if (pid < 0) die("fork failed");
@@ -1227,7 +1248,7 @@ int main(int argc, char **argv) {
 				q_in.push(std::move(b));
 			}
 		} else if (o.shard_n > 1) {
-			fail("--shard needs plain (uncompressed, 4-line) FASTQ input: the shard boundaries come from the record index");
+			fail("--shard needs 4-line FASTQ input (plain, or .gz small enough to be inflated into memory): the shard boundaries come from the record index");
 		} else {
 			SeqReader in1(path0.c_str());
 			std::unique_ptr<SeqReader> in2(path1.empty() ? nullptr : new SeqReader(path1.c_str()));
@@ -1527,6 +1548,18 @@ int main(int argc, char **argv) {
 			out_cv.notify_all();
 			if (b->text) {
 				const auto t_wr = std::chrono::steady_clock::now();
+				// (NGM_HIP_WRITERS=k: the batch's text in k slices written at the same time -- experiment: one file takes 9-14 GB/s whatever the
+				// number of writers, profiles/r03_write_calibration.txt, profiles/r04_e2e_writer.txt)
+				static const int n_writers = std::max(1, getenv("NGM_HIP_WRITERS") ? atoi(getenv("NGM_HIP_WRITERS")) : 1);
+				if (b->text_len && n_writers > 1) {
+					std::vector<std::thread> io;
+					std::atomic<bool> ok{true};
+					const size_t per = ((b->text_len + n_writers - 1) / n_writers + ((size_t) 4 << 20) - 1) & ~(((size_t) 4 << 20) - 1);
+					for (size_t at = 0; at < b->text_len; at += per)
+						io.emplace_back([&, at] { if (!put_all(b->text + at, std::min(per, b->text_len - at), out_off + at)) ok = false; });
+					for (auto &t : io) t.join();
+					if (!ok) fail("write error on " + o.out);
+				} else
 				if (b->text_len && !put_all(b->text, b->text_len, out_off)) fail("write error on " + o.out);
 				out_off += b->text_len;
 				t_write_us += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wr).count();

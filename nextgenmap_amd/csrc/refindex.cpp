@@ -832,6 +832,26 @@ int ngm_ref_index_copy(const ngm_ref *r, uint32_t *counts, uint32_t *raw_counts,
 	return 0;
 }
 
+// A cache file appears under its name complete or not at all: it is written to <name>.tmp.<pid>, every write is checked, and then
+// renamed (another process -- a sibling shard, another run -- may be mapping the old file while this one is written)
+namespace {
+struct CacheFile {
+	std::string fn, tmp;
+	FILE *fp = nullptr;
+	bool ok = true;
+	explicit CacheFile(const std::string &name) : fn(name), tmp(name + ".tmp." + std::to_string((long) getpid())) { fp = fopen(tmp.c_str(), "wb"); ok = fp != nullptr; }
+	void put(const void *p, size_t size, size_t n) { if (ok && n && fwrite(p, size, n, fp) != n) ok = false; }
+	bool commit() {
+		if (fp && fclose(fp) != 0) ok = false;
+		fp = nullptr;
+		if (ok && rename(tmp.c_str(), fn.c_str()) != 0) ok = false;
+		if (!ok) (void) unlink(tmp.c_str());
+		return ok;
+	}
+	~CacheFile() { if (fp) { fclose(fp); (void) unlink(tmp.c_str()); } }
+};
+}  // namespace
+
 int ngm_ref_write_ngm_cache(const ngm_ref *r, const char *fasta_path) {
 	(void) hipSetDevice(r->device);
 	const int k = r->prm.kmer;
@@ -839,13 +859,13 @@ int ngm_ref_write_ngm_cache(const ngm_ref *r, const char *fasta_path) {
 	// ---- <ref>-enc.2.ngm -------------------------------------------------------------------------------
 	{
 		const std::string fn = std::string(fasta_path) + "-enc.2.ngm";
-		FILE *fp = fopen(fn.c_str(), "wb");
-		if (!fp) { ngm::pipeline_set_error("cannot write %s", fn.c_str()); return -13; }
+		CacheFile cf(fn);
+		if (!cf.ok) { ngm::pipeline_set_error("cannot write %s", fn.c_str()); return -13; }
 		const uint32_t cookie = 0x74656, ref_count = (uint32_t) r->contigs.size();
 		uint64_t size = 1000;  // getSize(): SequenceProvider.cpp:210-226
 		for (const NgmContig &c : r->contigs) size += ((c.len | 1) + 1) + 1000;
 		const uint64_t bin_ref_index = r->n_bases, enc_size = ((size / 2) | 1) + 1;
-		fwrite(&cookie, 4, 1, fp); fwrite(&ref_count, 4, 1, fp); fwrite(&bin_ref_index, 8, 1, fp); fwrite(&enc_size, 8, 1, fp);
+		cf.put(&cookie, 4, 1); cf.put(&ref_count, 4, 1); cf.put(&bin_ref_index, 8, 1); cf.put(&enc_size, 8, 1);
 		struct RefIdx { uint32_t SeqId, Flags; uint64_t SeqStart; uint32_t SeqLen, NameLen; char name[100]; uint32_t pad; };
 		static_assert(sizeof(RefIdx) == 128, "RefIdx layout");
 		for (size_t i = 0; i < r->contigs.size(); ++i) {
@@ -853,22 +873,22 @@ int ngm_ref_write_ngm_cache(const ngm_ref *r, const char *fasta_path) {
 			x.SeqId = (uint32_t) i; x.SeqStart = r->contigs[i].start; x.SeqLen = (uint32_t) r->contigs[i].len;
 			x.NameLen = (uint32_t) std::min<size_t>(100, r->contigs[i].name.size());
 			memcpy(x.name, r->contigs[i].name.data(), x.NameLen);
-			fwrite(&x, sizeof(x), 1, fp);
+			cf.put(&x, sizeof(x), 1);
 		}
 		// 4 bits per base, first base in the high nibble, A0 T1 G2 C3 N4 (SequenceProvider.cpp:72-85, :310-313)
 		static const uint8_t enc[8] = {0, 3, 2, 1, 4, 4, 4, 4};
 		std::vector<uint8_t> data(enc_size, 0);
 		for (uint64_t i = 0; i + 1 < r->n_bases; i += 2) data[i >> 1] = (uint8_t) ((enc[r->host_cls[i] & 7] << 4) | enc[r->host_cls[i + 1] & 7]);
-		fwrite(data.data(), 1, enc_size, fp);
-		fclose(fp);
+		cf.put(data.data(), 1, enc_size);
+		if (!cf.commit()) { ngm::pipeline_set_error("write error on %s", fn.c_str()); return -5; }
 	}
 	// ---- <ref>-ht-<k>-<skip>.3.ngm ---------------------------------------------------------------------
 	{
 		const std::string fn = std::string(fasta_path) + "-ht-" + std::to_string(k) + "-" + std::to_string(r->prm.kmer_skip) + ".3.ngm";
-		FILE *fp = fopen(fn.c_str(), "wb");
-		if (!fp) { ngm::pipeline_set_error("cannot write %s", fn.c_str()); return -13; }
+		CacheFile cf(fn);
+		if (!cf.ok) { ngm::pipeline_set_error("cannot write %s", fn.c_str()); return -13; }
 		const uint32_t cookie = 0x74656, kk = (uint32_t) k, skip = (uint32_t) r->prm.kmer_skip, units = 1, index_size = n_kmers + 1;
-		fwrite(&cookie, 4, 1, fp); fwrite(&kk, 4, 1, fp); fwrite(&skip, 4, 1, fp); fwrite(&units, 4, 1, fp); fwrite(&index_size, 4, 1, fp);
+		cf.put(&cookie, 4, 1); cf.put(&kk, 4, 1); cf.put(&skip, 4, 1); cf.put(&units, 4, 1); cf.put(&index_size, 4, 1);
 		std::vector<uint32_t> raw(n_kmers);
 		std::vector<uint2> idx(n_kmers);
 		REF_HIP_TRY(hipMemcpy(raw.data(), r->d_raw_counts, (size_t) n_kmers * 4, hipMemcpyDeviceToHost));
@@ -876,7 +896,7 @@ int ngm_ref_write_ngm_cache(const ngm_ref *r, const char *fasta_path) {
 		std::vector<uint32_t> pos(r->n_entries + 1, 0);
 		if (r->n_entries) REF_HIP_TRY(hipMemcpy(pos.data(), r->d_positions, r->n_entries * 4, hipMemcpyDeviceToHost));
 		const uint32_t table_len = (uint32_t) r->n_entries;
-		fwrite(&table_len, 4, 1, fp);
+		cf.put(&table_len, 4, 1);
 		// Index { uint m_TabIndex; char m_RevCompIndex; } packed to 5 bytes (PrefixTable.h:18-61)
 		std::vector<uint8_t> ib((size_t) index_size * 5, 0);
 		uint32_t next = 0;
@@ -893,13 +913,13 @@ int ngm_ref_write_ngm_cache(const ngm_ref *r, const char *fasta_path) {
 		}
 		const uint32_t tab = next + 1;
 		memcpy(&ib[(size_t) n_kmers * 5], &tab, 4);
-		fwrite(ib.data(), 1, ib.size(), fp);
-		fwrite(pos.data(), 4, table_len, fp);
+		cf.put(ib.data(), 1, ib.size());
+		cf.put(pos.data(), 4, table_len);
 		const uint64_t offset = 0;
-		fwrite(&offset, 8, 1, fp);
+		cf.put(&offset, 8, 1);
 		const uint32_t signature = cookie + kk + skip + units + index_size;
-		fwrite(&signature, 4, 1, fp);
-		fclose(fp);
+		cf.put(&signature, 4, 1);
+		if (!cf.commit()) { ngm::pipeline_set_error("write error on %s", fn.c_str()); return -5; }
 	}
 	return 0;
 }

@@ -26,6 +26,7 @@ struct SamMeta {            // per read
 struct SamRef { uint32_t cig_off, md_off; uint16_t cig_len, md_len; };   // the read's CIGAR / MD in the byte stream
 
 struct SamArgs {
+	uint32_t unit_len_bound;   // bytes per unit the host's 32-bit overflow check allowed for (sam_lengths_kernel reports longer units in counters[3])
 	int n, q, paired;
 	const uint8_t *reads;       // n rows of q bytes
 	const uint8_t *quals;       // n rows of q bytes
@@ -291,6 +292,10 @@ __global__ __launch_bounds__(256) void sam_lengths_kernel(SamArgs A, int units) 
 	uint32_t cnt[3] = {0, 0, 0};
 	sam_unit(A, u, s, cnt);
 	A.unit_len[u] = s.n;
+	// the batch's offsets are 32-bit prefix sums: the host bounds the batch by a per-unit length (mapper.cpp) and checks it against
+	// the longest unit here (MP:Z / RA:Z of a SLAM-seq run can outgrow any fixed estimate)
+	const uint32_t names = A.paired ? (uint32_t) A.meta[2 * u].name_len + A.meta[2 * u + 1].name_len : (uint32_t) A.meta[u].name_len;   // (counted separately by the host)
+	if (s.n > A.unit_len_bound + names) atomicMax(&A.counters[3], (unsigned long long) s.n);
 }
 __global__ __launch_bounds__(256) void sam_write_kernel(SamArgs A, int units) {
 	__shared__ uint32_t s_cnt[3];
