@@ -35,10 +35,11 @@ constexpr int kCsCanonFirstLineWords = 32;   // words of a bucket fetched blind 
 constexpr int kCsCanonRel = 8;               // table entries completed by comparison (more: general sweep 2)
 constexpr int kCsCanonDraw = 4;              // reads a persistent workgroup draws from the launch's read counter at a time
 
+// SH2: the bins are four bases wide (bin_shift 2, the default): a plane word's byte address is a mask of the diagonal.
 // T waves per read; R1 rounds of blind first-line loads (a round covers T * 64 >> glog buckets, glog = log2 of the lanes per
 // first line: 3 for buckets of 32 words and more); R2 rounds of 16-byte chunk items.  R1 and R2 are even: votes are cast in
 // steps of 8 slots (two rounds), the shape the queue bookkeeping of cs_fast2_kernel was tuned for.
-template <int T, int R1, int R2, int CH = 1, int WPE = 8>
+template <int T, int R1, int R2, int CH = 1, int WPE = 8, bool SH2 = false>
 __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ? WPE : 1, T == 3 ? WPE : 8))) void cs_canon_kernel(CsArgs A) {
 	static_assert(R1 % 2 == 0 && R2 % 2 == 0, "steps of two rounds");
 	constexpr int NT = T * 64;
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 	// uniform, so no hash is needed (two multiplies less per vote); bins that collide are a multiple of plane_bits x 4 bp apart on the
 	// same diagonal -- rare, and a collision only sends a hit through the exact table
 	const uint32_t pmask = A.plane_bits - 1u;
+	const uint32_t wmask4 = ((A.plane_bits >> 5) - 1u) << 2;   // byte address of a plane word from (bin << 2)
+	const int wbits = 31 - __clz((int) (A.plane_bits >> 5));   // log2 of the plane's words
 	const int hs = 32 - log2_slots;
 	const int cb = 2 * (k >> 1) + 1;  // the bit that tells the two k-mers of a pair apart (refindex.h)
 	// LDS operations of one wave complete in program order: the queue hand-over inside a wave needs no hardware barrier, only
@@ -285,12 +288,16 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu(T == 3 ?
 			uint32_t dup[kCsSeg], msk[kCsSeg], ent[kCsSeg];
 #pragma unroll
 			for (int j = 0; j < NSL; ++j) {
-				const uint32_t bin = ((pos[j] - corr[j]) >> A.bin_shift) & 0x3FFFFFFFu;
-				const uint32_t b = bin & pmask;
-				msk[j] = valid[j] ? (1u << (b & 31)) : 0u;      // empty slots vote with an all-zero mask: branch-free
+				// plane bit of a bin: word = its low bits, bit = the five bits above them.  With bins of four bases (bin_shift 2, the
+				// default) the word's BYTE address is a mask of the diagonal itself -- (t >> 2) & (W - 1) words = t & ((W - 1) << 2) bytes --
+				// one instruction instead of shift + mask (round 4).
 				// (the plane starts at LDS address 0 -- see Shared above -- and is addressed as such: through the symbol of the dynamic array the
 				// compiler keeps an `add 0` per vote, the symbol's address being a link-time constant)
-				dup[j] = __hip_atomic_fetch_or(&plane0[b >> 5], msk[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & msk[j];   // != 0: a repeat on its bit
+				const uint32_t t = pos[j] - corr[j];
+				const uint32_t bin = (t >> A.bin_shift) & 0x3FFFFFFFu;
+				const uint32_t wbyte = SH2 ? (t & wmask4) : ((t >> (A.bin_shift - 2)) & wmask4);   // (the fast path is not used with bins below four bases)
+				msk[j] = valid[j] ? (1u << ((bin >> wbits) & 31)) : 0u;      // empty slots vote with an all-zero mask: branch-free
+				dup[j] = __hip_atomic_fetch_or((lds_u32 *) (uintptr_t) wbyte, msk[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & msk[j];   // != 0: a repeat on its bit
 				ent[j] = bin | revf[j];
 			}
 			uint32_t ndup = 0;

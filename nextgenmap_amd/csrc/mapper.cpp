@@ -169,7 +169,8 @@ size_t cs_canon_lds_bytes(const ngm::CsArgs &A, int shape) {  // k-mer info + he
 
 // shape 1-3; shape 2 exists in variants (experiments: NGM_HIP_CS_CANON_CH = the vote step after which the chunk loads are issued,
 // NGM_HIP_CS_CANON_WPE = waves per SIMD the register allocation aims at)
-const void *cs_canon_fn(int shape, int ch, int wpe) {
+const void *cs_canon_fn(int shape, int ch, int wpe, int bin_shift = 0) {
+	if (shape == 2 && ch == 1 && wpe == 7 && bin_shift == 2) return (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 7, true>;   // the default
 	if (shape == 1) return (const void *) ngm::cs_canon_kernel<3, 4, 2, 1>;
 	if (shape == 3) return (const void *) ngm::cs_canon_kernel<4, 8, 4, 1>;
 	if (wpe <= 5) return (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 5>;   // experiments: 86 VGPRs, no scratch, 5 waves per SIMD
@@ -293,7 +294,7 @@ int run_cs(ngm_mapper *m, int n) {
 			A.buckets = r->d_cbuckets; A.bucket_log2_words = r->cbucket_log2_words; A.pos_base = r->cbucket_pos_base;
 			const size_t lds = cs_canon_lds_bytes(A, m->cs_canon) - 96;  // (the kernel has no static LDS: its shared variables are the last 160 bytes of this)
 			// persistent workgroups: as many as the GPU holds at once, each walking the reads with that stride
-			const void *fn = cs_canon_fn(m->cs_canon, m->cs_canon_ch, m->cs_canon_wpe);
+			const void *fn = cs_canon_fn(m->cs_canon, m->cs_canon_ch, m->cs_canon_wpe, A.bin_shift);
 			int per_cu = 0, cus = 0;
 			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kCanonT[m->cs_canon] * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
 			if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
@@ -717,8 +718,8 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast))
 	NGM_CS_ATTR_T(2); NGM_CS_ATTR_T(3); NGM_CS_ATTR_T(4);
 #undef NGM_CS_ATTR_T
-	for (int shape = 1; shape <= 3; ++shape) for (int ch : {0, 1, 3}) for (int wpe : {5, 6, 7, 8})
-		(void) hipFuncSetAttribute(cs_canon_fn(shape, ch, wpe), hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_canon_lds_bytes(A, shape));
+	for (int shape = 1; shape <= 3; ++shape) for (int ch : {0, 1, 3}) for (int wpe : {5, 6, 7, 8}) for (int bs : {0, 2})
+		(void) hipFuncSetAttribute(cs_canon_fn(shape, ch, wpe, bs), hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_canon_lds_bytes(A, shape));
 	// three waves per read for the 768-segment size (150 bp reads), four for the 1 536-segment one (250 bp: 12.3 instead of 14.7 ms
 	// per 524 288 reads -- with twice the work items per read the fourth wave pays for the seventh-of-a-CU it costs)
 	m->cs_waves = m->cs_fast_items == ngm::kCsFastItemsLong ? 4 : 3;

@@ -1510,7 +1510,7 @@ int main(int argc, char **argv) {
 						b->chunks[c].swap(z);
 					}
 				}
-			}, 1);
+			}, 1, o.bam ? ngm::ThreadPool::cpu_quota() : 0);   // (BAM: records + deflate keep every thread busy for the whole batch)
 			for (int c = 0; c < n_chunks; ++c) { b->n_total += ct[c]; b->n_mapped += cm[c]; b->n_written += cw[c]; }
 			{
 				std::lock_guard<std::mutex> lk(spare_mu);

@@ -31,11 +31,14 @@ public:
 		const char *e = getenv("LOCAL_WORLD_SIZE");
 		if (!e) e = getenv("WORLD_SIZE");
 		const int ranks = std::max(1, e ? atoi(e) : 1);
-		return std::max(1, std::min(64, std::min((int) std::thread::hardware_concurrency(), cpu_quota()) / ranks));
+		// (not capped by the quota: the host stages of the mapping path are short bursts between GPU stages -- far below the quota on
+		// average -- and a burst on 64 threads ends sooner than on 16; loops that keep every thread busy for long pass cpu_quota() as
+		// their limit instead: BAM records + deflate)
+		return std::max(1, std::min(64, (int) std::thread::hardware_concurrency() / ranks));
 	}
 	// CPUs this process may use at once: the cgroup's CFS quota (containers: /sys/fs/cgroup/cpu.max "quota period") when there is one.
-	// More runnable threads than that do not just queue -- the group is throttled for the rest of every period, all threads at once,
-	// and 64 busy threads under a 16-CPU quota get LESS done than 16 (profiles/r04_cpu_quota_probe.txt: 12.2 x against 15.6 x one thread)
+	// More threads than that, busy for long, do not just queue -- the group is throttled for the rest of every period, all threads at
+	// once, and 64 busy threads under a 16-CPU quota get LESS done than 16 (profiles/r04_cpu_quota_probe.txt: 12.2 x against 15.6 x one thread)
 	static int cpu_quota() {
 		int cpus = 1 << 20;
 		if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -55,14 +58,16 @@ public:
 	int size() const { return (int) workers_.size() + 1; }
 
 	// f(lo, hi) over [0, n) in chunks of at least min_grain items; returns when all of it is done
+	// max_threads > 0: at most that many threads work on this loop at a time (sustained CPU-bound loops under a CPU quota)
 	template <typename F>
-	void parallel_for(int n, F &&f, int min_grain = 1024) {
+	void parallel_for(int n, F &&f, int min_grain = 1024, int max_threads = 0) {
 		if (n <= 0) return;
 		int chunks = std::min(size() * 4, std::max(1, n / std::max(1, min_grain)));
 		if (chunks <= 1 || workers_.empty()) { f(0, n); return; }
 		auto job = std::make_shared<Job>();
 		job->fn = [&f](int lo, int hi) { f(lo, hi); };
 		job->n = n; job->chunks = chunks; job->next.store(0); job->done.store(0);
+		job->limit = max_threads; job->active.store(1);   // (the caller)
 		{
 			std::lock_guard<std::mutex> lk(mu_);
 			jobs_.push_back(job);
@@ -90,7 +95,8 @@ private:
 	struct Job {
 		std::function<void(int, int)> fn;
 		int n = 0, chunks = 0;
-		std::atomic<int> next{0}, done{0};
+		std::atomic<int> next{0}, done{0}, active{0};
+		int limit = 0;
 		std::mutex mu;
 		std::condition_variable cv;
 	};
@@ -116,13 +122,13 @@ private:
 				std::unique_lock<std::mutex> lk(mu_);
 				cv_.wait(lk, [&] {
 					if (stop_) return true;
-					for (auto &j : jobs_) if (j->next.load() < j->chunks) return true;
+					for (auto &j : jobs_) if (j->next.load() < j->chunks && (j->limit <= 0 || j->active.load() < j->limit)) return true;
 					return false;
 				});
 				if (stop_) return;
-				for (auto &j : jobs_) if (j->next.load() < j->chunks) { job = j; break; }
+				for (auto &j : jobs_) if (j->next.load() < j->chunks && (j->limit <= 0 || j->active.load() < j->limit)) { job = j; j->active.fetch_add(1); break; }
 			}
-			if (job) run_chunks(*job);
+			if (job) { run_chunks(*job); job->active.fetch_sub(1); }
 		}
 	}
 	std::vector<std::thread> workers_;
