@@ -88,6 +88,9 @@ struct ngm_mapper {
 	uint64_t st_heavy = 0, st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0;
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
+	hipStream_t st_copy = nullptr;                  // the per-read arrays of a search travel to the host beside the score stage's kernels, not in front of them
+	hipEvent_t ev_cs_done = nullptr, ev_cs_copied = nullptr;
+	bool cs_copy_pending = false;
 	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank, d_order_scratch, d_order_info, d_order_big, d_order_gt, d_order_log2;
 	ngm::DevBuf<uint64_t> d_order_off;
 	ngm::CsArgs order_args{};                       // arguments of the replay in flight
@@ -471,11 +474,22 @@ int run_cs(ngm_mapper *m, int n) {
 			std::vector<unsigned long long> ctr(ctr_words + 16);
 			MAP_HIP_TRY(hipMemcpyAsync(ctr.data(), m->d_counters.p, ctr.size() * 8, hipMemcpyDeviceToHost, m->st));
 			if (m->h_base.b.reserve(n) || m->h_count.b.reserve(n) || m->h_maxv.b.reserve(n)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
-			MAP_HIP_TRY(hipMemcpyAsync(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipMemcpyAsync(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipMemcpyAsync(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
+			// the host needs the number of candidates now (it sizes the score stage); the per-read arrays (12 bytes per read) only after the
+			// score stage (cs_host_arrays): an experiment lets them travel on a stream of their own under its kernels
+			uint32_t last[2] = {0, 0};
+			MAP_HIP_TRY(hipMemcpyAsync(&last[0], m->d_cand_base.p + (n - 1), 4, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(&last[1], m->d_cand_count.p + (n - 1), 4, hipMemcpyDeviceToHost, m->st));
+			// (NGM_HIP_CS_COPY_SIDE_STREAM=1: measured on one box, three runs each -- 49.8 / 52.0 / 51.5 M reads/s with the side stream against
+			// 55.0 / 52.1 / 54.8 without: the copies are blit kernels either way, and a second stream only adds their scheduling: not the default)
+			static const bool side = getenv("NGM_HIP_CS_COPY_SIDE_STREAM") != nullptr;
+			hipStream_t cst = (side && m->st_copy && m->ev_cs_done && m->ev_cs_copied) ? m->st_copy : m->st;
+			if (cst != m->st) { MAP_HIP_TRY(hipEventRecord(m->ev_cs_done, m->st)); MAP_HIP_TRY(hipStreamWaitEvent(cst, m->ev_cs_done, 0)); }
+			MAP_HIP_TRY(hipMemcpyAsync(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost, cst));
+			MAP_HIP_TRY(hipMemcpyAsync(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost, cst));
+			MAP_HIP_TRY(hipMemcpyAsync(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost, cst));
+			if (cst != m->st) { MAP_HIP_TRY(hipEventRecord(m->ev_cs_copied, cst)); m->cs_copy_pending = true; }
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
-			m->n_cand = n > 0 ? (uint64_t) m->h_base[n - 1] + m->h_count[n - 1] : 0;
+			m->n_cand = (uint64_t) last[0] + last[1];
 			{
 				// the 32-bit prefix sums wrap silently: cross-check the total against the 64-bit candidate counters
 				unsigned long long sum = 0;
@@ -498,6 +512,14 @@ int run_cs(ngm_mapper *m, int n) {
 	}
 	ngm::pipeline_set_error("candidate buffer overflow persists");
 	return -75;
+}
+
+// h_base / h_count / h_maxv of the last search are complete (see the end of run_cs)
+int cs_host_arrays(ngm_mapper *m) {
+	if (!m->cs_copy_pending) return 0;
+	MAP_HIP_TRY(hipEventSynchronize(m->ev_cs_copied));
+	m->cs_copy_pending = false;
+	return 0;
 }
 
 int upload_reads(ngm_mapper *m, int n, const char *reads) {
@@ -630,6 +652,9 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		int lo = 0, hi = 0;
 		(void) hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = greatest priority
 		if (hipStreamCreateWithPriority(&m->st_hi, hipStreamNonBlocking, hi) != hipSuccess) m->st_hi = nullptr;
+		if (hipStreamCreateWithFlags(&m->st_copy, hipStreamNonBlocking) != hipSuccess) m->st_copy = nullptr;
+		if (hipEventCreateWithFlags(&m->ev_cs_done, hipEventDisableTiming) != hipSuccess) m->ev_cs_done = nullptr;
+		if (hipEventCreateWithFlags(&m->ev_cs_copied, hipEventDisableTiming) != hipSuccess) m->ev_cs_copied = nullptr;
 	}
 	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
@@ -746,6 +771,9 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	DevGuard g(m->ref->device);
 	(void) hipStreamSynchronize(m->st);
 	if (m->st_hi) { (void) hipStreamSynchronize(m->st_hi); (void) hipStreamDestroy(m->st_hi); }
+	if (m->st_copy) { (void) hipStreamSynchronize(m->st_copy); (void) hipStreamDestroy(m->st_copy); }
+	if (m->ev_cs_done) (void) hipEventDestroy(m->ev_cs_done);
+	if (m->ev_cs_copied) (void) hipEventDestroy(m->ev_cs_copied);
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
 	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_read2.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
 	m->d_gt_votes.release(); m->d_heavy_list.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
@@ -771,6 +799,7 @@ int ngm_mapper_cs(ngm_mapper *m, int n, const char *reads, uint32_t *cand_offset
 	if (int r = upload_reads(m, n, reads)) return r;
 	m->cs_paired = false;
 	if (int r = run_cs(m, n)) return r;
+	if (int r = cs_host_arrays(m)) return r;
 	uint32_t acc = 0;
 	for (int i = 0; i < n; ++i) { cand_offsets[i] = acc; acc += m->h_count[i]; max_votes[i] = m->h_maxv[i]; }
 	cand_offsets[n] = acc;
@@ -1203,6 +1232,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	const uint64_t np = m->n_cand;
 	lap(0);
 	if (const char *dump = getenv("NGM_HIP_DUMP_COUNTS")) {  // diagnostics: candidates per read, appended batch after batch
+		if (int rc = cs_host_arrays(m)) return rc;
 		if (FILE *f = fopen(dump, "ab")) { fwrite(m->h_count.data(), 4, (size_t) n, f); fclose(f); }
 	}
 
@@ -1211,7 +1241,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	uint32_t *h_winner = m->p_winner.p, *h_loc = m->p_loc.p, *h_sv = m->p_sv.p;
 	int32_t *h_mapq = m->p_mapq.p, *h_nbest = m->p_nbest.p;
 	float *h_best = m->p_best.p, *h_scores = m->p_scores.p;
-	if (np == 0) for (int i = 0; i < n; ++i) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; h_nbest[i] = 0; h_best[i] = 0.f; }
+	if (np == 0) { if (int rc = cs_host_arrays(m)) return rc; for (int i = 0; i < n; ++i) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; h_nbest[i] = 0; h_best[i] = 0.f; } }
 	std::vector<int> pair_flags(n, 0);
 	if (np > 0) {
 		// ---- score stage: all candidates of the batch in one BatchScore -------------------------------------
@@ -1251,6 +1281,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		if (paired) MAP_HIP_TRY(hipMemcpyAsync(h_scores, m->d_scores.p, np * 4, hipMemcpyDeviceToHost, m->st));
 		stage_cs.done_after(m->ev[4]);
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
+		if (int rc = cs_host_arrays(m)) return rc;
 		lap(1);
 		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
 		if ((!paired || m->fast_pairing) && m->prm.topn <= 1 && !position_order) {
