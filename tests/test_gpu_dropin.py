@@ -136,9 +136,16 @@ def test_shards_concatenate_to_the_single_run(tmp_path, layout):
     cat = str(tmp_path / "cat.sam")
     open(cat, "w").write("".join(parts))
     multi = str(tmp_path / "multi.sam")
+    if not paired:   # a cold index cache: ONE process builds and writes it before the shard processes start, complete files only
+        import glob
+        for fn in glob.glob(fa + "-*.ngm"):
+            os.remove(fn)
     c = subprocess.run([CLI, "-r", fa, "-o", multi, "--batch-size", "1024", "-g", "0,0", "--shard-output"] + inp, capture_output=True, text=True)
     assert c.returncode == 0, c.stderr[-2000:]
     assert "2 shards appended" in c.stderr and not os.path.exists(multi + ".shard1")
+    if not paired:
+        assert "building it once" in c.stderr and c.stderr.count("Reading reference index from") == 2, c.stderr[-3000:]
+        assert not glob.glob(fa + "-*.tmp.*") and len(glob.glob(fa + "-*.ngm")) == 2
     a, b, m = _body(one), _body(cat), _body(multi)
     assert len(a) == len(b) == len(m) and len([l for l in a if not l.startswith("@")]) == n
     if not paired:

@@ -137,3 +137,34 @@ def test_single_end_linear_personality_through_the_drop_in(world):
     assert set(a) == set(b) and len(a) == n // 4
     diff = _report("linear personality (drop-in)", a, b, c.stderr)
     assert len(diff) == 0, len(diff)
+
+
+def test_weighted_slam_seq_search_on_a_heavy_tailed_genome(world):
+    """`--slam-seq 4` (float votes in the reference's order, csrc/cs_slam_device.h) where reads carry tens of thousands of hits and the
+    persistent workgroups' slices are too small for some of them: the reference's own candidate search on the host (the drop-in)
+    against ngm-hip, 4 000 reads with T > C conversions."""
+    import numpy as np
+    dropin = os.path.join(ROOT, "oracle", "_ref", "dropin", "ngm-core-hip")
+    if not os.path.exists(dropin):
+        pytest.skip("drop-in build not present (oracle/build_dropin.sh)")
+    d = world["dir"]
+    rng = np.random.default_rng(5)
+    fq = str(d / "slam.fq")
+    with open(str(d / "se.fq"), "rb") as f, open(fq, "wb") as g:
+        for i in range(4000):
+            name, seq, plus, qual = f.readline(), bytearray(f.readline()), f.readline(), f.readline()
+            for j in range(len(seq) - 1):
+                if seq[j] == ord("T") and rng.random() < 0.06:
+                    seq[j] = ord("C")
+            g.write(name + bytes(seq) + plus + qual)
+    ref_sam, hip_sam = str(world["refdir"] / "slam.sam"), str(d / "slam_hip.sam")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "nextgenmap_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([dropin, "-r", world["ref_fa"], "-q", fq, "-o", ref_sam, "-t", "1", "--no-progress", "--slam-seq", "4"], capture_output=True, text=True,
+                       cwd=str(world["refdir"]), env=env, timeout=3000)
+    assert "Done" in r.stdout + r.stderr, (r.stdout + r.stderr)[-1500:]
+    c = subprocess.run([CLI, "-r", world["fa"], "-q", fq, "-o", hip_sam, "--slam-seq", "4"], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    a, b = _sam(ref_sam), _sam(hip_sam)
+    assert set(a) == set(b) and len(a) == 4000
+    diff = _report("weighted SLAM-seq search (drop-in)", a, b, c.stderr)
+    assert len(diff) == 0, len(diff)
