@@ -88,6 +88,8 @@ struct ngm_mapper {
 	uint64_t st_heavy = 0, st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0;
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
+	hipEvent_t turn_ev[16] = {};                     // GpuStage: the events that end this instance's turns
+	unsigned turn_next = 0;
 	hipStream_t st_copy = nullptr;                  // the per-read arrays of a search travel to the host beside the score stage's kernels, not in front of them
 	hipEvent_t ev_cs_done = nullptr, ev_cs_copied = nullptr;
 	bool cs_copy_pending = false;
@@ -192,10 +194,67 @@ size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
 	return w * 4;
 }
 
+// ---- whose kernels run now ------------------------------------------------------------------------------------------------
+// GPU stages (candidate search + score, align, SAM text: each from its first launch to the end of its last kernel) of the mapper
+// instances of one process take turns: kernels of different instances then do not slow each other down, while the host stages of one
+// instance -- and, since round 4, the downloads behind a stage's last kernel -- overlap the GPU stages of the others.
+// NGM_HIP_GPU_STAGE_LOCK: 0 no turns (streams share the GPU), 1 one lock per device (default), 2 one lock per stage kind (search + score
+// | align + SAM text).
+// NGM_HIP_STAGE_CHAIN=1 (experiment, round 4): the turn passed ON THE GPU -- the host mutex held only while kernels are enqueued, the stream
+// made to wait for the event behind the previous holder's kernels (hipStreamWaitEvent), every host synchronisation inside a stage ending
+// the turn so that another instance's kernels fill the gap.  Measured on one box, 20 steps, twice each: 51.6 / 47.3 M reads/s chained
+// against 54.8 / 51.3 with the host lock (three and four instances chained: 47.0 / 49.2): the cross-stream waits and the longer way of
+// a batch through finer turns cost more than the idle time they remove.  Not the default.
+struct StageChain { std::mutex mu; hipEvent_t last = nullptr; };
+StageChain g_chain[16][2];
+std::atomic<long long> g_stage_hold_us[3], g_stage_wait_us[3];   // diagnostics (NGM_HIP_HOST_TIMING): turn held / waited for on the host, per stage kind (0 search + score, 1 align, 2 SAM text)
+struct GpuStage {
+	ngm_mapper *m;
+	int kind, slot;
+	bool held = false;
+	StageChain *ch = nullptr;
+	std::chrono::steady_clock::time_point t_acq;
+	static int mode() { static const int v = getenv("NGM_HIP_GPU_STAGE_LOCK") ? atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) : 1; return v; }
+	static bool chained() { static const bool v = getenv("NGM_HIP_STAGE_CHAIN") && atoi(getenv("NGM_HIP_STAGE_CHAIN")) != 0; return v; }
+	GpuStage(ngm_mapper *m_, int kind_ = 0, bool now = true, int slot_ = -1) : m(m_), kind(kind_), slot(slot_ < 0 ? kind_ : slot_) {
+		ch = &g_chain[(unsigned) m->ref->device & 15u][mode() == 2 ? kind : 0];
+		if (now) acquire();
+	}
+	~GpuStage() { release(); }
+	void acquire() {   // before kernels are enqueued
+		if (mode() == 0 || held) return;
+		const auto t0 = std::chrono::steady_clock::now();
+		ch->mu.lock();
+		held = true;
+		t_acq = std::chrono::steady_clock::now();
+		g_stage_wait_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(t_acq - t0).count();
+		if (chained() && ch->last) (void) hipStreamWaitEvent(m->st, ch->last, 0);
+	}
+	void release() {   // the kernels of this turn have been enqueued (chained) / have finished (host lock)
+		if (!held) return;
+		if (chained()) {
+			hipEvent_t e = m->turn_ev[m->turn_next++ & 15u];
+			if (e && hipEventRecord(e, m->st) == hipSuccess) ch->last = e;
+		}
+		g_stage_hold_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_acq).count();
+		held = false;
+		ch->mu.unlock();
+	}
+	// the stage's last kernel has been enqueued and `ev` recorded behind it; copies to the host follow: chained, the turn ends here
+	void kernels_done() { if (chained()) release(); }
+	// ... host lock: it ends when that kernel has finished, not when the copies have (the next instance's kernels run under them)
+	void done_after(hipEvent_t ev) { if (held && !chained()) (void) hipEventSynchronize(ev); release(); }
+	void done() { release(); }
+	// a host synchronisation inside a stage: chained, the turn is passed on first (and taken again by the next acquire)
+	void before_sync() { if (chained()) release(); }
+};
+
 // candidate search for the reads already in m->d_reads; leaves per-read base/count/max votes and the
 // candidate arrays in HBM (and base/count/max votes on the host)
-int run_cs(ngm_mapper *m, int n) {
+int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 	const ngm_ref *r = m->ref;
+	auto hold = [&] { if (stage) stage->acquire(); };       // before kernels are enqueued
+	auto yield = [&] { if (stage) stage->before_sync(); };   // before the host waits for the stream
 	const int q = m->prm.qry_max_len;
 	if (n <= 0) { m->n_reads = 0; m->n_cand = 0; return 0; }
 	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) || m->d_max_both.reserve(n) ||
@@ -212,6 +271,7 @@ int run_cs(ngm_mapper *m, int n) {
 		// candidate offsets are 32-bit (base = region * capacity + cursor; the prefix sums over the counts)
 		if (cap + fixed_slots >= 0xFFFFFFFFull) { ngm::pipeline_set_error("more than 2^32 candidate slots needed for %d reads: use smaller batches or a higher sensitivity", n); return -75; }
 		if (m->d_out_loc.reserve(cap + fixed_slots) || m->d_out_sv.reserve(cap + fixed_slots) || m->d_out_loc2.reserve(cap + fixed_slots) || m->d_out_sv2.reserve(cap + fixed_slots)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
+		hold();
 		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 16) * 8, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 32) * 8, m->st));
@@ -254,6 +314,7 @@ int run_cs(ngm_mapper *m, int n) {
 			A.gtable_keys = m->d_gt_keys.p;
 			hipLaunchKernelGGL(ngm::cs_slam_kernel, dim3(grid), dim3(64), lds, m->st, A);
 			MAP_HIP_TRY(hipGetLastError());
+			yield();
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 			if (status[1] > 0) {
@@ -269,6 +330,7 @@ int run_cs(ngm_mapper *m, int n) {
 					uint32_t j1 = j0;
 					while (j1 < no && (j1 == j0 || total + ngm::cs_slam_words(qh[j1]) <= kPoolWords)) { off[j1] = total; lg[j1] = ngm::cs_slam_log2_slots(qh[j1]); total += ngm::cs_slam_words(qh[j1]); ++j1; }
 					if (m->d_gt_keys.reserve(total)) { ngm::pipeline_set_error("out of device memory (weighted SLAM-seq search, %llu words)", (unsigned long long) total); return -12; }
+					hold();
 					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, qr.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, m->st));
 					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, m->st));
 					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, m->st));
@@ -276,6 +338,7 @@ int run_cs(ngm_mapper *m, int n) {
 					Q.read_list = m->d_ovf_read2.p; Q.ovf_log2 = m->d_ovf_log2.p; Q.ovf_table_off = m->d_ovf_off.p; Q.gtable_keys = m->d_gt_keys.p;
 					hipLaunchKernelGGL(ngm::cs_slam_kernel, dim3(j1 - j0), dim3(64), lds, m->st, Q);
 					MAP_HIP_TRY(hipGetLastError());
+					yield();
 					MAP_HIP_TRY(hipStreamSynchronize(m->st));
 					j0 = j1;
 				}
@@ -345,6 +408,7 @@ int run_cs(ngm_mapper *m, int n) {
 		else hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
 		MAP_HIP_TRY(hipGetLastError());
 		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
+		yield();
 		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		timed(0);
@@ -371,6 +435,7 @@ int run_cs(ngm_mapper *m, int n) {
 				MAP_HIP_TRY(hipStreamSynchronize(m->st));
 				for (uint32_t i = 0; i < no; ++i) lists[round == 1 ? 3 : qh[i] <= classes[0].max_hits ? 0 : qh[i] <= classes[1].max_hits ? 1 : qh[i] <= classes[2].max_hits ? 2 : 3].push_back(qr[i]);
 				if (m->d_heavy_list.reserve(no)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
+				hold();
 				MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
 				MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
 				uint32_t off = 0;
@@ -386,6 +451,7 @@ int run_cs(ngm_mapper *m, int n) {
 					off += cnt;
 				}
 				MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
+				yield();
 				MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 				MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the lists live until here)
 				if (hipEventElapsedTime(&t_heavy[round], m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t_heavy[round];
@@ -408,6 +474,7 @@ int run_cs(ngm_mapper *m, int n) {
 		if (status[1] > 0) {
 			// pass 2 -- EXACT path, table in LDS, for the reads the fast path could not certify
 			const uint32_t no = status[1];
+			hold();
 			if (!bs) MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
 			MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
 			ngm::CsArgs B = A;
@@ -418,6 +485,7 @@ int run_cs(ngm_mapper *m, int n) {
 			hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactLds>, dim3(no), dim3(64), cs_lds_bytes(B, ngm::kCsExactLds), m->st, B);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
+			yield();
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 			timed(2);
@@ -443,6 +511,7 @@ int run_cs(ngm_mapper *m, int n) {
 				ngm::pipeline_set_error("out of device memory (overflow vote tables, %llu slots)", (unsigned long long) total_slots);
 				return -12;
 			}
+			hold();
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data(), no * 8, hipMemcpyHostToDevice, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data(), no * 4, hipMemcpyHostToDevice, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
@@ -453,6 +522,7 @@ int run_cs(ngm_mapper *m, int n) {
 			hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactGlobal>, dim3(no), dim3(64), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->cev[5], m->st));
+			yield();
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 			timed(4);
@@ -460,6 +530,7 @@ int run_cs(ngm_mapper *m, int n) {
 		}
 		if (status[0] == 0) {
 			// regions -> one dense candidate array in read order
+			hold();
 			size_t tmp_bytes = 0;
 			(void) rocprim::exclusive_scan(nullptr, tmp_bytes, m->d_cand_count.p, m->d_new_base.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), m->st);
 			if (m->d_scan_tmp.reserve(tmp_bytes + 16)) { ngm::pipeline_set_error("out of device memory (scan)"); return -12; }
@@ -468,6 +539,7 @@ int run_cs(ngm_mapper *m, int n) {
 					m->d_out_loc.p, m->d_out_sv.p, m->d_out_loc2.p, m->d_out_sv2.p);
 			MAP_HIP_TRY(hipGetLastError());
 			std::swap(m->d_out_loc, m->d_out_loc2); std::swap(m->d_out_sv, m->d_out_sv2); std::swap(m->d_cand_base, m->d_new_base);
+			yield();
 			m->last_cs = A;
 			m->cs_region_cap = cap;
 			m->n_reads = n;
@@ -537,27 +609,6 @@ std::atomic<int> g_live_mappers{0};  // mapper instances share the host cores
 // instance still overlap the GPU stages of the others (NGM_HIP_GPU_STAGE_LOCK=0: let the streams share the GPU)
 // NGM_HIP_GPU_STAGE_LOCK=2: one lock per stage KIND -- the align stage of one instance (1 wave per SIMD, hardly any LDS) may then
 // run under the search stage of another (LDS-bound at 10 waves per CU), only stages of the same kind take turns.
-std::mutex g_gpu_stage_mu[2];
-std::atomic<long long> g_stage_hold_us[3], g_stage_wait_us[3];   // diagnostics (NGM_HIP_HOST_TIMING): lock held / waited for, per stage kind (0 search + score, 1 align, 2 SAM text)
-struct GpuStage {
-	std::unique_lock<std::mutex> lk;
-	int kind, slot;
-	std::chrono::steady_clock::time_point t_acq;
-	explicit GpuStage(int kind_ = 0, bool now = true, int slot_ = -1) : kind(kind_), slot(slot_ < 0 ? kind_ : slot_) { if (now) acquire(); }
-	void acquire() {
-		static const int mode = getenv("NGM_HIP_GPU_STAGE_LOCK") ? atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) : 1;
-		if (mode == 0 || lk.owns_lock()) return;
-		const auto t0 = std::chrono::steady_clock::now();
-		lk = std::unique_lock<std::mutex>(g_gpu_stage_mu[mode == 2 ? kind : 0]);
-		t_acq = std::chrono::steady_clock::now();
-		g_stage_wait_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(t_acq - t0).count();
-	}
-	void done() { if (lk.owns_lock()) { g_stage_hold_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_acq).count(); lk.unlock(); } }
-	// the stage's last KERNEL has been enqueued and `ev` recorded behind it; copies to the host follow on the same stream: the lock is
-	// passed on when the kernels are done, not when the copies are -- the next instance's kernels run under this one's downloads
-	// (round 4: the GPU sat idle for ~2 ms per launch behind 14 MB + 50 MB of result copies)
-	void done_after(hipEvent_t ev) { if (lk.owns_lock()) { (void) hipEventSynchronize(ev); done(); } }
-};
 // per-read host loops run on the process-wide persistent pool (thread_pool.h): shared by the mapper instances, sized
 // to this rank's share of the host cores; no threads are started per call
 template <typename F>
@@ -653,6 +704,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 		(void) hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = greatest priority
 		if (hipStreamCreateWithPriority(&m->st_hi, hipStreamNonBlocking, hi) != hipSuccess) m->st_hi = nullptr;
 		if (hipStreamCreateWithFlags(&m->st_copy, hipStreamNonBlocking) != hipSuccess) m->st_copy = nullptr;
+		for (auto &e : m->turn_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
 		if (hipEventCreateWithFlags(&m->ev_cs_done, hipEventDisableTiming) != hipSuccess) m->ev_cs_done = nullptr;
 		if (hipEventCreateWithFlags(&m->ev_cs_copied, hipEventDisableTiming) != hipSuccess) m->ev_cs_copied = nullptr;
 	}
@@ -772,6 +824,13 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	(void) hipStreamSynchronize(m->st);
 	if (m->st_hi) { (void) hipStreamSynchronize(m->st_hi); (void) hipStreamDestroy(m->st_hi); }
 	if (m->st_copy) { (void) hipStreamSynchronize(m->st_copy); (void) hipStreamDestroy(m->st_copy); }
+	// (no other instance may be left waiting for an event of this one: its kernels have finished -- the stream was synchronised above)
+	for (int k2 = 0; k2 < 2; ++k2) {
+		StageChain &c = g_chain[(unsigned) m->ref->device & 15u][k2];
+		std::lock_guard<std::mutex> lk(c.mu);
+		for (auto &e : m->turn_ev) if (e && c.last == e) c.last = nullptr;
+	}
+	for (auto &e : m->turn_ev) if (e) (void) hipEventDestroy(e);
 	if (m->ev_cs_done) (void) hipEventDestroy(m->ev_cs_done);
 	if (m->ev_cs_copied) (void) hipEventDestroy(m->ev_cs_copied);
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
@@ -1225,9 +1284,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_meta.p, sam->meta, (size_t) n * sizeof(ngm::SamMeta), hipMemcpyHostToDevice, m->st));
 		hits = m->p_sam_hits.p;
 	}
-	GpuStage stage_cs;
+	GpuStage stage_cs(m);
 	m->cs_paired = paired;
-	if (int rc = run_cs(m, n)) return rc;
+	if (int rc = run_cs(m, n, &stage_cs)) return rc;
 	MAP_HIP_TRY(hipEventRecord(m->ev[1], m->st));
 	const uint64_t np = m->n_cand;
 	lap(0);
@@ -1248,6 +1307,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		if (m->d_pair_read.reserve(np) || m->d_scores.reserve(np) || m->d_winner.reserve(n) || m->d_mapq.reserve(n) || m->d_nbest.reserve(n) ||
 				m->d_best.reserve(n)) { ngm::pipeline_set_error("out of device memory (score stage)"); return -12; }
 		if (int rc = ngm::engine_reserve(eng, (int) np)) { ngm::pipeline_set_error("%s", ngm_hip_last_error(eng)); return rc; }
+		stage_cs.acquire();
 		hipLaunchKernelGGL(ngm::expand_pairs_kernel, dim3(n), dim3(64), 0, m->st, n, m->d_cand_base.p, m->d_cand_count.p, m->d_pair_read.p);
 		const int nb = (int) ((np + ngm::kSlots - 1) / ngm::kSlots);
 		ngm::WindowGeom Gs{r->n_bases - 1, ((q + c) | 1) + 1, c >> 1};  // refMaxLen of ScoreBuffer.h:112
@@ -1272,6 +1332,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_info.p, m->d_pair_info.p, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost, m->st));
 		}
 		MAP_HIP_TRY(hipEventRecord(m->ev[4], m->st));
+		stage_cs.kernels_done();
 		MAP_HIP_TRY(hipMemcpyAsync(h_winner, m->d_winner.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_mapq, m->d_mapq.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_nbest, m->d_nbest.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
@@ -1653,7 +1714,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	const int align_buf_len = (q + c) | 2;  // AlignmentBuffer.h:67: (qry_max_len + corridor) | 1 + 1
 	static const bool dev_strings = !getenv("NGM_HIP_HOST_CIGAR");
 	uint64_t str_base = 0;   // bytes of the device's CIGAR / MD stream (host-built strings of the SAM stage go behind them)
-	GpuStage stage_align(1, false);
+	GpuStage stage_align(m, 1, false);
 	if (na > 0) {
 		if (m->d_a_read.reserve(na) || m->d_a_loc.reserve(na) || m->d_a_sv.reserve(na) || m->d_records.reserve((size_t) na * 8) ||
 				m->d_runs.reserve((size_t) na * rs)) { ngm::pipeline_set_error("out of device memory (align stage)"); return -12; }
@@ -1680,7 +1741,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				m->d_runs_c.p, m->d_total.p);
 		MAP_HIP_TRY(hipGetLastError());
 		unsigned long long n_runs_total = 0, n_str_total = 0;
-		if (!dev_strings) MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st));   // (behind the stage's last kernel)
+		if (!dev_strings) { MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st)); stage_align.kernels_done(); }   // (behind the stage's last kernel)
 		// CIGAR / MD / NM / identity on the GPU (cigar_device.h); NGM_HIP_HOST_CIGAR=1 keeps the host builders (tests)
 		if (dev_strings) {
 			const unsigned long long scap = (unsigned long long) na * 96ull + 4096ull;
@@ -1695,6 +1756,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					(unsigned long long *) (m->d_total.p + 8), alt_cigar);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st));
+			stage_align.kernels_done();
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_cigout.p, m->d_cigout.p, (size_t) na * sizeof(ngm::CigarDevOut), hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(&n_str_total, m->d_total.p + 8, 8, hipMemcpyDeviceToHost, m->st));
 		}
@@ -1800,7 +1862,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	lap(4);
 	if (sam) {
 		// ---- SAM text on the GPU: lengths per unit, exclusive prefix sum, bytes (sam_device.h) ------------------------------
-		GpuStage stage_sam(1, false, 2);
+		GpuStage stage_sam(m, 1, false, 2);
 		const int units = paired ? n / 2 : n;
 		if (!extra.empty()) {
 			// the byte stream grows by the host-built strings (rare: strings beyond the device's scratch rows)
@@ -1848,6 +1910,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_sam_len.p, m->d_sam_off.p, 0u, (size_t) units + 1, rocprim::plus<uint32_t>(), m->st));
 			uint32_t total32 = 0;
 			unsigned long long longest = 0;
+			stage_sam.before_sync();
 			MAP_HIP_TRY(hipMemcpyAsync(&total32, m->d_sam_off.p + units, 4, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(&longest, m->d_total.p + 19, 8, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
@@ -1858,10 +1921,12 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			total = total32;
 			if (m->d_sam_text.reserve((size_t) total + 16)) { ngm::pipeline_set_error("out of device memory (SAM text)"); return -12; }
 			S.out = m->d_sam_text.p;
+			stage_sam.acquire();
 			hipLaunchKernelGGL(ngm::sam_write_kernel, dim3((units + 255) / 256), dim3(256), 0, m->st, S, units);
 			MAP_HIP_TRY(hipGetLastError());
 		}
 		MAP_HIP_TRY(hipEventRecord(e1, m->st));
+		stage_sam.kernels_done();
 		unsigned long long ctr[3] = {0, 0, 0};
 		MAP_HIP_TRY(hipMemcpyAsync(ctr, m->d_total.p + 16, 24, hipMemcpyDeviceToHost, m->st));
 		m->sam_text_bytes = total;
