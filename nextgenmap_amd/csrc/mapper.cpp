@@ -1366,7 +1366,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						if (h_rank[b + c] == ngm::kCsOrderUnknown) { known = false; break; }
 						if (h_rank[b + c] < pick_rank) { pick_rank = h_rank[b + c]; pick = b + c; }
 					}
-					if (known && pick != 0xFFFFFFFFu) h_winner[i] = pick;
+					// (without a positive score top1SE keeps the FIRST candidate, whatever its score: AS:i is that candidate's -- end-to-end mode)
+					if (known && pick != 0xFFFFFFFFu) { h_winner[i] = pick; h_best[i] = h_scores[pick]; }
 				}
 			}
 		}
@@ -1536,7 +1537,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 							if (h_rank_pe[b + c2] == ngm::kCsOrderUnknown) return;
 							if (h_rank_pe[b + c2] < pick_rank) { pick_rank = h_rank_pe[b + c2]; pick = b + c2; }
 						}
-						if (pick != 0xFFFFFFFFu) h_winner[i] = pick;
+						if (pick != 0xFFFFFFFFu) { h_winner[i] = pick; h_best[i] = h_scores[pick]; }
 					};
 					// ... but when both mates have candidates top1PE has already SORTED the arrays before it falls back to
 					// top1SE (ScoreBuffer.cpp:373-376, 449-455): the first of the best is the head of that (unstable) sort
@@ -1546,7 +1547,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						bool ranked = false;
 						std::vector<uint32_t> v(m->h_count[i]);
 						sort_like_reference(v.data(), m->h_base[i], m->h_count[i], h_loc, h_sv, h_scores, h_rank_pe, &ranked);
-						if (ranked) h_winner[i] = v[0];
+						if (ranked) { h_winner[i] = v[0]; h_best[i] = h_scores[v[0]]; }
 					};
 					qlap(2);
 					// Pass 3 (parallel): an open pair whose outcome is the same for every mean inside its bounds is settled too

@@ -1121,14 +1121,24 @@ int main(int argc, char **argv) {
 					write_mapped(s, n_written, v, 0, "*", 0, 0, BamMate{-1, -1, 0});
 					continue;
 				}
-				// GenericReadWriter::WriteRead with several alignments (GenericReadWriter.h:199-243): every alignment that
-				// passes the filters, one record per distinct location, 0x100 on all but candidate 0
+				// GenericReadWriter::WriteRead with several alignments (GenericReadWriter.h:199-243) behind AlignmentBuffer::WriteRead
+				// (AlignmentBuffer.cpp:165-175), as the reference does it -- quirks included, because on a repeat-rich genome they decide records
+				// (tests/test_gpu_humanlike.py): `mapped` starts as the answer of the LAST alignment's coordinate conversion ("TODO: fix for
+				// -n > 1" there), and the identity / residue filter is sticky: once an alignment fails it, no later one is written either.
+				// One record per distinct location, 0x100 on all but candidate 0.
+				const ngm_hit &h0 = *v.h;
+				const int calc = o.strata ? (h0.n_best <= topn ? h0.n_best : 0) : std::min(h0.n_candidates, topn);   // read->Calculated (ScoreBuffer::topNSE)
+				bool mapped = calc > 0 && h0.mapq >= o.min_mq && view(i, calc - 1).h->mapped;   // (AlignmentBuffer.cpp:47: the read's MAPQ against min_mq)
 				bool once = false;
 				seen.clear();
-				for (int t = 0; t < topn; ++t) {
+				float min_res = o.min_residues;
+				if (min_res <= 1.0f) min_res = v.L * min_res;
+				for (int t = 0; t < calc && mapped; ++t) {
 					const View vt = view(i, t);
-					if (!passes(vt)) continue;
+					mapped = vt.h->identity >= o.min_identity && (float) (vt.L - vt.h->qstart - vt.h->qend) >= min_res;
+					if (!mapped) break;
 					once = true;
+					if (!vt.h->mapped) continue;   // (its position did not convert: the reference would print an unconverted location here -- not mirrored)
 					const auto key = std::make_tuple(vt.h->contig, (unsigned long long) vt.h->pos, vt.h->reverse);
 					if (std::find(seen.begin(), seen.end(), key) != seen.end()) continue;
 					seen.push_back(key);
