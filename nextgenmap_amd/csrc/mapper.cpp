@@ -1543,7 +1543,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					// top1SE (ScoreBuffer.cpp:373-376, 449-455): the first of the best is the head of that (unstable) sort
 					auto first_sorted = [&](uint32_t i) {
 						if (!h_rank_pe) return;
-						if (m->h_count[i] <= 16) { first_best(i); return; }  // insertion sort: stable
+						// (also for the <= 16 candidates of a stable insertion sort: the head of the sorted array is the BEST score's first candidate --
+						// without a positive score top1SE then keeps it, not the first candidate of the unsorted list: end-to-end mode)
 						bool ranked = false;
 						std::vector<uint32_t> v(m->h_count[i]);
 						sort_like_reference(v.data(), m->h_base[i], m->h_count[i], h_loc, h_sv, h_scores, h_rank_pe, &ranked);

@@ -188,17 +188,17 @@ def _sam_multi(path):
 
 
 @needs_ref
-@pytest.mark.parametrize("mode", ["topn3", "topn2-strata", "end-to-end", "fast-pairing"])
+@pytest.mark.parametrize("mode", ["topn3", "topn2-strata", "end-to-end", "fast-pairing", "pe-end-to-end", "pe-strata"])
 def test_other_selection_modes_on_a_heavy_tailed_genome(world, mode):
     """the selection modes whose outcome hangs on the reference's candidate ORDER among equal scores (-n cuts a sorted list, --strata
     counts the equally best, top1SE keeps the first) where equal scores are the rule: reads from repeat families with hundreds of
     candidates.  12 000 reads (6 000 pairs for --fast-pairing), every SAM line equal to `ngm-core --affine -t 1`'s."""
     d = world["dir"]
-    if mode == "fast-pairing":
+    if mode in ("fast-pairing", "pe-end-to-end", "pe-strata"):
         f1, f2 = str(d / "fp_1.fq"), str(d / "fp_2.fq")
         _head(str(d / "pe_1.fq"), f1, 6000)
         _head(str(d / "pe_2.fq"), f2, 6000)
-        args, n = ["-1", f1, "-2", f2, "--fast-pairing"], 12000
+        args, n = ["-1", f1, "-2", f2] + {"fast-pairing": ["--fast-pairing"], "pe-end-to-end": ["-e"], "pe-strata": ["--strata"]}[mode], 12000
     else:
         fq = str(d / "modes.fq")
         _head(str(d / "se.fq"), fq, 12000)
@@ -206,7 +206,7 @@ def test_other_selection_modes_on_a_heavy_tailed_genome(world, mode):
         n = 12000
     ref_sam, hip_sam, log_ref, log_hip = _both(world, "mode_" + mode, args)
     a, b = _sam_multi(ref_sam), _sam_multi(hip_sam)
-    assert set(a) == set(b) and sum(len(v) for v in a.values()) >= (n if mode != "topn2-strata" else 1)
+    assert set(a) == set(b) and sum(len(v) for v in a.values()) >= (n if "strata" not in mode else 1)
     diff = [k for k in a if a[k] != b[k]]
     print("%s: %d reads, %d records, %d reads differ" % (mode, len(a), sum(len(v) for v in a.values()), len(diff)))
     for k in diff[:4]:
