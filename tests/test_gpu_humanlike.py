@@ -46,7 +46,7 @@ def world(tmp_path_factory):
     r1, r2 = H.make_reads(G, N_PE, 150, seed=12, paired=True)
     H.write_fastq(str(d / "pe_1.fq"), r1)
     H.write_fastq(str(d / "pe_2.fq"), r2)
-    return dict(dir=d, fa=fa, ref_fa=str(refdir / "ref.fa"), refdir=refdir)
+    return dict(dir=d, fa=fa, ref_fa=str(refdir / "ref.fa"), refdir=refdir, G=G)
 
 
 def _both(world, tag, args, hip_extra=()):
@@ -188,7 +188,7 @@ def _sam_multi(path):
 
 
 @needs_ref
-@pytest.mark.parametrize("mode", ["topn3", "topn2-strata", "end-to-end", "fast-pairing", "pe-end-to-end", "pe-strata"])
+@pytest.mark.parametrize("mode", ["topn3", "topn2-strata", "end-to-end", "fast-pairing", "pe-end-to-end", "pe-strata", "250bp-sensitive", "75bp"])
 def test_other_selection_modes_on_a_heavy_tailed_genome(world, mode):
     """the selection modes whose outcome hangs on the reference's candidate ORDER among equal scores (-n cuts a sorted list, --strata
     counts the equally best, top1SE keeps the first) where equal scores are the rule: reads from repeat families with hundreds of
@@ -199,6 +199,13 @@ def test_other_selection_modes_on_a_heavy_tailed_genome(world, mode):
         _head(str(d / "pe_1.fq"), f1, 6000)
         _head(str(d / "pe_2.fq"), f2, 6000)
         args, n = ["-1", f1, "-2", f2] + {"fast-pairing": ["--fast-pairing"], "pe-end-to-end": ["-e"], "pe-strata": ["--strata"]}[mode], 12000
+    elif mode in ("250bp-sensitive", "75bp"):
+        # other read lengths: 250 bp at 8 % substitutions with the wide band of BASELINE config 5 (-C 40 --sensitive), and 75 bp (few k-mers)
+        rl = 250 if mode.startswith("250") else 75
+        fq = str(d / ("len%d.fq" % rl))
+        n = 1200 if rl == 250 else 5000   # (the reference needs 50 ms per 250 bp read here: ~100 candidates each, 81-column band, one thread)
+        H.write_fastq(fq, H.make_reads(world["G"], n, rl, seed=31 + rl, sub_rate=0.08 if rl == 250 else 0.01, indel_rate=0.01 if rl == 250 else 0.001))
+        args = ["-q", fq] + (["-C", "40", "--sensitive"] if rl == 250 else [])
     else:
         fq = str(d / "modes.fq")
         _head(str(d / "se.fq"), fq, 12000)
