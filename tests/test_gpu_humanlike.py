@@ -222,3 +222,46 @@ def test_other_selection_modes_on_a_heavy_tailed_genome(world, mode):
         if "Candidate order" in line:
             print("  ", line)
     assert not diff, len(diff)
+
+
+@pytest.mark.parametrize("what", ["bs-mapping", "slam-seq-2"])
+def test_converted_reads_on_a_heavy_tailed_genome(world, what):
+    """`--bs-mapping` (every T > C variant of every read k-mer against a skip-0 index, the strand-specific score tables) and `--slam-seq 2`
+    on the repeat-rich genome: the reference's own program with this library behind IAlignment against ngm-hip, 3 000 converted reads."""
+    import numpy as np
+    dropin = os.path.join(ROOT, "oracle", "_ref", "dropin", "ngm-core-hip")
+    if not os.path.exists(dropin):
+        pytest.skip("drop-in build not present (oracle/build_dropin.sh)")
+    d = world["dir"]
+    rng = np.random.default_rng(9)
+    frm, to, rate = (ord("C"), ord("T"), 0.9) if what == "bs-mapping" else (ord("T"), ord("C"), 0.06)
+    fq = str(d / (what + ".fq"))
+    with open(str(d / "se.fq"), "rb") as f, open(fq, "wb") as g:
+        for i in range(3000):
+            name, seq, plus, qual = f.readline(), bytearray(f.readline()), f.readline(), f.readline()
+            for j in range(len(seq) - 1):
+                if seq[j] == frm and rng.random() < rate:
+                    seq[j] = to
+            g.write(name + bytes(seq) + plus + qual)
+    opt = ["--bs-mapping"] if what == "bs-mapping" else ["--slam-seq", "2"]
+    sub = world["refdir"] / what          # (a bisulfite run builds its own skip-0 index cache: keep the two programs' files apart)
+    sub.mkdir(exist_ok=True)
+    rfa = str(sub / "ref.fa")
+    if not os.path.exists(rfa):
+        os.link(world["fa"], rfa)
+    hsub = d / ("hip_" + what)
+    hsub.mkdir(exist_ok=True)
+    hfa = str(hsub / "ref.fa")
+    if not os.path.exists(hfa):
+        os.link(world["fa"], hfa)
+    ref_sam, hip_sam = str(sub / "out.sam"), str(d / (what + "_hip.sam"))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "nextgenmap_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([dropin, "-r", rfa, "-q", fq, "-o", ref_sam, "-t", "1", "--no-progress"] + opt, capture_output=True, text=True, cwd=str(sub), env=env, timeout=3000)
+    assert "Done" in r.stdout + r.stderr, (r.stdout + r.stderr)[-1500:]
+    c = subprocess.run([CLI, "-r", hfa, "-q", fq, "-o", hip_sam] + opt, capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    a, b = _sam(ref_sam), _sam(hip_sam)
+    assert set(a) == set(b) and len(a) == 3000
+    assert sum(1 for n in a if not a[n]["flag"] & 4) > 2000
+    diff = _report(what + " (drop-in)", a, b, c.stderr)
+    assert len(diff) == 0, len(diff)
