@@ -172,12 +172,14 @@ def write_fastq(rows, paths):
     return rec
 
 
-def _sam_body(path):
+def _sam_body(path, limit=None):
     out = {}
     with open(path, "rb") as f:
         for line in f:
             if line[:1] == b"@":
                 continue
+            if limit is not None and len(out) >= limit:
+                break
             t = line.split(b"\t", 2)
             out[(t[0], int(t[1]) & 0xC0)] = line
     return out
@@ -272,6 +274,13 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
            "gpu_busy_fraction_of_mapping_pass": (h["gpu"] / h["pass"]) if h["gpu"] and h["pass"] else None}
     # the same program on what real input looks like (.fastq.gz: the serial reader) and with --bam, on a slice
     ng = min(n, args.e2e_gz_reads) & ~1
+    # what the later comparisons need of the big SAM file stays in memory (the first records, in file order); the file itself goes now:
+    # 4 GB of dirty page cache behind the runs that follow make their writes wait for the write-back (measured with the same input
+    # written twice: mapping pass 0.50 s into a fresh file system state, 0.89 s behind the first run's file)
+    keep = min(n, max(ng, args.cpu_sample_reads, args.cpu_t1_reads))
+    ours = _sam_body(sam, keep)
+    out["sam_bytes"] = os.path.getsize(sam)
+    os.remove(sam)
     if ng > 0:
         try:
             cnt = ng // len(files)
@@ -288,13 +297,10 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
                 subprocess.run(["gzip", "-1", "-f", dst], check=True)
             t_gz = time.perf_counter() - t
             hz = run_hip([d + ".gz" for d in slices], os.path.join(workdir, "e2e_gz.sam"))
-            same = None
-            plain_sam = os.path.join(workdir, "e2e.sam")
-            if os.path.exists(plain_sam):  # the first ng records of the plain run (same order, same batches) against the .gz run's
-                with open(plain_sam) as fa_, open(os.path.join(workdir, "e2e_gz.sam")) as fb_:
-                    ra = (l for l in fa_ if not l.startswith("@"))
-                    rb = [l for l in fb_ if not l.startswith("@")]
-                    same = len(rb) == ng and all(x == y for x, y in zip(ra, rb))
+            # the first ng records of the plain run (same order, same batches) against the .gz run's
+            with open(os.path.join(workdir, "e2e_gz.sam"), "rb") as fb_:
+                rb = [l for l in fb_ if l[:1] != b"@"]
+            same = len(rb) == ng and all(x == y for x, y in zip(ours.values(), rb))
             out["fastq_gz_input"] = {"reads": ng, "value": ng / hz["io"], "unit": "reads/s", "seconds": hz["io"], "gzip_1_of_the_input_s": t_gz,
                                      "same_sam_as_plain_input": same}
             for fn in [d + ".gz" for d in slices] + [os.path.join(workdir, "e2e.bam"), os.path.join(workdir, "e2e_gz.sam")]:
@@ -331,8 +337,22 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
         ref_sam = os.path.join(workdir, "ref.sam")
         t_all = run_ref(slice_to(ns, "s"), ref_sam, threads)
         t_map = max(t_all - t_load, 1e-3)
-        ours = _sam_body(sam)
-        same, diffs = _sam_diff(_sam_body(ref_sam), ours)
+        ref_body = _sam_body(ref_sam)
+        same, diffs = _sam_diff(ref_body, ours)
+        # the same reference command a second time: which of its own lines move between two -t N runs (thread scheduling decides which reads
+        # share a CS thread's running mean insert size), and are the lines where ngm-hip differs among the reads it is undecided on itself?
+        self_check = None
+        if not args.no_reference_rerun:
+            ref2_sam = os.path.join(workdir, "ref2.sam")
+            run_ref(slice_to(ns, "s"), ref2_sam, threads)
+            ref2_body = _sam_body(ref2_sam)
+            same2, diffs2 = _sam_diff(ref_body, ref2_body)
+            moved = {k_ for k_ in ref_body if ref2_body.get(k_) != ref_body[k_]}
+            ours_off = {k_ for k_ in ref_body if ours.get(k_) != ref_body[k_]}
+            self_check = {"records_compared": len(ref_body), "identical_lines_between_two_reference_runs": same2, "first_differences": diffs2[:3],
+                          "ngm_hip_lines_that_differ_from_run_1": len(ours_off),
+                          "of_these_equal_to_run_2_or_moved_between_the_runs": len({k_ for k_ in ours_off if k_ in moved or ours.get(k_) == ref2_body.get(k_)})}
+            os.remove(ref2_sam)
         # ... and -t 1, the run whose output this library reproduces exactly (one CS thread: one running mean insert size)
         n1 = min(args.cpu_t1_reads, n) & ~1
         th1, same1, diffs1, t_t1, early = {}, 0, [], 0.0, None
@@ -357,7 +377,7 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
                                                     "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads},
                 "parity_vs_reference_sam_t1": {"records_compared": len(th1), "identical_lines": same1, "first_differences": diffs1, "seconds": t_t1, "ngm_hip_on_the_same_slice": early,
                                                "note": "ngm-core --affine -t 1 on the first %d reads: the run ngm-hip reproduces" % n1}}
-    for fn in [sam] + files:
+    for fn in files:
         try:
             os.remove(fn)
         except OSError:
@@ -405,7 +425,7 @@ def sharded_end_to_end(workdir, contigs, args, paired, affine, sens, world, exe)
            "sam_records": lines, "sam_bytes": os.path.getsize(sam), "make_input_s": t_make, "command": " ".join(["ngm-hip"] + cmd[1:])}
     out["value"] = n / out["seconds_first_input_byte_to_concatenated_sam_closed"]
     out["reads_per_s_of_process_wall"] = n / wall
-    for fn in [sam] + files:
+    for fn in files:
         try:
             os.remove(fn)
         except OSError:
@@ -515,7 +535,9 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
+    ap.add_argument("--no-reference-rerun", action="store_true", help="skip the second -t N run of the reference program (its own run-to-run differences)")
     ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
+    ap.add_argument("--read-sets", type=int, default=4, help="distinct sets of reads-per-step reads the timed steps rotate through (step i maps set i mod this)")
     ap.add_argument("--read-len", type=int, default=150, help="read length (150: BASELINE config #2/#3; 250: config #5's shape)")
     ap.add_argument("--corridor", type=int, default=0, help="band width; 0: NextGenMap's 5 + 0.15 * read length")
     ap.add_argument("--layout", choices=["pe", "se"], default="pe", help="paired-end (BASELINE.json config #2) or single-end reads")
@@ -624,10 +646,14 @@ def main():
     # ---- this rank's shard of the job's reads (weak scaling: R reads per rank per step) ----------------------------------
     lo_g, hi_g = sharding.shard_range(R * world, rank, world, paired=paired)
     assert hi_g - lo_g == R
-    rows, truth_c, truth_p = make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank, paired=paired, subs=args.subs,
-                                        indel_bases=args.indel_bases)  # config #2's seed, one shard per rank
+    # S distinct read sets, all resident in HBM; step i maps set i mod S (the steps do not map the same reads over and over)
+    S = max(1, min(args.read_sets, args.steps if args.steps > 0 else 1))
+    sets = [make_reads(contigs, R, seed=20240602 + 2 + 1000 * rank + 7919 * s_, paired=paired, subs=args.subs, indel_bases=args.indel_bases)
+            for s_ in range(S)]  # (set 0: config #2's seed, one shard per rank)
     sens = 0.5 - 0.35 * 0.5 if args.sensitive else 0.5
-    d_rows = None if stub else torch.from_numpy(rows).to(dev)
+    d_sets = [None if stub else torch.from_numpy(t_[0]).to(dev) for t_ in sets]
+    last_set = (max(1, args.steps) - 1) % S
+    rows, truth_c, truth_p = sets[last_set]   # what the outputs hold after the timed region (and after the isolated extra pass)
     # W mapper instances (own stream + workspace each, like NextGenMap's CS threads with their own IAlignment) work on
     # contiguous slices of the step's reads from W host threads: the host stages of one slice (pair selection, CIGAR,
     # downloads) overlap the kernels of the others
@@ -650,22 +676,23 @@ def main():
         lo, hi = bounds[w], bounds[w + 1]
         if stub:
             mps.append(StubMapper())
-            views.append((rows[lo:hi], None, tuple(o[lo:hi] for o in out), lo))
+            views.append(([t_[0][lo:hi] for t_ in sets], None, tuple(o[lo:hi] for o in out), lo))
             continue
         kw = dict(gap_read=33, gap_ref=33, gap_extend=3, personality=1) if affine else {}
         mps.append(Mapper(ref, Q, C, sensitivity=sens, **kw))
-        views.append((rows[lo:hi], d_rows[lo:hi], tuple(o[lo:hi] for o in out), lo))
+        views.append(([t_[0][lo:hi] for t_ in sets], [d_[lo:hi] for d_ in d_sets], tuple(o[lo:hi] for o in out), lo))
 
-    def worker(w, steps, acc):
-        rw, dw, ow, lo = views[w]
+    def worker(w, steps, acc, first=0):
+        rws, dws, ow, lo = views[w]
         k = np.zeros(8)
-        for _ in range(steps):
+        for i_ in range(steps):
+            s_ = (first + i_) % S
             if stub:
-                mps[w].map(rw, ow, lo)
+                mps[w].map(rws[s_], ow, lo)
             elif paired:
-                mps[w].map_pe_raw(rw, dw, ow)
+                mps[w].map_pe_raw(rws[s_], dws[s_], ow)
             else:
-                mps[w].map_se_raw(rw, dw, ow)
+                mps[w].map_se_raw(rws[s_], dws[s_], ow)
             k += np.array(mps[w].last_kernel_ms())
         acc[w] = k
 
@@ -693,7 +720,7 @@ def main():
         elapsed = float(t.item())
 
     # one extra, untimed pass of instance 0 alone: kernel durations without the other streams' kernels sharing the GPU
-    worker(0, 1, iso := [None] * W)
+    worker(0, 1, iso := [None] * W, first=last_set)
     iso_ms = iso[0]
     iso_ctr = mps[0].cs_counters()
     ctr = np.sum([m_.cs_counters() for m_ in mps], axis=0)
@@ -746,10 +773,10 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": ("%d x %dbp %s synthetic reads per GPU per step (%.1f %% substitutions%s) vs a synthetic %.0f Mbp genome (24 contigs, repeat "
                                     "families, N runs; GRCh38 itself is not available offline): candidate search (k=13, skip 2, s=%.3f) + "
-                                    "score + %s/MAPQ + align with traceback + CIGAR; reads resident in HBM")
+                                    "score + %s/MAPQ + align with traceback + CIGAR; reads resident in HBM; the steps rotate through %d distinct read sets")
                        % (R, READ_LEN, "PE (insert ~N(350,35), FR)" if paired else "SE", 100 * args.subs,
                           ", %.0f %% indel bases" % (100 * args.indel_bases) if args.indel_bases else "", args.genome_mbp, sens,
-                          "pair selection (top1PE)" if paired else "top-1"),
+                          "pair selection (top1PE)" if paired else "top-1", S),
                        "qry_max_len": Q, "corridor": C, "scoring": "affine (SeqAn banded Gotoh) 10/15/33/3 local" if affine else "linear 10/15/20/20 local", "reads_per_step_per_gpu": R, "mapper_instances_per_gpu": W, "host_cpus_per_rank_numa_pinned": pinned_cpus,
                        "parallelism": "reads sharded x%d (nextgenmap_amd.sharding.shard_range), genome+index replicated per GPU (built by rank 0, loaded from NextGenMap cache files by the others)" % world},
             "sw_gcells_per_s": {"score_kernel": score_cells / (kms[2] * 1e-3) / 1e9 if kms[2] > 0 else None,
@@ -815,7 +842,7 @@ def main():
         ref.close()
     if rank == 0:
         if world == 1 and not stub and args.heavy_tail_mbp > 0 and READ_LEN == 150:
-            del contigs, rows, d_rows
+            del contigs, rows, sets, d_sets, views
             try:
                 line["heavy_tailed_genome"] = heavy_tail_leg(args, dev, local_rank, paired, affine, sens)
             except Exception as e:

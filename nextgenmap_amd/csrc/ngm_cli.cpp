@@ -59,6 +59,7 @@
 #include "../../include/ngm_hip.h"
 #include "../../include/ngm_pipeline.h"
 #include "bam_writer.h"
+#include "gz_inflate.h"
 #include "thread_pool.h"
 
 namespace {
@@ -303,6 +304,7 @@ struct MappedFile {
 	size_t n = 0, map_len = 0;   // n: the bytes that hold records (white space at the end of the file is not a record: kseq skips it too)
 	int fd = -1;
 	char *owned = nullptr;        // gzip input: the inflated text lives here instead of in a file mapping
+	size_t owned_map = 0;         // != 0: `owned` is an anonymous mapping of this many bytes (gz_inflate.h), else malloc'ed
 	bool open(const char *path) {
 		fd = ::open(path, O_RDONLY);
 		if (fd < 0) return false;
@@ -325,6 +327,15 @@ struct MappedFile {
 	bool inflate_all(const char *path) {
 		const char *e = getenv("NGM_HIP_GZ_MEMORY_GB");
 		const size_t cap_max = (size_t) std::max(1, e ? atoi(e) : 64) << 30;
+		if (!getenv("NGM_HIP_GZ_ZLIB")) {   // (set: zlib's inflate, the reader of rounds 2-3 -- also what a stream gz_inflate.h refuses falls back to)
+			char *text = nullptr;
+			size_t len = 0, reserved = 0;
+			if (ngm::gz::inflate_file(path, &text, &len, &reserved, cap_max)) {
+				owned = text; owned_map = reserved; p = text; n = len; map_len = 0;
+				trim();
+				return n > 0;
+			}
+		}
 		gzFile g = gzopen(path, "rb");
 		if (!g) return false;
 		gzbuffer(g, 1 << 20);
@@ -350,8 +361,9 @@ struct MappedFile {
 		trim();
 		return n > 0;
 	}
-	void release() { if (owned) { free(owned); owned = nullptr; p = nullptr; n = 0; } }
-	~MappedFile() { if (owned) free(owned); else if (p) munmap((void *) p, map_len); if (fd >= 0) close(fd); }
+	void drop_owned() { if (owned_map) munmap(owned, owned_map); else free(owned); owned = nullptr; owned_map = 0; }
+	void release() { if (owned) { drop_owned(); p = nullptr; n = 0; } }
+	~MappedFile() { if (owned) drop_owned(); else if (p) munmap((void *) p, map_len); if (fd >= 0) close(fd); }
 	// touch every page from the pool threads: the page-table entries of a multi-GB input are then set up in parallel instead
 	// of one minor fault at a time under the (single) splitter thread
 	void prefault() const {
@@ -692,6 +704,51 @@ int main(int argc, char **argv) {
 	if (o.devices.size() == 1) {
 		const int cpus = ngm_host_pin_to_device_node(o.device);
 		if (cpus > 0) info("MAIN", "Host threads pinned to the " + std::to_string(cpus) + " CPUs of the GPU's NUMA node");
+	}
+	// Page-locked memory is slow to get (~0.1 s per 150 MB, ~0.9 GB for two workers): it is requested NOW, by threads of its own, under the
+	// load of the index -- measured (4 M reads, MI355X box): requested after the sensitivity estimate it is 0.14 s on the input-to-output
+	// path, requested under the estimate it slows that estimate's driver calls from 0.04 to 0.14 s.  Its size depends on the longest read,
+	// which only the scan of the input knows: the first records give a guess, and buffers that turn out too small are replaced where
+	// they are used.
+	struct TextBuf { char *p; size_t cap; };
+	struct EarlyPinned {
+		struct W { char *rows = nullptr, *qrows = nullptr, *names = nullptr; ngm_sam_read *meta = nullptr; };
+		std::thread th;
+		int q = 0, batch = 0;
+		std::vector<TextBuf> text;
+		std::vector<W> w;
+		~EarlyPinned() { if (th.joinable()) th.join(); }
+	} early;
+	{
+		const int early_topn = o.paired ? 1 : o.topn;
+		const bool early_gpu_sam = !o.bam && early_topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
+		if (early_gpu_sam && !(o.qry.empty() && o.qry1.empty()) && !o.out.empty() && !getenv("NGM_HIP_NO_EARLY_PINNED")) {
+			size_t peek_max = 0;
+			if (o.max_read_length > 0) peek_max = (size_t) o.max_read_length;
+			else {
+				SeqReader peek((o.qry1.empty() ? o.qry : o.qry1).c_str());
+				Read r;
+				for (int i = 0; i < 256 && peek.ok() && peek.next(r); ++i) peek_max = std::max(peek_max, std::min<size_t>(r.seq.size(), 9999));
+			}
+			if (peek_max > 0) {
+				early.q = std::min(1000, (int) ((peek_max | 1) + 1));
+				early.batch = o.paired ? (o.batch & ~1) : o.batch;
+				early.text.assign(o.devices.size() * (size_t) o.workers + 2, TextBuf{nullptr, 0});
+				early.w.resize(o.devices.size() * (size_t) o.workers);
+				early.th = std::thread([&early] {
+					const size_t cap = (size_t) early.batch * ((size_t) 2 * early.q + 288) + (1u << 20);
+					std::vector<std::thread> alloc;
+					for (TextBuf &t : early.text) alloc.emplace_back([&t, cap] { t.p = (char *) ngm_host_alloc(cap); t.cap = t.p ? cap : 0; });
+					for (EarlyPinned::W &w : early.w) alloc.emplace_back([&w, &early] {
+						const size_t rows = (size_t) early.batch * early.q;
+						w.rows = (char *) ngm_host_alloc(rows); w.qrows = (char *) ngm_host_alloc(rows);
+						w.meta = (ngm_sam_read *) ngm_host_alloc((size_t) early.batch * sizeof(ngm_sam_read));
+						w.names = (char *) ngm_host_alloc((size_t) early.batch * 32);
+					});
+					for (auto &t : alloc) t.join();
+				});
+			}
+		}
 	}
 	// an index cache next to the FASTA is loaded instead of rebuilding; a fresh build is saved for the next run unless
 	// --skip-save (src/PrefixTable.cpp:232-262, SequenceProvider.cpp:264-330)
@@ -1320,12 +1377,27 @@ int main(int argc, char **argv) {
 	auto us_since = [](std::chrono::steady_clock::time_point t0) { return (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); };
 	// GPU-formatted text: page-locked buffers that travel worker -> writer -> pool.  Their number bounds the formatted text in
 	// flight (a slow output file then stalls the workers instead of piling the output up in memory)
-	struct TextBuf { char *p; size_t cap; };
 	std::vector<TextBuf> text_free;
 	const size_t text_cap0 = (size_t) batch_reads * ((size_t) 2 * q + 288) + (1u << 20);
-	if (gpu_sam) {
+	if (early.th.joinable()) early.th.join();
+	bool early_ok = gpu_sam && early.q >= q && early.batch == batch_reads && early.w.size() == workers.size();
+	for (const TextBuf &t : early.text) early_ok = early_ok && t.p;
+	for (const EarlyPinned::W &w : early.w) early_ok = early_ok && w.rows && w.qrows && w.meta && w.names;
+	if (early_ok) {
+		text_free = early.text;
+		for (size_t i = 0; i < workers.size(); ++i) {
+			Worker &w = workers[i];
+			w.rows = early.w[i].rows; w.qrows = early.w[i].qrows; w.meta = early.w[i].meta; w.names = early.w[i].names;
+			w.rows_cap = (size_t) batch_reads * early.q; w.names_cap = (size_t) batch_reads * 32;
+		}
+	} else {
+		for (const TextBuf &t : early.text) ngm_host_free(t.p);
+		for (const EarlyPinned::W &w : early.w) { ngm_host_free(w.rows); ngm_host_free(w.qrows); ngm_host_free(w.meta); ngm_host_free(w.names); }
+	}
+	if (gpu_sam && !early_ok) {
 		// page-locked memory is slow to get (~0.1 s per 150 MB): everything a worker needs, and the text pool, at once and in parallel
-		// (measured: requesting it earlier, under the sensitivity estimate, slows the driver calls of that estimate down by more than it saves)
+		// (measured: requesting it under the sensitivity estimate slows the driver calls of that estimate down by more than it saves;
+		// under the input scan -- `early` above -- it is free)
 		std::vector<std::thread> alloc;
 		text_free.resize(workers.size() + 2);
 		for (TextBuf &t : text_free) alloc.emplace_back([&t, text_cap0] { t.p = (char *) ngm_host_alloc(text_cap0); t.cap = text_cap0; });

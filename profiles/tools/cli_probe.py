@@ -46,7 +46,7 @@ for r in runs:
     c = subprocess.run(cmd, capture_output=True, text=True, env=env)
     print("==== ngm-hip", " ".join(r), ("(gz input)" if gz else ""), "-> rc %d, %.2f s wall, %d output bytes" % (c.returncode, time.perf_counter() - t, os.path.getsize(out) if os.path.exists(out) else -1))
     for l in c.stderr.splitlines():
-        if l.startswith("[MAIN]") or l.startswith("[INPUT]") or "error" in l:
+        if l.startswith("[MAIN]") or l.startswith("[INPUT]") or "error" in l or "index ready" in l:
             print("   ", l[:400])
 import shutil
 shutil.rmtree(wd, ignore_errors=True)
