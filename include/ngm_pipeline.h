@@ -215,6 +215,18 @@ int ngm_mapper_set_batch_seq(ngm_mapper *m, uint64_t seq);
  * top1PE / CheckPairs; whether the two winners form a pair is decided where the records are written (src/AlignmentBuffer.cpp:176-199) */
 int ngm_mapper_set_fast_pairing(ngm_mapper *m, int on);
 
+/* BGZF blocks written by the GPU (csrc/bgzf_device.h): what bamtools' BgzfStream does for `ngm --bam`
+ * (lib/bamtools-2.3.0/src/api/internal/io/BgzfStream_p.cpp: DeflateBlock per 64 KB, zlib level 6) -- every 0xFF00 input bytes become one
+ * BGZF member (its own DEFLATE stream with dynamic Huffman codes, CRC-32, ISIZE), the members one after the other in `out`.
+ * raw / out: host memory (page-locked memory of ngm_host_alloc copies at PCIe rate); out_cap >= ngm_bgzf_bound(n).
+ * Returns the bytes written, < 0 on error (ngm_pipeline_last_error).  One call at a time per object; objects are independent. */
+typedef struct ngm_bgzf ngm_bgzf;
+ngm_bgzf *ngm_bgzf_create(int device);
+void ngm_bgzf_destroy(ngm_bgzf *z);
+size_t ngm_bgzf_bound(size_t n);
+long long ngm_bgzf_compress(ngm_bgzf *z, const void *raw, size_t n, void *out, size_t out_cap);
+float ngm_bgzf_last_kernel_ms(const ngm_bgzf *z);   /* HIP-event time of the last call's compression kernel */
+
 /* page-locked host memory for read batches (the H2D copy then runs at PCIe rate without a staging copy) */
 void *ngm_host_alloc(size_t bytes);
 void ngm_host_free(void *p);

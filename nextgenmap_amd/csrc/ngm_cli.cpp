@@ -988,8 +988,13 @@ int main(int argc, char **argv) {
 	ngm_pair_state *pair_state = ngm_pair_state_create();
 	// SAM text on the GPU (csrc/sam_device.h) for plain SAM output with one alignment per read; BAM and -n > 1 are formatted here
 	const bool gpu_sam = !o.bam && topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
+	// --bam: the records are formatted here, the BGZF blocks are written by the GPU (csrc/bgzf_device.h; NGM_HIP_BAM_ZLIB=1: zlib level 6 on the pool)
+	const bool gpu_bgzf = o.bam && !getenv("NGM_HIP_BAM_ZLIB");
+	std::atomic<long long> t_bgzf_gpu_us{0}, t_bgzf_call_us{0};
+	std::atomic<unsigned long long> bgzf_in_bytes{0}, bgzf_out_bytes{0};
 	struct Worker { ngm_mapper *m = nullptr; char *rows = nullptr; size_t rows_cap = 0; std::vector<ngm_hit> hits; std::vector<char> cig, md;
-		char *qrows = nullptr, *names = nullptr; size_t names_cap = 0; ngm_sam_read *meta = nullptr; };
+		char *qrows = nullptr, *names = nullptr; size_t names_cap = 0; ngm_sam_read *meta = nullptr;
+		ngm_bgzf *bz = nullptr; char *bam_raw = nullptr, *bam_out = nullptr; size_t bam_raw_cap = 0, bam_out_cap = 0; };
 	std::vector<Worker> workers(o.devices.size() * (size_t) o.workers);
 	for (size_t w = 0; w < workers.size(); ++w) {
 		workers[w].m = ngm_mapper_create(refs[w % refs.size()], &mp);
@@ -1003,6 +1008,10 @@ int main(int argc, char **argv) {
 			if (ngm_mapper_set_sam_options(workers[w].m, &so) < 0) die(ngm_pipeline_last_error());
 		}
 		ngm_mapper_set_reference_cs_batch(workers[w].m, 1800000 / std::max(1, avg_len));
+		if (gpu_bgzf) {
+			workers[w].bz = ngm_bgzf_create(o.devices[w % o.devices.size()]);
+			if (!workers[w].bz) die(ngm_pipeline_last_error());
+		}
 	}
 
 	// ---- the record -> SAM line code (SAMWriter::DoWriteReadGeneric, SAMWriter.cpp:98-228) -----------------------------
@@ -1585,15 +1594,46 @@ int main(int argc, char **argv) {
 					size_t t_loc = 0, m_loc = 0, w_loc = 0;  // (not ct[c] & co. directly: neighbouring chunks share cache lines, and these are bumped per record)
 					format_range(*b, w, u0 * per, u1 * per, b->chunks[c], t_loc, m_loc, w_loc);
 					ct[c] = t_loc; cm[c] = m_loc; cw[c] = w_loc;
-					if (o.bam && !b->chunks[c].empty()) {  // every chunk becomes whole BGZF blocks: they concatenate into one valid file
+					if (o.bam && !gpu_bgzf && !b->chunks[c].empty()) {  // every chunk becomes whole BGZF blocks: they concatenate into one valid file
 						std::string z;
 						z.reserve(b->chunks[c].size() / 3 + 64);
 						if (!ngm::bam::bgzf_compress(b->chunks[c].data(), b->chunks[c].size(), z)) fail("BGZF compression failed");
 						b->chunks[c].swap(z);
 					}
 				}
-			}, 1, o.bam ? ngm::ThreadPool::cpu_quota() : 0);   // (BAM: records + deflate keep every thread busy for the whole batch)
+			}, 1, (o.bam && !gpu_bgzf) ? ngm::ThreadPool::cpu_quota() : 0);   // (BAM with zlib: records + deflate keep every thread busy for the whole batch)
 			for (int c = 0; c < n_chunks; ++c) { b->n_total += ct[c]; b->n_mapped += cm[c]; b->n_written += cw[c]; }
+			if (gpu_bgzf) {
+				// the batch's records, chunk after chunk, in page-locked memory -> whole BGZF blocks from the GPU (a batch ends with a short
+				// block: batches -- and shards -- concatenate into one valid file) -> pieces for the writer
+				const auto tz = std::chrono::steady_clock::now();
+				std::vector<size_t> off(n_chunks + 1, 0);
+				for (int c = 0; c < n_chunks; ++c) off[c + 1] = off[c] + b->chunks[c].size();
+				const size_t total = off[n_chunks];
+				long long zlen = 0;
+				if (total > 0) {
+					if (total > w.bam_raw_cap) {
+						ngm_host_free(w.bam_raw); ngm_host_free(w.bam_out);
+						w.bam_raw_cap = total + total / 4 + (1u << 20); w.bam_out_cap = ngm_bgzf_bound(w.bam_raw_cap);
+						w.bam_raw = (char *) ngm_host_alloc(w.bam_raw_cap); w.bam_out = (char *) ngm_host_alloc(w.bam_out_cap);
+						if (!w.bam_raw || !w.bam_out) { w.bam_raw_cap = w.bam_out_cap = 0; fail(ngm_pipeline_last_error()); continue; }
+					}
+					pool.parallel_for(n_chunks, [&](int lo, int hi) { for (int c = lo; c < hi; ++c) memcpy(w.bam_raw + off[c], b->chunks[c].data(), b->chunks[c].size()); }, 1);
+					zlen = ngm_bgzf_compress(w.bz, w.bam_raw, total, w.bam_out, w.bam_out_cap);
+					if (zlen < 0) { fail(ngm_pipeline_last_error()); continue; }
+					t_bgzf_gpu_us += (long long) (ngm_bgzf_last_kernel_ms(w.bz) * 1000.0f);
+					bgzf_in_bytes += total; bgzf_out_bytes += (unsigned long long) zlen;
+				}
+				const int n_out = (int) std::max<long long>(1, std::min<long long>(n_chunks, zlen / (2 << 20) + 1));
+				b->chunks.resize((size_t) n_out);
+				pool.parallel_for(n_out, [&](int lo, int hi) {
+					for (int c = lo; c < hi; ++c) {
+						const size_t a = (size_t) ((unsigned long long) zlen * (unsigned) c / (unsigned) n_out), e = (size_t) ((unsigned long long) zlen * (unsigned) (c + 1) / (unsigned) n_out);
+						b->chunks[c].assign(w.bam_out + a, e - a);
+					}
+				}, 1);
+				t_bgzf_call_us += us_since(tz);
+			}
 			{
 				std::lock_guard<std::mutex> lk(spare_mu);
 				b->recs.clear();
@@ -1694,8 +1734,13 @@ int main(int argc, char **argv) {
 			t_gpu_us / 1e6, secs, 100.0 * (t_gpu_us / 1e6) / std::max(1e-9, secs));
 	info("MAIN", msg);
 	if (!gpu_sam) {
-		snprintf(msg, sizeof(msg), "Records%s formatted on the host pool: %.3f s of thread time = %.0f %% of %d threads x %.3f s", o.bam ? " + BGZF blocks" : "", t_format_cpu_us / 1e6,
+		snprintf(msg, sizeof(msg), "Records%s formatted on the host pool: %.3f s of thread time = %.0f %% of %d threads x %.3f s", (o.bam && !gpu_bgzf) ? " + BGZF blocks" : "", t_format_cpu_us / 1e6,
 				100.0 * (t_format_cpu_us / 1e6) / std::max(1e-9, pool.size() * secs), pool.size(), secs);
+		info("MAIN", msg);
+	}
+	if (gpu_bgzf) {
+		snprintf(msg, sizeof(msg), "BGZF blocks written by the GPU: %.1f MB of records -> %.1f MB, %.3f s of kernels, %.3f s inside the calls (copies to and from page-locked memory, both transfers, the kernels)",
+				bgzf_in_bytes.load() / 1e6, bgzf_out_bytes.load() / 1e6, t_bgzf_gpu_us / 1e6, t_bgzf_call_us / 1e6);
 		info("MAIN", msg);
 	}
 	if (gpu_sam) { snprintf(msg, sizeof(msg), "SAM text assembled on the GPU: %.3f s of kernels (included above)", t_sam_gpu_us / 1e6); info("MAIN", msg); }
@@ -1744,7 +1789,8 @@ int main(int argc, char **argv) {
 		info("MAIN", msg);
 	}
 	if (const char *pf = getenv("NGM_HIP_PROFILE")) prof::dump(pf);
-	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); ngm_host_free(w.qrows); ngm_host_free(w.names); ngm_host_free(w.meta); }
+	for (Worker &w : workers) { ngm_mapper_destroy(w.m); ngm_host_free(w.rows); ngm_host_free(w.qrows); ngm_host_free(w.names); ngm_host_free(w.meta);
+		ngm_bgzf_destroy(w.bz); ngm_host_free(w.bam_raw); ngm_host_free(w.bam_out); }
 	for (TextBuf &t : text_free) ngm_host_free(t.p);
 	ngm_pair_state_destroy(pair_state);
 	for (ngm_ref *r2 : refs) ngm_ref_destroy(r2);

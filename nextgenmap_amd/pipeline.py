@@ -67,12 +67,54 @@ def _lib():
         lib.ngm_mapper_cs_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_path_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.ngm_bgzf_create.restype = C.c_void_p
+        lib.ngm_bgzf_create.argtypes = [C.c_int]
+        lib.ngm_bgzf_destroy.argtypes = [C.c_void_p]
+        lib.ngm_bgzf_bound.restype = C.c_size_t
+        lib.ngm_bgzf_bound.argtypes = [C.c_size_t]
+        lib.ngm_bgzf_compress.restype = C.c_longlong
+        lib.ngm_bgzf_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        lib.ngm_bgzf_last_kernel_ms.restype = C.c_float
+        lib.ngm_bgzf_last_kernel_ms.argtypes = [C.c_void_p]
         _bound = True
     return lib
 
 
 def _err():
     return NgmHipError(_lib().ngm_pipeline_last_error().decode())
+
+
+class Bgzf:
+    """BGZF blocks written by the GPU (include/ngm_pipeline.h, ngm_bgzf_*): `ngm --bam`'s block compressor."""
+
+    def __init__(self, device=0):
+        self._h = _lib().ngm_bgzf_create(device)
+        if not self._h:
+            raise _err()
+
+    def compress(self, data):
+        lib = _lib()
+        data = bytes(data)
+        cap = lib.ngm_bgzf_bound(len(data))
+        out = C.create_string_buffer(cap)
+        n = lib.ngm_bgzf_compress(self._h, data, len(data), out, cap)
+        if n < 0:
+            raise _err()
+        return out.raw[:n]
+
+    def last_kernel_ms(self):
+        return float(_lib().ngm_bgzf_last_kernel_ms(self._h))
+
+    def close(self):
+        if self._h:
+            _lib().ngm_bgzf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Reference:
