@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -26,6 +27,7 @@ struct ngm_bgzf {
 	uint32_t *d_sizes = nullptr;
 	unsigned long long *d_offsets = nullptr;
 	uint2 *d_scratch = nullptr;
+	unsigned long long *d_phases = nullptr;
 	size_t raw_cap = 0, blocks_cap = 0, dense_cap = 0;
 	int grid = 0;
 	uint32_t *h_sizes = nullptr;              // page-locked
@@ -78,7 +80,8 @@ extern "C" ngm_bgzf *ngm_bgzf_create(int device) {
 	z->grid = ok ? prop.multiProcessorCount : 256;
 	ok = ok && hipStreamCreateWithFlags(&z->st, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipMalloc(&z->d_tables, kTabBytes) == hipSuccess && hipMemcpy(z->d_tables, t.data(), kTabBytes, hipMemcpyHostToDevice) == hipSuccess;
-	ok = ok && hipMalloc(&z->d_scratch, (size_t) z->grid * 4 * ngm::bgzf::kMatCap * sizeof(uint2)) == hipSuccess;
+	ok = ok && hipMalloc(&z->d_scratch, (size_t) z->grid * ngm::bgzf::kSegs * ngm::bgzf::kMatCap * sizeof(uint2)) == hipSuccess;
+	if (getenv("NGM_HIP_BGZF_PHASES")) ok = ok && hipMalloc(&z->d_phases, 64) == hipSuccess;
 	ok = ok && hipEventCreate(&z->ev0) == hipSuccess && hipEventCreate(&z->ev1) == hipSuccess;
 	ok = ok && hipFuncSetAttribute((const void *) ngm::bgzf::deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ngm::bgzf::deflate_lds_bytes()) == hipSuccess;
 	if (!ok) { ngm::pipeline_set_error("GPU BGZF compressor: set-up failed on device %d (%s)", device, hipGetErrorString(hipGetLastError())); ngm_bgzf_destroy(z); return nullptr; }
@@ -90,7 +93,7 @@ extern "C" void ngm_bgzf_destroy(ngm_bgzf *z) {
 	(void) hipSetDevice(z->device);
 	if (z->st) (void) hipStreamSynchronize(z->st);
 	(void) hipFree(z->d_raw); (void) hipFree(z->d_out); (void) hipFree(z->d_dense); (void) hipFree(z->d_tables); (void) hipFree(z->d_sizes);
-	(void) hipFree(z->d_offsets); (void) hipFree(z->d_scratch);
+	(void) hipFree(z->d_offsets); (void) hipFree(z->d_scratch); (void) hipFree(z->d_phases);
 	if (z->h_sizes) (void) hipHostFree(z->h_sizes);
 	if (z->h_offsets) (void) hipHostFree(z->h_offsets);
 	if (z->ev0) (void) hipEventDestroy(z->ev0);
@@ -139,6 +142,8 @@ extern "C" long long ngm_bgzf_compress(ngm_bgzf *z, const void *raw, size_t n, v
 	A.raw = z->d_raw; A.n = n; A.n_blocks = (int) nb; A.out = z->d_out; A.sizes = z->d_sizes; A.scratch = z->d_scratch;
 	A.crc_table = (const uint32_t *) (z->d_tables + kTabCrc); A.xpow = (const uint32_t *) (z->d_tables + kTabXpow);
 	A.len_code = z->d_tables + kTabLen; A.dist_code = z->d_tables + kTabDist;
+	A.phase_cycles = z->d_phases;
+	if (z->d_phases) BGZF_HIP_TRY(hipMemsetAsync(z->d_phases, 0, 64, z->st));
 	BGZF_HIP_TRY(hipEventRecord(z->ev0, z->st));
 	hipLaunchKernelGGL(ngm::bgzf::deflate_kernel, dim3((unsigned) std::min<size_t>(nb, (size_t) z->grid)), dim3(ngm::bgzf::kNT), ngm::bgzf::deflate_lds_bytes(), z->st, A);
 	BGZF_HIP_TRY(hipGetLastError());
@@ -164,6 +169,12 @@ extern "C" long long ngm_bgzf_compress(ngm_bgzf *z, const void *raw, size_t n, v
 	BGZF_HIP_TRY(hipGetLastError());
 	BGZF_HIP_TRY(hipMemcpyAsync(out, z->d_dense, (size_t) total, hipMemcpyDeviceToHost, z->st));
 	BGZF_HIP_TRY(hipStreamSynchronize(z->st));
+	if (z->d_phases) {
+		unsigned long long ph[8];
+		BGZF_HIP_TRY(hipMemcpy(ph, z->d_phases, 64, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[ngm-hip] BGZF kernel, us of thread 0 per block (100 MHz clock): load %.1f | matching %.1f | crc + histograms %.1f | code lengths + codes %.1f | header + match scan %.1f | token bits %.1f | emit + copy out %.1f\n",
+				ph[0] / 100.0 / nb, ph[1] / 100.0 / nb, ph[2] / 100.0 / nb, ph[3] / 100.0 / nb, ph[4] / 100.0 / nb, ph[5] / 100.0 / nb, ph[6] / 100.0 / nb);
+	}
 	float ms = 0.f;
 	if (hipEventElapsedTime(&ms, z->ev0, z->ev1) == hipSuccess) z->last_ms = ms;
 	return (long long) total;

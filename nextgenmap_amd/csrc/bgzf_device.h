@@ -5,20 +5,20 @@
 // with the reference's.  zlib level 6 costs ~25 core-ms per block, and the GPU boxes of this pool give a container 16 CPUs: 2 M reads/s
 // however the work is spread.  BGZF blocks are independent DEFLATE streams of <= 0xFF00 input bytes -- one workgroup
 // per block, the block in LDS:
-//   matching   the block is cut into 4 segments of 16 320 bytes, one wave each.  A wave walks its segment 64 positions at a time:
+//   matching   the block is cut into 8 segments of 8 192 bytes, one wave each.  A wave walks its segment 64 positions at a time:
 //              every lane hashes the 4 bytes at its position, reads the most recent earlier position with that hash from the wave's
 //              table (ds_max keeps the largest position: deterministic), extends that candidate and the distance-1 candidate (runs)
 //              by 4-byte compares; then the wave parses the 64 positions greedily, with one step of lazy evaluation, in a scalar loop
 //              over v_readlane -- bit masks of the positions that start a literal / a match, the matches (position, length, distance)
 //              appended to a list in global memory;
-//   CRC-32     256 bytes per thread, combined with x^(8 m) mod P from a table (the gzip trailer's CRC);
+//   CRC-32     128 bytes per thread, combined with x^(8 m) mod P from a table (the gzip trailer's CRC);
 //   Huffman    histograms by LDS atomics; code lengths by rank sort (parallel) + the two-queue merge and zlib's overflow repair (one
 //              thread; 286 symbols); canonical codes in parallel; the header carries all 286 + 30 lengths without run-length codes
 //              (~150 bytes per block);
-//   bits       every thread adds up the bits of the tokens that start in its 256 positions, a scan gives its bit offset, it writes its
+//   bits       every thread adds up the bits of the tokens that start in its 128 positions, a scan gives its bit offset, it writes its
 //              bits (whole words plain, the two shared boundary words by atomic OR) into the LDS image of the member;
 //   member     header (BSIZE), the DEFLATE bytes, CRC-32, ISIZE -> global memory, 64 KB stride; a block that does not shrink is stored.
-// Ratio against zlib level 6 on BAM records: see DESIGN.md 5 (hash of 4 bytes, one candidate + runs, 16 KB windows).
+// Ratio against zlib level 6 on BAM records: see DESIGN.md 5 (hash of 4 bytes, one candidate + runs, 8 KB windows).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -29,8 +29,10 @@ namespace ngm {
 namespace bgzf {
 
 constexpr int kIn = 0xFF00;        // input bytes per block
-constexpr int kNT = 256;
-constexpr int kSeg = 16320;        // bytes per wave (255 steps of 64)
+constexpr int kNT = 512;
+constexpr int kSegs = 8;           // waves = segments of a block
+constexpr int kSeg = 8192;         // bytes per wave (128 steps of 64; the last segment is shorter)
+constexpr int kChunk = 128;        // positions whose tokens one thread turns into bits (510 threads have some)
 constexpr int kStride = 65536;     // bytes between the members of consecutive blocks in the strided output
 constexpr int kMatCap = kSeg / 4 + 8;
 constexpr int kMaskWords = kIn / 32;   // 2040
@@ -42,11 +44,12 @@ struct Args {
 	int n_blocks;
 	uint8_t *out;                 // [n_blocks * kStride]
 	uint32_t *sizes;              // [n_blocks]
-	uint2 *scratch;               // [gridDim.x * 4 * kMatCap]
+	uint2 *scratch;               // [gridDim.x * kSegs * kMatCap]
 	const uint32_t *crc_table;    // [256]
 	const uint32_t *xpow;         // [kIn + 1]: x^(8 m) mod P, reflected
 	const uint8_t *len_code;      // [256]: length - 3 -> length symbol - 257
 	const uint8_t *dist_code;     // [512]: zlib's d_code table (distance - 1 < 256: [d], else [256 + (d >> 7)])
+	unsigned long long *phase_cycles;   // diagnostics (NGM_HIP_BGZF_PHASES): [8] cycles of thread 0 per phase, summed over the blocks
 };
 
 __device__ __constant__ const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -87,40 +90,48 @@ __device__ inline void build_lengths(const uint32_t *freq, int n, int max_bits, 
 		atomicAdd(&misc[0], 1u);
 	}
 	__syncthreads();
+	const int m = (int) misc[0];
+	uint32_t *bl = misc + 1;   // [max_bits + 2], then the number of leaves below max_bits
+	if (tid <= max_bits + 2) bl[tid] = 0;
+	if (m == 1) { if (tid == 0) len[ssym[0]] = 1; __syncthreads(); return; }
+	if (m == 0) { __syncthreads(); return; }
 	if (tid == 0) {
-		const int m = (int) misc[0];
-		if (m == 1) len[ssym[0]] = 1;
-		else if (m > 1) {
-			// two queues: leaves [0, m) ascending, internal nodes [m, 2 m - 1) in the order they are made (ascending too)
-			int i = 0, j = m;
-			for (int k = m; k < 2 * m - 1; ++k) {
-				uint32_t sum = 0;
-				for (int r = 0; r < 2; ++r) {
-					int pick;
-					if (i < m && (j >= k || w[i] <= w[j])) pick = i++; else pick = j++;
-					sum += w[pick];
-					parent[pick] = (uint32_t) k;
-				}
-				w[k] = sum;
+		// two queues: leaves [0, m) ascending, internal nodes [m, 2 m - 1) in the order they are made (ascending too); the heads in registers
+		int i = 0, j = m;
+		uint32_t wi = w[0], wj = 0xFFFFFFFFu;
+		for (int k = m; k < 2 * m - 1; ++k) {
+			uint32_t sum = 0;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				if (i < m && (j >= k || wi <= wj)) { sum += wi; parent[i] = (uint32_t) k; ++i; wi = i < m ? w[i] : 0xFFFFFFFFu; }
+				else { sum += wj; parent[j] = (uint32_t) k; ++j; wj = j < k ? w[j] : 0xFFFFFFFFu; }
 			}
-			uint32_t *bl = misc + 1;   // [max_bits + 2]
-			for (int b = 0; b <= max_bits + 1; ++b) bl[b] = 0;
-			w[2 * m - 2] = 0;   // depths over the weights, root first
-			int overflow = 0;
-			for (int k = 2 * m - 3; k >= 0; --k) {
-				const uint32_t d = w[parent[k]] + 1;
-				w[k] = d;
-				if (k < m) { if ((int) d > max_bits) { ++overflow; bl[max_bits] += 1; } else bl[d] += 1; }
-			}
-			while (overflow > 0) {   // zlib's gen_bitlen: move one leaf down from the deepest level that has one, two of the overflowing leaves take its place
-				int bits = max_bits - 1;
-				while (bl[bits] == 0) --bits;
-				bl[bits] -= 1; bl[bits + 1] += 2; bl[max_bits] -= 1;
-				overflow -= 2;
-			}
-			int k = 0;   // the rarest symbols get the longest codes
-			for (int bits = max_bits; bits >= 1; --bits) for (uint32_t c = 0; c < bl[bits]; ++c) len[ssym[k++]] = (uint32_t) bits;
+			w[k] = sum;
+			if (j == k) wj = sum;
 		}
+	}
+	__syncthreads();
+	// depth of every leaf: up the parents to the root (2 m - 2), all leaves at once
+	for (int k = tid; k < m; k += kNT) {
+		int d = 0;
+		for (uint32_t x = (uint32_t) k; x != (uint32_t) (2 * m - 2); x = parent[x]) ++d;
+		if (d > max_bits) { d = max_bits; atomicAdd(&bl[max_bits + 2], 1u); }
+		atomicAdd(&bl[d], 1u);
+	}
+	__syncthreads();
+	if (tid == 0) {
+		int overflow = (int) bl[max_bits + 2];
+		while (overflow > 0) {   // zlib's gen_bitlen: move one leaf down from the deepest level that has one, two of the overflowing leaves take its place
+			int bits = max_bits - 1;
+			while (bl[bits] == 0) --bits;
+			bl[bits] -= 1; bl[bits + 1] += 2; bl[max_bits] -= 1;
+			overflow -= 2;
+		}
+	}
+	__syncthreads();
+	for (int k = tid; k < m; k += kNT) {   // the rarest symbols get the longest codes
+		uint32_t c = 0;
+		for (int bits = max_bits; bits >= 1; --bits) { c += bl[bits]; if ((uint32_t) k < c) { len[ssym[k]] = (uint32_t) bits; break; } }
 	}
 	__syncthreads();
 }
@@ -172,7 +183,7 @@ struct BitOut {
 __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 	uint32_t *in = lds;                              // 65 536 bytes: the block + zero padding
-	uint32_t *U = in + 16384;                        // 65 536 bytes: the four hash tables, later the image of the member
+	uint32_t *U = in + 16384;                        // 65 536 bytes: the eight hash tables, later the image of the member
 	uint32_t *lit_mask = U + 16384;                  // [2048]
 	uint32_t *mat_mask = lit_mask + 2048;            // [2048]
 	uint32_t *hist_ll = mat_mask + 2048;             // [288]
@@ -189,8 +200,11 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 	uint32_t *sh = tmp + 5 * 288 + 64;               // [64] scalars: nmat[4], scans, CRC, bit counts
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint8_t *inb = (const uint8_t *) in;
-	crc_t[tid] = A.crc_table[tid];
+	if (tid < 256) crc_t[tid] = A.crc_table[tid];
+	unsigned long long t_prev = 0;
+	auto phase = [&](int k) { if (A.phase_cycles && tid == 0) { const unsigned long long t = wall_clock64(); if (k >= 0) atomicAdd(&A.phase_cycles[k], t - t_prev); t_prev = t; } };
 	for (int blk = blockIdx.x; blk < A.n_blocks; blk += gridDim.x) {
+		phase(-1);
 		const unsigned long long at = (unsigned long long) blk * kIn;
 		const int len = (int) (A.n - at < (unsigned long long) kIn ? A.n - at : (unsigned long long) kIn);
 		__syncthreads();   // (the previous block's image has been copied out)
@@ -212,11 +226,12 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 			if (tid < 64) sh[tid] = 0;
 		}
 		__syncthreads();
+		phase(0);
 		// ---- matching: one wave per segment ---------------------------------------------------------------------------
 		{
 			const int s0 = wv * kSeg, s1 = min(len, s0 + kSeg);
-			uint32_t *tab = U + wv * 4096;
-			uint2 *mlist = A.scratch + ((size_t) blockIdx.x * 4 + wv) * kMatCap;
+			uint32_t *tab = U + wv * 2048;
+			uint2 *mlist = A.scratch + ((size_t) blockIdx.x * kSegs + wv) * kMatCap;
 			int cur = s0, nm = 0;
 			for (int base = s0; base < s1; base += 64) {
 				const int i = base + lane;
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 				const bool can = i + 4 <= s1;
 				uint32_t cand = 0;
 				if (can) {
-					const uint32_t h = (load32u(in, (uint32_t) i) * 2654435761u) >> 20;
+					const uint32_t h = (load32u(in, (uint32_t) i) * 2654435761u) >> 21;
 					cand = tab[h];
 					atomicMax(&tab[h], (uint32_t) (i - s0 + 1));
 				}
@@ -249,20 +264,25 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 						if (l >= 4 && (uint32_t) l >= mylen) { mylen = (uint32_t) l; mydist = 1; }
 					}
 				}
-				// greedy parse of these 64 positions, one step of lazy evaluation (wave-uniform)
+				// greedy parse of these 64 positions, one step of lazy evaluation -- wave-uniform: the lanes with a match as a bit mask, the
+				// literals between two matches as a range of bits, v_readlane only where a match is taken or weighed
 				unsigned long long litb = 0, matb = 0;
-				const int step_end = min(base + 64, s1);
-				while (cur < step_end) {
+				const int nstep = min(64, s1 - base);
+				const unsigned long long mm = __ballot(mylen >= 4u);
+				auto below = [](int b) -> unsigned long long { return b >= 64 ? ~0ull : ((1ull << b) - 1ull); };
+				while (cur < base + nstep) {
 					const int k = __builtin_amdgcn_readfirstlane(cur - base);
-					const uint32_t L = (uint32_t) __builtin_amdgcn_readlane((int) mylen, k);
-					if (L >= 4) {
-						if (cur + 1 < step_end) {
-							const uint32_t L1 = (uint32_t) __builtin_amdgcn_readlane((int) mylen, k + 1);
-							if (L1 > L) { litb |= 1ull << k; cur += 1; continue; }
-						}
-						matb |= 1ull << k;
-						cur += (int) L;
-					} else { litb |= 1ull << k; cur += 1; }
+					const unsigned long long rest = mm & ~below(k);
+					if (rest == 0ull) { litb |= below(nstep) & ~below(k); cur = base + nstep; break; }
+					const int k2 = __builtin_amdgcn_readfirstlane((int) __ffsll((long long) rest) - 1);
+					litb |= below(k2) & ~below(k);
+					const uint32_t L = (uint32_t) __builtin_amdgcn_readlane((int) mylen, k2);
+					if (k2 + 1 < nstep && ((mm >> (k2 + 1)) & 1ull)) {
+						const uint32_t L1 = (uint32_t) __builtin_amdgcn_readlane((int) mylen, k2 + 1);
+						if (L1 > L) { litb |= 1ull << k2; cur = base + k2 + 1; continue; }
+					}
+					matb |= 1ull << k2;
+					cur = base + k2 + (int) L;
 				}
 				if ((matb >> lane) & 1ull) {
 					const int idx = nm + __popcll(matb & ((1ull << lane) - 1ull));
@@ -278,23 +298,24 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 		}
 		__threadfence_block();
 		__syncthreads();
+		phase(1);
 		// ---- image cleared; CRC-32; histograms -------------------------------------------------------------------------
 		for (int wd = tid; wd < 16384; wd += kNT) U[wd] = 0;
 		{
-			const int b0 = tid * 256, b1 = min(len, b0 + 256);
+			const int b0 = tid * kChunk, b1 = min(len, b0 + kChunk);
 			uint32_t c = 0;
 			for (int b = b0; b < b1; ++b) c = crc_t[(c ^ inb[b]) & 255u] ^ (c >> 8);
 			uint32_t part = (b1 > b0 && c) ? crc_mulmod(c, A.xpow[len - b1]) : 0u;
-			if (tid == 255) part ^= crc_mulmod(0xFFFFFFFFu, A.xpow[len]) ^ 0xFFFFFFFFu;
+			if (tid == kNT - 1) part ^= crc_mulmod(0xFFFFFFFFu, A.xpow[len]) ^ 0xFFFFFFFFu;
 			for (int o = 32; o > 0; o >>= 1) part ^= (uint32_t) __shfl_xor((int) part, o);
 			if (lane == 0) atomicXor(&sh[8], part);
-			// literals of my 256 positions, then my share of the matches
-			if (tid < 255) for (int j = 0; j < 8; ++j) {
-				uint32_t m = lit_mask[tid * 8 + j];
+			// literals of my positions, then my share of the matches
+			if (tid < kIn / kChunk) for (int j = 0; j < kChunk / 32; ++j) {
+				uint32_t m = lit_mask[tid * (kChunk / 32) + j];
 				while (m) { const int bit = __ffs((int) m) - 1; m &= m - 1; atomicAdd(&hist_ll[inb[b0 + j * 32 + bit]], 1u); }
 			}
-			for (int s = 0; s < 4; ++s) {
-				const uint2 *mlist = A.scratch + ((size_t) blockIdx.x * 4 + s) * kMatCap;
+			for (int s = 0; s < kSegs; ++s) {
+				const uint2 *mlist = A.scratch + ((size_t) blockIdx.x * kSegs + s) * kMatCap;
 				const int nm = (int) sh[s];
 				for (int m = tid; m < nm; m += kNT) {
 					const uint2 e = mlist[m];
@@ -306,6 +327,7 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 			if (tid == 0) atomicAdd(&hist_ll[256], 1u);
 		}
 		__syncthreads();
+		phase(2);
 		// ---- Huffman codes ----------------------------------------------------------------------------------------------
 		build_lengths(hist_ll, 286, 15, len_ll, tmp, tid);
 		build_lengths(hist_d, 30, 15, len_d, tmp, tid);
@@ -315,6 +337,7 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 		build_codes(len_ll, 286, code_ll, tmp, tid);
 		build_codes(len_d, 30, code_d, tmp, tid);
 		build_codes(len_p, 19, code_p, tmp, tid);
+		phase(3);
 		// ---- block header (thread 0) and the bits of every thread's tokens --------------------------------------------
 		if (tid == 0) {
 			BitOut o(U, kHdrBits);
@@ -330,12 +353,13 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 			o.finish();
 			sh[9] = bits;
 		}
-		// tokens that start in positions [256 tid, 256 tid + 256): walk(emit) -> bits
-		uint32_t my_words_l[8], my_words_m[8];
+		// tokens that start in positions [kChunk tid, kChunk (tid + 1)): walk(emit) -> bits
+		constexpr int kCW = kChunk / 32;
+		uint32_t my_words_l[kCW], my_words_m[kCW];
 		uint32_t nmatch_mine = 0;
-		if (tid < 255) {
+		if (tid < kIn / kChunk) {
 #pragma unroll
-			for (int j = 0; j < 8; ++j) { my_words_l[j] = lit_mask[tid * 8 + j]; my_words_m[j] = mat_mask[tid * 8 + j]; nmatch_mine += (uint32_t) __popc(my_words_m[j]); }
+			for (int j = 0; j < kCW; ++j) { my_words_l[j] = lit_mask[tid * kCW + j]; my_words_m[j] = mat_mask[tid * kCW + j]; nmatch_mine += (uint32_t) __popc(my_words_m[j]); }
 		}
 		// matches before my positions (block-wide exclusive scan of the per-thread counts)
 		uint32_t mscan = nmatch_mine;
@@ -346,15 +370,15 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 		for (int w2 = 0; w2 < wv; ++w2) mbefore += sh[16 + w2];
 		auto walk = [&](auto emit) -> uint32_t {
 			uint32_t bits = 0;
-			if (tid >= 255) return 0u;
-			const int p0 = tid * 256;
-			int seg = p0 / kSeg;
+			if (tid >= kIn / kChunk) return 0u;
+			const int p0 = tid * kChunk;
+			const int seg = p0 / kSeg;   // (a thread's positions lie in one segment)
 			uint32_t seg_first = 0;   // matches in the segments before `seg`
 			for (int s = 0; s < seg; ++s) seg_first += sh[s];
 			uint32_t midx = mbefore - seg_first;
-			const uint2 *mlist = A.scratch + ((size_t) blockIdx.x * 4 + seg) * kMatCap;
+			const uint2 *mlist = A.scratch + ((size_t) blockIdx.x * kSegs + seg) * kMatCap;
 #pragma unroll 1
-			for (int j = 0; j < 8; ++j) {
+			for (int j = 0; j < kCW; ++j) {
 				uint32_t lm = my_words_l[j], mm = my_words_m[j], both = lm | mm;
 				while (both) {
 					const int bit = __ffs((int) both) - 1;
@@ -365,8 +389,6 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 						bits += c >> 16;
 						emit(c & 0xFFFFu, (int) (c >> 16));
 					} else {
-						const int sg = pos / kSeg;
-						if (sg != seg) { seg = sg; midx = 0; mlist = A.scratch + ((size_t) blockIdx.x * 4 + seg) * kMatCap; }
 						const uint2 e = mlist[midx++];
 						const uint32_t l3 = (e.x >> 16) & 255u, lc = A.len_code[l3];
 						const uint32_t c = code_ll[257 + lc];
@@ -383,25 +405,27 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 			}
 			return bits;
 		};
+		phase(4);
 		const uint32_t my_bits = walk([](uint32_t, int) {});
 		uint32_t bscan = my_bits;
 		for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t) __shfl_up((int) bscan, o); if (lane >= o) bscan += v; }
-		if (lane == 63) sh[20 + wv] = bscan;
+		if (lane == 63) sh[24 + wv] = bscan;
 		__syncthreads();
 		uint32_t bit0 = kHdrBits + sh[9] + bscan - my_bits;
 		uint32_t total_bits = sh[9];
-		for (int w2 = 0; w2 < 4; ++w2) { if (w2 < wv) bit0 += sh[20 + w2]; total_bits += sh[20 + w2]; }
+		for (int w2 = 0; w2 < kSegs; ++w2) { if (w2 < wv) bit0 += sh[24 + w2]; total_bits += sh[24 + w2]; }
 		const uint32_t eob = code_ll[256];
 		total_bits += eob >> 16;
 		const uint32_t clen = (total_bits + 7u) >> 3;
 		const bool stored = clen >= (uint32_t) len + 5u || clen + 26u > (uint32_t) kStride;
 		uint8_t *dst = A.out + (size_t) blk * kStride;
 		const uint32_t crc = sh[8];
+		phase(5);
 		if (!stored) {
 			{
 				BitOut o(U, bit0);
 				(void) walk([&](uint32_t v, int nb) { o.put(v, nb); });
-				if (tid == 255) o.put(eob & 0xFFFFu, (int) (eob >> 16));   // (thread 255 has no positions: bit0 = the end of the tokens)
+				if (tid == kNT - 1) o.put(eob & 0xFFFFu, (int) (eob >> 16));   // (the last thread has no positions: bit0 = the end of the tokens)
 				o.finish();
 			}
 			const uint32_t size = 18u + clen + 8u;
@@ -432,6 +456,7 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 			}
 			for (int b = tid; b < len; b += kNT) dst[23 + b] = inb[b];
 		}
+		phase(6);
 	}
 }
 

@@ -712,9 +712,11 @@ int main(int argc, char **argv) {
 	// they are used.
 	struct TextBuf { char *p; size_t cap; };
 	struct EarlyPinned {
-		struct W { char *rows = nullptr, *qrows = nullptr, *names = nullptr; ngm_sam_read *meta = nullptr; };
+		struct W { char *rows = nullptr, *qrows = nullptr, *names = nullptr; ngm_sam_read *meta = nullptr; char *bam_raw = nullptr, *bam_out = nullptr; };
 		std::thread th;
 		int q = 0, batch = 0;
+		bool bam = false;
+		size_t bam_raw_cap = 0, bam_out_cap = 0;
 		std::vector<TextBuf> text;
 		std::vector<W> w;
 		~EarlyPinned() { if (th.joinable()) th.join(); }
@@ -722,7 +724,8 @@ int main(int argc, char **argv) {
 	{
 		const int early_topn = o.paired ? 1 : o.topn;
 		const bool early_gpu_sam = !o.bam && early_topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
-		if (early_gpu_sam && !(o.qry.empty() && o.qry1.empty()) && !o.out.empty() && !getenv("NGM_HIP_NO_EARLY_PINNED")) {
+		const bool early_gpu_bgzf = o.bam && !getenv("NGM_HIP_BAM_ZLIB");
+		if ((early_gpu_sam || early_gpu_bgzf) && !(o.qry.empty() && o.qry1.empty()) && !o.out.empty() && !getenv("NGM_HIP_NO_EARLY_PINNED")) {
 			size_t peek_max = 0;
 			if (o.max_read_length > 0) peek_max = (size_t) o.max_read_length;
 			else {
@@ -733,13 +736,21 @@ int main(int argc, char **argv) {
 			if (peek_max > 0) {
 				early.q = std::min(1000, (int) ((peek_max | 1) + 1));
 				early.batch = o.paired ? (o.batch & ~1) : o.batch;
-				early.text.assign(o.devices.size() * (size_t) o.workers + 2, TextBuf{nullptr, 0});
+				early.bam = early_gpu_bgzf;
+				if (!early.bam) early.text.assign(o.devices.size() * (size_t) o.workers + 2, TextBuf{nullptr, 0});
 				early.w.resize(o.devices.size() * (size_t) o.workers);
+				// (--bam: a batch's records -- 36 bytes + name + CIGAR + 1.5 bytes per base + tags each -- and its BGZF blocks)
+				early.bam_raw_cap = (size_t) early.batch * ((size_t) 2 * early.q + 224) + (1u << 20);
+				early.bam_out_cap = ngm_bgzf_bound(early.bam_raw_cap);
 				early.th = std::thread([&early] {
 					const size_t cap = (size_t) early.batch * ((size_t) 2 * early.q + 288) + (1u << 20);
 					std::vector<std::thread> alloc;
 					for (TextBuf &t : early.text) alloc.emplace_back([&t, cap] { t.p = (char *) ngm_host_alloc(cap); t.cap = t.p ? cap : 0; });
-					for (EarlyPinned::W &w : early.w) alloc.emplace_back([&w, &early] {
+					if (early.bam) for (EarlyPinned::W &w : early.w) {
+						alloc.emplace_back([&w, &early] { w.bam_raw = (char *) ngm_host_alloc(early.bam_raw_cap); });
+						alloc.emplace_back([&w, &early] { w.bam_out = (char *) ngm_host_alloc(early.bam_out_cap); });
+					}
+					else for (EarlyPinned::W &w : early.w) alloc.emplace_back([&w, &early] {
 						const size_t rows = (size_t) early.batch * early.q;
 						w.rows = (char *) ngm_host_alloc(rows); w.qrows = (char *) ngm_host_alloc(rows);
 						w.meta = (ngm_sam_read *) ngm_host_alloc((size_t) early.batch * sizeof(ngm_sam_read));
@@ -1389,7 +1400,16 @@ int main(int argc, char **argv) {
 	std::vector<TextBuf> text_free;
 	const size_t text_cap0 = (size_t) batch_reads * ((size_t) 2 * q + 288) + (1u << 20);
 	if (early.th.joinable()) early.th.join();
-	bool early_ok = gpu_sam && early.q >= q && early.batch == batch_reads && early.w.size() == workers.size();
+	if (early.bam && gpu_bgzf && early.w.size() == workers.size()) {
+		// (the GPU BGZF path: the buffers carry their sizes, a batch that needs more replaces them)
+		for (size_t i = 0; i < workers.size(); ++i) if (early.w[i].bam_raw && early.w[i].bam_out) {
+			workers[i].bam_raw = early.w[i].bam_raw; workers[i].bam_out = early.w[i].bam_out;
+			workers[i].bam_raw_cap = early.bam_raw_cap; workers[i].bam_out_cap = early.bam_out_cap;
+			early.w[i].bam_raw = early.w[i].bam_out = nullptr;
+		}
+	}
+	for (EarlyPinned::W &w : early.w) { ngm_host_free(w.bam_raw); ngm_host_free(w.bam_out); w.bam_raw = w.bam_out = nullptr; }
+	bool early_ok = gpu_sam && !early.bam && early.q >= q && early.batch == batch_reads && early.w.size() == workers.size();
 	for (const TextBuf &t : early.text) early_ok = early_ok && t.p;
 	for (const EarlyPinned::W &w : early.w) early_ok = early_ok && w.rows && w.qrows && w.meta && w.names;
 	if (early_ok) {
