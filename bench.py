@@ -374,7 +374,8 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
                           "with a 1-pair run" % (threads, os.cpu_count() or 1, cores, ns, t_all, t_load),
                 "parity_vs_reference_sam": {"records_compared": ns, "identical_lines": same, "first_differences": diffs,
                                             "note": "whole SAM lines, differing fields listed; the reference runs %d CS threads, each with its own running mean insert "
-                                                    "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads},
+                                                    "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads,
+                                            "reference_vs_itself": self_check},
                 "parity_vs_reference_sam_t1": {"records_compared": len(th1), "identical_lines": same1, "first_differences": diffs1, "seconds": t_t1, "ngm_hip_on_the_same_slice": early,
                                                "note": "ngm-core --affine -t 1 on the first %d reads: the run ngm-hip reproduces" % n1}}
     for fn in files:
@@ -706,6 +707,11 @@ def main():
             t.join()
         return np.sum(acc, axis=0)
 
+    # set-up, not warm-up: every read set once, so that the mappers' device and page-locked buffers have seen their largest batch
+    # (they grow to what a batch needs; with fewer warm-up steps than read sets that growth -- hipFree + hipMalloc, device-wide
+    # synchronisations -- would fall into the timed steps)
+    if S > 1:
+        run(S)
     run(args.warmup)
     barrier()
     t0 = time.perf_counter()

@@ -2,6 +2,8 @@
 // the mapping pipeline (mapper.cpp), plus the entry points that run the DP kernels on an already packed batch.
 #pragma once
 
+#include <algorithm>
+
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -22,6 +24,10 @@ struct DevBuf {
 		if (p) (void) hipFree(p);
 		p = nullptr;
 		cap = 0;
+		// (an eighth more than asked for: batches of a real run differ by a few per cent, and every new maximum would otherwise be a
+		// hipFree + hipMalloc -- two device-wide synchronisations -- in the middle of the mapping pass)
+		const size_t want = n + std::min<size_t>(n / 8, ((size_t) 64 << 20) / sizeof(T));   // (at most 64 MB more: the index arrays come through here too)
+		if (hipMalloc(&p, want * sizeof(T)) == hipSuccess) { cap = want; return 0; }
 		if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return -1;
 		cap = n;
 		return 0;
@@ -38,6 +44,8 @@ struct PinnedBuf {
 		if (p) (void) hipHostFree(p);
 		p = nullptr;
 		cap = 0;
+		const size_t want = n + std::min<size_t>(n / 8, ((size_t) 64 << 20) / sizeof(T));
+		if (hipHostMalloc(&p, want * sizeof(T), hipHostMallocDefault) == hipSuccess) { cap = want; return 0; }
 		if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) return -1;
 		cap = n;
 		return 0;

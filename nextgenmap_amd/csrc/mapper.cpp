@@ -1811,7 +1811,10 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			const bool rev = a_sv[j] & 1u;
 			h.reverse = rev;
 			const char *rd = reads + (size_t) i * q;
-			const int L = (int) strnlen(rd, q);
+			// (the read's length is only needed where the strings are built here: the rows of a batch -- 160 MB per million reads -- are
+			// not touched on the host when the GPU has built CIGAR and MD)
+			int L_cached = -1;
+			auto read_length = [&]() { if (L_cached < 0) L_cached = (int) strnlen(rd, q); return L_cached; };
 			ngm_hip_align_out ao{};
 			ao.cigar = sam ? scr.data() : cigars + o * str_stride;
 			ao.md = sam ? scr.data() + str_stride : mds + o * str_stride;
@@ -1829,12 +1832,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			} else if (m->prm.personality == NGM_PERSONALITY_AFFINE) {
 				// matches / mismatches were counted by the traceback kernel: no window decode, no reverse complement here.
 				// EndToEndAffine never touches pBuffer2: the SAM record carries AlignmentBuffer's "!!!" (AlignmentBuffer.cpp:109)
-				ngm::build_cigar_affine(&h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], nullptr, nullptr, q, &ao, L);
+				ngm::build_cigar_affine(&h_rec[(size_t) j * 8], &h_runs[(size_t) (uint32_t) h_rec[(size_t) j * 8 + 6]], nullptr, nullptr, q, &ao, read_length());
 				memcpy(ao.md, "!!!", 4);
 			} else {
 				const uint64_t offset = (uint64_t) a_loc[j] - (uint64_t) (c >> 1);
 				host_window(r, offset, align_buf_len, q + c, win.data());
 				memset(qry.data(), 0, qry.size());
+				const int L = read_length();
 				if (!rev) memcpy(qry.data(), rd, L);
 				else for (int t = 0; t < L; ++t) {
 					const char ch = rd[L - 1 - t];
