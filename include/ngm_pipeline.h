@@ -183,6 +183,8 @@ typedef struct ngm_sam_options {
 	const char *rg_id;          /* read group id for the RG:Z tag, or NULL */
 	int bs_mapping;             /* Config "bs_mapping": the ZS:Z tag (src/writer/SAMWriter.cpp:173-187) */
 	int slam_seq;               /* Config SLAM_SEQ != 0: the TC:i / RA:Z / MP:Z tags (src/writer/SAMWriter.cpp:203-221, GenericReadWriter.h:87-186) */
+	int bam;                    /* Config "bam": the records as BAM (src/writer/BAMWriter.cpp:147-375), in BGZF blocks written by the GPU -- what
+	                             * ngm_mapper_map_sam returns is then a piece of the BAM file (whole BGZF members); not with slam_seq */
 } ngm_sam_options;
 int ngm_mapper_set_sam_options(ngm_mapper *m, const ngm_sam_options *o);
 typedef struct ngm_sam_read {   /* per read: where its name is, how long its quality string is */
@@ -225,6 +227,7 @@ ngm_bgzf *ngm_bgzf_create(int device);
 void ngm_bgzf_destroy(ngm_bgzf *z);
 size_t ngm_bgzf_bound(size_t n);
 long long ngm_bgzf_compress(ngm_bgzf *z, const void *raw, size_t n, void *out, size_t out_cap);
+long long ngm_bgzf_compress_device(ngm_bgzf *z, const void *d_raw, size_t n, void *out, size_t out_cap);   /* raw bytes already in the device's memory */
 float ngm_bgzf_last_kernel_ms(const ngm_bgzf *z);   /* HIP-event time of the last call's compression kernel */
 
 /* page-locked host memory for read batches (the H2D copy then runs at PCIe rate without a staging copy) */

@@ -106,19 +106,34 @@ extern "C" size_t ngm_bgzf_bound(size_t n) { return n + 64 * ((n + ngm::bgzf::kI
 
 extern "C" float ngm_bgzf_last_kernel_ms(const ngm_bgzf *z) { return z ? z->last_ms : 0.f; }
 
+static long long compress_on_device(ngm_bgzf *z, const uint8_t *d_raw, size_t n, void *out, size_t out_cap);
+
 extern "C" long long ngm_bgzf_compress(ngm_bgzf *z, const void *raw, size_t n, void *out, size_t out_cap) {
 	if (!z || (!raw && n) || !out) { ngm::pipeline_set_error("ngm_bgzf_compress: bad arguments"); return -22; }
 	if (n == 0) return 0;
-	if (out_cap < ngm_bgzf_bound(n)) { ngm::pipeline_set_error("ngm_bgzf_compress: the output buffer holds %zu bytes, %zu may be needed", out_cap, ngm_bgzf_bound(n)); return -22; }
 	BGZF_HIP_TRY(hipSetDevice(z->device));
-	const size_t nb = (n + ngm::bgzf::kIn - 1) / ngm::bgzf::kIn;
-	if (nb > 0x7fffffffull) { ngm::pipeline_set_error("ngm_bgzf_compress: too much input for one call"); return -22; }
 	if (n + 16 > z->raw_cap) {
 		(void) hipFree(z->d_raw); z->d_raw = nullptr; z->raw_cap = 0;
 		const size_t cap = n + n / 4 + 4096;
 		BGZF_HIP_TRY(hipMalloc(&z->d_raw, cap));
 		z->raw_cap = cap;
 	}
+	BGZF_HIP_TRY(hipMemcpyAsync(z->d_raw, raw, n, hipMemcpyHostToDevice, z->st));
+	return compress_on_device(z, z->d_raw, n, out, out_cap);
+}
+
+// the same for bytes that already are in this device's memory (complete: the caller has synchronised the stream that wrote them)
+extern "C" long long ngm_bgzf_compress_device(ngm_bgzf *z, const void *d_raw, size_t n, void *out, size_t out_cap) {
+	if (!z || (!d_raw && n) || !out) { ngm::pipeline_set_error("ngm_bgzf_compress_device: bad arguments"); return -22; }
+	if (n == 0) return 0;
+	BGZF_HIP_TRY(hipSetDevice(z->device));
+	return compress_on_device(z, (const uint8_t *) d_raw, n, out, out_cap);
+}
+
+static long long compress_on_device(ngm_bgzf *z, const uint8_t *d_raw, size_t n, void *out, size_t out_cap) {
+	if (out_cap < ngm_bgzf_bound(n)) { ngm::pipeline_set_error("ngm_bgzf_compress: the output buffer holds %zu bytes, %zu may be needed", out_cap, ngm_bgzf_bound(n)); return -22; }
+	const size_t nb = (n + ngm::bgzf::kIn - 1) / ngm::bgzf::kIn;
+	if (nb > 0x7fffffffull) { ngm::pipeline_set_error("ngm_bgzf_compress: too much input for one call"); return -22; }
 	if (nb > z->blocks_cap) {
 		(void) hipFree(z->d_out); (void) hipFree(z->d_sizes); (void) hipFree(z->d_offsets);
 		z->d_out = nullptr; z->d_sizes = nullptr; z->d_offsets = nullptr; z->blocks_cap = 0;
@@ -137,9 +152,8 @@ extern "C" long long ngm_bgzf_compress(ngm_bgzf *z, const void *raw, size_t n, v
 		BGZF_HIP_TRY(hipHostMalloc(&z->h_offsets, cap * 8, hipHostMallocDefault));
 		z->h_cap = cap;
 	}
-	BGZF_HIP_TRY(hipMemcpyAsync(z->d_raw, raw, n, hipMemcpyHostToDevice, z->st));
 	ngm::bgzf::Args A{};
-	A.raw = z->d_raw; A.n = n; A.n_blocks = (int) nb; A.out = z->d_out; A.sizes = z->d_sizes; A.scratch = z->d_scratch;
+	A.raw = d_raw; A.n = n; A.n_blocks = (int) nb; A.out = z->d_out; A.sizes = z->d_sizes; A.scratch = z->d_scratch;
 	A.crc_table = (const uint32_t *) (z->d_tables + kTabCrc); A.xpow = (const uint32_t *) (z->d_tables + kTabXpow);
 	A.len_code = z->d_tables + kTabLen; A.dist_code = z->d_tables + kTabDist;
 	A.phase_cycles = z->d_phases;

@@ -126,6 +126,7 @@ struct ngm_mapper {
 	ngm::PinnedBuf<char> p_str;
 	// SAM text on the GPU (sam_device.h)
 	ngm_sam_options sam_opt{};
+	ngm_bgzf *bz = nullptr;   // sam_opt.bam: the BGZF compressor of this mapper's BAM records
 	bool sam_ready = false;
 	std::string sam_rg;
 	ngm::DevBuf<char> d_sam_contig_names, d_sam_rg, d_sam_names, d_sam_text;
@@ -822,6 +823,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 				g_stage_hold_us[0] / 1e3, g_stage_wait_us[0] / 1e3, g_stage_hold_us[1] / 1e3, g_stage_wait_us[1] / 1e3, g_stage_hold_us[2] / 1e3, g_stage_wait_us[2] / 1e3);
 	DevGuard g(m->ref->device);
 	(void) hipStreamSynchronize(m->st);
+	ngm_bgzf_destroy(m->bz);
 	if (m->st_hi) { (void) hipStreamSynchronize(m->st_hi); (void) hipStreamDestroy(m->st_hi); }
 	if (m->st_copy) { (void) hipStreamSynchronize(m->st_copy); (void) hipStreamDestroy(m->st_copy); }
 	// (no other instance may be left waiting for an event of this one: its kernels have finished -- the stream was synchronised above)
@@ -1040,8 +1042,10 @@ int ngm_mapper_map_pe_resident(ngm_mapper *m, int n, const char *reads, const vo
 int ngm_mapper_set_sam_options(ngm_mapper *m, const ngm_sam_options *o) {
 	if (!m || !o) return -22;
 	DevGuard g(m->ref->device);
+	if (o->bam && o->slam_seq) { ngm::pipeline_set_error("ngm_mapper_set_sam_options: BAM records with SLAM-seq tags are formatted by the caller"); return -22; }
 	m->sam_opt = *o;
 	m->sam_opt.rg_id = nullptr;
+	if (o->bam && !m->bz) { m->bz = ngm_bgzf_create(m->ref->device); if (!m->bz) return -12; }
 	m->sam_rg = o->rg_id ? o->rg_id : "";
 	const ngm_ref *r = m->ref;
 	std::string names;
@@ -1078,6 +1082,13 @@ long long ngm_mapper_map_sam(ngm_mapper *m, int n, const char *reads, const char
 int ngm_mapper_sam_fetch(ngm_mapper *m, char *out, size_t out_cap) {
 	if (!m || !out || out_cap < m->sam_text_bytes) return -22;
 	DevGuard g(m->ref->device);
+	if (m->sam_opt.bam) {   // the last call's records are still in HBM: their BGZF blocks into the larger buffer; returns their length
+		if (!m->sam_text_bytes) return 0;
+		const long long zlen = ngm_bgzf_compress_device(m->bz, m->d_sam_text.p, (size_t) m->sam_text_bytes, out, out_cap);
+		if (zlen < 0 || zlen > 0x7fffffffll) return zlen < 0 ? (int) zlen : -75;
+		m->sam_text_bytes = 0;
+		return (int) zlen;
+	}
 	if (m->sam_text_bytes) MAP_HIP_TRY(hipMemcpy(out, m->d_sam_text.p, (size_t) m->sam_text_bytes, hipMemcpyDeviceToHost));
 	return 0;
 }
@@ -1903,6 +1914,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		S.slam_seq = m->sam_opt.slam_seq; S.variant_cpu = m->prm.variant == NGM_VARIANT_OCL_CPU ? 1 : 0; S.alt_scoring = (m->prm.bs_mapping || (m->prm.slam_seq & 2)) ? 1 : 0;
 		S.genome = r->d_genome; S.contig_start = m->d_sam_contig_start.p;
 		S.unit_len = m->d_sam_len.p; S.unit_off = m->d_sam_off.p; S.counters = m->d_total.p + 16;
+		S.bam = m->sam_opt.bam ? 1 : 0;
 		hipEvent_t e0 = m->cev[0], e1 = m->cev[1];
 		MAP_HIP_TRY(hipEventRecord(e0, m->st));
 		unsigned long long total = 0;
@@ -1936,13 +1948,27 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		unsigned long long ctr[3] = {0, 0, 0};
 		MAP_HIP_TRY(hipMemcpyAsync(ctr, m->d_total.p + 16, 24, hipMemcpyDeviceToHost, m->st));
 		m->sam_text_bytes = total;
-		if (total <= sam->out_cap && total > 0) MAP_HIP_TRY(hipMemcpyAsync(sam->out, m->d_sam_text.p, (size_t) total, hipMemcpyDeviceToHost, m->st));
+		const bool bam = m->sam_opt.bam != 0;
+		if (!bam && total <= sam->out_cap && total > 0) MAP_HIP_TRY(hipMemcpyAsync(sam->out, m->d_sam_text.p, (size_t) total, hipMemcpyDeviceToHost, m->st));
 		stage_sam.done_after(e1);   // the text (~420 bytes per read) travels while the next instance's kernels run
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		sam->text_bytes = (long long) total;
+		float bgzf_ms = 0.f;
+		if (bam && total > 0) {
+			// the records stay in HBM: their BGZF blocks are written there too (bgzf_device.h, the compressor's own stream -- beside the next
+			// instance's kernels), and only those travel
+			if (sam->out_cap < ngm_bgzf_bound((size_t) total)) sam->text_bytes = (long long) ngm_bgzf_bound((size_t) total);   // (> out_cap: ngm_mapper_sam_fetch with a buffer of that size)
+			else {
+				const long long zlen = ngm_bgzf_compress_device(m->bz, m->d_sam_text.p, (size_t) total, sam->out, sam->out_cap);
+				if (zlen < 0) return (int) zlen;
+				sam->text_bytes = zlen;
+				m->sam_text_bytes = 0;
+				bgzf_ms = ngm_bgzf_last_kernel_ms(m->bz);
+			}
+		}
 		if (sam->stats) { sam->stats[0] = ctr[0]; sam->stats[1] = ctr[1]; sam->stats[2] = ctr[2]; }
 		float t = 0;
-		sam->kernel_ms = hipEventElapsedTime(&t, e0, e1) == hipSuccess ? t : 0.f;
+		sam->kernel_ms = (hipEventElapsedTime(&t, e0, e1) == hipSuccess ? t : 0.f) + bgzf_ms;
 		lap(5);
 	}
 	if (host_timing)

@@ -723,8 +723,9 @@ int main(int argc, char **argv) {
 	} early;
 	{
 		const int early_topn = o.paired ? 1 : o.topn;
-		const bool early_gpu_sam = !o.bam && early_topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
-		const bool early_gpu_bgzf = o.bam && !getenv("NGM_HIP_BAM_ZLIB");
+		const bool early_gpu_bam = o.bam && !o.slam_seq && !getenv("NGM_HIP_BAM_ZLIB") && !getenv("NGM_HIP_BAM_HOST_RECORDS");
+		const bool early_gpu_sam = (!o.bam || early_gpu_bam) && early_topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
+		const bool early_gpu_bgzf = o.bam && !early_gpu_sam && !getenv("NGM_HIP_BAM_ZLIB");
 		if ((early_gpu_sam || early_gpu_bgzf) && !(o.qry.empty() && o.qry1.empty()) && !o.out.empty() && !getenv("NGM_HIP_NO_EARLY_PINNED")) {
 			size_t peek_max = 0;
 			if (o.max_read_length > 0) peek_max = (size_t) o.max_read_length;
@@ -998,9 +999,12 @@ int main(int argc, char **argv) {
 	}
 	ngm_pair_state *pair_state = ngm_pair_state_create();
 	// SAM text on the GPU (csrc/sam_device.h) for plain SAM output with one alignment per read; BAM and -n > 1 are formatted here
-	const bool gpu_sam = !o.bam && topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
-	// --bam: the records are formatted here, the BGZF blocks are written by the GPU (csrc/bgzf_device.h; NGM_HIP_BAM_ZLIB=1: zlib level 6 on the pool)
-	const bool gpu_bgzf = o.bam && !getenv("NGM_HIP_BAM_ZLIB");
+	// --bam: the records and their BGZF blocks are written by the GPU as well (sam_device.h's BAM mode + bgzf_device.h); with -n > 1,
+	// --broken-pairs or SLAM-seq tags the records are formatted here and only the blocks come from the GPU
+	// (NGM_HIP_BAM_HOST_RECORDS=1 forces that; NGM_HIP_BAM_ZLIB=1: records here, zlib level 6 on the pool -- the round-3 path)
+	const bool gpu_bam = o.bam && !o.slam_seq && !getenv("NGM_HIP_BAM_ZLIB") && !getenv("NGM_HIP_BAM_HOST_RECORDS");
+	const bool gpu_sam = (!o.bam || gpu_bam) && topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
+	const bool gpu_bgzf = o.bam && !gpu_sam && !getenv("NGM_HIP_BAM_ZLIB");
 	std::atomic<long long> t_bgzf_gpu_us{0}, t_bgzf_call_us{0};
 	std::atomic<unsigned long long> bgzf_in_bytes{0}, bgzf_out_bytes{0};
 	struct Worker { ngm_mapper *m = nullptr; char *rows = nullptr; size_t rows_cap = 0; std::vector<ngm_hit> hits; std::vector<char> cig, md;
@@ -1015,7 +1019,7 @@ int main(int argc, char **argv) {
 		if (gpu_sam) {
 			ngm_sam_options so{};
 			so.paired = o.paired; so.min_insert_size = o.min_insert; so.max_insert_size = o.max_insert; so.min_mq = o.min_mq;
-			so.min_identity = o.min_identity; so.min_residues = o.min_residues; so.no_unal = o.no_unal; so.rg_id = o.rg[0].empty() ? nullptr : o.rg[0].c_str(); so.bs_mapping = o.bs_mapping; so.slam_seq = o.slam_seq;
+			so.min_identity = o.min_identity; so.min_residues = o.min_residues; so.no_unal = o.no_unal; so.rg_id = o.rg[0].empty() ? nullptr : o.rg[0].c_str(); so.bs_mapping = o.bs_mapping; so.slam_seq = o.slam_seq; so.bam = o.bam ? 1 : 0;
 			if (ngm_mapper_set_sam_options(workers[w].m, &so) < 0) die(ngm_pipeline_last_error());
 		}
 		ngm_mapper_set_reference_cs_batch(workers[w].m, 1800000 / std::max(1, avg_len));
@@ -1570,7 +1574,8 @@ int main(int argc, char **argv) {
 					ngm_host_free(tb.p);
 					tb.cap = (size_t) len + (1u << 20);
 					tb.p = (char *) ngm_host_alloc(tb.cap);
-					if (!tb.p || ngm_mapper_sam_fetch(w.m, tb.p, tb.cap) < 0) len = -1;
+					const int got = tb.p ? ngm_mapper_sam_fetch(w.m, tb.p, tb.cap) : -1;
+					if (got < 0) len = -1; else if (o.bam) len = got;   // (BAM: the BGZF blocks are made by the fetch; it says how long they are)
 				}
 				if (len < 0) { fail(ngm_pipeline_last_error()); std::lock_guard<std::mutex> lk(text_mu); if (tb.p) text_free.push_back(tb); text_cv.notify_one(); continue; }
 				t_map_us += us_since(tm);
@@ -1763,7 +1768,7 @@ int main(int argc, char **argv) {
 				bgzf_in_bytes.load() / 1e6, bgzf_out_bytes.load() / 1e6, t_bgzf_gpu_us / 1e6, t_bgzf_call_us / 1e6);
 		info("MAIN", msg);
 	}
-	if (gpu_sam) { snprintf(msg, sizeof(msg), "SAM text assembled on the GPU: %.3f s of kernels (included above)", t_sam_gpu_us / 1e6); info("MAIN", msg); }
+	if (gpu_sam) { snprintf(msg, sizeof(msg), "%s on the GPU: %.3f s of kernels (included above)", o.bam ? "BAM records and their BGZF blocks written" : "SAM text assembled", t_sam_gpu_us / 1e6); info("MAIN", msg); }
 	snprintf(msg, sizeof(msg), "Input to output: %.3f s (estimation pass + mapping pass, first input byte to output closed)",
 			std::chrono::duration<double>(std::chrono::steady_clock::now() - t_input).count());
 	info("MAIN", msg);

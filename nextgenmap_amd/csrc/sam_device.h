@@ -50,11 +50,13 @@ struct SamArgs {
 	const uint32_t *unit_off;   // [units] exclusive prefix sums
 	char *out;
 	unsigned long long *counters;  // [0] reads counted [1] reads mapped [2] lines written
+	int bam;                    // the records as BAM (binary, uncompressed: BAMWriter.cpp:147-375 over bamtools' BamWriter_p.cpp) instead of SAM text
 };
 
 struct SamCountSink {
 	uint32_t n = 0;
 	__device__ __forceinline__ void put(char) { ++n; }
+	__device__ __forceinline__ void put32(uint32_t) { n += 4; }
 	__device__ __forceinline__ void bytes(const char *, uint32_t len) { n += len; }
 	__device__ __forceinline__ void seq_fwd(const uint8_t *, int len) { n += (uint32_t) len; }
 	__device__ __forceinline__ void seq_rc(const uint8_t *, int, int len) { n += (uint32_t) len; }
@@ -63,6 +65,7 @@ struct SamCountSink {
 struct SamWriteSink {
 	char *p;
 	__device__ __forceinline__ void put(char c) { *p++ = c; }
+	__device__ __forceinline__ void put32(uint32_t v) { p[0] = (char) v; p[1] = (char) (v >> 8); p[2] = (char) (v >> 16); p[3] = (char) (v >> 24); p += 4; }
 	__device__ __forceinline__ void bytes(const char *s, uint32_t len) { for (uint32_t i = 0; i < len; ++i) p[i] = s[i]; p += len; }
 	__device__ __forceinline__ void seq_fwd(const uint8_t *s, int len) { for (int i = 0; i < len; ++i) p[i] = (char) s[i]; p += len; }
 	// len characters: complement of s[last], s[last - 1], ...
@@ -175,11 +178,136 @@ __device__ __forceinline__ void sam_slam_tags(const SamArgs &A, Sink &s, const S
 	}
 }
 
-// SAMWriter::DoWriteReadGeneric (SAMWriter.cpp:98-228).  rnext: 0 '*', 1 '=', 2 the name of contig rnext_contig
+
+// ---- BAM records (`ngm --bam`): BAMWriter::DoWriteReadGeneric / DoWriteUnmappedReadGeneric (src/writer/BAMWriter.cpp:147-375) over bamtools'
+// BamWriterPrivate::WriteAlignment (lib/bamtools-2.3.0/src/api/internal/bam/BamWriter_p.cpp:180-300): bin, packed CIGAR, 4-bit bases,
+// phred values, typed tags.  The host twin is bam_writer.h's put_record with the tags ngm_cli.cpp adds; tests/test_gpu_bam.py decodes
+// the file and compares it with the reference's own --bam output.
+__device__ __forceinline__ uint32_t bam_min_bin(int begin, int end) {   // BamWriterPrivate::CalculateMinimumBin (BamWriter_p.cpp:33-41)
+	--end;
+	if ((begin >> 14) == (end >> 14)) return (uint32_t) (4681 + (begin >> 14));
+	if ((begin >> 17) == (end >> 17)) return (uint32_t) (585 + (begin >> 17));
+	if ((begin >> 20) == (end >> 20)) return (uint32_t) (73 + (begin >> 20));
+	if ((begin >> 23) == (end >> 23)) return (uint32_t) (9 + (begin >> 23));
+	if ((begin >> 26) == (end >> 26)) return (uint32_t) (1 + (begin >> 26));
+	return 0;
+}
+__device__ __forceinline__ uint32_t bam_base_code(char c) {   // "=ACMGRSVTWYHKDBN"
+	switch (c) {
+	case '=': return 0; case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5;
+	case 'S': return 6; case 'V': return 7; case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11;
+	case 'K': return 12; case 'D': return 13; case 'B': return 14; default: return 15;
+	}
+}
+template <typename Sink> __device__ __forceinline__ void bam_tag_int(Sink &s, char a, char b, int v) { s.put(a); s.put(b); s.put('i'); s.put32((uint32_t) v); }
+template <typename Sink> __device__ __forceinline__ void bam_tag_str(Sink &s, char a, char b, const char *v, uint32_t len) { s.put(a); s.put(b); s.put('Z'); s.bytes(v, len); s.put('\0'); }
+// the operations of a CIGAR text: f(length, operation code); returns the reference span (BAMWriter.cpp:207-215, bam_writer.h put_record)
+template <typename F> __device__ __forceinline__ int bam_cigar_ops(const char *cig, uint32_t len, F f) {
+	int span = 0;
+	uint32_t num = 0;
+	for (uint32_t c = 0; c < len; ++c) {
+		const char ch = cig[c];
+		if (ch >= '0' && ch <= '9') { num = num * 10u + (uint32_t) (ch - '0'); continue; }
+		uint32_t op;
+		switch (ch) {
+		case 'M': op = 0; span += (int) num; break;
+		case 'I': op = 1; break;
+		case 'D': op = 2; span += (int) num; break;
+		case 'N': op = 3; span += (int) num; break;
+		case 'S': op = 4; break;
+		case 'H': op = 5; break;
+		case 'P': op = 6; break;
+		case '=': op = 7; span += (int) num; break;
+		default: op = 8; span += (int) num; break;
+		}
+		f(num, op);
+		num = 0;
+	}
+	return span;
+}
 template <typename Sink>
-__device__ __forceinline__ void sam_mapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int rnext, int rnext_contig, unsigned long long pnext, long long tlen) {
+__device__ __forceinline__ void bam_mapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int mate_ref, long long mate_pos0, long long tlen) {
 	const ngm_hit &h = *v.h;
 	const int L = v.L;
+	const int qlen = v.m.qual_len & 0x7FFF;
+	const bool noq = qlen == 0;
+	const bool clip = A.hard_clip || A.silent_clip;
+	const int s0 = clip ? h.qstart : 0, sl = clip ? L - h.qstart - h.qend : L;
+	const int n = max(0, min(sl, 1000));
+	const int QL = min(qlen, L);
+	const SamRef rf = A.refs[v.i];
+	uint32_t n_ops = 0;
+	const int span = bam_cigar_ops(A.str + rf.cig_off, rf.cig_len, [&](uint32_t, uint32_t) { if (n_ops < 512u) ++n_ops; });
+	const uint32_t l_name = (uint32_t) v.m.name_len + 1u;
+	const uint32_t tags = 21u + (A.bs_mapping ? 6u : 0u) + 7u + 21u + (3u + rf.md_len + 1u) + (A.rg_len > 0 ? 3u + (uint32_t) A.rg_len + 1u : 0u);
+	s.put32(32u + l_name + 4u * n_ops + (uint32_t) ((n + 1) / 2) + (uint32_t) n + tags);
+	s.put32((uint32_t) h.contig);
+	s.put32((uint32_t) (int) h.pos);
+	s.put32((bam_min_bin((int) h.pos, (int) h.pos + span) << 16) | ((uint32_t) h.mapq << 8) | l_name);
+	s.put32(((uint32_t) flags << 16) | n_ops);
+	s.put32((uint32_t) n);
+	s.put32((uint32_t) mate_ref);
+	s.put32((uint32_t) (int) mate_pos0);
+	s.put32((uint32_t) (int) tlen);
+	s.bytes(A.names + v.m.name_off, v.m.name_len); s.put('\0');
+	{
+		uint32_t k = 0;
+		(void) bam_cigar_ops(A.str + rf.cig_off, rf.cig_len, [&](uint32_t len, uint32_t op) { if (k < 512u) { s.put32((len << 4) | op); ++k; } });
+	}
+	auto base = [&](int t) -> char {
+		if (!h.reverse) return (char) v.row[s0 + t];
+		const char ch = (char) v.row[L - 1 - (s0 + t)];
+		return ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch;
+	};
+	for (int t = 0; t < n; t += 2) s.put((char) ((bam_base_code(base(t)) << 4) | (t + 1 < n ? bam_base_code(base(t + 1)) : 0u)));
+	for (int t = 0; t < n; ++t) {
+		char qc = ':';
+		if (!noq) {
+			if (!h.reverse) { if (s0 + t < QL) qc = (char) v.qual[s0 + t]; }
+			else { const int at = QL - 1 - (s0 + t); if (at >= 0) qc = (char) v.qual[at]; }
+		}
+		s.put((char) (qc - 33));
+	}
+	bam_tag_int(s, 'A', 'S', (int) h.score); bam_tag_int(s, 'N', 'M', h.nm); bam_tag_int(s, 'N', 'H', h.n_best);
+	if (A.bs_mapping) {   // BAMWriter.cpp:240-254
+		const bool second = A.paired && (flags & 0x80);
+		bam_tag_str(s, 'Z', 'S', second ? (h.reverse ? "+-" : "--") : (h.reverse ? "-+" : "++"), 2u);
+	}
+	s.put('X'); s.put('I'); s.put('f'); s.put32(__float_as_uint(roundf(h.identity * 10000.0f) / 10000.0f));
+	bam_tag_int(s, 'X', '0', h.n_best); bam_tag_int(s, 'X', 'E', (int) h.max_votes); bam_tag_int(s, 'X', 'R', L - h.qstart - h.qend);
+	bam_tag_str(s, 'M', 'D', A.str + rf.md_off, rf.md_len);
+	if (A.rg_len > 0) bam_tag_str(s, 'R', 'G', A.rg, (uint32_t) A.rg_len);
+}
+template <typename Sink>
+__device__ __forceinline__ void bam_unmapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int contig, unsigned long long pos1) {
+	const int qlen = v.m.qual_len & 0x7FFF;
+	const int n = min(v.L, 1000), QL = min(qlen, v.L);
+	const int ref = contig >= 0 ? contig : -1, p0 = contig >= 0 ? (int) pos1 - 1 : -1;
+	const uint32_t l_name = (uint32_t) v.m.name_len + 1u;
+	const uint32_t tags = A.rg_len > 0 ? 3u + (uint32_t) A.rg_len + 1u : 0u;
+	s.put32(32u + l_name + (uint32_t) ((n + 1) / 2) + (uint32_t) n + tags);
+	s.put32((uint32_t) ref);
+	s.put32((uint32_t) p0);
+	s.put32((bam_min_bin(p0, p0) << 16) | l_name);
+	s.put32((uint32_t) (flags | 0x4) << 16);
+	s.put32((uint32_t) n);
+	s.put32((uint32_t) ref);
+	s.put32((uint32_t) p0);
+	s.put32(0u);
+	s.bytes(A.names + v.m.name_off, v.m.name_len); s.put('\0');
+	for (int t = 0; t < n; t += 2) s.put((char) ((bam_base_code((char) v.row[t]) << 4) | (t + 1 < n ? bam_base_code((char) v.row[t + 1]) : 0u)));
+	for (int t = 0; t < n; ++t) s.put((char) (((qlen != 0 && t < QL) ? (char) v.qual[t] : ':') - 33));
+	if (A.rg_len > 0) bam_tag_str(s, 'R', 'G', A.rg, (uint32_t) A.rg_len);
+}
+
+// SAMWriter::DoWriteReadGeneric (SAMWriter.cpp:98-228).  rnext: 0 '*', 1 '=', 2 the name of contig rnext_contig; bm_*: what BAMWriter::DoWritePair
+// passes on instead (mate reference, 0-based mate position, its own TLEN rule)
+template <typename Sink>
+__device__ __forceinline__ void sam_mapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int rnext, int rnext_contig, unsigned long long pnext, long long tlen,
+		int bm_ref = -1, long long bm_pos0 = -1, long long bm_tlen = 0) {
+	const ngm_hit &h = *v.h;
+	const int L = v.L;
+	if (A.bam) { bam_mapped(A, s, v, flags | (h.reverse ? 0x10 : 0), bm_ref, bm_pos0, bm_tlen); return; }
 	const int qlen = v.m.qual_len & 0x7FFF;
 	const bool noq = qlen == 0;
 	if (h.reverse) flags |= 0x10;
@@ -217,6 +345,7 @@ __device__ __forceinline__ void sam_mapped(const SamArgs &A, Sink &s, const SamV
 template <typename Sink>
 __device__ __forceinline__ void sam_unmapped(const SamArgs &A, Sink &s, const SamView &v, int flags, int contig, unsigned long long pos1, char rnext, unsigned long long pnext1) {
 	const int qlen = v.m.qual_len & 0x7FFF;
+	if (A.bam) { bam_unmapped(A, s, v, flags, contig, pos1); return; }
 	s.bytes(A.names + v.m.name_off, v.m.name_len); s.put('\t'); sam_u64(s, (unsigned) (flags | 0x4)); s.put('\t');
 	if (contig >= 0) sam_contig(A, s, contig); else s.put('*');
 	s.put('\t'); sam_u64(s, pos1); sam_lit(s, "\t0\t*\t"); s.put(rnext); s.put('\t'); sam_u64(s, pnext1); sam_lit(s, "\t0\t");
@@ -258,28 +387,30 @@ __device__ __forceinline__ void sam_unit(const SamArgs &A, int unit, Sink &s, ui
 		if (unal) { sam_unmapped(A, s, v2, f2 | 0x8, -1, 0, '*', 0); sam_unmapped(A, s, v1, f1 | 0x8, -1, 0, '*', 0); }
 		cnt[2] += 2 * unal;
 	} else if (!m1) {
-		sam_mapped(A, s, v2, f2 | 0x8, 1, 0, p2, 0);
+		sam_mapped(A, s, v2, f2 | 0x8, 1, 0, p2, 0, h2.contig, (long long) h2.pos, 0);
 		if (unal) sam_unmapped(A, s, v1, f1, h2.contig, p2, '=', p2);
 		cnt[2] += 1 + unal;
 	} else if (!m2) {
 		if (unal) sam_unmapped(A, s, v2, f2, h1.contig, p1, '=', p1);
-		sam_mapped(A, s, v1, f1 | 0x8, 1, 0, p1, 0);
+		sam_mapped(A, s, v1, f1 | 0x8, 1, 0, p1, 0, h1.contig, (long long) h1.pos, 0);
 		cnt[2] += 1 + unal;
 	} else if (!paired_fail) {
 		if (!h1.reverse) {
 			const long long d = ((long long) h2.pos + v2.L - h2.qstart - h2.qend) - (long long) h1.pos;
-			sam_mapped(A, s, v2, f2 | 0x2, 1, 0, p1, -d);
-			sam_mapped(A, s, v1, f1 | 0x2 | 0x20, 1, 0, p2, d);
+			const long long db = (long long) h2.pos + v2.L - (long long) h1.pos;   // BAMWriter.cpp:428-433: the whole read length
+			sam_mapped(A, s, v2, f2 | 0x2, 1, 0, p1, -d, h2.contig, (long long) h1.pos, -db);
+			sam_mapped(A, s, v1, f1 | 0x2 | 0x20, 1, 0, p2, d, h2.contig, (long long) h2.pos, db);
 			cnt[2] += 2;
 		} else if (!h2.reverse) {
 			const long long d = ((long long) h1.pos + v1.L - h1.qstart - h1.qend) - (long long) h2.pos;
-			sam_mapped(A, s, v2, f2 | 0x2 | 0x20, 1, 0, p1, d);
-			sam_mapped(A, s, v1, f1 | 0x2, 1, 0, p2, -d);
+			const long long db = (long long) h1.pos + v1.L - (long long) h2.pos;
+			sam_mapped(A, s, v2, f2 | 0x2 | 0x20, 1, 0, p1, d, h2.contig, (long long) h1.pos, db);
+			sam_mapped(A, s, v1, f1 | 0x2, 1, 0, p2, -d, h2.contig, (long long) h2.pos, -db);
 			cnt[2] += 2;
 		}
 	} else {
-		sam_mapped(A, s, v2, f2 | (h1.reverse ? 0x20 : 0), 2, h1.contig, p1, 0);
-		sam_mapped(A, s, v1, f1 | (h2.reverse ? 0x20 : 0), 2, h2.contig, p2, 0);
+		sam_mapped(A, s, v2, f2 | (h1.reverse ? 0x20 : 0), 2, h1.contig, p1, 0, h1.contig, (long long) h1.pos, 0);
+		sam_mapped(A, s, v1, f1 | (h2.reverse ? 0x20 : 0), 2, h2.contig, p2, 0, h2.contig, (long long) h2.pos, 0);
 		cnt[2] += 2;
 	}
 }

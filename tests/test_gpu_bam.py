@@ -136,3 +136,28 @@ def test_bam_shards_concatenate(tmp_path):
     strip = lambda t: [l.split("\tCL:")[0] if l.startswith("@PG") else l for l in t.splitlines()]
     assert strip(ta) == strip(tb)
     assert a == b
+
+
+@pytest.mark.parametrize("layout,extra", [("se", []), ("pe", []), ("pe", ["--silent-clip", "--no-unal", "--rg-id", "x", "-i", "0.9"]), ("se", ["--bs-mapping"]),
+                                          ("pe", ["--hard-clip", "-R", "0.7", "-Q", "10"])],
+                         ids=["single-end", "paired-end", "pe-silent-clip-no-unal-rg-identity", "se-bisulfite", "pe-hard-clip-filters"])
+def test_bam_paths_write_the_same_records(tmp_path, layout, extra):
+    """the three ways `ngm-hip --bam` can make its file -- records and BGZF blocks on the GPU (default), records on the host and blocks on
+    the GPU, records on the host and zlib level 6 -- decode to the same header and the same records in the same order"""
+    fa, inp = _case(tmp_path, layout == "pe")
+    decoded = []
+    for tag, env in (("gpu", {}), ("host_records", {"NGM_HIP_BAM_HOST_RECORDS": "1"}), ("zlib", {"NGM_HIP_BAM_ZLIB": "1"})):
+        out = str(tmp_path / (tag + ".bam"))
+        pers = [] if "--bs-mapping" in extra else ["--affine"]   # (bisulfite mapping is the default personality's)
+        c = subprocess.run([CLI, "-r", fa, "-o", out, "--bam", "--batch-size", "1500"] + pers + inp + extra, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert c.returncode == 0, c.stderr[-2000:]
+        assert ("BAM records and their BGZF blocks written on the GPU" in c.stderr) == (tag == "gpu"), c.stderr[-1500:]
+        decoded.append(decode_bam(out))
+    (t0, r0, a), (t1, r1, b), (t2, r2, z) = decoded
+    strip = lambda t: [l.split("\tCL:")[0] if l.startswith("@PG") else l for l in t.splitlines()]   # (the command line names the output file)
+    assert strip(t0) == strip(t1) == strip(t2) and r0 == r1 == r2
+    assert len(a) == len(b) == len(z) and len(a) > 1000
+    bad = [i for i in range(len(a)) if a[i] != z[i]]
+    for i in bad[:3]:
+        print([(k, a[i][k], z[i][k]) for k in a[i] if a[i][k] != z[i][k]])
+    assert not bad and b == z
