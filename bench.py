@@ -368,6 +368,15 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
                 os.remove(os.path.join(workdir, "ours_t1.sam"))
             except Exception as e:
                 early = [str(e)[:200]]
+        # the reference against itself across thread counts: the same reads in its -t N and its -t 1 output
+        t1_vs_tn = None
+        if th1:
+            both = [k_ for k_ in th1 if k_ in ref_body]
+            ref_moves = [k_ for k_ in both if th1[k_] != ref_body[k_]]
+            ours_off_here = [k_ for k_ in both if ours.get(k_) != ref_body[k_]]
+            t1_vs_tn = {"records_in_both_runs": len(both), "lines_the_reference_writes_differently_at_t1_and_tN": len(ref_moves),
+                        "ngm_hip_lines_that_differ_from_tN_here": len(ours_off_here),
+                        "of_these_identical_to_the_reference_at_t1": len([k_ for k_ in ours_off_here if ours.get(k_) == th1[k_]])}
         base = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
                 "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d (the CPUs this container may use: %d hardware threads, cgroup quota %d) on the first %d reads of the "
                           "end-to-end input vs the same genome (index loaded from the same cache files): %.1f s total minus %.1f s index load/start-up measured "
@@ -375,7 +384,7 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
                 "parity_vs_reference_sam": {"records_compared": ns, "identical_lines": same, "first_differences": diffs,
                                             "note": "whole SAM lines, differing fields listed; the reference runs %d CS threads, each with its own running mean insert "
                                                     "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads,
-                                            "reference_vs_itself": self_check},
+                                            "reference_vs_itself": self_check, "reference_t1_vs_tN": t1_vs_tn},
                 "parity_vs_reference_sam_t1": {"records_compared": len(th1), "identical_lines": same1, "first_differences": diffs1, "seconds": t_t1, "ngm_hip_on_the_same_slice": early,
                                                "note": "ngm-core --affine -t 1 on the first %d reads: the run ngm-hip reproduces" % n1}}
     for fn in files:
