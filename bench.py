@@ -462,7 +462,10 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens):
     starts = HL.sample_starts(G, R // 2 if paired else R, 400 if paired else READ_LEN, seed=20260930, repeat_share=args.heavy_tail_repeat_share)
     rows, truth_c, truth_p = make_reads(G.contigs, R, seed=20260931, paired=paired, subs=args.subs, indel_bases=args.indel_bases, starts=starts)
     d_rows = torch.from_numpy(rows).to(dev)
-    W = max(1, min(args.workers, R // 2048))
+    # (this workload's host stages -- order replay, pair selection of pairs with hundreds of candidates -- outweigh its kernels: four mapper
+    # instances per GPU instead of two keep the GPU fed; measured on one box with 2 / 3 / 4 instances: 1.13 / 1.41 / 1.47 M reads/s, while
+    # the uniform genome's step goes 51.6 / 49.7 / 47.8 M the other way)
+    W = max(1, min(max(args.workers, args.heavy_tail_workers), R // 2048))
     bounds = [(R * w // W) & ~1 for w in range(W)] + [R]
     out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
     kw = dict(gap_read=33, gap_ref=33, gap_extend=3, personality=1) if affine else {}
@@ -499,6 +502,7 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens):
     correct = mapped & (hits["contig"] == truth_c) & (np.abs(hits["pos"].astype(np.int64) - truth_p) <= C // 2 + 4)
     nr = max(1, pc["reads"])
     res = {"value": R * args.heavy_tail_steps / elapsed, "unit": "reads/s", "steps": args.heavy_tail_steps, "ms_per_step": elapsed / args.heavy_tail_steps * 1e3,
+           "mapper_instances_per_gpu": W,
            "genome": "tests/humanlike.py make_genome(%d Mbp, 24 contigs, seed 20260929): %d repeat instances; automatic max. k-mer frequency %d (uniform genome: 100)"
                      % (args.heavy_tail_mbp, len(G.repeats), ref.auto_max_kfreq),
            "reads": "%d x %d bp %s per step, %.0f %% of the fragments start inside a repeat instance (kinds equally likely)" % (R, READ_LEN, "PE" if paired else "SE", 100 * args.heavy_tail_repeat_share),
@@ -546,6 +550,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
     ap.add_argument("--no-reference-rerun", action="store_true", help="skip the second -t N run of the reference program (its own run-to-run differences)")
+    ap.add_argument("--heavy-tail-workers", type=int, default=4, help="mapper instances per GPU of the heavy-tailed leg")
     ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
     ap.add_argument("--read-sets", type=int, default=4, help="distinct sets of reads-per-step reads the timed steps rotate through (step i maps set i mod this)")
     ap.add_argument("--read-len", type=int, default=150, help="read length (150: BASELINE config #2/#3; 250: config #5's shape)")
