@@ -150,4 +150,143 @@ __global__ __launch_bounds__(NT) void cs_heavy_kernel(CsArgs A) {
 	(void) cs_finish<kCsExactLds>(A, read, lane, R, t_keys, t_votes, n_slots);
 }
 
+
+// ---- the exact search with the table in global memory, one WORKGROUP per read (round 4) -------------------------------------------
+// cs_kernel<kCsExactGlobal> gives a read ONE wave: the reads that reach it on a heavy-tailed genome (17 000 - 190 000 hits, tens of
+// thousands of bins with votes: 4 % of the reads there) each clear, fill and scan -- three times: maximum, count, output -- a table of
+// 2^17 - 2^19 slots with 64 lanes, one L2 round trip per iteration: ~10 ms per read, 68-74 ms per 262 144 reads of the bench's
+// heavy-tailed leg (70 % of its search time).  Here NT threads share the read: the votes through cs_for_each_hit_block, the three table
+// passes NT slots at a time.  The candidates leave in cs_finish's order -- by (slot mod 64), then by slot -- so that nothing downstream
+// can tell the kernels apart: thread t owns the slots of lane class t mod 64 in the (t / 64)-th share of the table, and the output
+// offsets are a scan over the threads in (class, share) order.
+template <int NT>
+__global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+	constexpr int NW = NT / 64;
+	__shared__ uint32_t s_cnt[NT], s_wtot[NW], s_mx[NW], s_mxb[NW];
+	__shared__ unsigned long long s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int item = blockIdx.x;
+	const int read = (int) A.read_list[item];
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;                                  // [lists_cap]
+	uint32_t *l_pref = cs_lds + A.lists_cap;                     // [lists_cap + 1]
+	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);    // [q rounded up to 4]
+	const int log2_slots = (int) A.ovf_log2[item];
+	const uint32_t n_slots = 1u << log2_slots;
+	uint32_t *t_keys = A.gtable_keys + A.ovf_table_off[item];
+	uint32_t *t_votes = A.gtable_votes + A.ovf_table_off[item];
+	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+	const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);   // (every wave computes the same lists; the barrier inside is the block's)
+	const uint32_t H = R.H;
+	const int L = R.L;
+	__threadfence_block();
+	__syncthreads();
+	cs_for_each_hit_block<NT>(A.positions, l_start, l_pref, R.n_lists, H, tid, [&](uint32_t pos, int li) {
+		const int p = li >> 1;
+		const bool rev = (li & 1) != 0;
+		const uint32_t correction = rev ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
+		const uint32_t bin = (pos - correction) >> A.bin_shift;
+		uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
+		for (;;) {
+			const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+			if (prev == bin || prev == 0xFFFFFFFFu) break;
+			slot = (slot + 1) & (n_slots - 1);
+		}
+		atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
+	});
+	__threadfence_block();
+	__syncthreads();
+	// thread t: lane class c = t mod 64, share sh = t / 64 of the class's slots c, c + 64, c + 128, ...
+	const uint32_t per_class = n_slots >> 6;   // (n_slots >= 2^4: tables of fewer than 64 slots have per_class 0 -- such reads never get here, but stay correct below)
+	const uint32_t j0 = (uint32_t) ((unsigned long long) per_class * (unsigned) wv / (unsigned) NW), j1 = (uint32_t) ((unsigned long long) per_class * (unsigned) (wv + 1) / (unsigned) NW);
+	int mx = 0, mxb = 0;
+	if (n_slots >= 64u) {
+		for (uint32_t j = j0; j < j1; ++j) {
+			const uint32_t v = cs_tload<kCsExactGlobal>(&t_votes[(j << 6) + (uint32_t) lane]);
+			mx = max(mx, (int) max(v & 0xFFFFu, v >> 16));
+			mxb = max(mxb, (int) ((v & 0xFFFFu) + (v >> 16)));
+		}
+	} else if (wv == 0 && (uint32_t) lane < n_slots) {
+		const uint32_t v = cs_tload<kCsExactGlobal>(&t_votes[lane]);
+		mx = (int) max(v & 0xFFFFu, v >> 16); mxb = (int) ((v & 0xFFFFu) + (v >> 16));
+	}
+	mx = wave_reduce_max(mx);
+	mxb = wave_reduce_max(mxb);
+	if (lane == 0) { s_mx[wv] = (uint32_t) mx; s_mxb[wv] = (uint32_t) mxb; }
+	__syncthreads();
+	mx = 0; mxb = 0;
+#pragma unroll
+	for (int w2 = 0; w2 < NW; ++w2) { mx = max(mx, (int) s_mx[w2]); mxb = max(mxb, (int) s_mxb[w2]); }
+	const float max_hit = (float) mx;
+	const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
+	const uint32_t region = (uint32_t) read & (kCsRegions - 1);
+	if (tid == 0 && A.counters) {
+		atomicAdd(&A.counters[region * kCsCursorStride], (unsigned long long) R.n_valid);
+		atomicAdd(&A.counters[region * kCsCursorStride + 1], (unsigned long long) H);
+	}
+	auto my_slots = [&](auto f) {
+		if (n_slots >= 64u) { for (uint32_t j = j0; j < j1; ++j) f((j << 6) + (uint32_t) lane); }
+		else if (wv == 0 && (uint32_t) lane < n_slots) f((uint32_t) lane);
+	};
+	uint32_t count = 0;
+	my_slots([&](uint32_t s2) {
+		if (cs_tload<kCsExactGlobal>(&t_keys[s2]) != 0xFFFFFFFFu) {
+			const uint32_t v = cs_tload<kCsExactGlobal>(&t_votes[s2]);
+			count += ((float) (v & 0xFFFFu) >= thresh) + ((float) (v >> 16) >= thresh);
+		}
+	});
+	// exclusive scan in (class, share) order: entry o = lane * NW + wv
+	s_cnt[lane * NW + wv] = count;
+	__syncthreads();
+	{
+		const uint32_t v = s_cnt[tid];
+		const uint32_t incl = wave_inclusive_scan(v, lane);
+		__syncthreads();
+		s_cnt[tid] = incl - v;
+		if (lane == 63) s_wtot[wv] = incl;
+	}
+	__syncthreads();
+	const uint32_t o = (uint32_t) (lane * NW + wv);
+	uint32_t before = s_cnt[o], total = 0;
+#pragma unroll
+	for (int w2 = 0; w2 < NW; ++w2) { if ((uint32_t) w2 < (o >> 6)) before += s_wtot[w2]; total += s_wtot[w2]; }
+	if ((int64_t) total >= (int64_t) A.max_cmrs) total = 0;  // "if (index < maxScores) AllocScores" (CS.cpp:308-310)
+	const bool fixed = A.fixed_base != 0u && total <= (uint32_t) kCsFixedSlots;
+	if (tid == 0) {
+		unsigned long long base = 0;
+		if (!fixed) {
+			base = total ? atomicAdd(&A.out_total[region * kCsCursorStride], (unsigned long long) total) : 0ull;
+			if (base + total > A.out_capacity) { atomicExch(&A.status[0], 1u); }
+		}
+		s_base = base;
+		A.cand_base[read] = fixed ? A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots : (uint32_t) (region * A.out_capacity + base);
+		A.cand_count[read] = total;
+		A.max_votes[read] = max_hit;
+		if (A.max_both) A.max_both[read] = (float) mxb;
+		A.read_len[read] = (uint16_t) R.L;
+		if (A.counters && total) atomicAdd(&A.counters[region * kCsCursorStride + 2], (unsigned long long) total);
+	}
+	__syncthreads();
+	if (total == 0) return;
+	uint32_t w;
+	if (fixed) w = A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots + before;
+	else {
+		const unsigned long long base = s_base;
+		if (base + total > A.out_capacity) return;
+		w = (uint32_t) (region * A.out_capacity + base) + before;
+	}
+	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
+	my_slots([&](uint32_t s2) {
+		const uint32_t key = cs_tload<kCsExactGlobal>(&t_keys[s2]);
+		if (key != 0xFFFFFFFFu) {
+			const uint32_t v = cs_tload<kCsExactGlobal>(&t_votes[s2]);
+			const uint32_t f = v & 0xFFFFu, r = v >> 16;
+			const uint32_t loc = (key << A.bin_shift) + centre;
+			if ((float) f >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = f << 1; ++w; }
+			if ((float) r >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = (r << 1) | 1u; ++w; }
+		}
+	});
+}
+
 }  // namespace ngm

@@ -520,7 +520,12 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 			G.read_list = m->d_ovf_read2.p;
 			G.ovf_table_off = m->d_ovf_off.p; G.ovf_log2 = m->d_ovf_log2.p; G.gtable_keys = m->d_gt_keys.p; G.gtable_votes = m->d_gt_votes.p;
 			MAP_HIP_TRY(hipEventRecord(m->cev[4], m->st));
-			hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactGlobal>, dim3(no), dim3(64), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
+			// one workgroup per read (cs_global_kernel, cs_heavy_device.h); bisulfite runs keep the one-wave kernel (their lists come in chunks of variants)
+			static const int global_nt = getenv("NGM_HIP_CS_GLOBAL_THREADS") ? atoi(getenv("NGM_HIP_CS_GLOBAL_THREADS")) : 512;   // (64: the one-wave kernel of rounds 1-3)
+			if (G.bs || global_nt <= 64) hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactGlobal>, dim3(no), dim3(64), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
+			else if (global_nt >= 1024) hipLaunchKernelGGL(ngm::cs_global_kernel<1024>, dim3(no), dim3(1024), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
+			else if (global_nt >= 512) hipLaunchKernelGGL(ngm::cs_global_kernel<512>, dim3(no), dim3(512), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
+			else hipLaunchKernelGGL(ngm::cs_global_kernel<256>, dim3(no), dim3(256), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->cev[5], m->st));
 			yield();
