@@ -339,19 +339,25 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 		build_codes(len_p, 19, code_p, tmp, tid);
 		phase(3);
 		// ---- block header (thread 0) and the bits of every thread's tokens --------------------------------------------
-		if (tid == 0) {
-			BitOut o(U, kHdrBits);
-			o.put(1u, 1); o.put(2u, 2); o.put(286 - 257, 5); o.put(30 - 1, 5); o.put(19 - 4, 4);
-			for (int j = 0; j < 19; ++j) o.put(len_p[kPreOrder[j]], 3);
-			uint32_t bits = 3 + 14 + 57;
-			for (int s = 0; s < 286 + 30; ++s) {
-				const uint32_t l = s < 286 ? len_ll[s] : len_d[s - 286];
-				const uint32_t c = code_p[l];
-				o.put(c & 0xFFFFu, (int) (c >> 16));
-				bits += c >> 16;
+		// ---- block header: the fixed part by thread 0, the 286 + 30 code lengths one per thread ----------------------------
+		{
+			uint32_t hc = 0;   // this thread's code length symbol in the code length code: code | bits << 16
+			if (tid < 286 + 30) hc = code_p[tid < 286 ? len_ll[tid] : len_d[tid - 286]];
+			const uint32_t nb = hc >> 16;
+			uint32_t hscan = nb;
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t) __shfl_up((int) hscan, o); if (lane >= o) hscan += v; }
+			if (lane == 63) sh[32 + wv] = hscan;
+			__syncthreads();
+			uint32_t at = 3 + 14 + 57 + hscan - nb, all = 3 + 14 + 57;
+			for (int w2 = 0; w2 < kSegs; ++w2) { if (w2 < wv) at += sh[32 + w2]; all += sh[32 + w2]; }
+			if (tid == 0) {
+				BitOut o(U, kHdrBits);
+				o.put(1u, 1); o.put(2u, 2); o.put(286 - 257, 5); o.put(30 - 1, 5); o.put(19 - 4, 4);
+				for (int j = 0; j < 19; ++j) o.put(len_p[kPreOrder[j]], 3);
+				o.finish();
+				sh[9] = all;
 			}
-			o.finish();
-			sh[9] = bits;
+			if (nb) { BitOut o(U, kHdrBits + at); o.put(hc & 0xFFFFu, (int) nb); o.finish(); }
 		}
 		// tokens that start in positions [kChunk tid, kChunk (tid + 1)): walk(emit) -> bits
 		constexpr int kCW = kChunk / 32;

@@ -30,13 +30,5 @@ python profiles/tools/cpu_scale_probe.py > gpurun_out/profiles/${TAG}_cpu_quota_
 # round 4: the GPU's BGZF blocks (per-phase time of the kernel, ratio against zlib) and the drop-in with --bam / .gz input, stage by stage
 NGM_HIP_BGZF_PHASES=1 timeout 600 python -m pytest tests/test_gpu_bgzf.py -m gpu -q -s > gpurun_out/profiles/${TAG}_bgzf_kernel_phases_and_ratio.txt 2>&1
 timeout 900 python profiles/tools/cli_probe.py --mbp 3100 --reads 10000000 --gz -- --bam :: :: --gz-input > gpurun_out/profiles/${TAG}_cli_bam_sam_gz_10M_reads.txt 2>&1
-cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bam -o stats -- python $R/profiles/tools/cli_probe.py --mbp 200 --reads 4000000 -- --bam > $R/gpurun_out/prof_bam.log 2>&1
-cd $R
-B=$(find gpurun_out/prof_bam -name "*.db" | head -1)
-python - <<PY
-import subprocess, sys
-subprocess.run([sys.executable, "gpurun_out/summ.py", "${TAG}_ngm_hip_bam_4M_reads", "$B"])
-PY
 ls -la gpurun_out/profiles
-rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_lin gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_bam
+rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_lin gpurun_out/prof_fetch gpurun_out/prof_write
