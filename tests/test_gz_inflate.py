@@ -114,3 +114,41 @@ def test_damaged_files_are_refused(exe):
         with open(p, "wb") as f:
             f.write(data)
         assert subprocess.run([prog, p, p + ".out"]).returncode == 3, name
+
+
+def test_corrupted_inputs_are_refused_or_decoded_like_zlib(tmp_path):
+    """300 damaged files (flipped bits, truncation, overwritten and deleted spans) through a build with AddressSanitizer and
+    UndefinedBehaviorSanitizer: the decoder's unchecked hot loop must stay inside its buffers whatever the stream says -- exit 3 (refused)
+    or exit 0 with exactly zlib's text, never a crash."""
+    exe = str(tmp_path / "gz_inflate_check_asan")
+    c = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", os.path.join(ROOT, "tests", "cpp", "gz_inflate_check.cpp"), "-o", exe, "-lz", "-lpthread"],
+                       capture_output=True, text=True)
+    if c.returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here: " + c.stderr[-200:])
+    rnd = random.Random(7)
+    base = [gzip.compress(_fastq(1500, 1), 1), gzip.compress(_fastq(1500, 2), 9), gzip.compress(os.urandom(30000), 6), gzip.compress(bytes(200000), 6)]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    seen = {0: 0, 3: 0}
+    for it in range(300):
+        z = bytearray(rnd.choice(base))
+        mode = it % 4
+        if mode == 0:
+            for _ in range(rnd.randrange(1, 4)):
+                z[rnd.randrange(len(z))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:
+            z = z[:rnd.randrange(1, len(z))]
+        elif mode == 2:
+            a = rnd.randrange(len(z))
+            z[a:a + rnd.randrange(1, 50)] = os.urandom(rnd.randrange(1, 50))
+        else:
+            a = rnd.randrange(10, len(z))
+            z = z[:a] + z[a + rnd.randrange(1, 30):]
+        p = str(tmp_path / "damaged.gz")
+        with open(p, "wb") as f:
+            f.write(bytes(z))
+        r = subprocess.run([exe, p, p + ".out"], capture_output=True, env=env)
+        assert r.returncode in (0, 3), (it, r.returncode, r.stderr[-800:])
+        seen[r.returncode] += 1
+        if r.returncode == 0:
+            assert open(p + ".out", "rb").read() == gzip.decompress(bytes(z)), it
+    assert seen[3] > 200
