@@ -38,7 +38,7 @@ struct ngm_bgzf {
 };
 
 namespace {
-constexpr size_t kTabCrc = 0, kTabXpow = 1024, kTabLen = kTabXpow + 4 * (size_t) (ngm::bgzf::kIn + 1), kTabDist = kTabLen + 256, kTabBytes = kTabDist + 512;
+constexpr size_t kTabCrc = 0, kTabXpow = 4096, kTabLen = kTabXpow + 4 * (size_t) (ngm::bgzf::kIn + 1), kTabDist = kTabLen + 256, kTabBytes = kTabDist + 512;
 
 uint32_t mulmod(uint32_t a, uint32_t b) {
 	uint32_t p = 0;
@@ -56,6 +56,7 @@ void fill_tables(std::vector<uint8_t> &t) {
 		for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xedb88320u : c >> 1;
 		crc[i] = c;
 	}
+	for (uint32_t i = 0; i < 256; ++i) for (int k = 1; k < 4; ++k) crc[k * 256 + i] = crc[crc[(k - 1) * 256 + i] & 255u] ^ (crc[(k - 1) * 256 + i] >> 8);   // slicing-by-4
 	uint32_t *xp = (uint32_t *) (t.data() + kTabXpow);
 	xp[0] = 0x80000000u;   // x^0
 	for (int m = 1; m <= ngm::bgzf::kIn; ++m) xp[m] = mulmod(xp[m - 1], 0x00800000u);   // * x^8

@@ -45,7 +45,7 @@ struct Args {
 	uint8_t *out;                 // [n_blocks * kStride]
 	uint32_t *sizes;              // [n_blocks]
 	uint2 *scratch;               // [gridDim.x * kSegs * kMatCap]
-	const uint32_t *crc_table;    // [256]
+	const uint32_t *crc_table;    // [4][256]: slicing-by-4 tables (table k: the byte followed by k zero bytes)
 	const uint32_t *xpow;         // [kIn + 1]: x^(8 m) mod P, reflected
 	const uint8_t *len_code;      // [256]: length - 3 -> length symbol - 257
 	const uint8_t *dist_code;     // [512]: zlib's d_code table (distance - 1 < 256: [d], else [256 + (d >> 7)])
@@ -195,12 +195,12 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 	uint32_t *hist_p = code_d + 32;                  // [32]
 	uint32_t *len_p = hist_p + 32;                   // [32]
 	uint32_t *code_p = len_p + 32;                   // [32]
-	uint32_t *crc_t = code_p + 32;                   // [256]
-	uint32_t *tmp = crc_t + 256;                     // [5 * 288 + 64]
+	uint32_t *crc_t = code_p + 32;                   // [4][256]
+	uint32_t *tmp = crc_t + 1024;                    // [5 * 288 + 64]
 	uint32_t *sh = tmp + 5 * 288 + 64;               // [64] scalars: nmat[4], scans, CRC, bit counts
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const uint8_t *inb = (const uint8_t *) in;
-	if (tid < 256) crc_t[tid] = A.crc_table[tid];
+	for (int j = tid; j < 1024; j += kNT) crc_t[j] = A.crc_table[j];
 	unsigned long long t_prev = 0;
 	auto phase = [&](int k) { if (A.phase_cycles && tid == 0) { const unsigned long long t = wall_clock64(); if (k >= 0) atomicAdd(&A.phase_cycles[k], t - t_prev); t_prev = t; } };
 	for (int blk = blockIdx.x; blk < A.n_blocks; blk += gridDim.x) {
@@ -304,7 +304,21 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 		{
 			const int b0 = tid * kChunk, b1 = min(len, b0 + kChunk);
 			uint32_t c = 0;
-			for (int b = b0; b < b1; ++b) c = crc_t[(c ^ inb[b]) & 255u] ^ (c >> 8);
+			// (a full chunk comes from global memory, 16 bytes at a time: in LDS the chunks of the 64 lanes start 128 bytes apart -- the same bank)
+			const uint8_t *gsrc = A.raw + at + b0;
+			if (b1 - b0 == kChunk && ((uintptr_t) gsrc & 15u) == 0) {
+				const uint4 *g = (const uint4 *) gsrc;
+#pragma unroll
+				for (int q4 = 0; q4 < kChunk / 16; ++q4) {
+					const uint4 v = g[q4];
+					const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						c ^= w4[e];
+						c = crc_t[768 + (c & 255u)] ^ crc_t[512 + ((c >> 8) & 255u)] ^ crc_t[256 + ((c >> 16) & 255u)] ^ crc_t[c >> 24];
+					}
+				}
+			} else for (int b = b0; b < b1; ++b) c = crc_t[(c ^ inb[b]) & 255u] ^ (c >> 8);
 			uint32_t part = (b1 > b0 && c) ? crc_mulmod(c, A.xpow[len - b1]) : 0u;
 			if (tid == kNT - 1) part ^= crc_mulmod(0xFFFFFFFFu, A.xpow[len]) ^ 0xFFFFFFFFu;
 			for (int o = 32; o > 0; o >>= 1) part ^= (uint32_t) __shfl_xor((int) part, o);
@@ -487,7 +501,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint8_t *strided, con
 	}
 }
 
-inline size_t deflate_lds_bytes() { return (size_t) (16384 + 16384 + 4096 + 2 * (288 + 32) + (288 + 32) + 3 * 32 + 256 + 5 * 288 + 64 + 64) * 4; }
+inline size_t deflate_lds_bytes() { return (size_t) (16384 + 16384 + 4096 + 2 * (288 + 32) + (288 + 32) + 3 * 32 + 1024 + 5 * 288 + 64 + 64) * 4; }
 
 }  // namespace bgzf
 }  // namespace ngm

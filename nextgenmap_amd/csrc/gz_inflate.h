@@ -159,7 +159,6 @@ struct BitReader {
 	const uint8_t *in, *in_end;
 	uint64_t buf = 0;
 	int cnt = 0;   // valid bits in buf (above them: zeros, or bits of the bytes at `in` -- the same bits a later refill ORs in)
-	bool overrun = false;
 	// >= 56 bits when 8 bytes can be read at `in` (one unaligned load; `in` advances by the whole bytes that now count as buffered)
 	inline void refill_fast() {
 		uint64_t w;
