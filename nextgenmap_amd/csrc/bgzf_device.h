@@ -237,16 +237,21 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 				const int i = base + lane;
 				uint32_t mylen = 0, mydist = 0;
 				const bool can = i + 4 <= s1;
-				uint32_t cand = 0;
+				uint32_t cand = 0, v4 = 0;
 				if (can) {
-					const uint32_t h = (load32u(in, (uint32_t) i) * 2654435761u) >> 21;
+					v4 = load32u(in, (uint32_t) i);
+					const uint32_t h = (v4 * 2654435761u) >> 21;
 					cand = tab[h];
 					atomicMax(&tab[h], (uint32_t) (i - s0 + 1));
 				}
+				// the byte in front of this lane's four: the previous lane has it (lane 0: one read)
+				uint32_t before = (uint32_t) __shfl_up((int) v4, 1) & 255u;
+				if (lane == 0 && i > s0) before = inb[i - 1];
 				if (can && i >= cur) {
 					const int maxl = min(258, s1 - i);
-					auto match_len = [&](int p) {
-						int l = 0;
+					// both candidates are checked on the four bytes this lane holds before any compare loop runs: most candidates end there
+					auto extend = [&](int p) {   // in[p .. p + 3] == in[i .. i + 3] is known
+						int l = 4;
 						while (l < maxl) {
 							const uint32_t x = load32u(in, (uint32_t) (p + l)) ^ load32u(in, (uint32_t) (i + l));
 							if (x) { l += (__ffs((int) x) - 1) >> 3; break; }
@@ -256,12 +261,11 @@ __global__ __launch_bounds__(kNT) void deflate_kernel(Args A) {
 					};
 					if (cand) {
 						const int p = s0 + (int) cand - 1;
-						const int l = match_len(p);
-						if (l >= 4) { mylen = (uint32_t) l; mydist = (uint32_t) (i - p); }
+						if (load32u(in, (uint32_t) p) == v4) { mylen = (uint32_t) extend(p); mydist = (uint32_t) (i - p); }
 					}
-					if (i > s0 && inb[i - 1] == inb[i]) {
-						const int l = match_len(i - 1);
-						if (l >= 4 && (uint32_t) l >= mylen) { mylen = (uint32_t) l; mydist = 1; }
+					if (i > s0 && v4 == before * 0x01010101u) {   // in[i - 1 .. i + 3] are one byte value: a run of at least four at distance 1
+						const int l = extend(i - 1);
+						if ((uint32_t) l >= mylen) { mylen = (uint32_t) l; mydist = 1; }
 					}
 				}
 				// greedy parse of these 64 positions, one step of lazy evaluation -- wave-uniform: the lanes with a match as a bit mask, the
