@@ -921,7 +921,7 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 	m->st_order_big += big.size();
 	if (!big.empty()) {
 		// exact replay in global memory (cs_order_kernel<true>): per read a table of 2^l >= 2 (hits + candidates) slots x 5 words and a
-		// time line of `hits` words; launches of as many reads as fit a scratch pool of 1.5 GB
+		// time line of `hits` words; launches of as many reads as fit a scratch pool of 8 GB
 		const uint32_t nb = (uint32_t) big.size();
 		std::vector<uint32_t> reads(nb), lg(nb);
 		std::vector<uint64_t> off(nb), words(nb);
@@ -937,7 +937,9 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		ngm::CsArgs G = m->order_args;
 		G.order_info = nullptr; G.order_scratch = nullptr; G.order_gcap = 0; G.order_max_hits = 0; G.phase_cycles = nullptr;
 		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
-		constexpr uint64_t kPoolWords = 384ull << 20;
+		// (8 GB per launch: a read with 50 000 hits takes 2.6 MB of table and time line, and with the 1.5 GB pool of the first version the
+		// 5 500 such reads of a heavy-tailed batch went through ten launches of ~570 workgroups each -- two per CU, 118 ms of waiting per batch)
+		constexpr uint64_t kPoolWords = 2048ull << 20;
 		for (uint32_t j0 = 0; j0 < nb;) {
 			uint64_t total = 0;
 			uint32_t j1 = j0;
