@@ -872,12 +872,12 @@ int main(int argc, char **argv) {
 
 	const auto t_indexed = std::chrono::steady_clock::now();
 	// ---- sensitivity (ReadProvider.cpp:310-385) -----------------------------------------------------------
-	float sens = 0.5f;
-	bool estimated = false;
-	if (o.bs_mapping) {
-		if (o.sensitivity < 0) info("INPUT", "Sensitivity parameter set to 0.5");   // ReadProvider.cpp:317, :378-386: no estimate in this mode
-		estimated = true;
-	} else if (count >= 1000 && !sample.empty()) {
+	// The estimate of the reference runs even when -s sets the value (its result is then only logged, ReadProvider.cpp:359-365): in that
+	// case it runs beside the set-up of the mappers instead of in front of it (NGM_HIP_SYNC_ESTIMATE=1: in front, as without -s).
+	std::thread estimate_thread;
+	struct JoinEstimate { std::thread &t; ~JoinEstimate() { if (t.joinable()) t.join(); } } join_estimate{estimate_thread};
+	auto run_estimate = [&, mp](float &sens, bool &estimated) {
+		char msg[512];
 		ngm_mapper_params ep = mp;
 		ep.sensitivity = 0.0f;
 		ep.slam_seq &= ~4;   // (the estimate looks the read k-mers up as they are: ReadProvider's own PrefixSearch, src/ReadProvider.cpp:79-124)
@@ -926,6 +926,15 @@ int main(int argc, char **argv) {
 			// the drop-in run of the real program, tests/test_gpu_dropin.py)
 			{ char b[32]; snprintf(b, sizeof(b), "%f", sens); sens = (float) atof(b); }
 		}
+	};
+	float sens = 0.5f;
+	bool estimated = false;
+	if (o.bs_mapping) {
+		if (o.sensitivity < 0) info("INPUT", "Sensitivity parameter set to 0.5");   // ReadProvider.cpp:317, :378-386: no estimate in this mode
+		estimated = true;
+	} else if (count >= 1000 && !sample.empty()) {
+		if (o.sensitivity >= 0 && !getenv("NGM_HIP_SYNC_ESTIMATE")) estimate_thread = std::thread([&] { float s2 = 0.5f; bool e2 = false; run_estimate(s2, e2); });
+		else run_estimate(sens, estimated);
 	}
 	if (o.sensitivity >= 0) sens = o.sensitivity;
 	else if (!estimated) info("INPUT", "Sensitivity parameter neither set nor estimated. Falling back to default.");
@@ -1742,6 +1751,7 @@ int main(int argc, char **argv) {
 		for (auto &t : th) t.join();
 	}
 	splitter.join();
+	if (estimate_thread.joinable()) estimate_thread.join();   // (it finished long ago unless the input is a handful of reads; the reference it uses is released below)
 	{ std::lock_guard<std::mutex> lk(out_mu); workers_done = true; }
 	out_cv.notify_all();
 	writer.join();
