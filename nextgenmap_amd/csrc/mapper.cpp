@@ -33,6 +33,7 @@
 #define NGM_SAM_KERNELS
 #include "sam_device.h"
 #include "gather_device.h"
+#include "pair_device.h"
 #include "thread_pool.h"
 
 #define MAP_HIP_TRY(expr)                                                                      \
@@ -119,6 +120,12 @@ struct ngm_mapper {
 	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
 	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records, d_pair_info;
 	ngm::PinnedBuf<int32_t> p_pair_info;
+	ngm::DevBuf<ngm::PairOut> d_pair_out;      // pair_choice_kernel (pair_device.h): per pair, and the best-scoring combinations of the tied ones
+	ngm::DevBuf<ngm::PairTop> d_pair_top;
+	ngm::DevBuf<uint32_t> d_pair_tied_n;
+	ngm::PinnedBuf<ngm::PairOut> p_pair_out;
+	ngm::PinnedBuf<ngm::PairTop> p_pair_top;
+	ngm::PinnedBuf<uint32_t> p_pair_tied_n;
 	ngm::DevBuf<uint16_t> d_runs, d_runs_c;
 	ngm::DevBuf<char> d_str;   // CIGAR / MD on the device: the compact byte stream
 	ngm::DevBuf<ngm::CigarDevOut> d_cigout;
@@ -846,6 +853,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	m->d_pair_info.release(); m->p_pair_info.release(); m->d_sam_contig_start.release();
+	m->d_pair_out.release(); m->d_pair_top.release(); m->d_pair_tied_n.release(); m->p_pair_out.release(); m->p_pair_top.release(); m->p_pair_tied_n.release();
 	m->d_sam_contig_names.release(); m->d_sam_rg.release(); m->d_sam_names.release(); m->d_sam_text.release(); m->d_sam_contig_off.release(); m->d_sam_len.release(); m->d_sam_off.release();
 	m->d_sam_quals.release(); m->d_sam_meta.release(); m->d_sam_refs.release(); m->d_sam_hits.release(); m->p_sam_hits.release(); m->p_sam_refs.release(); m->p_sam_extra.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
@@ -1130,22 +1138,14 @@ struct PairTies {
 	int top_d[8], top_a[8], top_b[8];
 };
 
-// ScoreBuffer::top1PE + CheckPairs (src/ScoreBuffer.cpp:368-502) for one pair; `a` = the mate whose scores arrive last
-// (the odd read id: "read"), `b` = its mate.  Candidates are (pair index) lists into loc/score.
-static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_count, int *dist_out, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
-		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found,
-		PairTies *ties = nullptr) {
-	if (ties) *ties = PairTies{};
-	if (cnt_a == 1 && cnt_b == 1) {  // the common case: one candidate per mate
-		*mq_a = *mq_b = 60;
-		const uint64_t l1 = loc[base_a], l2 = loc[base_b];
-		const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
-		const int min_d1 = m->prm.min_insert_size, max_d1 = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
-		const float ps = score[base_a] + score[base_b];
-		*found = cur > min_d1 && cur < max_d1 && ps > 0.0f;
-		if (*found) { *dist_out = cur; *win_a = (int) base_a; *win_b = (int) base_b; *equal_out = 0; }
-		return;
-	}
+extern "C++" {
+// The part of ScoreBuffer::top1PE (src/ScoreBuffer.cpp:368-413) that does not depend on the running mean insert size: both candidate
+// arrays sorted like the reference sorts them, the MAPQs, the candidates at or above best * pair_score_cutoff, and -- f(pair score,
+// insert size, candidate of a, candidate of b) -- every combination inside the insert-size window in the order of the reference's
+// double loop.  `a` = the mate whose scores arrive last (the odd read id: "read"), `b` = its mate.
+template <typename F>
+static void walk_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
+		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *mq_a, int *mq_b, F &&f) {
 	auto mq_of = [&](const uint32_t *v, uint32_t cnt) {  // computeMQ(MappedRead*), ScoreBuffer.cpp:42-49
 		if (cnt <= 1) return 60;
 		const float best = score[v[0]], second = score[v[1]];
@@ -1167,11 +1167,6 @@ static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_coun
 	while (na < cnt_a && min_a <= score[A[na]]) ++na;
 	while (nb < cnt_b && min_b <= score[B[nb]]) ++nb;
 	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
-	float top = 0.0f;
-	int distance = 0, equal = 0, ta = -1, tb = -1, n_combo = 0;
-	float combo_s[64];  // pair score, insert size and candidates of every pair inside the insert-size window
-	int combo_d[64], combo_a[64], combo_b[64];
-	const int avg = (int) (dist_sum / std::max(1L, dist_count));
 	// Mates with hundreds of candidates each (repeat families of a GRCh38-like genome): CheckPairs walks all na x nb combinations,
 	// but only those inside the insert-size window do anything -- B's candidates sorted by position, per candidate of A the ones
 	// within max_d, visited in increasing j like the reference's inner loop: the same sequence of in-window pairs, so every
@@ -1200,20 +1195,75 @@ static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_coun
 			const size_t j = windowed ? js[jj] : jj;
 			const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
 			const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
-			bool take = false;
-			if (cur > min_d && cur < max_d) {
-				const float ps = score[A[i]] + score[B[j]];
-				if (n_combo < 64) { combo_s[n_combo] = ps; combo_d[n_combo] = cur; combo_a[n_combo] = (int) A[i]; combo_b[n_combo] = (int) B[j]; }
-				++n_combo;
-				if (ps > top * 1.00f) { top = ps; distance = cur; take = true; }
-				else if (ps == top) {
-					if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
-					else if (abs(distance) == abs(cur)) equal += 1;
-				}
-			}
-			if (take) { ta = (int) A[i]; tb = (int) B[j]; }
+			if (cur > min_d && cur < max_d) f(score[A[i]] + score[B[j]], cur, (int) A[i], (int) B[j]);
 		}
 	}
+}
+
+// One pair's in-window combinations in the reference's order (walk_pair), kept: ScoreBuffer::CheckPairs at a given running mean
+// is then a scan over them -- the sequential pass evaluates an open pair in microseconds instead of sorting and windowing again.
+struct PairSeq {
+	std::vector<float> ps;
+	std::vector<int> d, a, b;
+	int mq_a = 0, mq_b = 0;
+};
+struct PairOutcome { int wa, wb, mqa, mqb, equal, dist; bool found; };
+// the double loop of top1PE over CheckPairs (src/ScoreBuffer.cpp:405-413, :463-502) at running mean `avg`
+static PairOutcome eval_pair_seq(const PairSeq &q, int avg) {
+	float top = 0.0f;
+	int distance = 0, equal = 0, ta = -1, tb = -1;
+	const size_t nq = q.ps.size();
+	for (size_t x = 0; x < nq; ++x) {
+		const float ps = q.ps[x];
+		const int cur = q.d[x];
+		bool take = false;
+		if (ps > top * 1.00f) { top = ps; distance = cur; take = true; }
+		else if (ps == top) {
+			if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
+			else if (abs(distance) == abs(cur)) equal += 1;
+		}
+		if (take) { ta = q.a[x]; tb = q.b[x]; }
+	}
+	PairOutcome o{-1, -1, q.mq_a, q.mq_b, 0, 0, top > 0.0f};
+	if (o.found) { o.wa = ta; o.wb = tb; o.equal = equal; o.dist = distance; }
+	return o;
+}
+
+}  // extern "C++"
+
+// ScoreBuffer::top1PE + CheckPairs (src/ScoreBuffer.cpp:368-502) for one pair; `a` = the mate whose scores arrive last
+// (the odd read id: "read"), `b` = its mate.  Candidates are (pair index) lists into loc/score.
+static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_count, int *dist_out, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
+		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *win_a, int *win_b, int *mq_a, int *mq_b, int *equal_out, bool *found,
+		PairTies *ties = nullptr) {
+	if (ties) *ties = PairTies{};
+	if (cnt_a == 1 && cnt_b == 1) {  // the common case: one candidate per mate
+		*mq_a = *mq_b = 60;
+		const uint64_t l1 = loc[base_a], l2 = loc[base_b];
+		const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
+		const int min_d1 = m->prm.min_insert_size, max_d1 = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
+		const float ps = score[base_a] + score[base_b];
+		*found = cur > min_d1 && cur < max_d1 && ps > 0.0f;
+		if (*found) { *dist_out = cur; *win_a = (int) base_a; *win_b = (int) base_b; *equal_out = 0; }
+		return;
+	}
+	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
+	float top = 0.0f;
+	int distance = 0, equal = 0, ta = -1, tb = -1, n_combo = 0;
+	float combo_s[64];  // pair score, insert size and candidates of every pair inside the insert-size window
+	int combo_d[64], combo_a[64], combo_b[64];
+	const int avg = (int) (dist_sum / std::max(1L, dist_count));
+	walk_pair(m, base_a, cnt_a, len_a, base_b, cnt_b, len_b, loc, sv, score, rank, mq_a, mq_b, [&](float ps, int cur, int ia, int ib) {
+		if (n_combo < 64) { combo_s[n_combo] = ps; combo_d[n_combo] = cur; combo_a[n_combo] = ia; combo_b[n_combo] = ib; }
+		++n_combo;
+		bool take = false;
+		if (ps > top * 1.00f) { top = ps; distance = cur; take = true; }
+		else if (ps == top) {
+			if (abs(distance - avg) > abs(cur - avg)) { top = ps; distance = cur; take = true; }
+			else if (abs(distance) == abs(cur)) equal += 1;
+		}
+		if (take) { ta = ia; tb = ib; }
+	});
 	*found = top > 0.0f;
 	if (*found) { *dist_out = distance; *win_a = ta; *win_b = tb; *equal_out = equal; }
 	// Which state does the outcome depend on besides the scores?  CheckPairs consults the running mean insert size (the
@@ -1349,6 +1399,21 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_info.p, m->d_pair_info.p, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost, m->st));
 		}
+		// ... and the pairs with choices: everything the scores alone decide (pair_device.h); NGM_HIP_HOST_PAIR_CHOICE=1 keeps the host's walk
+		static const bool pair_choice_gpu = !getenv("NGM_HIP_HOST_PAIR_CHOICE");
+		const bool choice_on_gpu = simple_on_gpu && pair_choice_gpu;
+		if (choice_on_gpu) {
+			const size_t npairs = (size_t) n / 2;
+			if (m->d_pair_out.reserve(npairs + 1) || m->d_pair_top.reserve(npairs + 1) || m->d_pair_tied_n.reserve(4) || m->p_pair_out.reserve(npairs + 1) || m->p_pair_tied_n.reserve(4)) {
+				ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
+			MAP_HIP_TRY(hipMemsetAsync(m->d_pair_tied_n.p, 0, 4, m->st));
+			hipLaunchKernelGGL(ngm::pair_choice_kernel, dim3((unsigned) npairs), dim3(ngm::kPairThreads), 0, m->st, (int) npairs, m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p,
+					m->d_out_loc.p, m->d_read_len.p, m->prm.min_insert_size, m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX,
+					m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f, m->d_pair_info.p, m->d_pair_out.p, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_out.p, m->d_pair_out.p, npairs * sizeof(ngm::PairOut), hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_tied_n.p, m->d_pair_tied_n.p, 4, hipMemcpyDeviceToHost, m->st));
+		}
 		MAP_HIP_TRY(hipEventRecord(m->ev[4], m->st));
 		stage_cs.kernels_done();
 		MAP_HIP_TRY(hipMemcpyAsync(h_winner, m->d_winner.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
@@ -1361,6 +1426,11 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		stage_cs.done_after(m->ev[4]);
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		if (int rc = cs_host_arrays(m)) return rc;
+		if (choice_on_gpu && m->p_pair_tied_n.p[0] > 0) {   // the tied pairs' best-scoring combinations (a few thousand records)
+			const size_t nt = std::min<size_t>(m->p_pair_tied_n.p[0], (size_t) n / 2);
+			if (m->p_pair_top.reserve(nt)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+			MAP_HIP_TRY(hipMemcpy(m->p_pair_top.p, m->d_pair_top.p, nt * sizeof(ngm::PairTop), hipMemcpyDeviceToHost));
+		}
 		lap(1);
 		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
 		if ((!paired || m->fast_pairing) && m->prm.topn <= 1 && !position_order) {
@@ -1390,9 +1460,10 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			}
 		}
 		if (pe_select) {
-			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is
-			// sequential state of one CS thread in the reference; here every host thread continues from the value at
-			// the start of the batch and the increments are merged afterwards (NGM_HIP_HOST_THREADS=1: strictly sequential).
+			// Pairs in input order.  The running mean insert size (tie-break between equally scoring pairs only) is sequential state
+			// of one CS thread in the reference (pairDistSum / pairDistCount, ScoreBuffer.h:90).  Everything that does not depend on
+			// it happens outside this batch's turn for that state -- on the GPU (pair_simple_kernel, pair_choice_kernel) or in
+			// parallel on the host -- and the turn itself only scans what is left (NGM_HIP_HOST_THREADS=1: strictly sequential).
 			const bool pe_strata = m->prm.strata != 0;
 			auto commit = [&](int ra, int rb, bool found, int wa, int wb, int mqa, int mqb, int equal) {
 				if (found && pe_strata && equal > 0) {  // "To many equal scoring positions": both mates unmapped (ScoreBuffer.cpp:437-446)
@@ -1409,16 +1480,16 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;  // no pair inside the window: single-end selection stands
 				}
 			};
+			auto len_of = [&](int rd) { return (int) strnlen(reads + (size_t) rd * q, q); };
 			auto run_pair = [&](int pi, long sum, long cnt, const uint32_t *rank, int *wa, int *wb, int *mqa, int *mqb, int *equal, int *dist, bool *found, PairTies *ties) {
 				const int rb = 2 * pi, ra = 2 * pi + 1;
-				select_pair(m, sum, cnt, dist, m->h_base[ra], m->h_count[ra], (int) strnlen(reads + (size_t) ra * q, q), m->h_base[rb], m->h_count[rb],
-						(int) strnlen(reads + (size_t) rb * q, q), h_loc, h_sv, h_scores, rank, wa, wb, mqa, mqb, equal, found, ties);
+				select_pair(m, sum, cnt, dist, m->h_base[ra], m->h_count[ra], len_of(ra), m->h_base[rb], m->h_count[rb], len_of(rb), h_loc, h_sv, h_scores, rank, wa, wb, mqa, mqb, equal, found, ties);
 			};
-			// Pass 1 (parallel): every pair whose result depends on the scores alone -- nearly all of them.  The others
-			// ("tied": equally scoring pairs inside the window) depend on the running mean insert size, which is sequential
-			// state of the reference's CS thread (pairDistSum / pairDistCount), and some also on the candidate order.
-			// gap_*: insert sizes / number of the pairs selected since the previous tied pair; dist: this pair's once it is closed
-			struct Tied { int pi; bool found, dup, open; int dmin, dmax, mqa, mqb; long avg_lo, avg_hi; int n_top, top_d[8], top_a[8], top_b[8]; long gap_sum, gap_cnt; int dist; };
+			// Pass 1: every pair whose result depends on the scores alone -- nearly all of them -- is settled.  The others ("tied":
+			// equally scoring pairs inside the window) depend on the running mean insert size, and some also on the candidate order.
+			// gap_*: insert sizes / number of the pairs selected since the previous tied pair; dist: this pair's once it is closed;
+			// seq: its in-window combinations in the reference's order (pass 3), or -1
+			struct Tied { int pi; bool found, dup, open; int dmin, dmax, mqa, mqb; long avg_lo, avg_hi; int n_top, top_d[8], top_a[8], top_b[8]; long gap_sum, gap_cnt; int dist; int seq; };
 			auto tq0 = now(); double tq[5] = {0, 0, 0, 0, 0};
 			auto qlap = [&](int k) { auto t = now(); tq[k] += std::chrono::duration<double, std::milli>(t - tq0).count(); tq0 = t; };
 			std::mutex tied_mu;
@@ -1427,10 +1498,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			struct Chunk { int plo; std::vector<Tied> tied; std::vector<uint32_t> se; long tail_sum, tail_cnt; };
 			std::vector<Chunk> chunks;
 			auto se_check = [&](std::vector<uint32_t> &out, int i) { if (h_nbest[i] != 1 && m->h_count[i] > 1) out.push_back((uint32_t) i); };
+			const ngm::PairOut *h_po = choice_on_gpu ? m->p_pair_out.p : nullptr;
+			const ngm::PairTop *h_pt = choice_on_gpu ? m->p_pair_top.p : nullptr;
+			std::atomic<long> n_host_walk{0};
 			parallel_for(n / 2, [&](int plo, int phi) {
 				std::vector<Tied> local;
 				std::vector<uint32_t> local_se;
-				long gsum = 0, gcnt = 0;
+				long gsum = 0, gcnt = 0, walked = 0;
 				for (int pi = plo; pi < phi; ++pi) {
 					const int rb = 2 * pi, ra = 2 * pi + 1;
 					if (simple_on_gpu && m->p_pair_info.p[pi] >= 0) {   // one candidate per mate: pair_simple_kernel has settled it
@@ -1440,12 +1514,30 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						continue;
 					}
 					if (m->h_count[ra] == 0 || m->h_count[rb] == 0) { se_check(local_se, rb); se_check(local_se, ra); continue; }  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
+					if (h_po && !(h_po[pi].flags & ngm::kPairHost)) {   // pair_choice_kernel: settled, or what the sequential passes need
+						const ngm::PairOut &po = h_po[pi];
+						const bool found = (po.flags & ngm::kPairFound) != 0;
+						const int mqa = (po.flags >> 8) & 255, mqb = (po.flags >> 16) & 255;
+						if (po.flags & ngm::kPairTied) {
+							Tied t{pi, found, (po.flags & ngm::kPairDup) != 0, true, po.dmin, po.dmax, mqa, mqb, 0, 0, std::min((po.flags >> 24) & 15, 8), {}, {}, {}, gsum, gcnt, 0, -1};
+							gsum = gcnt = 0;
+							if (po.n_combo > ngm::kPairCombos) t.n_top = 0;
+							const ngm::PairTop &pt = h_pt[po.tied_ix];
+							for (int x = 0; x < t.n_top; ++x) { t.top_d[x] = pt.d[x]; t.top_a[x] = pt.a[x]; t.top_b[x] = pt.b[x]; }
+							local.push_back(t);
+							continue;
+						}
+						commit(ra, rb, found, po.wa, po.wb, mqa, mqb, 0);
+						if (found) { gsum += po.dist; ++gcnt; } else { se_check(local_se, rb); se_check(local_se, ra); }
+						continue;
+					}
+					++walked;
 					int wa = -1, wb = -1, mqa = 0, mqb = 0, equal = 0, dist = 0;
 					bool found = false;
 					PairTies ties;
 					run_pair(pi, 0, 1, nullptr, &wa, &wb, &mqa, &mqb, &equal, &dist, &found, &ties);
 					if (ties.equal_scores) {
-						Tied t{pi, found, ties.dup || pe_strata, true, ties.dmin_top, ties.dmax_top, mqa, mqb, 0, 0, std::min(ties.n_top, 8), {}, {}, {}, gsum, gcnt, 0};
+						Tied t{pi, found, ties.dup || pe_strata, true, ties.dmin_top, ties.dmax_top, mqa, mqb, 0, 0, std::min(ties.n_top, 8), {}, {}, {}, gsum, gcnt, 0, -1};
 						gsum = gcnt = 0;
 						for (int x = 0; x < t.n_top; ++x) { t.top_d[x] = ties.top_d[x]; t.top_a[x] = ties.top_a[x]; t.top_b[x] = ties.top_b[x]; }
 						local.push_back(t);
@@ -1454,6 +1546,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					commit(ra, rb, found, wa, wb, mqa, mqb, equal);
 					if (found) { gsum += dist; ++gcnt; } else { se_check(local_se, rb); se_check(local_se, ra); }
 				}
+				n_host_walk += walked;
 				{ std::lock_guard<std::mutex> lk(tied_mu); chunks.push_back(Chunk{plo, std::move(local), std::move(local_se), gsum, gcnt}); }
 			});
 			std::sort(chunks.begin(), chunks.end(), [](const Chunk &x, const Chunk &y) { return x.plo < y.plo; });  // pairs in input order again
@@ -1464,20 +1557,87 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				tied.insert(tied.end(), c.tied.begin(), c.tied.end());
 				se_tied.insert(se_tied.end(), c.se.begin(), c.se.end());
 			}
-			// the reference's candidate order is needed for: the pairs that stay open, and mates selected single-end (no pair
-			// in the window / mate without candidates) whose best score is shared.  Most of them are known by now: their
-			// replay runs on the GPU while pass 2 runs here.
-			std::vector<uint32_t> need, need_late;
-			for (const Tied &t : tied) if (t.dup) { need.push_back((uint32_t) (2 * t.pi)); need.push_back((uint32_t) (2 * t.pi + 1)); }
+			// a tied pair without a positive pair score fails whatever the mean: single-end selection for both mates
+			for (Tied &t : tied) if (!t.found) {
+				commit(2 * t.pi + 1, 2 * t.pi, false, -1, -1, 0, 0, 0);
+				se_check(se_tied, 2 * t.pi); se_check(se_tied, 2 * t.pi + 1);
+				t.open = false;
+			}
+			// Which tied pairs will stay open in the sequential pass?  Those whose equally scoring pairs also share the insert size
+			// (`dup`: the candidate order decides) -- and those whose best-scoring pair closest to the mean is not the same unique one
+			// over the range the mean can have when their turn comes.  That range is only known inside the turn (pass 2 carries exact
+			// bounds); the mean of thousands of insert sizes hardly moves, so outside the turn the pairs are picked with the last
+			// PUBLISHED mean +- 3: their candidate order is replayed and their combinations are listed (pass 3) before the turn
+			// begins.  A pair that pass 2 leaves open without having been picked here (the first batches of a run, while the mean
+			// still moves) is handled inside the turn, as every open pair was before round 5.
+			auto closest_top = [](const Tied &t, long avg, bool *unique) {
+				int best = 0, n_best = 0; long best_c = LONG_MAX;
+				for (int x = 0; x < t.n_top; ++x) {
+					const long cx = labs((long) t.top_d[x] - avg);
+					if (cx < best_c) { best_c = cx; best = x; n_best = 1; } else if (cx == best_c) ++n_best;
+				}
+				*unique = n_best == 1;
+				return best;
+			};
+			auto closed_between = [&](const Tied &t, long lo, long hi, int *which) {
+				if (t.dup || t.n_top <= 0) return false;
+				bool u_lo = false, u_hi = false;
+				const int x_lo = closest_top(t, lo, &u_lo), x_hi = closest_top(t, hi, &u_hi);
+				*which = x_lo;
+				return x_lo == x_hi && u_lo && u_hi;
+			};
+			long pub_sum = m->pair_dist_sum, pub_cnt = m->pair_dist_count;
+			if (m->ps && !pair_turn.held) { std::lock_guard<std::mutex> lk(m->ps->mu); pub_sum = m->ps->dist_sum; pub_cnt = m->ps->dist_count; }
+			const long pub_avg = pub_sum / std::max(1L, pub_cnt);
+			std::vector<int> picked;   // indices into `tied`
+			for (size_t x = 0; x < tied.size(); ++x) {
+				Tied &t = tied[x];
+				int which = 0;
+				if (t.found && (pe_strata || !closed_between(t, pub_avg - 3, pub_avg + 3, &which))) picked.push_back((int) x);
+			}
+			std::vector<uint32_t> need;
+			need.reserve(2 * picked.size() + se_tied.size());
+			for (int x : picked) { need.push_back((uint32_t) (2 * tied[x].pi)); need.push_back((uint32_t) (2 * tied[x].pi + 1)); }
 			need.insert(need.end(), se_tied.begin(), se_tied.end());
-			uint32_t *h_rank_pe = nullptr;
-			if (!need.empty() && !position_order) if (int rc = candidate_order(m, need, np, &h_rank_pe, false)) return rc;
 			qlap(0);
-			// Pass 2 (sequential, cheap): the running mean at every tied pair, as bounds -- a tied pair that stays open
-			// contributes one of the insert sizes of its best-scoring pairs.  Without pairs of equal score AND insert size the
-			// winner is the best-scoring pair closest to the mean: the same unique winner at both bounds is the winner for
-			// every mean in between, and its insert size keeps the bounds exact.  (With --strata a tied pair may contribute
-			// nothing at all; then every tied pair simply waits for pass 4.)
+			uint32_t *h_rank_pe = nullptr;
+			if (!need.empty() && !position_order) if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
+			qlap(1);
+			// Pass 3 (parallel, outside the turn): the in-window combinations of the picked pairs in the reference's order
+			std::vector<PairSeq> seqs(picked.size());
+			auto build_seq = [&](PairSeq &sq, int pi) {
+				const int rb = 2 * pi, ra = 2 * pi + 1;
+				walk_pair(m, m->h_base[ra], m->h_count[ra], len_of(ra), m->h_base[rb], m->h_count[rb], len_of(rb), h_loc, h_sv, h_scores, h_rank_pe, &sq.mq_a, &sq.mq_b,
+						[&](float ps, int cur, int ia, int ib) { sq.ps.push_back(ps); sq.d.push_back(cur); sq.a.push_back(ia); sq.b.push_back(ib); });
+			};
+			parallel_for((int) picked.size(), [&](int lo, int hi) { for (int x = lo; x < hi; ++x) { build_seq(seqs[x], tied[picked[x]].pi); tied[picked[x]].seq = x; } }, 8);
+			qlap(2);
+			auto first_best = [&](uint32_t i) {  // ScoreBuffer::top1SE keeps the first of the equally best candidates
+				const uint32_t b = m->h_base[i], cnt = m->h_count[i];
+				if (!h_rank_pe) return;
+				float best = h_scores[b];
+				for (uint32_t c2 = 1; c2 < cnt; ++c2) best = std::max(best, h_scores[b + c2]);
+				uint32_t pick = 0xFFFFFFFFu, pick_rank = ngm::kCsOrderUnknown;
+				for (uint32_t c2 = 0; c2 < cnt; ++c2) if (h_scores[b + c2] == best || !(best > 0.0f)) {
+					if (h_rank_pe[b + c2] == ngm::kCsOrderUnknown) return;
+					if (h_rank_pe[b + c2] < pick_rank) { pick_rank = h_rank_pe[b + c2]; pick = b + c2; }
+				}
+				if (pick != 0xFFFFFFFFu) { h_winner[i] = pick; h_best[i] = h_scores[pick]; }
+			};
+			// ... but when both mates have candidates top1PE has already SORTED the arrays before it falls back to
+			// top1SE (ScoreBuffer.cpp:373-376, 449-455): the first of the best is the head of that (unstable) sort
+			auto first_sorted = [&](uint32_t i) {
+				if (!h_rank_pe) return;
+				// (also for the <= 16 candidates of a stable insertion sort: the head of the sorted array is the BEST score's first candidate --
+				// without a positive score top1SE then keeps it, not the first candidate of the unsorted list: end-to-end mode)
+				bool ranked = false;
+				std::vector<uint32_t> v(m->h_count[i]);
+				sort_like_reference(v.data(), m->h_base[i], m->h_count[i], h_loc, h_sv, h_scores, h_rank_pe, &ranked);
+				if (ranked) { h_winner[i] = v[0]; h_best[i] = h_scores[v[0]]; }
+			};
+			// the single-end ties do not touch the mean: settled here, in parallel
+			parallel_for((int) se_tied.size(), [&](int lo, int hi) { for (int x = lo; x < hi; ++x) { const uint32_t i = se_tied[x]; if (m->h_count[i ^ 1u] > 0) first_sorted(i); else first_best(i); } }, 64);
+			// ---- this batch's turn for the running mean ----------------------------------------------------------------------
 			pair_turn.acquire();
 			{
 				// Diagnostics only: the reference hands a read to its ScoreBuffer right after the search (CS.cpp:436); when
@@ -1499,135 +1659,58 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				}
 				m->scores_so_far = tot; m->reads_so_far = at;
 			}
+			// Pass 2 (sequential, cheap): the running mean at every tied pair, as bounds -- a tied pair that stays open contributes one
+			// of the insert sizes of its best-scoring pairs.  Without pairs of equal score AND insert size the winner is the
+			// best-scoring pair closest to the mean: the same unique winner at both bounds is the winner for every mean in between,
+			// and its insert size keeps the bounds exact.  (With --strata a tied pair may contribute nothing at all; then every tied
+			// pair simply waits for pass 4.)
+			std::vector<int> late;   // left open without having been picked above
 			if (!pe_strata) {
 				long sum_lo = m->pair_dist_sum, sum_hi = m->pair_dist_sum, cnt = m->pair_dist_count;
-				for (Tied &t : tied) {
-					const int pi = t.pi;
+				for (size_t x = 0; x < tied.size(); ++x) {
+					Tied &t = tied[x];
 					sum_lo += t.gap_sum; sum_hi += t.gap_sum; cnt += t.gap_cnt;
 					t.avg_lo = sum_lo / std::max(1L, cnt); t.avg_hi = sum_hi / std::max(1L, cnt);
-					if (!t.found) {
-						commit(2 * pi + 1, 2 * pi, false, -1, -1, 0, 0, 0);
-						const size_t before = se_tied.size();
-						se_check(se_tied, 2 * pi); se_check(se_tied, 2 * pi + 1);
-						if (!t.dup) need_late.insert(need_late.end(), se_tied.begin() + before, se_tied.end());
+					if (!t.found) continue;
+					int which = 0;
+					if (closed_between(t, t.avg_lo, t.avg_hi, &which)) {
+						commit(2 * t.pi + 1, 2 * t.pi, true, t.top_a[which], t.top_b[which], t.mqa, t.mqb, 0);
+						t.dist = t.top_d[which];
+						sum_lo += t.top_d[which]; sum_hi += t.top_d[which]; ++cnt;
 						t.open = false;
 						continue;
 					}
-					if (!t.dup) {
-						auto closest = [&](long avg, bool *unique) {
-							int best = 0, n_best = 0; long best_c = LONG_MAX;
-							for (int x = 0; x < t.n_top; ++x) {
-								const long cx = labs((long) t.top_d[x] - avg);
-								if (cx < best_c) { best_c = cx; best = x; n_best = 1; } else if (cx == best_c) ++n_best;
-							}
-							*unique = n_best == 1;
-							return best;
-						};
-						bool u_lo = false, u_hi = false;
-						const int x_lo = closest(t.avg_lo, &u_lo), x_hi = closest(t.avg_hi, &u_hi);
-						if (x_lo == x_hi && u_lo && u_hi) {
-							commit(2 * pi + 1, 2 * pi, true, t.top_a[x_lo], t.top_b[x_lo], t.mqa, t.mqb, 0);
-							t.dist = t.top_d[x_lo];
-							sum_lo += t.top_d[x_lo]; sum_hi += t.top_d[x_lo]; ++cnt;
-							t.open = false;
-							continue;
-						}
-					}
-					if (!t.dup) { need_late.push_back((uint32_t) (2 * pi)); need_late.push_back((uint32_t) (2 * pi + 1)); }
+					if (t.seq < 0) late.push_back((int) x);
 					sum_lo += t.dmin; sum_hi += t.dmax; ++cnt;
 				}
 			}
-			qlap(1);
-			{
-				size_t n_open = 0;
-				for (const Tied &t : tied) n_open += t.open;
-				if (host_timing) fprintf(stderr, "[ngm-hip] order needed: %zu of %zu tied pairs, %zu single-end ties, %zu reads late\n", n_open, tied.size(), se_tied.size(), need_late.size());
-				{
-					if (!need.empty() && !position_order) if (int rc = candidate_order_wait(m, &h_rank_pe)) return rc;
-					if (!need_late.empty() && !position_order) if (int rc = candidate_order(m, need_late, np, &h_rank_pe)) return rc;
-					auto first_best = [&](uint32_t i) {  // ScoreBuffer::top1SE keeps the first of the equally best candidates
-						const uint32_t b = m->h_base[i], cnt = m->h_count[i];
-						if (!h_rank_pe) return;
-						float best = h_scores[b];
-						for (uint32_t c2 = 1; c2 < cnt; ++c2) best = std::max(best, h_scores[b + c2]);
-						uint32_t pick = 0xFFFFFFFFu, pick_rank = ngm::kCsOrderUnknown;
-						for (uint32_t c2 = 0; c2 < cnt; ++c2) if (h_scores[b + c2] == best || !(best > 0.0f)) {
-							if (h_rank_pe[b + c2] == ngm::kCsOrderUnknown) return;
-							if (h_rank_pe[b + c2] < pick_rank) { pick_rank = h_rank_pe[b + c2]; pick = b + c2; }
-						}
-						if (pick != 0xFFFFFFFFu) { h_winner[i] = pick; h_best[i] = h_scores[pick]; }
-					};
-					// ... but when both mates have candidates top1PE has already SORTED the arrays before it falls back to
-					// top1SE (ScoreBuffer.cpp:373-376, 449-455): the first of the best is the head of that (unstable) sort
-					auto first_sorted = [&](uint32_t i) {
-						if (!h_rank_pe) return;
-						// (also for the <= 16 candidates of a stable insertion sort: the head of the sorted array is the BEST score's first candidate --
-						// without a positive score top1SE then keeps it, not the first candidate of the unsorted list: end-to-end mode)
-						bool ranked = false;
-						std::vector<uint32_t> v(m->h_count[i]);
-						sort_like_reference(v.data(), m->h_base[i], m->h_count[i], h_loc, h_sv, h_scores, h_rank_pe, &ranked);
-						if (ranked) { h_winner[i] = v[0]; h_best[i] = h_scores[v[0]]; }
-					};
-					qlap(2);
-					// Pass 3 (parallel): an open pair whose outcome is the same for every mean inside its bounds is settled too
-					struct Outcome { int wa, wb, mqa, mqb, equal, dist; bool found; };
-					auto outcome_at = [&](int pi, long sum, long cnt) {
-						Outcome o{-1, -1, 0, 0, 0, 0, false};
-						run_pair(pi, sum, cnt, h_rank_pe, &o.wa, &o.wb, &o.mqa, &o.mqb, &o.equal, &o.dist, &o.found, nullptr);
-						return o;
-					};
-					std::vector<int> open_ix;
-					for (size_t x = 0; x < tied.size(); ++x) if (tied[x].open) open_ix.push_back((int) x);
-					std::vector<Outcome> settled(open_ix.size());
-					std::vector<char> is_settled(open_ix.size(), 0);
-					// (pairs whose bounds are wide -- many open pairs in front of them, each contributing a range -- are evaluated here, in
-					// parallel, at the three values the mean is most likely to have when their turn comes: the mean of thousands of insert
-					// sizes hardly moves inside a batch.  Pass 4 looks the outcome up and only evaluates on the spot when the exact mean is
-					// another one: with hundreds of candidates per mate an evaluation costs ~0.1 ms, and there are thousands of such pairs
-					// per batch on a repeat-rich genome)
-					const long spec_avg = m->pair_dist_sum / std::max(1L, m->pair_dist_count);
-					std::vector<Outcome> spec(open_ix.size() * 3);
-					std::vector<char> has_spec(open_ix.size(), 0);
-					if (!pe_strata) parallel_for((int) open_ix.size(), [&](int lo, int hi) {
-						for (int x = lo; x < hi; ++x) {
-							Tied &t = tied[open_ix[x]];
-							if (t.avg_hi - t.avg_lo > 3) {
-								for (int g = 0; g < 3; ++g) spec[(size_t) x * 3 + g] = outcome_at(t.pi, spec_avg - 1 + g, 1);
-								has_spec[x] = 1;
-								continue;
-							}
-							const Outcome o = outcome_at(t.pi, t.avg_lo, 1);
-							bool same = true;
-							for (long a = t.avg_lo + 1; a <= t.avg_hi && same; ++a) {
-								const Outcome o2 = outcome_at(t.pi, a, 1);
-								same = o2.found == o.found && o2.wa == o.wa && o2.wb == o.wb && o2.equal == o.equal && o2.dist == o.dist;
-							}
-							if (same) { settled[x] = o; is_settled[x] = 1; }
-						}
-					}, 16);
-					// Pass 4 (sequential): the running mean in input order; the open pairs see exactly the reference's value
-					size_t no = 0;
-					for (const Tied &t : tied) {
-						const int pi = t.pi;
-						m->pair_dist_sum += t.gap_sum; m->pair_dist_count += t.gap_cnt;
-						if (!t.open) { if (t.dist) { m->pair_dist_sum += t.dist; m->pair_dist_count += 1; } continue; }  // closed by pass 2
-						const long avg_now = m->pair_dist_sum / std::max(1L, m->pair_dist_count);
-						const Outcome o = is_settled[no] ? settled[no] : (has_spec[no] && avg_now >= spec_avg - 1 && avg_now <= spec_avg + 1) ? spec[no * 3 + (size_t) (avg_now - spec_avg + 1)] :
-								outcome_at(pi, m->pair_dist_sum, m->pair_dist_count);
-						++no;
-						const int rb = 2 * pi, ra = 2 * pi + 1;
-						const bool found = o.found;
-						commit(ra, rb, o.found, o.wa, o.wb, o.mqa, o.mqb, o.equal);
-						if (found && !(pe_strata && o.equal > 0)) { m->pair_dist_sum += o.dist; m->pair_dist_count += 1; }
-						if (!found) { if (h_nbest[ra] != 1 && m->h_count[ra] > 1) first_sorted((uint32_t) ra); if (h_nbest[rb] != 1 && m->h_count[rb] > 1) first_sorted((uint32_t) rb); }
-					}
-					m->pair_dist_sum += carry_sum; m->pair_dist_count += carry_cnt;
-					for (uint32_t i : se_tied) { if (m->h_count[i ^ 1u] > 0) first_sorted(i); else first_best(i); }
-					pair_turn.release();
-					qlap(3);
-					if (host_timing) fprintf(stderr, "[ngm-hip] pair selection ms: pass 1 %.2f | pass 2 %.2f | order %.2f | pass 3+4 %.2f\n", tq[0], tq[1], tq[2], tq[3]);
-				}
+			qlap(3);
+			size_t n_open = 0;
+			for (const Tied &t : tied) n_open += t.open;
+			if (!late.empty()) {
+				std::vector<uint32_t> need_late;
+				for (int x : late) { need_late.push_back((uint32_t) (2 * tied[x].pi)); need_late.push_back((uint32_t) (2 * tied[x].pi + 1)); }
+				if (!position_order) if (int rc = candidate_order(m, need_late, np, &h_rank_pe)) return rc;
+				const size_t s0 = seqs.size();
+				seqs.resize(s0 + late.size());
+				parallel_for((int) late.size(), [&](int lo, int hi) { for (int x = lo; x < hi; ++x) { build_seq(seqs[s0 + x], tied[late[x]].pi); tied[late[x]].seq = (int) (s0 + x); } }, 8);
 			}
+			// Pass 4 (sequential): the running mean in input order; the open pairs see exactly the reference's value
+			for (const Tied &t : tied) {
+				const int pi = t.pi;
+				m->pair_dist_sum += t.gap_sum; m->pair_dist_count += t.gap_cnt;
+				if (!t.open) { if (t.dist) { m->pair_dist_sum += t.dist; m->pair_dist_count += 1; } continue; }  // closed by pass 2 (or not found)
+				const PairOutcome o = eval_pair_seq(seqs[t.seq], (int) (m->pair_dist_sum / std::max(1L, m->pair_dist_count)));
+				const int rb = 2 * pi, ra = 2 * pi + 1;
+				commit(ra, rb, o.found, o.wa, o.wb, o.mqa, o.mqb, o.equal);
+				if (o.found && !(pe_strata && o.equal > 0)) { m->pair_dist_sum += o.dist; m->pair_dist_count += 1; }
+				if (!o.found) { if (h_nbest[ra] != 1 && m->h_count[ra] > 1) first_sorted((uint32_t) ra); if (h_nbest[rb] != 1 && m->h_count[rb] > 1) first_sorted((uint32_t) rb); }
+			}
+			m->pair_dist_sum += carry_sum; m->pair_dist_count += carry_cnt;
+			pair_turn.release();
+			qlap(4);
+			if (host_timing) fprintf(stderr, "[ngm-hip] pair selection: %zu tied pairs, %zu picked for the order replay + %zu single-end ties, %zu open in the turn, %zu of them late; %ld pairs walked on the host; "
+					"ms: pass 1 %.2f | order replay %.2f | pass 3 %.2f | turn: pass 2 %.2f, late + pass 4 %.2f\n", tied.size(), picked.size(), se_tied.size(), n_open, late.size(), (long) n_host_walk, tq[0], tq[1], tq[2], tq[3], tq[4]);
 		}
 	}
 	if (paired && np > 0 && m->prm.strata)  // mates selected single-end (top1SE): several equally best candidates -> unmapped
