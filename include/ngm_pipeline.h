@@ -149,6 +149,7 @@ typedef struct ngm_hit {
 
 #define NGM_PAIR_SELECTED 1  /* top1PE found a pair inside the insert-size window; n_best = pairs sharing its score and distance */
 #define NGM_PAIR_FAILED 2    /* both mates had candidates but no such pair: NGMNames::PairedFail, mates selected single-end */
+#define NGM_PAIR_LOST 4      /* the reference never writes this pair (ngm_mapper_set_reference_score_buffer): no record for either mate */
 
 /* Full single-end path for n reads; cigars/mds: n rows of 4*qry_max_len bytes (NUL-terminated strings).
  * With topn > 1 every read owns topn consecutive entries of hits / rows of cigars and mds (entry k = k-th best
@@ -242,14 +243,18 @@ void ngm_host_free(void *p);
  * NGM_HIP_NO_NUMA_PIN is set), < 0 on error.  (NextGenMap itself leaves placement to the OS; this replaces nothing there.) */
 int ngm_host_pin_to_device_node(int device);
 
-/* A reference artefact that is NOT mirrored: NextGenMap hands a read to its ScoreBuffer right after the search
- * (src/CS.cpp:436); when the scores of a pair's first mate end exactly on a multiple of the 1 024-entry score buffer
- * (src/seqan/EndToEndAffine.h:44-46), top1SE runs on that mate alone before its partner has scores
- * (src/ScoreBuffer.cpp:196-209) and narrows the pairing to that winner.  out[0] = pairs of this mapper's batches where that
- * would have happened, out[1] = those of them whose first mate has several candidates (only there can the outcome differ). */
-int ngm_mapper_early_top1se_counts(ngm_mapper *m, uint64_t out[2]);
+/* A reference artefact that IS mirrored on request: NextGenMap hands a read to its ScoreBuffer right after the search
+ * (src/CS.cpp:436); when the last score of a pair's first mate fills the score buffer exactly (src/ScoreBuffer.cpp:519-523; the
+ * buffer holds IAlignment::GetScoreBatchSize() entries: 1 024 for the SeqAn personality, src/seqan/EndToEndAffine.h:44-46), DoRun
+ * sees the mate's Calculated == -1 (src/MappedRead.cpp:14, src/ScoreBuffer.cpp:196) and selects nothing; if the mate then has no
+ * candidates it goes to the writer alone (src/CS.cpp:326-329) and the pair is never written -- "(2 discarded)" in the reference's
+ * summary.  With entries > 0 the mapper follows the reference's buffer through its batches (sequential state, like the running mean:
+ * exact for `ngm -t 1`) and flags such pairs NGM_PAIR_LOST: no alignment, no record.  0 (default): no pair is lost. */
+int ngm_mapper_set_reference_score_buffer(ngm_mapper *m, int entries);
+/* pairs flagged NGM_PAIR_LOST by this mapper so far */
+int ngm_mapper_lost_pairs(ngm_mapper *m, uint64_t *out);
 /* ... the reference flushes that buffer at the end of every CS batch of 1 800 000 / qry_avg_len reads (src/CS.cpp:26, :542-543,
- * even for paired input: src/NGM.cpp:238-243); tell the mapper that number (0: never flushed) so that the count follows it */
+ * even for paired input: src/NGM.cpp:238-243); tell the mapper that number (0: never flushed) so that the walk follows it */
 int ngm_mapper_set_reference_cs_batch(ngm_mapper *m, int reads);
 
 /* which paths the reads took, summed over all batches of this mapper: [0] reads searched, [1] candidates, [2] reads re-run by the exact

@@ -289,4 +289,372 @@ __global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
 	});
 }
 
+// ---- round 5: the heavy reads again -- segment-wise sweeps, a second counter row over the survivors, persistent workgroups ------------
+// What round 4's kernel left (profiles/r05_heavy_tail_probe_kernel_stats_before_heavy2.csv, per 262 144 reads of the heavy-tailed
+// leg): its four classes 26 ms, and cs_global_kernel 47 ms for the 10 275 reads none of them could certify -- reads with thousands of
+// bins near the threshold.  Two things were wrong with it.  (1) The table had to take every HIT on a counter >= T: T was the smallest
+// value whose hits fit, so a read with 3 000 bins of ~20 votes (60 000 hits on its hot counters) failed a table that its 3 000 bins
+// would have filled to a half.  And a single counter row lets every background hit that shares a counter with a hot bin through --
+// at 3-6 background hits per counter several times the hot bins themselves.  (2) The sweeps walked the lists hit by hit
+// (cs_for_each_hit_block: a bisection per 8 hits, three dependent LDS reads and a 4-byte load per hit).
+// Now:
+//   sweep A   every hit increments its counter of row 1 (16-bit, hash 1);
+//   T         the smallest value for which the COUNTERS >= T (about one bin each) fit the table; if even their hits fit, they go
+//             straight into the table (the round-4 path: most reads);
+//   sweep B   otherwise the hits on counters >= T are written (bin | strand << 31) to the workgroup's slice of a global scratch;
+//   sweep C   (over the slice) row 2: hash 2, the same LDS words as row 1 -- only the survivors count, so row 2 is almost free of noise;
+//   sweep D   (over the slice) the hits whose row-2 counter is >= T as well go into the exact table; entries are counted, and a table
+//             filling beyond 3/4 fails the read;
+//   check     a bin with v >= T votes has both its counters >= v >= T, so all its hits reach the table: as before, with M2 the
+//             largest strand count in the table, T - 1 < max(kmer_min, M2 * sensitivity) certifies the result exactly.
+// 16-bit counters in every class: a row is checked by its SUM (a field that wrapped into its neighbour changes the sum of the
+// fields), which replaces the 32-bit class.  Work items are 8-hit segments of one list (two 16-byte loads, constant strand and
+// diagonal correction; item -> list through a coarse table + a short bisection).  Workgroups are persistent (one scratch slice each)
+// and draw reads from a counter.  Candidates leave in cs_global_kernel's order.
+struct CsHeavy2Cfg { int log2c, log2s; uint32_t scratch_cap; };   // per class (host: mapper.cpp)
+
+inline size_t cs_heavy2_coarse_cap(int lists_cap, int max_kfreq) {   // items / 16 + slack: a read has at most lists_cap / 2 * max_kfreq hits
+	const size_t items = ((size_t) (lists_cap / 2) * (size_t) max_kfreq) / kCsSeg + (size_t) lists_cap;
+	return items / 16 + 4;
+}
+inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int log2_slots, size_t coarse_cap) {
+	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + ((size_t) 1 << (log2_counters - 1)) + 512 + ((size_t) 2 << log2_slots)) * 4;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list, uint32_t *__restrict__ work_counter, uint32_t *__restrict__ scratch, uint32_t scratch_cap,
+		uint32_t coarse_cap) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
+	constexpr int NW = NT / 64;
+	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct;
+	__shared__ uint32_t s_red[NW], s_cnt[NT], s_wtot[NW], s_mx[NW], s_mxb[NW];
+	__shared__ unsigned long long s_base;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int k = A.k;
+	uint32_t *l_start = cs_lds;                                  // [lists_cap]
+	uint32_t *l_pref = cs_lds + A.lists_cap;                     // [lists_cap + 1]
+	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);    // [q rounded up to 4]
+	uint32_t *seg_pref = (uint32_t *) l_code + (A.q + 3) / 4;    // [lists_cap + 1]: 8-hit segments in front of each list
+	uint16_t *coarse = (uint16_t *) (seg_pref + A.lists_cap + 1); // [coarse_cap]: the list that holds item 16 c
+	uint32_t *cnt = (uint32_t *) coarse + (coarse_cap + 1) / 2;  // [NC / 2]: two 16-bit counters per word
+	const int log2c = A.log2_bits;
+	const uint32_t cnt_words = (1u << log2c) >> 1;
+	uint32_t *hist_n = cnt + cnt_words;                          // [256]: counters of value c (255: and above)
+	uint32_t *hist_h = hist_n + 256;                             // [256]: ... and the hits on them
+	uint32_t *t_keys = hist_h + 256;
+	const int log2_slots = A.log2_slots;
+	const uint32_t n_slots = 1u << log2_slots;
+	uint32_t *t_votes = t_keys + n_slots;
+	const uint32_t cap = (n_slots * 3u) / 4u;
+	uint32_t *my_scratch = scratch + (size_t) blockIdx.x * scratch_cap;
+	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	for (;;) {
+		__syncthreads();   // (the previous read's shared state is no longer read)
+		if (tid == 0) s_next = atomicAdd(work_counter, 1u);
+		__syncthreads();
+		const uint32_t item_ix = s_next;
+		if (item_ix >= n_list) return;
+		const int read = (int) A.read_list[item_ix];
+		for (uint32_t s = tid; s < cnt_words; s += NT) cnt[s] = 0;
+		for (uint32_t s = tid; s < 512u; s += NT) hist_n[s] = 0;   // (hist_n and hist_h)
+		for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+		if (tid == 0) { s_T = 1; s_np = 0; s_entries = 0; s_fail = 0; s_direct = 1; }
+		// every wave computes the same lists (the barrier inside is the block's)
+		const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
+		const uint32_t H = R.H;
+		const int L = R.L;
+		const int n_lists = R.n_lists;
+		__syncthreads();
+		if (wv == 0) {
+			uint32_t carry = 0;
+			for (int base = 0; base < n_lists; base += 64) {
+				const int li = base + lane;
+				const uint32_t ns = li < n_lists ? (l_pref[li + 1] - l_pref[li] + kCsSeg - 1) / kCsSeg : 0u;
+				const uint32_t incl = wave_inclusive_scan(ns, lane);
+				if (li < n_lists) seg_pref[li] = carry + incl - ns;
+				carry += wave_last(incl);
+			}
+			if (lane == 0) seg_pref[n_lists] = carry;
+		}
+		__syncthreads();
+		const uint32_t n_items = seg_pref[n_lists];
+		if ((n_items >> 4) + 3u > coarse_cap) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // (block-uniform; sized from max_kfreq: not reached)
+		for (int li = tid; li < n_lists; li += NT) {
+			const uint32_t s0 = seg_pref[li], s1 = seg_pref[li + 1];
+			for (uint32_t c = (s0 + 15u) >> 4; (c << 4) < s1; ++c) coarse[c] = (uint16_t) li;
+		}
+		if (tid == 0) coarse[((n_items + 15u) >> 4)] = (uint16_t) max(n_lists - 1, 0), coarse[((n_items + 15u) >> 4) + 1] = (uint16_t) max(n_lists - 1, 0);
+		__syncthreads();
+		// f(position, list) for every hit: per thread one 8-hit segment at a time, the next one's loads in flight
+		auto sweep = [&](auto f) {
+			CsU4 cur[2], nxt[2];
+			auto fetch = [&](uint32_t idx, CsU4 (&d)[2]) -> uint32_t {
+				if (idx >= n_items) return 0xFFFFFFFFu;
+				int lo = (int) coarse[idx >> 4], hi = min((int) coarse[(idx >> 4) + 1] + 1, n_lists);   // the list with seg_pref[li] <= idx < seg_pref[li + 1] (never an empty one)
+				while (hi - lo > 1) {
+					const int mid = (lo + hi) >> 1;
+					if (seg_pref[mid] <= idx) lo = mid; else hi = mid;
+				}
+				const uint32_t sg = idx - seg_pref[lo];
+				const CsU4 *src = reinterpret_cast<const CsU4 *>(A.positions + l_start[lo] + sg * kCsSeg);
+				d[0] = src[0]; d[1] = src[1];  // the table is padded by 16 entries
+				return ((uint32_t) lo << 16) | sg;
+			};
+			uint32_t item = fetch((uint32_t) tid, cur);
+			for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += NT) {
+				const uint32_t item_n = fetch(idx + NT, nxt);
+				const int li = (int) (item >> 16);
+				const uint32_t sg = item & 0xFFFFu;
+				const uint32_t len = l_pref[li + 1] - l_pref[li];
+				const uint32_t cn = min((uint32_t) kCsSeg, len - sg * kCsSeg);
+				const int p = li >> 1;
+				const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
+				const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
+				f(pos8, cn, correction, (li & 1) != 0);
+				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1];
+			}
+		};
+		auto insert = [&](uint32_t bin, bool rev) {
+			uint32_t slot = (bin * 0x85EBCA6Bu) >> (32 - log2_slots);
+			for (;;) {
+				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
+				if (prev == bin) break;
+				if (prev == 0xFFFFFFFFu) { if (atomicAdd(&s_entries, 1u) >= cap) atomicExch(&s_fail, 1u); break; }
+				slot = (slot + 1) & (n_slots - 1);
+			}
+			atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
+		};
+		auto counter_of = [&](uint32_t hc) -> uint32_t { return (cnt[hc >> 1] >> ((hc & 1u) * 16u)) & 0xFFFFu; };
+		// sum of all 16-bit fields of the row == `want`: no field has wrapped
+		auto row_sum_is = [&](uint32_t want) -> bool {
+			uint32_t s = 0;
+			for (uint32_t i = tid; i < cnt_words; i += NT) { const uint32_t w = cnt[i]; s += (w & 0xFFFFu) + (w >> 16); }
+			s = wave_last(wave_inclusive_scan(s, lane));
+			__syncthreads();
+			if (lane == 0) s_red[wv] = s;
+			__syncthreads();
+			uint32_t tot = 0;
+#pragma unroll
+			for (int w2 = 0; w2 < NW; ++w2) tot += s_red[w2];
+			return tot == want;
+		};
+		uint32_t T = 1;
+		bool failed = false;
+		if (H > cap) {
+			// sweep A
+			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool) {
+#pragma unroll
+				for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) {
+					const uint32_t hc = (((pos8[j] - correction) >> A.bin_shift) * 0x9E3779B1u) >> (32 - log2c);
+					atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
+				}
+			});
+			__syncthreads();
+			if (!row_sum_is(H)) failed = true;   // (block-uniform)
+			if (!failed) {
+				for (uint32_t i = tid; i < cnt_words; i += NT) {
+					const uint32_t w = cnt[i];
+					const uint32_t c0 = w & 0xFFFFu, c1 = w >> 16;
+					if (c0 > 1u) { atomicAdd(&hist_n[min(c0, 255u)], 1u); atomicAdd(&hist_h[min(c0, 255u)], c0); }   // (counters of 0 and 1 are most of them: T >= 2 here, they never matter)
+					if (c1 > 1u) { atomicAdd(&hist_n[min(c1, 255u)], 1u); atomicAdd(&hist_h[min(c1, 255u)], c1); }
+				}
+				__syncthreads();
+				if (tid == 0) {
+					// the smallest T whose counters fit the table with a quarter of it to spare (one bin per counter, and what slips through
+					// both rows); when even their hits fit, no second row is needed; and the survivors must fit the scratch slice
+					uint32_t acc_n = 0, acc_h = 0, t = 256u, direct = 0;
+					const uint32_t room = (cap * 3u) / 4u;
+					for (uint32_t c = 255u; c >= 2u; --c) {
+						acc_n += hist_n[c]; acc_h += hist_h[c];
+						if (acc_h <= cap) { t = c; direct = 1; continue; }
+						if (acc_n > room || acc_h > scratch_cap) break;
+						t = c; direct = 0;
+					}
+					s_T = t; s_direct = direct;
+				}
+				__syncthreads();
+				T = s_T;
+				if (T > 255u) failed = true;
+			}
+			if (!failed && s_direct) {
+				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev) {
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) {
+						const uint32_t bin = (pos8[j] - correction) >> A.bin_shift;
+						if (counter_of((bin * 0x9E3779B1u) >> (32 - log2c)) >= T) insert(bin, rev);
+					}
+				});
+			} else if (!failed) {
+				// sweep B: the survivors of row 1 -> scratch slice (one slot request per wave and trip)
+				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev) {
+					uint32_t keep = 0, nk = 0;
+					uint32_t e[8];
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) {
+						const uint32_t bin = (pos8[j] - correction) >> A.bin_shift;
+						e[j] = (bin & 0x3FFFFFFFu) | (rev ? 0x80000000u : 0u);
+						if ((uint32_t) j < cn && counter_of((bin * 0x9E3779B1u) >> (32 - log2c)) >= T) { keep |= 1u << j; ++nk; }
+					}
+					// (lanes that left the loop do not take part: the prefix runs over the active ones)
+					const unsigned long long act = __ballot(true);
+					uint32_t pre = 0, tot = 0;
+#pragma unroll
+					for (int b = 0; b < 4; ++b) {
+						const unsigned long long mb = __ballot((nk >> b) & 1u);
+						pre += (uint32_t) __popcll(mb & lanes_below) << b;
+						tot += (uint32_t) __popcll(mb) << b;
+					}
+					uint32_t base = 0;
+					if (tot) {
+						const int leader = (int) __builtin_ctzll(act);
+						if (lane == leader) base = atomicAdd(&s_np, tot);
+						base = (uint32_t) __builtin_amdgcn_readlane((int) base, leader);
+					}
+					uint32_t w = base + pre;
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) if ((keep >> j) & 1u) { if (w < scratch_cap) my_scratch[w] = e[j]; ++w; }
+				});
+				__threadfence_block();
+				__syncthreads();
+				const uint32_t np = s_np;
+				if (np > scratch_cap) failed = true;
+				if (!failed) {
+					for (uint32_t s = tid; s < cnt_words; s += NT) cnt[s] = 0;
+					__syncthreads();
+					// sweep C: row 2 over the survivors
+					for (uint32_t x = tid; x < np; x += NT) {
+						const uint32_t bin = my_scratch[x] & 0x3FFFFFFFu;
+						const uint32_t hc = (bin * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c);
+						atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
+					}
+					__syncthreads();
+					if (!row_sum_is(np)) failed = true;
+				}
+				if (!failed) {
+					// row 2 is almost free of noise: its counters >= t are the bins with >= t votes -- the final T is the smallest one
+					// (not below row 1's) whose bins leave the table a quarter of its room
+					for (uint32_t s = tid; s < 256u; s += NT) hist_n[s] = 0;
+					__syncthreads();
+					for (uint32_t i = tid; i < cnt_words; i += NT) {
+						const uint32_t w = cnt[i];
+						const uint32_t c0 = w & 0xFFFFu, c1 = w >> 16;
+						if (c0 >= T) atomicAdd(&hist_n[min(c0, 255u)], 1u);
+						if (c1 >= T) atomicAdd(&hist_n[min(c1, 255u)], 1u);
+					}
+					__syncthreads();
+					if (tid == 0) {
+						uint32_t acc = 0, t = 256u;
+						const uint32_t room = (cap * 3u) / 4u;
+						for (uint32_t c = 255u; c >= T; --c) { acc += hist_n[c]; if (acc > room) break; t = c; }
+						s_T = t;
+					}
+					__syncthreads();
+					T = s_T;
+					if (T > 255u) failed = true;
+				}
+				if (!failed) {
+					// sweep D
+					for (uint32_t x = tid; x < np; x += NT) {
+						if (*(volatile uint32_t *) &s_fail) break;
+						const uint32_t e = my_scratch[x];
+						const uint32_t bin = e & 0x3FFFFFFFu;
+						if (counter_of((bin * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c)) >= T) insert(bin, (e >> 31) != 0u);
+					}
+				}
+			}
+		} else {
+			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev) {
+#pragma unroll
+				for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) insert((pos8[j] - correction) >> A.bin_shift, rev);
+			});
+		}
+		__syncthreads();
+		if (failed || s_fail) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
+		// the table: maximum, candidates (cs_global_kernel's order: thread t owns the slots of lane class t mod 64 in the (t / 64)-th share)
+		const uint32_t per_class = n_slots >> 6;
+		const uint32_t j0 = (uint32_t) ((unsigned long long) per_class * (unsigned) wv / (unsigned) NW), j1 = (uint32_t) ((unsigned long long) per_class * (unsigned) (wv + 1) / (unsigned) NW);
+		int mx = 0, mxb = 0;
+		for (uint32_t j = j0; j < j1; ++j) {
+			const uint32_t v = t_votes[(j << 6) + (uint32_t) lane];
+			mx = max(mx, (int) max(v & 0xFFFFu, v >> 16));
+			mxb = max(mxb, (int) ((v & 0xFFFFu) + (v >> 16)));
+		}
+		mx = wave_reduce_max(mx);
+		mxb = wave_reduce_max(mxb);
+		if (lane == 0) { s_mx[wv] = (uint32_t) mx; s_mxb[wv] = (uint32_t) mxb; }
+		__syncthreads();
+		mx = 0; mxb = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < NW; ++w2) { mx = max(mx, (int) s_mx[w2]); mxb = max(mxb, (int) s_mxb[w2]); }
+		const float max_hit = (float) mx;
+		const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
+		if (T > 1u && !((float) (T - 1u) < thresh)) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins outside the table could reach the threshold
+		const uint32_t region = (uint32_t) read & (kCsRegions - 1);
+		if (tid == 0 && A.counters) {
+			atomicAdd(&A.counters[region * kCsCursorStride], (unsigned long long) R.n_valid);
+			atomicAdd(&A.counters[region * kCsCursorStride + 1], (unsigned long long) H);
+		}
+		uint32_t count = 0;
+		for (uint32_t j = j0; j < j1; ++j) {
+			const uint32_t s2 = (j << 6) + (uint32_t) lane;
+			if (t_keys[s2] != 0xFFFFFFFFu) {
+				const uint32_t v = t_votes[s2];
+				count += ((float) (v & 0xFFFFu) >= thresh) + ((float) (v >> 16) >= thresh);
+			}
+		}
+		// exclusive scan in (class, share) order: entry o = lane * NW + wv
+		s_cnt[lane * NW + wv] = count;
+		__syncthreads();
+		{
+			const uint32_t v = s_cnt[tid];
+			const uint32_t incl = wave_inclusive_scan(v, lane);
+			__syncthreads();
+			s_cnt[tid] = incl - v;
+			if (lane == 63) s_wtot[wv] = incl;
+		}
+		__syncthreads();
+		const uint32_t o = (uint32_t) (lane * NW + wv);
+		uint32_t before = s_cnt[o], total = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < NW; ++w2) { if ((uint32_t) w2 < (o >> 6)) before += s_wtot[w2]; total += s_wtot[w2]; }
+		if ((int64_t) total >= (int64_t) A.max_cmrs) total = 0;  // "if (index < maxScores) AllocScores" (CS.cpp:308-310)
+		const bool fixed = A.fixed_base != 0u && total <= (uint32_t) kCsFixedSlots;
+		if (tid == 0) {
+			unsigned long long base = 0;
+			if (!fixed) {
+				base = total ? atomicAdd(&A.out_total[region * kCsCursorStride], (unsigned long long) total) : 0ull;
+				if (base + total > A.out_capacity) { atomicExch(&A.status[0], 1u); }
+			}
+			s_base = base;
+			A.cand_base[read] = fixed ? A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots : (uint32_t) (region * A.out_capacity + base);
+			A.cand_count[read] = total;
+			A.max_votes[read] = max_hit;
+			if (A.max_both) A.max_both[read] = (float) mxb;
+			A.read_len[read] = (uint16_t) R.L;
+			if (A.counters && total) atomicAdd(&A.counters[region * kCsCursorStride + 2], (unsigned long long) total);
+		}
+		__syncthreads();
+		if (total == 0) continue;
+		uint32_t w;
+		if (fixed) w = A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots + before;
+		else {
+			const unsigned long long base = s_base;
+			if (base + total > A.out_capacity) continue;
+			w = (uint32_t) (region * A.out_capacity + base) + before;
+		}
+		const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
+		for (uint32_t j = j0; j < j1; ++j) {
+			const uint32_t s2 = (j << 6) + (uint32_t) lane;
+			const uint32_t key = t_keys[s2];
+			if (key != 0xFFFFFFFFu) {
+				const uint32_t v = t_votes[s2];
+				const uint32_t f = v & 0xFFFFu, r = v >> 16;
+				const uint32_t loc = (key << A.bin_shift) + centre;
+				if ((float) f >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = f << 1; ++w; }
+				if ((float) r >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = (r << 1) | 1u; ++w; }
+			}
+		}
+	}
+}
+
 }  // namespace ngm

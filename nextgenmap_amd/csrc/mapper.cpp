@@ -83,7 +83,8 @@ struct ngm_mapper {
 	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
 	uint64_t scores_so_far = 0, reads_so_far = 0;  // see ngm_pair_state
 	int ref_cs_batch = 0;             // reads per CS batch of the reference (1 800 000 / average read length, CS.cpp:26, :542): its score buffer is flushed there
-	uint64_t early_se_pairs = 0, early_se_ambiguous = 0;  // ngm_mapper_early_top1se_counts
+	int ref_score_buffer = 0;         // entries of the reference's score buffer (IAlignment::GetScoreBatchSize there); 0: pairs are never lost (ngm_mapper_set_reference_score_buffer)
+	uint64_t lost_pairs = 0;          // ngm_mapper_lost_pairs
 	// ngm_mapper_path_counters: reads searched, candidates, reads re-run by the exact LDS / exact global-memory search, reads whose
 	// candidate order was replayed, of those beyond the LDS replay's limits (replayed by the exact global-memory kernel), left undetermined
 	uint64_t st_heavy = 0, st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0;
@@ -109,7 +110,7 @@ struct ngm_mapper {
 	ngm::DevBuf<uint16_t> d_read_len;
 	ngm::DevBuf<uint32_t> d_cand_base, d_cand_count, d_out_loc, d_out_sv, d_status, d_ovf_read, d_ovf_read2, d_ovf_hits, d_ovf_log2;
 	ngm::DevBuf<uint64_t> d_ovf_off;
-	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes, d_heavy_list;
+	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes, d_heavy_list, d_heavy_ctr;
 	ngm::DevBuf<float> d_max_votes, d_max_both, d_scores, d_best;
 	ngm::DevBuf<unsigned long long> d_total, d_counters;
 	ngm::DevBuf<uint32_t> d_out_loc2, d_out_sv2, d_new_base;
@@ -423,6 +424,81 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 		}
 		uint32_t n_heavy = 0;
 		static const bool heavy_on = !getenv("NGM_HIP_CS_NO_HEAVY");
+		static const bool heavy_v1 = getenv("NGM_HIP_CS_HEAVY_V1") != nullptr;   // round 4's kernel (cs_heavy_kernel), for A/B runs
+		if (!bs && heavy_on && !heavy_v1 && A.bin_shift >= 2 && status[1] > 0) {
+			// pass 1b -- the reads with more hits than the fast path takes (cs_heavy2_kernel, cs_heavy_device.h): two rows of sketch counters +
+			// an exact table in LDS, by hit count in three classes of persistent workgroups; pass 1c -- what the two smaller classes
+			// cannot certify, once more in the largest; what is left after that is queued for the exact kernels below
+			struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; uint32_t scratch_cap; const void *fn; };
+			static const HeavyClass classes[3] = {{16384u, 13, 11, 256, 16384u, (const void *) ngm::cs_heavy2_kernel<256>}, {32768u, 14, 12, 512, 32768u, (const void *) ngm::cs_heavy2_kernel<512>},
+					{0xFFFFFFFFu, 15, 13, 1024, 262144u, (const void *) ngm::cs_heavy2_kernel<1024>}};
+			const uint32_t coarse_cap = (uint32_t) ngm::cs_heavy2_coarse_cap(A.lists_cap, m->max_kfreq);
+			n_heavy = status[1];
+			float t_heavy[2] = {0, 0};
+			uint32_t in_round[2] = {0, 0};
+			int cus = 0;
+			if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
+			if (m->d_heavy_ctr.reserve(8)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
+			for (int round = 0; round < 2 && status[1] > 0; ++round) {
+				const uint32_t no = status[1];
+				std::vector<uint32_t> qr(no), qh(no), lists[3], keep_r, keep_h;
+				MAP_HIP_TRY(hipMemcpyAsync(qr.data(), m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
+				MAP_HIP_TRY(hipMemcpyAsync(qh.data(), m->d_ovf_hits.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
+				MAP_HIP_TRY(hipStreamSynchronize(m->st));
+				for (uint32_t i = 0; i < no; ++i) {
+					if (round == 0) lists[qh[i] <= classes[0].max_hits ? 0 : qh[i] <= classes[1].max_hits ? 1 : 2].push_back(qr[i]);
+					else if (qh[i] <= classes[1].max_hits) lists[2].push_back(qr[i]);   // failed in a smaller class: once more with the largest table
+					else { keep_r.push_back(qr[i]); keep_h.push_back(qh[i]); }          // (the largest class has seen it: the same kernel would fail the same way)
+				}
+				const uint32_t n_run = (uint32_t) (lists[0].size() + lists[1].size() + lists[2].size());
+				in_round[round] = n_run;
+				if (n_run == 0) break;
+				if (m->d_heavy_list.reserve(no)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
+				int grid[3] = {0, 0, 0};
+				size_t lds[3] = {0, 0, 0}, scratch_words = 0;
+				for (int c = 0; c < 3; ++c) {
+					if (lists[c].empty()) continue;
+					lds[c] = ngm::cs_heavy2_lds_bytes(A.lists_cap, A.q, classes[c].log2c, classes[c].log2s, coarse_cap);
+					int per_cu = 0;
+					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, classes[c].fn, classes[c].nt, lds[c]) != hipSuccess || per_cu < 1) per_cu = 1;
+					grid[c] = (int) std::min<size_t>(lists[c].size(), (size_t) per_cu * cus);
+					scratch_words += (size_t) grid[c] * classes[c].scratch_cap;
+				}
+				if (m->d_gt_keys.reserve(scratch_words)) { ngm::pipeline_set_error("out of device memory (candidate search scratch, %zu words)", scratch_words); return -12; }
+				hold();
+				// the queue restarts with the reads this round does not run again
+				const uint32_t n_keep = (uint32_t) keep_r.size();
+				MAP_HIP_TRY(hipMemcpyAsync(m->d_status.p + 1, &n_keep, 4, hipMemcpyHostToDevice, m->st));
+				if (n_keep) {
+					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read.p, keep_r.data(), (size_t) n_keep * 4, hipMemcpyHostToDevice, m->st));
+					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_hits.p, keep_h.data(), (size_t) n_keep * 4, hipMemcpyHostToDevice, m->st));
+				}
+				MAP_HIP_TRY(hipMemsetAsync(m->d_heavy_ctr.p, 0, 32, m->st));
+				MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
+				uint32_t off = 0;
+				size_t soff = 0;
+				for (int c = 2; c >= 0; --c) {   // (the largest reads first: their workgroups are the long ones)
+					const uint32_t cnt = (uint32_t) lists[c].size();
+					if (cnt == 0) continue;
+					MAP_HIP_TRY(hipMemcpyAsync(m->d_heavy_list.p + off, lists[c].data(), (size_t) cnt * 4, hipMemcpyHostToDevice, m->st));
+					ngm::CsArgs Hv = A;
+					Hv.read_list = m->d_heavy_list.p + off; Hv.log2_bits = classes[c].log2c; Hv.log2_slots = classes[c].log2s;
+					uint32_t n_list = cnt, scap = classes[c].scratch_cap, ccap = coarse_cap;
+					uint32_t *ctr = m->d_heavy_ctr.p + c, *scr = m->d_gt_keys.p + soff;
+					void *kargs[] = {(void *) &Hv, (void *) &n_list, (void *) &ctr, (void *) &scr, (void *) &scap, (void *) &ccap};
+					MAP_HIP_TRY(hipLaunchKernel(classes[c].fn, dim3(grid[c]), dim3(classes[c].nt), kargs, lds[c], m->st));
+					off += cnt;
+					soff += (size_t) grid[c] * classes[c].scratch_cap;
+				}
+				MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
+				yield();
+				MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
+				MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the lists live until here)
+				if (hipEventElapsedTime(&t_heavy[round], m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t_heavy[round];
+			}
+			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 1b (heavy reads): %.2f ms for %u reads; pass 1c (the largest class once more): %.2f ms for %u reads; %u left for the exact kernels\n",
+					t_heavy[0], in_round[0], t_heavy[1], in_round[1], status[1]);
+		} else
 		if (!bs && heavy_on && status[1] > 0) {
 			// pass 1b -- the reads with more hits than the fast path takes (cs_heavy_device.h): sketch counters + exact table in LDS, by
 			// hit count in three classes of workgroups; pass 1c -- what those cannot certify (more near-threshold bins than their table
@@ -819,6 +895,9 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy2_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy2_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
 	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 	if (p->bs_mapping) { A.bs = 1; A.lists_cap = 2 * ngm::kCsBsChunk; A.log2_slots = std::min(A.log2_slots, 13); }
@@ -849,7 +928,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	if (m->ev_cs_copied) (void) hipEventDestroy(m->ev_cs_copied);
 	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
 	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_read2.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
-	m->d_gt_votes.release(); m->d_heavy_list.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
+	m->d_gt_votes.release(); m->d_heavy_list.release(); m->d_heavy_ctr.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	m->d_pair_info.release(); m->p_pair_info.release(); m->d_sam_contig_start.release();
@@ -1370,6 +1449,39 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	float *h_best = m->p_best.p, *h_scores = m->p_scores.p;
 	if (np == 0) { if (int rc = cs_host_arrays(m)) return rc; for (int i = 0; i < n; ++i) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; h_nbest[i] = 0; h_best[i] = 0.f; } }
 	std::vector<int> pair_flags(n, 0);
+	auto reference_buffer_walk = [&]() {   // inside the batch's turn (sequential state)
+		// A pair the reference LOSES (round 5; the "early top1SE" earlier rounds described does not exist -- MappedRead::Calculated
+		// starts at -1, src/MappedRead.cpp:14, so ScoreBuffer.cpp:196 is false while the mate has not been searched).  CS::RunBatch
+		// hands a read to its ScoreBuffer right after the search (CS.cpp:436); when the last score of a pair's FIRST mate fills the
+		// buffer exactly (ScoreBuffer.cpp:519-523: DoRun), its scores are complete but the mate's Calculated is still -1: nothing is
+		// selected.  If the mate then turns out to have NO candidates it goes to the writer alone (CS.cpp:326-329) and no later
+		// DoRun ever looks at the first mate again: neither read is written ("(2 discarded)" in the reference's summary;
+		// profiles/r05_reference_lost_pair_experiment.txt).  Deterministic at -t 1 for a known buffer size (SeqAn personality:
+		// 1 024, src/seqan/EndToEndAffine.h:44-46); mirrored when the caller names that size (ngm_mapper_set_reference_score_buffer).
+		// Sequential like the running mean: part of the batch's turn.
+		uint64_t tot = m->scores_so_far, at = m->reads_so_far;
+		// (the next flush position is carried along: a 64-bit remainder per pair made this loop the longest part of the turn)
+		const uint64_t rb = m->ref_cs_batch > 0 ? (uint64_t) m->ref_cs_batch : 0;
+		const uint64_t sb = m->ref_score_buffer > 0 ? (uint64_t) m->ref_score_buffer : 0;
+		uint64_t next_flush = rb ? (at + rb - 1) / rb * rb : ~0ull;
+		uint64_t fill = sb ? tot % sb : 0;   // entries in the reference's score buffer
+		for (int pi = 0; pi < n / 2; ++pi, at += 2) {
+			while (at > next_flush) next_flush += rb;   // (an odd batch size: flush positions between two pairs never match `at`)
+			if (at == next_flush) { tot = 0; fill = 0; next_flush += rb; }  // the reference flushes its score buffer at the end of a CS batch (CS.cpp:488-500)
+			const uint32_t c1 = m->h_count[2 * pi], c2 = m->h_count[2 * pi + 1];
+			tot += (uint64_t) c1 + c2;
+			if (!sb) continue;
+			fill += c1;
+			const bool full_at_first_mate = c1 > 0 && fill % sb == 0;
+			fill = (fill + c2) % sb;
+			if (full_at_first_mate && c2 == 0) {
+				++m->lost_pairs;
+				pair_flags[2 * pi] = pair_flags[2 * pi + 1] = NGM_PAIR_LOST;
+				h_winner[2 * pi] = h_winner[2 * pi + 1] = 0xFFFFFFFFu;
+			}
+		}
+		m->scores_so_far = tot; m->reads_so_far = at;
+	};
 	if (np > 0) {
 		// ---- score stage: all candidates of the batch in one BatchScore -------------------------------------
 		if (m->d_pair_read.reserve(np) || m->d_scores.reserve(np) || m->d_winner.reserve(n) || m->d_mapq.reserve(n) || m->d_nbest.reserve(n) ||
@@ -1639,26 +1751,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			parallel_for((int) se_tied.size(), [&](int lo, int hi) { for (int x = lo; x < hi; ++x) { const uint32_t i = se_tied[x]; if (m->h_count[i ^ 1u] > 0) first_sorted(i); else first_best(i); } }, 64);
 			// ---- this batch's turn for the running mean ----------------------------------------------------------------------
 			pair_turn.acquire();
-			{
-				// Diagnostics only: the reference hands a read to its ScoreBuffer right after the search (CS.cpp:436); when
-				// the scores of a pair's first mate end exactly on a multiple of the 1 024-entry buffer (EndToEndAffine.h:44-46),
-				// DoRun runs top1SE on that mate alone before its partner has scores (ScoreBuffer.cpp:196-209).  That artefact is not
-				// mirrored; count where it would have struck, and where it could have changed something (several
-				// candidates for that mate).  Sequential like the running mean: part of the batch's turn.
-				uint64_t tot = m->scores_so_far, at = m->reads_so_far;
-				// (the next flush position is carried along: a 64-bit remainder per pair made this loop the longest part of the turn)
-				const uint64_t rb = m->ref_cs_batch > 0 ? (uint64_t) m->ref_cs_batch : 0;
-				uint64_t next_flush = rb ? (at + rb - 1) / rb * rb : ~0ull;
-				for (int pi = 0; pi < n / 2; ++pi, at += 2) {
-					while (at > next_flush) next_flush += rb;   // (an odd batch size: flush positions between two pairs never match `at`)
-					if (at == next_flush) { tot = 0; next_flush += rb; }  // the reference flushes its score buffer at the end of a CS batch (CS.cpp:488-500)
-					const uint32_t c1 = m->h_count[2 * pi], c2 = m->h_count[2 * pi + 1];
-					tot += c1;
-					if (c1 > 0 && c2 > 0 && (tot & 1023u) == 0) { ++m->early_se_pairs; if (c1 > 1) ++m->early_se_ambiguous; }
-					tot += c2;
-				}
-				m->scores_so_far = tot; m->reads_so_far = at;
-			}
+			reference_buffer_walk();
 			// Pass 2 (sequential, cheap): the running mean at every tied pair, as bounds -- a tied pair that stays open contributes one
 			// of the insert sizes of its best-scoring pairs.  Without pairs of equal score AND insert size the winner is the
 			// best-scoring pair closest to the mean: the same unique winner at both bounds is the winner for every mean in between,
@@ -1713,6 +1806,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					"ms: pass 1 %.2f | order replay %.2f | pass 3 %.2f | turn: pass 2 %.2f, late + pass 4 %.2f\n", tied.size(), picked.size(), se_tied.size(), n_open, late.size(), (long) n_host_walk, tq[0], tq[1], tq[2], tq[3], tq[4]);
 		}
 	}
+	if (paired && (np == 0 || m->fast_pairing)) { pair_turn.acquire(); reference_buffer_walk(); pair_turn.release(); }   // (--fast-pairing / a batch without candidates: no top1PE turn above)
 	if (paired && np > 0 && m->prm.strata)  // mates selected single-end (top1SE): several equally best candidates -> unmapped
 		parallel_for(n, [&](int lo, int hi) { for (int i = lo; i < hi; ++i) if (!(pair_flags[i] & NGM_PAIR_SELECTED) && h_nbest[i] > 1) { h_winner[i] = 0xFFFFFFFFu; h_mapq[i] = 0; } }, 16384);
 	const int topn = (!paired && m->prm.topn > 1) ? m->prm.topn : 1;
@@ -2138,9 +2232,15 @@ int ngm_mapper_set_reference_cs_batch(ngm_mapper *m, int reads) {
 	return 0;
 }
 
-int ngm_mapper_early_top1se_counts(ngm_mapper *m, uint64_t out[2]) {
+int ngm_mapper_set_reference_score_buffer(ngm_mapper *m, int entries) {
+	if (!m || entries < 0) return -22;
+	m->ref_score_buffer = entries;
+	return 0;
+}
+
+int ngm_mapper_lost_pairs(ngm_mapper *m, uint64_t *out) {
 	if (!m || !out) return -22;
-	out[0] = m->early_se_pairs; out[1] = m->early_se_ambiguous;
+	*out = m->lost_pairs;
 	return 0;
 }
 

@@ -1251,8 +1251,9 @@ int main(int argc, char **argv) {
 				continue;
 			}
 			if (v1.r->seq_len == 0 || v2.r->seq_len == 0) continue;  // GenericReadWriter.h:250-252
-			n_total += 2;
 			const ngm_hit &h1 = *v1.h, &h2 = *v2.h;
+			if ((h1.pair_flags | h2.pair_flags) & NGM_PAIR_LOST) continue;   // the reference never writes this pair (ngm_mapper_set_reference_score_buffer)
+			n_total += 2;
 			// AlignmentBuffer::WriteRead (AlignmentBuffer.cpp:175-199): is the pair consistent?
 			bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
 			if (h1.mapped && h2.mapped) {
@@ -1684,7 +1685,7 @@ int main(int argc, char **argv) {
 			out_cv.notify_all();
 		}
 	};
-	size_t n_total = 0, n_mapped = 0, n_written = 0;
+	size_t n_total = 0, n_mapped = 0, n_written = 0, n_read = 0;   // (n_read: records of the batches; n_total: reads the writer counted as mapped or unmapped)
 	std::thread writer([&] {
 		uint64_t next = 0;
 		for (;;) {
@@ -1721,7 +1722,7 @@ int main(int argc, char **argv) {
 				t_write_us += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wr).count();
 				{ std::lock_guard<std::mutex> lk(text_mu); text_free.push_back(TextBuf{b->text, b->text_cap}); }
 				text_cv.notify_one();
-				n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written;
+				n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written; n_read += (size_t) b->n;
 				++next;
 				continue;
 			}
@@ -1736,7 +1737,7 @@ int main(int argc, char **argv) {
 				std::lock_guard<std::mutex> lk(spare_mu);
 				spare_chunks.push_back(std::move(b->chunks));
 			}
-			n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written;
+			n_total += b->n_total; n_mapped += b->n_mapped; n_written += b->n_written; n_read += (size_t) b->n;
 			++next;
 		}
 	});
@@ -1759,7 +1760,12 @@ int main(int argc, char **argv) {
 	if (close(out_fd) != 0) fail("write error on " + o.out);
 	if (failed) die(fail_msg);
 	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-	snprintf(msg, sizeof(msg), "Done (%zu reads mapped (%.2f%%), %zu reads not mapped, %zu lines written)", n_mapped,
+	// src/NGM_main.cpp:150-160: reads that were read but never reached the writer's counters ("discarded": empty reads, and the pairs the
+	// reference loses -- ngm_mapper_set_reference_score_buffer) are listed when there are any
+	const size_t n_discarded = n_read > n_total ? n_read - n_total : 0;
+	if (n_discarded) snprintf(msg, sizeof(msg), "Done (%zu reads mapped (%.2f%%), %zu reads not mapped (%zu discarded), %zu lines written)", n_mapped,
+			100.0 * n_mapped / std::max<size_t>(1, n_total + n_discarded), n_total - n_mapped + n_discarded, n_discarded, n_written);
+	else snprintf(msg, sizeof(msg), "Done (%zu reads mapped (%.2f%%), %zu reads not mapped, %zu lines written)", n_mapped,
 			n_total ? 100.0 * n_mapped / n_total : 0.0, n_total - n_mapped, n_written);
 	info("MAIN", msg);
 	snprintf(msg, sizeof(msg), "Mapping pass: %.3f s, %.0f reads/s (%zu GPU(s) x %d worker(s), %d host threads, %s input)", secs, n_total / std::max(1e-9, secs),
@@ -1816,11 +1822,11 @@ int main(int argc, char **argv) {
 				(unsigned long long) pc[4], (unsigned long long) pc[5], (unsigned long long) pc[6]);
 		info("MAIN", msg);
 	}
-	if (o.paired) {
-		uint64_t hit = 0, amb = 0;
-		for (Worker &w : workers) { uint64_t c2[2] = {0, 0}; if (ngm_mapper_early_top1se_counts(w.m, c2) == 0) { hit += c2[0]; amb += c2[1]; } }
-		snprintf(msg, sizeof(msg), "Pairs whose first mate would have filled NextGenMap's score buffer exactly (early top1SE there, src/CS.cpp:436; not mirrored): %llu, %llu of them with several candidates for that mate",
-				(unsigned long long) hit, (unsigned long long) amb);
+	if (o.paired && o.ref_score_buffer > 0) {
+		uint64_t lost = 0;
+		for (Worker &w : workers) { uint64_t c2 = 0; if (ngm_mapper_lost_pairs(w.m, &c2) == 0) lost += c2; }
+		snprintf(msg, sizeof(msg), "Pairs lost as NextGenMap loses them (first mate's last score fills the %d-entry score buffer, second mate without candidates; src/ScoreBuffer.cpp:196, :519-523): %llu",
+				o.ref_score_buffer, (unsigned long long) lost);
 		info("MAIN", msg);
 	}
 	if (const char *pf = getenv("NGM_HIP_PROFILE")) prof::dump(pf);

@@ -370,8 +370,9 @@ __device__ __forceinline__ void sam_unit(const SamArgs &A, int unit, Sink &s, ui
 	// read1 = the first mate (even ReadId), written second by AlignmentBuffer::WriteRead; read2 = its mate
 	const SamView v1 = sam_view(A, 2 * unit), v2 = sam_view(A, 2 * unit + 1);
 	if ((v1.m.qual_len & 0x8000u) || (v2.m.qual_len & 0x8000u)) return;  // GenericReadWriter.h:250-252
-	cnt[0] += 2;
 	const ngm_hit &h1 = *v1.h, &h2 = *v2.h;
+	if ((h1.pair_flags | h2.pair_flags) & NGM_PAIR_LOST) return;   // the reference never writes this pair (ngm_mapper_set_reference_score_buffer)
+	cnt[0] += 2;
 	// AlignmentBuffer::WriteRead (AlignmentBuffer.cpp:175-199): is the pair consistent?
 	bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
 	if (h1.mapped && h2.mapped) {
