@@ -46,6 +46,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 Q, C, READ_LEN, KMER = 152, 27, 150, 13
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# roofline.traffic: the committed PMC pass of this round's default workload, and the kernel instance that workload launches (mapper.cpp cs_canon_fn)
+PMC_TRAFFIC_FILE = "r05_mapping_pe_affine_pmc_traffic.json"
+CS_DEFAULT_KERNEL = "ngm::cs_canon_kernel<3, 6, 2, 1, 7, true>"
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 COMP = np.zeros(256, np.uint8)
 COMP[list(b"ACGTN")] = list(b"TGCAN")
@@ -362,9 +365,10 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
             t_t1 = run_ref(t1_files, t1_sam, 1)
             th1 = _sam_body(t1_sam)
             same1, diffs1 = _sam_diff(th1, ours)
-            # ngm-hip on the same slice: how many of its pairs sit where the reference's score buffer would have filled exactly
+            # ngm-hip on the same slice: the pairs it loses because the reference loses them (first mate fills the score buffer exactly, second mate
+            # without candidates: DESIGN.md 2)
             try:
-                early = [l for l in run_hip(t1_files, os.path.join(workdir, "ours_t1.sam"))["log"].splitlines() if "not mirrored" in l][-1:]
+                early = [l for l in run_hip(t1_files, os.path.join(workdir, "ours_t1.sam"))["log"].splitlines() if "Pairs lost as NextGenMap" in l][-1:]
                 os.remove(os.path.join(workdir, "ours_t1.sam"))
             except Exception as e:
                 early = [str(e)[:200]]
@@ -377,13 +381,14 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
             t1_vs_tn = {"records_in_both_runs": len(both), "lines_the_reference_writes_differently_at_t1_and_tN": len(ref_moves),
                         "ngm_hip_lines_that_differ_from_tN_here": len(ours_off_here),
                         "of_these_identical_to_the_reference_at_t1": len([k_ for k_ in ours_off_here if ours.get(k_) == th1[k_]])}
-        base = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "kind": "reference",
+        base = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "cpu_quota": cores, "kind": "reference",
                 "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d (the CPUs this container may use: %d hardware threads, cgroup quota %d) on the first %d reads of the "
                           "end-to-end input vs the same genome (index loaded from the same cache files): %.1f s total minus %.1f s index load/start-up measured "
                           "with a 1-pair run" % (threads, os.cpu_count() or 1, cores, ns, t_all, t_load),
                 "parity_vs_reference_sam": {"records_compared": ns, "identical_lines": same, "first_differences": diffs,
-                                            "note": "whole SAM lines, differing fields listed; the reference runs %d CS threads, each with its own running mean insert "
-                                                    "size (ScoreBuffer.h:90) -- equal-score pair ties may differ from its own -t 1 output" % threads,
+                                            "note": "whole SAM lines, differing fields listed; the reference ran %d CS threads (ngm-hip reproduces its -t 1 output: "
+                                                    "parity_vs_reference_sam_t1).  reference_vs_itself says which lines the reference's own two -t %d runs moved and how many of "
+                                                    "the lines where ngm-hip differs are among them or equal run 2; the others are unexplained by this run" % (threads, threads),
                                             "reference_vs_itself": self_check, "reference_t1_vs_tN": t1_vs_tn},
                 "parity_vs_reference_sam_t1": {"records_compared": len(th1), "identical_lines": same1, "first_differences": diffs1, "seconds": t_t1, "ngm_hip_on_the_same_slice": early,
                                                "note": "ngm-core --affine -t 1 on the first %d reads: the run ngm-hip reproduces" % n1}}
@@ -443,14 +448,20 @@ def sharded_end_to_end(workdir, contigs, args, paired, affine, sens, world, exe)
     return out
 
 
-def heavy_tail_leg(args, dev, local_rank, paired, affine, sens):
-    """The same resident mapping path on a genome with a GRCh38-LIKE k-mer spectrum (tests/humanlike.py: one SINE-like family at ~10^5
-    copies per 300 Mbp, LINE-like families, satellite arrays, microsatellites, segmental duplications, isochores), half of the reads
-    drawn FROM the repeats: reads/s, candidates per read and the share of the reads on every fall-back path.  Not the headline: the
-    uniform genome above is the best case (1.2 candidates per read), this is what repeats cost."""
+def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
+    """The second headline: the same resident mapping path on a genome with a GRCh38-LIKE k-mer spectrum (tests/humanlike.py: one
+    SINE-like family at ~10^5 copies per 300 Mbp, LINE-like families, satellite arrays, microsatellites, segmental duplications,
+    isochores) of GRCh38's size.  Two sub-legs, each over --read-sets distinct read sets that the steps rotate through, each with its
+    own `roofline` (dominant kernel of THAT workload, SURVEY.md 8(d) bytes, HIP events) and `cpu_baseline` (ngm-core --affine on a
+    slice of the same reads against the same genome, its SAM compared with ngm-hip's on that slice):
+      reads_drawn_uniformly            fragments start anywhere (what sequencing a genome gives): the realistic one
+      half_of_the_reads_from_repeats   half of the fragments start inside a repeat instance (kinds equally likely): the stress"""
+    import re
     import threading
     import torch
     import humanlike as HL
+    import ref_files as RF
+    from nextgenmap_amd import build as B
     from nextgenmap_amd.pipeline import HIT_DTYPE, Mapper, Reference
     t0 = time.perf_counter()
     G = HL.make_genome(total_bp=int(args.heavy_tail_mbp * 1e6), n_contigs=24, seed=20260929)
@@ -459,65 +470,174 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens):
     ref = Reference.from_contigs(G.contigs, device=local_rank, kmer=KMER, kmer_skip=2, bin_size=2)
     t_index = time.perf_counter() - t0
     R = args.reads_per_step
-    starts = HL.sample_starts(G, R // 2 if paired else R, 400 if paired else READ_LEN, seed=20260930, repeat_share=args.heavy_tail_repeat_share)
-    rows, truth_c, truth_p = make_reads(G.contigs, R, seed=20260931, paired=paired, subs=args.subs, indel_bases=args.indel_bases, starts=starts)
-    d_rows = torch.from_numpy(rows).to(dev)
-    # (this workload's host stages -- order replay, pair selection of pairs with hundreds of candidates -- outweigh its kernels: four mapper
-    # instances per GPU instead of two keep the GPU fed; measured on one box with 2 / 3 / 4 instances: 1.13 / 1.41 / 1.47 M reads/s, while
-    # the uniform genome's step goes 51.6 / 49.7 / 47.8 M the other way)
+    S = max(1, min(args.read_sets, args.heavy_tail_steps))
+    band = C + 1 if affine else C
+    # (this workload's host stages -- order replay, the sequential part of the pair selection -- outweigh the uniform genome's: four mapper
+    # instances per GPU instead of two keep the GPU fed; round 4, one box, 2 / 3 / 4 instances: 1.13 / 1.41 / 1.47 M reads/s)
     W = max(1, min(max(args.workers, args.heavy_tail_workers), R // 2048))
     bounds = [(R * w // W) & ~1 for w in range(W)] + [R]
-    out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
     kw = dict(gap_read=33, gap_ref=33, gap_extend=3, personality=1) if affine else {}
     mps = [Mapper(ref, Q, C, sensitivity=sens, **kw) for _ in range(W)]
-    kms = [np.zeros(8) for _ in range(W)]
+    with_cpu = (not args.no_cpu_baseline) and affine and RF.have_reference_binary() and args.heavy_tail_cpu_reads > 0
+    cores = usable_cpus()
+    threads = min(os.cpu_count() or 1, 64)
+    fa = os.path.join(workdir, "heavy_ref.fa")
+    t_cache = t_load = 0.0
+    common = ["-s", "%.6f" % sens, "--no-progress", "--max-read-length", str(READ_LEN)] + (["--affine"] if affine else [])
 
-    def worker(w, steps):
-        lo, hi = bounds[w], bounds[w + 1]
-        for _ in range(steps):
-            (mps[w].map_pe_raw if paired else mps[w].map_se_raw)(rows[lo:hi], d_rows[lo:hi], tuple(o[lo:hi] for o in out))
-            kms[w] += np.array(mps[w].last_kernel_ms())
+    def inputs(fs):
+        return ["-1", fs[0], "-2", fs[1]] if paired else ["-q", fs[0]]
 
-    def run(steps):
-        ts = [threading.Thread(target=worker, args=(w, steps)) for w in range(W)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+    def run_ref(fs, outp, t):
+        c = [RF.NGM_CORE, "-r", fa] + inputs(fs) + ["-o", outp, "-t", str(t)] + common
+        t0_ = time.perf_counter()
+        rr = subprocess.run(c, capture_output=True, text=True, cwd=workdir)
+        dt = time.perf_counter() - t0_
+        if "Done" not in (rr.stdout + rr.stderr):
+            raise RuntimeError("reference run failed: " + (rr.stdout + rr.stderr)[-400:])
+        return dt
 
-    run(1)
-    for k in kms:
-        k[:] = 0
-    before = [m_.path_counters() for m_ in mps]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.heavy_tail_steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    pc = {k: sum(m_.path_counters()[k] - b[k] for m_, b in zip(mps, before)) for k in before[0]}
-    ctr = np.sum([m_.cs_counters() for m_ in mps], axis=0)
-    km = np.sum(kms, axis=0) / args.heavy_tail_steps
-    hits = out[0]
-    mapped = hits["mapped"] == 1
-    correct = mapped & (hits["contig"] == truth_c) & (np.abs(hits["pos"].astype(np.int64) - truth_p) <= C // 2 + 4)
-    nr = max(1, pc["reads"])
-    res = {"value": R * args.heavy_tail_steps / elapsed, "unit": "reads/s", "steps": args.heavy_tail_steps, "ms_per_step": elapsed / args.heavy_tail_steps * 1e3,
-           "mapper_instances_per_gpu": W,
-           "genome": "tests/humanlike.py make_genome(%d Mbp, 24 contigs, seed 20260929): %d repeat instances; automatic max. k-mer frequency %d (uniform genome: 100)"
+    def slice_files(rows, n, tag):
+        fs = [os.path.join(workdir, "%s_1.fq" % tag), os.path.join(workdir, "%s_2.fq" % tag)] if paired else [os.path.join(workdir, "%s.fq" % tag)]
+        write_fastq(rows[:n], fs)
+        return fs
+    cpu_err = None
+    if with_cpu:
+        try:
+            t0 = time.perf_counter()
+            with open(fa, "w") as f:
+                f.write(">stub\nACGT\n")  # with the caches present both programs only check that the file exists
+            ref.write_ngm_cache(fa)
+            t_cache = time.perf_counter() - t0
+        except Exception as e:
+            with_cpu, cpu_err = False, str(e)[:300]
+
+    def sub_leg(tag, share, seed0):
+        nonlocal t_load
+        t0 = time.perf_counter()
+        sets = []
+        for s_ in range(S):
+            starts = HL.sample_starts(G, R // 2 if paired else R, 400 if paired else READ_LEN, seed=seed0 + 17 * s_, repeat_share=share)
+            sets.append(make_reads(G.contigs, R, seed=seed0 + 1 + 17 * s_, paired=paired, subs=args.subs, indel_bases=args.indel_bases, starts=starts))
+        d_sets = [torch.from_numpy(t_[0]).to(dev) for t_ in sets]
+        t_reads = time.perf_counter() - t0
+        out = (np.zeros(R, HIT_DTYPE), np.zeros((R, 4 * Q), np.uint8), np.zeros((R, 4 * Q), np.uint8))
+        kms = [np.zeros(9) for _ in range(W)]
+
+        def worker(w, steps, first):
+            lo, hi = bounds[w], bounds[w + 1]
+            for i_ in range(steps):
+                s_ = (first + i_) % S
+                (mps[w].map_pe_raw if paired else mps[w].map_se_raw)(sets[s_][0][lo:hi], d_sets[s_][lo:hi], tuple(o[lo:hi] for o in out))
+                kms[w][:8] += np.array(mps[w].last_kernel_ms())
+                kms[w][8] += mps[w].last_order_replay_ms()
+
+        def run(steps, first=0):
+            ts = [threading.Thread(target=worker, args=(w, steps, first)) for w in range(W)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        run(S)   # set-up: every read set once (buffers grow to their largest batch, the running mean insert size settles)
+        for k in kms:
+            k[:] = 0
+        before = [m_.path_counters() for m_ in mps]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.heavy_tail_steps)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        steps = args.heavy_tail_steps
+        pc = {k: sum(m_.path_counters()[k] - b[k] for m_, b in zip(mps, before)) for k in before[0]}
+        ctr = np.sum([m_.cs_counters() for m_ in mps], axis=0)   # of the last step
+        km = np.sum(kms, axis=0) / steps
+        rows_last, truth_c, truth_p = sets[(steps - 1) % S]
+        hits = out[0]
+        mapped = hits["mapped"] == 1
+        correct = mapped & (hits["contig"] == truth_c) & (np.abs(hits["pos"].astype(np.int64) - truth_p) <= C // 2 + 4)
+        kmers, hits_voted, n_cand, n_aln = int(ctr[0]), int(ctr[1]), int(ctr[2]), int(mapped.sum())
+        b_cs = 20 * kmers + 4 * hits_voted + 16 * n_cand
+        kernels = {"candidate_search": (km[0], b_cs, "cs_fast_kernel / cs_heavy2_kernel / cs_global_kernel (candidate search): 20 B/k-mer + 4 B/index hit + 16 B/candidate"),
+                   "sw_score": (km[2], n_cand * (Q + Q + C + 4), "sw_*score*_kernel (BatchScore): B_score = q + (q + c) + 4 bytes per pair"),
+                   "sw_align": (km[5] + km[6], n_aln * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)), "sw_*align*_kernel + traceback (BatchAlign): B_align = q + (q + c) + 8 + 4 (2q + c + 1) bytes per pair")}
+        dom = max(kernels, key=lambda k_: kernels[k_][0])
+        dom_ms, dom_bytes, dom_note = kernels[dom]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        nr = max(1, pc["reads"])
+        ms_step = elapsed / steps * 1e3
+        all_k = float(km[:7].sum())
+        res = {"value": R * steps / elapsed, "unit": "reads/s", "steps": steps, "ms_per_step": ms_step, "read_sets": S,
+               "reads": "%d x %d bp %s per step, %.0f %% of the fragments start inside a repeat instance (kinds equally likely), %.1f %% substitutions; the steps rotate through %d distinct read sets"
+                        % (R, READ_LEN, "PE" if paired else "SE", 100 * share, 100 * args.subs, S),
+               "per_read": {"candidates": n_cand / R, "index_hits": hits_voted / R, "kmers": kmers / R},
+               "share_of_reads": {"heavy_read_kernel": pc["heavy"] / nr, "exact_search_lds_table": pc["exact_lds"] / nr, "exact_search_global_table": pc["exact_global"] / nr,
+                                  "candidate_order_replayed": pc["order_replayed"] / nr, "candidate_order_exact_global_replay": pc["order_exact_global"] / nr,
+                                  "candidate_order_undetermined": pc["order_undetermined"] / nr},
+               "kernel_ms": {"candidate_search": km[0], "gather_score": km[1], "sw_score": km[2], "select": km[3], "gather_align": km[4], "sw_align": km[5], "traceback": km[6],
+                             "all_kernels": all_k, "candidate_order_replay_on_its_own_stream": km[8], "candidate_search_stage_incl_host_sync": km[7]},
+               "gpu_kernels_fraction_of_step": {"stage_kernels": all_k / ms_step, "with_order_replay": (all_k + km[8]) / ms_step},
+               "sw_gcells_per_s": {"score_kernel": n_cand * READ_LEN * band / (km[2] * 1e-3) / 1e9 if km[2] > 0 else None,
+                                   "align_kernel": n_aln * READ_LEN * band / (km[5] * 1e-3) / 1e9 if km[5] > 0 else None},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": dom, "kernel_note": dom_note, "kernel_ms_per_step": float(dom_ms), "bytes_per_step": int(dom_bytes),
+                            "note": "the kernel group with the largest GPU time per step of THIS workload; achieved = its algorithmic bytes (SURVEY.md 8d) / its HIP-event "
+                                    "time on the launch streams (summed over the mapper instances); traffic: no PMC pass of this leg is consulted in the run "
+                                    "(profiles/r05_heavy_tail_pmc_hbm.csv holds the committed one)"},
+               "accuracy": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
+               "setup_s": {"read_sets": t_reads}}
+        if with_cpu:
+            try:
+                if t_load == 0.0:
+                    t_load = run_ref(slice_files(sets[0][0], 2, "h_one"), os.path.join(workdir, "h_one.sam"), threads)
+                pilot = min(4000, R) & ~1
+                t_pilot = max(run_ref(slice_files(sets[0][0], pilot, "h_pilot"), os.path.join(workdir, "h_pilot.sam"), threads) - t_load, 1e-3)
+                ns = int(min(args.heavy_tail_cpu_reads, R, max(pilot, 12.0 * pilot / t_pilot))) & ~1
+                fs = slice_files(sets[0][0], ns, "h_" + tag[:4])
+                ref_sam, hip_sam = os.path.join(workdir, "h_ref.sam"), os.path.join(workdir, "h_hip.sam")
+                t_all = run_ref(fs, ref_sam, threads)
+                t_map = max(t_all - t_load, 1e-3)
+                cmd = [B.CLI, "-r", fa] + inputs(fs) + ["-o", hip_sam] + common
+                t1 = time.perf_counter()
+                rr = subprocess.run(cmd, capture_output=True, text=True)
+                t_hip = time.perf_counter() - t1
+                if rr.returncode != 0:
+                    raise RuntimeError("ngm-hip failed: " + (rr.stdout + rr.stderr)[-400:])
+                mio = re.search(r"Input to output: ([0-9.]+) s", rr.stdout + rr.stderr)
+                same, diffs = _sam_diff(_sam_body(ref_sam), _sam_body(hip_sam))
+                res["cpu_baseline"] = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "cpu_quota": cores, "kind": "reference",
+                                       "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d (%d hardware threads visible, cgroup quota %d CPUs) on the first %d reads of this sub-leg's "
+                                                 "read set 0 vs the same genome (index from the cache files this library wrote): %.1f s total minus %.1f s index load / start-up "
+                                                 "measured with a 1-pair run" % (threads, os.cpu_count() or 1, cores, ns, t_all, t_load),
+                                       "parity_vs_reference_sam": {"records_compared": ns, "identical_lines": same, "first_differences": diffs,
+                                                                   "note": "whole SAM lines; the reference runs %d CS threads, each with its own running mean insert size "
+                                                                           "(ScoreBuffer.h:90): equal-score pair ties may differ from its -t 1 output, which is what ngm-hip reproduces "
+                                                                           "(tests/test_gpu_humanlike.py; profiles/r05_humanlike_t1_2M_reads.log)" % threads},
+                                       "ngm_hip_on_the_same_slice": {"seconds_first_input_byte_to_sam_closed": float(mio.group(1)) if mio else None, "process_wall_s": t_hip}}
+                for fn in fs + [ref_sam, hip_sam]:
+                    try:
+                        os.remove(fn)
+                    except OSError:
+                        pass
+            except Exception as e:
+                res["cpu_baseline"] = {"error": str(e)[:400]}
+        elif cpu_err:
+            res["cpu_baseline"] = {"error": cpu_err}
+        del d_sets
+        return res
+
+    out = {"genome": "tests/humanlike.py make_genome(%d Mbp, 24 contigs, seed 20260929): %d repeat instances; automatic max. k-mer frequency %d (uniform genome: 100)"
                      % (args.heavy_tail_mbp, len(G.repeats), ref.auto_max_kfreq),
-           "reads": "%d x %d bp %s per step, %.0f %% of the fragments start inside a repeat instance (kinds equally likely)" % (R, READ_LEN, "PE" if paired else "SE", 100 * args.heavy_tail_repeat_share),
-           "per_read": {"candidates": float(ctr[2]) / R, "index_hits": float(ctr[1]) / R, "kmers": float(ctr[0]) / R},
-           "share_of_reads": {"heavy_read_kernel": pc["heavy"] / nr, "exact_search_lds_table": pc["exact_lds"] / nr, "exact_search_global_table": pc["exact_global"] / nr,
-                              "candidate_order_replayed": pc["order_replayed"] / nr, "candidate_order_exact_global_replay": pc["order_exact_global"] / nr,
-                              "candidate_order_undetermined": pc["order_undetermined"] / nr},
-           "kernel_ms": {"candidate_search": km[0], "gather_score": km[1], "sw_score": km[2], "select": km[3], "gather_align": km[4], "sw_align": km[5], "traceback": km[6],
-                         "all_kernels": float(km[:7].sum()), "candidate_search_stage_incl_host_sync": km[7]},
-           "accuracy": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
-           "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries}}
+           "mapper_instances_per_gpu": W,
+           "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries, "cache_files_for_the_reference_program": t_cache}}
+    out["reads_drawn_uniformly"] = sub_leg("reads_drawn_uniformly", 0.0, 20260930)
+    out["half_of_the_reads_from_repeats"] = sub_leg("half_of_the_reads_from_repeats", args.heavy_tail_repeat_share, 20261930)
+    out["value"] = out["reads_drawn_uniformly"]["value"]
+    out["unit"] = "reads/s"
+    out["note"] = "value = the sub-leg with the reads drawn uniformly; both sub-legs carry their own roofline and cpu_baseline"
     for m_ in mps:
         m_.close()
     ref.close()
-    return res
+    return out
 
 
 def cpu_baseline_port(rows_qry, budget_s=8.0):
@@ -535,7 +655,7 @@ def cpu_baseline_port(rows_qry, budget_s=8.0):
     t = time.perf_counter()
     O.oracle_score(0, wins[idx], rows_qry[idx], C, nthreads=cores)
     ts = time.perf_counter() - t
-    return {"value": len(idx) / ts, "unit": "scored pairs/s", "cores": cores, "kind": "port",
+    return {"value": len(idx) / ts, "unit": "scored pairs/s", "cores": cores, "cpu_quota": cores, "kind": "port",
             "sample": "%d pairs, oracle C restatement of BatchScore only, OpenMP %d threads (no candidate search)" % (len(idx), cores)}
 
 
@@ -565,8 +685,9 @@ def main():
     ap.add_argument("--cpu-t1-reads", type=int, default=200_000, help="reads of the reference's -t 1 run (SAM cross-check)")
     ap.add_argument("--stub-mapper", action="store_true", help="CPU-only control-path run (tests)")
     ap.add_argument("--ngm-hip-exe", default=None, help="the program of the sharded end-to-end leg (default: nextgenmap_amd/ngm-hip; tests pass a stand-in)")
-    ap.add_argument("--heavy-tail-mbp", type=float, default=1000.0, help="size of the GRCh38-like (heavy-tailed k-mer spectrum) genome of the second leg; 0: skip")
-    ap.add_argument("--heavy-tail-steps", type=int, default=5)
+    ap.add_argument("--heavy-tail-mbp", type=float, default=3100.0, help="size of the GRCh38-like (heavy-tailed k-mer spectrum) genome of the second leg; 0: skip")
+    ap.add_argument("--heavy-tail-steps", type=int, default=8)
+    ap.add_argument("--heavy-tail-cpu-reads", type=int, default=400_000, help="most reads of a heavy-tail sub-leg's cpu_baseline sample (what the reference maps in ~12 s, at most this; 0: none)")
     ap.add_argument("--heavy-tail-repeat-share", type=float, default=0.5)
     args = ap.parse_args()
     global Q, C, READ_LEN
@@ -773,19 +894,18 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch of the candidate search: NOT measured in this run -- taken from the committed PMC passes
         # (profiles/*_pmc_traffic.json, keyed by kernel name and grid size; collected with this default workload)
+        # (only the pass of THIS round's kernel counts: the file of the round, the exact template instance the default workload launches --
+        # anything else and the field is null rather than another kernel's figure)
         traffic = traffic_source = None
-        if dom == "candidate_search" and int(args.genome_mbp) == 3100 and READ_LEN == 150 and not stub:
-            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-                if fn.endswith("_pmc_traffic.json"):
-                    try:
-                        tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                    except Exception:
-                        continue
-                    for k, v in tj.items():
-                        if k.startswith("ngm::cs_canon_kernel"):
-                            traffic, traffic_source = v, "profiles/" + fn + " [" + k + "]"
-                    if traffic is not None:
-                        break
+        if dom == "candidate_search" and int(args.genome_mbp) == 3100 and READ_LEN == 150 and not stub and paired and affine:
+            fn = PMC_TRAFFIC_FILE
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            except Exception:
+                tj = {}
+            for k, v in tj.items():
+                if k.startswith(CS_DEFAULT_KERNEL + "|"):
+                    traffic, traffic_source = v, "profiles/" + fn + " [" + k + "]"
         line = {
             "metric": "mapped reads/sec + SW Gcells/sec, 150bp vs GRCh38, at 1/2/4/8 MI355X",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -864,7 +984,7 @@ def main():
         if world == 1 and not stub and args.heavy_tail_mbp > 0 and READ_LEN == 150:
             del contigs, rows, sets, d_sets, views
             try:
-                line["heavy_tailed_genome"] = heavy_tail_leg(args, dev, local_rank, paired, affine, sens)
+                line["heavy_tailed_genome"] = heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir)
             except Exception as e:
                 line["heavy_tailed_genome"] = {"error": str(e)[:400]}
         print(json.dumps(line))

@@ -267,10 +267,31 @@ int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]);
  * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */
 int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]);
 
+/* ---- the one collective of the path: mapping statistics summed over the shard processes --------------------------
+ * Reads shard across GPUs with nothing shared on the data path (`ngm-hip -g a,b,... --shard-output`: one process per GPU, the genome and
+ * the index replicated); what the reference keeps in process-wide counters that all its CS threads add to (src/NGM.cpp:172-200
+ * AddMappedRead / AddUnmappedRead / AddWrittenRead / AddReadRead; the pair counters of src/AlignmentBuffer.cpp:175-199) is, across
+ * processes, the vector {reads, mapped, unmapped, written, pairs_total, pairs_broken, insert_sum, insert_cnt} summed with ONE
+ * ncclAllReduce (RCCL over xGMI; librccl is loaded at run time).  ngm_stats_unique_id: a new communicator id as 256 hex digits + NUL
+ * (the parent makes it and hands it to the shard processes); ngm_stats_comm_create: rank `rank` of `world` on `device` joins (about a
+ * second: call it beside the load of the index); ngm_stats_allreduce: v becomes the sum over all ranks.  All return < 0 / NULL with
+ * ngm_pipeline_last_error() set when librccl is missing or a call fails -- the parent's sum over the shards' pipes stands then. */
+typedef struct ngm_stats_comm ngm_stats_comm;
+int ngm_stats_unique_id(char hex[257]);
+ngm_stats_comm *ngm_stats_comm_create(int device, int rank, int world, const char *hex);
+int ngm_stats_allreduce(ngm_stats_comm *c, int64_t v[8]);
+void ngm_stats_comm_destroy(ngm_stats_comm *c);
+/* pairs with both mates mapped, those of them the writer flags as broken (other contig / insert size outside the window / same strand),
+ * and the sum of the others' insert sizes, of the last ngm_mapper_map_sam call (src/AlignmentBuffer.cpp:175-199 pairInsertCount,
+ * brokenPairs, pairInsertSum) */
+int ngm_mapper_last_pair_stats(ngm_mapper *m, uint64_t out[3]);
+
 /* kernel wall-clock of the last ngm_mapper_* call, HIP events on the launch stream, ms:
  * [0] candidate search kernels  [1] gather+pack  [2] score  [3] select  [4] gather+pack (align)  [5] align DP
  * [6] traceback  [7] candidate-search stage including host round trips between its passes */
 int ngm_mapper_last_kernel_ms(ngm_mapper *m, float ms[8]);
+/* ... and of the candidate-order replays of that call (cs_order_kernel: runs on a stream of its own beside the stages above) */
+float ngm_mapper_last_order_replay_ms(ngm_mapper *m);
 
 #ifdef __cplusplus
 }

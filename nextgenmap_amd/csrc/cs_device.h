@@ -1181,9 +1181,10 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 // out: cand_rank[c] = 2 * (rList position among the tracked bins) + strand for every candidate c of the read, i.e. its
 // relative order in CollectResultsStd's output (forward before reverse of one bin, src/CS.cpp:289-304).
 constexpr int kCsOrderLog2Slots = 10;       // tracked bins (>= 2 votes, plus bit collisions): 1024 slots
-constexpr uint32_t kCsOrderMaxHits = 7168;  // least time line entries in LDS (CsArgs::order_max_hits); reads with more hits use a slice of global memory
+constexpr uint32_t kCsOrderMaxHits = 4096;  // least time line entries in LDS (CsArgs::order_max_hits); reads with more hits use a slice of global memory
 constexpr uint32_t kCsOrderUnknown = 0xFFFFFFFFu;
 constexpr int kCsOrderThreads = 256;
+__host__ __device__ inline uint32_t cs_order_tau(int lists_cap) { return (uint32_t) lists_cap / 2u + 64u; }   // most votes of one (bin, strand) the replay follows: a list per k-mer and strand (+ the odd second hit of one list in a bin)
 
 // GLOBAL (the exact fall-back for the reads the LDS replay leaves: more hits than its time line, more repeated bins than its
 // 1 024-slot table -- common on a genome with a heavy-tailed k-mer spectrum): the same replay with the time line AND the table of
@@ -1217,10 +1218,13 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	uint32_t *t_cand = t_rank + n_slots;    // 1: the bin is one of the read's candidates (tracked even with a single vote)
 	uint32_t *ev_at = GLOBAL ? t_cand + n_slots : t_cand + n_slots;     // [order_max_hits]: slot | strand << 31 of the hit at that time, or empty (LDS; reads with more hits: global memory)
 	for (uint32_t s = tid; s < plane_words; s += NT) plane[s] = 0;
-	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_run[s] = 0; t_rank[s] = kCsOrderUnknown; t_cand[s] = 0; }
+	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; t_cand[s] = 0; }   // (t_run / t_rank: written for every slot in use before they are read, below)
 	if (tid == 0) s_keys = 0;
-	uint32_t *seg_pref = GLOBAL ? plane + plane_words : ev_at + A.order_max_hits;
+	uint32_t *tm = ev_at + A.order_max_hits;   // [order_max_hits]: hit times by (slot, strand) (LDS; GLOBAL / big reads: behind the time line in global memory, below)
+	uint32_t *seg_pref = GLOBAL ? plane + plane_words : tm + A.order_max_hits;
 	uint32_t *l_time = seg_pref + A.lists_cap + 1 + (A.bs ? (size_t) A.q + 1 + A.lists_cap / 4 + 1 : 0);   // GLOBAL: [lists_cap] time of every list's first hit
+	uint32_t *tau = l_time + (GLOBAL ? A.lists_cap : 0);   // [cs_order_tau(lists_cap)]
+	const uint32_t n_tau = cs_order_tau(A.lists_cap);
 	const bool diag = A.phase_cycles && (blockIdx.x & 63) == 0;
 	unsigned long long ck[6] = {0, 0, 0, 0, 0, 0};
 	if (diag) ck[0] = wall_clock64();  // [lists_cap + 1]: work items (8-hit list segments) in front of each list
@@ -1251,8 +1255,11 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	const bool big = !GLOBAL && H > A.order_max_hits;
 	if (big) {
 		if (!A.order_scratch || H > A.order_gcap || H >= 65536u) { give_up(2u, H, 0u); return; }
-		ev_at = A.order_scratch + (size_t) blockIdx.x * A.order_gcap;
+		ev_at = A.order_scratch + (size_t) blockIdx.x * 2u * A.order_gcap;
+		tm = ev_at + A.order_gcap;
 	}
+	if (GLOBAL) tm = ev_at + ((H + 63u) & ~63u);   // (the slice holds the table, the time line, the sorted times and the list of the slots in use: 6 * slots + 2 * (hits + 64) words)
+	uint32_t *t_list = GLOBAL ? tm + ((H + 63u) & ~63u) : nullptr;   // GLOBAL: the slots in use, in no particular order (the table is a few per cent full: the passes below walk this list, not the table)
 	__syncthreads();
 	if (GLOBAL && wv == 1) {
 		uint32_t carry = 0;
@@ -1285,7 +1292,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 			for (uint32_t probes = 0; probes < n_slots; ++probes) {
 				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
 				if (prev == bin) { t_cand[slot] = 1u; break; }
-				if (prev == 0xFFFFFFFFu) { atomicAdd(&s_keys, 1u); t_cand[slot] = 1u; break; }
+				if (prev == 0xFFFFFFFFu) { const uint32_t at = atomicAdd(&s_keys, 1u); if (GLOBAL) t_list[at] = slot; t_cand[slot] = 1u; break; }
 				slot = (slot + 1) & (n_slots - 1);
 			}
 		}
@@ -1312,7 +1319,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 			for (uint32_t probes = 0; probes < n_slots; ++probes) {
 				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
 				if (prev == bin) break;
-				if (prev == 0xFFFFFFFFu) { atomicAdd(&s_keys, 1u); break; }
+				if (prev == 0xFFFFFFFFu) { const uint32_t at = atomicAdd(&s_keys, 1u); if (GLOBAL) t_list[at] = slot; break; }
 				slot = (slot + 1) & (n_slots - 1);
 			}
 		}
@@ -1379,65 +1386,124 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	}
 	__syncthreads();
 	if (diag) ck[3] = wall_clock64();
-	// replay in time order.  A bin with one vote never moves the maximum beyond 1 and is never a candidate unless the final
-	// threshold is <= 1 (those are tracked as t_cand): the very first hit of the read already sets the maximum to 1
-	// (CS.cpp:197-202), so only the hits of those bins take part; they are packed to the front of the time line first.
-	const unsigned long long lanes_below = (1ull << lane) - 1ull;
-	uint32_t E = 0;
-	if (wv == 0) {
-	for (uint32_t t0 = 0; t0 < H; t0 += 64) {
-		const uint32_t t = t0 + (uint32_t) lane;
-		uint32_t e = (t < H) ? ev_at[t] : 0xFFFFFFFFu;
-		if (e != 0xFFFFFFFFu) {
-			const uint32_t v = og(&t_votes[e & 0x7FFFFFFFu]);
-			if ((v & 0xFFFFu) + (v >> 16) < 2u && !t_cand[e & 0x7FFFFFFFu]) e = 0xFFFFFFFFu;
+	// The replay, without its loop (round 5).  What the sequential loop of CS::AddLocationStd carries from hit to hit is (a) the votes of
+	// the hit's bin and strand so far and (b) the running maximum M (CS.cpp:197-202); a bin enters rList at its first hit with
+	// score >= M * sensitivity (CS.cpp:205-208).  Both follow from the TIMES of the hits of every tracked (bin, strand), sorted:
+	//   tau[v]  = the earliest time at which any (bin, strand) has v votes = min over them of the time of their v-th hit
+	//             (tau is increasing in v; tau[1] = 0: the first hit of the read);
+	//   M(t)    = the number of v with tau[v] <= t;
+	//   a candidate's bin enters at the earliest time t_j of a j-th hit of one of its strands with (float) j >= (float) M(t_j) * sensitivity.
+	// A bin with one vote never moves the maximum beyond 1 and is never a candidate unless the final threshold is <= 1 (those are
+	// tracked as t_cand), so only the hits of bins with >= 2 votes and of the candidates take part.  Every step is parallel over the
+	// slots or the hits: counting sort of the hit times by (slot, strand) -- offsets from a block scan over the votes, one atomic per
+	// hit for its place, an insertion sort per (short, nearly sorted) segment -- then atomicMin into tau (LDS) and one pass over the
+	// candidates' segments.  The sequential replay took 64 hits per trip with the table's latency on every trip: 20-30 ms for a read
+	// with 300 000 tracked hits in global memory (profiles/r05_heavy_tail_3100mbp_first.txt: 1.1 s of replay per 1 M reads).
+	// cand_rank[c] = 2 * (the time its bin entered rList) + strand: the same order as the rList positions, which is all its users compare.
+	{
+		uint32_t *t_off = t_run;    // offset of the slot's segment (forward hits, then reverse hits) in tm
+		uint32_t *t_fill = t_rank;  // hits placed so far (forward | reverse << 16); afterwards: the time the bin entered rList
+		__shared__ uint32_t s_scan[NT / 64], s_bad;
+		if (tid == 0) s_bad = 0;
+		for (uint32_t v = tid; v < n_tau; v += NT) tau[v] = v == 1u && H > 0u ? 0u : 0xFFFFFFFFu;
+		auto kept = [&](uint32_t s2, uint32_t &nf, uint32_t &nr) -> bool {   // does slot s2 take part, and with how many hits
+			nf = nr = 0;
+			if (!GLOBAL && t_keys[s2] == 0xFFFFFFFFu) return false;
+			const uint32_t v = og(&t_votes[s2]);
+			nf = v & 0xFFFFu; nr = v >> 16;
+			return nf + nr >= 2u || t_cand[s2] != 0u;
+		};
+		// the slots in use: entry i of the list (GLOBAL) or slot i of the table
+		const uint32_t n_ent = GLOBAL ? s_keys : n_slots;
+		auto slot_of = [&](uint32_t i) -> uint32_t { return GLOBAL ? t_list[i] : i; };
+		// (a) offsets: every thread a contiguous run of entries; a slot that does not take part is marked
+		const uint32_t per = (n_ent + NT - 1) / NT, s_lo = min(n_ent, (uint32_t) tid * per), s_hi = min(n_ent, s_lo + per);
+		uint32_t mine = 0;
+		for (uint32_t i = s_lo; i < s_hi; ++i) { uint32_t nf, nr; if (kept(slot_of(i), nf, nr)) mine += nf + nr; }
+		const uint32_t incl = wave_inclusive_scan(mine, lane);
+		if (lane == 63) s_scan[wv] = incl;
+		__syncthreads();
+		uint32_t run = incl - mine;
+		for (int w2 = 0; w2 < wv; ++w2) run += s_scan[w2];
+		for (uint32_t i = s_lo; i < s_hi; ++i) {
+			const uint32_t s2 = slot_of(i);
+			uint32_t nf, nr;
+			const bool k2 = kept(s2, nf, nr);
+			t_off[s2] = k2 ? run : 0xFFFFFFFFu; t_fill[s2] = 0;
+			if (k2) run += nf + nr;
 		}
-		const unsigned long long keep = __ballot(e != 0xFFFFFFFFu);
-		if (e != 0xFFFFFFFFu) ev_at[E + (uint32_t) __popcll(keep & lanes_below)] = e;  // E <= t0: behind everything still to be read
-		E += (uint32_t) __popcll(keep);
-	}
-	// 64 hits per trip instead of one: what the sequential loop of CS::AddLocationStd carries from hit to hit is (a) the
-	// votes of the hit's bin so far -- votes before this trip (t_run) + earlier lanes of the trip with the same bin and
-	// strand -- and (b) the running maximum (CS.cpp:197-202), an inclusive prefix maximum over the lanes.  A bin enters
-	// rList at its first hit with score >= maximum * sensitivity (CS.cpp:205-208); the ranks follow the lane order.
-	uint32_t max_votes = H > 0 ? 1u : 0u, next_rank = 0;
-	for (uint32_t c0 = 0; c0 < E; c0 += 64) {
-		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the trip before wrote t_run / t_rank in global memory
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // one wave: LDS operations complete in program order
-		const bool act = c0 + (uint32_t) lane < E;
-		const uint32_t e = act ? ev_at[c0 + (uint32_t) lane] : 0u;
-		const uint32_t slot = e & 0x7FFFFFFFu;
-		const bool rev = (e >> 31) != 0u;
-		unsigned long long same_bin = __ballot(act);  // lanes of this trip that hit the same bin
-#pragma unroll
-		for (int b = 0; b < (GLOBAL ? 30 : kCsOrderLog2Slots); ++b) {
-			if (GLOBAL && b >= log2_slots) break;
-			const bool bit = (slot >> b) & 1u;
-			const unsigned long long bb = __ballot(act && bit);
-			same_bin &= bit ? bb : ~bb;
+		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__syncthreads();
+		// (b) every tracked hit to its segment
+		for (uint32_t t = tid; t < H; t += NT) {
+			const uint32_t e = ev_at[t];
+			if (e == 0xFFFFFFFFu) continue;
+			const uint32_t slot = e & 0x7FFFFFFFu;
+			const uint32_t off = t_off[slot];
+			if (off == 0xFFFFFFFFu) continue;
+			const bool rev = (e >> 31) != 0u;
+			const uint32_t nf = rev ? (og(&t_votes[slot]) & 0xFFFFu) : 0u;
+			const uint32_t k = atomicAdd(&t_fill[slot], rev ? 0x10000u : 1u);
+			tm[off + (rev ? nf + (k >> 16) : (k & 0xFFFFu))] = t;
 		}
-		const unsigned long long rev_lanes = __ballot(act && rev);
-		const unsigned long long same_key = same_bin & (rev ? rev_lanes : ~rev_lanes);
-		const uint32_t run = act ? t_run[slot] : 0u;
-		const uint32_t score = act ? (rev ? run >> 16 : run & 0xFFFFu) + (uint32_t) __popcll(same_key & lanes_below) + 1u : 0u;
-		if (act && ((same_bin >> lane) >> 1) == 0ull)  // the bin's last lane of this trip
-			t_run[slot] = run + (uint32_t) __popcll(same_bin & ~rev_lanes) + ((uint32_t) __popcll(same_bin & rev_lanes) << 16);
-		const uint32_t mx = max(wave_inclusive_max(score), max_votes);
-		max_votes = wave_last(mx);
-		const bool enters = act && (float) score >= (float) mx * A.sensitivity && t_rank[slot] == kCsOrderUnknown;
-		const unsigned long long entering = __ballot(enters);
-		const bool first = enters && (entering & same_bin & lanes_below) == 0ull;
-		const unsigned long long firsts = __ballot(first);
-		if (first) t_rank[slot] = next_rank + (uint32_t) __popcll(firsts & lanes_below);
-		next_rank += (uint32_t) __popcll(firsts);
+		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__syncthreads();
+		// (c) segments sorted by time (they arrive nearly sorted: threads walk the time line upwards); tau
+		for (uint32_t i = tid; i < n_ent; i += NT) {
+			const uint32_t s2 = slot_of(i);
+			const uint32_t off = t_off[s2];
+			t_fill[s2] = kCsOrderUnknown;
+			if (off == 0xFFFFFFFFu) continue;
+			uint32_t nf, nr;
+			(void) kept(s2, nf, nr);
+			uint32_t *seg = tm + off;
+			for (int st = 0; st < 2; ++st) {
+				const uint32_t n2 = st ? nr : nf;
+				uint32_t *g = seg + (st ? nf : 0u);
+				for (uint32_t x = 1; x < n2; ++x) {
+					const uint32_t key = g[x];
+					uint32_t y = x;
+					while (y > 0 && g[y - 1] > key) { g[y] = g[y - 1]; --y; }
+					g[y] = key;
+				}
+				if (n2 >= n_tau) { atomicExch(&s_bad, 1u); continue; }
+				for (uint32_t j = 1; j <= n2; ++j) atomicMin(&tau[j], g[j - 1]);
+			}
+		}
+		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__syncthreads();
+		if (s_bad) { give_up(4u, H, s_keys); return; }   // (more votes for one bin and strand than the read has k-mers + 64: not reached)
+		// (d) when does every candidate's bin enter rList
+		for (uint32_t i = tid; i < n_ent; i += NT) {
+			const uint32_t s2 = slot_of(i);
+			if (!t_cand[s2]) continue;
+			const uint32_t off = t_off[s2];
+			if (off == 0xFFFFFFFFu) continue;
+			uint32_t nf, nr;
+			(void) kept(s2, nf, nr);
+			const uint32_t *seg = tm + off;
+			uint32_t enter = kCsOrderUnknown;
+			for (int st = 0; st < 2; ++st) {
+				const uint32_t n2 = st ? nr : nf;
+				const uint32_t *g = seg + (st ? nf : 0u);
+				for (uint32_t j = 1; j <= n2; ++j) {
+					const uint32_t t = g[j - 1];
+					if (t >= enter) break;
+					uint32_t lo = 1, hi = n_tau;   // M(t): the largest v with tau[v] <= t (tau[1] = 0 <= t)
+					while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tau[mid] <= t) lo = mid; else hi = mid; }
+					if ((float) j >= (float) lo * A.sensitivity) { enter = t; break; }
+				}
+			}
+			t_fill[s2] = enter;
+		}
+		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}
-	}  // wave 0
 	__syncthreads();
 	if (diag) ck[4] = wall_clock64();
 	if (diag && tid == 0) {  // 100 MHz ticks: lists, sweep A, sweep B, compaction + replay; sampled reads, big ones, hits, replayed hits
 		atomicAdd(&A.phase_cycles[8], ck[1] - ck[0]); atomicAdd(&A.phase_cycles[9], ck[2] - ck[1]); atomicAdd(&A.phase_cycles[10], ck[3] - ck[2]);
 		atomicAdd(&A.phase_cycles[11], ck[4] - ck[3]); atomicAdd(&A.phase_cycles[12], 1ull); 
-		atomicAdd(&A.phase_cycles[14], (unsigned long long) H); atomicAdd(&A.phase_cycles[15], (unsigned long long) E);
+		atomicAdd(&A.phase_cycles[14], (unsigned long long) H); atomicAdd(&A.phase_cycles[15], (unsigned long long) s_keys);
 	}
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;
 	for (uint32_t c = tid; c < cn; c += NT) {
@@ -1446,7 +1512,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 		uint32_t rank = kCsOrderUnknown;
 		for (uint32_t probes = 0; probes < n_slots; ++probes) {
 			const uint32_t key = og(&t_keys[slot]);
-			if (key == bin) { if (t_rank[slot] != kCsOrderUnknown) rank = 2u * t_rank[slot] + (cand_sv[cb + c] & 1u); break; }
+			if (key == bin) { if (t_rank[slot] != kCsOrderUnknown) rank = 2u * t_rank[slot] + (cand_sv[cb + c] & 1u); break; }   // (t_rank: the time the bin entered rList)
 			if (key == 0xFFFFFFFFu) break;
 			slot = (slot + 1) & (n_slots - 1);
 		}

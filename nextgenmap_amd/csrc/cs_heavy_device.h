@@ -318,15 +318,15 @@ inline size_t cs_heavy2_coarse_cap(int lists_cap, int max_kfreq) {   // items / 
 	return items / 16 + 4;
 }
 inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int log2_slots, size_t coarse_cap) {
-	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + ((size_t) 1 << (log2_counters - 1)) + 512 + ((size_t) 2 << log2_slots)) * 4;
+	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + 3 + ((size_t) 1 << (log2_counters - 1)) + 512 + ((size_t) 2 << log2_slots)) * 4;
 }
 
 template <int NT>
 __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list, uint32_t *__restrict__ work_counter, uint32_t *__restrict__ scratch, uint32_t scratch_cap,
-		uint32_t coarse_cap) {
+		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	constexpr int NW = NT / 64;
-	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct;
+	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct, s_nhot, s_nent;
 	__shared__ uint32_t s_red[NW], s_cnt[NT], s_wtot[NW], s_mx[NW], s_mxb[NW];
 	__shared__ unsigned long long s_base;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);    // [q rounded up to 4]
 	uint32_t *seg_pref = (uint32_t *) l_code + (A.q + 3) / 4;    // [lists_cap + 1]: 8-hit segments in front of each list
 	uint16_t *coarse = (uint16_t *) (seg_pref + A.lists_cap + 1); // [coarse_cap]: the list that holds item 16 c
-	uint32_t *cnt = (uint32_t *) coarse + (coarse_cap + 1) / 2;  // [NC / 2]: two 16-bit counters per word
+	uint32_t *cnt = cs_lds + (((size_t) ((uint32_t *) coarse - cs_lds) + (coarse_cap + 1) / 2 + 3) & ~(size_t) 3);  // [NC / 2]: two 16-bit counters per word (16-byte aligned: cleared with 128-bit stores)
 	const int log2c = A.log2_bits;
 	const uint32_t cnt_words = (1u << log2c) >> 1;
 	uint32_t *hist_n = cnt + cnt_words;                          // [256]: counters of value c (255: and above)
@@ -346,7 +346,8 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 	const uint32_t n_slots = 1u << log2_slots;
 	uint32_t *t_votes = t_keys + n_slots;
 	const uint32_t cap = (n_slots * 3u) / 4u;
-	uint32_t *my_scratch = scratch + (size_t) blockIdx.x * scratch_cap;
+	uint32_t *my_scratch = scratch + (size_t) blockIdx.x * ((size_t) scratch_cap + 2u * (size_t) ent_cap);   // survivors, then (max_parts > 1) the entries of all parts
+	uint32_t *my_ent = my_scratch + scratch_cap;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
 	for (;;) {
 		__syncthreads();   // (the previous read's shared state is no longer read)
@@ -355,9 +356,15 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		const uint32_t item_ix = s_next;
 		if (item_ix >= n_list) return;
 		const int read = (int) A.read_list[item_ix];
-		for (uint32_t s = tid; s < cnt_words; s += NT) cnt[s] = 0;
-		for (uint32_t s = tid; s < 512u; s += NT) hist_n[s] = 0;   // (hist_n and hist_h)
-		for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
+		const bool dg = diag != nullptr && (item_ix & 7u) == 0u && tid == 0;
+		unsigned long long tk = dg ? wall_clock64() : 0ull;
+		auto mark = [&](int ph) { if (dg) { const unsigned long long t2 = wall_clock64(); atomicAdd(&diag[ph], t2 - tk); tk = t2; } };
+		{
+			uint4 *c4 = reinterpret_cast<uint4 *>(cnt);   // counters, both histograms: zero; keys: empty; votes: zero
+			for (uint32_t s = tid; s < (cnt_words + 512u) / 4u; s += NT) c4[s] = make_uint4(0u, 0u, 0u, 0u);
+			uint4 *k4 = reinterpret_cast<uint4 *>(t_keys), *v4 = reinterpret_cast<uint4 *>(t_votes);
+			for (uint32_t s = tid; s < n_slots / 4u; s += NT) { k4[s] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); v4[s] = make_uint4(0u, 0u, 0u, 0u); }
+		}
 		if (tid == 0) { s_T = 1; s_np = 0; s_entries = 0; s_fail = 0; s_direct = 1; }
 		// every wave computes the same lists (the barrier inside is the block's)
 		const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
@@ -425,13 +432,19 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 			atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
 		};
 		auto counter_of = [&](uint32_t hc) -> uint32_t { return (cnt[hc >> 1] >> ((hc & 1u) * 16u)) & 0xFFFFu; };
-		// sum of all 16-bit fields of the row == `want`: no field has wrapped
-		auto row_sum_is = [&](uint32_t want) -> bool {
-			uint32_t s = 0;
-			for (uint32_t i = tid; i < cnt_words; i += NT) { const uint32_t w = cnt[i]; s += (w & 0xFFFFu) + (w >> 16); }
-			s = wave_last(wave_inclusive_scan(s, lane));
-			__syncthreads();
-			if (lane == 0) s_red[wv] = s;
+		// histogram of the row's counters of at least `from` (hist_n: how many of each value, 255: and above; with_hits: hist_h, the hits on
+		// them) and the sum of ALL its 16-bit fields, which must be `want`: a field that wrapped into its neighbour changes the sum
+		auto row_hist = [&](uint32_t want, uint32_t from, bool with_hits) -> bool {
+			uint32_t sm = 0;
+			for (uint32_t i = tid; i < cnt_words; i += NT) {
+				const uint32_t w = cnt[i];
+				const uint32_t c0 = w & 0xFFFFu, c1 = w >> 16;
+				sm += c0 + c1;
+				if (c0 >= from) { atomicAdd(&hist_n[min(c0, 255u)], 1u); if (with_hits) atomicAdd(&hist_h[min(c0, 255u)], c0); }   // (counters of 0 and 1 are most of them: T >= 2, they never matter)
+				if (c1 >= from) { atomicAdd(&hist_n[min(c1, 255u)], 1u); if (with_hits) atomicAdd(&hist_h[min(c1, 255u)], c1); }
+			}
+			sm = wave_last(wave_inclusive_scan(sm, lane));
+			if (lane == 0) s_red[wv] = sm;
 			__syncthreads();
 			uint32_t tot = 0;
 #pragma unroll
@@ -440,6 +453,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		};
 		uint32_t T = 1;
 		bool failed = false;
+		mark(0);
 		if (H > cap) {
 			// sweep A
 			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool) {
@@ -450,32 +464,38 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 				}
 			});
 			__syncthreads();
-			if (!row_sum_is(H)) failed = true;   // (block-uniform)
+			mark(1);
+			// histogram of the counter values -- and their sum: a 16-bit field that wrapped into its neighbour changes it
+			if (!row_hist(H, 2u, true)) failed = true;   // (block-uniform)
 			if (!failed) {
-				for (uint32_t i = tid; i < cnt_words; i += NT) {
-					const uint32_t w = cnt[i];
-					const uint32_t c0 = w & 0xFFFFu, c1 = w >> 16;
-					if (c0 > 1u) { atomicAdd(&hist_n[min(c0, 255u)], 1u); atomicAdd(&hist_h[min(c0, 255u)], c0); }   // (counters of 0 and 1 are most of them: T >= 2 here, they never matter)
-					if (c1 > 1u) { atomicAdd(&hist_n[min(c1, 255u)], 1u); atomicAdd(&hist_h[min(c1, 255u)], c1); }
-				}
-				__syncthreads();
-				if (tid == 0) {
+				if (wv == 0) {
 					// the smallest T whose counters fit the table with a quarter of it to spare (one bin per counter, and what slips through
-					// both rows); when even their hits fit, no second row is needed; and the survivors must fit the scratch slice
-					uint32_t acc_n = 0, acc_h = 0, t = 256u, direct = 0;
-					const uint32_t room = (cap * 3u) / 4u;
-					for (uint32_t c = 255u; c >= 2u; --c) {
-						acc_n += hist_n[c]; acc_h += hist_h[c];
-						if (acc_h <= cap) { t = c; direct = 1; continue; }
-						if (acc_n > room || acc_h > scratch_cap) break;
-						t = c; direct = 0;
+					// both rows) and whose hits fit the scratch slice; when even the hits fit the table, no second row is needed.  Both
+					// conditions are monotone in T: lane l looks at the values 4 l .. 4 l + 3, suffix sums from a wave scan.
+					const uint32_t room = ((cap * 3u) / 4u) * max(max_parts, 1u);   // (the largest class takes the bins in several parts: below)
+					uint32_t n4[4], h4[4], sn = 0, sh = 0;
+#pragma unroll
+					for (int j = 0; j < 4; ++j) { n4[j] = hist_n[4 * lane + j]; h4[j] = hist_h[4 * lane + j]; sn += n4[j]; sh += h4[j]; }
+					const uint32_t in_n = wave_inclusive_scan(sn, lane), in_h = wave_inclusive_scan(sh, lane);
+					const uint32_t tot_n = wave_last(in_n), tot_h = wave_last(in_h);
+					uint32_t below_n = in_n - sn, below_h = in_h - sh;   // counters / hits of the values below 4 l
+					int my_t = 256;
+					uint32_t my_h = 0;
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const uint32_t suf_n = tot_n - below_n, suf_h = tot_h - below_h;   // values >= 4 l + j
+						if (my_t == 256 && 4 * lane + j >= 2 && suf_n <= room && suf_h <= scratch_cap) { my_t = 4 * lane + j; my_h = suf_h; }
+						below_n += n4[j]; below_h += h4[j];
 					}
-					s_T = t; s_direct = direct;
+					const int t = wave_reduce_min(my_t);
+					const bool direct = __ballot(my_t == t && t < 256 && my_h <= cap) != 0ull;
+					if (lane == 0) { s_T = (uint32_t) t; s_direct = direct ? 1u : 0u; }
 				}
 				__syncthreads();
 				T = s_T;
 				if (T > 255u) failed = true;
 			}
+			mark(2);
 			if (!failed && s_direct) {
 				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev) {
 #pragma unroll
@@ -516,50 +536,185 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 				});
 				__threadfence_block();
 				__syncthreads();
+				mark(3);
 				const uint32_t np = s_np;
+				if (dg) atomicAdd(&diag[11], (unsigned long long) np);
 				if (np > scratch_cap) failed = true;
+				// the survivors, K at a time per thread: their loads (L2) are in flight together
+				constexpr int KS = 8;
+				auto for_survivors = [&](uint32_t np_, auto f) {
+					for (uint32_t x0 = (uint32_t) tid; x0 < np_; x0 += (uint32_t) NT * KS) {
+						uint32_t e[KS];
+#pragma unroll
+						for (int j = 0; j < KS; ++j) { const uint32_t x = x0 + (uint32_t) j * NT; e[j] = x < np_ ? my_scratch[x] : 0xFFFFFFFFu; }
+#pragma unroll
+						for (int j = 0; j < KS; ++j) if (x0 + (uint32_t) j * NT < np_) f(e[j]);
+					}
+				};
 				if (!failed) {
-					for (uint32_t s = tid; s < cnt_words; s += NT) cnt[s] = 0;
+					{
+						uint4 *c4 = reinterpret_cast<uint4 *>(cnt);
+						for (uint32_t s = tid; s < (cnt_words + 256u) / 4u; s += NT) c4[s] = make_uint4(0u, 0u, 0u, 0u);   // (the counters and hist_n)
+					}
 					__syncthreads();
 					// sweep C: row 2 over the survivors
-					for (uint32_t x = tid; x < np; x += NT) {
-						const uint32_t bin = my_scratch[x] & 0x3FFFFFFFu;
-						const uint32_t hc = (bin * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c);
+					for_survivors(np, [&](uint32_t e) {
+						const uint32_t hc = ((e & 0x3FFFFFFFu) * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c);
 						atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
-					}
+					});
 					__syncthreads();
-					if (!row_sum_is(np)) failed = true;
-				}
-				if (!failed) {
 					// row 2 is almost free of noise: its counters >= t are the bins with >= t votes -- the final T is the smallest one
 					// (not below row 1's) whose bins leave the table a quarter of its room
-					for (uint32_t s = tid; s < 256u; s += NT) hist_n[s] = 0;
-					__syncthreads();
-					for (uint32_t i = tid; i < cnt_words; i += NT) {
-						const uint32_t w = cnt[i];
-						const uint32_t c0 = w & 0xFFFFu, c1 = w >> 16;
-						if (c0 >= T) atomicAdd(&hist_n[min(c0, 255u)], 1u);
-						if (c1 >= T) atomicAdd(&hist_n[min(c1, 255u)], 1u);
-					}
-					__syncthreads();
-					if (tid == 0) {
-						uint32_t acc = 0, t = 256u;
-						const uint32_t room = (cap * 3u) / 4u;
-						for (uint32_t c = 255u; c >= T; --c) { acc += hist_n[c]; if (acc > room) break; t = c; }
-						s_T = t;
+					if (!row_hist(np, T, false)) failed = true;
+				}
+				if (!failed) {
+					if (wv == 0) {
+						const uint32_t room = ((cap * 3u) / 4u) * max(max_parts, 1u);
+						uint32_t n4[4], sn = 0;
+#pragma unroll
+						for (int j = 0; j < 4; ++j) { n4[j] = hist_n[4 * lane + j]; sn += n4[j]; }
+						const uint32_t in_n = wave_inclusive_scan(sn, lane);
+						const uint32_t tot_n = wave_last(in_n);
+						uint32_t below_n = in_n - sn;
+						int my_t = 256;
+						uint32_t my_n = 0;
+#pragma unroll
+						for (int j = 0; j < 4; ++j) {
+							if (my_t == 256 && (uint32_t) (4 * lane + j) >= T && tot_n - below_n <= room) { my_t = 4 * lane + j; my_n = tot_n - below_n; }
+							below_n += n4[j];
+						}
+						const int t = wave_reduce_min(my_t);
+						const unsigned long long own = __ballot(my_t == t && t < 256);
+						const uint32_t nh = own ? (uint32_t) __builtin_amdgcn_readlane((int) my_n, (int) __builtin_ctzll(own)) : 0u;
+						if (lane == 0) { s_T = (uint32_t) t; s_nhot = nh; }
 					}
 					__syncthreads();
 					T = s_T;
 					if (T > 255u) failed = true;
 				}
-				if (!failed) {
-					// sweep D
-					for (uint32_t x = tid; x < np; x += NT) {
+				mark(4);
+				// sweep D: KS survivors per thread and trip -- their counter reads, then their first probes, are in flight together; part `pt` of
+				// `parts` (a third hash of the bin): the bins the table takes in this pass
+				auto sweep_d = [&](uint32_t pt, uint32_t parts) {
+					for (uint32_t x0 = (uint32_t) tid; x0 < np; x0 += (uint32_t) NT * KS) {
 						if (*(volatile uint32_t *) &s_fail) break;
-						const uint32_t e = my_scratch[x];
-						const uint32_t bin = e & 0x3FFFFFFFu;
-						if (counter_of((bin * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c)) >= T) insert(bin, (e >> 31) != 0u);
+						uint32_t e[KS], cv[KS], slot[KS], prev[KS];
+#pragma unroll
+						for (int j = 0; j < KS; ++j) { const uint32_t x = x0 + (uint32_t) j * NT; e[j] = x < np ? my_scratch[x] : 0xFFFFFFFFu; }
+#pragma unroll
+						for (int j = 0; j < KS; ++j) {
+							cv[j] = e[j] != 0xFFFFFFFFu ? counter_of(((e[j] & 0x3FFFFFFFu) * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c)) : 0u;
+							if (parts > 1u && __umulhi((e[j] & 0x3FFFFFFFu) * 0x7FEB352Du, parts) != pt) cv[j] = 0u;
+						}
+#pragma unroll
+						for (int j = 0; j < KS; ++j) {
+							slot[j] = ((e[j] & 0x3FFFFFFFu) * 0x85EBCA6Bu) >> (32 - log2_slots);
+							prev[j] = 0;
+							if (cv[j] >= T) prev[j] = atomicCAS(&t_keys[slot[j]], 0xFFFFFFFFu, e[j] & 0x3FFFFFFFu);
+						}
+#pragma unroll
+						for (int j = 0; j < KS; ++j) if (cv[j] >= T) {
+							const uint32_t bin = e[j] & 0x3FFFFFFFu;
+							uint32_t sl = slot[j], pv = prev[j];
+							for (uint32_t probes = 0; pv != bin && pv != 0xFFFFFFFFu && probes < n_slots; ++probes) {
+								sl = (sl + 1) & (n_slots - 1);
+								pv = atomicCAS(&t_keys[sl], 0xFFFFFFFFu, bin);
+							}
+							if (pv == 0xFFFFFFFFu) { if (atomicAdd(&s_entries, 1u) >= cap) atomicExch(&s_fail, 1u); }
+							else if (pv != bin) { atomicExch(&s_fail, 1u); continue; }   // (the table is full: not reached, the entry count fails the read first)
+							atomicAdd(&t_votes[sl], (e[j] >> 31) ? 0x10000u : 1u);
+						}
 					}
+				};
+				const uint32_t room1 = (cap * 3u) / 4u;
+				const uint32_t parts = (failed || s_nhot <= room1) ? 1u : min(max(max_parts, 1u), (s_nhot + s_nhot / 8u + room1 - 1u) / room1);
+				if (!failed && parts == 1u) sweep_d(0u, 1u);
+				else if (!failed) {
+					// More bins at or above T than the table holds: the table takes them in `parts` passes over the survivors and hands its
+					// entries (bin, votes) to a list in the scratch slice; maximum, threshold and candidates then come from that list.
+					if (tid == 0) s_nent = 0;
+					int pmx = 0, pmxb = 0;
+					for (uint32_t pt = 0; pt < parts; ++pt) {
+						__syncthreads();
+						if (pt > 0u) {
+							uint4 *k4 = reinterpret_cast<uint4 *>(t_keys), *v4 = reinterpret_cast<uint4 *>(t_votes);
+							for (uint32_t s2 = tid; s2 < n_slots / 4u; s2 += NT) { k4[s2] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); v4[s2] = make_uint4(0u, 0u, 0u, 0u); }
+							if (tid == 0) s_entries = 0;
+							__syncthreads();
+						}
+						sweep_d(pt, parts);
+						__syncthreads();
+						if (s_fail) break;   // (block-uniform)
+						for (uint32_t s2 = tid; s2 < n_slots; s2 += NT) {
+							const uint32_t key = t_keys[s2];
+							if (key == 0xFFFFFFFFu) continue;
+							const uint32_t v = t_votes[s2];
+							pmx = max(pmx, (int) max(v & 0xFFFFu, v >> 16));
+							pmxb = max(pmxb, (int) ((v & 0xFFFFu) + (v >> 16)));
+							const uint32_t at = atomicAdd(&s_nent, 1u);
+							if (at < ent_cap) { my_ent[2u * at] = key; my_ent[2u * at + 1u] = v; }
+						}
+					}
+					__syncthreads();
+					mark(5);
+					if (dg) { atomicAdd(&diag[8], 1ull); atomicAdd(&diag[9], (unsigned long long) H); atomicAdd(&diag[12], (unsigned long long) parts); }
+					const uint32_t n_ent = s_nent;
+					if (s_fail || n_ent > ent_cap) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
+					pmx = wave_reduce_max(pmx); pmxb = wave_reduce_max(pmxb);
+					if (lane == 0) { s_mx[wv] = (uint32_t) pmx; s_mxb[wv] = (uint32_t) pmxb; }
+					__syncthreads();
+					pmx = 0; pmxb = 0;
+#pragma unroll
+					for (int w2 = 0; w2 < NW; ++w2) { pmx = max(pmx, (int) s_mx[w2]); pmxb = max(pmxb, (int) s_mxb[w2]); }
+					const float max_hit_p = (float) pmx;
+					const float thresh_p = fmaxf(A.kmer_min, max_hit_p * A.sensitivity);
+					if (!((float) (T - 1u) < thresh_p)) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins below T could reach the threshold
+					const uint32_t region_p = (uint32_t) read & (kCsRegions - 1);
+					if (tid == 0 && A.counters) {
+						atomicAdd(&A.counters[region_p * kCsCursorStride], (unsigned long long) R.n_valid);
+						atomicAdd(&A.counters[region_p * kCsCursorStride + 1], (unsigned long long) H);
+					}
+					uint32_t cnt_p = 0;
+					for (uint32_t x = tid; x < n_ent; x += NT) { const uint32_t v = my_ent[2u * x + 1u]; cnt_p += ((float) (v & 0xFFFFu) >= thresh_p) + ((float) (v >> 16) >= thresh_p); }
+					const uint32_t incl_p = wave_inclusive_scan(cnt_p, lane);
+					if (lane == 63) s_wtot[wv] = incl_p;
+					__syncthreads();
+					uint32_t before_p = incl_p - cnt_p, total_p = 0;
+#pragma unroll
+					for (int w2 = 0; w2 < NW; ++w2) { if (w2 < wv) before_p += s_wtot[w2]; total_p += s_wtot[w2]; }
+					if ((int64_t) total_p >= (int64_t) A.max_cmrs) total_p = 0;  // "if (index < maxScores) AllocScores" (CS.cpp:308-310)
+					const bool fixed_p = A.fixed_base != 0u && total_p <= (uint32_t) kCsFixedSlots;
+					if (tid == 0) {
+						unsigned long long base = 0;
+						if (!fixed_p) {
+							base = total_p ? atomicAdd(&A.out_total[region_p * kCsCursorStride], (unsigned long long) total_p) : 0ull;
+							if (base + total_p > A.out_capacity) { atomicExch(&A.status[0], 1u); }
+						}
+						s_base = base;
+						A.cand_base[read] = fixed_p ? A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots : (uint32_t) (region_p * A.out_capacity + base);
+						A.cand_count[read] = total_p;
+						A.max_votes[read] = max_hit_p;
+						if (A.max_both) A.max_both[read] = (float) pmxb;
+						A.read_len[read] = (uint16_t) R.L;
+						if (A.counters && total_p) atomicAdd(&A.counters[region_p * kCsCursorStride + 2], (unsigned long long) total_p);
+					}
+					__syncthreads();
+					if (total_p != 0u) {
+						uint32_t w = 0;
+						bool room_ok = true;
+						if (fixed_p) w = A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots + before_p;
+						else { const unsigned long long base = s_base; room_ok = base + total_p <= A.out_capacity; w = (uint32_t) (region_p * A.out_capacity + base) + before_p; }
+						const uint32_t centre_p = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
+						if (room_ok) for (uint32_t x = tid; x < n_ent; x += NT) {
+							const uint32_t key = my_ent[2u * x], v = my_ent[2u * x + 1u];
+							const uint32_t f = v & 0xFFFFu, r = v >> 16;
+							const uint32_t loc = (key << A.bin_shift) + centre_p;
+							if ((float) f >= thresh_p) { A.out_loc[w] = loc; A.out_sv[w] = f << 1; ++w; }
+							if ((float) r >= thresh_p) { A.out_loc[w] = loc; A.out_sv[w] = (r << 1) | 1u; ++w; }
+						}
+					}
+					mark(6);
+					continue;
 				}
 			}
 		} else {
@@ -569,6 +724,8 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 			});
 		}
 		__syncthreads();
+		mark(5);
+		if (dg) { atomicAdd(&diag[8], 1ull); atomicAdd(&diag[9], (unsigned long long) H); if (H > cap && s_direct) atomicAdd(&diag[10], 1ull); }
 		if (failed || s_fail) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
 		// the table: maximum, candidates (cs_global_kernel's order: thread t owns the slots of lane class t mod 64 in the (t / 64)-th share)
 		const uint32_t per_class = n_slots >> 6;
@@ -654,6 +811,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 				if ((float) r >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = (r << 1) | 1u; ++w; }
 			}
 		}
+		mark(6);
 	}
 }
 

@@ -112,12 +112,14 @@ struct ngm_mapper {
 	ngm::DevBuf<uint64_t> d_ovf_off;
 	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes, d_heavy_list, d_heavy_ctr;
 	ngm::DevBuf<float> d_max_votes, d_max_both, d_scores, d_best;
-	ngm::DevBuf<unsigned long long> d_total, d_counters;
+	ngm::DevBuf<unsigned long long> d_total, d_counters, d_heavy_diag;
 	ngm::DevBuf<uint32_t> d_out_loc2, d_out_sv2, d_new_base;
 	ngm::DevBuf<uint8_t> d_scan_tmp;
 	unsigned long long cs_kmers = 0, cs_hits = 0;
 	float cs_kernel_ms = 0.f;
 	hipEvent_t cev[6] = {};
+	hipEvent_t oev[4] = {};            // around the order replay's launches (its own stream)
+	float order_ms = 0.f;              // GPU time of the order replays of the last batch (ngm_mapper_last_order_replay_ms)
 	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
 	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records, d_pair_info;
 	ngm::PinnedBuf<int32_t> p_pair_info;
@@ -148,6 +150,7 @@ struct ngm_mapper {
 	ngm::PinnedBuf<ngm::SamRef> p_sam_refs;
 	ngm::PinnedBuf<char> p_sam_extra;
 	uint64_t sam_text_bytes = 0;      // of the last batch (still in d_sam_text)
+	uint64_t pair_stats[3] = {0, 0, 0};   // ngm_mapper_last_pair_stats
 	// last CS result on the host
 	int n_reads = 0;
 	// per-read candidate offsets / counts / best vote counts of the last search, downloaded into pinned memory
@@ -429,9 +432,21 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 			// pass 1b -- the reads with more hits than the fast path takes (cs_heavy2_kernel, cs_heavy_device.h): two rows of sketch counters +
 			// an exact table in LDS, by hit count in three classes of persistent workgroups; pass 1c -- what the two smaller classes
 			// cannot certify, once more in the largest; what is left after that is queued for the exact kernels below
-			struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; uint32_t scratch_cap; const void *fn; };
-			static const HeavyClass classes[3] = {{16384u, 13, 11, 256, 16384u, (const void *) ngm::cs_heavy2_kernel<256>}, {32768u, 14, 12, 512, 32768u, (const void *) ngm::cs_heavy2_kernel<512>},
-					{0xFFFFFFFFu, 15, 13, 1024, 262144u, (const void *) ngm::cs_heavy2_kernel<1024>}};
+			struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; uint32_t scratch_cap; const void *fn; uint32_t max_parts = 1; };   // max_parts: table passes a read may take (the largest class)
+			// (class limits measured on the heavy-tailed probe, per 262 144 reads: 16 384 / 32 768 / rest 18.3 ms; 16 384 / 65 536 / rest 16.1; 16 384 / all the
+			// rest in the middle class -- two workgroups per CU -- and the largest class only for what that cannot certify: 15.1)
+			static HeavyClass classes[3] = {{16384u, 13, 11, 256, 16384u, (const void *) ngm::cs_heavy2_kernel<256>}, {0xFFFFFFFEu, 14, 12, 512, 262144u, (const void *) ngm::cs_heavy2_kernel<512>},
+					{0xFFFFFFFFu, 15, 13, 1024, 1u << 20, (const void *) ngm::cs_heavy2_kernel<1024>, 16u}};
+			static const bool classes_env = [] {   // experiments: NGM_HIP_HEAVY_CLASSES=max0,max1 (hits up to which a read starts in class 0 / class 1)
+				if (const char *e = getenv("NGM_HIP_HEAVY_CLASSES")) {
+					unsigned long a = 0, b = 0;
+					if (sscanf(e, "%lu,%lu", &a, &b) == 2 && a > 0 && b >= a) {
+						classes[0].max_hits = (uint32_t) std::min<unsigned long>(a, 0xFFFFFFFEul); classes[1].max_hits = (uint32_t) std::min<unsigned long>(b, 0xFFFFFFFEul);
+						classes[0].scratch_cap = std::min<uint32_t>(classes[0].max_hits, 262144u); classes[1].scratch_cap = std::min<uint32_t>(classes[1].max_hits, 262144u);
+					}
+				}
+				return true; }();
+			(void) classes_env;
 			const uint32_t coarse_cap = (uint32_t) ngm::cs_heavy2_coarse_cap(A.lists_cap, m->max_kfreq);
 			n_heavy = status[1];
 			float t_heavy[2] = {0, 0};
@@ -456,13 +471,14 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 				if (m->d_heavy_list.reserve(no)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
 				int grid[3] = {0, 0, 0};
 				size_t lds[3] = {0, 0, 0}, scratch_words = 0;
+				auto ent_cap_of = [&](int c) -> uint32_t { return classes[c].max_parts > 1 ? classes[c].max_parts * ((3u << classes[c].log2s) / 4u) : 0u; };   // (bin, votes) entries of all table passes
 				for (int c = 0; c < 3; ++c) {
 					if (lists[c].empty()) continue;
 					lds[c] = ngm::cs_heavy2_lds_bytes(A.lists_cap, A.q, classes[c].log2c, classes[c].log2s, coarse_cap);
 					int per_cu = 0;
 					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, classes[c].fn, classes[c].nt, lds[c]) != hipSuccess || per_cu < 1) per_cu = 1;
 					grid[c] = (int) std::min<size_t>(lists[c].size(), (size_t) per_cu * cus);
-					scratch_words += (size_t) grid[c] * classes[c].scratch_cap;
+					scratch_words += (size_t) grid[c] * ((size_t) classes[c].scratch_cap + 2 * (size_t) ent_cap_of(c));
 				}
 				if (m->d_gt_keys.reserve(scratch_words)) { ngm::pipeline_set_error("out of device memory (candidate search scratch, %zu words)", scratch_words); return -12; }
 				hold();
@@ -474,6 +490,7 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_hits.p, keep_h.data(), (size_t) n_keep * 4, hipMemcpyHostToDevice, m->st));
 				}
 				MAP_HIP_TRY(hipMemsetAsync(m->d_heavy_ctr.p, 0, 32, m->st));
+				if (A.phase_cycles) { if (m->d_heavy_diag.reserve(64)) return -12; MAP_HIP_TRY(hipMemsetAsync(m->d_heavy_diag.p, 0, 64 * 8, m->st)); }
 				MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
 				uint32_t off = 0;
 				size_t soff = 0;
@@ -483,18 +500,29 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 					MAP_HIP_TRY(hipMemcpyAsync(m->d_heavy_list.p + off, lists[c].data(), (size_t) cnt * 4, hipMemcpyHostToDevice, m->st));
 					ngm::CsArgs Hv = A;
 					Hv.read_list = m->d_heavy_list.p + off; Hv.log2_bits = classes[c].log2c; Hv.log2_slots = classes[c].log2s;
-					uint32_t n_list = cnt, scap = classes[c].scratch_cap, ccap = coarse_cap;
+					uint32_t n_list = cnt, scap = classes[c].scratch_cap, ccap = coarse_cap, mparts = classes[c].max_parts, ecap = ent_cap_of(c);
 					uint32_t *ctr = m->d_heavy_ctr.p + c, *scr = m->d_gt_keys.p + soff;
-					void *kargs[] = {(void *) &Hv, (void *) &n_list, (void *) &ctr, (void *) &scr, (void *) &scap, (void *) &ccap};
+					unsigned long long *dg = A.phase_cycles ? m->d_heavy_diag.p + 16 * c : nullptr;
+					void *kargs[] = {(void *) &Hv, (void *) &n_list, (void *) &ctr, (void *) &scr, (void *) &scap, (void *) &ccap, (void *) &mparts, (void *) &ecap, (void *) &dg};
 					MAP_HIP_TRY(hipLaunchKernel(classes[c].fn, dim3(grid[c]), dim3(classes[c].nt), kargs, lds[c], m->st));
 					off += cnt;
-					soff += (size_t) grid[c] * classes[c].scratch_cap;
+					soff += (size_t) grid[c] * ((size_t) classes[c].scratch_cap + 2 * (size_t) ecap);
 				}
 				MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
 				yield();
 				MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
 				MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the lists live until here)
 				if (hipEventElapsedTime(&t_heavy[round], m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t_heavy[round];
+				if (A.phase_cycles) {
+					unsigned long long dg[64];
+					MAP_HIP_TRY(hipMemcpy(dg, m->d_heavy_diag.p, sizeof(dg), hipMemcpyDeviceToHost));
+					for (int c = 0; c < 3; ++c) if (dg[16 * c + 8]) {
+						const double ns = (double) dg[16 * c + 8];
+						fprintf(stderr, "[ngm-hip] heavy class %d (round %d, %zu reads, grid %d): us per sampled read: setup %.1f | sweep A %.1f | sum + T %.1f | insert / sweep B %.1f | row 2 %.1f | sweep D %.1f | candidates %.1f; hits %.0f, survivors %.0f, %.0f %% without a second row\n",
+								c, round, lists[c].size(), grid[c], dg[16 * c] / ns / 100.0, dg[16 * c + 1] / ns / 100.0, dg[16 * c + 2] / ns / 100.0, dg[16 * c + 3] / ns / 100.0, dg[16 * c + 4] / ns / 100.0,
+								dg[16 * c + 5] / ns / 100.0, dg[16 * c + 6] / ns / 100.0, dg[16 * c + 9] / ns, dg[16 * c + 11] / ns, 100.0 * dg[16 * c + 10] / ns);
+					}
+				}
 			}
 			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 1b (heavy reads): %.2f ms for %u reads; pass 1c (the largest class once more): %.2f ms for %u reads; %u left for the exact kernels\n",
 					t_heavy[0], in_round[0], t_heavy[1], in_round[1], status[1]);
@@ -800,6 +828,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
 	for (auto &e : m->cev) (void) hipEventCreate(&e);
+	for (auto &e : m->oev) (void) hipEventCreate(&e);
 	// fast-path geometry from the expected hits per read H = 2 (q - k) lists x average list length:
 	// bit planes >= 12 H bits (6-8 % of the single background hits collide and survive the filter),
 	// small exact table for the survivors + the real signal with headroom
@@ -937,7 +966,8 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_sam_quals.release(); m->d_sam_meta.release(); m->d_sam_refs.release(); m->d_sam_hits.release(); m->p_sam_hits.release(); m->p_sam_refs.release(); m->p_sam_extra.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
-	m->d_counters.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->d_order_info.release(); m->p_order_info.release(); m->d_order_big.release(); m->d_order_gt.release(); m->d_order_log2.release(); m->d_order_off.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
+	for (auto &e : m->oev) if (e) (void) hipEventDestroy(e);
+	m->d_counters.release(); m->d_heavy_diag.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->d_order_info.release(); m->p_order_info.release(); m->d_order_big.release(); m->d_order_gt.release(); m->d_order_log2.release(); m->d_order_off.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	m->d_str.release(); m->d_cigout.release(); m->p_cigout.release(); m->p_str.release();
@@ -998,6 +1028,7 @@ static int candidate_order_wait(ngm_mapper *m, uint32_t **h_rank) {
 // bins than its table: CsArgs::order_info) and replay those exactly in global memory.  No read keeps an undetermined order silently.
 static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 	MAP_HIP_TRY(hipStreamSynchronize(ost));
+	{ float t = 0; if (hipEventElapsedTime(&t, m->oev[0], m->oev[1]) == hipSuccess) m->order_ms += t; }
 	const uint32_t nl = (uint32_t) m->order_pending.size();
 	m->st_order_reads += nl;
 	std::vector<uint32_t> big;
@@ -1018,12 +1049,12 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 			uint32_t l = 11;
 			while ((1ull << l) < want && l < 30) ++l;
 			reads[j] = rd; lg[j] = l;
-			words[j] = (5ull << l) + hits + 64;
+			words[j] = (6ull << l) + 2 * (hits + 64) + 64;   // table (5 words per slot), time line, hit times by (slot, strand), the slots in use
 		}
 		if (m->d_order_big.reserve(nb) || m->d_order_log2.reserve(nb) || m->d_order_off.reserve(nb)) { ngm::pipeline_set_error("out of device memory (exact candidate order)"); return -12; }
 		ngm::CsArgs G = m->order_args;
 		G.order_info = nullptr; G.order_scratch = nullptr; G.order_gcap = 0; G.order_max_hits = 0; G.phase_cycles = nullptr;
-		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
+		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + ngm::cs_order_tau(G.lists_cap) + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
 		// (8 GB per launch: a read with 50 000 hits takes 2.6 MB of table and time line, and with the 1.5 GB pool of the first version the
 		// 5 500 such reads of a heavy-tailed batch went through ten launches of ~570 workgroups each -- two per CU, 118 ms of waiting per batch)
 		constexpr uint64_t kPoolWords = 2048ull << 20;
@@ -1036,9 +1067,12 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_log2.p + j0, lg.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, ost));
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_off.p + j0, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, ost));
 			G.read_list = m->d_order_big.p + j0; G.ovf_log2 = m->d_order_log2.p + j0; G.ovf_table_off = m->d_order_off.p + j0; G.gtable_keys = m->d_order_gt.p;
+			MAP_HIP_TRY(hipEventRecord(m->oev[2], ost));
 			hipLaunchKernelGGL(ngm::cs_order_kernel<true>, dim3(j1 - j0), dim3(ngm::kCsOrderThreads), lds, ost, G, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
 			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipEventRecord(m->oev[3], ost));
 			MAP_HIP_TRY(hipStreamSynchronize(ost));   // (reads, lg, off of this launch are consumed; the pool is reused by the next one)
+			{ float t = 0; if (hipEventElapsedTime(&t, m->oev[2], m->oev[3]) == hipSuccess) m->order_ms += t; }
 			j0 = j1;
 		}
 		MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
@@ -1086,20 +1120,23 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	static const size_t lds_budget_kb = getenv("NGM_HIP_ORDER_LDS_KB") ? (size_t) atoi(getenv("NGM_HIP_ORDER_LDS_KB")) : 80;  // (tuning)
 	const size_t lds_budget = lds_budget_kb * 1024;
 	if (A.bs) A.lists_cap = 2 * 3072;   // bisulfite mapping: the lists of all k-mer variants of a read (more: that read keeps the position order)
-	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ((size_t) 5 << ngm::kCsOrderLog2Slots) + (A.bs ? (size_t) A.q + 1 + A.lists_cap / 4 + 1 : 0)) * 4;
-	const size_t hits_room = lds_fixed + 4 * (size_t) ngm::kCsOrderMaxHits < lds_budget ? (lds_budget - 64 - lds_fixed) / 4 : (size_t) ngm::kCsOrderMaxHits;
+	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ngm::cs_order_tau(A.lists_cap) + ((size_t) 5 << ngm::kCsOrderLog2Slots) + (A.bs ? (size_t) A.q + 1 + A.lists_cap / 4 + 1 : 0)) * 4;
+	// (two arrays of that many entries: the time line and the hit times sorted by bin and strand)
+	const size_t hits_room = lds_fixed + 8 * (size_t) ngm::kCsOrderMaxHits < lds_budget ? (lds_budget - 64 - lds_fixed) / 8 : (size_t) ngm::kCsOrderMaxHits;
 	A.order_max_hits = (uint32_t) std::max<size_t>(ngm::kCsOrderMaxHits, std::min<size_t>(hits_room, 65535));  // (all of the budget: two workgroups per CU either way)
-	const size_t lds = lds_fixed + (size_t) A.order_max_hits * 4;
+	const size_t lds = lds_fixed + (size_t) A.order_max_hits * 8;
 	// reads with more hits than the LDS time line holds use a slice of a global scratch: launches of at most 4096 reads
 	constexpr uint32_t kChunk = 4096, kGcap = 49152;
-	if (m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap)) { A.order_scratch = nullptr; A.order_gcap = 0; }
+	if (m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap * 2)) { A.order_scratch = nullptr; A.order_gcap = 0; }   // (time line + hit times per workgroup)
 	else { A.order_scratch = m->d_order_scratch.p; A.order_gcap = kGcap; }
+	MAP_HIP_TRY(hipEventRecord(m->oev[0], ost));
 	for (uint32_t off = 0; off < nl; off += kChunk) {
 		A.read_list = m->d_order_list.p + off;
 		A.order_info = m->d_order_info.p + 2 * (size_t) off;
 		hipLaunchKernelGGL(ngm::cs_order_kernel<false>, dim3(std::min(kChunk, nl - off)), dim3(ngm::kCsOrderThreads), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
 		MAP_HIP_TRY(hipGetLastError());
 	}
+	MAP_HIP_TRY(hipEventRecord(m->oev[1], ost));
 	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
 	MAP_HIP_TRY(hipMemcpyAsync(m->p_order_info.p, m->d_order_info.p, 2 * (size_t) nl * 4, hipMemcpyDeviceToHost, ost));
 	m->order_args = A;
@@ -1406,6 +1443,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 	const int q = m->prm.qry_max_len, c = m->prm.corridor, mode = m->prm.mode;
 	const size_t str_stride = (size_t) 4 * std::max(1, q);
 	for (auto &x : m->ms) x = 0.f;
+	m->order_ms = 0.f;
 
 	// reads already in HBM: alias them as the batch (no copy); otherwise upload
 	ngm::DevBuf<uint8_t> own = m->d_reads;
@@ -1678,10 +1716,11 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// Which tied pairs will stay open in the sequential pass?  Those whose equally scoring pairs also share the insert size
 			// (`dup`: the candidate order decides) -- and those whose best-scoring pair closest to the mean is not the same unique one
 			// over the range the mean can have when their turn comes.  That range is only known inside the turn (pass 2 carries exact
-			// bounds); the mean of thousands of insert sizes hardly moves, so outside the turn the pairs are picked with the last
-			// PUBLISHED mean +- 3: their candidate order is replayed and their combinations are listed (pass 3) before the turn
-			// begins.  A pair that pass 2 leaves open without having been picked here (the first batches of a run, while the mean
-			// still moves) is handled inside the turn, as every open pair was before round 5.
+			// bounds); the mean of thousands of insert sizes hardly moves, so outside the turn pass 2 runs SPECULATIVELY from the last
+			// PUBLISHED mean +- 3 -- bounds that contain the exact ones leave a superset of the exact pass's pairs open -- and the pairs
+			// it leaves open have their candidate order replayed and their combinations listed (pass 3) before the turn begins.  A
+			// pair that the exact pass 2 leaves open without having been picked here (the first batches of a run, while the mean still
+			// moves by more than 3) is handled inside the turn, as every open pair was before round 5.
 			auto closest_top = [](const Tied &t, long avg, bool *unique) {
 				int best = 0, n_best = 0; long best_c = LONG_MAX;
 				for (int x = 0; x < t.n_top; ++x) {
@@ -1698,15 +1737,33 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				*which = x_lo;
 				return x_lo == x_hi && u_lo && u_hi;
 			};
+			// pass 2 itself (see below), from a given state of the running mean: exact -- it commits what it closes -- or speculative
+			auto pass2 = [&](long sum_lo, long sum_hi, long cnt, bool exact, std::vector<int> &left_open) {
+				for (size_t x = 0; x < tied.size(); ++x) {
+					Tied &t = tied[x];
+					sum_lo += t.gap_sum; sum_hi += t.gap_sum; cnt += t.gap_cnt;
+					const long a_lo = sum_lo / std::max(1L, cnt), a_hi = sum_hi / std::max(1L, cnt);
+					if (exact) { t.avg_lo = a_lo; t.avg_hi = a_hi; }
+					if (!t.found) continue;
+					int which = 0;
+					if (closed_between(t, a_lo, a_hi, &which)) {
+						if (exact) {
+							commit(2 * t.pi + 1, 2 * t.pi, true, t.top_a[which], t.top_b[which], t.mqa, t.mqb, 0);
+							t.dist = t.top_d[which];
+							t.open = false;
+						}
+						sum_lo += t.top_d[which]; sum_hi += t.top_d[which]; ++cnt;
+						continue;
+					}
+					left_open.push_back((int) x);
+					sum_lo += t.dmin; sum_hi += t.dmax; ++cnt;
+				}
+			};
 			long pub_sum = m->pair_dist_sum, pub_cnt = m->pair_dist_count;
 			if (m->ps && !pair_turn.held) { std::lock_guard<std::mutex> lk(m->ps->mu); pub_sum = m->ps->dist_sum; pub_cnt = m->ps->dist_count; }
-			const long pub_avg = pub_sum / std::max(1L, pub_cnt);
 			std::vector<int> picked;   // indices into `tied`
-			for (size_t x = 0; x < tied.size(); ++x) {
-				Tied &t = tied[x];
-				int which = 0;
-				if (t.found && (pe_strata || !closed_between(t, pub_avg - 3, pub_avg + 3, &which))) picked.push_back((int) x);
-			}
+			if (pe_strata) { for (size_t x = 0; x < tied.size(); ++x) if (tied[x].found) picked.push_back((int) x); }
+			else pass2(pub_sum - 3 * pub_cnt, pub_sum + 3 * pub_cnt, pub_cnt, false, picked);   // (bounds that contain the exact ones leave a superset of the exact pass's pairs open)
 			std::vector<uint32_t> need;
 			need.reserve(2 * picked.size() + se_tied.size());
 			for (int x : picked) { need.push_back((uint32_t) (2 * tied[x].pi)); need.push_back((uint32_t) (2 * tied[x].pi + 1)); }
@@ -1759,23 +1816,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			// pair simply waits for pass 4.)
 			std::vector<int> late;   // left open without having been picked above
 			if (!pe_strata) {
-				long sum_lo = m->pair_dist_sum, sum_hi = m->pair_dist_sum, cnt = m->pair_dist_count;
-				for (size_t x = 0; x < tied.size(); ++x) {
-					Tied &t = tied[x];
-					sum_lo += t.gap_sum; sum_hi += t.gap_sum; cnt += t.gap_cnt;
-					t.avg_lo = sum_lo / std::max(1L, cnt); t.avg_hi = sum_hi / std::max(1L, cnt);
-					if (!t.found) continue;
-					int which = 0;
-					if (closed_between(t, t.avg_lo, t.avg_hi, &which)) {
-						commit(2 * t.pi + 1, 2 * t.pi, true, t.top_a[which], t.top_b[which], t.mqa, t.mqb, 0);
-						t.dist = t.top_d[which];
-						sum_lo += t.top_d[which]; sum_hi += t.top_d[which]; ++cnt;
-						t.open = false;
-						continue;
-					}
-					if (t.seq < 0) late.push_back((int) x);
-					sum_lo += t.dmin; sum_hi += t.dmax; ++cnt;
-				}
+				std::vector<int> left_open;
+				pass2(m->pair_dist_sum, m->pair_dist_sum, m->pair_dist_count, true, left_open);
+				for (int x : left_open) if (tied[x].seq < 0) late.push_back(x);
 			}
 			qlap(3);
 			size_t n_open = 0;
@@ -2083,7 +2126,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		if (m->d_sam_len.reserve((size_t) units + 1) || m->d_sam_off.reserve((size_t) units + 1)) { ngm::pipeline_set_error("out of device memory (SAM stage)"); return -12; }
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_hits.p, hits, (size_t) n * sizeof(ngm_hit), hipMemcpyHostToDevice, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(m->d_sam_refs.p, sam_refs, (size_t) n * sizeof(ngm::SamRef), hipMemcpyHostToDevice, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 16, 0, 32, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p + 16, 0, 64, m->st));
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the uploads -- 64 bytes per read -- travel outside the stage lock)
 		stage_sam.acquire();
 		ngm::SamArgs S{};
@@ -2111,13 +2154,13 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(hipMemsetAsync(m->d_sam_len.p + units, 0, 4, m->st));
 			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_sam_len.p, m->d_sam_off.p, 0u, (size_t) units + 1, rocprim::plus<uint32_t>(), m->st));
 			uint32_t total32 = 0;
-			unsigned long long longest = 0;
+			unsigned long long total64 = 0;
 			stage_sam.before_sync();
 			MAP_HIP_TRY(hipMemcpyAsync(&total32, m->d_sam_off.p + units, 4, hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipMemcpyAsync(&longest, m->d_total.p + 19, 8, hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipMemcpyAsync(&total64, m->d_total.p + 19, 8, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
-			if (longest > 0) {   // a unit longer than the bound the 32-bit check above was made with: the prefix sums may have wrapped
-				ngm::pipeline_set_error("ngm_mapper_map_sam: a record of %llu bytes exceeds the %u bytes per read this batch was sized for (32-bit text offsets): use smaller batches", longest, S.unit_len_bound);
+			if (total64 != (unsigned long long) total32) {   // the 32-bit prefix sums have wrapped (detected directly, not through a per-record bound)
+				ngm::pipeline_set_error("ngm_mapper_map_sam: the text of this batch of %d reads is %llu bytes, beyond the 32-bit offsets of a batch: use smaller batches", n, total64);
 				return -75;
 			}
 			total = total32;
@@ -2129,8 +2172,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		}
 		MAP_HIP_TRY(hipEventRecord(e1, m->st));
 		stage_sam.kernels_done();
-		unsigned long long ctr[3] = {0, 0, 0};
-		MAP_HIP_TRY(hipMemcpyAsync(ctr, m->d_total.p + 16, 24, hipMemcpyDeviceToHost, m->st));
+		unsigned long long ctr[7] = {0, 0, 0, 0, 0, 0, 0};
+		MAP_HIP_TRY(hipMemcpyAsync(ctr, m->d_total.p + 16, 56, hipMemcpyDeviceToHost, m->st));
 		m->sam_text_bytes = total;
 		const bool bam = m->sam_opt.bam != 0;
 		if (!bam && total <= sam->out_cap && total > 0) MAP_HIP_TRY(hipMemcpyAsync(sam->out, m->d_sam_text.p, (size_t) total, hipMemcpyDeviceToHost, m->st));
@@ -2151,6 +2194,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			}
 		}
 		if (sam->stats) { sam->stats[0] = ctr[0]; sam->stats[1] = ctr[1]; sam->stats[2] = ctr[2]; }
+		m->pair_stats[0] = ctr[4]; m->pair_stats[1] = ctr[5]; m->pair_stats[2] = ctr[6];
 		float t = 0;
 		sam->kernel_ms = (hipEventElapsedTime(&t, e0, e1) == hipSuccess ? t : 0.f) + bgzf_ms;
 		lap(5);
@@ -2254,6 +2298,14 @@ int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]) {
 int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]) {
 	if (!m) return -22;
 	out[0] = m->cs_kmers; out[1] = m->cs_hits; out[2] = m->n_cand;
+	return 0;
+}
+
+float ngm_mapper_last_order_replay_ms(ngm_mapper *m) { return m ? m->order_ms : 0.f; }
+
+int ngm_mapper_last_pair_stats(ngm_mapper *m, uint64_t out[3]) {
+	if (!m || !out) return -22;
+	out[0] = m->pair_stats[0]; out[1] = m->pair_stats[1]; out[2] = m->pair_stats[2];
 	return 0;
 }
 

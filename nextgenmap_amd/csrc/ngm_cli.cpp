@@ -129,6 +129,8 @@ struct Opts {
 	int very_fast = 0, fast = 0, sensitive = 0, very_sensitive = 0, variant = NGM_VARIANT_OCL_GPU;
 	float sensitivity = -1.f, kmer_min = 0.f, min_identity = 0.65f, min_residues = 0.5f;
 	int batch = 1 << 18;
+	int stats_fd = -1;   // --stats-fd (set by the parent of shard processes): this shard's int64[8] statistics go there
+	int ref_score_buffer = -1;   // --reference-score-buffer: entries of NextGenMap's score buffer whose lost pairs are mirrored (-1: 1 024 with --affine, else 0 = none)
 	std::string cmdline;
 };
 
@@ -139,7 +141,7 @@ Opts parse(int argc, char **argv) {
 	Opts o;
 	for (int i = 1; i < argc; ++i) { if (i > 1) o.cmdline += " "; o.cmdline += argv[i]; }  // Config.cpp:565-574
 	enum { KSKIP = 1000, HARD, SILENT, KMIN, MB, MMP, GRP, GFP, MAXCMRS, NOUNAL, NOPROG, MAXRL, BINSZ, MAXKF, VFAST, FAST, SENS, VSENS, DEVICE,
-		SKIPSAVE, BATCH, VARIANT, SHARD, SHARDOUT, KEEPSHARDS, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, FASTPAIR, BROKENPAIRS, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
+		SKIPSAVE, BATCH, VARIANT, SHARD, SHARDOUT, KEEPSHARDS, BAMOUT, WORKERS, SERIAL, AFFINE, GEP, PEDELIM, STRATA, BSMAP, BSCUT, MBTT, MBTC, SLAM, FASTPAIR, BROKENPAIRS, REFSCOREBUF, STATSFD, RG0, RG_LAST = RG0 + 11, UNSUPPORTED };
 	static const option lo[] = {
 		{"ref", required_argument, 0, 'r'}, {"qry", required_argument, 0, 'q'}, {"output", required_argument, 0, 'o'},
 		{"cpu-threads", required_argument, 0, 't'}, {"gpu", no_argument, 0, 'g'}, {"sensitivity", required_argument, 0, 's'},
@@ -160,7 +162,7 @@ Opts parse(int argc, char **argv) {
 		{"rg-dt", required_argument, 0, RG0 + 3}, {"rg-fo", required_argument, 0, RG0 + 4}, {"rg-ks", required_argument, 0, RG0 + 5},
 		{"rg-lb", required_argument, 0, RG0 + 6}, {"rg-pg", required_argument, 0, RG0 + 7}, {"rg-pi", required_argument, 0, RG0 + 8},
 		{"rg-pl", required_argument, 0, RG0 + 9}, {"rg-pu", required_argument, 0, RG0 + 10}, {"rg-sm", required_argument, 0, RG0 + 11},
-		{"fast-pairing", no_argument, 0, FASTPAIR}, {"broken-pairs", no_argument, 0, BROKENPAIRS},
+		{"fast-pairing", no_argument, 0, FASTPAIR}, {"broken-pairs", no_argument, 0, BROKENPAIRS}, {"reference-score-buffer", required_argument, 0, REFSCOREBUF}, {"stats-fd", required_argument, 0, STATSFD},
 		{"affine", no_argument, 0, AFFINE}, {"gap-extend-penalty", required_argument, 0, GEP}, {"bam", no_argument, 0, BAMOUT}, {"workers", required_argument, 0, WORKERS}, {"serial-reader", no_argument, 0, SERIAL}, {"bs-mapping", no_argument, 0, BSMAP},
 		{"bs-cutoff", required_argument, 0, BSCUT}, {"match-bonus-tt", required_argument, 0, MBTT}, {"match-bonus-tc", required_argument, 0, MBTC},
 		{"slam-seq", required_argument, 0, SLAM}, {"topn", required_argument, 0, 'n'}, {"strata", no_argument, 0, STRATA},
@@ -239,6 +241,8 @@ Opts parse(int argc, char **argv) {
 		case SHARDOUT: o.shard_output = 1; break;
 		case KEEPSHARDS: o.keep_shards = 1; break;
 		case FASTPAIR: o.fast_pairing = 1; break;
+		case REFSCOREBUF: o.ref_score_buffer = std::max(0, atoi(optarg)); break;
+		case STATSFD: o.stats_fd = atoi(optarg); break;
 		case BROKENPAIRS: o.broken_pairs = 1; break;
 		case UNSUPPORTED: die(std::string("option --") + lo[idx].name + " is not supported by the HIP backend yet");
 		default: die("unknown option (see src/config/Options.h of NextGenMap for the option set)");
@@ -272,6 +276,9 @@ Opts parse(int argc, char **argv) {
 	if (o.gap_read < 0) o.gap_read = o.affine ? 33 : 20;
 	if (o.gap_ref < 0) o.gap_ref = o.affine ? 33 : 20;
 	if (o.gap_extend < 0) o.gap_extend = o.affine ? 3 : 5;
+	// the pairs NextGenMap loses (ngm_mapper_set_reference_score_buffer): its SeqAn personality scores in batches of 1 024
+	// (src/seqan/EndToEndAffine.h:44-46); the OpenCL personality's batch depends on the device it finds -- nothing to mirror by default
+	if (o.ref_score_buffer < 0) o.ref_score_buffer = o.affine ? 1024 : 0;
 	if (o.devices.empty()) o.devices.assign(1, o.device);
 	o.device = o.devices[0];
 	if (getenv("NGM_HIP_WORKERS")) o.workers = std::max(1, atoi(getenv("NGM_HIP_WORKERS")));
@@ -640,11 +647,27 @@ int run_sharded(int argc, char **argv, const Opts &o) {
 			if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0) die("building the index failed (its messages are above)");
 		}
 	}
+	// The one collective of the path: every shard's int64[8] statistics, summed.  The shards hand their vectors to this
+	// process over a pipe each -- that sum is printed in any case -- and, on distinct GPUs, also run the ncclAllReduce among themselves
+	// (RCCL over xGMI; the communicator id made here travels in their environment).
+	bool distinct = true;
+	for (int a = 0; a < N; ++a) for (int b = a + 1; b < N; ++b) if (o.devices[a] == o.devices[b]) distinct = false;
+	if (distinct && !getenv("NGM_HIP_NO_RCCL")) {
+		char hex[257];
+		if (ngm_stats_unique_id(hex) == 0) setenv("NGM_HIP_RCCL_ID", hex, 1);
+		else info("MAIN", std::string("note: no RCCL all-reduce of the statistics (") + ngm_pipeline_last_error() + "); summing the shards' vectors here");
+	} else unsetenv("NGM_HIP_RCCL_ID");
+	std::vector<int> stat_rd(N, -1);
 	for (int k = 0; k < N; ++k) {
+		int pfd[2];
+		if (pipe(pfd) != 0) die("pipe failed");
+		stat_rd[k] = pfd[0];
 		const pid_t pid = fork();
 		if (pid < 0) die("fork failed");
 		if (pid == 0) {
+			for (int j = 0; j <= k; ++j) close(stat_rd[j]);
 			std::vector<std::string> a(argv, argv + argc);
+			a.push_back("--stats-fd"); a.push_back(std::to_string(pfd[1]));
 			a.push_back("--device"); a.push_back(std::to_string(o.devices[k]));
 			a.push_back("--shard"); a.push_back(std::to_string(k) + "/" + std::to_string(N));
 			a.push_back("-o"); a.push_back(parts[k]);
@@ -654,11 +677,27 @@ int run_sharded(int argc, char **argv, const Opts &o) {
 			execv("/proc/self/exe", av.data());
 			_exit(127);
 		}
+		close(pfd[1]);
 		kids.push_back(pid);
+	}
+	long long total[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	int got = 0;
+	for (int k = 0; k < N; ++k) {   // (64 bytes each, written when a shard is done: read until its end of file)
+		int64_t v[8];
+		size_t have = 0;
+		while (have < sizeof(v)) { const ssize_t r = read(stat_rd[k], (char *) v + have, sizeof(v) - have); if (r <= 0) break; have += (size_t) r; }
+		close(stat_rd[k]);
+		if (have == sizeof(v)) { ++got; for (int j = 0; j < 8; ++j) total[j] += v[j]; }
 	}
 	bool ok = true;
 	for (pid_t pid : kids) { int st = 0; if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
 	if (!ok) die("a shard process failed (its messages are above)");
+	if (got == N) {
+		char dm[400];
+		snprintf(dm, sizeof(dm), "Done, %d shards summed (%lld reads mapped (%.2f%%), %lld reads not mapped, %lld lines written; %lld reads; %lld pairs with both mates mapped, %lld of them broken, mean insert size %.1f)",
+				N, total[1], total[0] ? 100.0 * total[1] / total[0] : 0.0, total[2], total[3], total[0], total[4], total[5], total[7] > 0 ? (double) total[6] / (double) total[7] : 0.0);
+		info("MAIN", dm);
+	} else info("MAIN", "warning: not every shard handed over its statistics");
 	if (o.keep_shards) { info("MAIN", "Shards written: " + parts[0] + " .. " + parts.back() + " (concatenate in this order)"); return 0; }
 	const auto t0 = std::chrono::steady_clock::now();
 	if (rename(parts[0].c_str(), o.out.c_str()) != 0) die("cannot rename " + parts[0]);
@@ -694,7 +733,21 @@ int main(int argc, char **argv) {
 	mallopt(M_TOP_PAD, 64 << 20);
 	const auto t_process = std::chrono::steady_clock::now();
 	Opts o = parse(argc, argv);
-	if (o.shard_output && o.devices.size() > 1 && o.shard_n == 1 && !o.out.empty() && !(o.qry.empty() && o.qry1.empty())) return run_sharded(argc, argv, o);
+	if (o.shard_output && (o.devices.size() > 1 || getenv("NGM_HIP_SHARD_SINGLE")) && o.shard_n == 1 && !o.out.empty() && !(o.qry.empty() && o.qry1.empty())) return run_sharded(argc, argv, o);
+	// a shard process of `-g a,b,... --shard-output` on distinct GPUs: join the communicator of the one collective of the path (the final
+	// statistics all-reduce, RCCL over xGMI) NOW, on a thread of its own -- ncclCommInitRank takes about a second, the load of the index hides it
+	ngm_stats_comm *stats_comm = nullptr;
+	std::string stats_comm_error;
+	std::thread stats_comm_thread;
+	if (const char *id = getenv("NGM_HIP_RCCL_ID")) {
+		if (o.shard_n >= 1 && o.stats_fd >= 0) {
+			const std::string id_s = id;
+			stats_comm_thread = std::thread([&, id_s] {
+				stats_comm = ngm_stats_comm_create(o.device, o.shard_i, o.shard_n, id_s.c_str());
+				if (!stats_comm) stats_comm_error = ngm_pipeline_last_error();
+			});
+		}
+	}
 	// bisulfite mapping: the index holds every reference k-mer, the run's kmer_skip applies to the reads (src/PrefixTable.cpp:199-207, src/CS.cpp:556-560)
 	ngm_ref_params rp{o.kmer, o.bs_mapping ? 0 : o.kmer_skip, o.bin_size};
 	info("MAIN", "NextGenMap-compatible HIP backend (gfx950)");
@@ -1032,6 +1085,7 @@ int main(int argc, char **argv) {
 			if (ngm_mapper_set_sam_options(workers[w].m, &so) < 0) die(ngm_pipeline_last_error());
 		}
 		ngm_mapper_set_reference_cs_batch(workers[w].m, 1800000 / std::max(1, avg_len));
+		ngm_mapper_set_reference_score_buffer(workers[w].m, o.ref_score_buffer);
 		if (gpu_bgzf) {
 			workers[w].bz = ngm_bgzf_create(o.devices[w % o.devices.size()]);
 			if (!workers[w].bz) die(ngm_pipeline_last_error());
@@ -1191,7 +1245,12 @@ int main(int argc, char **argv) {
 		++n_written;
 	};
 	// one worker's batch, records [lo, hi) (paired: lo and hi even) -> SAM text + counters
+	// AlignmentBuffer::WriteRead's pair counters (src/AlignmentBuffer.cpp:175-199): pairs with both mates mapped, those of them broken, the
+	// others' insert sizes -- summed over the run (the GPU formatter counts the same: ngm_mapper_last_pair_stats)
+	std::atomic<uint64_t> pair_stat[3];
+	for (auto &x : pair_stat) x = 0;
 	auto format_range = [&](const Batch &b, const Worker &w, int lo, int hi, std::string &s, size_t &n_total, size_t &n_mapped, size_t &n_written) {
+		struct PairAcc { std::atomic<uint64_t> *t; uint64_t v[3] = {0, 0, 0}; ~PairAcc() { for (int k = 0; k < 3; ++k) if (v[k]) t[k] += v[k]; } } pacc{pair_stat};
 		auto view = [&](int i, int t = 0) {
 			const size_t e = (size_t) i * topn + t;
 			View v{&b.recs[i], &w.hits[e], w.rows + (size_t) i * q, 0, &w.cig[e * stride], &w.md[e * stride]};
@@ -1258,7 +1317,9 @@ int main(int argc, char **argv) {
 			bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
 			if (h1.mapped && h2.mapped) {
 				const long long distance = (h2.pos > h1.pos) ? (long long) (h2.pos - h1.pos) + v1.L : (long long) (h1.pos - h2.pos) + v2.L;
-				if (h1.contig != h2.contig || distance < o.min_insert || distance > max_insert || h1.reverse == h2.reverse) paired_fail = true;
+				++pacc.v[0];
+				if (h1.contig != h2.contig || distance < o.min_insert || distance > max_insert || h1.reverse == h2.reverse) { paired_fail = true; ++pacc.v[1]; }
+				else pacc.v[2] += (uint64_t) distance;
 			}
 			const bool m1 = passes(v1), m2 = passes(v2);  // GenericReadWriter::WritePair
 			n_mapped += (m1 ? 1 : 0) + (m2 ? 1 : 0);
@@ -1589,6 +1650,7 @@ int main(int argc, char **argv) {
 				}
 				if (len < 0) { fail(ngm_pipeline_last_error()); std::lock_guard<std::mutex> lk(text_mu); if (tb.p) text_free.push_back(tb); text_cv.notify_one(); continue; }
 				t_map_us += us_since(tm);
+				if (o.paired) { uint64_t ps3[3] = {0, 0, 0}; if (ngm_mapper_last_pair_stats(w.m, ps3) == 0) for (int k2 = 0; k2 < 3; ++k2) pair_stat[k2] += ps3[k2]; }
 				{ float kms[8] = {0}; if (ngm_mapper_last_kernel_ms(w.m, kms) == 0) { double sum = sam_ms; for (int k2 = 0; k2 < 7; ++k2) sum += kms[k2]; t_gpu_us += (long long) (sum * 1000.0); } }
 				t_sam_gpu_us += (long long) (sam_ms * 1000.0);
 				b->text = tb.p; b->text_cap = tb.cap; b->text_len = (size_t) len;
@@ -1768,6 +1830,30 @@ int main(int argc, char **argv) {
 	else snprintf(msg, sizeof(msg), "Done (%zu reads mapped (%.2f%%), %zu reads not mapped, %zu lines written)", n_mapped,
 			n_total ? 100.0 * n_mapped / n_total : 0.0, n_total - n_mapped, n_written);
 	info("MAIN", msg);
+	{
+		// this process's share of the mapping statistics
+		int64_t sv[8] = {(int64_t) n_read, (int64_t) n_mapped, (int64_t) (n_read - n_mapped), (int64_t) n_written, (int64_t) pair_stat[0].load(), (int64_t) pair_stat[1].load(),
+				(int64_t) pair_stat[2].load(), (int64_t) (pair_stat[0].load() - pair_stat[1].load())};
+		if (o.stats_fd >= 0) {   // a shard process: the parent sums the shards' vectors
+			if (write(o.stats_fd, sv, sizeof(sv)) != (ssize_t) sizeof(sv)) info("MAIN", "warning: could not hand the statistics to the parent process");
+			close(o.stats_fd);
+		}
+		if (stats_comm_thread.joinable()) stats_comm_thread.join();
+		if (stats_comm) {
+			const auto t_ar = std::chrono::steady_clock::now();
+			int64_t all[8];
+			memcpy(all, sv, sizeof(all));
+			if (ngm_stats_allreduce(stats_comm, all) == 0) {
+				if (o.shard_i == 0) {
+					snprintf(msg, sizeof(msg), "Statistics all-reduce over %d GPUs (RCCL, %.0f us): %lld reads, %lld mapped, %lld not mapped, %lld lines written; %lld pairs with both mates mapped, %lld of them broken, mean insert size %.1f",
+							o.shard_n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_ar).count(), (long long) all[0], (long long) all[1], (long long) all[2], (long long) all[3],
+							(long long) all[4], (long long) all[5], all[7] > 0 ? (double) all[6] / (double) all[7] : 0.0);
+					info("MAIN", msg);
+				}
+			} else info("MAIN", std::string("warning: statistics all-reduce failed: ") + ngm_pipeline_last_error());
+			ngm_stats_comm_destroy(stats_comm);
+		} else if (!stats_comm_error.empty() && o.shard_i == 0) info("MAIN", "note: no RCCL communicator for the statistics (" + stats_comm_error + "); the parent process sums them");
+	}
 	snprintf(msg, sizeof(msg), "Mapping pass: %.3f s, %.0f reads/s (%zu GPU(s) x %d worker(s), %d host threads, %s input)", secs, n_total / std::max(1e-9, secs),
 			o.devices.size(), o.workers, pool.size(), plain ? (mf0.owned ? "gzip FASTQ inflated to memory" : "memory-mapped plain FASTQ") : "serial reader");
 	info("MAIN", msg);

@@ -26,7 +26,7 @@ struct SamMeta {            // per read
 struct SamRef { uint32_t cig_off, md_off; uint16_t cig_len, md_len; };   // the read's CIGAR / MD in the byte stream
 
 struct SamArgs {
-	uint32_t unit_len_bound;   // bytes per unit the host's 32-bit overflow check allowed for (sam_lengths_kernel reports longer units in counters[3])
+	uint32_t unit_len_bound;   // (unused since round 5: the 32-bit offsets are checked against the 64-bit sum of the lengths, counters[3])
 	int n, q, paired;
 	const uint8_t *reads;       // n rows of q bytes
 	const uint8_t *quals;       // n rows of q bytes
@@ -355,9 +355,10 @@ __device__ __forceinline__ void sam_unmapped(const SamArgs &A, Sink &s, const Sa
 	s.put('\n');
 }
 
-// one unit: read `unit` (single-end) or reads 2 * unit, 2 * unit + 1 (paired).  cnt: reads counted / mapped, lines written
+// one unit: read `unit` (single-end) or reads 2 * unit, 2 * unit + 1 (paired).  cnt: reads counted / mapped, lines written; pairs with
+// both mates mapped, of those broken, insert size of the others (AlignmentBuffer.cpp:175-199 pairInsertCount / brokenPairs / pairInsertSum)
 template <typename Sink>
-__device__ __forceinline__ void sam_unit(const SamArgs &A, int unit, Sink &s, uint32_t (&cnt)[3]) {
+__device__ __forceinline__ void sam_unit(const SamArgs &A, int unit, Sink &s, uint32_t (&cnt)[6]) {
 	if (!A.paired) {
 		const SamView v = sam_view(A, unit);
 		if (v.m.qual_len & 0x8000u) return;  // NGMNames::Empty reads are discarded (GenericReadWriter.h:245-247)
@@ -377,7 +378,9 @@ __device__ __forceinline__ void sam_unit(const SamArgs &A, int unit, Sink &s, ui
 	bool paired_fail = (h1.pair_flags & NGM_PAIR_FAILED) || (h2.pair_flags & NGM_PAIR_FAILED);
 	if (h1.mapped && h2.mapped) {
 		const long long distance = (h2.pos > h1.pos) ? (long long) (h2.pos - h1.pos) + v1.L : (long long) (h1.pos - h2.pos) + v2.L;
-		if (h1.contig != h2.contig || distance < A.min_insert || distance > A.max_insert || h1.reverse == h2.reverse) paired_fail = true;
+		++cnt[3];
+		if (h1.contig != h2.contig || distance < A.min_insert || distance > A.max_insert || h1.reverse == h2.reverse) { paired_fail = true; ++cnt[4]; }
+		else cnt[5] += (uint32_t) distance;
 	}
 	const bool m1 = sam_passes(A, v1), m2 = sam_passes(A, v2);  // GenericReadWriter::WritePair
 	cnt[1] += (m1 ? 1u : 0u) + (m2 ? 1u : 0u);
@@ -418,30 +421,37 @@ __device__ __forceinline__ void sam_unit(const SamArgs &A, int unit, Sink &s, ui
 
 #ifdef NGM_SAM_KERNELS
 __global__ __launch_bounds__(256) void sam_lengths_kernel(SamArgs A, int units) {
-	const int u = blockIdx.x * blockDim.x + threadIdx.x;
-	if (u >= units) return;
-	SamCountSink s;
-	uint32_t cnt[3] = {0, 0, 0};
-	sam_unit(A, u, s, cnt);
-	A.unit_len[u] = s.n;
-	// the batch's offsets are 32-bit prefix sums: the host bounds the batch by a per-unit length (mapper.cpp) and checks it against
-	// the longest unit here (MP:Z / RA:Z of a SLAM-seq run can outgrow any fixed estimate)
-	const uint32_t names = A.paired ? (uint32_t) A.meta[2 * u].name_len + A.meta[2 * u + 1].name_len : (uint32_t) A.meta[u].name_len;   // (counted separately by the host)
-	if (s.n > A.unit_len_bound + names) atomicMax(&A.counters[3], (unsigned long long) s.n);
-}
-__global__ __launch_bounds__(256) void sam_write_kernel(SamArgs A, int units) {
-	__shared__ uint32_t s_cnt[3];
-	if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+	__shared__ unsigned long long s_sum;
+	if (threadIdx.x == 0) s_sum = 0;
 	__syncthreads();
 	const int u = blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t cnt[3] = {0, 0, 0};
+	uint32_t len = 0;
+	if (u < units) {
+		SamCountSink s;
+		uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
+		sam_unit(A, u, s, cnt);
+		A.unit_len[u] = len = s.n;
+	}
+	// the batch's offsets are 32-bit prefix sums: their total is checked against this 64-bit sum of the same lengths (a wrap is
+	// detected directly, whatever the length of a single record -- MP:Z / RA:Z of a SLAM-seq run can outgrow any per-read estimate)
+	if (len) atomicAdd(&s_sum, (unsigned long long) len);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_sum) atomicAdd(&A.counters[3], s_sum);
+}
+__global__ __launch_bounds__(256) void sam_write_kernel(SamArgs A, int units) {
+	__shared__ unsigned long long s_cnt[6];
+	if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
+	__syncthreads();
+	const int u = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t cnt[6] = {0, 0, 0, 0, 0, 0};
 	if (u < units) {
 		SamWriteSink s{A.out + A.unit_off[u]};
 		sam_unit(A, u, s, cnt);
 	}
-	for (int k = 0; k < 3; ++k) if (cnt[k]) atomicAdd(&s_cnt[k], cnt[k]);
+	for (int k = 0; k < 6; ++k) if (cnt[k]) atomicAdd(&s_cnt[k], (unsigned long long) cnt[k]);
 	__syncthreads();
-	if (threadIdx.x < 3 && s_cnt[threadIdx.x]) atomicAdd(&A.counters[threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
+	// counters: [0..2] reads counted / mapped, lines written; [3] the 64-bit sum of the unit lengths (sam_lengths_kernel); [4..6] the pair counters
+	if (threadIdx.x < 6 && s_cnt[threadIdx.x]) atomicAdd(&A.counters[threadIdx.x < 3 ? threadIdx.x : threadIdx.x + 1], s_cnt[threadIdx.x]);
 }
 #endif
 

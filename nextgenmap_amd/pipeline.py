@@ -67,6 +67,8 @@ def _lib():
         lib.ngm_mapper_cs_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_path_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        lib.ngm_mapper_last_order_replay_ms.restype = C.c_float
+        lib.ngm_mapper_last_order_replay_ms.argtypes = [C.c_void_p]
         lib.ngm_bgzf_create.restype = C.c_void_p
         lib.ngm_bgzf_create.argtypes = [C.c_int]
         lib.ngm_bgzf_destroy.argtypes = [C.c_void_p]
@@ -306,6 +308,10 @@ class Mapper:
         ms = (C.c_float * 8)()
         self.lib.ngm_mapper_last_kernel_ms(self.h, ms)
         return list(ms)
+
+    def last_order_replay_ms(self):
+        """GPU time of the candidate-order replays of the last call (their own stream)"""
+        return float(self.lib.ngm_mapper_last_order_replay_ms(self.h))
 
     def path_counters(self):
         """summed over all batches: reads searched, candidates, reads re-run by the exact search (LDS table / global-memory table),

@@ -83,7 +83,7 @@ def main():
                 early.update(int(i) // 2 for i in hit if i % 2 == 0)
             dp = sorted({int(k[0].split("_")[0][1:]) for k in diff})
             print("   pairs whose first mate's scores end a 1024-score buffer:", len(early), "; differing pairs:", len(dp), "; of those early:", len([x for x in dp if x in early]))
-            print("   ngm-hip's own count:", [l for l in c.stderr.splitlines() if "early top1SE" in l])
+            print("   ngm-hip's own count:", [l for l in c.stderr.splitlines() if "Pairs lost as NextGenMap" in l])
             print("   counts of differing pairs:", [(x, int(cnt[2 * x]), int(cnt[2 * x + 1])) for x in dp[:20]])
         for k in diff[:6]:
             x, y = a[k][0], (b.get(k) or [()])[0]

@@ -486,3 +486,65 @@ def test_broken_pairs_interleaved_equals_reference_program(tmp_path):
     # the refusal that is left: --broken-pairs needs an interleaved file
     c = subprocess.run([CLI, "-r", fa, "-o", str(tmp_path / "x.sam"), "-1", fq, "-2", fq, "--broken-pairs"], capture_output=True, text=True)
     assert c.returncode != 0 and "interleaved" in c.stderr
+
+
+@pytest.mark.skipif(not RF.have_reference_binary(), reason="reference binary not built (oracle/ngm_ref.mk)")
+def test_pair_lost_by_the_reference_is_lost_here_too(tmp_path):
+    """NextGenMap hands a read to its score buffer right after the search (src/CS.cpp:436).  When the last score of a pair's FIRST mate
+    fills the buffer exactly (1 024 entries with --affine, src/seqan/EndToEndAffine.h:44-46) its scores are complete, but the mate has
+    not been searched yet (MappedRead::Calculated == -1, src/MappedRead.cpp:14): ScoreBuffer.cpp:196 selects nothing; a mate that
+    then has NO candidates goes to the writer alone and the pair is never written.  One constructed pair: every read has exactly one
+    candidate, pair 0's second mate is all N (shifts the buffer by one), pair 512's first mate is the buffer's 1 024th score and its
+    second mate is all N.  `ngm-core --affine -t 1` writes 1 398 lines and reports 2 discarded reads; `ngm-hip --affine` must
+    write the same file; with `--reference-score-buffer 0` (the intended semantics) the pair is back."""
+    from nextgenmap_amd import build
+    build.build()
+    rng = np.random.default_rng(5)
+    ACGT = np.frombuffer(b"ACGT", np.uint8)
+    G = ACGT[rng.integers(0, 4, 2_000_000)]
+    fa = str(tmp_path / "ref.fa")
+    with open(fa, "w") as f:
+        f.write(">chr1\n" + G.tobytes().decode() + "\n")
+    comp = {65: 84, 84: 65, 67: 71, 71: 67}
+    n_pairs, junk = 700, {0, 512}
+    r = np.random.default_rng(9)
+    f1, f2 = str(tmp_path / "l_1.fq"), str(tmp_path / "l_2.fq")
+    with open(f1, "w") as g1, open(f2, "w") as g2:
+        for p in range(n_pairs):
+            s0 = int(r.integers(1000, 1_900_000))
+            a = G[s0:s0 + 100].tobytes()
+            b = bytes(comp[x] for x in G[s0 + 250:s0 + 350].tobytes()[::-1])
+            if p in junk:
+                b = b"N" * 100
+            g1.write("@p%d/1\n%s\n+\n%s\n" % (p, a.decode(), "I" * 100))
+            g2.write("@p%d/2\n%s\n+\n%s\n" % (p, b.decode(), "I" * 100))
+    d1 = tmp_path / "refrun"
+    d1.mkdir()
+    fa1 = str(d1 / "ref.fa")
+    os.link(fa, fa1)
+    rr = RF.run_ngm(["-r", fa1, "-1", f1, "-2", f2, "-o", str(d1 / "out.sam"), "--affine", "-t", "1", "--no-progress", "-s", "0.5"], cwd=str(d1))
+    log_ref = rr.stdout + rr.stderr
+    assert "(2 discarded)" in log_ref, log_ref[-800:]
+
+    def body(path):
+        return [l for l in open(path) if not l.startswith("@")]
+
+    def names(lines):
+        return [l.split("\t")[0] for l in lines]
+    ref = body(str(d1 / "out.sam"))
+    assert len(ref) == 2 * n_pairs - 2 and "p512" not in names(ref)
+    c = subprocess.run([CLI, "-r", fa, "-1", f1, "-2", f2, "-o", str(tmp_path / "hip.sam"), "--affine", "-s", "0.5"], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-2000:]
+    ours = body(str(tmp_path / "hip.sam"))
+    assert ours == ref, [(x, y) for x, y in zip(ref, ours) if x != y][:2]
+    assert re.search(r"Pairs lost as NextGenMap loses them .*: 1\b", c.stderr), c.stderr[-1500:]
+    assert "(2 discarded)" in c.stderr
+    # the same through the host formatter and as BAM-free intended semantics
+    c2 = subprocess.run([CLI, "-r", fa, "-1", f1, "-2", f2, "-o", str(tmp_path / "hip0.sam"), "--affine", "-s", "0.5", "--reference-score-buffer", "0"], capture_output=True, text=True)
+    assert c2.returncode == 0, c2.stderr[-2000:]
+    full = body(str(tmp_path / "hip0.sam"))
+    assert len(full) == 2 * n_pairs and names(full).count("p512") == 2
+    assert [l for l in full if not l.startswith("p512\t")] == ref
+    env = dict(os.environ, NGM_HIP_HOST_SAM="1")
+    c3 = subprocess.run([CLI, "-r", fa, "-1", f1, "-2", f2, "-o", str(tmp_path / "hip_host.sam"), "--affine", "-s", "0.5"], capture_output=True, text=True, env=env)
+    assert c3.returncode == 0 and body(str(tmp_path / "hip_host.sam")) == ref

@@ -148,6 +148,20 @@ def test_shards_concatenate_to_the_single_run(tmp_path, layout):
         assert not glob.glob(fa + "-*.tmp.*") and len(glob.glob(fa + "-*.ngm")) == 2
     a, b, m = _body(one), _body(cat), _body(multi)
     assert len(a) == len(b) == len(m) and len([l for l in a if not l.startswith("@")]) == n
+    # the product's one reduction -- every shard hands its int64[8] statistics to the parent, which prints ONE summed line
+    # (on distinct GPUs the shards also run the ncclAllReduce among themselves; two shards of one GPU cannot: RCCL refuses the duplicate)
+    import re
+    done = re.findall(r"Done \((\d+) reads mapped \([0-9.]+%\), (\d+) reads not mapped, (\d+) lines written\)", c.stderr)
+    summed = re.search(r"Done, 2 shards summed \((\d+) reads mapped \([0-9.]+%\), (\d+) reads not mapped, (\d+) lines written; (\d+) reads; (\d+) pairs with both mates mapped, (\d+) of them broken", c.stderr)
+    assert len(done) == 2 and summed, c.stderr[-3000:]
+    assert [int(x) for x in summed.groups()[:3]] == [sum(int(d[k]) for d in done) for k in range(3)]
+    assert int(summed.group(4)) == n and int(summed.group(3)) == len([l for l in m if not l.startswith("@")])
+    if paired:
+        recs = [l.split("\t") for l in m if not l.startswith("@")]
+        mapped_both = sum(1 for f in recs if (int(f[1]) & 0x40) and not (int(f[1]) & 0x4) and not (int(f[1]) & 0x8))
+        assert abs(int(summed.group(5)) - mapped_both) <= n // 100, (summed.group(5), mapped_both)   # (the writer's identity filter can still unmap a mate of a counted pair)
+    else:
+        assert int(summed.group(5)) == 0
     if not paired:
         assert a == b and a == m
     else:
@@ -304,3 +318,20 @@ def test_slam_seq_real_program_with_plugin_vs_ngm_hip(tmp_path, layout, slam):
     assert c.returncode == 0, c.stderr[-2000:]
     strip = lambda p: [l for l in open(p) if not l.startswith("@PG")]
     assert strip(host) == strip(ours)
+
+
+def test_one_shard_process_runs_the_rccl_all_reduce(tmp_path):
+    """The collective itself: with NGM_HIP_SHARD_SINGLE=1 `-g 0 --shard-output` goes through the shard machinery with ONE shard process --
+    a communicator of one rank (what a 1-GPU box allows: RCCL refuses two ranks on one GPU) -- and that process runs ncclAllReduce on its
+    int64[8] statistics (librccl loaded at run time, the id made by the parent).  The reduced vector equals the parent's sum."""
+    import re
+    fa, inp, n = _case(tmp_path, True)
+    out = str(tmp_path / "one_shard.sam")
+    env = dict(os.environ, NGM_HIP_SHARD_SINGLE="1")
+    c = subprocess.run([CLI, "-r", fa, "-o", out, "-g", "0", "--shard-output"] + inp, capture_output=True, text=True, env=env)
+    assert c.returncode == 0, c.stderr[-2000:]
+    ar = re.search(r"Statistics all-reduce over 1 GPUs \(RCCL, \d+ us\): (\d+) reads, (\d+) mapped, (\d+) not mapped, (\d+) lines written; (\d+) pairs with both mates mapped, (\d+) of them broken", c.stderr)
+    summed = re.search(r"Done, 1 shards summed \((\d+) reads mapped \([0-9.]+%\), (\d+) reads not mapped, (\d+) lines written; (\d+) reads; (\d+) pairs with both mates mapped, (\d+) of them broken", c.stderr)
+    assert ar and summed, c.stderr[-3000:]
+    assert (ar.group(1), ar.group(2), ar.group(3), ar.group(4), ar.group(5), ar.group(6)) == (summed.group(4), summed.group(1), summed.group(2), summed.group(3), summed.group(5), summed.group(6))
+    assert int(ar.group(1)) == n
