@@ -266,15 +266,33 @@ def end_to_end(ref, contigs, workdir, args, paired, affine, sens):
                 "gpu": float(mg.group(1)) if mg else None, "pass": float(mg.group(2)) if mg else None}
 
     sam = os.path.join(workdir, "e2e.sam")
-    h = run_hip(files, sam)
-    out = {"reads": n, "seconds_first_input_byte_to_sam_closed": h["io"], "value": n / h["io"], "unit": "reads/s",
-           "index_load_s": h["index"], "process_wall_s": h["wall"], "reads_per_s_of_process_wall": n / h["wall"],
+    # (one sample per box is not a measurement) the same run --e2e-runs times: the first one's SAM is the one compared below;
+    # between runs the file is removed and the dirty pages of the last run are flushed (a run that writes 4 GB leaves 4 GB of write-back
+    # behind, and the next run's writes wait for it: measured in round 4, mapping pass 0.50 s -> 0.89 s)
+    runs = []
+    h = None
+    for rep in range(max(1, args.e2e_runs)):
+        if rep > 0:
+            os.remove(sam)
+            os.sync()
+        hr = run_hip(files, sam)
+        runs.append(hr)
+        if rep == 0:
+            h = hr
+    ios = sorted(r_["io"] for r_ in runs)
+    med = ios[len(ios) // 2]
+    h_med = [r_ for r_ in runs if r_["io"] == med][0]
+    out = {"reads": n, "seconds_first_input_byte_to_sam_closed": med, "value": n / med, "unit": "reads/s",
+           "runs": {"n": len(runs), "seconds_min_median_max": [ios[0], med, ios[-1]], "reads_per_s_min_median_max": [n / ios[-1], n / med, n / ios[0]],
+                    "per_run": [{"input_to_output_s": r_["io"], "mapping_pass_s": r_["pass"], "gpu_kernel_s": r_["gpu"], "index_load_s": r_["index"], "process_wall_s": r_["wall"]} for r_ in runs],
+                    "note": "value = the median run; the output file is removed and os.sync() called between runs"},
+           "index_load_s": h_med["index"], "process_wall_s": h_med["wall"], "reads_per_s_of_process_wall": n / h_med["wall"],
            "sam_bytes": os.path.getsize(sam), "fastq_bytes": len(files) * (n // len(files)) * rec,
            "command": " ".join(["ngm-hip"] + h["cmd"][1:]), "cli_log_tail": [l for l in h["log"].splitlines() if "Before the mapping pass" in l or "Sensitivity estimate, s" in l] + [l for l in h["log"].splitlines() if "MAIN" in l][-4:],
            "input": "%s plain FASTQ (%d x %d bp %s, fixed-width names), page cache warm; index from NextGenMap cache files"
                     % ("two" if paired else "one", n // 2 if paired else n, READ_LEN, "pairs" if paired else "reads"),
-           "make_input_s": t_make, "gpu_kernel_s": h["gpu"], "mapping_pass_s": h["pass"],
-           "gpu_busy_fraction_of_mapping_pass": (h["gpu"] / h["pass"]) if h["gpu"] and h["pass"] else None}
+           "make_input_s": t_make, "gpu_kernel_s": h_med["gpu"], "mapping_pass_s": h_med["pass"],
+           "gpu_busy_fraction_of_mapping_pass": (h_med["gpu"] / h_med["pass"]) if h_med["gpu"] and h_med["pass"] else None}
     # the same program on what real input looks like (.fastq.gz: the serial reader) and with --bam, on a slice
     ng = min(n, args.e2e_gz_reads) & ~1
     # what the later comparisons need of the big SAM file stays in memory (the first records, in file order); the file itself goes now:
@@ -433,7 +451,16 @@ def sharded_end_to_end(workdir, contigs, args, paired, affine, sens, world, exe)
     with open(sam, "rb") as f:
         for l in f:
             lines += l[:1] != b"@"
+    # the product's own reduction (round 5): the parent sums the int64[8] vectors its shard processes hand over and prints ONE line; on
+    # distinct GPUs shard 0 also prints what the ncclAllReduce among the shards gave (the per-shard lines stay as a cross-check)
+    summed = re.search(r"Done, (\d+) shards summed \((\d+) reads mapped \([0-9.]+%\), (\d+) reads not mapped, (\d+) lines written; (\d+) reads; (\d+) pairs with both mates mapped, (\d+) of them broken, mean insert size ([0-9.]+)\)", log)
+    rccl = re.search(r"Statistics all-reduce over (\d+) GPUs \(RCCL, (\d+) us\): (\d+) reads, (\d+) mapped, (\d+) not mapped, (\d+) lines written", log)
     out = {"reads": n, "shards": world, "scaling": "strong", "unit": "reads/s",
+           "stats_summed_by_the_parent_process": ({"shards": int(summed.group(1)), "mapped": int(summed.group(2)), "unmapped": int(summed.group(3)), "written": int(summed.group(4)),
+                                                   "reads": int(summed.group(5)), "pairs_total": int(summed.group(6)), "pairs_broken": int(summed.group(7)), "mean_insert_size": float(summed.group(8))}
+                                                  if summed else None),
+           "stats_allreduce_rccl_among_the_shards": ({"ranks": int(rccl.group(1)), "microseconds": int(rccl.group(2)), "reads": int(rccl.group(3)), "mapped": int(rccl.group(4)),
+                                                      "unmapped": int(rccl.group(5)), "written": int(rccl.group(6))} if rccl else None),
            "seconds_first_input_byte_to_concatenated_sam_closed": (max(io) if io else wall) + (float(app.group(1)) if app else 0.0),
            "per_shard_input_to_output_s": io, "per_shard_index_load_s": idx, "append_s": float(app.group(1)) if app else None, "process_wall_s": wall,
            "stats_summed_over_shards": {"mapped": sum(d[0] for d in done), "unmapped": sum(d[1] for d in done), "written": sum(d[2] for d in done)},
@@ -591,7 +618,7 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
                     t_load = run_ref(slice_files(sets[0][0], 2, "h_one"), os.path.join(workdir, "h_one.sam"), threads)
                 pilot = min(4000, R) & ~1
                 t_pilot = max(run_ref(slice_files(sets[0][0], pilot, "h_pilot"), os.path.join(workdir, "h_pilot.sam"), threads) - t_load, 1e-3)
-                ns = int(min(args.heavy_tail_cpu_reads, R, max(pilot, 12.0 * pilot / t_pilot))) & ~1
+                ns = int(min(args.heavy_tail_cpu_reads, R, max(pilot, 8.0 * pilot / t_pilot))) & ~1
                 fs = slice_files(sets[0][0], ns, "h_" + tag[:4])
                 ref_sam, hip_sam = os.path.join(workdir, "h_ref.sam"), os.path.join(workdir, "h_hip.sam")
                 t_all = run_ref(fs, ref_sam, threads)
@@ -681,13 +708,14 @@ def main():
     ap.add_argument("--sensitive", action="store_true", help="config #5: sensitivity 0.5 - 0.35 * 0.5 (what --sensitive does to an estimate of 0.5)")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads of the end-to-end ngm-hip run (BASELINE config #3: 10 000 000)")
+    ap.add_argument("--e2e-runs", type=int, default=3, help="repetitions of the end-to-end ngm-hip run (the median is reported)")
     ap.add_argument("--e2e-gz-reads", type=int, default=2_000_000, help="reads of the .fastq.gz-input and --bam-output runs of ngm-hip (0: skip)")
     ap.add_argument("--cpu-t1-reads", type=int, default=200_000, help="reads of the reference's -t 1 run (SAM cross-check)")
     ap.add_argument("--stub-mapper", action="store_true", help="CPU-only control-path run (tests)")
     ap.add_argument("--ngm-hip-exe", default=None, help="the program of the sharded end-to-end leg (default: nextgenmap_amd/ngm-hip; tests pass a stand-in)")
     ap.add_argument("--heavy-tail-mbp", type=float, default=3100.0, help="size of the GRCh38-like (heavy-tailed k-mer spectrum) genome of the second leg; 0: skip")
-    ap.add_argument("--heavy-tail-steps", type=int, default=8)
-    ap.add_argument("--heavy-tail-cpu-reads", type=int, default=400_000, help="most reads of a heavy-tail sub-leg's cpu_baseline sample (what the reference maps in ~12 s, at most this; 0: none)")
+    ap.add_argument("--heavy-tail-steps", type=int, default=4)
+    ap.add_argument("--heavy-tail-cpu-reads", type=int, default=400_000, help="most reads of a heavy-tail sub-leg's cpu_baseline sample (what the reference maps in ~8 s, at most this; 0: none)")
     ap.add_argument("--heavy-tail-repeat-share", type=float, default=0.5)
     args = ap.parse_args()
     global Q, C, READ_LEN

@@ -1191,15 +1191,16 @@ __host__ __device__ inline uint32_t cs_order_tau(int lists_cap) { return (uint32
 // tracked bins in a per-read slice of global memory sized from the read's hits (A.ovf_table_off / A.ovf_log2 / A.gtable_keys), and
 // 32-bit hit times (l_time) instead of the 16-bit ones packed into l_pref.  Nothing is given up but a bisulfite read with more
 // k-mer variants than the list rows hold.
+constexpr int kCsOrderThreadsGlobal = 1024;   // the exact replay in global memory: every step of it waits for L2 -- four times the waves per read
 template <bool GLOBAL>
-__global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
+__global__ __launch_bounds__(GLOBAL ? kCsOrderThreadsGlobal : kCsOrderThreads) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
 		uint32_t *__restrict__ cand_rank) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	__shared__ uint32_t s_keys;  // distinct tracked bins
 	const unsigned long long t_block = A.phase_cycles ? wall_clock64() : 0ull;
 	// four waves: the sweeps over the hits (most of the time) are spread over all of them, the sequential parts -- the time-ordered
 	// compaction and the replay -- stay with wave 0; cs_prepare is run by every wave (same values, its barrier is the block's)
-	constexpr int NT = kCsOrderThreads;
+	constexpr int NT = GLOBAL ? kCsOrderThreadsGlobal : kCsOrderThreads;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	auto og = [](const uint32_t *p) -> uint32_t { return GLOBAL ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };   // words updated by L2 atomics: not through L1
 	const int read = (int) A.read_list[blockIdx.x];
@@ -1305,23 +1306,36 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	};
 	// sweep A (the only pass over the position lists): every hit is written to the time line (bin | strand << 31);
 	// bins hit at least twice (or colliding on a plane bit) become tracked keys
-	auto vote = [&](uint32_t pos, int li, uint32_t t) {
-		const uint32_t bin = bin_of(pos, li);
-		ev_at[t] = bin | ((li & 1) ? 0x80000000u : 0u);
-		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
-		const uint32_t msk = 1u << (b & 31);
-		if (atomicOr(&plane[b >> 5], msk) & msk) {
-			// (a read whose repeated bins outgrow the table is given up below: stop inserting as soon as that is certain -- with
-			// the table nearly full every further hit would walk hundreds of slots, and one such read per launch of 4 096 kept
-			// the launch alive for 25 ms: 1.7 s instead of 0.1 s for config 5's 256 k tied reads)
-			if (!GLOBAL && *(volatile uint32_t *) &s_keys > (n_slots * 3u) / 4u) return;
-			uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
-			for (uint32_t probes = 0; probes < n_slots; ++probes) {
-				const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
-				if (prev == bin) break;
-				if (prev == 0xFFFFFFFFu) { const uint32_t at = atomicAdd(&s_keys, 1u); if (GLOBAL) t_list[at] = slot; break; }
-				slot = (slot + 1) & (n_slots - 1);
+	// (round 5: the eight hits of a work item together -- their plane updates, then the first probes of those that need the table, are in
+	// flight at the same time; one hit after the other, every probe of a table in global memory was a round trip to L2 on its own)
+	auto vote8 = [&](const uint32_t (&pos8)[8], uint32_t cnt, int li, uint32_t t0) {
+		uint32_t bin[kCsSeg], slot[kCsSeg], prev[kCsSeg];
+		bool need[kCsSeg];
+		const uint32_t sbit = (li & 1) ? 0x80000000u : 0u;
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) {
+			need[j] = false;
+			if ((uint32_t) j < cnt) {
+				bin[j] = bin_of(pos8[j], li);
+				ev_at[t0 + (uint32_t) j] = bin[j] | sbit;
+				const uint32_t b = (bin[j] * 0x9E3779B1u) >> 16;
+				const uint32_t msk = 1u << (b & 31);
+				need[j] = (atomicOr(&plane[b >> 5], msk) & msk) != 0u;
 			}
+		}
+		// (a read whose repeated bins outgrow the LDS table is given up below: stop inserting as soon as that is certain -- with the table
+		// nearly full every further hit would walk hundreds of slots)
+		if (!GLOBAL && *(volatile uint32_t *) &s_keys > (n_slots * 3u) / 4u) return;
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) if (need[j]) { slot[j] = (bin[j] * 2654435761u) >> (32 - log2_slots); prev[j] = atomicCAS(&t_keys[slot[j]], 0xFFFFFFFFu, bin[j]); }
+#pragma unroll
+		for (int j = 0; j < kCsSeg; ++j) if (need[j]) {
+			uint32_t sl = slot[j], pv = prev[j];
+			for (uint32_t probes = 1; pv != bin[j] && pv != 0xFFFFFFFFu && probes < n_slots; ++probes) {
+				sl = (sl + 1) & (n_slots - 1);
+				pv = atomicCAS(&t_keys[sl], 0xFFFFFFFFu, bin[j]);
+			}
+			if (pv == 0xFFFFFFFFu) { const uint32_t at = atomicAdd(&s_keys, 1u); if (GLOBAL) t_list[at] = sl; }
 		}
 	};
 	{
@@ -1348,8 +1362,7 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 			const uint32_t meta = l_pref[li];
 			const uint32_t cnt = min((uint32_t) kCsSeg, (meta & 0xFFFFu) - sg * kCsSeg), t0 = (GLOBAL ? l_time[li] : (meta >> 16)) + sg * kCsSeg;
 			const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
-#pragma unroll
-			for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cnt) vote(pos8[j], (int) li, t0 + (uint32_t) j);
+			vote8(pos8, cnt, (int) li, t0);
 			item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1];
 		}
 	}
@@ -1363,26 +1376,38 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 	// empty.  The plane is rebuilt as a bit set of the tracked keys first, so that the ~90 % untracked hits cost one read.
 	for (uint32_t s2 = tid; s2 < plane_words; s2 += NT) plane[s2] = 0;
 	__syncthreads();
-	for (uint32_t s2 = tid; s2 < n_slots; s2 += NT) {
-		const uint32_t key = og(&t_keys[s2]);
+	// the slots in use: entry i of the list (GLOBAL) or slot i of the table
+	const uint32_t n_ent = GLOBAL ? s_keys : n_slots;
+	auto slot_of = [&](uint32_t i) -> uint32_t { return GLOBAL ? t_list[i] : i; };
+	for (uint32_t i = tid; i < n_ent; i += NT) {
+		const uint32_t key = og(&t_keys[slot_of(i)]);
 		if (key != 0xFFFFFFFFu) { const uint32_t b = (key * 0x9E3779B1u) >> 16; atomicOr(&plane[b >> 5], 1u << (b & 31)); }
 	}
 	__syncthreads();
-	for (uint32_t t = tid; t < H; t += NT) {
-		const uint32_t e = ev_at[t];
-		const uint32_t bin = e & 0x3FFFFFFFu;
-		const uint32_t b = (bin * 0x9E3779B1u) >> 16;
-		uint32_t out = 0xFFFFFFFFu;
-		if ((plane[b >> 5] >> (b & 31)) & 1u) {
-			uint32_t slot = (bin * 2654435761u) >> (32 - log2_slots);
-			for (;;) {
-				const uint32_t key = og(&t_keys[slot]);
-				if (key == bin) { atomicAdd(&t_votes[slot], (e & 0x80000000u) ? 0x10000u : 1u); out = slot | (e & 0x80000000u); break; }
-				if (key == 0xFFFFFFFFu) break;
-				slot = (slot + 1) & (n_slots - 1);
-			}
+	constexpr int KB = 8;   // time line entries per thread and trip: their loads and first probes are in flight together
+	for (uint32_t t0 = (uint32_t) tid; t0 < H; t0 += (uint32_t) NT * KB) {
+		uint32_t e[KB], slot[KB], key[KB];
+		bool in[KB];
+#pragma unroll
+		for (int j = 0; j < KB; ++j) { const uint32_t t = t0 + (uint32_t) j * NT; e[j] = t < H ? ev_at[t] : 0u; }
+#pragma unroll
+		for (int j = 0; j < KB; ++j) {
+			const uint32_t bin = e[j] & 0x3FFFFFFFu;
+			const uint32_t b = (bin * 0x9E3779B1u) >> 16;
+			in[j] = t0 + (uint32_t) j * NT < H && ((plane[b >> 5] >> (b & 31)) & 1u) != 0u;
+			slot[j] = (bin * 2654435761u) >> (32 - log2_slots);
+			key[j] = in[j] ? og(&t_keys[slot[j]]) : 0xFFFFFFFFu;
 		}
-		ev_at[t] = out;
+#pragma unroll
+		for (int j = 0; j < KB; ++j) {
+			const uint32_t t = t0 + (uint32_t) j * NT;
+			if (t >= H) continue;
+			const uint32_t bin = e[j] & 0x3FFFFFFFu;
+			uint32_t out = 0xFFFFFFFFu, sl = slot[j], ky = key[j];
+			while (ky != bin && ky != 0xFFFFFFFFu) { sl = (sl + 1) & (n_slots - 1); ky = og(&t_keys[sl]); }
+			if (in[j] && ky == bin) { atomicAdd(&t_votes[sl], (e[j] & 0x80000000u) ? 0x10000u : 1u); out = sl | (e[j] & 0x80000000u); }
+			ev_at[t] = out;
+		}
 	}
 	__syncthreads();
 	if (diag) ck[3] = wall_clock64();
@@ -1413,9 +1438,6 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 			nf = v & 0xFFFFu; nr = v >> 16;
 			return nf + nr >= 2u || t_cand[s2] != 0u;
 		};
-		// the slots in use: entry i of the list (GLOBAL) or slot i of the table
-		const uint32_t n_ent = GLOBAL ? s_keys : n_slots;
-		auto slot_of = [&](uint32_t i) -> uint32_t { return GLOBAL ? t_list[i] : i; };
 		// (a) offsets: every thread a contiguous run of entries; a slot that does not take part is marked
 		const uint32_t per = (n_ent + NT - 1) / NT, s_lo = min(n_ent, (uint32_t) tid * per), s_hi = min(n_ent, s_lo + per);
 		uint32_t mine = 0;
@@ -1434,17 +1456,24 @@ __global__ __launch_bounds__(kCsOrderThreads) void cs_order_kernel(CsArgs A, con
 		}
 		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		__syncthreads();
-		// (b) every tracked hit to its segment
-		for (uint32_t t = tid; t < H; t += NT) {
-			const uint32_t e = ev_at[t];
-			if (e == 0xFFFFFFFFu) continue;
-			const uint32_t slot = e & 0x7FFFFFFFu;
-			const uint32_t off = t_off[slot];
-			if (off == 0xFFFFFFFFu) continue;
-			const bool rev = (e >> 31) != 0u;
-			const uint32_t nf = rev ? (og(&t_votes[slot]) & 0xFFFFu) : 0u;
-			const uint32_t k = atomicAdd(&t_fill[slot], rev ? 0x10000u : 1u);
-			tm[off + (rev ? nf + (k >> 16) : (k & 0xFFFFu))] = t;
+		// (b) every tracked hit to its segment (KB entries of the time line per thread and trip)
+		for (uint32_t t0 = (uint32_t) tid; t0 < H; t0 += (uint32_t) NT * KB) {
+			uint32_t e[KB], off[KB], nfw[KB], kk[KB];
+#pragma unroll
+			for (int j = 0; j < KB; ++j) { const uint32_t t = t0 + (uint32_t) j * NT; e[j] = t < H ? ev_at[t] : 0xFFFFFFFFu; }
+#pragma unroll
+			for (int j = 0; j < KB; ++j) off[j] = e[j] != 0xFFFFFFFFu ? t_off[e[j] & 0x7FFFFFFFu] : 0xFFFFFFFFu;
+#pragma unroll
+			for (int j = 0; j < KB; ++j) {
+				const bool rev = (e[j] >> 31) != 0u;
+				nfw[j] = (off[j] != 0xFFFFFFFFu && rev) ? (og(&t_votes[e[j] & 0x7FFFFFFFu]) & 0xFFFFu) : 0u;
+				kk[j] = off[j] != 0xFFFFFFFFu ? atomicAdd(&t_fill[e[j] & 0x7FFFFFFFu], rev ? 0x10000u : 1u) : 0u;
+			}
+#pragma unroll
+			for (int j = 0; j < KB; ++j) if (off[j] != 0xFFFFFFFFu) {
+				const bool rev = (e[j] >> 31) != 0u;
+				tm[off[j] + (rev ? nfw[j] + (kk[j] >> 16) : (kk[j] & 0xFFFFu))] = t0 + (uint32_t) j * NT;
+			}
 		}
 		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		__syncthreads();

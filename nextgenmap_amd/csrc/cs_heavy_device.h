@@ -311,11 +311,11 @@ __global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
 // fields), which replaces the 32-bit class.  Work items are 8-hit segments of one list (two 16-byte loads, constant strand and
 // diagonal correction; item -> list through a coarse table + a short bisection).  Workgroups are persistent (one scratch slice each)
 // and draw reads from a counter.  Candidates leave in cs_global_kernel's order.
-struct CsHeavy2Cfg { int log2c, log2s; uint32_t scratch_cap; };   // per class (host: mapper.cpp)
+constexpr int kCsHeavyCoarseShift = 5;   // the coarse item -> list table has an entry per 32 items (16: at GRCh38 size the middle class needed 82 KB of LDS -- one workgroup per CU instead of two)
 
-inline size_t cs_heavy2_coarse_cap(int lists_cap, int max_kfreq) {   // items / 16 + slack: a read has at most lists_cap / 2 * max_kfreq hits
+inline size_t cs_heavy2_coarse_cap(int lists_cap, int max_kfreq) {   // items / 32 + slack: a read has at most lists_cap / 2 * max_kfreq hits
 	const size_t items = ((size_t) (lists_cap / 2) * (size_t) max_kfreq) / kCsSeg + (size_t) lists_cap;
-	return items / 16 + 4;
+	return (items >> kCsHeavyCoarseShift) + 4;
 }
 inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int log2_slots, size_t coarse_cap) {
 	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + 3 + ((size_t) 1 << (log2_counters - 1)) + 512 + ((size_t) 2 << log2_slots)) * 4;
@@ -323,10 +323,10 @@ inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int l
 
 template <int NT>
 __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list, uint32_t *__restrict__ work_counter, uint32_t *__restrict__ scratch, uint32_t scratch_cap,
-		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several
+		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several, [13] reads sent into a second pass
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	constexpr int NW = NT / 64;
-	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct, s_nhot, s_nent;
+	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct, s_nhot, s_nent, s_force, s_retry_ix, s_retry_T;
 	__shared__ uint32_t s_red[NW], s_cnt[NT], s_wtot[NW], s_mx[NW], s_mxb[NW];
 	__shared__ unsigned long long s_base;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 	uint32_t *l_pref = cs_lds + A.lists_cap;                     // [lists_cap + 1]
 	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);    // [q rounded up to 4]
 	uint32_t *seg_pref = (uint32_t *) l_code + (A.q + 3) / 4;    // [lists_cap + 1]: 8-hit segments in front of each list
-	uint16_t *coarse = (uint16_t *) (seg_pref + A.lists_cap + 1); // [coarse_cap]: the list that holds item 16 c
+	uint16_t *coarse = (uint16_t *) (seg_pref + A.lists_cap + 1); // [coarse_cap]: the list that holds item 32 c
 	uint32_t *cnt = cs_lds + (((size_t) ((uint32_t *) coarse - cs_lds) + (coarse_cap + 1) / 2 + 3) & ~(size_t) 3);  // [NC / 2]: two 16-bit counters per word (16-byte aligned: cleared with 128-bit stores)
 	const int log2c = A.log2_bits;
 	const uint32_t cnt_words = (1u << log2c) >> 1;
@@ -349,11 +349,20 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 	uint32_t *my_scratch = scratch + (size_t) blockIdx.x * ((size_t) scratch_cap + 2u * (size_t) ent_cap);   // survivors, then (max_parts > 1) the entries of all parts
 	uint32_t *my_ent = my_scratch + scratch_cap;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	// A read of the largest class (max_parts > 1) gets a SECOND pass when the first one -- T the smallest value whose bins fit ONE table -- ends
+	// with T - 1 >= max(kmer_min, M2 * sensitivity): M2, exact for the bins it saw, is a lower bound of the true maximum, so the largest T' with
+	// T' - 1 < that threshold is sure to certify, and the bins at or above T' are taken in as many table passes as they need (s_retry_*).
+	if (tid == 0) s_retry_T = 0;
 	for (;;) {
 		__syncthreads();   // (the previous read's shared state is no longer read)
-		if (tid == 0) s_next = atomicAdd(work_counter, 1u);
+		if (tid == 0) {
+			if (s_retry_T) { s_next = s_retry_ix; s_force = s_retry_T; s_retry_T = 0; }
+			else { s_next = atomicAdd(work_counter, 1u); s_force = 0; }
+		}
 		__syncthreads();
 		const uint32_t item_ix = s_next;
+		const uint32_t T_force = s_force;
+		const uint32_t parts_now = T_force ? max(max_parts, 1u) : 1u;
 		if (item_ix >= n_list) return;
 		const int read = (int) A.read_list[item_ix];
 		const bool dg = diag != nullptr && (item_ix & 7u) == 0u && tid == 0;
@@ -385,19 +394,23 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		}
 		__syncthreads();
 		const uint32_t n_items = seg_pref[n_lists];
-		if ((n_items >> 4) + 3u > coarse_cap) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // (block-uniform; sized from max_kfreq: not reached)
+		if ((n_items >> kCsHeavyCoarseShift) + 3u > coarse_cap) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // (block-uniform; sized from max_kfreq: not reached)
 		for (int li = tid; li < n_lists; li += NT) {
 			const uint32_t s0 = seg_pref[li], s1 = seg_pref[li + 1];
-			for (uint32_t c = (s0 + 15u) >> 4; (c << 4) < s1; ++c) coarse[c] = (uint16_t) li;
+			constexpr uint32_t cm = (1u << kCsHeavyCoarseShift) - 1u;
+			for (uint32_t c = (s0 + cm) >> kCsHeavyCoarseShift; (c << kCsHeavyCoarseShift) < s1; ++c) coarse[c] = (uint16_t) li;
 		}
-		if (tid == 0) coarse[((n_items + 15u) >> 4)] = (uint16_t) max(n_lists - 1, 0), coarse[((n_items + 15u) >> 4) + 1] = (uint16_t) max(n_lists - 1, 0);
+		if (tid == 0) {
+			constexpr uint32_t cm = (1u << kCsHeavyCoarseShift) - 1u;
+			coarse[((n_items + cm) >> kCsHeavyCoarseShift)] = (uint16_t) max(n_lists - 1, 0); coarse[((n_items + cm) >> kCsHeavyCoarseShift) + 1] = (uint16_t) max(n_lists - 1, 0);
+		}
 		__syncthreads();
 		// f(position, list) for every hit: per thread one 8-hit segment at a time, the next one's loads in flight
 		auto sweep = [&](auto f) {
 			CsU4 cur[2], nxt[2];
 			auto fetch = [&](uint32_t idx, CsU4 (&d)[2]) -> uint32_t {
 				if (idx >= n_items) return 0xFFFFFFFFu;
-				int lo = (int) coarse[idx >> 4], hi = min((int) coarse[(idx >> 4) + 1] + 1, n_lists);   // the list with seg_pref[li] <= idx < seg_pref[li + 1] (never an empty one)
+				int lo = (int) coarse[idx >> kCsHeavyCoarseShift], hi = min((int) coarse[(idx >> kCsHeavyCoarseShift) + 1] + 1, n_lists);   // the list with seg_pref[li] <= idx < seg_pref[li + 1] (never an empty one)
 				while (hi - lo > 1) {
 					const int mid = (lo + hi) >> 1;
 					if (seg_pref[mid] <= idx) lo = mid; else hi = mid;
@@ -472,7 +485,8 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					// the smallest T whose counters fit the table with a quarter of it to spare (one bin per counter, and what slips through
 					// both rows) and whose hits fit the scratch slice; when even the hits fit the table, no second row is needed.  Both
 					// conditions are monotone in T: lane l looks at the values 4 l .. 4 l + 3, suffix sums from a wave scan.
-					const uint32_t room = ((cap * 3u) / 4u) * max(max_parts, 1u);   // (the largest class takes the bins in several parts: below)
+					const uint32_t room = ((cap * 3u) / 4u) * parts_now;   // (a read's second pass takes the bins in several parts: below)
+					const int t_min = (int) max(2u, T_force);
 					uint32_t n4[4], h4[4], sn = 0, sh = 0;
 #pragma unroll
 					for (int j = 0; j < 4; ++j) { n4[j] = hist_n[4 * lane + j]; h4[j] = hist_h[4 * lane + j]; sn += n4[j]; sh += h4[j]; }
@@ -484,7 +498,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 #pragma unroll
 					for (int j = 0; j < 4; ++j) {
 						const uint32_t suf_n = tot_n - below_n, suf_h = tot_h - below_h;   // values >= 4 l + j
-						if (my_t == 256 && 4 * lane + j >= 2 && suf_n <= room && suf_h <= scratch_cap) { my_t = 4 * lane + j; my_h = suf_h; }
+						if (my_t == 256 && 4 * lane + j >= t_min && suf_n <= room && suf_h <= scratch_cap) { my_t = 4 * lane + j; my_h = suf_h; }
 						below_n += n4[j]; below_h += h4[j];
 					}
 					const int t = wave_reduce_min(my_t);
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 				}
 				if (!failed) {
 					if (wv == 0) {
-						const uint32_t room = ((cap * 3u) / 4u) * max(max_parts, 1u);
+						const uint32_t room = ((cap * 3u) / 4u) * parts_now;
 						uint32_t n4[4], sn = 0;
 #pragma unroll
 						for (int j = 0; j < 4; ++j) { n4[j] = hist_n[4 * lane + j]; sn += n4[j]; }
@@ -627,7 +641,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					}
 				};
 				const uint32_t room1 = (cap * 3u) / 4u;
-				const uint32_t parts = (failed || s_nhot <= room1) ? 1u : min(max(max_parts, 1u), (s_nhot + s_nhot / 8u + room1 - 1u) / room1);
+				const uint32_t parts = (failed || s_nhot <= room1) ? 1u : min(parts_now, (s_nhot + s_nhot / 8u + room1 - 1u) / room1);
 				if (!failed && parts == 1u) sweep_d(0u, 1u);
 				else if (!failed) {
 					// More bins at or above T than the table holds: the table takes them in `parts` passes over the survivors and hands its
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					for (int w2 = 0; w2 < NW; ++w2) { pmx = max(pmx, (int) s_mx[w2]); pmxb = max(pmxb, (int) s_mxb[w2]); }
 					const float max_hit_p = (float) pmx;
 					const float thresh_p = fmaxf(A.kmer_min, max_hit_p * A.sensitivity);
-					if (!((float) (T - 1u) < thresh_p)) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins below T could reach the threshold
+					if (!((float) (T - 1u) < thresh_p)) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins below T could reach the threshold (a second pass: T was forced as low as the first pass's maximum asks for; the table did not take it)
 					const uint32_t region_p = (uint32_t) read & (kCsRegions - 1);
 					if (tid == 0 && A.counters) {
 						atomicAdd(&A.counters[region_p * kCsCursorStride], (unsigned long long) R.n_valid);
@@ -726,7 +740,11 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		__syncthreads();
 		mark(5);
 		if (dg) { atomicAdd(&diag[8], 1ull); atomicAdd(&diag[9], (unsigned long long) H); if (H > cap && s_direct) atomicAdd(&diag[10], 1ull); }
-		if (failed || s_fail) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
+		if (failed || s_fail) {
+			if (!failed && !T_force && max_parts > 1u && T > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = T; } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // the table overflowed: the same T in several passes
+			if (wv == 0) cs_enqueue(A, read, lane, R);
+			continue;
+		}
 		// the table: maximum, candidates (cs_global_kernel's order: thread t owns the slots of lane class t mod 64 in the (t / 64)-th share)
 		const uint32_t per_class = n_slots >> 6;
 		const uint32_t j0 = (uint32_t) ((unsigned long long) per_class * (unsigned) wv / (unsigned) NW), j1 = (uint32_t) ((unsigned long long) per_class * (unsigned) (wv + 1) / (unsigned) NW);
@@ -745,7 +763,11 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		for (int w2 = 0; w2 < NW; ++w2) { mx = max(mx, (int) s_mx[w2]); mxb = max(mxb, (int) s_mxb[w2]); }
 		const float max_hit = (float) mx;
 		const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
-		if (T > 1u && !((float) (T - 1u) < thresh)) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins outside the table could reach the threshold
+		if (T > 1u && !((float) (T - 1u) < thresh)) {   // bins outside the table could reach the threshold
+			if (!T_force && max_parts > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = max(2u, (uint32_t) ceilf(thresh)); } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // once more, from the T this maximum asks for
+			if (wv == 0) cs_enqueue(A, read, lane, R);
+			continue;
+		}
 		const uint32_t region = (uint32_t) read & (kCsRegions - 1);
 		if (tid == 0 && A.counters) {
 			atomicAdd(&A.counters[region * kCsCursorStride], (unsigned long long) R.n_valid);

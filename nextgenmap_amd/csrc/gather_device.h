@@ -171,15 +171,38 @@ __global__ void select_top1_kernel(int n_reads, const uint32_t *__restrict__ can
 // Paired-end selection, the common case on the GPU: both mates have exactly ONE candidate.  ScoreBuffer::top1PE / CheckPairs
 // (src/ScoreBuffer.cpp:368-502) then has nothing to choose: the pair is taken when its insert size lies inside the window and
 // its score is positive (MAPQ 60 for both mates, no equally good pair), otherwise the single-end selection of
-// select_top1_kernel stands and the pair is flagged as failed.  info[pair] = -1: more candidates, left to the host;
-// else bit 0 = pair taken, bits 1.. = its insert size (the host only sums those for the running mean, ScoreBuffer.h:90).
+// select_top1_kernel stands and the pair is flagged as failed.
+// info[pair] >= 0: bit 0 = pair taken, bits 1.. = its insert size (the host only sums those for the running mean, ScoreBuffer.h:90);
+// -1: a mate without candidates (top1SE for the other one: the host's); <= -2: a pair with choices -- entry -2 - info[pair] of
+// pair_choice_kernel's output (pair_device.h): the pair is appended to the list of the small pairs (both mates at most 64
+// candidates: one wave each there) or, beyond 2^30, to the list of the large ones.
 __global__ void pair_simple_kernel(int n_pairs, const uint32_t *__restrict__ cand_base, const uint32_t *__restrict__ cand_count,
 		const float *__restrict__ scores, const uint32_t *__restrict__ pair_loc, const uint16_t *__restrict__ read_len, int min_d, int max_d,
-		int32_t *__restrict__ mapq, int32_t *__restrict__ n_best, int32_t *__restrict__ info) {
+		int32_t *__restrict__ mapq, int32_t *__restrict__ n_best, int32_t *__restrict__ info, uint32_t *__restrict__ list_small, uint32_t *__restrict__ list_large,
+		uint32_t *__restrict__ list_counts) {
 	const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-	if (pi >= n_pairs) return;
+	const bool live = pi < n_pairs;
 	const int rb = 2 * pi, ra = 2 * pi + 1;   // `a` = the mate whose scores arrive last in the reference (the odd read id)
-	if (cand_count[ra] != 1u || cand_count[rb] != 1u) { info[pi] = -1; return; }
+	const uint32_t ca = live ? cand_count[ra] : 1u, cb = live ? cand_count[rb] : 1u;
+	{
+		// the pairs with choices go to the two lists: ONE atomic per wave and list (a counter serves ~86 M returning atomics per second:
+		// one per pair made this kernel 0.4 ms per 262 144 pairs)
+		const bool choice = live && (ca != 1u || cb != 1u) && ca != 0u && cb != 0u && list_counts != nullptr;
+		const bool small = choice && ca <= 64u && cb <= 64u, large = choice && !small;
+		const unsigned long long ms = __ballot(small), ml = __ballot(large);
+		const int lane = threadIdx.x & 63;
+		const unsigned long long below = (1ull << lane) - 1ull;
+		uint32_t bs = 0, bl = 0;
+		if (ms && lane == (int) __builtin_ctzll(ms)) bs = atomicAdd(&list_counts[0], (uint32_t) __popcll(ms));
+		if (ml && lane == (int) __builtin_ctzll(ml)) bl = atomicAdd(&list_counts[1], (uint32_t) __popcll(ml));
+		if (ms) bs = (uint32_t) __builtin_amdgcn_readlane((int) bs, (int) __builtin_ctzll(ms));
+		if (ml) bl = (uint32_t) __builtin_amdgcn_readlane((int) bl, (int) __builtin_ctzll(ml));
+		if (small) { const uint32_t at = bs + (uint32_t) __popcll(ms & below); list_small[at] = (uint32_t) pi; info[pi] = -2 - (int32_t) at; }
+		if (large) { const uint32_t at = bl + (uint32_t) __popcll(ml & below); list_large[at] = (uint32_t) pi; info[pi] = -2 - (int32_t) (at + (1u << 30)); }
+		if (choice) return;
+	}
+	if (!live) return;
+	if (ca != 1u || cb != 1u) { info[pi] = -1; return; }
 	const uint32_t ba = cand_base[ra], bb = cand_base[rb];
 	const uint64_t l1 = pair_loc[ba], l2 = pair_loc[bb];
 	const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) read_len[rb] : l1 - l2 + (uint64_t) read_len[ra]);

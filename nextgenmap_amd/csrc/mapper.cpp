@@ -125,7 +125,7 @@ struct ngm_mapper {
 	ngm::PinnedBuf<int32_t> p_pair_info;
 	ngm::DevBuf<ngm::PairOut> d_pair_out;      // pair_choice_kernel (pair_device.h): per pair, and the best-scoring combinations of the tied ones
 	ngm::DevBuf<ngm::PairTop> d_pair_top;
-	ngm::DevBuf<uint32_t> d_pair_tied_n;
+	ngm::DevBuf<uint32_t> d_pair_tied_n, d_pair_list;
 	ngm::PinnedBuf<ngm::PairOut> p_pair_out;
 	ngm::PinnedBuf<ngm::PairTop> p_pair_top;
 	ngm::PinnedBuf<uint32_t> p_pair_tied_n;
@@ -518,9 +518,9 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 					MAP_HIP_TRY(hipMemcpy(dg, m->d_heavy_diag.p, sizeof(dg), hipMemcpyDeviceToHost));
 					for (int c = 0; c < 3; ++c) if (dg[16 * c + 8]) {
 						const double ns = (double) dg[16 * c + 8];
-						fprintf(stderr, "[ngm-hip] heavy class %d (round %d, %zu reads, grid %d): us per sampled read: setup %.1f | sweep A %.1f | sum + T %.1f | insert / sweep B %.1f | row 2 %.1f | sweep D %.1f | candidates %.1f; hits %.0f, survivors %.0f, %.0f %% without a second row\n",
+						fprintf(stderr, "[ngm-hip] heavy class %d (round %d, %zu reads, grid %d): us per sampled read: setup %.1f | sweep A %.1f | sum + T %.1f | insert / sweep B %.1f | row 2 %.1f | sweep D %.1f | candidates %.1f; hits %.0f, survivors %.0f, %.0f %% without a second row; second passes %.0f %% of the reads, table passes of the partitioned reads %.1f\n",
 								c, round, lists[c].size(), grid[c], dg[16 * c] / ns / 100.0, dg[16 * c + 1] / ns / 100.0, dg[16 * c + 2] / ns / 100.0, dg[16 * c + 3] / ns / 100.0, dg[16 * c + 4] / ns / 100.0,
-								dg[16 * c + 5] / ns / 100.0, dg[16 * c + 6] / ns / 100.0, dg[16 * c + 9] / ns, dg[16 * c + 11] / ns, 100.0 * dg[16 * c + 10] / ns);
+								dg[16 * c + 5] / ns / 100.0, dg[16 * c + 6] / ns / 100.0, dg[16 * c + 9] / ns, dg[16 * c + 11] / ns, 100.0 * dg[16 * c + 10] / ns, 100.0 * dg[16 * c + 13] / ns, (double) dg[16 * c + 12]);
 					}
 				}
 			}
@@ -802,7 +802,7 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	ep.personality = p->personality; ep.gap_extend_penalty = p->gap_extend_penalty;
 	if (p->bs_mapping) {
 		if (ref->prm.kmer_skip != 0) { ngm::pipeline_set_error("ngm_mapper_create: bisulfite mapping needs a reference index built with kmer_skip 0 (src/PrefixTable.cpp:199-207)"); return nullptr; }
-		if (p->mode != 0 || p->topn > 1) { ngm::pipeline_set_error("ngm_mapper_create: '--bs-mapping' and '--end-to-end' / '-n' can't be used at the same time"); return nullptr; }
+		if (p->mode != 0) { ngm::pipeline_set_error("ngm_mapper_create: '--bs-mapping' and '--end-to-end' can't be used at the same time"); return nullptr; }   // Config.cpp:448-470 (-n is allowed there: ScoreBuffer::topNSE)
 		ep.alt_scoring = ep.alt_cigar = NGM_ALT_BISULFITE; ep.match_bonus_tt = p->match_bonus_tt; ep.match_bonus_tc = p->match_bonus_tc;
 	}
 	if (p->slam_seq) {
@@ -961,7 +961,7 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	m->d_pair_info.release(); m->p_pair_info.release(); m->d_sam_contig_start.release();
-	m->d_pair_out.release(); m->d_pair_top.release(); m->d_pair_tied_n.release(); m->p_pair_out.release(); m->p_pair_top.release(); m->p_pair_tied_n.release();
+	m->d_pair_out.release(); m->d_pair_top.release(); m->d_pair_tied_n.release(); m->d_pair_list.release(); m->p_pair_out.release(); m->p_pair_top.release(); m->p_pair_tied_n.release();
 	m->d_sam_contig_names.release(); m->d_sam_rg.release(); m->d_sam_names.release(); m->d_sam_text.release(); m->d_sam_contig_off.release(); m->d_sam_len.release(); m->d_sam_off.release();
 	m->d_sam_quals.release(); m->d_sam_meta.release(); m->d_sam_refs.release(); m->d_sam_hits.release(); m->p_sam_hits.release(); m->p_sam_refs.release(); m->p_sam_extra.release();
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
@@ -1053,7 +1053,9 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		}
 		if (m->d_order_big.reserve(nb) || m->d_order_log2.reserve(nb) || m->d_order_off.reserve(nb)) { ngm::pipeline_set_error("out of device memory (exact candidate order)"); return -12; }
 		ngm::CsArgs G = m->order_args;
-		G.order_info = nullptr; G.order_scratch = nullptr; G.order_gcap = 0; G.order_max_hits = 0; G.phase_cycles = nullptr;
+		G.order_info = nullptr; G.order_scratch = nullptr; G.order_gcap = 0; G.order_max_hits = 0;
+		G.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + (size_t) ngm::kCsRegions * ngm::kCsCursorStride : nullptr;   // diagnostics: phases of every 64th workgroup
+		if (G.phase_cycles) MAP_HIP_TRY(hipMemsetAsync(G.phase_cycles + 8, 0, 12 * 8, ost));
 		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + ngm::cs_order_tau(G.lists_cap) + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
 		// (8 GB per launch: a read with 50 000 hits takes 2.6 MB of table and time line, and with the 1.5 GB pool of the first version the
 		// 5 500 such reads of a heavy-tailed batch went through ten launches of ~570 workgroups each -- two per CU, 118 ms of waiting per batch)
@@ -1068,7 +1070,7 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_off.p + j0, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, ost));
 			G.read_list = m->d_order_big.p + j0; G.ovf_log2 = m->d_order_log2.p + j0; G.ovf_table_off = m->d_order_off.p + j0; G.gtable_keys = m->d_order_gt.p;
 			MAP_HIP_TRY(hipEventRecord(m->oev[2], ost));
-			hipLaunchKernelGGL(ngm::cs_order_kernel<true>, dim3(j1 - j0), dim3(ngm::kCsOrderThreads), lds, ost, G, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
+			hipLaunchKernelGGL(ngm::cs_order_kernel<true>, dim3(j1 - j0), dim3(ngm::kCsOrderThreadsGlobal), lds, ost, G, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->oev[3], ost));
 			MAP_HIP_TRY(hipStreamSynchronize(ost));   // (reads, lg, off of this launch are consumed; the pool is reused by the next one)
@@ -1077,6 +1079,13 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		}
 		MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
 		MAP_HIP_TRY(hipStreamSynchronize(ost));
+		if (G.phase_cycles) {
+			unsigned long long ph[12];
+			MAP_HIP_TRY(hipMemcpy(ph, G.phase_cycles + 8, sizeof(ph), hipMemcpyDeviceToHost));
+			const double ns = (double) std::max(1ull, ph[4]);
+			fprintf(stderr, "[ngm-hip] exact order replay in global memory (%u reads), us per sampled read: lists %.1f | sweep A %.1f | sweep B %.1f | times + tau + entering %.1f; hits %.0f, slots in use %.0f per read; workgroups start to end %.1f us on average, the slowest %.1f us\n",
+					nb, ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[6] / ns, ph[7] / ns, (double) (ph[5] >> 8) / 100.0 / std::max(1u, nb), ph[8] / 100.0);
+		}
 		for (uint32_t j = 0; j < nb; ++j) {
 			const uint32_t rd = reads[j], b = m->h_base[rd], c = m->h_count[rd];
 			bool unknown = false;
@@ -1541,28 +1550,38 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		static const bool pair_gpu = !getenv("NGM_HIP_HOST_PAIR_PASS1");
 		const bool pe_select = paired && !m->fast_pairing;   // --fast-pairing: the mates are selected single-end, the writer checks the pair (AlignmentBuffer.cpp:176-199)
 		const bool simple_on_gpu = pe_select && pair_gpu && m->prm.strata == 0;   // (--strata touches NH of every pair: host)
-		if (simple_on_gpu) {
-			// pairs whose mates have one candidate each (most): settled here, the host only sums their insert sizes
-			if (m->d_pair_info.reserve(n / 2 + 1) || m->p_pair_info.reserve(n / 2 + 1)) { ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
-			hipLaunchKernelGGL(ngm::pair_simple_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, m->st, n / 2, m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p,
-					m->d_out_loc.p, m->d_read_len.p, m->prm.min_insert_size, m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX, m->d_mapq.p, m->d_nbest.p, m->d_pair_info.p);
-			MAP_HIP_TRY(hipGetLastError());
-			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_info.p, m->d_pair_info.p, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost, m->st));
-		}
 		// ... and the pairs with choices: everything the scores alone decide (pair_device.h); NGM_HIP_HOST_PAIR_CHOICE=1 keeps the host's walk
 		static const bool pair_choice_gpu = !getenv("NGM_HIP_HOST_PAIR_CHOICE");
 		const bool choice_on_gpu = simple_on_gpu && pair_choice_gpu;
-		if (choice_on_gpu) {
+		if (simple_on_gpu) {
+			// pairs whose mates have one candidate each (most): settled here, the host only sums their insert sizes; the others are sorted
+			// into two lists for pair_choice_kernel (mates with up to 64 candidates each: one wave per pair; the rest: a workgroup)
 			const size_t npairs = (size_t) n / 2;
-			if (m->d_pair_out.reserve(npairs + 1) || m->d_pair_top.reserve(npairs + 1) || m->d_pair_tied_n.reserve(4) || m->p_pair_out.reserve(npairs + 1) || m->p_pair_tied_n.reserve(4)) {
-				ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
-			MAP_HIP_TRY(hipMemsetAsync(m->d_pair_tied_n.p, 0, 4, m->st));
-			hipLaunchKernelGGL(ngm::pair_choice_kernel, dim3((unsigned) npairs), dim3(ngm::kPairThreads), 0, m->st, (int) npairs, m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p,
-					m->d_out_loc.p, m->d_read_len.p, m->prm.min_insert_size, m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX,
-					m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f, m->d_pair_info.p, m->d_pair_out.p, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs);
+			if (m->d_pair_info.reserve(npairs + 1) || m->p_pair_info.reserve(npairs + 1)) { ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
+			if (choice_on_gpu) {
+				if (m->d_pair_out.reserve(2 * npairs + 2) || m->d_pair_top.reserve(npairs + 1) || m->d_pair_tied_n.reserve(4) || m->p_pair_tied_n.reserve(4) || m->d_pair_list.reserve(2 * npairs + 2)) {
+					ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
+				MAP_HIP_TRY(hipMemsetAsync(m->d_pair_tied_n.p, 0, 16, m->st));   // [0] tied pairs, [1] small pairs, [2] large pairs
+			}
+			uint32_t *counts = choice_on_gpu ? m->d_pair_tied_n.p + 1 : nullptr;
+			hipLaunchKernelGGL(ngm::pair_simple_kernel, dim3((n / 2 + 255) / 256), dim3(256), 0, m->st, n / 2, m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p,
+					m->d_out_loc.p, m->d_read_len.p, m->prm.min_insert_size, m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX, m->d_mapq.p, m->d_nbest.p, m->d_pair_info.p,
+					m->d_pair_list.p, m->d_pair_list.p + npairs, counts);
 			MAP_HIP_TRY(hipGetLastError());
-			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_out.p, m->d_pair_out.p, npairs * sizeof(ngm::PairOut), hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_tied_n.p, m->d_pair_tied_n.p, 4, hipMemcpyDeviceToHost, m->st));
+			if (choice_on_gpu) {
+				// persistent workgroups over the two lists (their lengths stay on the device); entries of the small pairs at out[0 ..), of the large
+				// ones at out[npairs ..) (2^30 + ... in the numbering pair_simple_kernel puts into d_pair_info)
+				const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
+				const float cutoff = m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f;
+				hipLaunchKernelGGL((ngm::pair_choice_kernel<64, 64>), dim3((unsigned) std::min<size_t>(npairs, 8192)), dim3(64), 0, m->st, (const uint32_t *) m->d_pair_list.p, (const uint32_t *) counts,
+						m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff, m->d_pair_out.p, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs);
+				hipLaunchKernelGGL((ngm::pair_choice_kernel<ngm::kPairThreads, ngm::kPairCap>), dim3((unsigned) std::min<size_t>(npairs, 1024)), dim3(ngm::kPairThreads), 0, m->st,
+						(const uint32_t *) (m->d_pair_list.p + npairs), (const uint32_t *) (counts + 1), m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff,
+						m->d_pair_out.p + npairs, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs);
+				MAP_HIP_TRY(hipGetLastError());
+				MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_tied_n.p, m->d_pair_tied_n.p, 16, hipMemcpyDeviceToHost, m->st));
+			}
+			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_info.p, m->d_pair_info.p, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost, m->st));
 		}
 		MAP_HIP_TRY(hipEventRecord(m->ev[4], m->st));
 		stage_cs.kernels_done();
@@ -1576,10 +1595,14 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		stage_cs.done_after(m->ev[4]);
 		MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		if (int rc = cs_host_arrays(m)) return rc;
-		if (choice_on_gpu && m->p_pair_tied_n.p[0] > 0) {   // the tied pairs' best-scoring combinations (a few thousand records)
-			const size_t nt = std::min<size_t>(m->p_pair_tied_n.p[0], (size_t) n / 2);
-			if (m->p_pair_top.reserve(nt)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
-			MAP_HIP_TRY(hipMemcpy(m->p_pair_top.p, m->d_pair_top.p, nt * sizeof(ngm::PairTop), hipMemcpyDeviceToHost));
+		if (choice_on_gpu) {   // pair_choice_kernel's entries (the pairs with choices only) and the tied pairs' best-scoring combinations
+			const size_t npairs = (size_t) n / 2;
+			const size_t n_small = std::min<size_t>(m->p_pair_tied_n.p[1], npairs), n_large = std::min<size_t>(m->p_pair_tied_n.p[2], npairs), nt = std::min<size_t>(m->p_pair_tied_n.p[0], npairs);
+			if (m->p_pair_out.reserve(2 * npairs + 2) || m->p_pair_top.reserve(nt + 1)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
+			if (n_small) MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_out.p, m->d_pair_out.p, n_small * sizeof(ngm::PairOut), hipMemcpyDeviceToHost, m->st));
+			if (n_large) MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_out.p + npairs, m->d_pair_out.p + npairs, n_large * sizeof(ngm::PairOut), hipMemcpyDeviceToHost, m->st));
+			if (nt) MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_top.p, m->d_pair_top.p, nt * sizeof(ngm::PairTop), hipMemcpyDeviceToHost, m->st));
+			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		}
 		lap(1);
 		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
@@ -1657,21 +1680,23 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				long gsum = 0, gcnt = 0, walked = 0;
 				for (int pi = plo; pi < phi; ++pi) {
 					const int rb = 2 * pi, ra = 2 * pi + 1;
-					if (simple_on_gpu && m->p_pair_info.p[pi] >= 0) {   // one candidate per mate: pair_simple_kernel has settled it
+					const int pinfo = simple_on_gpu ? m->p_pair_info.p[pi] : -1;
+					if (simple_on_gpu && pinfo >= 0) {   // one candidate per mate: pair_simple_kernel has settled it
 						const int info = m->p_pair_info.p[pi];
 						if (info & 1) { pair_flags[ra] = pair_flags[rb] = NGM_PAIR_SELECTED; gsum += info >> 1; ++gcnt; }
 						else pair_flags[ra] = pair_flags[rb] = NGM_PAIR_FAILED;
 						continue;
 					}
 					if (m->h_count[ra] == 0 || m->h_count[rb] == 0) { se_check(local_se, rb); se_check(local_se, ra); continue; }  // top1SE for the mate that has candidates (ScoreBuffer.cpp:204-209)
-					if (h_po && !(h_po[pi].flags & ngm::kPairHost)) {   // pair_choice_kernel: settled, or what the sequential passes need
-						const ngm::PairOut &po = h_po[pi];
+					const ngm::PairOut *pe = nullptr;
+					if (h_po && pinfo <= -2) { const uint32_t e = (uint32_t) (-2 - (long long) pinfo); pe = &h_po[e >= (1u << 30) ? (size_t) (n / 2) + (e - (1u << 30)) : e]; }
+					if (pe && !(pe->flags & ngm::kPairHost)) {   // pair_choice_kernel: settled, or what the sequential passes need
+						const ngm::PairOut &po = *pe;
 						const bool found = (po.flags & ngm::kPairFound) != 0;
 						const int mqa = (po.flags >> 8) & 255, mqb = (po.flags >> 16) & 255;
 						if (po.flags & ngm::kPairTied) {
 							Tied t{pi, found, (po.flags & ngm::kPairDup) != 0, true, po.dmin, po.dmax, mqa, mqb, 0, 0, std::min((po.flags >> 24) & 15, 8), {}, {}, {}, gsum, gcnt, 0, -1};
 							gsum = gcnt = 0;
-							if (po.n_combo > ngm::kPairCombos) t.n_top = 0;
 							const ngm::PairTop &pt = h_pt[po.tied_ix];
 							for (int x = 0; x < t.n_top; ++x) { t.top_d[x] = pt.d[x]; t.top_a[x] = pt.a[x]; t.top_b[x] = pt.b[x]; }
 							local.push_back(t);

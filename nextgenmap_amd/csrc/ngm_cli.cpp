@@ -258,7 +258,6 @@ Opts parse(int argc, char **argv) {
 		info("MAIN", "Using bs-mapping scoring scheme");
 		if (o.affine) die("'--bs-mapping' and '--affine' can't be used at the same time!");
 		if (o.mode == 1) die("'--bs-mapping' and '--e/--end-to-end' can't be used at the same time!");
-		if (o.topn > 1) die("'--bs-mapping' and '-n/--topn' can't be used at the same time (HIP backend)");
 		if (!o.match_set) o.match = 4;
 		if (!o.mismatch_set) o.mismatch = 2;
 		if (o.gap_read < 0) o.gap_read = 10;
@@ -733,7 +732,7 @@ int main(int argc, char **argv) {
 	mallopt(M_TOP_PAD, 64 << 20);
 	const auto t_process = std::chrono::steady_clock::now();
 	Opts o = parse(argc, argv);
-	if (o.shard_output && (o.devices.size() > 1 || getenv("NGM_HIP_SHARD_SINGLE")) && o.shard_n == 1 && !o.out.empty() && !(o.qry.empty() && o.qry1.empty())) return run_sharded(argc, argv, o);
+	if (o.shard_output && (o.devices.size() > 1 || getenv("NGM_HIP_SHARD_SINGLE")) && o.shard_n == 1 && o.stats_fd < 0 && !o.out.empty() && !(o.qry.empty() && o.qry1.empty())) return run_sharded(argc, argv, o);   // (a shard process has its parent's --stats-fd)
 	// a shard process of `-g a,b,... --shard-output` on distinct GPUs: join the communicator of the one collective of the path (the final
 	// statistics all-reduce, RCCL over xGMI) NOW, on a thread of its own -- ncclCommInitRank takes about a second, the load of the index hides it
 	ngm_stats_comm *stats_comm = nullptr;

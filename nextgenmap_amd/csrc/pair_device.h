@@ -26,34 +26,41 @@ namespace ngm {
 constexpr int kPairThreads = 256, kPairCap = 2048, kPairCombos = 64;
 enum : int32_t { kPairFound = 1, kPairTied = 2, kPairDup = 4, kPairHost = 8 };
 
-// flags: kPair* | mq_a << 8 | mq_b << 16 | n_top << 24 (n_top <= 8: the listed best-scoring combinations; 15: more than 8)
-struct PairOut { int32_t flags, wa, wb, dist, dmin, dmax, tied_ix, n_combo; };
+// flags: kPair* | mq_a << 8 | mq_b << 16 | n_top << 24 (n_top <= 8: the listed best-scoring combinations; 15: more than 8; 0 with more than
+// kPairCombos combinations inside the window: none listed)
+struct PairOut { int32_t flags, wa, wb, dist, dmin, dmax, tied_ix, pair; };   // pair: the pair this entry belongs to
 struct PairTop { int32_t d[8], a[8], b[8]; };
 
 __device__ __forceinline__ int pair_f2o(float f) { const int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7FFFFFFF); }   // float order as signed-int order
 __device__ __forceinline__ float pair_o2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7FFFFFFF)); }
 
-// info[pair] >= 0: settled by pair_simple_kernel; mates without candidates are the host's (top1SE for the other mate).
-__global__ __launch_bounds__(kPairThreads) void pair_choice_kernel(int n_pairs, const uint32_t *__restrict__ cand_base, const uint32_t *__restrict__ cand_count,
-		const float *__restrict__ scores, const uint32_t *__restrict__ pair_loc, const uint16_t *__restrict__ read_len, int min_d, int max_d, float cutoff,
-		const int32_t *__restrict__ info, PairOut *__restrict__ out, PairTop *__restrict__ tops, uint32_t *__restrict__ tied_count, uint32_t tied_cap) {
-	constexpr int NT = kPairThreads, NW = NT / 64;
-	__shared__ uint32_t s_loc[2][kPairCap];
-	__shared__ uint16_t s_ix[2][kPairCap];
+// list[0 .. *list_count): the pairs pair_simple_kernel left (both mates have candidates, at least one of them several); out[i] belongs to
+// list[i] (PairOut::pair names it); persistent workgroups walk the list with the grid's stride.
+// NT threads per pair, at most CAP candidates above the cut-off per mate: <64, 64> (one wave) for the pairs whose mates have up to 64
+// candidates each -- nearly all of them --, <kPairThreads, kPairCap> for the others (pair_simple_kernel sorts them into the two lists).
+template <int NT, int CAP>
+__global__ __launch_bounds__(NT) void pair_choice_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count, const uint32_t *__restrict__ cand_base,
+		const uint32_t *__restrict__ cand_count, const float *__restrict__ scores, const uint32_t *__restrict__ pair_loc, const uint16_t *__restrict__ read_len, int min_d, int max_d,
+		float cutoff, PairOut *__restrict__ out, PairTop *__restrict__ tops, uint32_t *__restrict__ tied_count, uint32_t tied_cap) {
+	constexpr int NW = NT / 64;
+	__shared__ uint32_t s_loc[2][CAP];
+	__shared__ uint16_t s_ix[2][CAP];
 	__shared__ int s_red[3][NW];
 	__shared__ uint32_t s_n[2], s_ncombo;
 	__shared__ int s_top;   // bits of the largest positive pair score inside the window (0: none)
 	__shared__ float s_cps[kPairCombos];
 	__shared__ int s_cd[kPairCombos], s_ca[kPairCombos], s_cb[kPairCombos];
-	const int pi = blockIdx.x;
-	if (pi >= n_pairs || info[pi] >= 0) return;
+	const uint32_t n_list = *list_count;
+	for (uint32_t item = blockIdx.x; item < n_list; item += gridDim.x) {
+	__syncthreads();   // (the previous pair's shared state is no longer read)
+	const int pi = (int) list[item];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int rb = 2 * pi, ra = 2 * pi + 1;   // `a` = the mate whose scores arrive last in the reference (the odd read id): the outer loop of top1PE
 	const uint32_t cnt[2] = {cand_count[ra], cand_count[rb]}, base[2] = {cand_base[ra], cand_base[rb]};
-	if (cnt[0] == 0u || cnt[1] == 0u) return;
 	const int len_a = (int) read_len[ra], len_b = (int) read_len[rb];
 	if (tid == 0) { s_n[0] = s_n[1] = 0; s_ncombo = 0; s_top = 0; }
-	PairOut po{0, -1, -1, 0, 0, 0, -1, 0};
+	__syncthreads();
+	PairOut po{0, -1, -1, 0, 0, 0, -1, pi};
 	bool to_host = false;
 	int mq[2];
 	for (int side = 0; side < 2; ++side) {
@@ -89,17 +96,17 @@ __global__ __launch_bounds__(kPairThreads) void pair_choice_kernel(int n_pairs, 
 			const float s = scores[b0 + j];
 			if (head_only ? (pair_f2o(s) == mx) : (mn <= s)) {
 				const uint32_t at = atomicAdd(&s_n[side], 1u);
-				if (at < (uint32_t) kPairCap) { s_loc[side][at] = pair_loc[b0 + j]; s_ix[side][at] = (uint16_t) min(j, 65535u); }
+				if (at < (uint32_t) CAP) { s_loc[side][at] = pair_loc[b0 + j]; s_ix[side][at] = (uint16_t) min(j, 65535u); }
 			}
 		}
 		if (c > 65535u) to_host = true;
 		__syncthreads();
 	}
 	const uint32_t na = s_n[0], nbb = s_n[1];
-	if (na > (uint32_t) kPairCap || nbb > (uint32_t) kPairCap) to_host = true;
+	if (na > (uint32_t) CAP || nbb > (uint32_t) CAP) to_host = true;
 	if (to_host) {
-		if (tid == 0) { po.flags = kPairHost | (mq[0] << 8) | (mq[1] << 16); out[pi] = po; }
-		return;
+		if (tid == 0) { po.flags = kPairHost | (mq[0] << 8) | (mq[1] << 16); out[item] = po; }
+		continue;
 	}
 	// every combination inside the insert-size window; the larger side across the lanes
 	{
@@ -126,11 +133,10 @@ __global__ __launch_bounds__(kPairThreads) void pair_choice_kernel(int n_pairs, 
 		}
 	}
 	__syncthreads();
-	if (wv != 0) return;
+	if (wv != 0) continue;
 	const uint32_t nc = s_ncombo;
 	const float top = __int_as_float(s_top);   // 0.0f: no positive pair score
 	const bool found = s_top > 0;
-	po.n_combo = (int32_t) min(nc, 0x7FFFFFFFu);
 	int flags = (found ? kPairFound : 0) | (mq[0] << 8) | (mq[1] << 16);
 	int n_top = 0;
 	if (nc > (uint32_t) kPairCombos) {
@@ -182,7 +188,8 @@ __global__ __launch_bounds__(kPairThreads) void pair_choice_kernel(int n_pairs, 
 			}
 		} else flags = (flags & ~(kPairTied | kPairDup)) | kPairHost;   // (the list is sized for every pair: not reached)
 	}
-	if (lane == 0) { po.flags = flags | (min(n_top, 15) << 24); out[pi] = po; }
+	if (lane == 0) { po.flags = flags | ((nc > (uint32_t) kPairCombos ? 0 : min(n_top, 15)) << 24); out[item] = po; }
+	}
 }
 
 }  // namespace ngm

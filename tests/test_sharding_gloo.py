@@ -103,6 +103,8 @@ FAKE_NGM_HIP = textwrap.dedent('''\
         sys.stderr.write("[PREPROCESS] Reference and index ready: 0.%%d00 s (cache)\\n" %% (k + 1))
         sys.stderr.write("[MAIN] Done (%%d reads mapped (99.00%%%%), %%d reads not mapped, %%d lines written)\\n" %% (per - 1, 1, per))
         sys.stderr.write("[MAIN] Input to output: 0.%%d50 s (estimation pass + mapping pass, first input byte to output closed)\\n" %% (k + 1))
+    sys.stderr.write("[MAIN] Done, %%d shards summed (%%d reads mapped (99.00%%%%), %%d reads not mapped, %%d lines written; %%d reads; %%d pairs with both mates mapped, %%d of them broken, mean insert size 350.0)\\n"
+                     %% (len(gpus), len(gpus) * (per - 1), len(gpus), len(gpus) * per, len(gpus) * per, len(gpus) * per // 2 - 1, 3))
     sys.stderr.write("[MAIN] %%d shards appended to the output in 0.010 s\\n" %% len(gpus))
 ''')
 
@@ -129,4 +131,5 @@ def test_bench_config4_leg_two_ranks(tmp_path):
     assert e["per_shard_input_to_output_s"] == [0.15, 0.25] and e["per_shard_index_load_s"] == [0.1, 0.2] and e["append_s"] == 0.01
     assert abs(e["seconds_first_input_byte_to_concatenated_sam_closed"] - 0.26) < 1e-9 and abs(e["value"] - 10000 / 0.26) < 1e-6
     assert e["stats_summed_over_shards"] == {"mapped": 2 * 4999, "unmapped": 2, "written": 10000}
+    assert e["stats_summed_by_the_parent_process"] == {"shards": 2, "mapped": 2 * 4999, "unmapped": 2, "written": 10000, "reads": 10000, "pairs_total": 4999, "pairs_broken": 3, "mean_insert_size": 350.0}
     assert "-g 0,1 --shard-output" in e["command"]
