@@ -1191,6 +1191,7 @@ __host__ __device__ inline uint32_t cs_order_tau(int lists_cap) { return (uint32
 // tracked bins in a per-read slice of global memory sized from the read's hits (A.ovf_table_off / A.ovf_log2 / A.gtable_keys), and
 // 32-bit hit times (l_time) instead of the 16-bit ones packed into l_pref.  Nothing is given up but a bisulfite read with more
 // k-mer variants than the list rows hold.
+constexpr uint32_t kCsOrderStage = 2048;      // entries of a wave's staging buffer (GLOBAL)
 constexpr int kCsOrderThreadsGlobal = 1024;   // the exact replay in global memory: every step of it waits for L2 -- four times the waves per read
 template <bool GLOBAL>
 __global__ __launch_bounds__(GLOBAL ? kCsOrderThreadsGlobal : kCsOrderThreads) void cs_order_kernel(CsArgs A, const uint32_t *__restrict__ cand_loc, const uint32_t *__restrict__ cand_sv,
@@ -1226,6 +1227,10 @@ __global__ __launch_bounds__(GLOBAL ? kCsOrderThreadsGlobal : kCsOrderThreads) v
 	uint32_t *l_time = seg_pref + A.lists_cap + 1 + (A.bs ? (size_t) A.q + 1 + A.lists_cap / 4 + 1 : 0);   // GLOBAL: [lists_cap] time of every list's first hit
 	uint32_t *tau = l_time + (GLOBAL ? A.lists_cap : 0);   // [cs_order_tau(lists_cap)]
 	const uint32_t n_tau = cs_order_tau(A.lists_cap);
+	// GLOBAL: per wave a staging buffer for the hit times of 64 slots at a time (their segments are contiguous in tm: one coalesced copy
+	// in, the segments sorted in LDS, one coalesced copy out -- a load per segment from L2 was 1 of the 1.5 ms of the replay's last phase)
+	const uint32_t stage = GLOBAL ? A.order_gcap : 0u;   // (GLOBAL: order_gcap carries the staging entries per wave; 0: none -- bisulfite runs, whose list rows take the LDS)
+	uint32_t *wbuf = tau + n_tau + (size_t) (threadIdx.x >> 6) * stage;
 	const bool diag = A.phase_cycles && (blockIdx.x & 63) == 0;
 	unsigned long long ck[6] = {0, 0, 0, 0, 0, 0};
 	if (diag) ck[0] = wall_clock64();  // [lists_cap + 1]: work items (8-hit list segments) in front of each list
@@ -1477,53 +1482,174 @@ __global__ __launch_bounds__(GLOBAL ? kCsOrderThreadsGlobal : kCsOrderThreads) v
 		}
 		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		__syncthreads();
-		// (c) segments sorted by time (they arrive nearly sorted: threads walk the time line upwards); tau
-		for (uint32_t i = tid; i < n_ent; i += NT) {
-			const uint32_t s2 = slot_of(i);
-			const uint32_t off = t_off[s2];
-			t_fill[s2] = kCsOrderUnknown;
-			if (off == 0xFFFFFFFFu) continue;
-			uint32_t nf, nr;
-			(void) kept(s2, nf, nr);
-			uint32_t *seg = tm + off;
-			for (int st = 0; st < 2; ++st) {
-				const uint32_t n2 = st ? nr : nf;
-				uint32_t *g = seg + (st ? nf : 0u);
-				for (uint32_t x = 1; x < n2; ++x) {
-					const uint32_t key = g[x];
-					uint32_t y = x;
-					while (y > 0 && g[y - 1] > key) { g[y] = g[y - 1]; --y; }
-					g[y] = key;
+		// (c) segments sorted by time; tau.  A WAVE per segment (round 5, second version: a thread per slot walked its segments with one
+		// dependent load per element -- 1.5 of the 2.3 ms of an average read replayed in global memory): the lanes of a wave take the
+		// meta data of 64 slots, then the wave goes through their segments one by one -- one coalesced load (the next segment's already
+		// in flight), every element's rank by counting (times are distinct), the element stored at its rank, atomicMin into tau.
+		// Segments of more than 64 hits (a bin with more votes than that on one strand) stay with the lane that owns the slot.
+		auto serial_segment = [&](uint32_t *g, uint32_t n2) {
+			for (uint32_t x = 1; x < n2; ++x) {
+				const uint32_t key = g[x];
+				uint32_t y = x;
+				while (y > 0 && g[y - 1] > key) { g[y] = g[y - 1]; --y; }
+				g[y] = key;
+			}
+			if (n2 >= n_tau) { atomicExch(&s_bad, 1u); return; }
+			for (uint32_t j = 1; j <= n2; ++j) atomicMin(&tau[j], g[j - 1]);
+		};
+		for (uint32_t i0 = (uint32_t) wv * 64u; i0 < n_ent; i0 += (uint32_t) (NT / 64) * 64u) {
+			const uint32_t i = i0 + (uint32_t) lane;
+			const uint32_t s2 = i < n_ent ? slot_of(i) : 0u;
+			uint32_t off = i < n_ent ? t_off[s2] : 0xFFFFFFFFu, nf = 0, nr = 0;
+			if (i < n_ent) t_fill[s2] = kCsOrderUnknown;
+			if (off != 0xFFFFFFFFu) (void) kept(s2, nf, nr);
+			// segments of more than 64 hits (a bin that nearly every k-mer of the read votes for: satellite arrays) -- up to 320 by the
+			// whole wave, five elements per lane, ranks by counting over all chunks; beyond that the owning lane, serially.  (Left to the
+			// owning lanes they were most of this phase: one dependent load per element and an insertion sort in global memory.)
+			{
+				const bool bigseg = off != 0xFFFFFFFFu && (nf > 64u || nr > 64u);
+				if (bigseg && (nf > 320u || nr > 320u)) { serial_segment(tm + off, nf); serial_segment(tm + off + nf, nr); }
+				unsigned long long bm = __ballot(bigseg && nf <= 320u && nr <= 320u);
+				while (bm) {
+					const int kb = (int) __builtin_ctzll(bm);
+					bm &= bm - 1ull;
+					const uint32_t o = (uint32_t) __builtin_amdgcn_readlane((int) off, kb), f = (uint32_t) __builtin_amdgcn_readlane((int) nf, kb), r = (uint32_t) __builtin_amdgcn_readlane((int) nr, kb);
+					for (int st2 = 0; st2 < 2; ++st2) {
+						const uint32_t n2 = st2 ? r : f;
+						uint32_t *g = tm + o + (st2 ? f : 0u);
+						if (n2 == 0u) continue;
+						uint32_t ev[5], rk[5];
+#pragma unroll
+						for (int c2 = 0; c2 < 5; ++c2) { const uint32_t x = (uint32_t) c2 * 64u + (uint32_t) lane; ev[c2] = x < n2 ? g[x] : 0xFFFFFFFFu; rk[c2] = 0; }
+#pragma unroll
+						for (int cm = 0; cm < 5; ++cm) {
+							if ((uint32_t) cm * 64u >= n2) break;
+							const uint32_t lim = min(64u, n2 - (uint32_t) cm * 64u);
+							for (uint32_t mm = 0; mm < lim; ++mm) {
+								const uint32_t vk = (uint32_t) __builtin_amdgcn_readlane((int) ev[cm], (int) mm);
+#pragma unroll
+								for (int c2 = 0; c2 < 5; ++c2) rk[c2] += vk < ev[c2] ? 1u : 0u;
+							}
+						}
+#pragma unroll
+						for (int c2 = 0; c2 < 5; ++c2) if ((uint32_t) c2 * 64u + (uint32_t) lane < n2) {
+							g[rk[c2]] = ev[c2];
+							if (rk[c2] + 1u < n_tau) atomicMin(&tau[rk[c2] + 1u], ev[c2]); else atomicExch(&s_bad, 1u);
+						}
+					}
 				}
-				if (n2 >= n_tau) { atomicExch(&s_bad, 1u); continue; }
-				for (uint32_t j = 1; j <= n2; ++j) atomicMin(&tau[j], g[j - 1]);
+				if (bigseg) off = 0xFFFFFFFFu;
+			}
+			const unsigned long long todo = __ballot(off != 0xFFFFFFFFu);
+			// GLOBAL: the 64 slots' segments are one contiguous range of tm (offsets were handed out in list order): through the staging buffer
+			uint32_t *src = tm;
+			uint32_t r_lo = 0, r_hi = 0, sub = 0;
+			bool staged = false;
+			if (GLOBAL && todo) {
+				r_lo = (uint32_t) wave_reduce_min(off != 0xFFFFFFFFu ? (int) off : 0x7FFFFFFF);
+				r_hi = (uint32_t) wave_reduce_max(off != 0xFFFFFFFFu ? (int) (off + nf + nr) : 0);
+				if (r_hi - r_lo <= stage) {
+					for (uint32_t x = (uint32_t) lane; x < r_hi - r_lo; x += 64u) wbuf[x] = tm[r_lo + x];
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					src = wbuf; sub = r_lo;   // (indexed with the same offsets, less the range's start)
+					staged = true;
+				}
+			}
+			// the segments of these slots, forward then reverse, one after the other; the next one's elements are loaded before the current one is ranked
+			uint32_t e_cur = 0xFFFFFFFFu, n_cur = 0, base_cur = 0;
+			unsigned long long left = todo;
+			int kk = left ? (int) __builtin_ctzll(left) : 64, st = 0;
+			auto next_segment = [&](uint32_t &e, uint32_t &n2, uint32_t &base) {   // advances (kk, st) to the next non-empty segment and issues its load
+				n2 = 0; e = 0xFFFFFFFFu; base = 0;
+				while (kk < 64) {
+					const uint32_t o = (uint32_t) __builtin_amdgcn_readlane((int) off, kk), f = (uint32_t) __builtin_amdgcn_readlane((int) nf, kk), r = (uint32_t) __builtin_amdgcn_readlane((int) nr, kk);
+					const uint32_t n = st ? r : f, b2 = o + (st ? f : 0u);
+					if (st == 0) st = 1; else { st = 0; left &= left - 1ull; kk = left ? (int) __builtin_ctzll(left) : 64; }
+					if (n) { n2 = n; base = b2 - sub; e = (uint32_t) lane < n ? src[base + (uint32_t) lane] : 0xFFFFFFFFu; return; }
+				}
+			};
+			next_segment(e_cur, n_cur, base_cur);
+			while (n_cur) {
+				uint32_t e_nx, n_nx, base_nx;
+				next_segment(e_nx, n_nx, base_nx);
+				uint32_t rank = 0;
+				for (uint32_t mm = 0; mm < n_cur; ++mm) rank += (uint32_t) __builtin_amdgcn_readlane((int) e_cur, (int) mm) < e_cur ? 1u : 0u;
+				if ((uint32_t) lane < n_cur) {
+					src[base_cur + rank] = e_cur;
+					if (rank + 1u < n_tau) atomicMin(&tau[rank + 1u], e_cur); else atomicExch(&s_bad, 1u);
+				}
+				e_cur = e_nx; n_cur = n_nx; base_cur = base_nx;
+			}
+			if (staged) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				for (uint32_t x = (uint32_t) lane; x < r_hi - r_lo; x += 64u) tm[r_lo + x] = wbuf[x];
 			}
 		}
 		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		__syncthreads();
 		if (s_bad) { give_up(4u, H, s_keys); return; }   // (more votes for one bin and strand than the read has k-mers + 64: not reached)
-		// (d) when does every candidate's bin enter rList
-		for (uint32_t i = tid; i < n_ent; i += NT) {
-			const uint32_t s2 = slot_of(i);
-			if (!t_cand[s2]) continue;
-			const uint32_t off = t_off[s2];
-			if (off == 0xFFFFFFFFu) continue;
-			uint32_t nf, nr;
-			(void) kept(s2, nf, nr);
-			const uint32_t *seg = tm + off;
-			uint32_t enter = kCsOrderUnknown;
-			for (int st = 0; st < 2; ++st) {
-				const uint32_t n2 = st ? nr : nf;
-				const uint32_t *g = seg + (st ? nf : 0u);
-				for (uint32_t j = 1; j <= n2; ++j) {
-					const uint32_t t = g[j - 1];
-					if (t >= enter) break;
-					uint32_t lo = 1, hi = n_tau;   // M(t): the largest v with tau[v] <= t (tau[1] = 0 <= t)
-					while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tau[mid] <= t) lo = mid; else hi = mid; }
-					if ((float) j >= (float) lo * A.sensitivity) { enter = t; break; }
+		// (d) when does every candidate's bin enter rList: a wave per candidate slot, lane j - 1 looks at the j-th hit of a strand
+		for (uint32_t i0 = (uint32_t) wv * 64u; i0 < n_ent; i0 += (uint32_t) (NT / 64) * 64u) {
+			const uint32_t i = i0 + (uint32_t) lane;
+			const uint32_t s2 = i < n_ent ? slot_of(i) : 0u;
+			uint32_t off = (i < n_ent && t_cand[s2]) ? t_off[s2] : 0xFFFFFFFFu, nf = 0, nr = 0;
+			if (off != 0xFFFFFFFFu) (void) kept(s2, nf, nr);
+			uint32_t enter_mine = kCsOrderUnknown;
+			{
+				// a candidate's segments of more than 64 hits: the wave looks at them 64 hits at a time (times increase with j: the first chunk
+				// with a qualifying hit ends the strand)
+				const bool bigseg = off != 0xFFFFFFFFu && (nf > 64u || nr > 64u);
+				unsigned long long bm = __ballot(bigseg);
+				while (bm) {
+					const int kb = (int) __builtin_ctzll(bm);
+					bm &= bm - 1ull;
+					const uint32_t o = (uint32_t) __builtin_amdgcn_readlane((int) off, kb), f = (uint32_t) __builtin_amdgcn_readlane((int) nf, kb), r = (uint32_t) __builtin_amdgcn_readlane((int) nr, kb);
+					uint32_t enter = kCsOrderUnknown;
+					for (int st2 = 0; st2 < 2; ++st2) {
+						const uint32_t n2 = st2 ? r : f;
+						const uint32_t *g = tm + o + (st2 ? f : 0u);
+						for (uint32_t j0 = 0; j0 < n2; j0 += 64u) {
+							const uint32_t j = j0 + (uint32_t) lane + 1u;
+							const uint32_t t = j <= n2 ? g[j - 1u] : 0xFFFFFFFFu;
+							uint32_t lo = 1, hi = n_tau;
+							while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tau[mid] <= t) lo = mid; else hi = mid; }
+							const unsigned long long mk = __ballot(t != 0xFFFFFFFFu && (float) j >= (float) lo * A.sensitivity);
+							if (mk) { enter = min(enter, (uint32_t) __builtin_amdgcn_readlane((int) t, (int) __builtin_ctzll(mk))); break; }
+						}
+					}
+					if (lane == kb) enter_mine = enter;
+				}
+				if (bigseg) { t_fill[s2] = enter_mine; off = 0xFFFFFFFFu; }
+			}
+			unsigned long long left = __ballot(off != 0xFFFFFFFFu);
+			const uint32_t *src = tm;
+			uint32_t sub = 0;
+			if (GLOBAL && left) {   // the candidates' segments of these 64 slots: staged when they lie close together
+				const uint32_t r_lo = (uint32_t) wave_reduce_min(off != 0xFFFFFFFFu ? (int) off : 0x7FFFFFFF), r_hi = (uint32_t) wave_reduce_max(off != 0xFFFFFFFFu ? (int) (off + nf + nr) : 0);
+				if (r_hi - r_lo <= stage) {
+					for (uint32_t x = (uint32_t) lane; x < r_hi - r_lo; x += 64u) wbuf[x] = tm[r_lo + x];
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					src = wbuf; sub = r_lo;
 				}
 			}
-			t_fill[s2] = enter;
+			while (left) {
+				const int kk = (int) __builtin_ctzll(left);
+				left &= left - 1ull;
+				const uint32_t o = (uint32_t) __builtin_amdgcn_readlane((int) off, kk), f = (uint32_t) __builtin_amdgcn_readlane((int) nf, kk), r = (uint32_t) __builtin_amdgcn_readlane((int) nr, kk);
+				const uint32_t tf = (uint32_t) lane < f ? src[o - sub + (uint32_t) lane] : 0xFFFFFFFFu, tr = (uint32_t) lane < r ? src[o - sub + f + (uint32_t) lane] : 0xFFFFFFFFu;
+				uint32_t enter = kCsOrderUnknown;
+#pragma unroll
+				for (int st2 = 0; st2 < 2; ++st2) {
+					const uint32_t t = st2 ? tr : tf;
+					uint32_t lo = 1, hi = n_tau;   // M(t): the largest v with tau[v] <= t (tau[1] = 0 <= t)
+					while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tau[mid] <= t) lo = mid; else hi = mid; }
+					const bool in = t != 0xFFFFFFFFu && (float) (lane + 1) >= (float) lo * A.sensitivity;
+					const unsigned long long mk = __ballot(in);
+					if (mk) enter = min(enter, (uint32_t) __builtin_amdgcn_readlane((int) t, (int) __builtin_ctzll(mk)));   // the first j that qualifies (times increase with j)
+				}
+				if (lane == kk) enter_mine = enter;
+			}
+			if (off != 0xFFFFFFFFu) t_fill[s2] = enter_mine;
 		}
 		if (GLOBAL) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 	}

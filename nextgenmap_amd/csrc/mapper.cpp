@@ -819,7 +819,11 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	{
 		int lo = 0, hi = 0;
 		(void) hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = greatest priority
-		if (hipStreamCreateWithPriority(&m->st_hi, hipStreamNonBlocking, hi) != hipSuccess) m->st_hi = nullptr;
+		// (the order replay's stream: greatest priority by default -- persistent search workgroups hold every CU until their launch ends, and
+		// the replay gets in as they leave; NGM_HIP_ORDER_PRIORITY=low / normal: experiments on workloads whose replays are long)
+		int prio = hi;
+		if (const char *e = getenv("NGM_HIP_ORDER_PRIORITY")) prio = !strcmp(e, "low") ? lo : !strcmp(e, "normal") ? (lo + hi) / 2 : hi;
+		if (hipStreamCreateWithPriority(&m->st_hi, hipStreamNonBlocking, prio) != hipSuccess) m->st_hi = nullptr;
 		if (hipStreamCreateWithFlags(&m->st_copy, hipStreamNonBlocking) != hipSuccess) m->st_copy = nullptr;
 		for (auto &e : m->turn_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
 		if (hipEventCreateWithFlags(&m->ev_cs_done, hipEventDisableTiming) != hipSuccess) m->ev_cs_done = nullptr;
@@ -1053,10 +1057,11 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		}
 		if (m->d_order_big.reserve(nb) || m->d_order_log2.reserve(nb) || m->d_order_off.reserve(nb)) { ngm::pipeline_set_error("out of device memory (exact candidate order)"); return -12; }
 		ngm::CsArgs G = m->order_args;
-		G.order_info = nullptr; G.order_scratch = nullptr; G.order_gcap = 0; G.order_max_hits = 0;
+		G.order_info = nullptr; G.order_scratch = nullptr; G.order_max_hits = 0;
+		G.order_gcap = G.bs ? 0u : ngm::kCsOrderStage;   // (cs_order_kernel<true>: staging entries per wave)
 		G.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + (size_t) ngm::kCsRegions * ngm::kCsCursorStride : nullptr;   // diagnostics: phases of every 64th workgroup
 		if (G.phase_cycles) MAP_HIP_TRY(hipMemsetAsync(G.phase_cycles + 8, 0, 12 * 8, ost));
-		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + ngm::cs_order_tau(G.lists_cap) + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
+		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + ngm::cs_order_tau(G.lists_cap) + (size_t) (ngm::kCsOrderThreadsGlobal / 64) * G.order_gcap + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
 		// (8 GB per launch: a read with 50 000 hits takes 2.6 MB of table and time line, and with the 1.5 GB pool of the first version the
 		// 5 500 such reads of a heavy-tailed batch went through ten launches of ~570 workgroups each -- two per CU, 118 ms of waiting per batch)
 		constexpr uint64_t kPoolWords = 2048ull << 20;
@@ -1551,8 +1556,12 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		const bool pe_select = paired && !m->fast_pairing;   // --fast-pairing: the mates are selected single-end, the writer checks the pair (AlignmentBuffer.cpp:176-199)
 		const bool simple_on_gpu = pe_select && pair_gpu && m->prm.strata == 0;   // (--strata touches NH of every pair: host)
 		// ... and the pairs with choices: everything the scores alone decide (pair_device.h); NGM_HIP_HOST_PAIR_CHOICE=1 keeps the host's walk
-		static const bool pair_choice_gpu = !getenv("NGM_HIP_HOST_PAIR_CHOICE");
-		const bool choice_on_gpu = simple_on_gpu && pair_choice_gpu;
+		// (which side walks the pairs with choices depends on the workload: with ~1.2 candidates per read -- a genome without a heavy tail --
+		// the pairs with choices have two or three candidates, the host's pass 1 is 1.4 ms on the pool beside the other instance's kernels,
+		// and the two extra kernel launches cost the step more than they save: 50.0-50.3 M reads/s against 51.8 M on one box,
+		// profiles/r05_main_leg_ab_vs_r04.txt; from 3 candidates per read on the GPU takes them.  NGM_HIP_HOST_PAIR_CHOICE=1 / NGM_HIP_GPU_PAIR_CHOICE=1 force a side)
+		static const bool pair_choice_host = getenv("NGM_HIP_HOST_PAIR_CHOICE") != nullptr, pair_choice_force = getenv("NGM_HIP_GPU_PAIR_CHOICE") != nullptr;
+		const bool choice_on_gpu = simple_on_gpu && !pair_choice_host && (pair_choice_force || np >= 3ull * (uint64_t) n);
 		if (simple_on_gpu) {
 			// pairs whose mates have one candidate each (most): settled here, the host only sums their insert sizes; the others are sorted
 			// into two lists for pair_choice_kernel (mates with up to 64 candidates each: one wave per pair; the rest: a workgroup)

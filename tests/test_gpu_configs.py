@@ -109,9 +109,9 @@ def test_pipeline_output_independent_of_workers_and_batches(tmp_path):
     S.write_fastq(f2, r2)
     subprocess.check_call("gzip -k %s %s" % (f1, f2), shell=True)
 
-    def run(tag, extra, inputs):
+    def run(tag, extra, inputs, env=None):
         out = str(tmp_path / (tag + ".sam"))
-        c = subprocess.run([CLI, "-r", fa, "-o", out, "--affine"] + inputs + extra, capture_output=True, text=True)
+        c = subprocess.run([CLI, "-r", fa, "-o", out, "--affine"] + inputs + extra, capture_output=True, text=True, env=dict(os.environ, **env) if env else None)
         assert c.returncode == 0, c.stderr[-2000:]
         body = [l for l in open(out, "rb") if not l.startswith(b"@PG")]
         return body, c.stderr
@@ -126,6 +126,10 @@ def test_pipeline_output_independent_of_workers_and_batches(tmp_path):
     c1 = re.search(r"Pairs lost as NextGenMap loses them .*: (\d+)", log1)
     assert c0 and c1 and c0.groups() == c1.groups(), (log0[-600:], log1[-600:])
     assert len(base) == len(piped) and base == piped
+    # the pairs with choices: settled by pair_choice_kernel (what a repeat-rich genome gets by itself) or walked by the host -- same records
+    on_gpu, _ = run("pair-gpu", ["--workers", "2", "--batch-size", "8192"], ["-1", f1, "-2", f2], env={"NGM_HIP_GPU_PAIR_CHOICE": "1"})
+    on_host, _ = run("pair-host", ["--workers", "2", "--batch-size", "8192"], ["-1", f1, "-2", f2], env={"NGM_HIP_HOST_PAIR_CHOICE": "1"})
+    assert on_gpu == base and on_host == base
     gz, log2 = run("gz", ["--workers", "2", "--batch-size", "10000"], ["-1", f1 + ".gz", "-2", f2 + ".gz"])
     assert "gzip FASTQ inflated to memory" in log2
     assert gz == base
