@@ -569,6 +569,7 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
         for k in kms:
             k[:] = 0
         before = [m_.path_counters() for m_ in mps]
+        before_t = sum(m_.order_table_reads() for m_ in mps)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(args.heavy_tail_steps)
@@ -599,6 +600,7 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
                "per_read": {"candidates": n_cand / R, "index_hits": hits_voted / R, "kmers": kmers / R},
                "share_of_reads": {"heavy_read_kernel": pc["heavy"] / nr, "exact_search_lds_table": pc["exact_lds"] / nr, "exact_search_global_table": pc["exact_global"] / nr,
                                   "candidate_order_replayed": pc["order_replayed"] / nr, "candidate_order_exact_global_replay": pc["order_exact_global"] / nr,
+                                  "candidate_order_replay_with_a_table_in_global_memory": (sum(m_.order_table_reads() for m_ in mps) - before_t) / nr,
                                   "candidate_order_undetermined": pc["order_undetermined"] / nr},
                "kernel_ms": {"candidate_search": km[0], "gather_score": km[1], "sw_score": km[2], "select": km[3], "gather_align": km[4], "sw_align": km[5], "traceback": km[6],
                              "all_kernels": all_k, "candidate_order_replay_on_its_own_stream": km[8], "candidate_search_stage_incl_host_sync": km[7]},

@@ -259,9 +259,13 @@ int ngm_mapper_set_reference_cs_batch(ngm_mapper *m, int reads);
 
 /* which paths the reads took, summed over all batches of this mapper: [0] reads searched, [1] candidates, [2] reads re-run by the exact
  * search with its table in LDS, [3] ... in global memory, [4] reads whose candidate order (rList, src/CS.cpp:196-211) was replayed because
- * it decides a tie, [5] of those beyond the limits of the LDS replay (replayed exactly in global memory), [6] reads whose order was
+ * it decides a tie, [5] of those beyond the limits of the LDS replay (replayed exactly through buckets / a table in global memory), [6] reads whose order was
  * left undetermined (ties then resolve by position), [7] reads searched by the heavy-read kernel (more index hits than the fast path takes) */
 int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]);
+
+/* of path counter [5] (reads beyond the LDS replay): the reads the bucket replay (csrc/cs_order_bucket_device.h) left to the replay with a
+ * table in global memory (cs_order_kernel<true>) -- bisulfite runs, a read with a bucket of more than 256 hits, NGM_HIP_ORDER_NO_BUCKETS */
+int ngm_mapper_order_table_reads(ngm_mapper *m, uint64_t *out);
 
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted
  * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */

@@ -61,7 +61,7 @@ inline uint32_t reverse_bits(uint32_t v, int n) {
 // entry_of(symbol) gives the entry without its bit count.  Returns false for an over-subscribed code; an incomplete code is legal only
 // where the format allows it (a single distance code): the unused entries then read "not a valid symbol".
 template <typename F>
-inline bool build_table(const uint8_t *lens, int n, uint32_t *table, int root, int cap, F entry_of) {
+inline bool build_table(const uint8_t *lens, int n, uint32_t *table, int root, int cap, F entry_of, bool code_lengths = false) {
 	int count[16] = {0};
 	for (int i = 0; i < n; ++i) count[lens[i]]++;
 	count[0] = 0;
@@ -74,6 +74,11 @@ inline bool build_table(const uint8_t *lens, int n, uint32_t *table, int root, i
 		code = (code + (uint32_t) count[l - 1]) << 1;
 		next_code[l] = code;
 	}
+	// an incomplete code is an error, as for zlib's inflate_table: only a literal/length or distance alphabet of ONE code of one bit
+	// (or of no code at all) may leave code space unused
+	int longest = 15;
+	while (longest >= 1 && count[longest] == 0) --longest;
+	if (left > 0 && longest != 0 && (code_lengths || longest != 1)) return false;
 	const uint32_t invalid = kExcept | (1u << 16) | 1u;   // (the decoder stops on it)
 	const int root_size = 1 << root;
 	for (int i = 0; i < root_size; ++i) table[i] = invalid;
@@ -219,7 +224,7 @@ inline uint8_t *inflate_stream(BitReader &r, Tables &T, uint8_t *out_begin, uint
 					if (r.cnt < 3) { r.refill_safe(); if (r.cnt < 3) return nullptr; }
 					pl[order[i]] = (uint8_t) r.take(3);
 				}
-				if (!build_table(pl, 19, T.pre, kPreRoot, kPreCap, [](int s) { return (uint32_t) s << 16; })) return nullptr;
+				if (!build_table(pl, 19, T.pre, kPreRoot, kPreCap, [](int s) { return (uint32_t) s << 16; }, true)) return nullptr;
 				uint8_t l[286 + 30 + 140];
 				int i = 0;
 				const int total = hlit + hdist;
@@ -365,15 +370,20 @@ inline bool inflate_file(const char *path, char **text, size_t *len, size_t *res
 	std::atomic<size_t> produced{0};
 	std::atomic<int> state{0};   // 1: all members listed, 2: stop
 	std::atomic<bool> crc_bad{false};
-	// first touch of the output pages: a thread that stays up to 64 MB ahead of the decoder takes the page faults off its path
-	// (an atomic OR with 0 faults a page in for writing and cannot change what the decoder has stored there meanwhile)
+	// first touch of the output pages: a thread that stays up to 64 MB ahead of the decoder takes the page faults off its path.  The
+	// pages are populated by the kernel (MADV_POPULATE_WRITE, Linux 5.14): no store of this thread ever lands in memory the decoder
+	// writes.  Where the kernel lacks it, the decoder takes its own faults.
 	std::thread toucher([&] {
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 		size_t touched = 0;
 		while (state.load(std::memory_order_acquire) == 0) {
-			const size_t target = std::min(want, produced.load(std::memory_order_acquire) + ((size_t) 64 << 20));
+			const size_t target = std::min(want, produced.load(std::memory_order_acquire) + ((size_t) 64 << 20)) & ~(size_t) 4095;
 			if (touched >= target) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }
 			const size_t stop = std::min(target, touched + ((size_t) 4 << 20));
-			for (; touched < stop; touched += 4096) __atomic_fetch_or(out_begin + touched, (uint8_t) 0, __ATOMIC_RELAXED);
+			if (madvise(out_begin + touched, stop - touched, MADV_POPULATE_WRITE) != 0) return;
+			touched = stop;
 		}
 	});
 	std::thread helper;

@@ -29,6 +29,7 @@
 #include "cs_device.h"
 #include "cs_canon_device.h"
 #include "cs_heavy_device.h"
+#include "cs_order_bucket_device.h"
 #include "cs_slam_device.h"
 #define NGM_SAM_KERNELS
 #include "sam_device.h"
@@ -87,7 +88,7 @@ struct ngm_mapper {
 	uint64_t lost_pairs = 0;          // ngm_mapper_lost_pairs
 	// ngm_mapper_path_counters: reads searched, candidates, reads re-run by the exact LDS / exact global-memory search, reads whose
 	// candidate order was replayed, of those beyond the LDS replay's limits (replayed by the exact global-memory kernel), left undetermined
-	uint64_t st_heavy = 0, st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0;
+	uint64_t st_heavy = 0, st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0, st_order_table = 0;
 	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
 	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
 	hipEvent_t turn_ev[16] = {};                     // GpuStage: the events that end this instance's turns
@@ -1031,7 +1032,14 @@ static int candidate_order_wait(ngm_mapper *m, uint32_t **h_rank) {
 // After the LDS replay: wait for it, account for the reads it left to the exact kernel (more hits than its time line, more repeated
 // bins than its table: CsArgs::order_info) and replay those exactly in global memory.  No read keeps an undetermined order silently.
 static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
+	static const bool trace = getenv("NGM_HIP_ORDER_TRACE") != nullptr;   // (diagnostics: where the time of a replay goes, stage by stage)
+	const auto t_trace = std::chrono::steady_clock::now();
+	auto tr = [&](const char *what, unsigned long long a = 0, unsigned long long b = 0, unsigned long long c = 0) {
+		if (trace) fprintf(stderr, "[ngm-hip] order trace %p +%.1f ms: %s %llu %llu %llu\n", (void *) m, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_trace).count(), what, a, b, c);
+	};
+	tr("wait for the LDS replay", m->order_pending.size());
 	MAP_HIP_TRY(hipStreamSynchronize(ost));
+	tr("LDS replay done");
 	{ float t = 0; if (hipEventElapsedTime(&t, m->oev[0], m->oev[1]) == hipSuccess) m->order_ms += t; }
 	const uint32_t nl = (uint32_t) m->order_pending.size();
 	m->st_order_reads += nl;
@@ -1041,6 +1049,73 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		if (FILE *f = fopen(hf, "a")) { for (uint32_t i = 0; i < nl; ++i) fprintf(f, "%u %u %u\n", m->p_order_info.p[2 * i], m->p_order_info.p[2 * i + 1] & 0xFFu, m->p_order_info.p[2 * i + 1] >> 8); fclose(f); }
 	}
 	m->st_order_big += big.size();
+	const std::vector<uint32_t> beyond_lds = big;
+	// The reads beyond the LDS replay: hits dealt into buckets (cs_order_bucket_kernel -- no table in global memory); what that kernel
+	// leaves (bisulfite runs, a bucket of more than 256 hits) goes on to the replay with a table in global memory below.
+	static const bool buckets_on = getenv("NGM_HIP_ORDER_NO_BUCKETS") == nullptr;
+	if (!big.empty() && buckets_on && !m->order_args.bs && ngm::cs_order_tau(m->order_args.lists_cap) <= ngm::kCsOrderBucketMaxTau) {
+		const uint32_t nb = (uint32_t) big.size();
+		std::sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { const uint32_t ha = m->p_order_info.p[2 * a], hb = m->p_order_info.p[2 * b]; return ha != hb ? ha > hb : a < b; });   // the longest first: they end the launch
+		std::vector<uint32_t> reads(nb);
+		for (uint32_t j = 0; j < nb; ++j) reads[j] = m->order_pending[big[j]];
+		ngm::CsArgs B = m->order_args;
+		B.order_info = nullptr; B.order_scratch = nullptr; B.order_max_hits = 0; B.order_gcap = 0;
+		const size_t coarse_cap = ngm::cs_heavy2_coarse_cap(B.lists_cap, B.max_kfreq);
+		const size_t lds = ngm::cs_order_bucket_lds_bytes(B.lists_cap, B.q, coarse_cap);
+		static const bool two_per_cu = getenv("NGM_HIP_ORDER_BUCKET_W8") != nullptr;   // (experiments)
+		auto kern = two_per_cu ? ngm::cs_order_bucket_kernel_w8<ngm::kCsOrderBucketThreads> : ngm::cs_order_bucket_kernel<ngm::kCsOrderBucketThreads>;
+		int per_cu = 0, cus = 0;
+		if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, ngm::kCsOrderBucketThreads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->ref->device) != hipSuccess || cus < 1) cus = 256;
+		// elements of a workgroup's slice: the most hits a read of this run can have (a list per k-mer and strand, none longer than max_kfreq) --
+		// not the most of THIS list: every new maximum would be a hipFree + hipMalloc, two device-wide synchronisations, in the middle of the run
+		uint64_t cap = std::min<uint64_t>(ngm::kCsOrderBucketMaxHits, (((uint64_t) (B.lists_cap / 2) * (uint64_t) std::max(B.max_kfreq, 1)) + 63) & ~63ull);
+		uint32_t grid = (uint32_t) per_cu * (uint32_t) cus;
+		{
+			size_t free_b = 0, total_b = 0;
+			uint64_t room = 4ull << 30;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) room = std::min<uint64_t>(room, ((uint64_t) free_b + (uint64_t) m->d_order_gt.cap * 4) / 2);
+			cap = std::min<uint64_t>(cap, room / 8);                       // (a read with more hits than that goes on to the table kernel)
+			grid = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(grid, room / 8 / std::max<uint64_t>(cap, 1)));
+		}
+		const size_t slice_words = (size_t) grid * cap * 2;
+		grid = std::min<uint32_t>(grid, nb);
+		tr("bucket stage: reads, grid, slice", nb, grid, cap);
+		bool ok = cap >= 64 && !m->d_order_gt.reserve(slice_words) && !m->d_order_big.reserve(nb) && !m->d_order_log2.reserve(nb + 1) && !m->d_order_info.reserve(2 * (size_t) nb);
+		if (ok) {
+			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_big.p, reads.data(), (size_t) nb * 4, hipMemcpyHostToDevice, ost));
+			MAP_HIP_TRY(hipMemsetAsync(m->d_order_log2.p, 0, 4, ost));
+			MAP_HIP_TRY(hipMemsetAsync(m->d_order_info.p, 0xFF, 2 * (size_t) nb * 4, ost));
+			unsigned long long *diag = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + (size_t) ngm::kCsRegions * ngm::kCsCursorStride + 8 : nullptr;
+			if (diag) MAP_HIP_TRY(hipMemsetAsync(diag, 0, 12 * 8, ost));
+			B.read_list = m->d_order_big.p;
+			MAP_HIP_TRY(hipEventRecord(m->oev[2], ost));
+			hipLaunchKernelGGL(kern, dim3(grid), dim3(ngm::kCsOrderBucketThreads), lds, ost, B, nb, m->d_order_log2.p, (uint2 *) m->d_order_gt.p, (uint32_t) cap, (uint32_t) coarse_cap,
+					(const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p, m->d_order_info.p, diag);
+			MAP_HIP_TRY(hipGetLastError());
+			MAP_HIP_TRY(hipEventRecord(m->oev[3], ost));
+			tr("bucket kernel launched");
+			std::vector<uint32_t> binfo(2 * (size_t) nb);
+			MAP_HIP_TRY(hipMemcpyAsync(binfo.data(), m->d_order_info.p, binfo.size() * 4, hipMemcpyDeviceToHost, ost));
+			MAP_HIP_TRY(hipStreamSynchronize(ost));
+			{ float t = 0; if (hipEventElapsedTime(&t, m->oev[2], m->oev[3]) == hipSuccess) m->order_ms += t; }
+			tr("bucket kernel done");
+			if (diag) {
+				unsigned long long ph[12];
+				MAP_HIP_TRY(hipMemcpy(ph, diag, sizeof(ph), hipMemcpyDeviceToHost));
+				const double ns = (double) std::max(1ull, ph[8]);
+				fprintf(stderr, "[ngm-hip] order replay through buckets (%u reads, grid %u, %d per CU, slice %llu hits), us per sampled read: lists %.1f | count %.1f | scan + scatter %.1f | v + tau %.1f | qualifying hits %.1f | candidates %.1f; hits %.0f, candidates %.0f per read; %llu left to the table kernel\n",
+						nb, grid, per_cu, (unsigned long long) cap, ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[4] / ns / 100.0, ph[5] / ns / 100.0, ph[9] / ns, ph[10] / ns, ph[11]);
+			}
+			std::vector<uint32_t> left;
+			for (uint32_t j = 0; j < nb; ++j) if (binfo[2 * j + 1] != 0u) left.push_back(big[j]);
+			std::sort(left.begin(), left.end());
+			m->st_order_table += left.size();
+			big.swap(left);
+		} else m->st_order_table += big.size();   // (no room for the slices: all of them to the table kernel)
+	}
+	if (!big.empty() && (!buckets_on || m->order_args.bs || ngm::cs_order_tau(m->order_args.lists_cap) > ngm::kCsOrderBucketMaxTau)) m->st_order_table += big.size();
 	if (!big.empty()) {
 		// exact replay in global memory (cs_order_kernel<true>): per read a table of 2^l >= 2 (hits + candidates) slots x 5 words and a
 		// time line of `hits` words; launches of as many reads as fit a scratch pool of 8 GB
@@ -1064,12 +1139,23 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + ngm::cs_order_tau(G.lists_cap) + (size_t) (ngm::kCsOrderThreadsGlobal / 64) * G.order_gcap + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
 		// (8 GB per launch: a read with 50 000 hits takes 2.6 MB of table and time line, and with the 1.5 GB pool of the first version the
 		// 5 500 such reads of a heavy-tailed batch went through ten launches of ~570 workgroups each -- two per CU, 118 ms of waiting per batch)
-		constexpr uint64_t kPoolWords = 2048ull << 20;
+		// (the pool never asks for more than half of what the device has free, a read that needs more than the pool -- or a pool
+		// that cannot be had -- keeps an UNDETERMINED order, which the run reports (st_order_unknown) instead of dying: ties then resolve by position)
+		uint64_t pool_words = 2048ull << 20;
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) pool_words = std::max<uint64_t>(std::min<uint64_t>(pool_words, ((uint64_t) free_b + (uint64_t) m->d_order_gt.cap * 4) / 8), 1ull << 20);
+		}
 		for (uint32_t j0 = 0; j0 < nb;) {
+			if (words[j0] > pool_words) { ++j0; continue; }   // (its candidates keep kCsOrderUnknown from the LDS replay's give-up)
 			uint64_t total = 0;
 			uint32_t j1 = j0;
-			while (j1 < nb && (j1 == j0 || total + words[j1] <= kPoolWords)) { off[j1] = total; total += words[j1]; ++j1; }
-			if (m->d_order_gt.reserve(total)) { ngm::pipeline_set_error("out of device memory (exact candidate order, %llu words)", (unsigned long long) total); return -12; }
+			while (j1 < nb && total + words[j1] <= pool_words) { off[j1] = total; total += words[j1]; ++j1; }
+			if (m->d_order_gt.reserve(total)) {
+				if (pool_words > (1ull << 22)) { pool_words /= 2; continue; }   // a smaller pool, more launches
+				break;                                                        // no memory at all: the remaining reads stay undetermined
+			}
+			tr("table kernel: reads, words", j1 - j0, total, pool_words);
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_big.p + j0, reads.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, ost));
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_log2.p + j0, lg.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, ost));
 			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_off.p + j0, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, ost));
@@ -1082,17 +1168,22 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 			{ float t = 0; if (hipEventElapsedTime(&t, m->oev[2], m->oev[3]) == hipSuccess) m->order_ms += t; }
 			j0 = j1;
 		}
-		MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
-		MAP_HIP_TRY(hipStreamSynchronize(ost));
 		if (G.phase_cycles) {
+			MAP_HIP_TRY(hipStreamSynchronize(ost));
 			unsigned long long ph[12];
 			MAP_HIP_TRY(hipMemcpy(ph, G.phase_cycles + 8, sizeof(ph), hipMemcpyDeviceToHost));
 			const double ns = (double) std::max(1ull, ph[4]);
 			fprintf(stderr, "[ngm-hip] exact order replay in global memory (%u reads), us per sampled read: lists %.1f | sweep A %.1f | sweep B %.1f | times + tau + entering %.1f; hits %.0f, slots in use %.0f per read; workgroups start to end %.1f us on average, the slowest %.1f us\n",
 					nb, ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[6] / ns, ph[7] / ns, (double) (ph[5] >> 8) / 100.0 / std::max(1u, nb), ph[8] / 100.0);
 		}
-		for (uint32_t j = 0; j < nb; ++j) {
-			const uint32_t rd = reads[j], b = m->h_base[rd], c = m->h_count[rd];
+	}
+	if (!beyond_lds.empty()) {
+		tr("ranks");
+		MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
+		MAP_HIP_TRY(hipStreamSynchronize(ost));
+		tr("done");
+		for (uint32_t i : beyond_lds) {
+			const uint32_t rd = m->order_pending[i], b = m->h_base[rd], c = m->h_count[rd];
 			bool unknown = false;
 			for (uint32_t x = 0; x < c && !unknown; ++x) unknown = m->p_rank.p[b + x] == ngm::kCsOrderUnknown;
 			m->st_order_unknown += unknown ? 1 : 0;
@@ -1141,7 +1232,12 @@ static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uin
 	const size_t lds = lds_fixed + (size_t) A.order_max_hits * 8;
 	// reads with more hits than the LDS time line holds use a slice of a global scratch: launches of at most 4096 reads
 	constexpr uint32_t kChunk = 4096, kGcap = 49152;
-	if (m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap * 2)) { A.order_scratch = nullptr; A.order_gcap = 0; }   // (time line + hit times per workgroup)
+	// reads with more hits than the LDS time line holds: to the bucket kernel (cs_order_bucket_kernel) -- the LDS replay with its time line in a
+	// slice of global memory is what bisulfite runs (no bucket kernel) and NGM_HIP_ORDER_LDS_BIG=1 / NGM_HIP_ORDER_NO_BUCKETS=1 still use
+	// (measured at 3.1 Gbp, half of the reads from repeats: 0.745 M reads/s without it, 0.669 M with it)
+	static const bool lds_big_env = getenv("NGM_HIP_ORDER_LDS_BIG") != nullptr || getenv("NGM_HIP_ORDER_NO_BUCKETS") != nullptr;
+	const bool no_lds_big = !lds_big_env && !A.bs && ngm::cs_order_tau(A.lists_cap) <= ngm::kCsOrderBucketMaxTau;
+	if (no_lds_big || m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap * 2)) { A.order_scratch = nullptr; A.order_gcap = 0; }   // (time line + hit times per workgroup)
 	else { A.order_scratch = m->d_order_scratch.p; A.order_gcap = kGcap; }
 	MAP_HIP_TRY(hipEventRecord(m->oev[0], ost));
 	for (uint32_t off = 0; off < nl; off += kChunk) {
@@ -2326,6 +2422,12 @@ int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]) {
 	if (!m || !out) return -22;
 	out[0] = m->st_reads; out[1] = m->st_cands; out[2] = m->st_exact_lds; out[3] = m->st_exact_global;
 	out[4] = m->st_order_reads; out[5] = m->st_order_big; out[6] = m->st_order_unknown; out[7] = m->st_heavy;
+	return 0;
+}
+
+int ngm_mapper_order_table_reads(ngm_mapper *m, uint64_t *out) {
+	if (!m || !out) return -22;
+	*out = m->st_order_table;
 	return 0;
 }
 

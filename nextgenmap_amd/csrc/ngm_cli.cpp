@@ -135,6 +135,7 @@ struct Opts {
 };
 
 [[noreturn]] void die(const std::string &msg) { fprintf(stderr, "[ngm-hip] error: %s\n", msg.c_str()); exit(1); }
+// (one fprintf per message: stdio locks the stream for the call, so the lines of the reader, the writer and the estimate's thread never interleave)
 void info(const char *tag, const std::string &msg) { fprintf(stderr, "[%s] %s\n", tag, msg.c_str()); }
 
 Opts parse(int argc, char **argv) {
@@ -629,7 +630,12 @@ int run_sharded(int argc, char **argv, const Opts &o) {
 	// them -- not N builds of the same index, N times the host memory, all writing the same two files
 	{
 		const std::string enc = o.ref + "-enc.2.ngm", ht = o.ref + "-ht-" + std::to_string(o.kmer) + "-" + std::to_string(o.bs_mapping ? 0 : o.kmer_skip) + ".3.ngm";
-		if (!o.skip_save && (access(enc.c_str(), R_OK) != 0 || access(ht.c_str(), R_OK) != 0)) {
+		// (a reference directory that cannot be written gets no cache either way: every shard then builds its own index in memory, and
+		// a build in front of them would only be one more)
+		std::string dir = o.ref;
+		const size_t slash = dir.find_last_of('/');
+		dir = slash == std::string::npos ? "." : slash == 0 ? "/" : dir.substr(0, slash);
+		if (!o.skip_save && access(dir.c_str(), W_OK) == 0 && (access(enc.c_str(), R_OK) != 0 || access(ht.c_str(), R_OK) != 0)) {
 			info("MAIN", "No index cache next to the reference: building it once before the shard processes start");
 			const pid_t pid = fork();
 			if (pid < 0) die("fork failed");
@@ -928,21 +934,31 @@ int main(int argc, char **argv) {
 	// case it runs beside the set-up of the mappers instead of in front of it (NGM_HIP_SYNC_ESTIMATE=1: in front, as without -s).
 	std::thread estimate_thread;
 	struct JoinEstimate { std::thread &t; ~JoinEstimate() { if (t.joinable()) t.join(); } } join_estimate{estimate_thread};
-	auto run_estimate = [&, mp](float &sens, bool &estimated) {
+	// (on its own thread the estimate never ends the process: its value is only logged there, so a failure is a note and the run goes on)
+	auto run_estimate = [&, mp](float &sens, bool &estimated, bool logged_only) {
 		char msg[512];
+		auto give_up = [&](const char *why) {
+			if (!logged_only) die(why);
+			info("INPUT", std::string("note: no sensitivity estimate (it is only logged with -s): ") + why);
+		};
 		ngm_mapper_params ep = mp;
 		ep.sensitivity = 0.0f;
 		ep.slam_seq &= ~4;   // (the estimate looks the read k-mers up as they are: ReadProvider's own PrefixSearch, src/ReadProvider.cpp:79-124)
 		const auto te0 = std::chrono::steady_clock::now();
 		ngm_mapper *em = ngm_mapper_create(ref, &ep);
-		if (!em) die(ngm_pipeline_last_error());
+		if (!em) { give_up(ngm_pipeline_last_error()); return; }
 		const auto te1 = std::chrono::steady_clock::now();
 		const int ns = (int) sample.size();
 		std::vector<char> rows((size_t) ns * q);
 		for (int i = 0; i < ns; ++i) pack_row(sample[i], q, &rows[(size_t) i * q]);
 		std::vector<uint32_t> offs(ns + 1);
 		std::vector<float> mv(ns), both(ns);
-		if (ngm_mapper_cs(em, ns, rows.data(), offs.data(), mv.data()) < 0 || ngm_mapper_cs_max_combined(em, both.data()) < 0) die(ngm_pipeline_last_error());
+		if (ngm_mapper_cs(em, ns, rows.data(), offs.data(), mv.data()) < 0 || ngm_mapper_cs_max_combined(em, both.data()) < 0) {
+			const std::string why = ngm_pipeline_last_error();
+			ngm_mapper_destroy(em);
+			give_up(why.c_str());
+			return;
+		}
 		float sum = 0.f;
 		int n_used = 0;
 		const int skip = o.kmer_skip + 1;
@@ -985,8 +1001,8 @@ int main(int argc, char **argv) {
 		if (o.sensitivity < 0) info("INPUT", "Sensitivity parameter set to 0.5");   // ReadProvider.cpp:317, :378-386: no estimate in this mode
 		estimated = true;
 	} else if (count >= 1000 && !sample.empty()) {
-		if (o.sensitivity >= 0 && !getenv("NGM_HIP_SYNC_ESTIMATE")) estimate_thread = std::thread([&] { float s2 = 0.5f; bool e2 = false; run_estimate(s2, e2); });
-		else run_estimate(sens, estimated);
+		if (o.sensitivity >= 0 && !getenv("NGM_HIP_SYNC_ESTIMATE")) estimate_thread = std::thread([&] { float s2 = 0.5f; bool e2 = false; run_estimate(s2, e2, true); });
+		else run_estimate(sens, estimated, false);
 	}
 	if (o.sensitivity >= 0) sens = o.sensitivity;
 	else if (!estimated) info("INPUT", "Sensitivity parameter neither set nor estimated. Falling back to default.");
@@ -1903,8 +1919,10 @@ int main(int argc, char **argv) {
 		snprintf(msg, sizeof(msg), "Candidate search: %llu reads, %.2f candidates per read; heavy-read kernel for %llu reads (%.3f %%), exact search with the table in LDS for %llu (%.3f %%), in global memory for %llu (%.3f %%)",
 				(unsigned long long) pc[0], pc[1] / nr, (unsigned long long) pc[7], 100.0 * pc[7] / nr, (unsigned long long) pc[2], 100.0 * pc[2] / nr, (unsigned long long) pc[3], 100.0 * pc[3] / nr);
 		info("MAIN", msg);
-		snprintf(msg, sizeof(msg), "Candidate order replay: %llu reads, %llu of them beyond the LDS replay (exact replay in global memory); order left undetermined for %llu reads",
-				(unsigned long long) pc[4], (unsigned long long) pc[5], (unsigned long long) pc[6]);
+		uint64_t by_table = 0;
+		for (Worker &w : workers) { uint64_t c2 = 0; if (ngm_mapper_order_table_reads(w.m, &c2) == 0) by_table += c2; }
+		snprintf(msg, sizeof(msg), "Candidate order replay: %llu reads, %llu of them beyond the LDS replay (exact replay through buckets in global memory, %llu of them with a table there); order left undetermined for %llu reads",
+				(unsigned long long) pc[4], (unsigned long long) pc[5], (unsigned long long) by_table, (unsigned long long) pc[6]);
 		info("MAIN", msg);
 	}
 	if (o.paired && o.ref_score_buffer > 0) {

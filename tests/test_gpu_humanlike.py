@@ -113,6 +113,35 @@ def test_paired_end_on_a_heavy_tailed_genome(world):
     assert len(diff) == 0, len(diff)
 
 
+def test_three_order_replays_agree_on_a_heavy_tailed_genome(world):
+    """The candidate order of a read beyond the LDS replay comes from cs_order_bucket_kernel (hits dealt into buckets); what it leaves, and
+    everything with NGM_HIP_ORDER_NO_BUCKETS, from cs_order_kernel<true> (a table in global memory); NGM_HIP_ORDER_LDS_BIG keeps the reads
+    of up to 49 152 hits with the LDS replay (its time line in a slice of global memory).  Three implementations of CS::AddLocationStd's
+    rList order (src/CS.cpp:196-211): byte-identical SAM."""
+    d = world["dir"]
+    args = ["-1", str(d / "pe_1.fq"), "-2", str(d / "pe_2.fq")]
+
+    def run(tag, env):
+        out = str(d / ("order_" + tag + ".sam"))
+        c = subprocess.run([CLI, "-r", world["fa"], "-o", out, "--affine"] + args, capture_output=True, text=True, env=dict(os.environ, **env))
+        assert c.returncode == 0, c.stderr[-2000:]
+        return [l for l in open(out, "rb") if not l.startswith(b"@PG")], c.stderr
+    base, log = run("buckets", {})
+    beyond = re.search(r"Candidate order replay: (\d+) reads, (\d+) of them beyond", log)
+    assert beyond and int(beyond.group(2)) > 0, log[-2000:]
+    unknown = re.search(r"order left undetermined for (\d+) reads", log)
+    assert unknown and int(unknown.group(1)) == 0, log[-2000:]
+    with_table = re.search(r"(\d+) of them with a table there", log)
+    assert with_table and int(with_table.group(1)) < int(beyond.group(2)), log[-2000:]
+    table, log1 = run("table", {"NGM_HIP_ORDER_NO_BUCKETS": "1"})
+    assert re.search(r"(\d+) of them with a table there", log1).group(1) == beyond.group(2)
+    assert table == base
+    lds_big, log2 = run("lds-big", {"NGM_HIP_ORDER_LDS_BIG": "1"})
+    beyond2 = re.search(r"Candidate order replay: (\d+) reads, (\d+) of them beyond", log2)
+    assert beyond2 and 0 < int(beyond2.group(2)) <= int(beyond.group(2))
+    assert lds_big == base
+
+
 def test_single_end_linear_personality_through_the_drop_in(world):
     """the DEFAULT (linear-gap) personality on the same reads: the reference's own program with this library behind IAlignment
     (oracle/build_dropin.sh) against ngm-hip"""

@@ -116,6 +116,47 @@ def test_damaged_files_are_refused(exe):
         assert subprocess.run([prog, p, p + ".out"]).returncode == 3, name
 
 
+def _incomplete_literal_code_member():
+    """a dynamic block whose literal/length alphabet has two codes of two bits (byte 0x00 and end-of-block): half the code space unused.
+    zlib's inflate_table refuses it ("invalid literal/lengths set")."""
+    bits = []
+
+    def put(v, n):            # header fields: least significant bit first
+        bits.extend((v >> i) & 1 for i in range(n))
+
+    def code(v, n):           # Huffman codes: most significant bit first
+        bits.extend((v >> (n - 1 - i)) & 1 for i in range(n))
+
+    put(1, 1); put(2, 2)      # last block, dynamic codes
+    put(0, 5); put(0, 5); put(12, 4)   # 257 literal/length codes, 1 distance code, 16 code-length code lengths
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2]
+    pre = {18: 1, 0: 2, 2: 2}  # complete: 18 -> 0, 0 -> 10, 2 -> 11
+    for s in order:
+        put(pre.get(s, 0), 3)
+    code(3, 2)                          # literal 0: length 2
+    code(0, 1); put(138 - 11, 7)        # 138 zeros
+    code(0, 1); put(117 - 11, 7)        # 117 zeros (literals 1..255)
+    code(3, 2)                          # end of block: length 2
+    code(2, 2)                          # the one distance code: unused
+    code(0, 2); code(0, 2); code(1, 2)  # two bytes 0x00, end of block
+    while len(bits) % 8:
+        bits.append(0)
+    body = bytes(sum(b << i for i, b in enumerate(bits[k:k + 8])) for k in range(0, len(bits), 8))
+    text = b"\0\0"
+    return b"\x1f\x8b\x08\x00" + bytes(6) + body + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
+
+
+def test_incomplete_literal_code_is_refused_as_zlib_refuses_it(exe):
+    prog, d = exe
+    z = _incomplete_literal_code_member()
+    with pytest.raises(zlib.error, match="invalid literal/lengths set"):
+        zlib.decompress(z, 31)
+    p = str(d / "incomplete_code.gz")
+    with open(p, "wb") as f:
+        f.write(z + bytes(40))   # (the checker wants a file of some size)
+    assert subprocess.run([prog, p, p + ".out"]).returncode == 3
+
+
 def test_corrupted_inputs_are_refused_or_decoded_like_zlib(tmp_path):
     """300 damaged files (flipped bits, truncation, overwritten and deleted spans) through a build with AddressSanitizer and
     UndefinedBehaviorSanitizer: the decoder's unchecked hot loop must stay inside its buffers whatever the stream says -- exit 3 (refused)
