@@ -11,8 +11,8 @@
 // into 2^b BUCKETS by a hash of their bin -- count (LDS), scan, scatter of (bin | strand << 31, time) pairs into the workgroup's slice
 // of a scratch: one 8-byte store per hit, nothing else leaves the CU -- and a bucket (8 hits on average, every hit of a bin in the
 // same one) is a few lanes of a wave: a hit's v is 1 + the number of hits of its (bin, strand) in the bucket with a smaller time.
-// One atomicMin into tau (LDS) per hit; then, tau complete, one pass marks the hits that qualify and a lane per candidate looks
-// through the candidate's bucket for the earliest of them.
+// tau[v] = the minimum over the hits (LDS); then, tau complete, a lane per candidate looks through the candidate's bucket for the
+// earliest hit of its bin that qualifies.
 // Workgroups are persistent (one slice each) and draw reads from a counter; the host lists the reads by decreasing hits.
 // Left to cs_order_kernel<true>: bisulfite runs (lists per k-mer variant), reads of more than 2^20 hits.
 #pragma once
@@ -37,7 +37,7 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 		unsigned long long *__restrict__ diag) {   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] their candidates, [11] reads left to the table kernel
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	constexpr int NW = NT / 64;
-	__shared__ uint32_t s_next, s_bad, s_scan[NW];
+	__shared__ uint32_t s_next, s_bad, s_scan[NW], s_mlo[257];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;                                   // [lists_cap]
@@ -174,81 +174,116 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 			const uint32_t b_lo = (uint32_t) wv * (nb / NW), b_hi = b_lo + nb / NW;   // (nb >= 64: a multiple of the waves)
 			// the window that starts with bucket b (at hit p): buckets b .. b2 - 1, hits p .. p + n - 1; n > 64: the one bucket b
 			auto window = [&](uint32_t b, uint32_t p, uint32_t &b2, uint32_t &n) -> uint2 {
-				while (b < b_hi && bk[b + 1] == p) ++b;   // (empty buckets)
+				// (everything here is the same in every lane; what comes out of LDS is made uniform by hand, or the loops over it run under exec masks)
+				p = (uint32_t) __builtin_amdgcn_readfirstlane((int) p);
+				while (b < b_hi && (uint32_t) __builtin_amdgcn_readfirstlane((int) bk[b + 1]) == p) ++b;   // (empty buckets)
 				if (b >= b_hi) { b2 = b_hi; n = 0; return none; }
 				const uint32_t idx = b + 1u + (uint32_t) lane;
 				const uint32_t fits = (uint32_t) __popcll(__ballot(idx <= b_hi && bk[idx] <= p + 64u));   // (bk increases: a run of lanes from 0)
 				b2 = b + max(fits, 1u);
-				n = bk[b2] - p;
+				n = (uint32_t) __builtin_amdgcn_readfirstlane((int) (bk[b2] - p));
 				return (uint32_t) lane < n ? my[p + (uint32_t) lane] : none;
 			};
-			uint32_t b_c = b_lo, p_c = bk[b_lo], b2_c = 0, n_c = 0;
-			uint2 e_c = window(b_c, p_c, b2_c, n_c);
-			while (n_c) {
-				p_c = bk[b2_c] - n_c;   // (window() skipped empty buckets: the hits end at bk[b2])
-				uint32_t b2_n = 0, n_n = 0;
-				const uint2 e_n = window(b2_c, bk[b2_c], b2_n, n_n);
+			// returns v of this lane's hit of a window of at most 64 hits (the caller stores it); a larger bucket is finished here
+			auto process = [&](const uint2 &e_c, uint32_t p_c, uint32_t n_c) -> uint32_t {
 				if (n_c <= 64u) {
+					// every hit of the window against every other, through scalar registers (v_readlane with a scalar loop counter: n_c comes out of
+					// LDS, and until it was made uniform by hand the compiler ran this loop under an exec mask with a waterfall around each readlane
+					// -- ~95 cycles per trip, 0.5 of the 0.6 ms of a read; walking only the lanes of the hit's own bucket by ds_bpermute was no
+					// faster: a chain of LDS round trips as long as the longest bucket, and a repeat family's bin fills a window by itself)
 					const uint32_t key = e_c.x, t = e_c.y;
-					uint32_t ls = 0, le = 0;
-					if (key != 0xFFFFFFFFu) { const uint32_t b = bucket_of(key & 0x3FFFFFFFu); ls = bk[b] - p_c; le = bk[b + 1] - p_c; }
-					const uint32_t longest = (uint32_t) wave_reduce_max((int) (le - ls));
 					uint32_t v = 1;
-					for (uint32_t mm = 0; mm < longest; ++mm) {
-						const uint32_t src = min(ls + mm, 63u);
-						const uint32_t k2 = (uint32_t) __shfl((int) key, (int) src), t2 = (uint32_t) __shfl((int) t, (int) src);
-						v += (ls + mm < le && k2 == key && t2 < t) ? 1u : 0u;
+					const uint32_t n_u = (uint32_t) __builtin_amdgcn_readfirstlane((int) n_c);
+#pragma unroll 4
+					for (uint32_t mm = 0; mm < n_u; ++mm) {
+						const uint32_t k2 = (uint32_t) __builtin_amdgcn_readlane((int) key, (int) mm), t2 = (uint32_t) __builtin_amdgcn_readlane((int) t, (int) mm);
+						v += (k2 == key && t2 < t) ? 1u : 0u;
 					}
 					if (key != 0xFFFFFFFFu) {
-						if (v < n_tau) atomicMin(&tau[v], t); else atomicExch(&s_bad, 4u);
-						my[p_c + (uint32_t) lane].y = (v << 20) | t;
+						if (v >= n_tau) atomicExch(&s_bad, 4u); else if (t < tau[v]) atomicMin(&tau[v], t);
 					}
+					return v;
 				} else {
-					for (uint32_t c0 = 0; c0 < n_c; c0 += 64u) {
-						const uint2 mine = c0 + (uint32_t) lane < n_c ? my[p_c + c0 + (uint32_t) lane] : none;
+					const uint32_t n_b = (uint32_t) __builtin_amdgcn_readfirstlane((int) n_c);
+					for (uint32_t c0 = 0; c0 < n_b; c0 += 64u) {
+						const uint2 mine = c0 + (uint32_t) lane < n_b ? my[p_c + c0 + (uint32_t) lane] : none;
 						uint32_t v = 1;
-						for (uint32_t d0 = 0; d0 < n_c; d0 += 64u) {
-							const uint2 other = d0 + (uint32_t) lane < n_c ? my[p_c + d0 + (uint32_t) lane] : none;
-							const uint32_t lim = min(64u, n_c - d0);
+						for (uint32_t d0 = 0; d0 < n_b; d0 += 64u) {
+							const uint2 other = d0 + (uint32_t) lane < n_b ? my[p_c + d0 + (uint32_t) lane] : none;
+							const uint32_t lim = min(64u, n_b - d0);
 							for (uint32_t mm = 0; mm < lim; ++mm) {
 								const uint32_t k2 = (uint32_t) __builtin_amdgcn_readlane((int) other.x, (int) mm), t2 = (uint32_t) __builtin_amdgcn_readlane((int) other.y, (int) mm);
 								v += (k2 == mine.x && (t2 & 0xFFFFFu) < mine.y) ? 1u : 0u;   // (the hits in front have their v in the upper bits already)
 							}
 						}
 						if (mine.x != 0xFFFFFFFFu) {
-							if (v < n_tau) atomicMin(&tau[v], mine.y); else atomicExch(&s_bad, 4u);
+							if (v >= n_tau) atomicExch(&s_bad, 4u); else if (mine.y < tau[v]) atomicMin(&tau[v], mine.y);
 						}
 						// (the chunks after this one read these words again: masked to the time, the same value before and after this store)
 						if (mine.x != 0xFFFFFFFFu) my[p_c + c0 + (uint32_t) lane].y = (min(v, kCsOrderBucketMaxTau - 1u) << 20) | mine.y;
 					}
+					return 0u;
 				}
-				b_c = b2_c; b2_c = b2_n; n_c = n_n; e_c = e_n;
+			};
+			// four windows at a time: their bounds come from LDS, so the four loads are in flight together; and the NEXT four are issued before this
+			// batch's v are stored -- a wave's loads and stores complete in order, and behind its own stores every batch waited ~10 us
+			// (measured: 2.6 us per window, the same with one and with three workgroups per CU)
+			constexpr int KW = 4;
+			uint32_t b_next = b_lo;
+			unsigned long long tw = 0, tp = 0, nwin = 0;   // (diagnostics: wave 0 of the sampled reads)
+			uint32_t pW[KW], nW[KW];
+			uint2 eW[KW];
+			auto issue = [&](uint32_t (&pp)[KW], uint32_t (&nn)[KW], uint2 (&ee)[KW]) {
+#pragma unroll
+				for (int w = 0; w < KW; ++w) {
+					uint32_t b2 = b_hi, n = 0;
+					ee[w] = window(b_next, bk[b_next], b2, n);
+					nn[w] = n; pp[w] = (uint32_t) __builtin_amdgcn_readfirstlane((int) (bk[b2] - n)); b_next = b2;
+				}
+			};
+			issue(pW, nW, eW);
+			while (nW[0]) {
+				const unsigned long long c0 = dg ? wall_clock64() : 0ull;
+				uint32_t pN[KW], nN[KW], vW[KW];
+				uint2 eN[KW];
+				issue(pN, nN, eN);
+				const unsigned long long c1 = dg ? wall_clock64() : 0ull;
+#pragma unroll
+				for (int w = 0; w < KW; ++w) { vW[w] = nW[w] ? process(eW[w], pW[w], nW[w]) : 0u; nwin += nW[w] ? 1u : 0u; }
+#pragma unroll
+				for (int w = 0; w < KW; ++w) if (nW[w] && nW[w] <= 64u && eW[w].x != 0xFFFFFFFFu) my[pW[w] + (uint32_t) lane].y = (vW[w] << 20) | eW[w].y;
+				if (dg) { const unsigned long long c2 = wall_clock64(); tw += c1 - c0; tp += c2 - c1; }
+#pragma unroll
+				for (int w = 0; w < KW; ++w) { pW[w] = pN[w]; nW[w] = nN[w]; eW[w] = eN[w]; }
 			}
+			if (dg) { atomicAdd(&diag[12], tw); atomicAdd(&diag[13], tp); atomicAdd(&diag[14], nwin); }
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		__syncthreads();
 		mark(3);
 		if (s_bad) { give_up(s_bad, H); continue; }
-		// 5. tau is complete: the hits that qualify, (float) v >= (float) M(t) * sensitivity, get bit 30 of their key
-		for (uint32_t i0 = (uint32_t) tid; i0 < H; i0 += 4u * NT) {
-			uint2 e[4];
-#pragma unroll
-			for (int j = 0; j < 4; ++j) { const uint32_t i = i0 + (uint32_t) j * NT; e[j] = i < H ? my[i] : none; }
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const uint32_t i = i0 + (uint32_t) j * NT;
-				if (i >= H) continue;
-				const uint32_t v = e[j].y >> 20, t = e[j].y & 0xFFFFFu;
-				uint32_t lo = 1, hi = n_tau;   // M(t): the largest v with tau[v] <= t (tau[1] = 0 <= t)
-				while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tau[mid] <= t) lo = mid; else hi = mid; }
-				if ((float) v >= (float) lo * A.sensitivity) my[i].x = e[j].x | 0x40000000u;
-			}
+		// 5. tau is complete.  M(t) -- the largest v with tau[v] <= t (tau[1] = 0 <= t) -- from a table of M at 256 evenly spaced times and a step
+		// or two along tau, not a bisection per hit
+		int m_shift = 0;
+		while ((H >> m_shift) > 256u) ++m_shift;
+		if (tid < 257) {
+			const uint32_t t = (uint32_t) tid << m_shift;
+			uint32_t lo = 1, hi = n_tau;
+			while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tau[mid] <= t) lo = mid; else hi = mid; }
+			s_mlo[tid] = lo;
 		}
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		__syncthreads();
 		mark(4);
-		// 6. the earliest qualifying hit of every candidate's bin (either strand), in the bin's bucket: a lane per candidate, 64 candidates of a
-		// wave at a time; the buckets of more than 64 hits among them are then scanned by the whole wave, one after the other
+		// the time of the hit if it is one of `bin` (either strand) and qualifies -- (float) v >= (float) M(t) * sensitivity (CS.cpp:205) -- else "never"
+		auto qualifies = [&](const uint2 &e, uint32_t bin) -> uint32_t {
+			if ((e.x & 0x7FFFFFFFu) != bin) return kCsOrderUnknown;   // (an empty lane's key has bit 30 set)
+			const uint32_t v = e.y >> 20, t = e.y & 0xFFFFFu;
+			uint32_t mt = s_mlo[t >> m_shift];
+			while (mt + 1u < n_tau && tau[mt + 1u] <= t) ++mt;
+			return (float) v >= (float) mt * A.sensitivity ? t : kCsOrderUnknown;
+		};
+		// 6. the earliest qualifying hit of every candidate's bin, in the bin's bucket: a lane per candidate, 64 candidates of a wave at a time;
+		// the buckets of more than 64 hits among them are then scanned by the whole wave, one after the other
 		for (uint32_t c0 = (uint32_t) wv * 64u; c0 < cn; c0 += (uint32_t) NT) {
 			const uint32_t c = c0 + (uint32_t) lane;
 			uint32_t bin = 0, s0 = 0, s1 = 0;
@@ -260,17 +295,29 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 #pragma unroll
 				for (int j = 0; j < 4; ++j) e[j] = i + (uint32_t) j < s1 ? my[i + (uint32_t) j] : none;
 #pragma unroll
-				for (int j = 0; j < 4; ++j) if ((e[j].x & 0x7FFFFFFFu) == (bin | 0x40000000u)) enter = min(enter, e[j].y & 0xFFFFFu);
+				for (int j = 0; j < 4; ++j) enter = min(enter, qualifies(e[j], bin));
 			}
+			// (the first 128 hits of the next such bucket are loaded before this one's are looked at)
 			unsigned long long bm = __ballot(big);
-			while (bm) {
-				const int kb = (int) __builtin_ctzll(bm);
-				bm &= bm - 1ull;
-				const uint32_t bin2 = (uint32_t) __builtin_amdgcn_readlane((int) bin, kb), t0 = (uint32_t) __builtin_amdgcn_readlane((int) s0, kb), t1 = (uint32_t) __builtin_amdgcn_readlane((int) s1, kb);
-				uint32_t en = 0x7FFFFFFFu;
-				for (uint32_t i = t0 + (uint32_t) lane; i < t1; i += 64u) { const uint2 e = my[i]; if ((e.x & 0x7FFFFFFFu) == (bin2 | 0x40000000u)) en = min(en, e.y & 0xFFFFFu); }
-				en = (uint32_t) wave_reduce_min((int) en);
-				if (lane == kb) enter = en == 0x7FFFFFFFu ? kCsOrderUnknown : en;
+			auto start = [&](int kb, uint32_t &bin2, uint32_t &t0, uint32_t &t1, uint2 &h0, uint2 &h1) {
+				bin2 = (uint32_t) __builtin_amdgcn_readlane((int) bin, kb); t0 = (uint32_t) __builtin_amdgcn_readlane((int) s0, kb); t1 = (uint32_t) __builtin_amdgcn_readlane((int) s1, kb);
+				h0 = t0 + (uint32_t) lane < t1 ? my[t0 + (uint32_t) lane] : none;
+				h1 = t0 + 64u + (uint32_t) lane < t1 ? my[t0 + 64u + (uint32_t) lane] : none;
+			};
+			int ck = -1;
+			uint32_t cbin = 0, ct0 = 0, ct1 = 0;
+			uint2 ch0 = none, ch1 = none;
+			if (bm) { ck = (int) __builtin_ctzll(bm); bm &= bm - 1ull; start(ck, cbin, ct0, ct1, ch0, ch1); }
+			while (ck >= 0) {
+				int nk = -1;
+				uint32_t nbin = 0, nt0 = 0, nt1 = 0;
+				uint2 nh0 = none, nh1 = none;
+				if (bm) { nk = (int) __builtin_ctzll(bm); bm &= bm - 1ull; start(nk, nbin, nt0, nt1, nh0, nh1); }
+				uint32_t en = min(qualifies(ch0, cbin), qualifies(ch1, cbin));
+				for (uint32_t i = ct0 + 128u + (uint32_t) lane; i < ct1; i += 64u) en = min(en, qualifies(my[i], cbin));
+				en = (uint32_t) wave_reduce_min((int) min(en, 0x7FFFFFFFu));
+				if (lane == ck) enter = en == 0x7FFFFFFFu ? kCsOrderUnknown : en;
+				ck = nk; cbin = nbin; ct0 = nt0; ct1 = nt1; ch0 = nh0; ch1 = nh1;
 			}
 			if (c < cn) cand_rank[cb + c] = enter == kCsOrderUnknown ? kCsOrderUnknown : 2u * enter + (cand_sv[cb + c] & 1u);
 		}

@@ -1059,7 +1059,8 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		std::vector<uint32_t> reads(nb);
 		for (uint32_t j = 0; j < nb; ++j) reads[j] = m->order_pending[big[j]];
 		ngm::CsArgs B = m->order_args;
-		B.order_info = nullptr; B.order_scratch = nullptr; B.order_max_hits = 0; B.order_gcap = 0;
+		B.order_info = nullptr; B.order_scratch = nullptr; B.order_max_hits = 0;
+		B.order_gcap = 0;
 		const size_t coarse_cap = ngm::cs_heavy2_coarse_cap(B.lists_cap, B.max_kfreq);
 		const size_t lds = ngm::cs_order_bucket_lds_bytes(B.lists_cap, B.q, coarse_cap);
 		static const bool two_per_cu = getenv("NGM_HIP_ORDER_BUCKET_W8") != nullptr;   // (experiments)
@@ -1068,6 +1069,10 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, ngm::kCsOrderBucketThreads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
 		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->ref->device) != hipSuccess || cus < 1) cus = 256;
+		// ONE workgroup per CU unless told otherwise: its eight waves leave the CU's other wave slots and LDS to the search kernels of the other
+		// mapper instances, which run at the same time (measured at 3.1 Gbp, four instances: 2.63 M reads/s with one, 2.54 M with the two that fit)
+		static const int per_cu_env = getenv("NGM_HIP_ORDER_BUCKET_PER_CU") ? atoi(getenv("NGM_HIP_ORDER_BUCKET_PER_CU")) : 1;
+		if (per_cu_env > 0) per_cu = std::min(per_cu, per_cu_env);
 		// elements of a workgroup's slice: the most hits a read of this run can have (a list per k-mer and strand, none longer than max_kfreq) --
 		// not the most of THIS list: every new maximum would be a hipFree + hipMalloc, two device-wide synchronisations, in the middle of the run
 		uint64_t cap = std::min<uint64_t>(ngm::kCsOrderBucketMaxHits, (((uint64_t) (B.lists_cap / 2) * (uint64_t) std::max(B.max_kfreq, 1)) + 63) & ~63ull);
@@ -1088,7 +1093,7 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 			MAP_HIP_TRY(hipMemsetAsync(m->d_order_log2.p, 0, 4, ost));
 			MAP_HIP_TRY(hipMemsetAsync(m->d_order_info.p, 0xFF, 2 * (size_t) nb * 4, ost));
 			unsigned long long *diag = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + (size_t) ngm::kCsRegions * ngm::kCsCursorStride + 8 : nullptr;
-			if (diag) MAP_HIP_TRY(hipMemsetAsync(diag, 0, 12 * 8, ost));
+			if (diag) MAP_HIP_TRY(hipMemsetAsync(diag, 0, 16 * 8, ost));
 			B.read_list = m->d_order_big.p;
 			MAP_HIP_TRY(hipEventRecord(m->oev[2], ost));
 			hipLaunchKernelGGL(kern, dim3(grid), dim3(ngm::kCsOrderBucketThreads), lds, ost, B, nb, m->d_order_log2.p, (uint2 *) m->d_order_gt.p, (uint32_t) cap, (uint32_t) coarse_cap,
@@ -1102,11 +1107,11 @@ static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 			{ float t = 0; if (hipEventElapsedTime(&t, m->oev[2], m->oev[3]) == hipSuccess) m->order_ms += t; }
 			tr("bucket kernel done");
 			if (diag) {
-				unsigned long long ph[12];
+				unsigned long long ph[16];
 				MAP_HIP_TRY(hipMemcpy(ph, diag, sizeof(ph), hipMemcpyDeviceToHost));
 				const double ns = (double) std::max(1ull, ph[8]);
-				fprintf(stderr, "[ngm-hip] order replay through buckets (%u reads, grid %u, %d per CU, slice %llu hits), us per sampled read: lists %.1f | count %.1f | scan + scatter %.1f | v + tau %.1f | qualifying hits %.1f | candidates %.1f; hits %.0f, candidates %.0f per read; %llu left to the table kernel\n",
-						nb, grid, per_cu, (unsigned long long) cap, ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[4] / ns / 100.0, ph[5] / ns / 100.0, ph[9] / ns, ph[10] / ns, ph[11]);
+				fprintf(stderr, "[ngm-hip] order replay through buckets (%u reads, grid %u, %d per CU, slice %llu hits), us per sampled read: lists %.1f | count %.1f | scan + scatter %.1f | v + tau %.1f (wave 0: %.0f windows, bounds + loads issued %.1f, counted + stored %.1f) | table of M %.1f | candidates %.1f; hits %.0f, candidates %.0f per read; %llu left to the table kernel\n",
+						nb, grid, per_cu, (unsigned long long) cap, ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[14] / ns, ph[12] / ns / 100.0, ph[13] / ns / 100.0, ph[4] / ns / 100.0, ph[5] / ns / 100.0, ph[9] / ns, ph[10] / ns, ph[11]);
 			}
 			std::vector<uint32_t> left;
 			for (uint32_t j = 0; j < nb; ++j) if (binfo[2 * j + 1] != 0u) left.push_back(big[j]);
