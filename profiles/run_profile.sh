@@ -34,6 +34,6 @@ NGM_HIP_CS_PHASES=1 timeout 600 python profiles/tools/heavy_tail_probe.py > gpur
 timeout 1500 python -m pytest tests/test_gpu_humanlike.py -m gpu -q -s > gpurun_out/profiles/${TAG}_humanlike_parity.log 2>&1
 timeout 2400 python profiles/tools/humanlike_t1.py --reads 2000000 > gpurun_out/profiles/${TAG}_humanlike_t1_2M_reads.log 2>&1
 python profiles/tools/cpu_scale_probe.py > gpurun_out/profiles/${TAG}_cpu_quota_probe.txt 2>&1
-python profiles/tools/kernel_resources.py nextgenmap_amd/build/mapper.o "cs_canon_kernel<3, 6, 2, 1, 7, true>" cs_heavy2 cs_order_kernel pair_choice cs_global > gpurun_out/profiles/${TAG}_kernel_registers_and_spills.txt 2>&1
+python profiles/tools/kernel_resources.py nextgenmap_amd/build/mapper.o "cs_canon_kernel<3, 6, 2, 1, 7, true>" cs_heavy2 cs_order_kernel cs_order_bucket pair_choice cs_global > gpurun_out/profiles/${TAG}_kernel_registers_and_spills.txt 2>&1
 ls -la gpurun_out/profiles
 rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_lin gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_hstats gpurun_out/prof_hfetch gpurun_out/prof_hwrite
