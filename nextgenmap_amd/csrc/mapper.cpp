@@ -438,6 +438,8 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 			// rest in the middle class -- two workgroups per CU -- and the largest class only for what that cannot certify: 15.1)
 			static HeavyClass classes[3] = {{16384u, 13, 11, 256, 16384u, (const void *) ngm::cs_heavy2_kernel<256>}, {0xFFFFFFFEu, 14, 12, 512, 262144u, (const void *) ngm::cs_heavy2_kernel<512>},
 					{0xFFFFFFFFu, 15, 13, 1024, 1u << 20, (const void *) ngm::cs_heavy2_kernel<1024>, 16u}};
+			static const bool parts_env = [] { if (const char *e = getenv("NGM_HIP_HEAVY_PARTS")) classes[2].max_parts = (uint32_t) std::max(1, std::min(256, atoi(e))); return true; }();   // experiments: table passes of the largest class
+			(void) parts_env;
 			static const bool classes_env = [] {   // experiments: NGM_HIP_HEAVY_CLASSES=max0,max1 (hits up to which a read starts in class 0 / class 1)
 				if (const char *e = getenv("NGM_HIP_HEAVY_CLASSES")) {
 					unsigned long a = 0, b = 0;
