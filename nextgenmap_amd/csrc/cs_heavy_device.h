@@ -466,6 +466,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		};
 		uint32_t T = 1;
 		bool failed = false;
+		uint32_t why = 0;   // (diagnostics) what sent the read on: 1 a counter row wrapped, 2 no T <= 255 fits, 3 more survivors than the slice, 4 the table (or the entry list) overflowed, 5 T - 1 not below the threshold
 		mark(0);
 		if (H > cap) {
 			// sweep A
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 			__syncthreads();
 			mark(1);
 			// histogram of the counter values -- and their sum: a 16-bit field that wrapped into its neighbour changes it
-			if (!row_hist(H, 2u, true)) failed = true;   // (block-uniform)
+			if (!row_hist(H, 2u, true)) { failed = true; why = 1; }   // (block-uniform)
 			if (!failed) {
 				if (wv == 0) {
 					// the smallest T whose counters fit the table with a quarter of it to spare (one bin per counter, and what slips through
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 				}
 				__syncthreads();
 				T = s_T;
-				if (T > 255u) failed = true;
+				if (T > 255u) { failed = true; why = 2; }
 			}
 			mark(2);
 			if (!failed && s_direct) {
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 				mark(3);
 				const uint32_t np = s_np;
 				if (dg) atomicAdd(&diag[11], (unsigned long long) np);
-				if (np > scratch_cap) failed = true;
+				if (np > scratch_cap) { failed = true; why = 3; }
 				// the survivors, K at a time per thread: their loads (L2) are in flight together
 				constexpr int KS = 8;
 				auto for_survivors = [&](uint32_t np_, auto f) {
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					__syncthreads();
 					// row 2 is almost free of noise: its counters >= t are the bins with >= t votes -- the final T is the smallest one
 					// (not below row 1's) whose bins leave the table a quarter of its room
-					if (!row_hist(np, T, false)) failed = true;
+					if (!row_hist(np, T, false)) { failed = true; why = 1; }
 				}
 				if (!failed) {
 					if (wv == 0) {
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					}
 					__syncthreads();
 					T = s_T;
-					if (T > 255u) failed = true;
+					if (T > 255u) { failed = true; why = 2; }
 				}
 				mark(4);
 				// sweep D: KS survivors per thread and trip -- their counter reads, then their first probes, are in flight together; part `pt` of
@@ -641,16 +642,22 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					}
 				};
 				const uint32_t room1 = (cap * 3u) / 4u;
-				const uint32_t parts = (failed || s_nhot <= room1) ? 1u : min(parts_now, (s_nhot + s_nhot / 8u + room1 - 1u) / room1);
-				if (!failed && parts == 1u) sweep_d(0u, 1u);
+				uint32_t parts = (failed || s_nhot <= room1) ? 1u : min(parts_now, (s_nhot + s_nhot / 8u + room1 - 1u) / room1);
+				if (!failed && parts == 1u && parts_now == 1u) sweep_d(0u, 1u);
 				else if (!failed) {
 					// More bins at or above T than the table holds: the table takes them in `parts` passes over the survivors and hands its
 					// entries (bin, votes) to a list in the scratch slice; maximum, threshold and candidates then come from that list.
-					if (tid == 0) s_nent = 0;
+					// s_nhot counts COUNTERS: with more such bins than the row has counters (a read whose every k-mer is in a family of
+					// tens of thousands of copies) it is far too small, a pass overflows, and the read used to leave for cs_global_kernel --
+					// 1 000 reads per 262 144 at 3.1 Gbp, 15 % of that leg's GPU time.  Now the passes start over with twice as many parts.
 					int pmx = 0, pmxb = 0;
+					for (bool again = false;; again = true) {
+					__syncthreads();
+					if (tid == 0) s_nent = 0;
+					pmx = 0; pmxb = 0;
 					for (uint32_t pt = 0; pt < parts; ++pt) {
 						__syncthreads();
-						if (pt > 0u) {
+						if (pt > 0u || again) {
 							uint4 *k4 = reinterpret_cast<uint4 *>(t_keys), *v4 = reinterpret_cast<uint4 *>(t_votes);
 							for (uint32_t s2 = tid; s2 < n_slots / 4u; s2 += NT) { k4[s2] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); v4[s2] = make_uint4(0u, 0u, 0u, 0u); }
 							if (tid == 0) s_entries = 0;
@@ -670,10 +677,15 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 						}
 					}
 					__syncthreads();
+					if (!s_fail || parts >= parts_now) break;   // (block-uniform)
+					parts = min(parts_now, parts * 2u);
+					__syncthreads();
+					if (tid == 0) s_fail = 0;
+					}
 					mark(5);
 					if (dg) { atomicAdd(&diag[8], 1ull); atomicAdd(&diag[9], (unsigned long long) H); atomicAdd(&diag[12], (unsigned long long) parts); }
 					const uint32_t n_ent = s_nent;
-					if (s_fail || n_ent > ent_cap) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
+					if (s_fail || n_ent > ent_cap) { if (diag && tid == 0) atomicAdd(&diag[15], 1ull); if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
 					pmx = wave_reduce_max(pmx); pmxb = wave_reduce_max(pmxb);
 					if (lane == 0) { s_mx[wv] = (uint32_t) pmx; s_mxb[wv] = (uint32_t) pmxb; }
 					__syncthreads();
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					for (int w2 = 0; w2 < NW; ++w2) { pmx = max(pmx, (int) s_mx[w2]); pmxb = max(pmxb, (int) s_mxb[w2]); }
 					const float max_hit_p = (float) pmx;
 					const float thresh_p = fmaxf(A.kmer_min, max_hit_p * A.sensitivity);
-					if (!((float) (T - 1u) < thresh_p)) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins below T could reach the threshold (a second pass: T was forced as low as the first pass's maximum asks for; the table did not take it)
+					if (!((float) (T - 1u) < thresh_p)) { if (diag && tid == 0) atomicAdd(&diag[15], 1ull << 32); if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins below T could reach the threshold (a second pass: T was forced as low as the first pass's maximum asks for; the table did not take it)
 					const uint32_t region_p = (uint32_t) read & (kCsRegions - 1);
 					if (tid == 0 && A.counters) {
 						atomicAdd(&A.counters[region_p * kCsCursorStride], (unsigned long long) R.n_valid);
@@ -742,6 +754,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		if (dg) { atomicAdd(&diag[8], 1ull); atomicAdd(&diag[9], (unsigned long long) H); if (H > cap && s_direct) atomicAdd(&diag[10], 1ull); }
 		if (failed || s_fail) {
 			if (!failed && !T_force && max_parts > 1u && T > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = T; } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // the table overflowed: the same T in several passes
+			if (diag && tid == 0) { if (failed && why <= 2u) atomicAdd(&diag[14], why == 2u ? 1ull << 32 : 1ull); else atomicAdd(&diag[15], 1ull); }
 			if (wv == 0) cs_enqueue(A, read, lane, R);
 			continue;
 		}
@@ -765,6 +778,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
 		if (T > 1u && !((float) (T - 1u) < thresh)) {   // bins outside the table could reach the threshold
 			if (!T_force && max_parts > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = max(2u, (uint32_t) ceilf(thresh)); } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // once more, from the T this maximum asks for
+			if (diag && tid == 0) atomicAdd(&diag[15], 1ull << 32);
 			if (wv == 0) cs_enqueue(A, read, lane, R);
 			continue;
 		}

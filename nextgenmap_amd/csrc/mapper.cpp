@@ -437,7 +437,7 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 			// (class limits measured on the heavy-tailed probe, per 262 144 reads: 16 384 / 32 768 / rest 18.3 ms; 16 384 / 65 536 / rest 16.1; 16 384 / all the
 			// rest in the middle class -- two workgroups per CU -- and the largest class only for what that cannot certify: 15.1)
 			static HeavyClass classes[3] = {{16384u, 13, 11, 256, 16384u, (const void *) ngm::cs_heavy2_kernel<256>}, {0xFFFFFFFEu, 14, 12, 512, 262144u, (const void *) ngm::cs_heavy2_kernel<512>},
-					{0xFFFFFFFFu, 15, 13, 1024, 1u << 20, (const void *) ngm::cs_heavy2_kernel<1024>, 16u}};
+					{0xFFFFFFFFu, 15, 13, 1024, 1u << 20, (const void *) ngm::cs_heavy2_kernel<1024>, 32u}};
 			static const bool parts_env = [] { if (const char *e = getenv("NGM_HIP_HEAVY_PARTS")) classes[2].max_parts = (uint32_t) std::max(1, std::min(256, atoi(e))); return true; }();   // experiments: table passes of the largest class
 			(void) parts_env;
 			static const bool classes_env = [] {   // experiments: NGM_HIP_HEAVY_CLASSES=max0,max1 (hits up to which a read starts in class 0 / class 1)
@@ -524,6 +524,9 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
 						fprintf(stderr, "[ngm-hip] heavy class %d (round %d, %zu reads, grid %d): us per sampled read: setup %.1f | sweep A %.1f | sum + T %.1f | insert / sweep B %.1f | row 2 %.1f | sweep D %.1f | candidates %.1f; hits %.0f, survivors %.0f, %.0f %% without a second row; second passes %.0f %% of the reads, table passes of the partitioned reads %.1f\n",
 								c, round, lists[c].size(), grid[c], dg[16 * c] / ns / 100.0, dg[16 * c + 1] / ns / 100.0, dg[16 * c + 2] / ns / 100.0, dg[16 * c + 3] / ns / 100.0, dg[16 * c + 4] / ns / 100.0,
 								dg[16 * c + 5] / ns / 100.0, dg[16 * c + 6] / ns / 100.0, dg[16 * c + 9] / ns, dg[16 * c + 11] / ns, 100.0 * dg[16 * c + 10] / ns, 100.0 * dg[16 * c + 13] / ns, (double) dg[16 * c + 12]);
+						const unsigned long long w = dg[16 * c + 14], x = dg[16 * c + 15];
+						if (w | x) fprintf(stderr, "[ngm-hip] heavy class %d sent on: %llu reads with a wrapped counter row, %llu without a T <= 255 that fits, %llu with more survivors than the slice or an overflowing table / entry list, %llu with T - 1 not below the threshold\n",
+								c, w & 0xFFFFFFFFull, w >> 32, x & 0xFFFFFFFFull, x >> 32);
 					}
 				}
 			}
