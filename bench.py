@@ -699,7 +699,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
     ap.add_argument("--no-reference-rerun", action="store_true", help="skip the second -t N run of the reference program (its own run-to-run differences)")
-    ap.add_argument("--heavy-tail-workers", type=int, default=4, help="mapper instances per GPU of the heavy-tailed leg")
+    ap.add_argument("--heavy-tail-workers", type=int, default=8, help="mapper instances per GPU of the heavy-tailed leg (round 5: its kernels are 0.65-0.8 of a step with four, the heavy reads take three host round trips per batch; measured 2.52 M reads/s with 4, 2.49 with 6, 2.70 with 8, 2.57 with 12)")
     ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
     ap.add_argument("--read-sets", type=int, default=4, help="distinct sets of reads-per-step reads the timed steps rotate through (step i maps set i mod this)")
     ap.add_argument("--read-len", type=int, default=150, help="read length (150: BASELINE config #2/#3; 250: config #5's shape)")
