@@ -267,6 +267,17 @@ int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]);
  * table in global memory (cs_order_kernel<true>) -- bisulfite runs, a read with a bucket of more than 256 hits, NGM_HIP_ORDER_NO_BUCKETS */
 int ngm_mapper_order_table_reads(ngm_mapper *m, uint64_t *out);
 
+/* test hook: ScoreBuffer::top1SE + computeMQ (src/ScoreBuffer.cpp:228-277, :34-49) as the score stage runs it (select_top1_kernel) over
+ * host arrays: read i owns candidates [base[i], base[i] + count[i]); out: winner (candidate index, 0xFFFFFFFF: none), MAPQ, number of
+ * best-scoring candidates, best score.  tests/test_gpu_select.py compares it with the reference's sequential loop. */
+int ngm_debug_select_top1(int device, int n_reads, const uint32_t *base, const uint32_t *count, uint64_t n_cand, const float *scores, const uint32_t *loc,
+		const uint32_t *strand_votes, uint32_t *winner, int32_t *mapq, int32_t *n_best, float *best_score);
+
+/* of path counter [7] (reads searched by the heavy-read kernel, csrc/cs_heavy_device.h), summed over all batches: [0] reads given a second
+ * pass (T from the first pass's maximum), [1] table passes started over with twice the parts, [2] reads a class could not certify and
+ * queued again, [3] times the pool of global-memory vote tables had to grow (one more synchronisation in that batch) */
+int ngm_mapper_heavy_counters(ngm_mapper *m, uint64_t out[4]);
+
 /* work counters of the last candidate search: [0] k-mers looked up, [1] index hits voted, [2] candidates emitted
  * (algorithmic bytes of the search = 20 * kmers + 4 * hits + 16 * candidates) */
 int ngm_mapper_cs_counters(ngm_mapper *m, uint64_t out[3]);

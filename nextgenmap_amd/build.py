@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 LIB = os.path.join(HERE, "libngm_hip.so")
-SOURCES = ["ngm_hip.cpp", "jit.cpp", "ialignment_adapter.cpp", "refindex.cpp", "mapper.cpp", "bgzf.cpp", "stats_reduce.cpp"]
+SOURCES = ["ngm_hip.cpp", "jit.cpp", "ialignment_adapter.cpp", "refindex.cpp", "mapper.cpp", "mapper_search.cpp", "bgzf.cpp", "stats_reduce.cpp"]
 JIT_HEADERS = ["sw_device.h", "align_device.h", "affine_device.h"]  # DP kernel templates, also compiled at run time (hiprtc)
 OBJ_DIR = os.path.join(HERE, "build")
 

@@ -36,6 +36,7 @@ constexpr int kCsRegions = 256, kCsCursorStride = 16;
 struct CsArgs {
 	const uint8_t *reads;       // n rows of q bytes
 	const uint32_t *read_list;  // optional: workgroup i handles read read_list[i] (re-run of queued reads)
+	const uint32_t *n_list_dev; // optional (cs_kernel, cs_global_kernel): the number of listed reads lives in this device word and the workgroups stride over the list (cs_queue_device.h); null: one workgroup per item of the grid
 	int n;
 	int q;
 	int k;
@@ -1083,10 +1084,8 @@ __global__ __launch_bounds__(T * 64) __attribute__((amdgpu_waves_per_eu((T == 3 
 
 // ---- EXACT paths: every hit goes into an open-addressing table (LDS, or global memory for very repetitive reads) --
 template <int MODE>
-__global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
+__device__ __forceinline__ void cs_exact_read(const CsArgs &A, const int item, const int lane) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	const int lane = threadIdx.x;
-	const int item = blockIdx.x;
 	const int read = A.read_list ? (int) A.read_list[item] : item;
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;                        // [lists_cap]
@@ -1166,6 +1165,16 @@ __global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
 	__syncthreads();
 	if (MODE == kCsExactGlobal) __threadfence_block();
 	(void) cs_finish<MODE>(A, read, lane, R, t_keys, t_votes, n_slots);
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void cs_kernel(CsArgs A) {
+	const int lane = threadIdx.x;
+	if (!A.n_list_dev) { cs_exact_read<MODE>(A, (int) blockIdx.x, lane); return; }
+	const int n_items = (int) *A.n_list_dev;
+	for (int item = blockIdx.x; item < n_items; item += (int) gridDim.x) {
+		cs_exact_read<MODE>(A, item, lane);
+		__syncthreads();
+	}
 }
 
 // ---- candidate ORDER --------------------------------------------------------------------------------------------

@@ -1,28 +1,18 @@
-// cs_heavy_device.h -- candidate search for the reads the fast path hands on: thousands to tens of thousands of index hits
-// (round 4).  Same semantics as every other search kernel: CS::PrefixIteration (src/CSstatic.cpp:26-76), GetRefEntry
+// cs_heavy_device.h -- candidate search for the reads the fast path hands on: thousands to tens of thousands of index hits.
+// Same semantics as every other search kernel: CS::PrefixIteration (src/CSstatic.cpp:26-76), GetRefEntry
 // (src/PrefixTable.cpp:750-817), PrefixSearch / AddLocationStd (src/CS.cpp:114-213), CollectResultsStd (src/CS.cpp:263-313).
 //
-// Why it exists.  On a genome with a GRCh38-like k-mer spectrum (tests/humanlike.py; automatic max. k-mer frequency 1 531 instead
-// of 100) a third to a half of the reads carry more hits than the fast path's bit plane and 1 024-slot table take, and the exact
-// kernels that used to receive them hold ONE read per CU (a 128 KB table in LDS, one wave) or vote through L2 atomics into
-// tables in global memory: 33 ms + 243 ms per 262 144 reads against 3 ms for the fast path
-// (profiles/r04_heavy_tail_cs_passes.txt).  A read with H hits needs H votes, not a table of H entries:
-//
-//   sweep 1  every hit increments a 16-bit counter, hash(bin) -> one of NC counters in LDS (a count-min sketch with one row: a
-//            counter is an UPPER bound of the votes -- both strands -- of every bin that maps to it);
-//   T        from the histogram of the counter values: the smallest T for which the hits on counters >= T fit the exact table;
-//   sweep 2  the hits whose counter is >= T -- all hits of their bins, or none -- go into the exact table (key = bin,
-//            value = forward | reverse votes);
-//   check    with M2 the largest strand count in the table: a bin outside the table has at most T - 1 votes, so if
-//            T - 1 < max(kmer_min, M2 * sensitivity) (in float, as the reference computes its threshold) then M2 is the true
-//            maximum, the threshold is final, and every candidate is in the table: exact.  Otherwise (a read with more
-//            near-threshold bins than the table holds) the read goes on to the exact kernels as before.
-// The position lists are read twice (the second time mostly from L2); the counters cost 2 bytes of LDS each, so a workgroup
-// needs 36 KB (reads up to 16 384 hits: four per CU) up to 100 KB (65 535 hits: one per CU, 1 024 threads); reads with more hits, and
-// the reads whose near-threshold bins outgrow the table of their class, are taken by a last class with 32-bit counters and 8 192 slots.
+// Why it exists.  On a genome with a GRCh38-like k-mer spectrum (tests/humanlike.py; automatic max. k-mer frequency 1 531 - 4 681
+// instead of 100) a third to a half of the reads carry more hits than the fast path's bit plane and 1 024-slot table take, and the
+// exact kernels that used to receive them hold ONE read per CU (a 128 KB table in LDS, one wave) or vote through L2 atomics into
+// tables in global memory: 33 ms + 243 ms per 262 144 reads against 3 ms for the fast path (profiles/r04_heavy_tail_cs_passes.txt).
+// A read with H hits needs H votes, not a table of H entries: cs_heavy2_kernel below (round 5; round 4's one-row kernel is gone) counts
+// the hits in a sketch, filters them by it, and certifies the exact table it then builds.  cs_global_kernel is what remains for the
+// reads no class can certify.
 #pragma once
 
 #include "cs_device.h"
+#include "cs_queue_device.h"
 
 namespace ngm {
 
@@ -55,102 +45,6 @@ __device__ __forceinline__ void cs_for_each_hit_block(const uint32_t *__restrict
 	}
 }
 
-constexpr uint32_t kCsHeavyMaxHits16 = 65535u;   // 16-bit counters: no counter can wrap below this many hits
-
-inline size_t cs_heavy_lds_bytes(int lists_cap, int q, int log2_counters, int log2_slots, bool wide) {
-	return ((size_t) lists_cap * 2 + 1 + (size_t) (q + 3) / 4 + ((size_t) 1 << (log2_counters - (wide ? 0 : 1))) + 256 + ((size_t) 2 << log2_slots)) * 4;
-}
-
-// A.read_list: the reads; A.log2_bits: log2 of the counters; A.log2_slots: log2 of the table slots; reads that cannot be certified
-// are appended to A.ovf_read / A.ovf_hits (A.status[1]) for the exact kernels
-// WIDE: 32-bit counters (reads of any hit count; twice the LDS per counter)
-template <int NT, bool WIDE = false>
-__global__ __launch_bounds__(NT) void cs_heavy_kernel(CsArgs A) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
-	__shared__ uint32_t s_T;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int read = (int) A.read_list[blockIdx.x];
-	const int k = A.k;
-	uint32_t *l_start = cs_lds;                                  // [lists_cap]
-	uint32_t *l_pref = cs_lds + A.lists_cap;                     // [lists_cap + 1]
-	uint8_t *l_code = (uint8_t *) (l_pref + A.lists_cap + 1);    // [q rounded up to 4]
-	uint32_t *cnt = (uint32_t *) l_code + (A.q + 3) / 4;         // [NC / 2]: two 16-bit counters per word (WIDE: [NC])
-	const int log2c = A.log2_bits;
-	const uint32_t n_cnt = 1u << log2c;
-	const uint32_t cnt_words = WIDE ? n_cnt : (n_cnt >> 1);
-	uint32_t *hist = cnt + cnt_words;                            // [256]: hits on the counters of value c (255: and above)
-	uint32_t *t_keys = hist + 256;
-	const int log2_slots = A.log2_slots;
-	const uint32_t n_slots = 1u << log2_slots;
-	uint32_t *t_votes = t_keys + n_slots;
-	for (uint32_t s = tid; s < cnt_words; s += NT) cnt[s] = 0;
-	for (uint32_t s = tid; s < 256u; s += NT) hist[s] = 0;
-	for (uint32_t s = tid; s < n_slots; s += NT) { t_keys[s] = 0xFFFFFFFFu; t_votes[s] = 0; }
-	// every wave computes the same lists (the barrier inside is the block's)
-	const CsRead R = cs_prepare<false>(A, read, lane, l_start, l_pref, l_code);
-	const uint32_t H = R.H;
-	const int L = R.L;
-	if (!WIDE && H > kCsHeavyMaxHits16) { if (wv == 0) cs_enqueue(A, read, lane, R); return; }   // (block-uniform)
-	__syncthreads();
-	const uint32_t cap = (n_slots * 3u) / 4u;
-	auto bin_of = [&](uint32_t pos, int li) -> uint32_t {
-		const int p = li >> 1;
-		const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
-		return (pos - correction) >> A.bin_shift;
-	};
-	auto insert = [&](uint32_t bin, bool rev) {
-		uint32_t slot = (bin * 0x85EBCA6Bu) >> (32 - log2_slots);
-		for (;;) {
-			const uint32_t prev = atomicCAS(&t_keys[slot], 0xFFFFFFFFu, bin);
-			if (prev == bin || prev == 0xFFFFFFFFu) break;
-			slot = (slot + 1) & (n_slots - 1);
-		}
-		atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
-	};
-	uint32_t T = 1;
-	if (H > cap) {
-		cs_for_each_hit_block<NT>(A.positions, l_start, l_pref, R.n_lists, H, tid, [&](uint32_t pos, int li) {
-			const uint32_t hc = (bin_of(pos, li) * 0x9E3779B1u) >> (32 - log2c);
-			if (WIDE) atomicAdd(&cnt[hc], 1u); else atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
-		});
-		__syncthreads();
-		for (uint32_t i = tid; i < cnt_words; i += NT) {
-			const uint32_t w = cnt[i];
-			const uint32_t c0 = WIDE ? w : (w & 0xFFFFu), c1 = WIDE ? 0u : (w >> 16);
-			if (c0 > 1u) atomicAdd(&hist[min(c0, 255u)], c0);   // (counters of 0 and 1 are most of them: T >= 2 here, they never matter)
-			if (c1 > 1u) atomicAdd(&hist[min(c1, 255u)], c1);
-		}
-		__syncthreads();
-		if (tid == 0) {
-			uint32_t acc = 0, t = 256u;   // 256: even the counters of 255 and more carry more hits than the table takes
-			for (uint32_t c = 255u; c >= 2u; --c) { acc += hist[c]; if (acc > cap) break; t = c; }
-			s_T = t;
-		}
-		__syncthreads();
-		T = s_T;
-		if (T > 255u) { if (wv == 0) cs_enqueue(A, read, lane, R); return; }
-		cs_for_each_hit_block<NT>(A.positions, l_start, l_pref, R.n_lists, H, tid, [&](uint32_t pos, int li) {
-			const uint32_t bin = bin_of(pos, li);
-			const uint32_t hc = (bin * 0x9E3779B1u) >> (32 - log2c);
-			const uint32_t c = WIDE ? cnt[hc] : ((cnt[hc >> 1] >> ((hc & 1u) * 16u)) & 0xFFFFu);
-			if (c >= T) insert(bin, (li & 1) != 0);
-		});
-	} else {
-		cs_for_each_hit_block<NT>(A.positions, l_start, l_pref, R.n_lists, H, tid, [&](uint32_t pos, int li) { insert(bin_of(pos, li), (li & 1) != 0); });
-	}
-	__syncthreads();
-	if (wv != 0) return;
-	if (T > 1u) {
-		int mx = 0;
-		for (uint32_t s = lane; s < n_slots; s += 64) { const uint32_t v = t_votes[s]; mx = max(mx, (int) max(v & 0xFFFFu, v >> 16)); }
-		mx = wave_reduce_max(mx);
-		const float thresh = fmaxf(A.kmer_min, (float) mx * A.sensitivity);
-		if (!((float) (T - 1u) < thresh)) { cs_enqueue(A, read, lane, R); return; }   // bins outside the table could reach the threshold
-	}
-	(void) cs_finish<kCsExactLds>(A, read, lane, R, t_keys, t_votes, n_slots);
-}
-
-
 // ---- the exact search with the table in global memory, one WORKGROUP per read (round 4) -------------------------------------------
 // cs_kernel<kCsExactGlobal> gives a read ONE wave: the reads that reach it on a heavy-tailed genome (17 000 - 190 000 hits, tens of
 // thousands of bins with votes: 4 % of the reads there) each clear, fill and scan -- three times: maximum, count, output -- a table of
@@ -159,6 +53,7 @@ __global__ __launch_bounds__(NT) void cs_heavy_kernel(CsArgs A) {
 // passes NT slots at a time.  The candidates leave in cs_finish's order -- by (slot mod 64), then by slot -- so that nothing downstream
 // can tell the kernels apart: thread t owns the slots of lane class t mod 64 in the (t / 64)-th share of the table, and the output
 // offsets are a scan over the threads in (class, share) order.
+// Round 6: the number of listed reads comes from a device word (A.n_list_dev; cs_queue_device.h) and the workgroups stride over the list.
 template <int NT>
 __global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
@@ -166,7 +61,9 @@ __global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
 	__shared__ uint32_t s_cnt[NT], s_wtot[NW], s_mx[NW], s_mxb[NW];
 	__shared__ unsigned long long s_base;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int item = blockIdx.x;
+	const int n_items = A.n_list_dev ? (int) *A.n_list_dev : (int) gridDim.x;
+	for (int item = blockIdx.x; item < n_items; item += (int) gridDim.x) {
+	__syncthreads();   // (the previous read's shared state is no longer read)
 	const int read = (int) A.read_list[item];
 	const int k = A.k;
 	uint32_t *l_start = cs_lds;                                  // [lists_cap]
@@ -268,12 +165,12 @@ __global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
 		if (A.counters && total) atomicAdd(&A.counters[region * kCsCursorStride + 2], (unsigned long long) total);
 	}
 	__syncthreads();
-	if (total == 0) return;
+	if (total == 0) continue;
 	uint32_t w;
 	if (fixed) w = A.fixed_base + (uint32_t) read * (uint32_t) kCsFixedSlots + before;
 	else {
 		const unsigned long long base = s_base;
-		if (base + total > A.out_capacity) return;
+		if (base + total > A.out_capacity) continue;
 		w = (uint32_t) (region * A.out_capacity + base) + before;
 	}
 	const uint32_t centre = A.bin_shift > 0 ? (1u << (A.bin_shift - 1)) : 0u;  // ResolveBin, CS.h:170-175
@@ -287,6 +184,7 @@ __global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
 			if ((float) r >= thresh) { A.out_loc[w] = loc; A.out_sv[w] = (r << 1) | 1u; ++w; }
 		}
 	});
+	}
 }
 
 // ---- round 5: the heavy reads again -- segment-wise sweeps, a second counter row over the survivors, persistent workgroups ------------
@@ -310,7 +208,11 @@ __global__ __launch_bounds__(NT) void cs_global_kernel(CsArgs A) {
 // 16-bit counters in every class: a row is checked by its SUM (a field that wrapped into its neighbour changes the sum of the
 // fields), which replaces the 32-bit class.  Work items are 8-hit segments of one list (two 16-byte loads, constant strand and
 // diagonal correction; item -> list through a coarse table + a short bisection).  Workgroups are persistent (one scratch slice each)
-// and draw reads from a counter.  Candidates leave in cs_global_kernel's order.
+// and draw reads from a counter.  The ORDER in which a read's candidates leave is that of the table's slots (one table), or of the list
+// the table passes append their entries to (several) -- neither is fixed from run to run: two bins that hash to one slot race for it,
+// and the list grows by an atomic counter.  Nothing downstream reads it: select_top1_kernel and pair_choice_kernel compare
+// (location, strand) keys, the host's sorts (sort_like_reference, ngm_mapper_cs_fetch) use total orders on rank / location / strand,
+// and the reference's own candidate order -- where it decides a tie -- comes from the replay kernels, never from this one.
 constexpr int kCsHeavyCoarseShift = 5;   // the coarse item -> list table has an entry per 32 items (16: at GRCh38 size the middle class needed 82 KB of LDS -- one workgroup per CU instead of two)
 
 inline size_t cs_heavy2_coarse_cap(int lists_cap, int max_kfreq) {   // items / 32 + slack: a read has at most lists_cap / 2 * max_kfreq hits
@@ -322,8 +224,8 @@ inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int l
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list, uint32_t *__restrict__ work_counter, uint32_t *__restrict__ scratch, uint32_t scratch_cap,
-		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several, [13] reads sent into a second pass
+__global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__restrict__ ctl, int cls, uint32_t *__restrict__ scratch, uint32_t scratch_cap,
+		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // ctl: the search's control block (cs_queue_device.h) -- the class's list length and work counter, the run's statistics   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several, [13] reads sent into a second pass
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	constexpr int NW = NT / 64;
 	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct, s_nhot, s_nent, s_force, s_retry_ix, s_retry_T;
@@ -349,6 +251,8 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 	uint32_t *my_scratch = scratch + (size_t) blockIdx.x * ((size_t) scratch_cap + 2u * (size_t) ent_cap);   // survivors, then (max_parts > 1) the entries of all parts
 	uint32_t *my_ent = my_scratch + scratch_cap;
 	const unsigned long long lanes_below = (1ull << lane) - 1ull;
+	const uint32_t n_list = ctl[kCsqCount + cls];   // (written by cs_heavy_classify_kernel before this launch)
+	uint32_t *const work_counter = ctl + kCsqWork + cls;
 	// A read of the largest class (max_parts > 1) gets a SECOND pass when the first one -- T the smallest value whose bins fit ONE table -- ends
 	// with T - 1 >= max(kmer_min, M2 * sensitivity): M2, exact for the bins it saw, is a lower bound of the true maximum, so the largest T' with
 	// T' - 1 < that threshold is sure to certify, and the bins at or above T' are taken in as many table passes as they need (s_retry_*).
@@ -394,7 +298,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		}
 		__syncthreads();
 		const uint32_t n_items = seg_pref[n_lists];
-		if ((n_items >> kCsHeavyCoarseShift) + 3u > coarse_cap) { if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // (block-uniform; sized from max_kfreq: not reached)
+		if ((n_items >> kCsHeavyCoarseShift) + 3u > coarse_cap) { if (wv == 0) { cs_enqueue(A, read, lane, R); if (lane == 0) atomicAdd(&ctl[kCsqSentOn], 1u); } continue; }   // (block-uniform; sized from max_kfreq: not reached)
 		for (int li = tid; li < n_lists; li += NT) {
 			const uint32_t s0 = seg_pref[li], s1 = seg_pref[li + 1];
 			constexpr uint32_t cm = (1u << kCsHeavyCoarseShift) - 1u;
@@ -680,12 +584,12 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					if (!s_fail || parts >= parts_now) break;   // (block-uniform)
 					parts = min(parts_now, parts * 2u);
 					__syncthreads();
-					if (tid == 0) s_fail = 0;
+					if (tid == 0) { s_fail = 0; atomicAdd(&ctl[kCsqRestart], 1u); }
 					}
 					mark(5);
 					if (dg) { atomicAdd(&diag[8], 1ull); atomicAdd(&diag[9], (unsigned long long) H); atomicAdd(&diag[12], (unsigned long long) parts); }
 					const uint32_t n_ent = s_nent;
-					if (s_fail || n_ent > ent_cap) { if (diag && tid == 0) atomicAdd(&diag[15], 1ull); if (wv == 0) cs_enqueue(A, read, lane, R); continue; }
+					if (s_fail || n_ent > ent_cap) { if (diag && tid == 0) atomicAdd(&diag[15], 1ull); if (wv == 0) { cs_enqueue(A, read, lane, R); if (lane == 0) atomicAdd(&ctl[kCsqSentOn], 1u); } continue; }
 					pmx = wave_reduce_max(pmx); pmxb = wave_reduce_max(pmxb);
 					if (lane == 0) { s_mx[wv] = (uint32_t) pmx; s_mxb[wv] = (uint32_t) pmxb; }
 					__syncthreads();
@@ -694,7 +598,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 					for (int w2 = 0; w2 < NW; ++w2) { pmx = max(pmx, (int) s_mx[w2]); pmxb = max(pmxb, (int) s_mxb[w2]); }
 					const float max_hit_p = (float) pmx;
 					const float thresh_p = fmaxf(A.kmer_min, max_hit_p * A.sensitivity);
-					if (!((float) (T - 1u) < thresh_p)) { if (diag && tid == 0) atomicAdd(&diag[15], 1ull << 32); if (wv == 0) cs_enqueue(A, read, lane, R); continue; }   // bins below T could reach the threshold (a second pass: T was forced as low as the first pass's maximum asks for; the table did not take it)
+					if (!((float) (T - 1u) < thresh_p)) { if (diag && tid == 0) atomicAdd(&diag[15], 1ull << 32); if (wv == 0) { cs_enqueue(A, read, lane, R); if (lane == 0) atomicAdd(&ctl[kCsqSentOn], 1u); } continue; }   // bins below T could reach the threshold (a second pass: T was forced as low as the first pass's maximum asks for; the table did not take it)
 					const uint32_t region_p = (uint32_t) read & (kCsRegions - 1);
 					if (tid == 0 && A.counters) {
 						atomicAdd(&A.counters[region_p * kCsCursorStride], (unsigned long long) R.n_valid);
@@ -753,9 +657,9 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		mark(5);
 		if (dg) { atomicAdd(&diag[8], 1ull); atomicAdd(&diag[9], (unsigned long long) H); if (H > cap && s_direct) atomicAdd(&diag[10], 1ull); }
 		if (failed || s_fail) {
-			if (!failed && !T_force && max_parts > 1u && T > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = T; } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // the table overflowed: the same T in several passes
+			if (!failed && !T_force && max_parts > 1u && T > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = T; atomicAdd(&ctl[kCsqSecond], 1u); } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // the table overflowed: the same T in several passes
 			if (diag && tid == 0) { if (failed && why <= 2u) atomicAdd(&diag[14], why == 2u ? 1ull << 32 : 1ull); else atomicAdd(&diag[15], 1ull); }
-			if (wv == 0) cs_enqueue(A, read, lane, R);
+			if (wv == 0) { cs_enqueue(A, read, lane, R); if (lane == 0) atomicAdd(&ctl[kCsqSentOn], 1u); }
 			continue;
 		}
 		// the table: maximum, candidates (cs_global_kernel's order: thread t owns the slots of lane class t mod 64 in the (t / 64)-th share)
@@ -777,9 +681,9 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t n_list
 		const float max_hit = (float) mx;
 		const float thresh = fmaxf(A.kmer_min, max_hit * A.sensitivity);
 		if (T > 1u && !((float) (T - 1u) < thresh)) {   // bins outside the table could reach the threshold
-			if (!T_force && max_parts > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = max(2u, (uint32_t) ceilf(thresh)); } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // once more, from the T this maximum asks for
+			if (!T_force && max_parts > 1u) { if (tid == 0) { s_retry_ix = item_ix; s_retry_T = max(2u, (uint32_t) ceilf(thresh)); atomicAdd(&ctl[kCsqSecond], 1u); } if (dg) atomicAdd(&diag[13], 1ull); continue; }   // once more, from the T this maximum asks for
 			if (diag && tid == 0) atomicAdd(&diag[15], 1ull << 32);
-			if (wv == 0) cs_enqueue(A, read, lane, R);
+			if (wv == 0) { cs_enqueue(A, read, lane, R); if (lane == 0) atomicAdd(&ctl[kCsqSentOn], 1u); }
 			continue;
 		}
 		const uint32_t region = (uint32_t) read & (kCsRegions - 1);

@@ -84,7 +84,8 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 			if (lane == 0) seg_pref[n_lists] = carry;
 		}
 		int log2_nb = 6;
-		while (log2_nb < kCsOrderBucketLog2Max && (8u << log2_nb) < H) ++log2_nb;   // ~8 hits per bucket where the LDS allows it
+		const int log2_nb_max = min(kCsOrderBucketLog2Max, max(6, A.log2_bits));   // (A.log2_bits: the host's limit -- kCsOrderBucketLog2Max unless a test asks for crowded buckets)
+		while (log2_nb < log2_nb_max && (8u << log2_nb) < H) ++log2_nb;   // ~8 hits per bucket where the LDS allows it
 		const uint32_t nb = 1u << log2_nb;
 		for (uint32_t b = tid; b <= nb; b += NT) bk[b] = 0;
 		for (uint32_t v = tid; v < n_tau; v += NT) tau[v] = 0xFFFFFFFFu;
@@ -327,15 +328,9 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 	}
 }
 
-// two builds of the same body: registers as the compiler likes them, or held to 64 (experiments)
 template <int NT>
 __global__ __launch_bounds__(NT) void cs_order_bucket_kernel(CsArgs A, uint32_t n_list, uint32_t *work_counter, uint2 *scratch, uint32_t scratch_cap, uint32_t coarse_cap,
 		const uint32_t *cand_loc, const uint32_t *cand_sv, uint32_t *cand_rank, uint32_t *info, unsigned long long *diag) {
-	cs_order_bucket_body<NT>(A, n_list, work_counter, scratch, scratch_cap, coarse_cap, cand_loc, cand_sv, cand_rank, info, diag);
-}
-template <int NT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void cs_order_bucket_kernel_w8(CsArgs A, uint32_t n_list, uint32_t *work_counter, uint2 *scratch, uint32_t scratch_cap,
-		uint32_t coarse_cap, const uint32_t *cand_loc, const uint32_t *cand_sv, uint32_t *cand_rank, uint32_t *info, unsigned long long *diag) {
 	cs_order_bucket_body<NT>(A, n_list, work_counter, scratch, scratch_cap, coarse_cap, cand_loc, cand_sv, cand_rank, info, diag);
 }
 

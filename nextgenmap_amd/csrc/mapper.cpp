@@ -2,720 +2,29 @@
 //   candidate search -> window gather -> BatchScore -> top-1 selection / MAPQ -> window gather -> BatchAlign.
 // One ngm_mapper is what one NextGenMap CS thread owns (CS + ScoreBuffer + AlignmentBuffer + IAlignment,
 // src/CS.cpp:455-461); everything between the read upload and the traceback download stays in HBM.
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <climits>
-#include <cmath>
-#include <cstdlib>
-#include <cstdio>
-#include <cstring>
-#include <condition_variable>
-#include <mutex>
-#include <numeric>
-#include <thread>
-#include <vector>
-
-#include <string.h>
-#include <ctype.h>
-#include <sched.h>
-#include <rocprim/rocprim.hpp>
-
-#include "refindex.h"
-#include "engine_internal.h"
-#include "align_device.h"
-#include "cigar_md.h"
-#include "cigar_device.h"
-#include "cs_device.h"
-#include "cs_canon_device.h"
-#include "cs_heavy_device.h"
-#include "cs_order_bucket_device.h"
-#include "cs_slam_device.h"
+// This file: the mapper's life cycle, the score / select / align / SAM stages and the C entry points; the candidate-search stage and the
+// candidate-order replay live in mapper_search.cpp (mapper_internal.h is what the two share).
 #define NGM_SAM_KERNELS
-#include "sam_device.h"
+#include "mapper_internal.h"
+#include <rocprim/rocprim.hpp>
+#include "align_device.h"
 #include "gather_device.h"
-#include "pair_device.h"
-#include "thread_pool.h"
 
-#define MAP_HIP_TRY(expr)                                                                      \
-	do {                                                                                       \
-		hipError_t e_ = (expr);                                                                \
-		if (e_ != hipSuccess) {                                                                \
-			ngm::pipeline_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-			return -5;                                                                         \
-		}                                                                                      \
-	} while (0)
+using ngm::DevGuard;
+using ngm::GpuStage;
+using ngm::run_cs;
+using ngm::cs_host_arrays;
+using ngm::candidate_order;
+using ngm::candidate_order_wait;
 
-// ScoreBuffer's running insert-size sum / count (src/ScoreBuffer.h:90) when several mapper instances work on one input:
-// batches carry their input-order number and the order-dependent part of the selection takes turns in that order, so
-// every batch starts from the state the reference's single CS thread would have at its first pair.
-struct ngm_pair_state {
-	std::mutex mu;
-	std::condition_variable cv;
-	uint64_t next = 0;                 // sequence number of the batch whose turn it is
-	long dist_count = 1, dist_sum = 0;
-	uint64_t scores_so_far = 0;        // candidates of the pairs of the reference's current CS batch: where its score buffer would stand
-	uint64_t reads_so_far = 0;         // reads of all batches so far (position inside the reference's CS batches)
-};
-
-struct ngm_mapper {
-	const ngm_ref *ref = nullptr;
-	ngm_pair_state *ps = nullptr;      // shared paired-end state (null: the mapper's own)
-	uint64_t batch_seq = 0;            // ... and the input-order number of the next paired-end batch
-	int fast_pairing = 0;              // Config "fast_pairing": top1SE for both mates instead of top1PE (src/ScoreBuffer.cpp:203-216)
-	ngm_mapper_params prm{};
-	ngm_hip_ctx *eng = nullptr;
-	hipStream_t st = nullptr;
-	int max_kfreq = 0;
-	int cs_log2_slots = 14;   // large LDS vote table: 2^14 slots * 8 B = 128 KB (2^13 when the lists of very long reads need the room)
-	int cs_log2_small = 10;   // fast path: small exact table ...
-	uint32_t cs_plane_bits = 65536;
-	uint32_t cs_plane_bits0 = 65536;  // ... before it was trimmed to the LDS granule
-	int cs_log2_bits = 16;    // ... behind two bit planes of this many bits; both picked from the index density
-	uint32_t cs_queued_exact = 0;
-	int cs_fast_items = ngm::kCsFastItemsShort;
-	size_t cs_region_cap = 0; // candidate slots of all output regions together (grows when a batch overflows)
-	double cs_hexp = 4096;    // expected index hits per read
-	int cs_waves = 3;         // waves per read of the fast path (cs_fast2_kernel; 1: cs_fast_kernel, NGM_HIP_CS_WAVES)
-	bool cs_paired = false;   // the batch being searched holds pairs (bisulfite mapping: second mates are searched A>G)
-	int cs_canon_wpe = 7;      // 72 VGPRs: with 64 the sweeps spill (scratch round trips inside the vote loop cost more than the tenth read per CU brings)
-	int cs_canon_ch = 1;      // canonical path, shape 2: chunk loads issued after this vote step (NGM_HIP_CS_CANON_CH: 0, 1, 3)
-	int cs_canon = 0;         // 0: fast path over one bucket per k-mer (cs_fast2_kernel); 1-3: over canonical pair buckets, cs_canon_kernel<3,4,2> / <3,6,2> / <4,8,4>
-	long pair_dist_count = 1, pair_dist_sum = 0;  // ScoreBuffer.h:90
-	uint64_t scores_so_far = 0, reads_so_far = 0;  // see ngm_pair_state
-	int ref_cs_batch = 0;             // reads per CS batch of the reference (1 800 000 / average read length, CS.cpp:26, :542): its score buffer is flushed there
-	int ref_score_buffer = 0;         // entries of the reference's score buffer (IAlignment::GetScoreBatchSize there); 0: pairs are never lost (ngm_mapper_set_reference_score_buffer)
-	uint64_t lost_pairs = 0;          // ngm_mapper_lost_pairs
-	// ngm_mapper_path_counters: reads searched, candidates, reads re-run by the exact LDS / exact global-memory search, reads whose
-	// candidate order was replayed, of those beyond the LDS replay's limits (replayed by the exact global-memory kernel), left undetermined
-	uint64_t st_heavy = 0, st_reads = 0, st_cands = 0, st_exact_lds = 0, st_exact_global = 0, st_order_reads = 0, st_order_big = 0, st_order_unknown = 0, st_order_table = 0;
-	ngm::CsArgs last_cs{};                          // arguments of the last candidate search (for the order replay)
-	hipStream_t st_hi = nullptr;                    // high-priority stream: the (small) order replay runs outside the stage lock
-	hipEvent_t turn_ev[16] = {};                     // GpuStage: the events that end this instance's turns
-	unsigned turn_next = 0;
-	hipStream_t st_copy = nullptr;                  // the per-read arrays of a search travel to the host beside the score stage's kernels, not in front of them
-	hipEvent_t ev_cs_done = nullptr, ev_cs_copied = nullptr;
-	bool cs_copy_pending = false;
-	ngm::DevBuf<uint32_t> d_order_list, d_cand_rank, d_order_scratch, d_order_info, d_order_big, d_order_gt, d_order_log2;
-	ngm::DevBuf<uint64_t> d_order_off;
-	ngm::CsArgs order_args{};                       // arguments of the replay in flight
-	ngm::PinnedBuf<uint32_t> p_rank, p_order_info;
-	std::vector<uint32_t> order_pending;            // the reads of the replay in flight (candidate_order_finish accounts for them)
-	// pinned staging for the per-batch downloads
-	ngm::PinnedBuf<uint32_t> p_winner, p_loc, p_sv;
-	ngm::PinnedBuf<int32_t> p_mapq, p_nbest, p_rec;
-	ngm::PinnedBuf<float> p_best, p_scores;
-	ngm::PinnedBuf<uint16_t> p_runs;
-	// batch state in HBM
-	ngm::DevBuf<uint8_t> d_reads;
-	ngm::DevBuf<uint16_t> d_read_len;
-	ngm::DevBuf<uint32_t> d_cand_base, d_cand_count, d_out_loc, d_out_sv, d_status, d_ovf_read, d_ovf_read2, d_ovf_hits, d_ovf_log2;
-	ngm::DevBuf<uint64_t> d_ovf_off;
-	ngm::DevBuf<uint32_t> d_gt_keys, d_gt_votes, d_heavy_list, d_heavy_ctr;
-	ngm::DevBuf<float> d_max_votes, d_max_both, d_scores, d_best;
-	ngm::DevBuf<unsigned long long> d_total, d_counters, d_heavy_diag;
-	ngm::DevBuf<uint32_t> d_out_loc2, d_out_sv2, d_new_base;
-	ngm::DevBuf<uint8_t> d_scan_tmp;
-	unsigned long long cs_kmers = 0, cs_hits = 0;
-	float cs_kernel_ms = 0.f;
-	hipEvent_t cev[6] = {};
-	hipEvent_t oev[4] = {};            // around the order replay's launches (its own stream)
-	float order_ms = 0.f;              // GPU time of the order replays of the last batch (ngm_mapper_last_order_replay_ms)
-	ngm::DevBuf<uint32_t> d_pair_read, d_winner, d_a_read, d_a_loc, d_a_sv;
-	ngm::DevBuf<int32_t> d_mapq, d_nbest, d_records, d_pair_info;
-	ngm::PinnedBuf<int32_t> p_pair_info;
-	ngm::DevBuf<ngm::PairOut> d_pair_out;      // pair_choice_kernel (pair_device.h): per pair, and the best-scoring combinations of the tied ones
-	ngm::DevBuf<ngm::PairTop> d_pair_top;
-	ngm::DevBuf<uint32_t> d_pair_tied_n, d_pair_list;
-	ngm::PinnedBuf<ngm::PairOut> p_pair_out;
-	ngm::PinnedBuf<ngm::PairTop> p_pair_top;
-	ngm::PinnedBuf<uint32_t> p_pair_tied_n;
-	ngm::DevBuf<uint16_t> d_runs, d_runs_c;
-	ngm::DevBuf<char> d_str;   // CIGAR / MD on the device: the compact byte stream
-	ngm::DevBuf<ngm::CigarDevOut> d_cigout;
-	ngm::PinnedBuf<ngm::CigarDevOut> p_cigout;
-	ngm::PinnedBuf<char> p_str;
-	// SAM text on the GPU (sam_device.h)
-	ngm_sam_options sam_opt{};
-	ngm_bgzf *bz = nullptr;   // sam_opt.bam: the BGZF compressor of this mapper's BAM records
-	bool sam_ready = false;
-	std::string sam_rg;
-	ngm::DevBuf<char> d_sam_contig_names, d_sam_rg, d_sam_names, d_sam_text;
-	ngm::DevBuf<uint32_t> d_sam_contig_off, d_sam_len, d_sam_off;
-	ngm::DevBuf<uint64_t> d_sam_contig_start;
-	ngm::DevBuf<uint8_t> d_sam_quals;
-	ngm::DevBuf<ngm::SamMeta> d_sam_meta;
-	ngm::DevBuf<ngm::SamRef> d_sam_refs;
-	ngm::DevBuf<ngm_hit> d_sam_hits;
-	ngm::PinnedBuf<ngm_hit> p_sam_hits;
-	ngm::PinnedBuf<ngm::SamRef> p_sam_refs;
-	ngm::PinnedBuf<char> p_sam_extra;
-	uint64_t sam_text_bytes = 0;      // of the last batch (still in d_sam_text)
-	uint64_t pair_stats[3] = {0, 0, 0};   // ngm_mapper_last_pair_stats
-	// last CS result on the host
-	int n_reads = 0;
-	// per-read candidate offsets / counts / best vote counts of the last search, downloaded into pinned memory
-	template <typename T> struct HostArr {
-		ngm::PinnedBuf<T> b;
-		T &operator[](size_t i) { return b.p[i]; }
-		const T &operator[](size_t i) const { return b.p[i]; }
-		T *data() { return b.p; }
-	};
-	HostArr<uint32_t> h_base, h_count;
-	HostArr<float> h_maxv;
-	uint64_t n_cand = 0;
-	hipEvent_t ev[10] = {};   // [8]: behind the last kernel of the align stage
-	float ms[8] = {};
-};
+namespace ngm {
+StageLock g_stage_lock[16][2];
+std::atomic<long long> g_stage_hold_us[3], g_stage_wait_us[3];
+}
+using ngm::g_stage_hold_us;
+using ngm::g_stage_wait_us;
 
 namespace {
-
-struct DevGuard {
-	int prev = -1;
-	explicit DevGuard(int d) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != d) (void) hipSetDevice(d); else prev = -1; }
-	~DevGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
-};
-
-// canonical fast path: waves per read and chunk-item rounds of the kernel shapes (cs_canon_device.h)
-constexpr int kCanonT[4] = {0, 3, 3, 4}, kCanonR1[4] = {0, 4, 6, 8}, kCanonR2[4] = {0, 2, 2, 4};
-constexpr int kCsCanonMode = 3;
-size_t cs_canon_lds_bytes(const ngm::CsArgs &A, int shape) {  // k-mer info + headers, codes, chunk items (16-bit), plane, table, queue (+ the kernel's static variables)
-	const size_t w = (size_t) A.lists_cap + (A.q + 3) / 4 + (size_t) kCanonR2[shape] * kCanonT[shape] * 64 / 2 + ((size_t) A.plane_bits >> 5) + ((size_t) 2 << A.log2_slots) +
-			((size_t) 3 << A.log2_slots) / 4 + 96;  // (+ slack: the per-wave k-mer rows round up, the static variables)
-	return w * 4;
-}
-
-// shape 1-3; shape 2 exists in variants (experiments: NGM_HIP_CS_CANON_CH = the vote step after which the chunk loads are issued,
-// NGM_HIP_CS_CANON_WPE = waves per SIMD the register allocation aims at)
-const void *cs_canon_fn(int shape, int ch, int wpe, int bin_shift = 0) {
-	if (shape == 2 && ch == 1 && wpe == 7 && bin_shift == 2) return (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 7, true>;   // the default
-	if (shape == 1) return (const void *) ngm::cs_canon_kernel<3, 4, 2, 1>;
-	if (shape == 3) return (const void *) ngm::cs_canon_kernel<4, 8, 4, 1>;
-	if (wpe <= 5) return (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 5>;   // experiments: 86 VGPRs, no scratch, 5 waves per SIMD
-	if (wpe == 6) return (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 6>;   // 80 VGPRs, 5 spilled dwords
-	if (wpe <= 7) return ch == 0 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 0, 7> : (const void *) ngm::cs_canon_kernel<3, 6, 2, 1, 7>;
-	return ch == 0 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 0> : ch >= 3 ? (const void *) ngm::cs_canon_kernel<3, 6, 2, 3> : (const void *) ngm::cs_canon_kernel<3, 6, 2, 1>;
-}
-
-size_t cs_lds_bytes(const ngm::CsArgs &A, int mode) {
-	size_t w = (size_t) A.lists_cap * 2 + 1 + (A.q + 3) / 4;
-	if (mode == ngm::kCsFast)  // list starts (32-bit) + lengths (16-bit), codes, plane, items, table, queue
-		w = (size_t) A.lists_cap + (size_t) A.lists_cap / 2 + (A.q + 3) / 4 + ((size_t) A.plane_bits >> 5) + (size_t) A.fast_items * 64 / (A.items16 ? 2 : 1) +
-				((size_t) 3 << A.log2_slots) / 4 + 32;  // + the kernels' static variables (<= 128 bytes): this is what the occupancy math sees
-	if (mode != ngm::kCsFast && A.bs) w += (size_t) A.q + 1 + ngm::kCsBsChunk / 2;  // l_vbase, l_vpos
-	if (mode != ngm::kCsExactGlobal) w += (size_t) 2 << A.log2_slots;
-	return w * 4;
-}
-
-// ---- whose kernels run now ------------------------------------------------------------------------------------------------
-// GPU stages (candidate search + score, align, SAM text: each from its first launch to the end of its last kernel) of the mapper
-// instances of one process take turns: kernels of different instances then do not slow each other down, while the host stages of one
-// instance -- and, since round 4, the downloads behind a stage's last kernel -- overlap the GPU stages of the others.
-// NGM_HIP_GPU_STAGE_LOCK: 0 no turns (streams share the GPU), 1 one lock per device (default), 2 one lock per stage kind (search + score
-// | align + SAM text).
-// NGM_HIP_STAGE_CHAIN=1 (experiment, round 4): the turn passed ON THE GPU -- the host mutex held only while kernels are enqueued, the stream
-// made to wait for the event behind the previous holder's kernels (hipStreamWaitEvent), every host synchronisation inside a stage ending
-// the turn so that another instance's kernels fill the gap.  Measured on one box, 20 steps, twice each: 51.6 / 47.3 M reads/s chained
-// against 54.8 / 51.3 with the host lock (three and four instances chained: 47.0 / 49.2): the cross-stream waits and the longer way of
-// a batch through finer turns cost more than the idle time they remove.  Not the default.
-struct StageChain { std::mutex mu; hipEvent_t last = nullptr; };
-StageChain g_chain[16][2];
-std::atomic<long long> g_stage_hold_us[3], g_stage_wait_us[3];   // diagnostics (NGM_HIP_HOST_TIMING): turn held / waited for on the host, per stage kind (0 search + score, 1 align, 2 SAM text)
-struct GpuStage {
-	ngm_mapper *m;
-	int kind, slot;
-	bool held = false;
-	StageChain *ch = nullptr;
-	std::chrono::steady_clock::time_point t_acq;
-	static int mode() { static const int v = getenv("NGM_HIP_GPU_STAGE_LOCK") ? atoi(getenv("NGM_HIP_GPU_STAGE_LOCK")) : 1; return v; }
-	static bool chained() { static const bool v = getenv("NGM_HIP_STAGE_CHAIN") && atoi(getenv("NGM_HIP_STAGE_CHAIN")) != 0; return v; }
-	GpuStage(ngm_mapper *m_, int kind_ = 0, bool now = true, int slot_ = -1) : m(m_), kind(kind_), slot(slot_ < 0 ? kind_ : slot_) {
-		ch = &g_chain[(unsigned) m->ref->device & 15u][mode() == 2 ? kind : 0];
-		if (now) acquire();
-	}
-	~GpuStage() { release(); }
-	void acquire() {   // before kernels are enqueued
-		if (mode() == 0 || held) return;
-		const auto t0 = std::chrono::steady_clock::now();
-		ch->mu.lock();
-		held = true;
-		t_acq = std::chrono::steady_clock::now();
-		g_stage_wait_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(t_acq - t0).count();
-		if (chained() && ch->last) (void) hipStreamWaitEvent(m->st, ch->last, 0);
-	}
-	void release() {   // the kernels of this turn have been enqueued (chained) / have finished (host lock)
-		if (!held) return;
-		if (chained()) {
-			hipEvent_t e = m->turn_ev[m->turn_next++ & 15u];
-			if (e && hipEventRecord(e, m->st) == hipSuccess) ch->last = e;
-		}
-		g_stage_hold_us[slot] += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_acq).count();
-		held = false;
-		ch->mu.unlock();
-	}
-	// the stage's last kernel has been enqueued and `ev` recorded behind it; copies to the host follow: chained, the turn ends here
-	void kernels_done() { if (chained()) release(); }
-	// ... host lock: it ends when that kernel has finished, not when the copies have (the next instance's kernels run under them)
-	void done_after(hipEvent_t ev) { if (held && !chained()) (void) hipEventSynchronize(ev); release(); }
-	void done() { release(); }
-	// a host synchronisation inside a stage: chained, the turn is passed on first (and taken again by the next acquire)
-	void before_sync() { if (chained()) release(); }
-};
-
-// candidate search for the reads already in m->d_reads; leaves per-read base/count/max votes and the
-// candidate arrays in HBM (and base/count/max votes on the host)
-int run_cs(ngm_mapper *m, int n, GpuStage *stage = nullptr) {
-	const ngm_ref *r = m->ref;
-	auto hold = [&] { if (stage) stage->acquire(); };       // before kernels are enqueued
-	auto yield = [&] { if (stage) stage->before_sync(); };   // before the host waits for the stream
-	const int q = m->prm.qry_max_len;
-	if (n <= 0) { m->n_reads = 0; m->n_cand = 0; return 0; }
-	if (m->d_read_len.reserve(n) || m->d_cand_base.reserve(n) || m->d_cand_count.reserve(n) || m->d_max_votes.reserve(n) || m->d_max_both.reserve(n) ||
-			m->d_status.reserve(4) || m->d_total.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 16) || m->d_counters.reserve(ngm::kCsRegions * ngm::kCsCursorStride + 32) || m->d_new_base.reserve(n) || m->d_ovf_read.reserve(n) || m->d_ovf_read2.reserve(n) ||
-			m->d_ovf_hits.reserve(n)) {
-		ngm::pipeline_set_error("out of device memory (candidate search, %d reads)", n);
-		return -12;
-	}
-	const size_t ctr_words = (size_t) ngm::kCsRegions * ngm::kCsCursorStride;
-	size_t cap = std::max<size_t>(m->cs_region_cap, (size_t) n * 4 + 64 * ngm::kCsRegions);
-	cap = (cap + ngm::kCsRegions - 1) / ngm::kCsRegions * ngm::kCsRegions;
-	const size_t fixed_slots = getenv("NGM_HIP_CS_NO_FIXED_SLOTS") ? 0 : (size_t) n * ngm::kCsFixedSlots;
-	for (int attempt = 0; attempt < 8; ++attempt) {
-		// candidate offsets are 32-bit (base = region * capacity + cursor; the prefix sums over the counts)
-		if (cap + fixed_slots >= 0xFFFFFFFFull) { ngm::pipeline_set_error("more than 2^32 candidate slots needed for %d reads: use smaller batches or a higher sensitivity", n); return -75; }
-		if (m->d_out_loc.reserve(cap + fixed_slots) || m->d_out_sv.reserve(cap + fixed_slots) || m->d_out_loc2.reserve(cap + fixed_slots) || m->d_out_sv2.reserve(cap + fixed_slots)) { ngm::pipeline_set_error("out of device memory (candidates)"); return -12; }
-		hold();
-		MAP_HIP_TRY(hipMemsetAsync(m->d_status.p, 0, 16, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 16) * 8, m->st));
-		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 32) * 8, m->st));
-		ngm::CsArgs A{};
-		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
-		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
-		A.index = r->d_index; A.positions = r->d_positions;
-		A.lists_cap = 2 * std::max(1, q - r->prm.kmer + 1);
-		A.read_len = m->d_read_len.p; A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p; A.max_votes = m->d_max_votes.p; A.max_both = m->d_max_both.p;
-		A.out_loc = m->d_out_loc.p; A.out_sv = m->d_out_sv.p; A.out_total = m->d_total.p; A.out_capacity = cap / ngm::kCsRegions;
-		A.fixed_base = fixed_slots ? (uint32_t) cap : 0u;
-		A.status = m->d_status.p; A.ovf_read = m->d_ovf_read.p; A.ovf_hits = m->d_ovf_hits.p; A.counters = m->d_counters.p;
-		A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + ctr_words : nullptr;
-		A.debug_stop = getenv("NGM_HIP_CS_STOP") ? atoi(getenv("NGM_HIP_CS_STOP")) : 0;
-		uint32_t status[4];
-		m->cs_kernel_ms = 0;
-		float pass_ms[3] = {0, 0, 0};
-		auto timed = [&](int e) { float t = 0; if (hipEventElapsedTime(&t, m->cev[e], m->cev[e + 1]) == hipSuccess) { m->cs_kernel_ms += t; pass_ms[e / 2] = t; } };
-
-		const bool bs = m->prm.bs_mapping != 0;
-		A.bs = bs ? 1 : 0; A.bs_cutoff = m->prm.bs_cutoff; A.bs_read_skip = std::max(0, m->prm.bs_read_skip); A.bs_paired = m->cs_paired ? 1 : 0;
-		if (bs) A.lists_cap = 2 * ngm::kCsBsChunk;  // the exact kernels hold the lists of kCsBsChunk k-mer variants at a time
-		// pass 1 -- FAST path for every read (bit-plane filter + small exact table, many workgroups per CU)
-		A.log2_bits = m->cs_log2_bits; A.plane_bits = m->cs_plane_bits; A.log2_slots = m->cs_log2_small; A.fast_items = m->cs_fast_items;
-		A.buckets = r->d_buckets; A.bucket_log2_words = r->bucket_log2_words; A.pos_base = r->bucket_pos_base;
-		A.hit_cap = m->cs_plane_bits / 6u;
-		if (A.bin_shift < 2) A.hit_cap = 0;  // the register encoding of the fast path keeps bins in 30 bits
-		MAP_HIP_TRY(hipEventRecord(m->cev[0], m->st));
-		const bool slamw = (m->prm.slam_seq & 4) != 0;
-		if (slamw) {
-			// `--slam-seq` with bit 2: the weighted search (cs_slam_device.h) -- float votes in the reference's order, one wave per read,
-			// tables in slices of global memory.  Persistent workgroups with a slice each; reads whose hits outgrow it are queued and re-run
-			// with a slice of their own.
-			A.bs = 2; A.bs_cutoff = 0; A.bs_read_skip = 0; A.bs_paired = m->cs_paired ? 1 : 0;
-			A.lists_cap = 2 * ngm::kCsBsChunk;
-			const size_t lds = cs_lds_bytes(A, ngm::kCsExactGlobal);
-			const int grid = std::min(n, 2048);
-			A.slam_slice_words = ngm::cs_slam_words(49152u);
-			if (m->d_gt_keys.reserve((size_t) grid * A.slam_slice_words)) { ngm::pipeline_set_error("out of device memory (weighted SLAM-seq search)"); return -12; }
-			A.gtable_keys = m->d_gt_keys.p;
-			hipLaunchKernelGGL(ngm::cs_slam_kernel, dim3(grid), dim3(64), lds, m->st, A);
-			MAP_HIP_TRY(hipGetLastError());
-			yield();
-			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipStreamSynchronize(m->st));
-			if (status[1] > 0) {
-				const uint32_t no = status[1];
-				std::vector<uint32_t> qr(no), qh(no), lg(no);
-				std::vector<uint64_t> off(no);
-				MAP_HIP_TRY(hipMemcpy(qr.data(), m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToHost));
-				MAP_HIP_TRY(hipMemcpy(qh.data(), m->d_ovf_hits.p, (size_t) no * 4, hipMemcpyDeviceToHost));
-				if (m->d_ovf_off.reserve(no) || m->d_ovf_log2.reserve(no) || m->d_ovf_read2.reserve(no)) { ngm::pipeline_set_error("out of device memory (weighted SLAM-seq search)"); return -12; }
-				constexpr uint64_t kPoolWords = 1ull << 30;
-				for (uint32_t j0 = 0; j0 < no;) {
-					uint64_t total = 0;
-					uint32_t j1 = j0;
-					while (j1 < no && (j1 == j0 || total + ngm::cs_slam_words(qh[j1]) <= kPoolWords)) { off[j1] = total; lg[j1] = ngm::cs_slam_log2_slots(qh[j1]); total += ngm::cs_slam_words(qh[j1]); ++j1; }
-					if (m->d_gt_keys.reserve(total)) { ngm::pipeline_set_error("out of device memory (weighted SLAM-seq search, %llu words)", (unsigned long long) total); return -12; }
-					hold();
-					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, qr.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, m->st));
-					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, m->st));
-					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, m->st));
-					ngm::CsArgs Q = A;
-					Q.read_list = m->d_ovf_read2.p; Q.ovf_log2 = m->d_ovf_log2.p; Q.ovf_table_off = m->d_ovf_off.p; Q.gtable_keys = m->d_gt_keys.p;
-					hipLaunchKernelGGL(ngm::cs_slam_kernel, dim3(j1 - j0), dim3(64), lds, m->st, Q);
-					MAP_HIP_TRY(hipGetLastError());
-					yield();
-					MAP_HIP_TRY(hipStreamSynchronize(m->st));
-					j0 = j1;
-				}
-				MAP_HIP_TRY(hipMemcpy(status, m->d_status.p, 16, hipMemcpyDeviceToHost));
-			}
-			MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
-			MAP_HIP_TRY(hipStreamSynchronize(m->st));
-			timed(0);
-			status[1] = 0;
-		} else if (bs) {
-			// bisulfite mapping: no fast path (a read looks up ~10 variants of every k-mer: exact tables only); every read starts in pass 2
-			MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
-			status[0] = 0; status[1] = (uint32_t) n; status[2] = status[3] = 0;
-		} else {
-		// 16-bit work items when every list index fits 9 bits and no used list can have more than 128 segments
-		A.items16 = (A.lists_cap <= 512 && m->max_kfreq <= 128 * ngm::kCsSeg) ? 1 : 0;
-		if (!A.items16) A.fast_items = ngm::kCsFastItemsLong;  // the 32-bit item list only exists in the large size
-		if (m->cs_canon) {
-			A.buckets = r->d_cbuckets; A.bucket_log2_words = r->cbucket_log2_words; A.pos_base = r->cbucket_pos_base;
-			const size_t lds = cs_canon_lds_bytes(A, m->cs_canon) - 96;  // (the kernel has no static LDS: its shared variables are the last 160 bytes of this)
-			// persistent workgroups: as many as the GPU holds at once, each walking the reads with that stride
-			const void *fn = cs_canon_fn(m->cs_canon, m->cs_canon_ch, m->cs_canon_wpe, A.bin_shift);
-			int per_cu = 0, cus = 0;
-			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kCanonT[m->cs_canon] * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-			if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
-			int grid = std::min(n, per_cu * cus);
-			if (const char *e = getenv("NGM_HIP_CS_GRID_PER_CU")) grid = std::min(n, std::max(1, atoi(e)) * cus);  // experiments
-			// (experiment, NGM_HIP_CS_READS_PER_WG=16..128: 5.55 / 5.74 / 6.44 ms per 524 288 reads with runs of 32 / 64 / 128 reads against 5.41 with
-			// persistent workgroups on the same box, and the other instance's order replay waits as long either way: not the default)
-			static const int run_env = getenv("NGM_HIP_CS_READS_PER_WG") ? atoi(getenv("NGM_HIP_CS_READS_PER_WG")) : 0;
-			A.reads_per_wg = std::max(0, run_env);
-			if (A.reads_per_wg > 0) grid = (n + A.reads_per_wg - 1) / A.reads_per_wg;
-			// NGM_HIP_CS_SPLIT=k: the batch in k launches -- persistent workgroups hold every CU until their launch ends, and a kernel of
-			// another stream (the other mapper instance's order replay, on a high-priority stream) only gets in between launches
-			static const int split = std::max(1, getenv("NGM_HIP_CS_SPLIT") ? atoi(getenv("NGM_HIP_CS_SPLIT")) : 1);
-			const int n_all = A.n;
-			for (int part = 0; part < split; ++part) {
-				ngm::CsArgs P = A;
-				P.read_lo = (int) ((long long) n_all * part / split);
-				P.n = (int) ((long long) n_all * (part + 1) / split);
-				if (P.n <= P.read_lo) continue;
-				const int cnt = P.n - P.read_lo;
-				const int g = A.reads_per_wg > 0 ? (cnt + A.reads_per_wg - 1) / A.reads_per_wg : std::min(cnt, grid);
-				if (part > 0) (void) hipMemsetAsync(m->d_status.p + 2, 0, 4, m->st);
-				void *kargs[] = {(void *) &P};
-				(void) hipLaunchKernel(fn, dim3(g), dim3(kCanonT[m->cs_canon] * 64), kargs, lds, m->st);
-			}
-			if (A.phase_cycles)
-				fprintf(stderr, "[ngm-hip] cs canonical path (shape %d): %zu bytes of LDS per read, %d reads resident per CU (grid %d), bucket 2^%d words\n", m->cs_canon, lds, per_cu, grid, A.bucket_log2_words);
-		}
-		else if (m->cs_waves >= 2 && A.items16) {  // T waves per read: the same 768 / 1 536 segments, dealt to T * 64 lanes
-			const bool shrt = A.fast_items == ngm::kCsFastItemsShort;
-			const size_t lds = cs_lds_bytes(A, ngm::kCsFast) - 128;  // the kernel's static variables take the rest
-#define NGM_CS_LAUNCH_T(T) \
-			do { if (shrt) hipLaunchKernelGGL((ngm::cs_fast2_kernel<T, ngm::kCsFastItemsShort / T, uint16_t>), dim3(n), dim3(T * 64), lds, m->st, A); \
-				else hipLaunchKernelGGL((ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>), dim3(n), dim3(T * 64), lds, m->st, A); } while (0)
-			if (m->cs_waves == 2) NGM_CS_LAUNCH_T(2); else if (m->cs_waves == 3) NGM_CS_LAUNCH_T(3); else NGM_CS_LAUNCH_T(4);
-			if (A.phase_cycles && m->cs_waves == 3 && shrt) {  // diagnostics: reads resident per CU
-				int blocks = 0;
-				(void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, (const void *) ngm::cs_fast2_kernel<3, ngm::kCsFastItemsShort / 3, uint16_t>, 192, lds);
-				fprintf(stderr, "[ngm-hip] cs fast path: %zu bytes of LDS per read, %d reads resident per CU\n", lds, blocks);
-			}
-#undef NGM_CS_LAUNCH_T
-		}
-		else if (A.fast_items == ngm::kCsFastItemsShort && A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
-		else if (A.items16) hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
-		else hipLaunchKernelGGL((ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>), dim3(n), dim3(64), cs_lds_bytes(A, ngm::kCsFast), m->st, A);
-		MAP_HIP_TRY(hipGetLastError());
-		MAP_HIP_TRY(hipEventRecord(m->cev[1], m->st));
-		yield();
-		MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
-		MAP_HIP_TRY(hipStreamSynchronize(m->st));
-		timed(0);
-		}
-		uint32_t n_heavy = 0;
-		static const bool heavy_on = !getenv("NGM_HIP_CS_NO_HEAVY");
-		static const bool heavy_v1 = getenv("NGM_HIP_CS_HEAVY_V1") != nullptr;   // round 4's kernel (cs_heavy_kernel), for A/B runs
-		if (!bs && heavy_on && !heavy_v1 && A.bin_shift >= 2 && status[1] > 0) {
-			// pass 1b -- the reads with more hits than the fast path takes (cs_heavy2_kernel, cs_heavy_device.h): two rows of sketch counters +
-			// an exact table in LDS, by hit count in three classes of persistent workgroups; pass 1c -- what the two smaller classes
-			// cannot certify, once more in the largest; what is left after that is queued for the exact kernels below
-			struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; uint32_t scratch_cap; const void *fn; uint32_t max_parts = 1; };   // max_parts: table passes a read may take (the largest class)
-			// (class limits measured on the heavy-tailed probe, per 262 144 reads: 16 384 / 32 768 / rest 18.3 ms; 16 384 / 65 536 / rest 16.1; 16 384 / all the
-			// rest in the middle class -- two workgroups per CU -- and the largest class only for what that cannot certify: 15.1)
-			static HeavyClass classes[3] = {{16384u, 13, 11, 256, 16384u, (const void *) ngm::cs_heavy2_kernel<256>}, {0xFFFFFFFEu, 14, 12, 512, 262144u, (const void *) ngm::cs_heavy2_kernel<512>},
-					{0xFFFFFFFFu, 15, 13, 1024, 1u << 20, (const void *) ngm::cs_heavy2_kernel<1024>, 32u}};
-			static const bool parts_env = [] { if (const char *e = getenv("NGM_HIP_HEAVY_PARTS")) classes[2].max_parts = (uint32_t) std::max(1, std::min(256, atoi(e))); return true; }();   // experiments: table passes of the largest class
-			(void) parts_env;
-			static const bool classes_env = [] {   // experiments: NGM_HIP_HEAVY_CLASSES=max0,max1 (hits up to which a read starts in class 0 / class 1)
-				if (const char *e = getenv("NGM_HIP_HEAVY_CLASSES")) {
-					unsigned long a = 0, b = 0;
-					if (sscanf(e, "%lu,%lu", &a, &b) == 2 && a > 0 && b >= a) {
-						classes[0].max_hits = (uint32_t) std::min<unsigned long>(a, 0xFFFFFFFEul); classes[1].max_hits = (uint32_t) std::min<unsigned long>(b, 0xFFFFFFFEul);
-						classes[0].scratch_cap = std::min<uint32_t>(classes[0].max_hits, 262144u); classes[1].scratch_cap = std::min<uint32_t>(classes[1].max_hits, 262144u);
-					}
-				}
-				return true; }();
-			(void) classes_env;
-			const uint32_t coarse_cap = (uint32_t) ngm::cs_heavy2_coarse_cap(A.lists_cap, m->max_kfreq);
-			n_heavy = status[1];
-			float t_heavy[2] = {0, 0};
-			uint32_t in_round[2] = {0, 0};
-			int cus = 0;
-			if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, r->device) != hipSuccess || cus < 1) cus = 256;
-			if (m->d_heavy_ctr.reserve(8)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
-			for (int round = 0; round < 2 && status[1] > 0; ++round) {
-				const uint32_t no = status[1];
-				std::vector<uint32_t> qr(no), qh(no), lists[3], keep_r, keep_h;
-				MAP_HIP_TRY(hipMemcpyAsync(qr.data(), m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
-				MAP_HIP_TRY(hipMemcpyAsync(qh.data(), m->d_ovf_hits.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
-				MAP_HIP_TRY(hipStreamSynchronize(m->st));
-				for (uint32_t i = 0; i < no; ++i) {
-					if (round == 0) lists[qh[i] <= classes[0].max_hits ? 0 : qh[i] <= classes[1].max_hits ? 1 : 2].push_back(qr[i]);
-					else if (qh[i] <= classes[1].max_hits) lists[2].push_back(qr[i]);   // failed in a smaller class: once more with the largest table
-					else { keep_r.push_back(qr[i]); keep_h.push_back(qh[i]); }          // (the largest class has seen it: the same kernel would fail the same way)
-				}
-				const uint32_t n_run = (uint32_t) (lists[0].size() + lists[1].size() + lists[2].size());
-				in_round[round] = n_run;
-				if (n_run == 0) break;
-				if (m->d_heavy_list.reserve(no)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
-				int grid[3] = {0, 0, 0};
-				size_t lds[3] = {0, 0, 0}, scratch_words = 0;
-				auto ent_cap_of = [&](int c) -> uint32_t { return classes[c].max_parts > 1 ? classes[c].max_parts * ((3u << classes[c].log2s) / 4u) : 0u; };   // (bin, votes) entries of all table passes
-				for (int c = 0; c < 3; ++c) {
-					if (lists[c].empty()) continue;
-					lds[c] = ngm::cs_heavy2_lds_bytes(A.lists_cap, A.q, classes[c].log2c, classes[c].log2s, coarse_cap);
-					int per_cu = 0;
-					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, classes[c].fn, classes[c].nt, lds[c]) != hipSuccess || per_cu < 1) per_cu = 1;
-					grid[c] = (int) std::min<size_t>(lists[c].size(), (size_t) per_cu * cus);
-					scratch_words += (size_t) grid[c] * ((size_t) classes[c].scratch_cap + 2 * (size_t) ent_cap_of(c));
-				}
-				if (m->d_gt_keys.reserve(scratch_words)) { ngm::pipeline_set_error("out of device memory (candidate search scratch, %zu words)", scratch_words); return -12; }
-				hold();
-				// the queue restarts with the reads this round does not run again
-				const uint32_t n_keep = (uint32_t) keep_r.size();
-				MAP_HIP_TRY(hipMemcpyAsync(m->d_status.p + 1, &n_keep, 4, hipMemcpyHostToDevice, m->st));
-				if (n_keep) {
-					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read.p, keep_r.data(), (size_t) n_keep * 4, hipMemcpyHostToDevice, m->st));
-					MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_hits.p, keep_h.data(), (size_t) n_keep * 4, hipMemcpyHostToDevice, m->st));
-				}
-				MAP_HIP_TRY(hipMemsetAsync(m->d_heavy_ctr.p, 0, 32, m->st));
-				if (A.phase_cycles) { if (m->d_heavy_diag.reserve(64)) return -12; MAP_HIP_TRY(hipMemsetAsync(m->d_heavy_diag.p, 0, 64 * 8, m->st)); }
-				MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
-				uint32_t off = 0;
-				size_t soff = 0;
-				for (int c = 2; c >= 0; --c) {   // (the largest reads first: their workgroups are the long ones)
-					const uint32_t cnt = (uint32_t) lists[c].size();
-					if (cnt == 0) continue;
-					MAP_HIP_TRY(hipMemcpyAsync(m->d_heavy_list.p + off, lists[c].data(), (size_t) cnt * 4, hipMemcpyHostToDevice, m->st));
-					ngm::CsArgs Hv = A;
-					Hv.read_list = m->d_heavy_list.p + off; Hv.log2_bits = classes[c].log2c; Hv.log2_slots = classes[c].log2s;
-					uint32_t n_list = cnt, scap = classes[c].scratch_cap, ccap = coarse_cap, mparts = classes[c].max_parts, ecap = ent_cap_of(c);
-					uint32_t *ctr = m->d_heavy_ctr.p + c, *scr = m->d_gt_keys.p + soff;
-					unsigned long long *dg = A.phase_cycles ? m->d_heavy_diag.p + 16 * c : nullptr;
-					void *kargs[] = {(void *) &Hv, (void *) &n_list, (void *) &ctr, (void *) &scr, (void *) &scap, (void *) &ccap, (void *) &mparts, (void *) &ecap, (void *) &dg};
-					MAP_HIP_TRY(hipLaunchKernel(classes[c].fn, dim3(grid[c]), dim3(classes[c].nt), kargs, lds[c], m->st));
-					off += cnt;
-					soff += (size_t) grid[c] * ((size_t) classes[c].scratch_cap + 2 * (size_t) ecap);
-				}
-				MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
-				yield();
-				MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
-				MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the lists live until here)
-				if (hipEventElapsedTime(&t_heavy[round], m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t_heavy[round];
-				if (A.phase_cycles) {
-					unsigned long long dg[64];
-					MAP_HIP_TRY(hipMemcpy(dg, m->d_heavy_diag.p, sizeof(dg), hipMemcpyDeviceToHost));
-					for (int c = 0; c < 3; ++c) if (dg[16 * c + 8]) {
-						const double ns = (double) dg[16 * c + 8];
-						fprintf(stderr, "[ngm-hip] heavy class %d (round %d, %zu reads, grid %d): us per sampled read: setup %.1f | sweep A %.1f | sum + T %.1f | insert / sweep B %.1f | row 2 %.1f | sweep D %.1f | candidates %.1f; hits %.0f, survivors %.0f, %.0f %% without a second row; second passes %.0f %% of the reads, table passes of the partitioned reads %.1f\n",
-								c, round, lists[c].size(), grid[c], dg[16 * c] / ns / 100.0, dg[16 * c + 1] / ns / 100.0, dg[16 * c + 2] / ns / 100.0, dg[16 * c + 3] / ns / 100.0, dg[16 * c + 4] / ns / 100.0,
-								dg[16 * c + 5] / ns / 100.0, dg[16 * c + 6] / ns / 100.0, dg[16 * c + 9] / ns, dg[16 * c + 11] / ns, 100.0 * dg[16 * c + 10] / ns, 100.0 * dg[16 * c + 13] / ns, (double) dg[16 * c + 12]);
-						const unsigned long long w = dg[16 * c + 14], x = dg[16 * c + 15];
-						if (w | x) fprintf(stderr, "[ngm-hip] heavy class %d sent on: %llu reads with a wrapped counter row, %llu without a T <= 255 that fits, %llu with more survivors than the slice or an overflowing table / entry list, %llu with T - 1 not below the threshold\n",
-								c, w & 0xFFFFFFFFull, w >> 32, x & 0xFFFFFFFFull, x >> 32);
-					}
-				}
-			}
-			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 1b (heavy reads): %.2f ms for %u reads; pass 1c (the largest class once more): %.2f ms for %u reads; %u left for the exact kernels\n",
-					t_heavy[0], in_round[0], t_heavy[1], in_round[1], status[1]);
-		} else
-		if (!bs && heavy_on && status[1] > 0) {
-			// pass 1b -- the reads with more hits than the fast path takes (cs_heavy_device.h): sketch counters + exact table in LDS, by
-			// hit count in three classes of workgroups; pass 1c -- what those cannot certify (more near-threshold bins than their table
-			// holds) and the reads beyond 65 535 hits: the same with 32-bit counters and 8 192 slots; what is left after that is queued
-			// for the exact kernels below
-			struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; bool wide; const void *fn; };
-			static const HeavyClass classes[4] = {{16384u, 13, 11, 256, false, (const void *) ngm::cs_heavy_kernel<256>}, {32768u, 14, 12, 512, false, (const void *) ngm::cs_heavy_kernel<512>},
-					{ngm::kCsHeavyMaxHits16, 15, 12, 1024, false, (const void *) ngm::cs_heavy_kernel<1024>}, {0xFFFFFFFFu, 14, 13, 1024, true, (const void *) ngm::cs_heavy_kernel<1024, true>}};
-			n_heavy = status[1];
-			float t_heavy[2] = {0, 0};
-			uint32_t in_round[2] = {0, 0};
-			for (int round = 0; round < 2 && status[1] > 0; ++round) {
-				const uint32_t no = status[1];
-				in_round[round] = no;
-				std::vector<uint32_t> qr(no), qh(no), lists[4];
-				MAP_HIP_TRY(hipMemcpyAsync(qr.data(), m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
-				MAP_HIP_TRY(hipMemcpyAsync(qh.data(), m->d_ovf_hits.p, (size_t) no * 4, hipMemcpyDeviceToHost, m->st));
-				MAP_HIP_TRY(hipStreamSynchronize(m->st));
-				for (uint32_t i = 0; i < no; ++i) lists[round == 1 ? 3 : qh[i] <= classes[0].max_hits ? 0 : qh[i] <= classes[1].max_hits ? 1 : qh[i] <= classes[2].max_hits ? 2 : 3].push_back(qr[i]);
-				if (m->d_heavy_list.reserve(no)) { ngm::pipeline_set_error("out of device memory (candidate search)"); return -12; }
-				hold();
-				MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
-				MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
-				uint32_t off = 0;
-				for (int c = 0; c < 4; ++c) {
-					const uint32_t cnt = (uint32_t) lists[c].size();
-					if (cnt == 0) continue;
-					MAP_HIP_TRY(hipMemcpyAsync(m->d_heavy_list.p + off, lists[c].data(), (size_t) cnt * 4, hipMemcpyHostToDevice, m->st));
-					ngm::CsArgs Hv = A;
-					Hv.read_list = m->d_heavy_list.p + off; Hv.log2_bits = classes[c].log2c; Hv.log2_slots = classes[c].log2s;
-					const size_t lds = ngm::cs_heavy_lds_bytes(Hv.lists_cap, Hv.q, Hv.log2_bits, Hv.log2_slots, classes[c].wide);
-					void *kargs[] = {(void *) &Hv};
-					MAP_HIP_TRY(hipLaunchKernel(classes[c].fn, dim3(cnt), dim3(classes[c].nt), kargs, lds, m->st));
-					off += cnt;
-				}
-				MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
-				yield();
-				MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
-				MAP_HIP_TRY(hipStreamSynchronize(m->st));   // (the lists live until here)
-				if (hipEventElapsedTime(&t_heavy[round], m->cev[2], m->cev[3]) == hipSuccess) m->cs_kernel_ms += t_heavy[round];
-			}
-			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 1b (heavy reads): %.2f ms for %u reads; pass 1c (32-bit counters, 8 192 slots): %.2f ms for %u reads; %u left for the exact kernels\n",
-					t_heavy[0], in_round[0], t_heavy[1], in_round[1], status[1]);
-		}
-		m->cs_queued_exact = status[1];
-		const uint32_t n_exact_lds = status[1];
-		uint32_t n_exact_global = 0;
-		auto dump_queue = [&](int pass, uint32_t cnt) {   // diagnostics (NGM_HIP_DUMP_OVF=file): index hits of the reads queued for `pass`
-			const char *fn = getenv("NGM_HIP_DUMP_OVF");
-			if (!fn || cnt == 0) return;
-			std::vector<uint32_t> hh(cnt);
-			if (hipMemcpy(hh.data(), m->d_ovf_hits.p, (size_t) cnt * 4, hipMemcpyDeviceToHost) != hipSuccess) return;
-			if (FILE *f = fopen(fn, "a")) { for (uint32_t x : hh) fprintf(f, "%d %u\n", pass, x); fclose(f); }
-		};
-		dump_queue(2, status[1]);
-		if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 1 (fast path): %.2f ms for %d reads, %u queued for the exact path\n", pass_ms[0], n, status[1]);
-		if (status[1] > 0) {
-			// pass 2 -- EXACT path, table in LDS, for the reads the fast path could not certify
-			const uint32_t no = status[1];
-			hold();
-			if (!bs) MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
-			MAP_HIP_TRY(hipMemsetAsync(m->d_status.p + 1, 0, 4, m->st));
-			ngm::CsArgs B = A;
-			B.log2_slots = bs ? std::min(m->cs_log2_slots, 13) : m->cs_log2_slots;
-			B.hit_cap = (uint32_t) ((1u << B.log2_slots) * 0.66f);
-			B.read_list = bs ? nullptr : m->d_ovf_read2.p;
-			MAP_HIP_TRY(hipEventRecord(m->cev[2], m->st));
-			hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactLds>, dim3(no), dim3(64), cs_lds_bytes(B, ngm::kCsExactLds), m->st, B);
-			MAP_HIP_TRY(hipGetLastError());
-			MAP_HIP_TRY(hipEventRecord(m->cev[3], m->st));
-			yield();
-			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipStreamSynchronize(m->st));
-			timed(2);
-		}
-		if (status[1] > 0) {
-			// pass 3 -- EXACT path with per-read tables in global memory (reads with more hits than LDS holds)
-			const uint32_t no = status[1];
-			n_exact_global = no;
-			dump_queue(3, no);
-			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 2 (exact, LDS table): %.2f ms for %u reads, %u queued for the global-memory tables\n", pass_ms[1], n_exact_lds, no);
-			std::vector<uint32_t> hits(no), lg(no);
-			std::vector<uint64_t> off(no);
-			MAP_HIP_TRY(hipMemcpy(hits.data(), m->d_ovf_hits.p, no * 4, hipMemcpyDeviceToHost));
-			uint64_t total_slots = 0;
-			for (uint32_t i = 0; i < no; ++i) {
-				uint32_t l = 4;
-				while ((1ull << l) < 2ull * hits[i]) ++l;
-				lg[i] = l;
-				off[i] = total_slots;
-				total_slots += 1ull << l;
-			}
-			if (m->d_gt_keys.reserve(total_slots) || m->d_gt_votes.reserve(total_slots) || m->d_ovf_off.reserve(no) || m->d_ovf_log2.reserve(no)) {
-				ngm::pipeline_set_error("out of device memory (overflow vote tables, %llu slots)", (unsigned long long) total_slots);
-				return -12;
-			}
-			hold();
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_off.p, off.data(), no * 8, hipMemcpyHostToDevice, m->st));
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_log2.p, lg.data(), no * 4, hipMemcpyHostToDevice, m->st));
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_ovf_read2.p, m->d_ovf_read.p, (size_t) no * 4, hipMemcpyDeviceToDevice, m->st));
-			ngm::CsArgs G = A;
-			G.read_list = m->d_ovf_read2.p;
-			G.ovf_table_off = m->d_ovf_off.p; G.ovf_log2 = m->d_ovf_log2.p; G.gtable_keys = m->d_gt_keys.p; G.gtable_votes = m->d_gt_votes.p;
-			MAP_HIP_TRY(hipEventRecord(m->cev[4], m->st));
-			// one workgroup per read (cs_global_kernel, cs_heavy_device.h); bisulfite runs keep the one-wave kernel (their lists come in chunks of variants)
-			static const int global_nt = getenv("NGM_HIP_CS_GLOBAL_THREADS") ? atoi(getenv("NGM_HIP_CS_GLOBAL_THREADS")) : 512;   // (64: the one-wave kernel of rounds 1-3)
-			if (G.bs || global_nt <= 64) hipLaunchKernelGGL(ngm::cs_kernel<ngm::kCsExactGlobal>, dim3(no), dim3(64), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
-			else if (global_nt >= 1024) hipLaunchKernelGGL(ngm::cs_global_kernel<1024>, dim3(no), dim3(1024), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
-			else if (global_nt >= 512) hipLaunchKernelGGL(ngm::cs_global_kernel<512>, dim3(no), dim3(512), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
-			else hipLaunchKernelGGL(ngm::cs_global_kernel<256>, dim3(no), dim3(256), cs_lds_bytes(G, ngm::kCsExactGlobal), m->st, G);
-			MAP_HIP_TRY(hipGetLastError());
-			MAP_HIP_TRY(hipEventRecord(m->cev[5], m->st));
-			yield();
-			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 16, hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipStreamSynchronize(m->st));
-			timed(4);
-			if (getenv("NGM_HIP_HOST_TIMING")) fprintf(stderr, "[ngm-hip] candidate search pass 3 (exact, global-memory tables): %.2f ms for %u reads\n", pass_ms[2], no);
-		}
-		if (status[0] == 0) {
-			// regions -> one dense candidate array in read order
-			hold();
-			size_t tmp_bytes = 0;
-			(void) rocprim::exclusive_scan(nullptr, tmp_bytes, m->d_cand_count.p, m->d_new_base.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), m->st);
-			if (m->d_scan_tmp.reserve(tmp_bytes + 16)) { ngm::pipeline_set_error("out of device memory (scan)"); return -12; }
-			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_cand_count.p, m->d_new_base.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), m->st));
-			hipLaunchKernelGGL(ngm::compact_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, m->st, n, m->d_cand_base.p, m->d_new_base.p, m->d_cand_count.p,
-					m->d_out_loc.p, m->d_out_sv.p, m->d_out_loc2.p, m->d_out_sv2.p);
-			MAP_HIP_TRY(hipGetLastError());
-			std::swap(m->d_out_loc, m->d_out_loc2); std::swap(m->d_out_sv, m->d_out_sv2); std::swap(m->d_cand_base, m->d_new_base);
-			yield();
-			m->last_cs = A;
-			m->cs_region_cap = cap;
-			m->n_reads = n;
-			std::vector<unsigned long long> ctr(ctr_words + 16);
-			MAP_HIP_TRY(hipMemcpyAsync(ctr.data(), m->d_counters.p, ctr.size() * 8, hipMemcpyDeviceToHost, m->st));
-			if (m->h_base.b.reserve(n) || m->h_count.b.reserve(n) || m->h_maxv.b.reserve(n)) { ngm::pipeline_set_error("out of pinned host memory"); return -12; }
-			// the host needs the number of candidates now (it sizes the score stage); the per-read arrays (12 bytes per read) only after the
-			// score stage (cs_host_arrays): an experiment lets them travel on a stream of their own under its kernels
-			uint32_t last[2] = {0, 0};
-			MAP_HIP_TRY(hipMemcpyAsync(&last[0], m->d_cand_base.p + (n - 1), 4, hipMemcpyDeviceToHost, m->st));
-			MAP_HIP_TRY(hipMemcpyAsync(&last[1], m->d_cand_count.p + (n - 1), 4, hipMemcpyDeviceToHost, m->st));
-			// (NGM_HIP_CS_COPY_SIDE_STREAM=1: measured on one box, three runs each -- 49.8 / 52.0 / 51.5 M reads/s with the side stream against
-			// 55.0 / 52.1 / 54.8 without: the copies are blit kernels either way, and a second stream only adds their scheduling: not the default)
-			static const bool side = getenv("NGM_HIP_CS_COPY_SIDE_STREAM") != nullptr;
-			hipStream_t cst = (side && m->st_copy && m->ev_cs_done && m->ev_cs_copied) ? m->st_copy : m->st;
-			if (cst != m->st) { MAP_HIP_TRY(hipEventRecord(m->ev_cs_done, m->st)); MAP_HIP_TRY(hipStreamWaitEvent(cst, m->ev_cs_done, 0)); }
-			MAP_HIP_TRY(hipMemcpyAsync(m->h_base.data(), m->d_cand_base.p, (size_t) n * 4, hipMemcpyDeviceToHost, cst));
-			MAP_HIP_TRY(hipMemcpyAsync(m->h_count.data(), m->d_cand_count.p, (size_t) n * 4, hipMemcpyDeviceToHost, cst));
-			MAP_HIP_TRY(hipMemcpyAsync(m->h_maxv.data(), m->d_max_votes.p, (size_t) n * 4, hipMemcpyDeviceToHost, cst));
-			if (cst != m->st) { MAP_HIP_TRY(hipEventRecord(m->ev_cs_copied, cst)); m->cs_copy_pending = true; }
-			MAP_HIP_TRY(hipStreamSynchronize(m->st));
-			m->n_cand = (uint64_t) last[0] + last[1];
-			{
-				// the 32-bit prefix sums wrap silently: cross-check the total against the 64-bit candidate counters
-				unsigned long long sum = 0;
-				for (int g = 0; g < ngm::kCsRegions; ++g) sum += ctr[(size_t) g * ngm::kCsCursorStride + 2];
-				if (sum != m->n_cand) { ngm::pipeline_set_error("%llu candidates in one batch of %d reads exceed the 32-bit candidate index: use smaller batches", sum, n); return -75; }
-			}
-			m->st_heavy += n_heavy; m->st_reads += (uint64_t) n; m->st_cands += m->n_cand; m->st_exact_lds += n_exact_lds; m->st_exact_global += n_exact_global;
-			m->cs_kmers = m->cs_hits = 0;
-			for (int g = 0; g < ngm::kCsRegions; ++g) { m->cs_kmers += ctr[(size_t) g * ngm::kCsCursorStride]; m->cs_hits += ctr[(size_t) g * ngm::kCsCursorStride + 1]; }
-			const unsigned long long *ph = ctr.data() + ctr_words;
-			if (A.phase_cycles)
-				fprintf(stderr, "[ngm-hip] cs fast path, 100 MHz ticks per read: lists %.1f sweep1 %.1f sweep2 %.1f candidates %.1f; %u of %d reads re-run by the exact path; kernels %.2f + %.2f + %.2f ms\n",
-						(double) ph[0] * 256 / n, (double) ph[1] * 256 / n, (double) ph[2] * 256 / n, (double) ph[3] * 256 / n, m->cs_queued_exact, n, pass_ms[0], pass_ms[1], pass_ms[2]);
-			if (A.phase_cycles && m->cs_canon)
-				fprintf(stderr, "[ngm-hip] cs canonical path, inside sweep 1: first lines arrived %.1f | chunk items %.1f | first-line votes %.1f | chunk votes %.1f; in front of the phases (resets, prefetch) %.1f\n",
-						(double) ph[4] * 256 / n, (double) ph[5] * 256 / n, (double) ph[6] * 256 / n, (double) ph[7] * 256 / n, (double) ph[8] * 256 / n);
-			return 0;
-		}
-		cap *= 4;  // candidate buffer too small: grow and redo the batch
-	}
-	ngm::pipeline_set_error("candidate buffer overflow persists");
-	return -75;
-}
-
-// h_base / h_count / h_maxv of the last search are complete (see the end of run_cs)
-int cs_host_arrays(ngm_mapper *m) {
-	if (!m->cs_copy_pending) return 0;
-	MAP_HIP_TRY(hipEventSynchronize(m->ev_cs_copied));
-	m->cs_copy_pending = false;
-	return 0;
-}
 
 int upload_reads(ngm_mapper *m, int n, const char *reads) {
 	const size_t bytes = (size_t) n * m->prm.qry_max_len;
@@ -825,124 +134,15 @@ ngm_mapper *ngm_mapper_create(const ngm_ref *ref, const ngm_mapper_params *p) {
 	{
 		int lo = 0, hi = 0;
 		(void) hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = greatest priority
-		// (the order replay's stream: greatest priority by default -- persistent search workgroups hold every CU until their launch ends, and
-		// the replay gets in as they leave; NGM_HIP_ORDER_PRIORITY=low / normal: experiments on workloads whose replays are long)
-		int prio = hi;
-		if (const char *e = getenv("NGM_HIP_ORDER_PRIORITY")) prio = !strcmp(e, "low") ? lo : !strcmp(e, "normal") ? (lo + hi) / 2 : hi;
-		if (hipStreamCreateWithPriority(&m->st_hi, hipStreamNonBlocking, prio) != hipSuccess) m->st_hi = nullptr;
-		if (hipStreamCreateWithFlags(&m->st_copy, hipStreamNonBlocking) != hipSuccess) m->st_copy = nullptr;
-		for (auto &e : m->turn_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-		if (hipEventCreateWithFlags(&m->ev_cs_done, hipEventDisableTiming) != hipSuccess) m->ev_cs_done = nullptr;
-		if (hipEventCreateWithFlags(&m->ev_cs_copied, hipEventDisableTiming) != hipSuccess) m->ev_cs_copied = nullptr;
+		// (the order replay's stream: greatest priority -- persistent search workgroups hold every CU until their launch ends, and the replay
+		// gets in as they leave)
+		if (hipStreamCreateWithPriority(&m->st_hi, hipStreamNonBlocking, hi) != hipSuccess) m->st_hi = nullptr;
 	}
 	m->max_kfreq = p->max_kfreq > 0 ? p->max_kfreq : ref->auto_max_kfreq;
 	for (auto &e : m->ev) (void) hipEventCreate(&e);
 	for (auto &e : m->cev) (void) hipEventCreate(&e);
 	for (auto &e : m->oev) (void) hipEventCreate(&e);
-	// fast-path geometry from the expected hits per read H = 2 (q - k) lists x average list length:
-	// bit planes >= 12 H bits (6-8 % of the single background hits collide and survive the filter),
-	// small exact table for the survivors + the real signal with headroom
-	{
-		const double avg_list = (double) ref->n_entries / (double) (1ull << (2 * ref->prm.kmer));
-		const double hexp = std::max(64.0, 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer) * avg_list);
-		m->cs_hexp = hexp;
-		int lb = 12;
-		while ((double) (1u << lb) < 12.0 * hexp && lb < 17) ++lb;
-		m->cs_log2_bits = lb;
-		// plane of P bits (any multiple of 2048 from 12 bits per expected hit up to the next power of two) and table of
-		// 2^ls slots, 3/4 of which may fill: entries = hits that find their bit already set -- H^2 / (2 P) by collision
-		// -- plus the real repeats, with headroom.  Take the pair that needs the least LDS.
-		size_t best_bytes = ~(size_t) 0;
-		const double p_lo = std::min(131072.0, std::max(4096.0, ceil(12.0 * hexp / 2048.0) * 2048.0)), p_hi = (double) (1u << lb);
-		for (double P = p_lo; P <= p_hi; P += 2048.0) {
-			int ls = 8;
-			while (0.75 * (double) (1u << ls) < 1.3 * hexp * hexp / (2.0 * P) + 0.02 * hexp + 100.0 && ls < 12) ++ls;
-			const size_t bytes = (size_t) P / 8 + ((size_t) 8 << ls) + ((size_t) 3 << ls);  // plane + keys/votes + queue
-			if (bytes < best_bytes) { best_bytes = bytes; m->cs_plane_bits = (uint32_t) P; m->cs_log2_small = ls; }
-		}
-		// expected 8-hit segments per read: every list contributes its hits / 8 plus, on average, 7/16 of a segment of slack
-		const double segs = hexp / 8.0 + 0.44 * 2.0 * std::max(1, p->qry_max_len - ref->prm.kmer);
-		m->cs_fast_items = segs * 1.10 > 64.0 * ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;
-		if (const char *e = getenv("NGM_HIP_CS_FAST_ITEMS")) m->cs_fast_items = atoi(e) > ngm::kCsFastItemsShort ? ngm::kCsFastItemsLong : ngm::kCsFastItemsShort;  // tests
-		const uint32_t plane_untrimmed = m->cs_plane_bits;
-		m->cs_plane_bits0 = plane_untrimmed;
-		// The kernel is bound by reads in flight per CU, and those by LDS, which gfx950 hands out in granules of
-		// 1 280 bytes (160 KB / 128: hipOccupancyMaxActiveBlocksPerMultiprocessor reports 9 workgroups of 16 328 bytes per CU and 10
-		// of 15 360).  The plane is sized generously (12 bits per expected hit): when giving up at most a fifth of it (never below
-		// 10 bits per hit -- the spurious table entries H^2 / 2P stay far from the table's capacity) lets one more read in, do it.
-		{
-			ngm::CsArgs G{};
-			G.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); G.q = p->qry_max_len; G.log2_slots = m->cs_log2_small;
-			G.fast_items = m->cs_fast_items; G.items16 = (G.lists_cap <= 512) ? 1 : 0; G.plane_bits = m->cs_plane_bits;
-			const size_t granule = 1280, lds = 160 * 1024;
-			const size_t bytes = (cs_lds_bytes(G, ngm::kCsFast) + granule - 1) / granule * granule;
-			const size_t per_cu = lds / std::max<size_t>(bytes, 1);
-			if (per_cu >= 1 && per_cu < 10) {
-				const size_t target = lds / (per_cu + 1) / granule * granule;  // bytes that would let one more read in
-				const size_t have = cs_lds_bytes(G, ngm::kCsFast);
-				if (have > target) {
-					const uint32_t cut_bits = (uint32_t) (((have - target) * 8 + 31) / 32 * 32);
-					if (cut_bits <= m->cs_plane_bits / 5 && (double) (m->cs_plane_bits - cut_bits) >= 10.0 * hexp) m->cs_plane_bits -= cut_bits;
-				}
-			}
-		}
-	}
-	// which index layout the fast path gathers from: canonical pair buckets (odd k, up to 256 k-mers per read, k-mer pairs in
-	// use shorter than 1 000 hits: the chunk items are 16-bit) unless NGM_HIP_CS_PLAIN_BUCKETS asks for one bucket per k-mer
-	{
-		const int n_kmers = std::max(1, p->qry_max_len - ref->prm.kmer + 1);
-		const bool canon_ok = (ref->prm.kmer & 1) && n_kmers <= 256 && m->max_kfreq <= 1000 && !getenv("NGM_HIP_CS_PLAIN_BUCKETS") && !p->bs_mapping;
-		if (!p->bs_mapping && ngm_ref_ensure_buckets(ref, canon_ok ? 1 : 0) != 0) { ngm_mapper_destroy(m); return nullptr; }   // (bisulfite mapping: exact paths only, no buckets)
-		if (canon_ok) {
-			const int glog = std::min(ref->cbucket_log2_words, 5) - 2;
-			int shape = 1;
-			while (shape < 3 && (n_kmers > kCanonT[shape] * 64 || n_kmers > kCanonR1[shape] * ((kCanonT[shape] * 64) >> glog))) ++shape;
-			if (const char *e = getenv("NGM_HIP_CS_CANON_SHAPE")) shape = std::max(shape, std::min(3, atoi(e)));  // tests: a larger shape than needed
-			m->cs_canon = shape;
-			if (const char *e = getenv("NGM_HIP_CS_CANON_CH")) m->cs_canon_ch = atoi(e);
-			if (const char *e = getenv("NGM_HIP_CS_CANON_WPE")) m->cs_canon_wpe = atoi(e);
-			// the canonical kernel indexes its plane with the low bits of the bin: a power of two of bits, at least 10 per expected hit
-			// (150 bp reads at GRCh38 size: 65 536 bits; with the rest of a read's LDS 16 KB -> 13 granules of 1 280 bytes, nine reads per CU)
-			uint32_t pb = 4096;
-			while ((double) pb < 10.0 * m->cs_hexp && pb < 131072u) pb <<= 1;
-			m->cs_plane_bits = pb;
-		}
-	}
-	ngm::CsArgs A{}; A.lists_cap = 2 * std::max(1, p->qry_max_len - ref->prm.kmer + 1); A.q = p->qry_max_len;
-	A.log2_slots = m->cs_log2_slots;
-	if (cs_lds_bytes(A, ngm::kCsExactLds) > 158 * 1024) { m->cs_log2_slots = 13; A.log2_slots = 13; } A.log2_bits = 17; A.plane_bits = 131072;
-	A.fast_items = ngm::kCsFastItemsLong;
-	A.items16 = 0;
-	const int log2_exact = A.log2_slots;
-	A.log2_slots = 12;  // the largest table the fast path picks (above)
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsShort, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast_kernel<ngm::kCsFastItemsLong, uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast));
-#define NGM_CS_ATTR_T(T) \
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsShort / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast)); \
-	(void) hipFuncSetAttribute((const void *) ngm::cs_fast2_kernel<T, ngm::kCsFastItemsLong / T, uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsFast))
-	NGM_CS_ATTR_T(2); NGM_CS_ATTR_T(3); NGM_CS_ATTR_T(4);
-#undef NGM_CS_ATTR_T
-	for (int shape = 1; shape <= 3; ++shape) for (int ch : {0, 1, 3}) for (int wpe : {5, 6, 7, 8}) for (int bs : {0, 2})
-		(void) hipFuncSetAttribute(cs_canon_fn(shape, ch, wpe, bs), hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_canon_lds_bytes(A, shape));
-	// three waves per read for the 768-segment size (150 bp reads), four for the 1 536-segment one (250 bp: 12.3 instead of 14.7 ms
-	// per 524 288 reads -- with twice the work items per read the fourth wave pays for the seventh-of-a-CU it costs)
-	m->cs_waves = m->cs_fast_items == ngm::kCsFastItemsLong ? 4 : 3;
-	if (const char *e = getenv("NGM_HIP_CS_WAVES")) m->cs_waves = std::min(4, std::max(1, atoi(e)));
-	A.log2_slots = log2_exact;
-	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy2_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_heavy2_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);  // per device
-	(void) hipFuncSetAttribute((const void *) ngm::cs_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-	if (p->bs_mapping) { A.bs = 1; A.lists_cap = 2 * ngm::kCsBsChunk; A.log2_slots = std::min(A.log2_slots, 13); }
-	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactLds>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactLds));
-	(void) hipFuncSetAttribute((const void *) ngm::cs_kernel<ngm::kCsExactGlobal>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) cs_lds_bytes(A, ngm::kCsExactGlobal));
-	(void) hipGetLastError();  // a refused attribute shows up as a launch failure where it matters, not as a stale error at the next check
+	if (ngm::cs_configure(m, p) != 0) { ngm_mapper_destroy(m); return nullptr; }
 	return m;
 }
 
@@ -955,19 +155,8 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	(void) hipStreamSynchronize(m->st);
 	ngm_bgzf_destroy(m->bz);
 	if (m->st_hi) { (void) hipStreamSynchronize(m->st_hi); (void) hipStreamDestroy(m->st_hi); }
-	if (m->st_copy) { (void) hipStreamSynchronize(m->st_copy); (void) hipStreamDestroy(m->st_copy); }
-	// (no other instance may be left waiting for an event of this one: its kernels have finished -- the stream was synchronised above)
-	for (int k2 = 0; k2 < 2; ++k2) {
-		StageChain &c = g_chain[(unsigned) m->ref->device & 15u][k2];
-		std::lock_guard<std::mutex> lk(c.mu);
-		for (auto &e : m->turn_ev) if (e && c.last == e) c.last = nullptr;
-	}
-	for (auto &e : m->turn_ev) if (e) (void) hipEventDestroy(e);
-	if (m->ev_cs_done) (void) hipEventDestroy(m->ev_cs_done);
-	if (m->ev_cs_copied) (void) hipEventDestroy(m->ev_cs_copied);
-	m->d_reads.release(); m->d_read_len.release(); m->d_cand_base.release(); m->d_cand_count.release(); m->d_out_loc.release(); m->d_out_sv.release();
-	m->d_status.release(); m->d_ovf_read.release(); m->d_ovf_read2.release(); m->d_ovf_hits.release(); m->d_ovf_log2.release(); m->d_ovf_off.release(); m->d_gt_keys.release();
-	m->d_gt_votes.release(); m->d_heavy_list.release(); m->d_heavy_ctr.release(); m->d_max_votes.release(); m->d_max_both.release(); m->d_scores.release(); m->d_best.release(); m->d_total.release(); m->d_pair_read.release();
+	ngm::cs_release(m);
+	m->d_reads.release(); m->d_scores.release(); m->d_best.release(); m->d_pair_read.release();
 	m->d_winner.release(); m->d_a_read.release(); m->d_a_loc.release(); m->d_a_sv.release(); m->d_mapq.release(); m->d_nbest.release();
 	m->d_records.release(); m->d_runs.release(); m->d_runs_c.release();
 	m->d_pair_info.release(); m->p_pair_info.release(); m->d_sam_contig_start.release();
@@ -977,7 +166,6 @@ void ngm_mapper_destroy(ngm_mapper *m) {
 	for (auto &e : m->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->cev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : m->oev) if (e) (void) hipEventDestroy(e);
-	m->d_counters.release(); m->d_heavy_diag.release(); m->d_order_list.release(); m->d_cand_rank.release(); m->d_order_scratch.release(); m->d_order_info.release(); m->p_order_info.release(); m->d_order_big.release(); m->d_order_gt.release(); m->d_order_log2.release(); m->d_order_off.release(); m->p_rank.release(); m->h_base.b.release(); m->h_count.b.release(); m->h_maxv.b.release(); m->d_out_loc2.release(); m->d_out_sv2.release(); m->d_new_base.release(); m->d_scan_tmp.release();
 	m->p_winner.release(); m->p_loc.release(); m->p_sv.release(); m->p_mapq.release(); m->p_nbest.release(); m->p_rec.release();
 	m->p_best.release(); m->p_scores.release(); m->p_runs.release();
 	m->d_str.release(); m->d_cigout.release(); m->p_cigout.release(); m->p_str.release();
@@ -1024,258 +212,6 @@ int ngm_mapper_cs_fetch(ngm_mapper *m, uint64_t *loc, uint8_t *strand, float *vo
 // the SAM stage of a call (ngm_mapper_map_sam): inputs the records need beyond the reads, where the text goes
 struct SamCall { const char *quals; const char *names; size_t names_bytes; const ngm::SamMeta *meta; char *out; size_t out_cap; uint64_t *stats; long long text_bytes; float kernel_ms; };
 static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads_ext, ngm_hit *hits, char *cigars, char *mds, bool paired, SamCall *sam = nullptr);
-
-// Reference order of the candidates of the listed reads (cs_order_kernel): h_rank[c] for every candidate c of those
-// reads, kCsOrderUnknown where it could not be determined.  Only called for reads where the order decides something.
-static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np);
-static int candidate_order_wait(ngm_mapper *m, uint32_t **h_rank) {
-	static const bool order_on_main = getenv("NGM_HIP_ORDER_ON_MAIN_STREAM") != nullptr;
-	if (int rc = candidate_order_finish(m, (m->st_hi && !order_on_main) ? m->st_hi : m->st, m->n_cand)) return rc;
-	*h_rank = m->p_rank.p;
-	return 0;
-}
-// After the LDS replay: wait for it, account for the reads it left to the exact kernel (more hits than its time line, more repeated
-// bins than its table: CsArgs::order_info) and replay those exactly in global memory.  No read keeps an undetermined order silently.
-static int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
-	static const bool trace = getenv("NGM_HIP_ORDER_TRACE") != nullptr;   // (diagnostics: where the time of a replay goes, stage by stage)
-	const auto t_trace = std::chrono::steady_clock::now();
-	auto tr = [&](const char *what, unsigned long long a = 0, unsigned long long b = 0, unsigned long long c = 0) {
-		if (trace) fprintf(stderr, "[ngm-hip] order trace %p +%.1f ms: %s %llu %llu %llu\n", (void *) m, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_trace).count(), what, a, b, c);
-	};
-	tr("wait for the LDS replay", m->order_pending.size());
-	MAP_HIP_TRY(hipStreamSynchronize(ost));
-	tr("LDS replay done");
-	{ float t = 0; if (hipEventElapsedTime(&t, m->oev[0], m->oev[1]) == hipSuccess) m->order_ms += t; }
-	const uint32_t nl = (uint32_t) m->order_pending.size();
-	m->st_order_reads += nl;
-	std::vector<uint32_t> big;
-	for (uint32_t i = 0; i < nl; ++i) if (m->p_order_info.p[2 * i + 1] & 0xFFu) big.push_back(i);
-	if (const char *hf = getenv("NGM_HIP_ORDER_HIST")) {   // diagnostics: hits / tracked bins / outcome of every replayed read
-		if (FILE *f = fopen(hf, "a")) { for (uint32_t i = 0; i < nl; ++i) fprintf(f, "%u %u %u\n", m->p_order_info.p[2 * i], m->p_order_info.p[2 * i + 1] & 0xFFu, m->p_order_info.p[2 * i + 1] >> 8); fclose(f); }
-	}
-	m->st_order_big += big.size();
-	const std::vector<uint32_t> beyond_lds = big;
-	// The reads beyond the LDS replay: hits dealt into buckets (cs_order_bucket_kernel -- no table in global memory); what that kernel
-	// leaves (bisulfite runs, a bucket of more than 256 hits) goes on to the replay with a table in global memory below.
-	static const bool buckets_on = getenv("NGM_HIP_ORDER_NO_BUCKETS") == nullptr;
-	if (!big.empty() && buckets_on && !m->order_args.bs && ngm::cs_order_tau(m->order_args.lists_cap) <= ngm::kCsOrderBucketMaxTau) {
-		const uint32_t nb = (uint32_t) big.size();
-		std::sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { const uint32_t ha = m->p_order_info.p[2 * a], hb = m->p_order_info.p[2 * b]; return ha != hb ? ha > hb : a < b; });   // the longest first: they end the launch
-		std::vector<uint32_t> reads(nb);
-		for (uint32_t j = 0; j < nb; ++j) reads[j] = m->order_pending[big[j]];
-		ngm::CsArgs B = m->order_args;
-		B.order_info = nullptr; B.order_scratch = nullptr; B.order_max_hits = 0;
-		B.order_gcap = 0;
-		const size_t coarse_cap = ngm::cs_heavy2_coarse_cap(B.lists_cap, B.max_kfreq);
-		const size_t lds = ngm::cs_order_bucket_lds_bytes(B.lists_cap, B.q, coarse_cap);
-		static const bool two_per_cu = getenv("NGM_HIP_ORDER_BUCKET_W8") != nullptr;   // (experiments)
-		auto kern = two_per_cu ? ngm::cs_order_bucket_kernel_w8<ngm::kCsOrderBucketThreads> : ngm::cs_order_bucket_kernel<ngm::kCsOrderBucketThreads>;
-		int per_cu = 0, cus = 0;
-		if (lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, ngm::kCsOrderBucketThreads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->ref->device) != hipSuccess || cus < 1) cus = 256;
-		// ONE workgroup per CU unless told otherwise: its eight waves leave the CU's other wave slots and LDS to the search kernels of the other
-		// mapper instances, which run at the same time (measured at 3.1 Gbp, four instances: 2.63 M reads/s with one, 2.54 M with the two that fit)
-		static const int per_cu_env = getenv("NGM_HIP_ORDER_BUCKET_PER_CU") ? atoi(getenv("NGM_HIP_ORDER_BUCKET_PER_CU")) : 1;
-		if (per_cu_env > 0) per_cu = std::min(per_cu, per_cu_env);
-		// elements of a workgroup's slice: the most hits a read of this run can have (a list per k-mer and strand, none longer than max_kfreq) --
-		// not the most of THIS list: every new maximum would be a hipFree + hipMalloc, two device-wide synchronisations, in the middle of the run
-		uint64_t cap = std::min<uint64_t>(ngm::kCsOrderBucketMaxHits, (((uint64_t) (B.lists_cap / 2) * (uint64_t) std::max(B.max_kfreq, 1)) + 63) & ~63ull);
-		uint32_t grid = (uint32_t) per_cu * (uint32_t) cus;
-		{
-			size_t free_b = 0, total_b = 0;
-			uint64_t room = 4ull << 30;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) room = std::min<uint64_t>(room, ((uint64_t) free_b + (uint64_t) m->d_order_gt.cap * 4) / 2);
-			cap = std::min<uint64_t>(cap, room / 8);                       // (a read with more hits than that goes on to the table kernel)
-			grid = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(grid, room / 8 / std::max<uint64_t>(cap, 1)));
-		}
-		const size_t slice_words = (size_t) grid * cap * 2;
-		grid = std::min<uint32_t>(grid, nb);
-		tr("bucket stage: reads, grid, slice", nb, grid, cap);
-		bool ok = cap >= 64 && !m->d_order_gt.reserve(slice_words) && !m->d_order_big.reserve(nb) && !m->d_order_log2.reserve(nb + 1) && !m->d_order_info.reserve(2 * (size_t) nb);
-		if (ok) {
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_big.p, reads.data(), (size_t) nb * 4, hipMemcpyHostToDevice, ost));
-			MAP_HIP_TRY(hipMemsetAsync(m->d_order_log2.p, 0, 4, ost));
-			MAP_HIP_TRY(hipMemsetAsync(m->d_order_info.p, 0xFF, 2 * (size_t) nb * 4, ost));
-			unsigned long long *diag = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + (size_t) ngm::kCsRegions * ngm::kCsCursorStride + 8 : nullptr;
-			if (diag) MAP_HIP_TRY(hipMemsetAsync(diag, 0, 16 * 8, ost));
-			B.read_list = m->d_order_big.p;
-			MAP_HIP_TRY(hipEventRecord(m->oev[2], ost));
-			hipLaunchKernelGGL(kern, dim3(grid), dim3(ngm::kCsOrderBucketThreads), lds, ost, B, nb, m->d_order_log2.p, (uint2 *) m->d_order_gt.p, (uint32_t) cap, (uint32_t) coarse_cap,
-					(const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p, m->d_order_info.p, diag);
-			MAP_HIP_TRY(hipGetLastError());
-			MAP_HIP_TRY(hipEventRecord(m->oev[3], ost));
-			tr("bucket kernel launched");
-			std::vector<uint32_t> binfo(2 * (size_t) nb);
-			MAP_HIP_TRY(hipMemcpyAsync(binfo.data(), m->d_order_info.p, binfo.size() * 4, hipMemcpyDeviceToHost, ost));
-			MAP_HIP_TRY(hipStreamSynchronize(ost));
-			{ float t = 0; if (hipEventElapsedTime(&t, m->oev[2], m->oev[3]) == hipSuccess) m->order_ms += t; }
-			tr("bucket kernel done");
-			if (diag) {
-				unsigned long long ph[16];
-				MAP_HIP_TRY(hipMemcpy(ph, diag, sizeof(ph), hipMemcpyDeviceToHost));
-				const double ns = (double) std::max(1ull, ph[8]);
-				fprintf(stderr, "[ngm-hip] order replay through buckets (%u reads, grid %u, %d per CU, slice %llu hits), us per sampled read: lists %.1f | count %.1f | scan + scatter %.1f | v + tau %.1f (wave 0: %.0f windows, bounds + loads issued %.1f, counted + stored %.1f) | table of M %.1f | candidates %.1f; hits %.0f, candidates %.0f per read; %llu left to the table kernel\n",
-						nb, grid, per_cu, (unsigned long long) cap, ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[14] / ns, ph[12] / ns / 100.0, ph[13] / ns / 100.0, ph[4] / ns / 100.0, ph[5] / ns / 100.0, ph[9] / ns, ph[10] / ns, ph[11]);
-			}
-			std::vector<uint32_t> left;
-			for (uint32_t j = 0; j < nb; ++j) if (binfo[2 * j + 1] != 0u) left.push_back(big[j]);
-			std::sort(left.begin(), left.end());
-			m->st_order_table += left.size();
-			big.swap(left);
-		} else m->st_order_table += big.size();   // (no room for the slices: all of them to the table kernel)
-	}
-	if (!big.empty() && (!buckets_on || m->order_args.bs || ngm::cs_order_tau(m->order_args.lists_cap) > ngm::kCsOrderBucketMaxTau)) m->st_order_table += big.size();
-	if (!big.empty()) {
-		// exact replay in global memory (cs_order_kernel<true>): per read a table of 2^l >= 2 (hits + candidates) slots x 5 words and a
-		// time line of `hits` words; launches of as many reads as fit a scratch pool of 8 GB
-		const uint32_t nb = (uint32_t) big.size();
-		std::vector<uint32_t> reads(nb), lg(nb);
-		std::vector<uint64_t> off(nb), words(nb);
-		for (uint32_t j = 0; j < nb; ++j) {
-			const uint32_t i = big[j], rd = m->order_pending[i];
-			const uint64_t hits = m->p_order_info.p[2 * i], want = 2ull * (hits + m->h_count[rd]);
-			uint32_t l = 11;
-			while ((1ull << l) < want && l < 30) ++l;
-			reads[j] = rd; lg[j] = l;
-			words[j] = (6ull << l) + 2 * (hits + 64) + 64;   // table (5 words per slot), time line, hit times by (slot, strand), the slots in use
-		}
-		if (m->d_order_big.reserve(nb) || m->d_order_log2.reserve(nb) || m->d_order_off.reserve(nb)) { ngm::pipeline_set_error("out of device memory (exact candidate order)"); return -12; }
-		ngm::CsArgs G = m->order_args;
-		G.order_info = nullptr; G.order_scratch = nullptr; G.order_max_hits = 0;
-		G.order_gcap = G.bs ? 0u : ngm::kCsOrderStage;   // (cs_order_kernel<true>: staging entries per wave)
-		G.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + (size_t) ngm::kCsRegions * ngm::kCsCursorStride : nullptr;   // diagnostics: phases of every 64th workgroup
-		if (G.phase_cycles) MAP_HIP_TRY(hipMemsetAsync(G.phase_cycles + 8, 0, 12 * 8, ost));
-		const size_t lds = ((size_t) G.lists_cap * 4 + 4 + (G.q + 3) / 4 + 2048 + ngm::cs_order_tau(G.lists_cap) + (size_t) (ngm::kCsOrderThreadsGlobal / 64) * G.order_gcap + (G.bs ? (size_t) G.q + 1 + G.lists_cap / 4 + 1 : 0)) * 4;
-		// (8 GB per launch: a read with 50 000 hits takes 2.6 MB of table and time line, and with the 1.5 GB pool of the first version the
-		// 5 500 such reads of a heavy-tailed batch went through ten launches of ~570 workgroups each -- two per CU, 118 ms of waiting per batch)
-		// (the pool never asks for more than half of what the device has free, a read that needs more than the pool -- or a pool
-		// that cannot be had -- keeps an UNDETERMINED order, which the run reports (st_order_unknown) instead of dying: ties then resolve by position)
-		uint64_t pool_words = 2048ull << 20;
-		{
-			size_t free_b = 0, total_b = 0;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) pool_words = std::max<uint64_t>(std::min<uint64_t>(pool_words, ((uint64_t) free_b + (uint64_t) m->d_order_gt.cap * 4) / 8), 1ull << 20);
-		}
-		for (uint32_t j0 = 0; j0 < nb;) {
-			if (words[j0] > pool_words) { ++j0; continue; }   // (its candidates keep kCsOrderUnknown from the LDS replay's give-up)
-			uint64_t total = 0;
-			uint32_t j1 = j0;
-			while (j1 < nb && total + words[j1] <= pool_words) { off[j1] = total; total += words[j1]; ++j1; }
-			if (m->d_order_gt.reserve(total)) {
-				if (pool_words > (1ull << 22)) { pool_words /= 2; continue; }   // a smaller pool, more launches
-				break;                                                        // no memory at all: the remaining reads stay undetermined
-			}
-			tr("table kernel: reads, words", j1 - j0, total, pool_words);
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_big.p + j0, reads.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, ost));
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_log2.p + j0, lg.data() + j0, (size_t) (j1 - j0) * 4, hipMemcpyHostToDevice, ost));
-			MAP_HIP_TRY(hipMemcpyAsync(m->d_order_off.p + j0, off.data() + j0, (size_t) (j1 - j0) * 8, hipMemcpyHostToDevice, ost));
-			G.read_list = m->d_order_big.p + j0; G.ovf_log2 = m->d_order_log2.p + j0; G.ovf_table_off = m->d_order_off.p + j0; G.gtable_keys = m->d_order_gt.p;
-			MAP_HIP_TRY(hipEventRecord(m->oev[2], ost));
-			hipLaunchKernelGGL(ngm::cs_order_kernel<true>, dim3(j1 - j0), dim3(ngm::kCsOrderThreadsGlobal), lds, ost, G, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
-			MAP_HIP_TRY(hipGetLastError());
-			MAP_HIP_TRY(hipEventRecord(m->oev[3], ost));
-			MAP_HIP_TRY(hipStreamSynchronize(ost));   // (reads, lg, off of this launch are consumed; the pool is reused by the next one)
-			{ float t = 0; if (hipEventElapsedTime(&t, m->oev[2], m->oev[3]) == hipSuccess) m->order_ms += t; }
-			j0 = j1;
-		}
-		if (G.phase_cycles) {
-			MAP_HIP_TRY(hipStreamSynchronize(ost));
-			unsigned long long ph[12];
-			MAP_HIP_TRY(hipMemcpy(ph, G.phase_cycles + 8, sizeof(ph), hipMemcpyDeviceToHost));
-			const double ns = (double) std::max(1ull, ph[4]);
-			fprintf(stderr, "[ngm-hip] exact order replay in global memory (%u reads), us per sampled read: lists %.1f | sweep A %.1f | sweep B %.1f | times + tau + entering %.1f; hits %.0f, slots in use %.0f per read; workgroups start to end %.1f us on average, the slowest %.1f us\n",
-					nb, ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[6] / ns, ph[7] / ns, (double) (ph[5] >> 8) / 100.0 / std::max(1u, nb), ph[8] / 100.0);
-		}
-	}
-	if (!beyond_lds.empty()) {
-		tr("ranks");
-		MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
-		MAP_HIP_TRY(hipStreamSynchronize(ost));
-		tr("done");
-		for (uint32_t i : beyond_lds) {
-			const uint32_t rd = m->order_pending[i], b = m->h_base[rd], c = m->h_count[rd];
-			bool unknown = false;
-			for (uint32_t x = 0; x < c && !unknown; ++x) unknown = m->p_rank.p[b + x] == ngm::kCsOrderUnknown;
-			m->st_order_unknown += unknown ? 1 : 0;
-		}
-	}
-	m->order_pending.clear();
-	return 0;
-}
-// wait = false: only enqueue (the list must stay alive until candidate_order_wait)
-static int candidate_order(ngm_mapper *m, const std::vector<uint32_t> &list, uint64_t np, uint32_t **h_rank, bool wait = true) {
-	const uint32_t nl = (uint32_t) list.size();
-	if (m->prm.slam_seq & 4) {
-		// the weighted SLAM-seq search replays the votes in the reference's order anyway: its candidates leave in rList order
-		if (m->p_rank.reserve(np + 1)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
-		for (uint32_t rd : list) { const uint32_t b = m->h_base[rd], c = m->h_count[rd]; for (uint32_t x = 0; x < c; ++x) m->p_rank.p[b + x] = x; }
-		m->st_order_reads += nl;
-		m->order_pending.clear();
-		*h_rank = m->p_rank.p;
-		(void) wait;
-		return 0;
-	}
-	static const bool order_on_main = getenv("NGM_HIP_ORDER_ON_MAIN_STREAM") != nullptr;  // diagnostics
-	hipStream_t ost = (m->st_hi && !order_on_main) ? m->st_hi : m->st;  // everything this depends on has been synchronised by the caller
-	const auto t_begin = std::chrono::steady_clock::now();
-	if (m->d_order_list.reserve(nl) || m->d_cand_rank.reserve(np + 1) || m->p_rank.reserve(np + 1) || m->d_order_info.reserve(2 * (size_t) nl) || m->p_order_info.reserve(2 * (size_t) nl)) { ngm::pipeline_set_error("out of memory (candidate order)"); return -12; }
-	m->order_pending = list;
-	MAP_HIP_TRY(hipMemcpyAsync(m->d_order_list.p, list.data(), (size_t) nl * 4, hipMemcpyHostToDevice, ost));
-	ngm::CsArgs A = m->last_cs;
-	A.read_list = m->d_order_list.p;
-	A.cand_base = m->d_cand_base.p; A.cand_count = m->d_cand_count.p;
-	A.counters = nullptr;
-	const size_t ctr_words_o = (size_t) ngm::kCsRegions * ngm::kCsCursorStride;
-	A.phase_cycles = getenv("NGM_HIP_CS_PHASES") ? m->d_counters.p + ctr_words_o : nullptr;
-	if (A.phase_cycles) MAP_HIP_TRY(hipMemsetAsync(A.phase_cycles + 8, 0, 12 * 8, ost));
-	// the time line takes what is left of 80 KB of LDS (reads with more hits walk a slice of global memory, ~10 x slower): the
-	// size that lets TWO workgroups share a CU: measured on MI355X, this kernel with 88 KB of LDS has 26
-	// workgroups in flight instead of 232 (NGM_HIP_CS_PHASES=1 prints the summed workgroup time; a plain spinning kernel of the
-	// same LDS size does reach 232, profiles/tools/lds_occupancy_calib.hip) -- 1.7 s instead of 0.1 s for config 5's 256 k tied reads
-	static const size_t lds_budget_kb = getenv("NGM_HIP_ORDER_LDS_KB") ? (size_t) atoi(getenv("NGM_HIP_ORDER_LDS_KB")) : 80;  // (tuning)
-	const size_t lds_budget = lds_budget_kb * 1024;
-	if (A.bs) A.lists_cap = 2 * 3072;   // bisulfite mapping: the lists of all k-mer variants of a read (more: that read keeps the position order)
-	const size_t lds_fixed = ((size_t) A.lists_cap * 3 + 2 + (A.q + 3) / 4 + 2048 + ngm::cs_order_tau(A.lists_cap) + ((size_t) 5 << ngm::kCsOrderLog2Slots) + (A.bs ? (size_t) A.q + 1 + A.lists_cap / 4 + 1 : 0)) * 4;
-	// (two arrays of that many entries: the time line and the hit times sorted by bin and strand)
-	const size_t hits_room = lds_fixed + 8 * (size_t) ngm::kCsOrderMaxHits < lds_budget ? (lds_budget - 64 - lds_fixed) / 8 : (size_t) ngm::kCsOrderMaxHits;
-	A.order_max_hits = (uint32_t) std::max<size_t>(ngm::kCsOrderMaxHits, std::min<size_t>(hits_room, 65535));  // (all of the budget: two workgroups per CU either way)
-	const size_t lds = lds_fixed + (size_t) A.order_max_hits * 8;
-	// reads with more hits than the LDS time line holds use a slice of a global scratch: launches of at most 4096 reads
-	constexpr uint32_t kChunk = 4096, kGcap = 49152;
-	// reads with more hits than the LDS time line holds: to the bucket kernel (cs_order_bucket_kernel) -- the LDS replay with its time line in a
-	// slice of global memory is what bisulfite runs (no bucket kernel) and NGM_HIP_ORDER_LDS_BIG=1 / NGM_HIP_ORDER_NO_BUCKETS=1 still use
-	// (measured at 3.1 Gbp, half of the reads from repeats: 0.745 M reads/s without it, 0.669 M with it)
-	static const bool lds_big_env = getenv("NGM_HIP_ORDER_LDS_BIG") != nullptr || getenv("NGM_HIP_ORDER_NO_BUCKETS") != nullptr;
-	const bool no_lds_big = !lds_big_env && !A.bs && ngm::cs_order_tau(A.lists_cap) <= ngm::kCsOrderBucketMaxTau;
-	if (no_lds_big || m->d_order_scratch.reserve((size_t) std::min(nl, kChunk) * kGcap * 2)) { A.order_scratch = nullptr; A.order_gcap = 0; }   // (time line + hit times per workgroup)
-	else { A.order_scratch = m->d_order_scratch.p; A.order_gcap = kGcap; }
-	MAP_HIP_TRY(hipEventRecord(m->oev[0], ost));
-	for (uint32_t off = 0; off < nl; off += kChunk) {
-		A.read_list = m->d_order_list.p + off;
-		A.order_info = m->d_order_info.p + 2 * (size_t) off;
-		hipLaunchKernelGGL(ngm::cs_order_kernel<false>, dim3(std::min(kChunk, nl - off)), dim3(ngm::kCsOrderThreads), lds, ost, A, (const uint32_t *) m->d_out_loc.p, (const uint32_t *) m->d_out_sv.p, m->d_cand_rank.p);
-		MAP_HIP_TRY(hipGetLastError());
-	}
-	MAP_HIP_TRY(hipEventRecord(m->oev[1], ost));
-	MAP_HIP_TRY(hipMemcpyAsync(m->p_rank.p, m->d_cand_rank.p, np * 4, hipMemcpyDeviceToHost, ost));
-	MAP_HIP_TRY(hipMemcpyAsync(m->p_order_info.p, m->d_order_info.p, 2 * (size_t) nl * 4, hipMemcpyDeviceToHost, ost));
-	m->order_args = A;
-	if (!wait) return 0;
-	if (int rc = candidate_order_finish(m, ost, np)) return rc;
-	*h_rank = m->p_rank.p;
-	if (A.phase_cycles) {
-		unsigned long long ph[12];
-		MAP_HIP_TRY(hipMemcpy(ph, A.phase_cycles + 8, sizeof(ph), hipMemcpyDeviceToHost));
-		fprintf(stderr, "[ngm-hip] order replay: slowest workgroup %.1f us; %llu workgroups above 1 ms (most hits among them %llu, most tracked bins %llu)\n", ph[8] / 100.0, ph[9], ph[10], ph[11]);
-		const double ns = (double) std::max(1ull, ph[4]);
-		fprintf(stderr, "[ngm-hip] order replay, us per sampled read: lists %.1f | sweep A %.1f | sweep B %.1f | compaction + replay %.1f; %llu sampled, %llu gave up, %llu on the global time line; hits %.0f, replayed %.0f per read\n",
-				ph[0] / ns / 100.0, ph[1] / ns / 100.0, ph[2] / ns / 100.0, ph[3] / ns / 100.0, ph[4], ph[5] & 0xFFull, 0ull, ph[6] / ns, ph[7] / ns);
-		fprintf(stderr, "[ngm-hip] order replay: %.1f us per workgroup start to end, summed %.1f ms over %u workgroups\n", (double) (ph[5] >> 8) / 100.0 / std::max(1u, nl), (double) (ph[5] >> 8) / 1e5, nl);
-	}
-	if (getenv("NGM_HIP_HOST_TIMING"))
-		fprintf(stderr, "[ngm-hip] candidate order replay: %u reads, %.2f ms\n", nl, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
-	return 0;
-}
 
 int ngm_mapper_map_se(ngm_mapper *m, int n, const char *reads, ngm_hit *hits, char *cigars, char *mds) {
 	return map_impl(m, n, reads, nullptr, hits, cigars, mds, false);
@@ -1699,7 +635,6 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_info.p, m->d_pair_info.p, (size_t) (n / 2) * 4, hipMemcpyDeviceToHost, m->st));
 		}
 		MAP_HIP_TRY(hipEventRecord(m->ev[4], m->st));
-		stage_cs.kernels_done();
 		MAP_HIP_TRY(hipMemcpyAsync(h_winner, m->d_winner.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_mapq, m->d_mapq.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
 		MAP_HIP_TRY(hipMemcpyAsync(h_nbest, m->d_nbest.p, (size_t) n * 4, hipMemcpyDeviceToHost, m->st));
@@ -2121,7 +1056,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				m->d_runs_c.p, m->d_total.p);
 		MAP_HIP_TRY(hipGetLastError());
 		unsigned long long n_runs_total = 0, n_str_total = 0;
-		if (!dev_strings) { MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st)); stage_align.kernels_done(); }   // (behind the stage's last kernel)
+		if (!dev_strings) { MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st)); }   // (behind the stage's last kernel)
 		// CIGAR / MD / NM / identity on the GPU (cigar_device.h); NGM_HIP_HOST_CIGAR=1 keeps the host builders (tests)
 		if (dev_strings) {
 			const unsigned long long scap = (unsigned long long) na * 96ull + 4096ull;
@@ -2136,7 +1071,6 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 					(unsigned long long *) (m->d_total.p + 8), alt_cigar);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipEventRecord(m->ev[8], m->st));
-			stage_align.kernels_done();
 			MAP_HIP_TRY(hipMemcpyAsync(m->p_cigout.p, m->d_cigout.p, (size_t) na * sizeof(ngm::CigarDevOut), hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(&n_str_total, m->d_total.p + 8, 8, hipMemcpyDeviceToHost, m->st));
 		}
@@ -2295,7 +1229,6 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_sam_len.p, m->d_sam_off.p, 0u, (size_t) units + 1, rocprim::plus<uint32_t>(), m->st));
 			uint32_t total32 = 0;
 			unsigned long long total64 = 0;
-			stage_sam.before_sync();
 			MAP_HIP_TRY(hipMemcpyAsync(&total32, m->d_sam_off.p + units, 4, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipMemcpyAsync(&total64, m->d_total.p + 19, 8, hipMemcpyDeviceToHost, m->st));
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
@@ -2311,7 +1244,6 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(hipGetLastError());
 		}
 		MAP_HIP_TRY(hipEventRecord(e1, m->st));
-		stage_sam.kernels_done();
 		unsigned long long ctr[7] = {0, 0, 0, 0, 0, 0, 0};
 		MAP_HIP_TRY(hipMemcpyAsync(ctr, m->d_total.p + 16, 56, hipMemcpyDeviceToHost, m->st));
 		m->sam_text_bytes = total;
@@ -2432,6 +1364,40 @@ int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]) {
 	if (!m || !out) return -22;
 	out[0] = m->st_reads; out[1] = m->st_cands; out[2] = m->st_exact_lds; out[3] = m->st_exact_global;
 	out[4] = m->st_order_reads; out[5] = m->st_order_big; out[6] = m->st_order_unknown; out[7] = m->st_heavy;
+	return 0;
+}
+
+int ngm_debug_select_top1(int device, int n_reads, const uint32_t *base, const uint32_t *count, uint64_t n_cand, const float *scores, const uint32_t *loc,
+		const uint32_t *strand_votes, uint32_t *winner, int32_t *mapq, int32_t *n_best, float *best_score) {
+	if (n_reads <= 0 || !base || !count || !winner || !mapq || !n_best || !best_score) return -22;
+	DevGuard g(device);
+	ngm::DevBuf<uint32_t> d_base, d_count, d_loc, d_sv, d_win;
+	ngm::DevBuf<int32_t> d_mq, d_nb;
+	ngm::DevBuf<float> d_sc, d_best;
+	const size_t nc = (size_t) std::max<uint64_t>(n_cand, 1);
+	if (d_base.reserve(n_reads) || d_count.reserve(n_reads) || d_loc.reserve(nc) || d_sv.reserve(nc) || d_sc.reserve(nc) || d_win.reserve(n_reads) || d_mq.reserve(n_reads) ||
+			d_nb.reserve(n_reads) || d_best.reserve(n_reads)) { ngm::pipeline_set_error("out of device memory (ngm_debug_select_top1)"); return -12; }
+	MAP_HIP_TRY(hipMemcpy(d_base.p, base, (size_t) n_reads * 4, hipMemcpyHostToDevice));
+	MAP_HIP_TRY(hipMemcpy(d_count.p, count, (size_t) n_reads * 4, hipMemcpyHostToDevice));
+	if (n_cand) {
+		MAP_HIP_TRY(hipMemcpy(d_sc.p, scores, (size_t) n_cand * 4, hipMemcpyHostToDevice));
+		MAP_HIP_TRY(hipMemcpy(d_loc.p, loc, (size_t) n_cand * 4, hipMemcpyHostToDevice));
+		MAP_HIP_TRY(hipMemcpy(d_sv.p, strand_votes, (size_t) n_cand * 4, hipMemcpyHostToDevice));
+	}
+	hipLaunchKernelGGL(ngm::select_top1_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, 0, n_reads, d_base.p, d_count.p, d_sc.p, d_loc.p, d_sv.p, d_win.p, d_mq.p, d_nb.p, d_best.p);
+	MAP_HIP_TRY(hipGetLastError());
+	MAP_HIP_TRY(hipDeviceSynchronize());
+	MAP_HIP_TRY(hipMemcpy(winner, d_win.p, (size_t) n_reads * 4, hipMemcpyDeviceToHost));
+	MAP_HIP_TRY(hipMemcpy(mapq, d_mq.p, (size_t) n_reads * 4, hipMemcpyDeviceToHost));
+	MAP_HIP_TRY(hipMemcpy(n_best, d_nb.p, (size_t) n_reads * 4, hipMemcpyDeviceToHost));
+	MAP_HIP_TRY(hipMemcpy(best_score, d_best.p, (size_t) n_reads * 4, hipMemcpyDeviceToHost));
+	d_base.release(); d_count.release(); d_loc.release(); d_sv.release(); d_win.release(); d_mq.release(); d_nb.release(); d_sc.release(); d_best.release();
+	return 0;
+}
+
+int ngm_mapper_heavy_counters(ngm_mapper *m, uint64_t out[4]) {
+	if (!m || !out) return -22;
+	out[0] = m->st_heavy_second; out[1] = m->st_heavy_restart; out[2] = m->st_heavy_sent_on; out[3] = m->st_pool_regrown;
 	return 0;
 }
 

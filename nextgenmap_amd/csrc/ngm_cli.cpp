@@ -32,6 +32,8 @@
 #include <malloc.h>
 #include <getopt.h>
 #include <sys/mman.h>
+#include <poll.h>
+#include <signal.h>
 #include <sys/stat.h>
 #include <sys/sendfile.h>
 #include <sys/wait.h>
@@ -278,6 +280,14 @@ Opts parse(int argc, char **argv) {
 	if (o.gap_extend < 0) o.gap_extend = o.affine ? 3 : 5;
 	// the pairs NextGenMap loses (ngm_mapper_set_reference_score_buffer): its SeqAn personality scores in batches of 1 024
 	// (src/seqan/EndToEndAffine.h:44-46); the OpenCL personality's batch depends on the device it finds -- nothing to mirror by default
+	// The walk that finds those pairs is sequential over the WHOLE input (it follows the reference's CS batches and score-buffer fill from
+	// the first read on, as `ngm -t 1` does): a shard that starts in the middle of the input cannot know where the reference's buffer
+	// stands at its first read, would lose pairs the reference keeps, and `cat shards` would no longer equal the single run.
+	// Sharded runs therefore never mirror them.
+	if (o.shard_n > 1) {
+		if (o.ref_score_buffer > 0) fprintf(stderr, "[MAIN] --reference-score-buffer is ignored with --shard: the reference's score buffer cannot be followed from the middle of the input\n");
+		o.ref_score_buffer = 0;
+	}
 	if (o.ref_score_buffer < 0) o.ref_score_buffer = o.affine ? 1024 : 0;
 	if (o.devices.empty()) o.devices.assign(1, o.device);
 	o.device = o.devices[0];
@@ -685,17 +695,50 @@ int run_sharded(int argc, char **argv, const Opts &o) {
 		close(pfd[1]);
 		kids.push_back(pid);
 	}
+	// The shards' vectors (64 bytes each, written when a shard is done) and their exit codes, as they come.  A shard that fails must not
+	// leave the others -- and this process -- waiting: on distinct GPUs they sit in ncclCommInitRank / ncclAllReduce, which have no timeout
+	// and wait for EVERY rank.  So the pipes are polled, the children reaped as they exit, and the first failure ends the rest.
 	long long total[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int got = 0;
-	for (int k = 0; k < N; ++k) {   // (64 bytes each, written when a shard is done: read until its end of file)
-		int64_t v[8];
-		size_t have = 0;
-		while (have < sizeof(v)) { const ssize_t r = read(stat_rd[k], (char *) v + have, sizeof(v) - have); if (r <= 0) break; have += (size_t) r; }
-		close(stat_rd[k]);
-		if (have == sizeof(v)) { ++got; for (int j = 0; j < 8; ++j) total[j] += v[j]; }
-	}
 	bool ok = true;
-	for (pid_t pid : kids) { int st = 0; if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0) ok = false; }
+	{
+		std::vector<int64_t> vec((size_t) N * 8, 0);
+		std::vector<size_t> have(N, 0);
+		std::vector<bool> open_fd(N, true), alive(N, true);
+		int n_alive = N, n_open = N;
+		auto end_the_others = [&] { for (int k = 0; k < N; ++k) if (alive[k]) kill(kids[k], SIGTERM); };
+		while (n_alive > 0 || n_open > 0) {
+			std::vector<struct pollfd> pf;
+			std::vector<int> which;
+			for (int k = 0; k < N; ++k) if (open_fd[k]) { struct pollfd x; x.fd = stat_rd[k]; x.events = POLLIN; x.revents = 0; pf.push_back(x); which.push_back(k); }
+			if (!pf.empty()) (void) poll(pf.data(), (nfds_t) pf.size(), 200);
+			else usleep(20000);
+			for (size_t j = 0; j < pf.size(); ++j) {
+				if (!(pf[j].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+				const int k = which[j];
+				const ssize_t r = have[k] < 64 ? read(stat_rd[k], (char *) &vec[(size_t) k * 8] + have[k], 64 - have[k]) : 0;
+				if (r > 0) have[k] += (size_t) r;
+				if (r <= 0 || have[k] == 64) {   // (end of file, or the vector is complete)
+					if (r <= 0 || (pf[j].revents & POLLHUP)) { close(stat_rd[k]); open_fd[k] = false; --n_open; }
+				}
+			}
+			for (;;) {
+				int st = 0;
+				const pid_t pid = waitpid(-1, &st, WNOHANG);
+				if (pid <= 0) break;
+				for (int k = 0; k < N; ++k) if (alive[k] && kids[k] == pid) {
+					alive[k] = false; --n_alive;
+					if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) { if (ok) end_the_others(); ok = false; }
+				}
+			}
+			if (n_alive == 0) for (int k = 0; k < N; ++k) if (open_fd[k]) {   // (every writer has gone: what is in the pipes is all there will be)
+				const ssize_t r = have[k] < 64 ? read(stat_rd[k], (char *) &vec[(size_t) k * 8] + have[k], 64 - have[k]) : 0;
+				if (r > 0) have[k] += (size_t) r;
+				close(stat_rd[k]); open_fd[k] = false; --n_open;
+			}
+		}
+		for (int k = 0; k < N; ++k) if (have[k] == 64) { ++got; for (int j = 0; j < 8; ++j) total[j] += vec[(size_t) k * 8 + j]; }
+	}
 	if (!ok) die("a shard process failed (its messages are above)");
 	if (got == N) {
 		char dm[400];
@@ -1918,6 +1961,11 @@ int main(int argc, char **argv) {
 		const double nr = (double) std::max<uint64_t>(1, pc[0]);
 		snprintf(msg, sizeof(msg), "Candidate search: %llu reads, %.2f candidates per read; heavy-read kernel for %llu reads (%.3f %%), exact search with the table in LDS for %llu (%.3f %%), in global memory for %llu (%.3f %%)",
 				(unsigned long long) pc[0], pc[1] / nr, (unsigned long long) pc[7], 100.0 * pc[7] / nr, (unsigned long long) pc[2], 100.0 * pc[2] / nr, (unsigned long long) pc[3], 100.0 * pc[3] / nr);
+		info("MAIN", msg);
+		uint64_t hc[4] = {0, 0, 0, 0};
+		for (Worker &w : workers) { uint64_t c4[4]; if (ngm_mapper_heavy_counters(w.m, c4) == 0) for (int x = 0; x < 4; ++x) hc[x] += c4[x]; }
+		snprintf(msg, sizeof(msg), "Heavy-read kernel: %llu second passes, %llu table passes started over, %llu reads sent on to the exact kernels; table pool regrown %llu times",
+				(unsigned long long) hc[0], (unsigned long long) hc[1], (unsigned long long) hc[2], (unsigned long long) hc[3]);
 		info("MAIN", msg);
 		uint64_t by_table = 0;
 		for (Worker &w : workers) { uint64_t c2 = 0; if (ngm_mapper_order_table_reads(w.m, &c2) == 0) by_table += c2; }

@@ -14,7 +14,17 @@
 #include <mutex>
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+
+// The handful of RCCL declarations this file needs, stated here instead of #include <rccl/rccl.h>: the library is found at RUN time,
+// and a ROCm install without the RCCL development headers must still build libngm_hip.so.  Values as in rccl.h (NCCL 2.x ABI).
+extern "C" {
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclInt64 = 4 } ncclDataType_t;
+}
 
 #include "refindex.h"   // ngm::pipeline_set_error
 

@@ -67,6 +67,7 @@ def _lib():
         lib.ngm_mapper_cs_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_path_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_order_table_reads.argtypes = [C.c_void_p, C.c_void_p]
+        lib.ngm_mapper_heavy_counters.argtypes = [C.c_void_p, C.c_void_p]
         lib.ngm_mapper_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         lib.ngm_mapper_last_order_replay_ms.restype = C.c_float
         lib.ngm_mapper_last_order_replay_ms.argtypes = [C.c_void_p]
@@ -320,6 +321,12 @@ class Mapper:
         out = np.zeros(8, np.uint64)
         self.lib.ngm_mapper_path_counters(self.h, out.ctypes.data)
         return dict(zip(("reads", "candidates", "exact_lds", "exact_global", "order_replayed", "order_exact_global", "order_undetermined", "heavy"), (int(x) for x in out[:8])))
+
+    def heavy_counters(self):
+        """of path_counters()["heavy"]: second passes, table passes started over, reads sent on to the exact kernels, regrown table pools"""
+        out = np.zeros(4, np.uint64)
+        self.lib.ngm_mapper_heavy_counters(self.h, out.ctypes.data)
+        return dict(zip(("second_passes", "table_pass_restarts", "sent_on", "pool_regrown"), (int(x) for x in out)))
 
     def order_table_reads(self):
         """of path_counters()["order_exact_global"]: the reads the bucket replay left to the replay with a table in global memory"""
