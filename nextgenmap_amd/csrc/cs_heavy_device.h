@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // ctl: the search's control block (cs_queue_device.h) -- the class's list length and work counter, the run's statistics   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several, [13] reads sent into a second pass
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
 	constexpr int NW = NT / 64;
-	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct, s_nhot, s_nent, s_force, s_retry_ix, s_retry_T;
+	__shared__ uint32_t s_T, s_next, s_np, s_entries, s_fail, s_direct, s_nhot, s_nent, s_force, s_retry_ix, s_retry_T, s_short;
 	__shared__ uint32_t s_red[NW], s_cnt[NT], s_wtot[NW], s_mx[NW], s_mxb[NW];
 	__shared__ unsigned long long s_base;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				const int p = li >> 1;
 				const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
 				const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
-				f(pos8, cn, correction, (li & 1) != 0);
+				f(pos8, cn, correction, (li & 1) != 0, len);
 				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1];
 			}
 		};
@@ -368,21 +368,81 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 			for (int w2 = 0; w2 < NW; ++w2) tot += s_red[w2];
 			return tot == want;
 		};
+		// Round 6: a LOWER bound of the read's maximum before the threshold is picked.  Sweep A also votes the hits of the SHORT lists -- the
+		// lists of at most `n_short` hits, as many of them as half the table takes -- into the exact table: the largest strand count L found
+		// there is made of real votes of one bin, so the read's maximum is at least L and its final threshold at least max(kmer_min, L *
+		// sensitivity).  Every T with T - 1 below THAT is certain to certify (the bin behind L has at least L >= T votes: it reaches the
+		// table, M2 >= L), so T starts there instead of at the smallest value the table's room allows: on a GRCh38-sized index, where a
+		// k-mer has ~15 chance occurrences, half of a read's lists are short, L is about half the true maximum, and the survivors of
+		// row 1 fall from ~40 % of the hits (T = 3-5: counters with a few chance hits) to the hits of bins with real votes.
+		if (H > cap && wv == 0) {
+			const uint32_t budget = n_slots / 2u;
+			for (int base = 0; base < n_lists; base += 64) {
+				const int li = base + lane;
+				const uint32_t len = li < n_lists ? l_pref[li + 1] - l_pref[li] : 0u;
+				if (len >= 1u && len <= 64u) atomicAdd(&hist_h[len], len);   // (hist_h is zero here; entries 1..64 are zeroed again below)
+			}
+			const uint32_t mine = hist_h[lane + 1];
+			const uint32_t incl = wave_inclusive_scan(mine, lane);
+			const uint32_t ns = (uint32_t) __popcll(__ballot(incl <= budget));   // lists of up to ns hits fit (the sums grow with the length)
+			hist_h[lane + 1] = 0;
+			if (lane == 0) s_short = (T_force || A.fast_items < 0) ? 0u : ns;   // (a second pass has its T from the first pass's exact maximum; fast_items < 0: A/B runs without the bound)
+		}
 		uint32_t T = 1;
 		bool failed = false;
 		uint32_t why = 0;   // (diagnostics) what sent the read on: 1 a counter row wrapped, 2 no T <= 255 fits, 3 more survivors than the slice, 4 the table (or the entry list) overflowed, 5 T - 1 not below the threshold
 		mark(0);
 		if (H > cap) {
 			// sweep A
-			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool) {
+			__syncthreads();
+			const uint32_t n_short = s_short;
+			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t len) {
+				uint32_t bin[kCsSeg];
 #pragma unroll
-				for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) {
-					const uint32_t hc = (((pos8[j] - correction) >> A.bin_shift) * 0x9E3779B1u) >> (32 - log2c);
-					atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
+				for (int j = 0; j < kCsSeg; ++j) {
+					bin[j] = (pos8[j] - correction) >> A.bin_shift;
+					if ((uint32_t) j < cn) {
+						const uint32_t hc = (bin[j] * 0x9E3779B1u) >> (32 - log2c);
+						atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
+					}
+				}
+				if (len <= n_short) {
+					// the segment's first probes in flight together (a returning LDS atomic per hit, one after the other, made this sweep three
+					// times as long); no entry count: the budget keeps the table below half full, and it is emptied again below
+					uint32_t slot[kCsSeg], prev[kCsSeg];
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) {
+						slot[j] = (bin[j] * 0x85EBCA6Bu) >> (32 - log2_slots);
+						prev[j] = (uint32_t) j < cn ? atomicCAS(&t_keys[slot[j]], 0xFFFFFFFFu, bin[j]) : 0u;
+					}
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) {
+						uint32_t sl = slot[j], pv = prev[j];
+						while (pv != bin[j] && pv != 0xFFFFFFFFu) { sl = (sl + 1) & (n_slots - 1); pv = atomicCAS(&t_keys[sl], 0xFFFFFFFFu, bin[j]); }
+						atomicAdd(&t_votes[sl], rev ? 0x10000u : 1u);
+					}
 				}
 			});
 			__syncthreads();
 			mark(1);
+			uint32_t T_low = 2;
+			if (n_short) {   // (block-uniform) L from the table, then the table is empty again
+				int lm = 0;
+				uint4 *k4 = reinterpret_cast<uint4 *>(t_keys), *v4 = reinterpret_cast<uint4 *>(t_votes);
+				for (uint32_t s2 = tid; s2 < n_slots / 4u; s2 += NT) {
+					const uint4 v = v4[s2];
+					lm = max(lm, (int) max(max(max(v.x & 0xFFFFu, v.x >> 16), max(v.y & 0xFFFFu, v.y >> 16)), max(max(v.z & 0xFFFFu, v.z >> 16), max(v.w & 0xFFFFu, v.w >> 16))));
+					k4[s2] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); v4[s2] = make_uint4(0u, 0u, 0u, 0u);
+				}
+				lm = wave_reduce_max(lm);
+				if (lane == 0) s_mx[wv] = (uint32_t) lm;
+				__syncthreads();
+				lm = 0;
+#pragma unroll
+				for (int w2 = 0; w2 < NW; ++w2) lm = max(lm, (int) s_mx[w2]);
+				T_low = min(255u, max(2u, (uint32_t) ceilf(fmaxf(A.kmer_min, (float) lm * A.sensitivity))));
+				if (dg) atomicAdd(&diag[7], (unsigned long long) T_low);
+			}
 			// histogram of the counter values -- and their sum: a 16-bit field that wrapped into its neighbour changes it
 			if (!row_hist(H, 2u, true)) { failed = true; why = 1; }   // (block-uniform)
 			if (!failed) {
@@ -391,7 +451,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 					// both rows) and whose hits fit the scratch slice; when even the hits fit the table, no second row is needed.  Both
 					// conditions are monotone in T: lane l looks at the values 4 l .. 4 l + 3, suffix sums from a wave scan.
 					const uint32_t room = ((cap * 3u) / 4u) * parts_now;   // (a read's second pass takes the bins in several parts: below)
-					const int t_min = (int) max(2u, T_force);
+					const int t_min = (int) max(max(2u, T_force), T_low);
 					uint32_t n4[4], h4[4], sn = 0, sh = 0;
 #pragma unroll
 					for (int j = 0; j < 4; ++j) { n4[j] = hist_n[4 * lane + j]; h4[j] = hist_h[4 * lane + j]; sn += n4[j]; sh += h4[j]; }
@@ -416,7 +476,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 			}
 			mark(2);
 			if (!failed && s_direct) {
-				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev) {
+				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t) {
 #pragma unroll
 					for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) {
 						const uint32_t bin = (pos8[j] - correction) >> A.bin_shift;
@@ -425,7 +485,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				});
 			} else if (!failed) {
 				// sweep B: the survivors of row 1 -> scratch slice (one slot request per wave and trip)
-				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev) {
+				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t) {
 					uint32_t keep = 0, nk = 0;
 					uint32_t e[8];
 #pragma unroll
@@ -648,7 +708,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				}
 			}
 		} else {
-			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev) {
+			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t) {
 #pragma unroll
 				for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) insert((pos8[j] - correction) >> A.bin_shift, rev);
 			});

@@ -125,11 +125,15 @@ __global__ __launch_bounds__(1024) void cs_global_prepare_kernel(uint32_t *__res
 // candidate regions -> one dense array in read order (new_base = exclusive prefix sum of cand_count): a thread copies its own read's
 // (few) candidates, a read with more than kCompactSmall of them is copied by a wave (round 5: one thread per read, 2.8 ms per
 // 131 072 reads of the GRCh38-like genome -- candidates per read: median 1, 99th percentile 1 356, maximum 9 383)
+// The compaction is enqueued behind the passes without the host having seen their status: when a pass ran out of candidate room, or the
+// reads queued for the global-memory tables were not run (pool too small), bases and counts are not all valid -- the kernel then does
+// nothing (the host repeats the batch, or that pass and the compaction).
 constexpr uint32_t kCompactSmall = 8;
-__global__ __launch_bounds__(256) void compact_candidates_kernel(int n_reads, const uint32_t *__restrict__ old_base, const uint32_t *__restrict__ new_base,
+__global__ __launch_bounds__(256) void compact_candidates_kernel(int n_reads, const uint32_t *__restrict__ status, const uint32_t *__restrict__ old_base, const uint32_t *__restrict__ new_base,
 		const uint32_t *__restrict__ cand_count, const uint32_t *__restrict__ loc_in, const uint32_t *__restrict__ sv_in,
 		uint32_t *__restrict__ loc_out, uint32_t *__restrict__ sv_out) {
 	__shared__ uint32_t s_big[256], s_nbig;
+	if (status[kCsqStatusMain] | status[kCsqStatusExact] | status[8] | status[kCsqPoolFlag]) return;   // (uniform)
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	if (tid == 0) s_nbig = 0;
 	__syncthreads();

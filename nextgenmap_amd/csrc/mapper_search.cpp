@@ -238,6 +238,7 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage) {
 		MAP_HIP_TRY(hipMemsetAsync(m->d_total.p, 0, (ctr_words + 16) * 8, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_counters.p, 0, (ctr_words + 32) * 8, m->st));
 		MAP_HIP_TRY(hipMemsetAsync(m->d_heavy_ctr.p, 0, kCsqWords * 4, m->st));
+		MAP_HIP_TRY(hipMemsetAsync(m->d_cand_count.p, 0, (size_t) n * 4, m->st));   // (a read no pass has finished -- a pass skipped for want of pool room -- has no candidates yet)
 		CsArgs A{};
 		A.reads = m->d_reads.p; A.n = n; A.q = q; A.k = r->prm.kmer; A.bin_shift = r->prm.bin_size;
 		A.max_kfreq = m->max_kfreq; A.sensitivity = m->prm.sensitivity; A.kmer_min = m->prm.kmer_min; A.max_cmrs = m->prm.max_cmrs;
@@ -283,7 +284,7 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage) {
 		uint32_t last[2] = {0, 0};
 		auto enqueue_finish = [&]() -> int {
 			MAP_HIP_TRY(rocprim::exclusive_scan(m->d_scan_tmp.p, tmp_bytes, m->d_cand_count.p, m->d_new_base.p, 0u, (size_t) n, rocprim::plus<uint32_t>(), m->st));
-			hipLaunchKernelGGL(compact_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, m->st, n, m->d_cand_base.p, m->d_new_base.p, m->d_cand_count.p,
+			hipLaunchKernelGGL(compact_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, m->st, n, (const uint32_t *) m->d_status.p, m->d_cand_base.p, m->d_new_base.p, m->d_cand_count.p,
 					m->d_out_loc.p, m->d_out_sv.p, m->d_out_loc2.p, m->d_out_sv2.p);
 			MAP_HIP_TRY(hipGetLastError());
 			MAP_HIP_TRY(hipMemcpyAsync(status, m->d_status.p, 64, hipMemcpyDeviceToHost, m->st));
@@ -469,6 +470,7 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage) {
 						if (grid[c] == 0) continue;
 						CsArgs Hv = A;
 						Hv.read_list = m->d_heavy_list.p + (size_t) c * n; Hv.log2_bits = classes[c].log2c; Hv.log2_slots = classes[c].log2s;
+						if (test_limit("heavy_no_short", 0)) Hv.fast_items = -1;   // (A/B: T without the lower bound from the short lists)
 						uint32_t scap = classes[c].scratch_cap, ccap = coarse_cap, mparts = classes[c].max_parts, ecap = ent_cap_of(c);
 						uint32_t *ctl_d = m->d_heavy_ctr.p, *scr = m->d_gt_keys.p + soff;
 						int cls = c;
@@ -516,9 +518,9 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage) {
 				MAP_HIP_TRY(hipMemcpy(dg, m->d_heavy_diag.p, sizeof(dg), hipMemcpyDeviceToHost));
 				for (int c = 0; c < 3; ++c) if (dg[16 * c + 8]) {
 					const double ns = (double) dg[16 * c + 8];
-					fprintf(stderr, "[ngm-hip] heavy class %d (%u reads): us per sampled read: setup %.1f | sweep A %.1f | sum + T %.1f | insert / sweep B %.1f | row 2 %.1f | sweep D %.1f | candidates %.1f; hits %.0f, survivors %.0f, %.0f %% without a second row; second passes %.0f %% of the reads, table passes of the partitioned reads %.1f\n",
+					fprintf(stderr, "[ngm-hip] heavy class %d (%u reads): us per sampled read: setup %.1f | sweep A %.1f | sum + T %.1f | insert / sweep B %.1f | row 2 %.1f | sweep D %.1f | candidates %.1f; hits %.0f, survivors %.0f, %.0f %% without a second row; T from the short lists %.1f; second passes %.0f %% of the reads, table passes of the partitioned reads %.1f\n",
 							c, c == 2 ? ctl[kCsqRun + 1] : ctl[kCsqCount + c], dg[16 * c] / ns / 100.0, dg[16 * c + 1] / ns / 100.0, dg[16 * c + 2] / ns / 100.0, dg[16 * c + 3] / ns / 100.0, dg[16 * c + 4] / ns / 100.0,
-							dg[16 * c + 5] / ns / 100.0, dg[16 * c + 6] / ns / 100.0, dg[16 * c + 9] / ns, dg[16 * c + 11] / ns, 100.0 * dg[16 * c + 10] / ns, 100.0 * dg[16 * c + 13] / ns, (double) dg[16 * c + 12]);
+							dg[16 * c + 5] / ns / 100.0, dg[16 * c + 6] / ns / 100.0, dg[16 * c + 9] / ns, dg[16 * c + 11] / ns, 100.0 * dg[16 * c + 10] / ns, dg[16 * c + 7] / ns, 100.0 * dg[16 * c + 13] / ns, (double) dg[16 * c + 12]);
 					const unsigned long long w = dg[16 * c + 14], x = dg[16 * c + 15];
 					if (w | x) fprintf(stderr, "[ngm-hip] heavy class %d sent on: %llu reads with a wrapped counter row, %llu without a T <= 255 that fits, %llu with more survivors than the slice or an overflowing table / entry list, %llu with T - 1 not below the threshold\n",
 							c, w & 0xFFFFFFFFull, w >> 32, x & 0xFFFFFFFFull, x >> 32);
@@ -581,8 +583,8 @@ int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		size_t free_b = 0, total_b = 0;
 		uint64_t room = want_bytes;
 		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) room = std::min<uint64_t>(room, ((uint64_t) free_b + (uint64_t) m->d_order_gt.cap * 4) / 2);
-		const long mb = test_limit("order_pool_mb", 0);
-		if (mb > 0) room = std::min<uint64_t>(room, (uint64_t) mb << 20);
+		const long kb = test_limit("order_pool_kb", 0);
+		if (kb > 0) room = std::min<uint64_t>(room, (uint64_t) kb << 10);
 		return room;
 	};
 	// The reads beyond the LDS replay: hits dealt into buckets (cs_order_bucket_kernel -- no table in global memory); what that kernel
@@ -683,7 +685,7 @@ int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		// 5 500 such reads of a heavy-tailed batch went through ten launches of ~570 workgroups each -- two per CU, 118 ms of waiting per batch)
 		// (the pool never asks for more than half of what the device has free, a read that needs more than the pool -- or a pool
 		// that cannot be had -- keeps an UNDETERMINED order, which the run reports (st_order_unknown) instead of dying: ties then resolve by position)
-		uint64_t pool_words = std::max<uint64_t>(scratch_room(8ull << 30) / 4, 1ull << 18);
+		uint64_t pool_words = std::max<uint64_t>(scratch_room(8ull << 30) / 4, test_limit("order_pool_kb", 0) > 0 ? 1024ull : 1ull << 18);
 		for (uint32_t j0 = 0; j0 < (uint32_t) big.size();) {
 			if (words[j0] > pool_words) { ++j0; continue; }   // (its candidates keep kCsOrderUnknown from the LDS replay's give-up)
 			uint64_t total = 0;

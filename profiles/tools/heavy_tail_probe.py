@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One batch of reads against the GRCh38-like genome of bench.py's heavy-tail leg, with the library's per-pass timing on
-(NGM_HIP_HOST_TIMING) and the hit counts of the reads each exact pass receives (NGM_HIP_DUMP_OVF).
+(NGM_HIP_HOST_TIMING; NGM_HIP_CS_PHASES=1 adds the phases inside the kernels).
   python profiles/tools/heavy_tail_probe.py [--mbp 1000] [--reads 262144] [--repeat-share 0.5] [--steps 2]"""
 import argparse, os, sys, time
 import numpy as np
@@ -12,12 +12,8 @@ ap.add_argument("--reads", type=int, default=262144)
 ap.add_argument("--repeat-share", type=float, default=0.5)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--se", action="store_true")
-ap.add_argument("--dump", default="/tmp/ovf.txt")
 a = ap.parse_args()
 os.environ["NGM_HIP_HOST_TIMING"] = "1"
-os.environ["NGM_HIP_DUMP_OVF"] = a.dump
-if os.path.exists(a.dump):
-    os.remove(a.dump)
 import torch
 import bench as B
 import humanlike as HL
@@ -31,17 +27,10 @@ rows, tc, tp = B.make_reads(G.contigs, a.reads, seed=20260931, paired=paired, st
 d_rows = torch.from_numpy(rows).cuda()
 m = Mapper(ref, B.Q, B.C, sensitivity=0.5, gap_read=33, gap_ref=33, gap_extend=3, personality=1)
 for s in range(a.steps):
-    if s == a.steps - 1 and os.path.exists(a.dump):
-        os.remove(a.dump)
     t = time.perf_counter()
     hits, _, _ = (m.map_pe_raw if paired else m.map_se_raw)(rows, d_rows)
     print("step %d: %.1f ms, kernels %s" % (s, 1e3 * (time.perf_counter() - t), ["%.2f" % x for x in m.last_kernel_ms()]), flush=True)
 print("path counters", m.path_counters(), "cs counters", m.cs_counters())
 nc = hits["n_candidates"]
 print("candidates per read percentiles 50/90/99/99.9/max:", np.percentile(nc, [50, 90, 99, 99.9, 100]).astype(int), "mean %.1f" % nc.mean())
-if os.path.exists(a.dump):
-    d = np.loadtxt(a.dump, dtype=np.int64).reshape(-1, 2)
-    for p in (2, 3):
-        h = d[d[:, 0] == p, 1]
-        if len(h):
-            print("pass %d: %d reads, hits percentiles 5/25/50/75/95/99/max: %s, sum %.3g" % (p, len(h), np.percentile(h, [5, 25, 50, 75, 95, 99, 100]).astype(int), h.sum()))
+print("heavy counters", m.heavy_counters())

@@ -113,6 +113,72 @@ def test_paired_end_on_a_heavy_tailed_genome(world):
     assert len(diff) == 0, len(diff)
 
 
+# The limits below make a 120 Mbp genome behave like GRCh38 does with the product's real ones ("what's missing" 1): tables of
+# cs_heavy2_kernel a 64th of their size, so that table passes overflow and start over with twice the parts, reads fail every class
+# and reach the exact kernels -- the LDS table and, beyond its 10 813 hits, cs_global_kernel with tables from a pool that must grow --;
+# 64 buckets per read in the bucket replay, so that every bucket is a window of its own (> 64 hits).
+FORCED = "heavy_log2c=9,heavy_log2s=7,heavy_max0=1500,heavy_scratch=4096,gtable_pool_log2=12,order_buckets_log2=6"
+
+
+def _counters(log):
+    pat = {"heavy": r"heavy-read kernel for (\d+) reads", "exact_lds": r"table in LDS for (\d+)", "exact_global": r"in global memory for (\d+)",
+           "second": r"Heavy-read kernel: (\d+) second passes", "restart": r"(\d+) table passes started over", "sent_on": r"(\d+) reads sent on",
+           "regrown": r"table pool regrown (\d+) times", "replayed": r"Candidate order replay: (\d+) reads", "beyond": r"(\d+) of them beyond the LDS replay",
+           "unknown": r"order left undetermined for (\d+) reads"}
+    out = {}
+    for k, p in pat.items():
+        mm = re.search(p, log)
+        assert mm, (k, log[-3000:])
+        out[k] = int(mm.group(1))
+    return out
+
+
+@needs_ref
+def test_grch38_sized_paths_under_forced_limits(world):
+    """The paths only a GRCh38-sized index reaches with the real limits -- table passes started over (csrc/cs_heavy_device.h), the exact
+    kernels for ordinary reads incl. cs_global_kernel and its pool (csrc/mapper_search.cpp), crowded buckets in the order replay
+    (csrc/cs_order_bucket_device.h) -- forced on this genome by NGM_HIP_TEST_LIMITS, counted, and 100 000 paired-end records compared
+    with `ngm-core --affine -t 1` (the reference's own overflow handling: src/CS.cpp:397-430)."""
+    d = world["dir"]
+    args = ["-1", str(d / "pe_1.fq"), "-2", str(d / "pe_2.fq")]
+    ref_sam = str(world["refdir"] / "pe.sam")
+    if not os.path.exists(ref_sam):   # (test_paired_end_on_a_heavy_tailed_genome leaves it; run alone: make it)
+        r = RF.run_ngm(["-r", world["ref_fa"], "-o", ref_sam, "--affine", "-t", "1", "--no-progress"] + args, cwd=str(world["refdir"]), timeout=3000)
+        assert "Done" in r.stdout + r.stderr
+    hip_sam = str(d / "forced_hip.sam")
+    c = subprocess.run([CLI, "-r", world["fa"], "-o", hip_sam, "--affine"] + args, capture_output=True, text=True, env=dict(os.environ, NGM_HIP_TEST_LIMITS=FORCED))
+    assert c.returncode == 0, c.stderr[-2000:]
+    k = _counters(c.stderr)
+    print("forced limits:", k)
+    assert k["heavy"] > 0 and k["second"] > 0 and k["restart"] > 0 and k["sent_on"] > 0, k
+    assert k["exact_lds"] > 0 and k["exact_global"] > 0 and k["regrown"] > 0, k
+    assert k["beyond"] > 0 and k["unknown"] == 0, k
+    a, b = _sam_pe(ref_sam), _sam_pe(hip_sam)
+    assert set(a) == set(b) and len(a) == 2 * N_PE and len(a) >= 100_000
+    diff = _report("paired-end, forced limits", a, b, c.stderr)
+    assert len(diff) == 0, len(diff)
+    # the same reads with the product's own limits take none of those paths on this genome: that is why the test forces them
+    base = subprocess.run([CLI, "-r", world["fa"], "-o", str(d / "unforced_hip.sam"), "--affine"] + args, capture_output=True, text=True)
+    assert base.returncode == 0
+    k0 = _counters(base.stderr)
+    print("product limits:", k0)
+    assert [l for l in open(hip_sam, "rb") if not l.startswith(b"@PG")] == [l for l in open(str(d / "unforced_hip.sam"), "rb") if not l.startswith(b"@PG")]
+
+
+def test_order_replay_without_room_degrades_and_says_so(world):
+    """a replay whose scratch cannot hold a read leaves that read's candidate order UNDETERMINED -- counted and printed, ties then
+    resolve by position -- instead of ending the run.  A 64 KB pool (NGM_HIP_TEST_LIMITS) is too small for the reads of the repeat families."""
+    d = world["dir"]
+    out = str(d / "degraded.sam")
+    c = subprocess.run([CLI, "-r", world["fa"], "-o", out, "--affine", "-q", str(d / "se.fq")], capture_output=True, text=True,
+                       env=dict(os.environ, NGM_HIP_TEST_LIMITS="order_pool_kb=64"))
+    assert c.returncode == 0, c.stderr[-2000:]
+    k = _counters(c.stderr)
+    print("replay pool of 64 KB:", k)
+    assert k["beyond"] > 0 and k["unknown"] > 0, k
+    assert sum(1 for l in open(out) if not l.startswith("@")) == N_SE
+
+
 def test_three_order_replays_agree_on_a_heavy_tailed_genome(world):
     """The candidate order of a read beyond the LDS replay comes from cs_order_bucket_kernel (hits dealt into buckets); what it leaves, and
     everything with NGM_HIP_ORDER_NO_BUCKETS, from cs_order_kernel<true> (a table in global memory); NGM_HIP_ORDER_LDS_BIG keeps the reads
