@@ -47,7 +47,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 Q, C, READ_LEN, KMER = 152, 27, 150, 13
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # roofline.traffic: the committed PMC pass of this round's default workload, and the kernel instance that workload launches (mapper.cpp cs_canon_fn)
-PMC_TRAFFIC_FILE = "r05_mapping_pe_affine_pmc_traffic.json"
+PMC_TRAFFIC_FILE = "r06_mapping_pe_affine_pmc_traffic.json"
+HEAVY_CS_TRAFFIC_FILE = "r06_heavy_tail_%s_cs_traffic.json"   # per sub-leg (uniform / repeats): profiles/summarize_rocprof.py, from PMC passes of profiles/tools/heavy_leg_only.py --only ...
 CS_DEFAULT_KERNEL = "ngm::cs_canon_kernel<3, 6, 2, 1, 7, true>"
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 COMP = np.zeros(256, np.uint8)
@@ -529,7 +530,8 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
         write_fastq(rows[:n], fs)
         return fs
     cpu_err = None
-    if with_cpu:
+    with_e2e = args.heavy_tail_e2e_reads > 0 and affine
+    if with_cpu or with_e2e:
         try:
             t0 = time.perf_counter()
             with open(fa, "w") as f:
@@ -537,7 +539,9 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
             ref.write_ngm_cache(fa)
             t_cache = time.perf_counter() - t0
         except Exception as e:
-            with_cpu, cpu_err = False, str(e)[:300]
+            with_cpu, with_e2e, cpu_err = False, False, str(e)[:300]
+
+    kept, kept_sets = {}, {}   # per sub-leg: the reference's SAM of the cpu_baseline slice, the read sets (the end-to-end run below starts with them)
 
     def sub_leg(tag, share, seed0):
         nonlocal t_load
@@ -591,6 +595,16 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
         dom = max(kernels, key=lambda k_: kernels[k_][0])
         dom_ms, dom_bytes, dom_note = kernels[dom]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = traffic_source = None
+        if dom == "candidate_search":
+            fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", HEAVY_CS_TRAFFIC_FILE % ("uniform" if share == 0.0 else "repeats"))
+            try:
+                with open(fn) as f:
+                    tj = json.load(f)
+                traffic = int(tj["candidate_search_bytes_per_batch"]) * W   # (a step = W searches of R / W reads, as in the PMC pass)
+                traffic_source = "profiles/" + os.path.basename(fn) + " [candidate_search_bytes_per_batch x %d searches per step]" % W
+            except (OSError, ValueError, KeyError):
+                pass
         nr = max(1, pc["reads"])
         ms_step = elapsed / steps * 1e3
         all_k = float(km[:7].sum())
@@ -607,20 +621,22 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
                "gpu_kernels_fraction_of_step": {"stage_kernels": all_k / ms_step, "with_order_replay": (all_k + km[8]) / ms_step},
                "sw_gcells_per_s": {"score_kernel": n_cand * READ_LEN * band / (km[2] * 1e-3) / 1e9 if km[2] > 0 else None,
                                    "align_kernel": n_aln * READ_LEN * band / (km[5] * 1e-3) / 1e9 if km[5] > 0 else None},
-               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                            "traffic_over_algorithmic": (traffic / dom_bytes) if traffic and dom_bytes else None,
                             "kernel": dom, "kernel_note": dom_note, "kernel_ms_per_step": float(dom_ms), "bytes_per_step": int(dom_bytes),
                             "note": "the kernel group with the largest GPU time per step of THIS workload; achieved = its algorithmic bytes (SURVEY.md 8d) / its HIP-event "
-                                    "time on the launch streams (summed over the mapper instances); traffic: no PMC pass of this leg is consulted in the run "
-                                    "(profiles/r05_heavy_tail_pmc_hbm.csv holds the committed one)"},
+                                    "time on the launch streams (summed over the mapper instances); traffic = HBM bytes per step of the same group from this round's committed "
+                                    "rocprofv3 PMC passes of this sub-leg (FETCH_SIZE / WRITE_SIZE in separate passes, profiles/summarize_rocprof.py), per search x the "
+                                    "searches of a step -- not measured in this run"},
                "accuracy": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
                "setup_s": {"read_sets": t_reads}}
         if with_cpu:
             try:
                 if t_load == 0.0:
                     t_load = run_ref(slice_files(sets[0][0], 2, "h_one"), os.path.join(workdir, "h_one.sam"), threads)
-                pilot = min(4000, R) & ~1
-                t_pilot = max(run_ref(slice_files(sets[0][0], pilot, "h_pilot"), os.path.join(workdir, "h_pilot.sam"), threads) - t_load, 1e-3)
-                ns = int(min(args.heavy_tail_cpu_reads, R, max(pilot, 8.0 * pilot / t_pilot))) & ~1
+                # (a sample large enough that the paths only this genome takes are in it -- 50 000 records by default, 1-2.5
+                # minutes of the reference on a 16-CPU quota -- instead of what it maps in ~8 s)
+                ns = int(min(args.heavy_tail_cpu_reads, R)) & ~1
                 fs = slice_files(sets[0][0], ns, "h_" + tag[:4])
                 ref_sam, hip_sam = os.path.join(workdir, "h_ref.sam"), os.path.join(workdir, "h_hip.sam")
                 t_all = run_ref(fs, ref_sam, threads)
@@ -632,7 +648,9 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
                 if rr.returncode != 0:
                     raise RuntimeError("ngm-hip failed: " + (rr.stdout + rr.stderr)[-400:])
                 mio = re.search(r"Input to output: ([0-9.]+) s", rr.stdout + rr.stderr)
-                same, diffs = _sam_diff(_sam_body(ref_sam), _sam_body(hip_sam))
+                ref_body = _sam_body(ref_sam)
+                kept[tag] = (ns, ref_body)
+                same, diffs = _sam_diff(ref_body, _sam_body(hip_sam))
                 res["cpu_baseline"] = {"value": ns / t_map, "unit": "reads/s", "cores": threads, "cpu_quota": cores, "kind": "reference",
                                        "sample": "NextGenMap 0.5.5 ngm-core --affine -t %d (%d hardware threads visible, cgroup quota %d CPUs) on the first %d reads of this sub-leg's "
                                                  "read set 0 vs the same genome (index from the cache files this library wrote): %.1f s total minus %.1f s index load / start-up "
@@ -652,15 +670,91 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
         elif cpu_err:
             res["cpu_baseline"] = {"error": cpu_err}
         del d_sets
+        kept_sets[tag] = [t_[0] for t_ in sets]
         return res
 
     out = {"genome": "tests/humanlike.py make_genome(%d Mbp, 24 contigs, seed 20260929): %d repeat instances; automatic max. k-mer frequency %d (uniform genome: 100)"
                      % (args.heavy_tail_mbp, len(G.repeats), ref.auto_max_kfreq),
            "mapper_instances_per_gpu": W,
            "setup_s": {"genome_generation": t_gen, "encode+index_build": t_index, "index_entries": ref.index_entries, "cache_files_for_the_reference_program": t_cache}}
-    out["reads_drawn_uniformly"] = sub_leg("reads_drawn_uniformly", 0.0, 20260930)
-    out["half_of_the_reads_from_repeats"] = sub_leg("half_of_the_reads_from_repeats", args.heavy_tail_repeat_share, 20261930)
-    out["value"] = out["reads_drawn_uniformly"]["value"]
+    only = getattr(args, "heavy_tail_only", "both")   # (profiles/tools/heavy_leg_only.py --only: one sub-leg, for the PMC passes)
+    if only in ("both", "uniform"):
+        out["reads_drawn_uniformly"] = sub_leg("reads_drawn_uniformly", 0.0, 20260930)
+    if only in ("both", "repeats"):
+        out["half_of_the_reads_from_repeats"] = sub_leg("half_of_the_reads_from_repeats", args.heavy_tail_repeat_share, 20261930)
+    for m_ in mps:
+        m_.close()
+    mps = []
+    if with_e2e:
+        # BASELINE config #3 verbatim on THIS genome: the product, `ngm-hip -1 a_1.fq -2 a_2.fq --affine -o out.sam`, on
+        # --heavy-tail-e2e-reads reads drawn uniformly, from the first input byte to the closed SAM file (src/NGM_main.cpp:85-178 is what it
+        # stands for), --e2e-runs times (median).  The input starts with the read sets of the sub-leg above, so its first records are the
+        # cpu_baseline slice: the SAM of the big run is compared with the reference's SAM of that slice.
+        try:
+            import gc
+            ne = args.heavy_tail_e2e_reads & ~1
+            t0 = time.perf_counter()
+            parts, have = [], 0
+            for rows_ in kept_sets.get("reads_drawn_uniformly", []):
+                if have < ne:
+                    parts.append(rows_[:ne - have])
+                    have += len(parts[-1])
+            k_ = 0
+            while have < ne:
+                nn = min(2_000_000, ne - have) & ~1
+                st_ = HL.sample_starts(G, nn // 2 if paired else nn, 400 if paired else READ_LEN, seed=20270101 + 17 * k_, repeat_share=0.0)
+                parts.append(make_reads(G.contigs, nn, seed=20270102 + 17 * k_, paired=paired, subs=args.subs, indel_bases=args.indel_bases, starts=st_)[0])
+                have += nn
+                k_ += 1
+            rows_all = np.concatenate(parts)
+            del parts
+            efs = [os.path.join(workdir, "he2e_1.fq"), os.path.join(workdir, "he2e_2.fq")] if paired else [os.path.join(workdir, "he2e.fq")]
+            rec = write_fastq(rows_all, efs)
+            del rows_all
+            gc.collect()
+            t_make = time.perf_counter() - t0
+            esam = os.path.join(workdir, "he2e.sam")
+            runs = []
+            for rep_ in range(max(1, args.e2e_runs)):
+                if rep_ > 0:
+                    os.remove(esam)
+                    os.sync()
+                cmd = [B.CLI, "-r", fa] + inputs(efs) + ["-o", esam, "--workers", str(W)] + common   # (as many mapper instances as the resident leg above)
+                t1 = time.perf_counter()
+                rr = subprocess.run(cmd, capture_output=True, text=True)
+                wall = time.perf_counter() - t1
+                log = rr.stdout + rr.stderr
+                if rr.returncode != 0 or "Done" not in log:
+                    raise RuntimeError("ngm-hip failed: " + log[-600:])
+                mio = re.search(r"Input to output: ([0-9.]+) s", log)
+                mi = re.search(r"Reference and index ready: ([0-9.]+) s", log)
+                mg = re.search(r"GPU kernels: ([0-9.]+) s of the ([0-9.]+) s mapping pass", log)
+                runs.append({"io": float(mio.group(1)) if mio else wall, "index": float(mi.group(1)) if mi else None, "wall": wall,
+                             "gpu": float(mg.group(1)) if mg else None, "pass": float(mg.group(2)) if mg else None, "log": log})
+            ios = sorted(r_["io"] for r_ in runs)
+            med = ios[len(ios) // 2]
+            hm = [r_ for r_ in runs if r_["io"] == med][0]
+            e2e = {"reads": ne, "value": ne / med, "unit": "reads/s", "seconds_first_input_byte_to_sam_closed": med,
+                   "runs": {"n": len(runs), "seconds_min_median_max": [ios[0], med, ios[-1]], "reads_per_s_min_median_max": [ne / ios[-1], ne / med, ne / ios[0]],
+                            "per_run": [{"input_to_output_s": r_["io"], "mapping_pass_s": r_["pass"], "gpu_kernel_s": r_["gpu"], "index_load_s": r_["index"], "process_wall_s": r_["wall"]} for r_ in runs]},
+                   "index_load_s": hm["index"], "process_wall_s": hm["wall"], "sam_bytes": os.path.getsize(esam), "fastq_bytes": len(efs) * (ne // len(efs)) * rec, "make_input_s": t_make,
+                   "command": " ".join(["ngm-hip"] + cmd[1:]),
+                   "cli_log_tail": [l for l in hm["log"].splitlines() if "Candidate search:" in l or "Heavy-read kernel:" in l or "Candidate order replay:" in l or "Done" in l][-5:],
+                   "input": "%d x %d bp %s drawn uniformly from the GRCh38-like genome, plain FASTQ, page cache warm; index from NextGenMap cache files" % (ne // 2 if paired else ne, READ_LEN, "pairs" if paired else "reads")}
+            if "reads_drawn_uniformly" in kept:
+                ns_, ref_body = kept["reads_drawn_uniformly"]
+                same, diffs = _sam_diff(ref_body, _sam_body(esam, ns_))
+                e2e["parity_vs_reference_sam"] = {"records_compared": len(ref_body), "identical_lines": same, "first_differences": diffs,
+                                                  "note": "the first %d records of this run's SAM against ngm-core --affine -t N on those reads (the cpu_baseline slice of reads_drawn_uniformly)" % ns_}
+            out["end_to_end"] = e2e
+            for fn in efs + [esam]:
+                try:
+                    os.remove(fn)
+                except OSError:
+                    pass
+        except Exception as e:
+            out["end_to_end"] = {"error": str(e)[:400]}
+    out["value"] = out.get("reads_drawn_uniformly", out.get("half_of_the_reads_from_repeats"))["value"]
     out["unit"] = "reads/s"
     out["note"] = "value = the sub-leg with the reads drawn uniformly; both sub-legs carry their own roofline and cpu_baseline"
     for m_ in mps:
@@ -700,7 +794,7 @@ def main():
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
     ap.add_argument("--no-reference-rerun", action="store_true", help="skip the second -t N run of the reference program (its own run-to-run differences)")
     ap.add_argument("--heavy-tail-workers", type=int, default=8, help="mapper instances per GPU of the heavy-tailed leg (round 5: its kernels are 0.65-0.8 of a step with four, the heavy reads take three host round trips per batch; measured 2.52 M reads/s with 4, 2.49 with 6, 2.70 with 8, 2.57 with 12)")
-    ap.add_argument("--workers", type=int, default=2, help="mapper instances (streams + host threads) per GPU")
+    ap.add_argument("--workers", type=int, default=3, help="mapper instances (streams + host threads) per GPU (round 6, one box, 20 steps each: 2 / 3 / 4 instances 43.7 / 53.4 / 52.4 M reads/s -- a batch's host stages are 10-12 ms of its 20-24 ms, so two instances leave the GPU idle a third of the time)")
     ap.add_argument("--read-sets", type=int, default=4, help="distinct sets of reads-per-step reads the timed steps rotate through (step i maps set i mod this)")
     ap.add_argument("--read-len", type=int, default=150, help="read length (150: BASELINE config #2/#3; 250: config #5's shape)")
     ap.add_argument("--corridor", type=int, default=0, help="band width; 0: NextGenMap's 5 + 0.15 * read length")
@@ -717,7 +811,8 @@ def main():
     ap.add_argument("--ngm-hip-exe", default=None, help="the program of the sharded end-to-end leg (default: nextgenmap_amd/ngm-hip; tests pass a stand-in)")
     ap.add_argument("--heavy-tail-mbp", type=float, default=3100.0, help="size of the GRCh38-like (heavy-tailed k-mer spectrum) genome of the second leg; 0: skip")
     ap.add_argument("--heavy-tail-steps", type=int, default=4)
-    ap.add_argument("--heavy-tail-cpu-reads", type=int, default=400_000, help="most reads of a heavy-tail sub-leg's cpu_baseline sample (what the reference maps in ~8 s, at most this; 0: none)")
+    ap.add_argument("--heavy-tail-cpu-reads", type=int, default=50_000, help="reads of a heavy-tail sub-leg's cpu_baseline sample (the reference maps 350-800 of them per second; 0: none)")
+    ap.add_argument("--heavy-tail-e2e-reads", type=int, default=10_000_000, help="reads of the ngm-hip run on the GRCh38-like genome, FASTQ -> closed SAM (BASELINE config #3; 0: skip)")
     ap.add_argument("--heavy-tail-repeat-share", type=float, default=0.5)
     args = ap.parse_args()
     global Q, C, READ_LEN

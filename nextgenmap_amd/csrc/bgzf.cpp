@@ -82,7 +82,7 @@ extern "C" ngm_bgzf *ngm_bgzf_create(int device) {
 	ok = ok && hipStreamCreateWithFlags(&z->st, hipStreamNonBlocking) == hipSuccess;
 	ok = ok && hipMalloc(&z->d_tables, kTabBytes) == hipSuccess && hipMemcpy(z->d_tables, t.data(), kTabBytes, hipMemcpyHostToDevice) == hipSuccess;
 	ok = ok && hipMalloc(&z->d_scratch, (size_t) z->grid * ngm::bgzf::kSegs * ngm::bgzf::kMatCap * sizeof(uint2)) == hipSuccess;
-	if (getenv("NGM_HIP_BGZF_PHASES")) ok = ok && hipMalloc(&z->d_phases, 64) == hipSuccess;
+	if (getenv("NGM_HIP_CS_PHASES")) ok = ok && hipMalloc(&z->d_phases, 64) == hipSuccess;   // (the diagnostics switch of the search kernels: phases of the deflate kernel too)
 	ok = ok && hipEventCreate(&z->ev0) == hipSuccess && hipEventCreate(&z->ev1) == hipSuccess;
 	ok = ok && hipFuncSetAttribute((const void *) ngm::bgzf::deflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ngm::bgzf::deflate_lds_bytes()) == hipSuccess;
 	if (!ok) { ngm::pipeline_set_error("GPU BGZF compressor: set-up failed on device %d (%s)", device, hipGetErrorString(hipGetLastError())); ngm_bgzf_destroy(z); return nullptr; }

@@ -594,9 +594,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 		hipLaunchKernelGGL(ngm::select_top1_kernel, dim3((n + 255) / 256), dim3(256), 0, m->st, n, m->d_cand_base.p, m->d_cand_count.p,
 				m->d_scores.p, m->d_out_loc.p, m->d_out_sv.p, m->d_winner.p, m->d_mapq.p, m->d_nbest.p, m->d_best.p);
 		MAP_HIP_TRY(hipGetLastError());
-		static const bool pair_gpu = !getenv("NGM_HIP_HOST_PAIR_PASS1");
 		const bool pe_select = paired && !m->fast_pairing;   // --fast-pairing: the mates are selected single-end, the writer checks the pair (AlignmentBuffer.cpp:176-199)
-		const bool simple_on_gpu = pe_select && pair_gpu && m->prm.strata == 0;   // (--strata touches NH of every pair: host)
+		const bool simple_on_gpu = pe_select && m->prm.strata == 0;   // (--strata touches NH of every pair: host)
 		// ... and the pairs with choices: everything the scores alone decide (pair_device.h); NGM_HIP_HOST_PAIR_CHOICE=1 keeps the host's walk
 		// (which side walks the pairs with choices depends on the workload: with ~1.2 candidates per read -- a genome without a heavy tail --
 		// the pairs with choices have two or three candidates, the host's pass 1 is 1.4 ms on the pool beside the other instance's kernels,
@@ -655,8 +654,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			MAP_HIP_TRY(hipStreamSynchronize(m->st));
 		}
 		lap(1);
-		static const bool position_order = getenv("NGM_HIP_POSITION_ORDER") != nullptr;
-		if ((!paired || m->fast_pairing) && m->prm.topn <= 1 && !position_order) {
+		if ((!paired || m->fast_pairing) && m->prm.topn <= 1) {
 			// several candidates share the best score: the reference keeps the first one in ITS candidate order
 			// (ScoreBuffer::top1SE over CollectResultsStd's rList order); replay the votes of just those reads
 			std::vector<uint32_t> tied;
@@ -845,7 +843,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			need.insert(need.end(), se_tied.begin(), se_tied.end());
 			qlap(0);
 			uint32_t *h_rank_pe = nullptr;
-			if (!need.empty() && !position_order) if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
+			if (!need.empty()) if (int rc = candidate_order(m, need, np, &h_rank_pe)) return rc;
 			qlap(1);
 			// Pass 3 (parallel, outside the turn): the in-window combinations of the picked pairs in the reference's order
 			std::vector<PairSeq> seqs(picked.size());
@@ -901,7 +899,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			if (!late.empty()) {
 				std::vector<uint32_t> need_late;
 				for (int x : late) { need_late.push_back((uint32_t) (2 * tied[x].pi)); need_late.push_back((uint32_t) (2 * tied[x].pi + 1)); }
-				if (!position_order) if (int rc = candidate_order(m, need_late, np, &h_rank_pe)) return rc;
+				if (int rc = candidate_order(m, need_late, np, &h_rank_pe)) return rc;
 				const size_t s0 = seqs.size();
 				seqs.resize(s0 + late.size());
 				parallel_for((int) late.size(), [&](int lo, int hi) { for (int x = lo; x < hi; ++x) { build_seq(seqs[s0 + x], tied[late[x]].pi); tied[late[x]].seq = (int) (s0 + x); } }, 8);
@@ -940,7 +938,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			tn_pairs.assign((size_t) n * topn, 0xFFFFFFFFu);
 			// equally scoring candidates keep the reference's candidate order (the cut at -n is order dependent)
 			uint32_t *h_rank_tn = nullptr;
-			if (!getenv("NGM_HIP_POSITION_ORDER")) {
+			{
 				std::vector<uint32_t> need;
 				for (int i = 0; i < n; ++i) {
 					const uint32_t b = m->h_base[i], cnt = m->h_count[i];
@@ -1302,7 +1300,6 @@ void *ngm_host_alloc(size_t bytes) {
 void ngm_host_free(void *p) { if (p) (void) hipHostFree(p); }
 
 int ngm_host_pin_to_device_node(int device) {
-	if (getenv("NGM_HIP_NO_NUMA_PIN")) return 0;
 	char bdf[64] = {0};
 	if (hipDeviceGetPCIBusId(bdf, (int) sizeof(bdf), device) != hipSuccess) { ngm::pipeline_set_error("no PCI bus id for device %d", device); return -19; }
 	for (char *c = bdf; *c; ++c) *c = (char) tolower((unsigned char) *c);

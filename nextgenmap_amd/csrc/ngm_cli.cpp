@@ -291,8 +291,6 @@ Opts parse(int argc, char **argv) {
 	if (o.ref_score_buffer < 0) o.ref_score_buffer = o.affine ? 1024 : 0;
 	if (o.devices.empty()) o.devices.assign(1, o.device);
 	o.device = o.devices[0];
-	if (getenv("NGM_HIP_WORKERS")) o.workers = std::max(1, atoi(getenv("NGM_HIP_WORKERS")));
-	if (getenv("NGM_HIP_SERIAL_READER")) o.serial_reader = 1;
 	if (o.broken_pairs) {
 		if (!(o.paired && !o.qry.empty())) die("--broken-pairs only works with interleaved paired-end files.");   // ReadProvider.cpp:176-179
 		if (o.shard_n > 1 || o.shard_output) die("--broken-pairs cannot be combined with --shard / --shard-output: the pairing of the records is decided while they are read");
@@ -340,11 +338,10 @@ struct MappedFile {
 	void trim() { while (n > 0 && (p[n - 1] == '\n' || p[n - 1] == '\r' || p[n - 1] == ' ' || p[n - 1] == '\t')) --n; }
 	// .gz input: inflated ONCE into memory (zlib, one thread per file -- the two files of a pair at the same time) and then read
 	// like a mapped plain file by all pool threads, instead of twice through a line-by-line reader (estimation pass, mapping pass).
-	// Inputs that inflate to more than NGM_HIP_GZ_MEMORY_GB (default 64) per file go through the serial reader.
+	// Inputs that inflate to more than 64 GB per file go through the serial reader.
 	bool inflate_all(const char *path) {
-		const char *e = getenv("NGM_HIP_GZ_MEMORY_GB");
-		const size_t cap_max = (size_t) std::max(1, e ? atoi(e) : 64) << 30;
-		if (!getenv("NGM_HIP_GZ_ZLIB")) {   // (set: zlib's inflate, the reader of rounds 2-3 -- also what a stream gz_inflate.h refuses falls back to)
+		const size_t cap_max = (size_t) 64 << 30;
+		{   // (what gz_inflate.h refuses -- a damaged stream, a wrong CRC or length -- falls back to zlib's inflate below)
 			char *text = nullptr;
 			size_t len = 0, reserved = 0;
 			if (ngm::gz::inflate_file(path, &text, &len, &reserved, cap_max)) {
@@ -827,7 +824,7 @@ int main(int argc, char **argv) {
 		const bool early_gpu_bam = o.bam && !o.slam_seq && !getenv("NGM_HIP_BAM_ZLIB") && !getenv("NGM_HIP_BAM_HOST_RECORDS");
 		const bool early_gpu_sam = (!o.bam || early_gpu_bam) && early_topn == 1 && !o.broken_pairs && !getenv("NGM_HIP_HOST_SAM");
 		const bool early_gpu_bgzf = o.bam && !early_gpu_sam && !getenv("NGM_HIP_BAM_ZLIB");
-		if ((early_gpu_sam || early_gpu_bgzf) && !(o.qry.empty() && o.qry1.empty()) && !o.out.empty() && !getenv("NGM_HIP_NO_EARLY_PINNED")) {
+		if ((early_gpu_sam || early_gpu_bgzf) && !(o.qry.empty() && o.qry1.empty()) && !o.out.empty()) {
 			size_t peek_max = 0;
 			if (o.max_read_length > 0) peek_max = (size_t) o.max_read_length;
 			else {
@@ -974,7 +971,7 @@ int main(int argc, char **argv) {
 	const auto t_indexed = std::chrono::steady_clock::now();
 	// ---- sensitivity (ReadProvider.cpp:310-385) -----------------------------------------------------------
 	// The estimate of the reference runs even when -s sets the value (its result is then only logged, ReadProvider.cpp:359-365): in that
-	// case it runs beside the set-up of the mappers instead of in front of it (NGM_HIP_SYNC_ESTIMATE=1: in front, as without -s).
+	// case it runs beside the set-up of the mappers instead of in front of it.
 	std::thread estimate_thread;
 	struct JoinEstimate { std::thread &t; ~JoinEstimate() { if (t.joinable()) t.join(); } } join_estimate{estimate_thread};
 	// (on its own thread the estimate never ends the process: its value is only logged there, so a failure is a note and the run goes on)
@@ -1044,7 +1041,7 @@ int main(int argc, char **argv) {
 		if (o.sensitivity < 0) info("INPUT", "Sensitivity parameter set to 0.5");   // ReadProvider.cpp:317, :378-386: no estimate in this mode
 		estimated = true;
 	} else if (count >= 1000 && !sample.empty()) {
-		if (o.sensitivity >= 0 && !getenv("NGM_HIP_SYNC_ESTIMATE")) estimate_thread = std::thread([&] { float s2 = 0.5f; bool e2 = false; run_estimate(s2, e2, true); });
+		if (o.sensitivity >= 0) estimate_thread = std::thread([&] { float s2 = 0.5f; bool e2 = false; run_estimate(s2, e2, true); });
 		else run_estimate(sens, estimated, false);
 	}
 	if (o.sensitivity >= 0) sens = o.sensitivity;
@@ -1453,9 +1450,8 @@ int main(int argc, char **argv) {
 			const size_t gran = (size_t) std::max(sub_step, (o.paired && !two) ? 2 : 1);
 			auto bound = [&](int i) -> size_t { return i >= o.shard_n ? ix0.n_records : (size_t) ((unsigned __int128) ix0.n_records * (unsigned) i / (unsigned) o.shard_n) / gran * gran; };
 			const size_t rec_lo = bound(o.shard_i), rec_hi = bound(o.shard_i + 1);
-			// (NGM_HIP_FIRST_BATCH_DIV=4 makes the first batch of every worker a quarter batch so that the writer starts earlier; measured on one box,
-			// twice each: mapping pass 0.57 / 0.64 s against 0.52 / 0.54 s with whole batches -- not the default)
-			const int first_div = std::max(1, getenv("NGM_HIP_FIRST_BATCH_DIV") ? atoi(getenv("NGM_HIP_FIRST_BATCH_DIV")) : 1);
+			// (a quarter-size first batch per worker, so that the writer starts earlier, was measured slower: mapping pass 0.57 / 0.64 s against 0.52 / 0.54 s)
+			const int first_div = 1;
 			const size_t first_share = std::max<size_t>((size_t) sub_step, (size_t) per_file_reads / (size_t) first_div / (size_t) sub_step * (size_t) sub_step);
 			for (size_t r0 = rec_lo, step = 0; !failed && r0 < rec_hi; r0 += step) {
 				auto b = std::make_unique<Batch>();
@@ -1825,18 +1821,8 @@ int main(int argc, char **argv) {
 			out_cv.notify_all();
 			if (b->text) {
 				const auto t_wr = std::chrono::steady_clock::now();
-				// (NGM_HIP_WRITERS=k: the batch's text in k slices written at the same time -- experiment: one file takes 9-14 GB/s whatever the
-				// number of writers, profiles/r03_write_calibration.txt, profiles/r04_e2e_writer.txt)
-				static const int n_writers = std::max(1, getenv("NGM_HIP_WRITERS") ? atoi(getenv("NGM_HIP_WRITERS")) : 1);
-				if (b->text_len && n_writers > 1) {
-					std::vector<std::thread> io;
-					std::atomic<bool> ok{true};
-					const size_t per = ((b->text_len + n_writers - 1) / n_writers + ((size_t) 4 << 20) - 1) & ~(((size_t) 4 << 20) - 1);
-					for (size_t at = 0; at < b->text_len; at += per)
-						io.emplace_back([&, at] { if (!put_all(b->text + at, std::min(per, b->text_len - at), out_off + at)) ok = false; });
-					for (auto &t : io) t.join();
-					if (!ok) fail("write error on " + o.out);
-				} else
+				// (the batch's text in k slices written at the same time was tried: one file takes 9-14 GB/s whatever the number of writers,
+				// profiles/r03_write_calibration.txt)
 				if (b->text_len && !put_all(b->text, b->text_len, out_off)) fail("write error on " + o.out);
 				out_off += b->text_len;
 				t_write_us += (long long) std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_wr).count();

@@ -323,7 +323,6 @@ int build_buckets_kind(ngm_ref *r, int kind) {
 		const double mu = (double) r->n_entries / (double) n_pairs;
 		int lw = 2;
 		while (lw < 6 && (double) ((1 << lw) - 1) < mu + 4.0 * sqrt(mu) + 0.5) ++lw;
-		if (const char *e = getenv("NGM_HIP_CBUCKET_LOG2_WORDS")) lw = std::max(2, std::min(6, atoi(e)));  // tests
 		while (lw > 2 && ((uint64_t) n_pairs << lw) + r->n_entries + 16 >= 0xFFFFFFFFull) --lw;
 		const uint64_t words = (uint64_t) n_pairs << lw;
 		uint32_t *d = nullptr;
@@ -342,7 +341,6 @@ int build_buckets_kind(ngm_ref *r, int kind) {
 	const double mu = (double) r->n_entries / (double) n_kmers;
 	int lw = 2;
 	while (lw < 5 && (double) ((1 << lw) - 1) < mu + 4.0 * sqrt(mu) + 0.5) ++lw;
-	if (const char *e = getenv("NGM_HIP_BUCKET_LOG2_WORDS")) lw = std::max(2, std::min(5, atoi(e)));  // tests
 	// the buckets are followed by a copy of the position table, so that one 32-bit word offset addresses an inline list and a
 	// list that did not fit alike; both must stay below 2^32 words
 	while (lw > 2 && (((uint64_t) n_kmers + 1) << lw) + r->n_entries + 16 >= 0xFFFFFFFFull) --lw;
@@ -363,7 +361,7 @@ int build_index(ngm_ref *r) {
 	const uint32_t n_kmers = 1u << (2 * k);
 	uint32_t *d_keys = nullptr, *d_vals = nullptr, *d_keys2 = nullptr, *d_starts = nullptr;
 	uint64_t n = 0;
-	if (!getenv("NGM_HIP_HOST_KMER_WALK")) {
+	{
 		// the walk on the GPU (CountKmerFreq decodes a contig with bufferLength = len and DecodeRefSequence emits len - 2 bases,
 		// 'x' / NUL after that, which encode() maps to 0: the last two bases of a contig act as 'A' -- handled in the kernels)
 		if (gpu_kmer_walk(r, &d_keys, &d_vals, &n) != 0) { d_keys = d_vals = nullptr; n = 0; (void) hipGetLastError(); }  // e.g. out of memory on a shared GPU: the host walk needs no scratch
@@ -618,7 +616,7 @@ ngm_ref *ngm_ref_create_from_cache(int device, const ngm_ref_params *p, const ch
 	const std::string ht_fn = std::string(fasta_path) + "-ht-" + std::to_string(p->kmer) + "-" + std::to_string(p->kmer_skip) + ".3.ngm";
 	MappedCache fe, fh;
 	if (!fe.open(enc_fn.c_str()) || !fh.open(ht_fn.c_str())) { ngm::pipeline_set_error("no index cache next to %s", fasta_path); return nullptr; }
-	const bool timing = getenv("NGM_HIP_LOAD_TIMING") != nullptr;
+	const bool timing = getenv("NGM_HIP_HOST_TIMING") != nullptr;
 	auto t0 = std::chrono::steady_clock::now();
 	auto lap = [&](const char *what) {
 		if (!timing) return;
@@ -799,7 +797,7 @@ extern "C" {
 int ngm_ref_prepare_search(ngm_ref *r, int bs_mapping) {
 	if (!r) return -22;
 	if (bs_mapping) return 0;
-	const bool canon = (r->prm.kmer & 1) && !getenv("NGM_HIP_CS_PLAIN_BUCKETS");   // (mapper.cpp: reads of more than 256 k-mers fall back to one bucket per k-mer)
+	const bool canon = (r->prm.kmer & 1) != 0;   // (mapper.cpp: reads of more than 256 k-mers fall back to one bucket per k-mer)
 	return ngm_ref_ensure_buckets(r, canon ? 1 : 0);
 }
 

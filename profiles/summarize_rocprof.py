@@ -65,6 +65,25 @@ def main():
                 traffic["%s|grid=%d" % (name, grid)] = int(rb + wb)
         with open(os.path.join(HERE, tag + "_pmc_traffic.json"), "w") as f:
             json.dump(traffic, f, indent=1, sort_keys=True)
+        # round 6: the candidate-search GROUP per batch (every kernel of one ngm_mapper search: fast path, queue kernels, heavy classes, exact
+        # kernels, compaction), and the order replay beside it -- bench.py's heavy-tailed leg prices the group's algorithmic bytes against this
+        batches = sum(d.get("FETCH_SIZE", (0,))[0] for (name, grid), d in agg.items() if "compact_candidates_kernel" in name)
+        if batches:
+            group, replay = {}, {}
+            for (name, grid), d in agg.items():
+                fe, wr = d.get("FETCH_SIZE", (0, 0.0, 0)), d.get("WRITE_SIZE", (0, 0.0, 0))
+                total = fetch_factor(name) * fe[1] * 1024 * fe[0] + wr[1] * 1024 * wr[0]
+                if "cs_order" in name:
+                    replay[name] = replay.get(name, 0) + total
+                elif "cs_" in name or "compact_candidates" in name:
+                    group[name] = group.get(name, 0) + total
+            with open(os.path.join(HERE, tag + "_cs_traffic.json"), "w") as f:
+                json.dump({"batches": batches, "candidate_search_bytes_per_batch": int(sum(group.values()) / batches),
+                           "order_replay_bytes_per_batch": int(sum(replay.values()) / batches),
+                           "candidate_search_by_kernel_per_batch": {k: int(v / batches) for k, v in sorted(group.items())},
+                           "order_replay_by_kernel_per_batch": {k: int(v / batches) for k, v in sorted(replay.items())},
+                           "note": "FETCH_SIZE x calibrated factor + WRITE_SIZE, summed over the dispatches of the pass and divided by the "
+                                   "number of searches (dispatches of compact_candidates_kernel)"}, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
