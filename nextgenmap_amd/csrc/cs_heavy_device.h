@@ -219,18 +219,16 @@ inline size_t cs_heavy2_coarse_cap(int lists_cap, int max_kfreq) {   // items / 
 	const size_t items = ((size_t) (lists_cap / 2) * (size_t) max_kfreq) / kCsSeg + (size_t) lists_cap;
 	return (items >> kCsHeavyCoarseShift) + 4;
 }
-inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int log2_slots, size_t coarse_cap, int rows = 1) {
-	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + 3 + (size_t) rows * ((size_t) 1 << (log2_counters - 1)) + 512 + ((size_t) 2 << log2_slots)) * 4;
+inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int log2_slots, size_t coarse_cap) {
+	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + 3 + ((size_t) 1 << (log2_counters - 1)) + 512 + ((size_t) 2 << log2_slots)) * 4;
 }
 
-// ROWS2 (round 6): BOTH counter rows are filled by sweep A, over all hits, and the second sweep over the lists votes the hits whose two
-// counters are at or above T straight into the exact table: a hit is fetched twice and nothing is written to or read from a scratch
-// slice (the one-row variant fetches the lists twice, writes the survivors of row 1 -- 30-40 % of the hits of a read with 90 000 of
-// them --, and reads them twice more: 2.9 x the algorithmic bytes, and at 3.1 Gbp its middle class ran at the memory system's rate).
-// Row 2 over all hits is noisier than row 2 over the survivors, so the rows are twice as large for the reads that take this variant
-// (2 x 2^14 counters: one workgroup of 1 024 threads per CU); a read whose table overflows at the T the rows suggest goes on to the
-// one-row kernel's largest class, which takes its bins in several table passes.
-template <int NT, bool ROWS2 = false>
+// Round 6 also tried BOTH counter rows in sweep A (over all hits) with the second sweep voting straight into the table -- a hit fetched
+// twice, no scratch slice: 2.0 x the algorithmic bytes instead of 2.9 x.  The rows must then be twice as large (row 2 over all hits is
+// noisier than over the survivors): one workgroup of 1 024 threads per CU instead of two of 512, and although a read took 54 us
+// instead of 86, a CU finished fewer of them: candidate search 252 against 188 ms per step at 3.1 Gbp (profiles/r06_cs_heavy2_two_rows.patch,
+// profiles/r06_heavy_tail_two_rows_ab.txt).  The sweeps are latency chains, not traffic: reads in flight per CU decide.
+template <int NT>
 __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__restrict__ ctl, int cls, uint32_t *__restrict__ scratch, uint32_t scratch_cap,
 		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // ctl: the search's control block (cs_queue_device.h) -- the class's list length and work counter, the run's statistics   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several, [13] reads sent into a second pass
 	extern __shared__ __attribute__((aligned(16))) uint32_t cs_lds[];
@@ -248,8 +246,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 	uint32_t *cnt = cs_lds + (((size_t) ((uint32_t *) coarse - cs_lds) + (coarse_cap + 1) / 2 + 3) & ~(size_t) 3);  // [NC / 2]: two 16-bit counters per word (16-byte aligned: cleared with 128-bit stores)
 	const int log2c = A.log2_bits;
 	const uint32_t cnt_words = (1u << log2c) >> 1;
-	uint32_t *cnt2 = cnt + cnt_words;                            // ROWS2: [NC / 2] the second row
-	uint32_t *hist_n = cnt + cnt_words * (ROWS2 ? 2u : 1u);      // [256]: counters of value c (255: and above)
+	uint32_t *hist_n = cnt + cnt_words;                          // [256]: counters of value c (255: and above)
 	uint32_t *hist_h = hist_n + 256;                             // [256]: ... and the hits on them
 	uint32_t *t_keys = hist_h + 256;
 	const int log2_slots = A.log2_slots;
@@ -282,7 +279,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 		auto mark = [&](int ph) { if (dg) { const unsigned long long t2 = wall_clock64(); atomicAdd(&diag[ph], t2 - tk); tk = t2; } };
 		{
 			uint4 *c4 = reinterpret_cast<uint4 *>(cnt);   // counters, both histograms: zero; keys: empty; votes: zero
-			for (uint32_t s = tid; s < (cnt_words * (ROWS2 ? 2u : 1u) + 512u) / 4u; s += NT) c4[s] = make_uint4(0u, 0u, 0u, 0u);
+			for (uint32_t s = tid; s < (cnt_words + 512u) / 4u; s += NT) c4[s] = make_uint4(0u, 0u, 0u, 0u);
 			uint4 *k4 = reinterpret_cast<uint4 *>(t_keys), *v4 = reinterpret_cast<uint4 *>(t_votes);
 			for (uint32_t s = tid; s < n_slots / 4u; s += NT) { k4[s] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); v4[s] = make_uint4(0u, 0u, 0u, 0u); }
 		}
@@ -357,7 +354,6 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 			atomicAdd(&t_votes[slot], rev ? 0x10000u : 1u);
 		};
 		auto counter_of = [&](uint32_t hc) -> uint32_t { return (cnt[hc >> 1] >> ((hc & 1u) * 16u)) & 0xFFFFu; };
-		auto counter2_of = [&](uint32_t hc) -> uint32_t { return (cnt2[hc >> 1] >> ((hc & 1u) * 16u)) & 0xFFFFu; };
 		// histogram of the row's counters of at least `from` (hist_n: how many of each value, 255: and above; with_hits: hist_h, the hits on
 		// them) and the sum of ALL its 16-bit fields, which must be `want`: a field that wrapped into its neighbour changes the sum
 		auto row_hist = [&](const uint32_t *row, uint32_t want, uint32_t from, bool with_hits) -> bool {
@@ -413,10 +409,6 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 					if ((uint32_t) j < cn) {
 						const uint32_t hc = (bin[j] * 0x9E3779B1u) >> (32 - log2c);
 						atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
-						if (ROWS2) {
-							const uint32_t h2 = (bin[j] * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c);
-							atomicAdd(&cnt2[h2 >> 1], 1u << ((h2 & 1u) * 16u));
-						}
 					}
 				}
 				if (len <= n_short) {
@@ -456,80 +448,6 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				T_low = min(255u, max(2u, (uint32_t) ceilf(fmaxf(A.kmer_min, (float) lm * A.sensitivity))));
 				if (dg) atomicAdd(&diag[7], (unsigned long long) T_low);
 			}
-			if constexpr (ROWS2) {
-				// both rows: their sums (a 16-bit field that wrapped into its neighbour changes the sum), and per value the counters at or above
-				// it; T = the smallest value (not below what the short lists allow) for which the rarer row's counters -- about one bin with
-				// that many votes each -- leave the table a quarter of its room
-				if (!row_hist(cnt, H, 2u, false)) { failed = true; why = 1; }   // (block-uniform)
-				uint32_t suf1[4] = {0u, 0u, 0u, 0u};
-				if (wv == 0) {
-					uint32_t n4[4], sn = 0;
-#pragma unroll
-					for (int j = 0; j < 4; ++j) { n4[j] = hist_n[4 * lane + j]; sn += n4[j]; }
-					const uint32_t in_n = wave_inclusive_scan(sn, lane);
-					uint32_t below_n = in_n - sn;
-					const uint32_t tot_n = wave_last(in_n);
-#pragma unroll
-					for (int j = 0; j < 4; ++j) { suf1[j] = tot_n - below_n; below_n += n4[j]; }
-				}
-				__syncthreads();
-				for (uint32_t s2 = tid; s2 < 256u; s2 += NT) hist_n[s2] = 0;
-				__syncthreads();
-				if (!row_hist(cnt2, H, 2u, false)) { failed = true; why = 1; }
-				if (!failed) {
-					if (wv == 0) {
-						const uint32_t room = (cap * 3u) / 4u;
-						const int t_min = (int) max(max(2u, T_force), T_low);
-						uint32_t n4[4], sn = 0;
-#pragma unroll
-						for (int j = 0; j < 4; ++j) { n4[j] = hist_n[4 * lane + j]; sn += n4[j]; }
-						const uint32_t in_n = wave_inclusive_scan(sn, lane);
-						uint32_t below_n = in_n - sn;
-						const uint32_t tot_n = wave_last(in_n);
-						int my_t = 256;
-#pragma unroll
-						for (int j = 0; j < 4; ++j) {
-							const uint32_t suf2 = tot_n - below_n;
-							if (my_t == 256 && 4 * lane + j >= t_min && min(suf1[j], suf2) <= room) my_t = 4 * lane + j;
-							below_n += n4[j];
-						}
-						const int t = wave_reduce_min(my_t);
-						if (lane == 0) { s_T = (uint32_t) t; s_direct = 1u; }
-					}
-					__syncthreads();
-					T = s_T;
-					if (T > 255u) { failed = true; why = 2; }
-				}
-				mark(2);
-				if (!failed) {
-					sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t) {
-						uint32_t bin[kCsSeg], pass = 0;
-#pragma unroll
-						for (int j = 0; j < kCsSeg; ++j) {
-							bin[j] = (pos8[j] - correction) >> A.bin_shift;
-							if ((uint32_t) j < cn && counter_of((bin[j] * 0x9E3779B1u) >> (32 - log2c)) >= T && counter2_of((bin[j] * 0xC2B2AE35u + 0x27D4EB2Fu) >> (32 - log2c)) >= T) pass |= 1u << j;
-						}
-						if (pass == 0u || *(volatile uint32_t *) &s_fail) return;
-						uint32_t slot[kCsSeg], prev[kCsSeg];   // (the first probes in flight together)
-#pragma unroll
-						for (int j = 0; j < kCsSeg; ++j) {
-							slot[j] = (bin[j] * 0x85EBCA6Bu) >> (32 - log2_slots);
-							prev[j] = ((pass >> j) & 1u) ? atomicCAS(&t_keys[slot[j]], 0xFFFFFFFFu, bin[j]) : 0u;
-						}
-#pragma unroll
-						for (int j = 0; j < kCsSeg; ++j) if ((pass >> j) & 1u) {
-							uint32_t sl = slot[j], pv = prev[j];
-							for (uint32_t probes = 0; pv != bin[j] && pv != 0xFFFFFFFFu && probes < n_slots; ++probes) {
-								sl = (sl + 1) & (n_slots - 1);
-								pv = atomicCAS(&t_keys[sl], 0xFFFFFFFFu, bin[j]);
-							}
-							if (pv == 0xFFFFFFFFu) { if (atomicAdd(&s_entries, 1u) >= cap) atomicExch(&s_fail, 1u); }
-							else if (pv != bin[j]) { atomicExch(&s_fail, 1u); continue; }   // (the table is full: not reached, the entry count fails the read first)
-							atomicAdd(&t_votes[sl], rev ? 0x10000u : 1u);
-						}
-					});
-				}
-			} else {
 			// histogram of the counter values -- and their sum: a 16-bit field that wrapped into its neighbour changes it
 			if (!row_hist(cnt, H, 2u, true)) { failed = true; why = 1; }   // (block-uniform)
 			if (!failed) {
@@ -794,7 +712,6 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 					continue;
 				}
 			}
-			}   // (one row)
 		} else {
 			sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t) {
 #pragma unroll

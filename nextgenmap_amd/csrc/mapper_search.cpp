@@ -69,12 +69,12 @@ long test_limit(const char *key, long dflt) {
 
 // the classes of cs_heavy2_kernel: reads of up to max_hits index hits start in the class; counters, table slots, threads, survivors
 // the scratch slice holds, table passes a read may take (the largest class)
-struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; uint32_t scratch_cap; const void *fn; uint32_t max_parts; int rows; };   // rows 2: cs_heavy2_kernel<NT, true> (both counter rows in sweep A, no scratch)
+struct HeavyClass { uint32_t max_hits; int log2c, log2s, nt; uint32_t scratch_cap; const void *fn; uint32_t max_parts; };
 // (limits measured on the heavy-tailed probe, per 262 144 reads: 16 384 / 32 768 / rest 18.3 ms; 16 384 / 65 536 / rest 16.1; 16 384 / all the
 // rest in the middle class -- two workgroups per CU -- and the largest class only for what that cannot certify: 15.1)
 const HeavyClass *heavy_classes() {
-	static HeavyClass cl[3] = {{16384u, 13, 11, 256, 16384u, (const void *) cs_heavy2_kernel<256>, 1u, 1}, {0xFFFFFFFEu, 14, 13, 1024, 0u, (const void *) cs_heavy2_kernel<1024, true>, 1u, 2},
-			{0xFFFFFFFFu, 15, 13, 1024, 1u << 20, (const void *) cs_heavy2_kernel<1024>, 32u, 1}};
+	static HeavyClass cl[3] = {{16384u, 13, 11, 256, 16384u, (const void *) cs_heavy2_kernel<256>, 1u}, {0xFFFFFFFEu, 14, 12, 512, 262144u, (const void *) cs_heavy2_kernel<512>, 1u},
+			{0xFFFFFFFFu, 15, 13, 1024, 1u << 20, (const void *) cs_heavy2_kernel<1024>, 32u}};
 	static const bool once = [] {
 		const long shrink_c = test_limit("heavy_log2c", 0), shrink_s = test_limit("heavy_log2s", 0);   // log2 of the SMALLEST class's counters / slots; the others follow
 		if (shrink_c > 0) for (int c = 0; c < 3; ++c) cl[c].log2c = (int) std::min<long>(cl[c].log2c, std::max<long>(6, shrink_c + c));
@@ -82,7 +82,6 @@ const HeavyClass *heavy_classes() {
 		const long m0 = test_limit("heavy_max0", 0), m1 = test_limit("heavy_max1", 0);
 		if (m0 > 0) { cl[0].max_hits = (uint32_t) m0; cl[0].scratch_cap = std::min<uint32_t>(cl[0].scratch_cap, (uint32_t) m0); }
 		if (m1 > 0 && m1 >= (long) cl[0].max_hits) cl[1].max_hits = (uint32_t) m1;
-		if (test_limit("heavy_one_row", 0)) cl[1] = HeavyClass{cl[1].max_hits, std::min(cl[1].log2c, 14), std::min(cl[1].log2s, 12), 512, 262144u, (const void *) cs_heavy2_kernel<512>, 1u, 1};   // (A/B: round 5's middle class)
 		const long sc = test_limit("heavy_scratch", 0);
 		if (sc > 0) for (int c = 1; c < 3; ++c) cl[c].scratch_cap = std::min<uint32_t>(cl[c].scratch_cap, (uint32_t) sc << (c - 1));
 		return true; }();
@@ -185,7 +184,6 @@ int cs_configure(ngm_mapper *m, const ngm_mapper_params *p) {
 	(void) hipFuncSetAttribute((const void *) cs_heavy2_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAttr);
 	(void) hipFuncSetAttribute((const void *) cs_heavy2_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAttr);
 	(void) hipFuncSetAttribute((const void *) cs_heavy2_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAttr);
-	(void) hipFuncSetAttribute((const void *) cs_heavy2_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAttr);
 	(void) hipFuncSetAttribute((const void *) cs_order_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAttr);  // per device
 	(void) hipFuncSetAttribute((const void *) cs_order_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsAttr);
 	if (p->bs_mapping) { A.bs = 1; A.lists_cap = 2 * kCsBsChunk; A.log2_slots = std::min(A.log2_slots, 13); }
@@ -444,7 +442,7 @@ int run_cs(ngm_mapper *m, int n, GpuStage *stage) {
 				int grid[3] = {0, 0, 0};
 				size_t lds[3] = {0, 0, 0}, words[3] = {0, 0, 0};
 				for (int c = 0; c < 3; ++c) {
-					lds[c] = cs_heavy2_lds_bytes(A.lists_cap, A.q, classes[c].log2c, classes[c].log2s, coarse_cap, classes[c].rows);
+					lds[c] = cs_heavy2_lds_bytes(A.lists_cap, A.q, classes[c].log2c, classes[c].log2s, coarse_cap);
 					if (lds[c] > (size_t) kLdsAttr) { grid[c] = 0; continue; }   // (very long reads: the class's lists do not fit beside its table -- its reads go on to the exact kernels)
 					int &per_cu = m->heavy_per_cu[c];
 					if (per_cu <= 0 || m->heavy_lds[c] != lds[c]) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, classes[c].fn, classes[c].nt, lds[c]) != hipSuccess || per_cu < 1) per_cu = 1; m->heavy_lds[c] = lds[c]; }
