@@ -345,6 +345,143 @@ __global__ __launch_bounds__(256) void sw_affine_score_pk_kernel(const uint32_t 
 	if (hasB && pairB < n) { if (lenVB < 1 || lenHB < 1) bestB = 0; scores[pairB] = (float) bestB; }
 }
 
+// Score-only variant for WIDE bands (round 6; BASELINE config 5: 250 bp reads, corridor 80), local mode: the band's columns split over
+// TWO lanes.  With 81 columns sw_affine_score_pk_kernel keeps S and Ev of the whole band in 162 VGPRs (338 with the window queue): one
+// wave per SIMD, and the dependent packed operations of a row wait for each other with nothing to hide behind (3.4 Tcells/s against
+// 5.1 at 28 columns).  Here lanes 2k / 2k + 1 share slot k of a block pair: the even lane owns band columns [0, CL), the odd lane
+// [CL, CP), and the odd lane runs ONE ROW BEHIND, which is what makes the split legal --
+//   Eh(v, d) needs (v, d - 1): the odd lane's first column of row v - 1 needs the even lane's last column of row v - 1, finished one
+//   step earlier (kept in saveS / saveEh);
+//   Ev(v, d) needs (v - 1, d + 1): the even lane's last column of row v needs the odd lane's first column of row v - 1, which the odd
+//   lane computes first thing in the same step.
+// Two DPP swaps in each direction per row; everything else is the one-lane kernel on half the columns: the odd lane's window queue
+// starts CL - 1 bytes further (a multiple of eight: whole words), its read character and re-basing floor are the even lane's of the
+// step before.  Step 0 has no row for the odd lane: it computes on a NUL class and is put back to the initial state afterwards (a
+// wave-uniform branch, once per pair).  When CP is odd the odd lane's last column does not exist and is held at "unreachable".
+// 181 VGPRs: two waves per SIMD.  (Held to 168 for three waves -- amdgpu_waves_per_eu(3, 3) -- the kernel spills 15 registers to scratch:
+// alone it is faster still (282 against 335 ms per step of BASELINE config 5's shape, 5.6 against 4.6 Tcells/s), but the step is slower
+// (500-512 against 466-476 ms, two alternating runs each): the search and align kernels of the other mapper instances took 1.5-5 x as long
+// beside it.  profiles/r06_config5_split_kernel_ab.txt)
+template <int CP>
+__global__ __launch_bounds__(256) void sw_affine_score_pk_split_kernel(const uint32_t *__restrict__ packed, const uint16_t *__restrict__ lens,
+		const uint16_t *__restrict__ blk_rows, float *__restrict__ scores, int n, int n_blocks, int RW, AffConst K) {
+	__shared__ uint2 s_tab[8];
+	if (threadIdx.x < 8) s_tab[threadIdx.x] = aff_row_table(threadIdx.x, K);
+	__syncthreads();
+	constexpr int CL = ((CP + 1) / 2 + 6) / 8 * 8 + 1;   // columns of the even lane: CL - 1 is a multiple of 8
+	constexpr int CR = CP - CL;                          // real columns of the odd lane (the others are held unreachable)
+	static_assert(CR >= 1 && CR <= CL, "band too narrow to split");
+	constexpr int NRG = sel_regs(CL);
+	constexpr int WOFF = (CL - 1) / 8;                   // the odd lane's window starts this many words further
+	const int lane = threadIdx.x & 63;
+	const bool isR = (lane & 1) != 0;
+	const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);   // (block pair, half of its 64 slots)
+	const int blkA = 2 * (unit >> 1);
+	if (blkA >= n_blocks) return;
+	const bool hasB = blkA + 1 < n_blocks;
+	const int blkB = hasB ? blkA + 1 : blkA;
+	const int slot = (lane >> 1) + 32 * (unit & 1);
+	const int FW = RW + sel_regs(CP) / 2;
+	const uint32_t *rdA = packed + (size_t) blkA * (RW + FW) * kSlots + slot, *rdB = packed + (size_t) blkB * (RW + FW) * kSlots + slot;
+	const uint32_t *fdA = rdA + (size_t) RW * kSlots, *fdB = rdB + (size_t) RW * kSlots;
+	const int pairA = blkA * kSlots + slot, pairB = blkB * kSlots + slot;
+	const int lenVA = (pairA < n) ? (int) lens[pairA] : 0, lenVB = (pairB < n) ? (int) lens[pairB] : 0;
+	const int rows = max(__builtin_amdgcn_readfirstlane((int) blk_rows[blkA]), __builtin_amdgcn_readfirstlane((int) blk_rows[blkB]));
+	const int ngroups = (rows + 7) >> 3, ngroups2 = (rows + 1 + 7) >> 3;   // (the odd lane's last row is one step later)
+	const int woff = isR ? WOFF : 0;
+	auto swap2 = [](v2s x) -> v2s { return __builtin_bit_cast(v2s, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false)); };   // quad_perm [1, 0, 3, 2]: the other lane of the pair
+
+	v2s S[CL], Ev[CL];
+#pragma unroll
+	for (int d = 0; d < CL; ++d) { S[d] = pk_splat(0); Ev[d] = pk_splat(0); }
+	uint32_t RGA[NRG], RGB[NRG];
+#pragma unroll
+	for (int r = 0; r < NRG / 2; ++r) {
+		const int w = min(r + woff, FW - 1);
+		const uint32_t xa = fdA[(size_t) w * kSlots], xb = fdB[(size_t) w * kSlots];
+		RGA[2 * r] = xa & 0x0F0F0F0Fu; RGA[2 * r + 1] = (xa >> 4) & 0x0F0F0F0Fu;
+		RGB[2 * r] = xb & 0x0F0F0F0Fu; RGB[2 * r + 1] = (xb >> 4) & 0x0F0F0F0Fu;
+	}
+	int fl = K.tZ;                           // re-based zero of the even lane's row
+	const int rz = isR ? K.tZ : 0;           // ... the odd lane is one row behind
+	v2s best2 = pk_splat(0);
+	const v2s ext2 = pk_splat(K.ext), open2 = pk_splat(K.open), vext2 = pk_splat(K.vext), vopen2 = pk_splat(K.vopen);
+	const v2s neg2 = pk_splat(kAffNeg16), zero2 = pk_splat(0);
+	v2s saveS = neg2, saveEh = neg2;         // the even lane's last column of the step before
+	uint32_t prevA = 6u, prevB = 6u;         // read classes of the step before (the odd lane's row)
+	uint32_t rnA = (ngroups > 0) ? rdA[0] : 0x66666666u, rnB = (ngroups > 0) ? rdB[0] : 0x66666666u;
+
+	for (int g = 0; g < ngroups2; ++g) {
+		const uint32_t rxA = rnA, rxB = rnB;
+		rnA = (g + 1 < ngroups) ? rdA[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		rnB = (g + 1 < ngroups) ? rdB[(size_t) (g + 1) * kSlots] : 0x66666666u;
+		const int wn = min(g + NRG / 2 + woff, FW - 1);   // (beyond the window only behind the read's last row: those rows match nothing)
+		const uint32_t fxA = fdA[(size_t) wn * kSlots], fxB = fdB[(size_t) wn * kSlots];
+		const uint32_t rsA[2] = {rxA & 0x0F0F0F0Fu, (rxA >> 4) & 0x0F0F0F0Fu}, rsB[2] = {rxB & 0x0F0F0F0Fu, (rxB >> 4) & 0x0F0F0F0Fu};
+#pragma unroll
+		for (int s = 0; s < 8; ++s) {
+			const int i = g * 8 + s;   // the even lane's read position; the odd lane's is i - 1
+			uint32_t curA = (rsA[s >> 2] >> (8 * (s & 3))) & 0xFFu, curB = (rsB[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+			curA = (i < lenVA) ? curA : 6u;
+			curB = (i < lenVB) ? curB : 6u;
+			const uint32_t rcA = isR ? prevA : curA, rcB = isR ? prevB : curB;
+			prevA = curA; prevB = curB;
+			const uint2 TA = s_tab[rcA], TB = s_tab[rcB];
+			uint32_t PA[NRG], PB[NRG];
+#pragma unroll
+			for (int r = 0; r < NRG; ++r) {
+				const bool used = (s + CL - 1) / 4 >= r && s / 4 <= r;
+				PA[r] = used ? __builtin_amdgcn_perm(TA.y, TA.x, RGA[r]) : 0u;
+				PB[r] = used ? __builtin_amdgcn_perm(TB.y, TB.x, RGB[r]) : 0u;
+			}
+			const v2s fl2 = pk_splat(fl - rz);
+			// the odd lane's horizontal predecessor: the even lane's last column of the same row (the step before)
+			const v2s gotS = swap2(saveS), gotEh = swap2(saveEh);
+			v2s leftS = isR ? gotS : neg2, leftEh = isR ? gotEh : neg2;
+			v2s nxS = neg2, nxEv = neg2;   // the even lane's vertical predecessor of its last column: the odd lane's first column (below)
+			v2s rowmax = fl2;
+#pragma unroll
+			for (int d = 0; d < CL; ++d) {
+				const int bi = s + d, kb = bi & 3;
+				const uint32_t sel = 0x0C000C00u | (uint32_t) kb | ((uint32_t) (4 + kb) << 16);
+				const v2s t = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(PB[bi >> 2], PA[bi >> 2], sel));
+				const v2s dg = S[d] + t;
+				const v2s eh = pk_max(leftEh + ext2, leftS + open2);
+				v2s ev = (d < CL - 1) ? pk_max(Ev[d + 1] + vext2, S[d + 1] + vopen2) : pk_max(nxEv + vext2, nxS + vopen2);
+				v2s sc = pk_max(pk_max(pk_max(ev, eh), dg), fl2);   // local clamp: only S (see sw_affine_score_pk_kernel)
+				if (d >= CR) { sc = isR ? neg2 : sc; ev = isR ? neg2 : ev; }   // (CP odd: the odd lane's last column does not exist)
+				rowmax = pk_max(rowmax, sc);
+				S[d] = sc;
+				Ev[d] = ev;
+				leftS = sc;
+				leftEh = eh;
+				if (d == 0) {
+					v2s xS = swap2(sc), xEv = swap2(ev);
+					if (s == 0 && g == 0) { xS = zero2; xEv = zero2; }   // (wave-uniform) step 0: the odd lane's row 0 is the initial state
+					nxS = isR ? neg2 : xS; nxEv = isR ? neg2 : xEv;
+				}
+				if (d == CL - 1) { saveS = sc; saveEh = eh; }
+			}
+			best2 = pk_max(best2, rowmax - fl2);
+			if (s == 0 && g == 0) {   // (wave-uniform, once) the odd lane had no row in this step: back to the initial state
+#pragma unroll
+				for (int d = 0; d < CL; ++d) { S[d] = isR ? zero2 : S[d]; Ev[d] = isR ? zero2 : Ev[d]; }
+				best2 = isR ? zero2 : best2;
+			}
+			fl += K.tZ;
+		}
+#pragma unroll
+		for (int r = 0; r + 2 < NRG; ++r) { RGA[r] = RGA[r + 2]; RGB[r] = RGB[r + 2]; }
+		RGA[NRG - 2] = fxA & 0x0F0F0F0Fu; RGA[NRG - 1] = (fxA >> 4) & 0x0F0F0F0Fu;
+		RGB[NRG - 2] = fxB & 0x0F0F0F0Fu; RGB[NRG - 1] = (fxB >> 4) & 0x0F0F0F0Fu;
+	}
+	best2 = pk_max(best2, swap2(best2));
+	if (isR) return;
+	int bestA = best2.x, bestB = best2.y;
+	if (pairA < n) { if (lenVA < 1) bestA = 0; scores[pairA] = (float) bestA; }
+	if (hasB && pairB < n) { if (lenVB < 1) bestB = 0; scores[pairB] = (float) bestB; }
+}
+
 // Align variant, packed 16-bit, local mode: two pairs per lane like the score kernel above, plus what the traceback needs.
 // * Trace: 4 bits per cell instead of SeqAn's 7-bit value in a byte -- "gap opened here" for the horizontal and the vertical
 //   gap (bits 0, 1) and which of {none, diagonal, horizontal maximum, vertical maximum} the cell took (bits 2-3); the Hori /

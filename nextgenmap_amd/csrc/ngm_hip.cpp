@@ -93,6 +93,12 @@ const void *find_pk_affine_score_kernel(int c, bool endfree) {
 	return nullptr;
 }
 
+// wide bands, local mode: the band's columns split over two lanes (sw_affine_score_pk_split_kernel; three waves per SIMD instead of one)
+const void *find_pk_affine_score_split_kernel(int c) {
+	if (c == 80) return (const void *) ngm::sw_affine_score_pk_split_kernel<81>;
+	return nullptr;
+}
+
 // window = false: the plain row key (<= 32 band columns, scores below 2 048); true: the windowed one (<= 128 columns)
 template <int CP> const void *pk_affine_align_ptr(bool window) {
 	if (!window) { if constexpr (CP <= 32) return (const void *) ngm::sw_affine_align_pk_kernel<CP, false>; else return nullptr; }
@@ -151,6 +157,13 @@ int engine_score_packed(ngm_hip_ctx *ctx, int mode, int n, float *d_scores, hipS
 	if (ctx->prm.personality == NGM_PERSONALITY_AFFINE) {
 		const bool ef = (mode & NGM_MODE_ALIGN_MASK) == NGM_MODE_END_TO_END;
 		if (!force32 && (long) ctx->q * ctx->KA.tM < 30000 && ctx->prm.gap_read_penalty + (long) ctx->q * (ctx->prm.gap_extend_penalty + ctx->KA.tZ) < 19000) {
+			if (const void *sp = ef ? nullptr : find_pk_affine_score_split_kernel(ctx->c)) {
+				KernelRef kp; kp.aot = sp;
+				const int units = 2 * ((nb + 1) / 2);   // (block pair, half of its slots) per wave
+				HIP_TRY(ctx, launch_kernel(kp, dim3((units + 3) / 4), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
+						(const uint16_t *) ctx->blk_rows.p, d_scores, n, nb, ctx->RW, ctx->KA));
+				return 0;
+			}
 			if (const void *pk = find_pk_affine_score_kernel(ctx->c, ef)) {
 				KernelRef kp; kp.aot = pk;
 				HIP_TRY(ctx, launch_kernel(kp, dim3((nb + 7) / 8), dim3(256), st, (const uint32_t *) ctx->packed.p, (const uint16_t *) ctx->lens.p,
