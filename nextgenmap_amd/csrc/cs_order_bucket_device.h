@@ -188,17 +188,27 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 			// returns v of this lane's hit of a window of at most 64 hits (the caller stores it); a larger bucket is finished here
 			auto process = [&](const uint2 &e_c, uint32_t p_c, uint32_t n_c) -> uint32_t {
 				if (n_c <= 64u) {
-					// every hit of the window against every other, through scalar registers (v_readlane with a scalar loop counter: n_c comes out of
-					// LDS, and until it was made uniform by hand the compiler ran this loop under an exec mask with a waterfall around each readlane
-					// -- ~95 cycles per trip, 0.5 of the 0.6 ms of a read; walking only the lanes of the hit's own bucket by ds_bpermute was no
-					// faster: a chain of LDS round trips as long as the longest bucket, and a repeat family's bin fills a window by itself)
+					// Round 5 compared every hit of the window with every other through scalar registers: 64 trips of two v_readlane, two compares,
+					// an AND and an add -- the VALU of a CU's two waves per SIMD kept busy for ~70 cycles per trip, 290 of the 650 us of a 66 000-hit
+					// read.  Round 6 walks the window's DISTINCT keys instead (a ballot per key: which lanes hold it), and only a key held by
+					// several lanes has its holders ranked by time -- one v_readlane, one compare and one add per holder, with the other lanes'
+					// time set to 0 so that they count nothing.  A window of 64 single hits costs 64 x 2 instructions instead of 64 x 6, a window
+					// filled by one repeat-family bin 2 + 64 x 3.  (Walking a hit's own bucket by ds_bpermute, tried in round 5, was no faster.)
 					const uint32_t key = e_c.x, t = e_c.y;
 					uint32_t v = 1;
-					const uint32_t n_u = (uint32_t) __builtin_amdgcn_readfirstlane((int) n_c);
-#pragma unroll 4
-					for (uint32_t mm = 0; mm < n_u; ++mm) {
-						const uint32_t k2 = (uint32_t) __builtin_amdgcn_readlane((int) key, (int) mm), t2 = (uint32_t) __builtin_amdgcn_readlane((int) t, (int) mm);
-						v += (k2 == key && t2 < t) ? 1u : 0u;
+					unsigned long long todo = __ballot(key != 0xFFFFFFFFu);
+					while (todo) {
+						const int leader = (int) __builtin_ctzll(todo);
+						const uint32_t kL = (uint32_t) __builtin_amdgcn_readlane((int) key, leader);
+						const unsigned long long same = __ballot(key == kL);
+						todo &= ~same;
+						if (__popcll(same) > 1) {
+							const uint32_t t_m = key == kL ? t : 0u;   // (no time is below 0: the other lanes count nothing)
+							for (unsigned long long mm = same; mm; mm &= mm - 1ull) {
+								const uint32_t t2 = (uint32_t) __builtin_amdgcn_readlane((int) t, (int) __builtin_ctzll(mm));
+								v += t2 < t_m ? 1u : 0u;
+							}
+						}
 					}
 					if (key != 0xFFFFFFFFu) {
 						if (v >= n_tau) atomicExch(&s_bad, 4u); else if (t < tau[v]) atomicMin(&tau[v], t);
@@ -211,10 +221,20 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 						uint32_t v = 1;
 						for (uint32_t d0 = 0; d0 < n_b; d0 += 64u) {
 							const uint2 other = d0 + (uint32_t) lane < n_b ? my[p_c + d0 + (uint32_t) lane] : none;
-							const uint32_t lim = min(64u, n_b - d0);
-							for (uint32_t mm = 0; mm < lim; ++mm) {
-								const uint32_t k2 = (uint32_t) __builtin_amdgcn_readlane((int) other.x, (int) mm), t2 = (uint32_t) __builtin_amdgcn_readlane((int) other.y, (int) mm);
-								v += (k2 == mine.x && (t2 & 0xFFFFFu) < mine.y) ? 1u : 0u;   // (the hits in front have their v in the upper bits already)
+							const uint32_t ot = other.y & 0xFFFFFu;   // (the hits in front have their v in the upper bits already)
+							// the distinct keys of the other chunk; only those some lane of this chunk holds have their holders walked
+							unsigned long long todo = __ballot(other.x != 0xFFFFFFFFu);
+							while (todo) {
+								const uint32_t kL = (uint32_t) __builtin_amdgcn_readlane((int) other.x, (int) __builtin_ctzll(todo));
+								const unsigned long long same = __ballot(other.x == kL);
+								todo &= ~same;
+								if (__ballot(mine.x == kL) != 0ull) {
+									const uint32_t t_m = mine.x == kL ? mine.y : 0u;
+									for (unsigned long long mm = same; mm; mm &= mm - 1ull) {
+										const uint32_t t2 = (uint32_t) __builtin_amdgcn_readlane((int) ot, (int) __builtin_ctzll(mm));
+										v += t2 < t_m ? 1u : 0u;
+									}
+								}
 							}
 						}
 						if (mine.x != 0xFFFFFFFFu) {

@@ -35,13 +35,14 @@ def short(name):
 
 def main():
     tag, stats_db = sys.argv[1], sys.argv[2]
-    cur = sqlite3.connect(stats_db).cursor()
-    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
-        for name, calls, tot, avg, pct in rows:
-            w.writerow([short(name), calls, "%.3f" % tot, "%.3f" % avg, "%.2f" % pct])
+    if stats_db != "-":   # ("-": only the PMC passes)
+        cur = sqlite3.connect(stats_db).cursor()
+        rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+        with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+            for name, calls, tot, avg, pct in rows:
+                w.writerow([short(name), calls, "%.3f" % tot, "%.3f" % avg, "%.2f" % pct])
     if len(sys.argv) >= 5:
         agg = {}
         for db, ctr in ((sys.argv[3], "FETCH_SIZE"), (sys.argv[4], "WRITE_SIZE")):
