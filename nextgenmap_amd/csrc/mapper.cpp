@@ -292,9 +292,43 @@ static void sort_like_reference(uint32_t *v, uint32_t base, uint32_t cnt, const 
 	bool ranked = rank != nullptr;
 	for (uint32_t x = base; ranked && x < base + cnt; ++x) ranked = rank[x] != ngm::kCsOrderUnknown;
 	if (ranked_out) *ranked_out = ranked;
-	if (!ranked) { std::sort(v, v + cnt, [&](uint32_t x, uint32_t y) { return score[x] != score[y] ? score[x] > score[y] : by_place(x, y); }); return; }
+	if (!ranked) {
+		if (cnt > 64) {   // (a total order: any algorithm gives the same result -- sorted as records, not through the index arrays)
+			struct Rec { float s; uint32_t l, st, i; };
+			thread_local std::vector<Rec> recs;
+			recs.resize(cnt);
+			for (uint32_t x = 0; x < cnt; ++x) { const uint32_t i = base + x; recs[x] = Rec{score[i], loc[i], sv[i] & 1u, i}; }
+			std::sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) { return a.s != b.s ? a.s > b.s : a.l != b.l ? a.l < b.l : a.st < b.st; });
+			for (uint32_t x = 0; x < cnt; ++x) v[x] = recs[x].i;
+			return;
+		}
+		std::sort(v, v + cnt, [&](uint32_t x, uint32_t y) { return score[x] != score[y] ? score[x] > score[y] : by_place(x, y); });
+		return;
+	}
 	auto by_rank = [&](uint32_t x, uint32_t y) { return rank[x] != rank[y] ? rank[x] < rank[y] : by_place(x, y); };
 	if (cnt <= 16) { std::sort(v, v + cnt, [&](uint32_t x, uint32_t y) { return score[x] != score[y] ? score[x] > score[y] : by_rank(x, y); }); return; }
+	// Round 6: the same two sorts on VALUES instead of through the index arrays (a read of a repeat family has thousands of candidates, and
+	// the stress sub-leg of the bench sorts ~10 000 such lists per batch on a 16-CPU quota: every comparison was two or four cache misses).
+	// (1) the reference's candidate order: ranks are distinct (2 x the entering time of the bin + strand), so (rank << 32 | index) sorts as
+	// integers -- should two ranks ever be equal, the comparator path below decides as before; (2) std::sort by score on (score, index)
+	// records in that order: the same algorithm asked the same questions in the same sequence moves the same elements.
+	{
+		thread_local std::vector<uint64_t> keys;
+		struct Rec { float s; uint32_t i; };
+		thread_local std::vector<Rec> recs;
+		keys.resize(cnt);
+		for (uint32_t x = 0; x < cnt; ++x) keys[x] = ((uint64_t) rank[base + x] << 32) | (uint64_t) (base + x);
+		std::sort(keys.begin(), keys.end());
+		bool distinct = true;
+		for (uint32_t x = 1; x < cnt && distinct; ++x) distinct = (keys[x] >> 32) != (keys[x - 1] >> 32);
+		if (distinct) {
+			recs.resize(cnt);
+			for (uint32_t x = 0; x < cnt; ++x) { const uint32_t i = (uint32_t) keys[x]; recs[x] = Rec{score[i], i}; }
+			std::sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) { return a.s > b.s; });
+			for (uint32_t x = 0; x < cnt; ++x) v[x] = recs[x].i;
+			return;
+		}
+	}
 	std::sort(v, v + cnt, by_rank);
 	std::sort(v, v + cnt, [&](uint32_t x, uint32_t y) { return score[x] > score[y]; });
 }
