@@ -188,29 +188,30 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 			// returns v of this lane's hit of a window of at most 64 hits (the caller stores it); a larger bucket is finished here
 			auto process = [&](const uint2 &e_c, uint32_t p_c, uint32_t n_c) -> uint32_t {
 				if (n_c <= 64u) {
-					// Round 5 compared every hit of the window with every other through scalar registers: 64 trips of two v_readlane, two compares,
-					// an AND and an add -- the VALU of a CU's two waves per SIMD kept busy for ~70 cycles per trip, 290 of the 650 us of a 66 000-hit
-					// read.  Round 6 walks the window's DISTINCT keys instead (a ballot per key: which lanes hold it), and only a key held by
-					// several lanes has its holders ranked by time -- one v_readlane, one compare and one add per holder, with the other lanes'
-					// time set to 0 so that they count nothing.  A window of 64 single hits costs 64 x 2 instructions instead of 64 x 6, a window
-					// filled by one repeat-family bin 2 + 64 x 3.  (Walking a hit's own bucket by ds_bpermute, tried in round 5, was no faster.)
+					// A hit's v = 1 + the hits of its (bin, strand) with a smaller time; those can only sit in its own BUCKET, whose bounds are in LDS.
+					// Round 5 compared every hit of the window with every other through scalar registers (64 trips of two v_readlane, two compares, an
+					// AND and an add: ~5 600 cycles per window, 290 of the 650 us of a 66 000-hit read).  Round 6: every lane walks its own bucket
+					// through ds_bpermute, EIGHT trips' permutes in flight (the walk round 5 tried waited for every LDS round trip in turn: "no
+					// faster"); the trip count is the window's longest bucket -- ~8 in a window of chance hits, 64 when one repeat-family bin fills it.
 					const uint32_t key = e_c.x, t = e_c.y;
+					const bool live = key != 0xFFFFFFFFu;
+					const uint32_t bkt = live ? bucket_of(key & 0x3FFFFFFFu) : 0u;
+					const uint32_t bs = live ? bk[bkt] - p_c : (uint32_t) lane, be = live ? bk[bkt + 1u] - p_c : (uint32_t) lane;   // this lane's bucket inside the window
+					const uint32_t longest = (uint32_t) wave_reduce_max((int) (be - bs));
 					uint32_t v = 1;
-					unsigned long long todo = __ballot(key != 0xFFFFFFFFu);
-					while (todo) {
-						const int leader = (int) __builtin_ctzll(todo);
-						const uint32_t kL = (uint32_t) __builtin_amdgcn_readlane((int) key, leader);
-						const unsigned long long same = __ballot(key == kL);
-						todo &= ~same;
-						if (__popcll(same) > 1) {
-							const uint32_t t_m = key == kL ? t : 0u;   // (no time is below 0: the other lanes count nothing)
-							for (unsigned long long mm = same; mm; mm &= mm - 1ull) {
-								const uint32_t t2 = (uint32_t) __builtin_amdgcn_readlane((int) t, (int) __builtin_ctzll(mm));
-								v += t2 < t_m ? 1u : 0u;
-							}
+					for (uint32_t j0 = 0; j0 < longest; j0 += 8u) {
+						uint32_t k2[8], t2[8];
+#pragma unroll
+						for (int u = 0; u < 8; ++u) {
+							const uint32_t at = bs + j0 + (uint32_t) u;
+							const uint32_t src = at < be ? at : (uint32_t) lane;   // (beyond the bucket: this lane itself, whose time is not below its own)
+							k2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) key);
+							t2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) t);
 						}
+#pragma unroll
+						for (int u = 0; u < 8; ++u) v += (k2[u] == key && t2[u] < t) ? 1u : 0u;
 					}
-					if (key != 0xFFFFFFFFu) {
+					if (live) {
 						if (v >= n_tau) atomicExch(&s_bad, 4u); else if (t < tau[v]) atomicMin(&tau[v], t);
 					}
 					return v;
@@ -222,19 +223,18 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 						for (uint32_t d0 = 0; d0 < n_b; d0 += 64u) {
 							const uint2 other = d0 + (uint32_t) lane < n_b ? my[p_c + d0 + (uint32_t) lane] : none;
 							const uint32_t ot = other.y & 0xFFFFFu;   // (the hits in front have their v in the upper bits already)
-							// the distinct keys of the other chunk; only those some lane of this chunk holds have their holders walked
-							unsigned long long todo = __ballot(other.x != 0xFFFFFFFFu);
-							while (todo) {
-								const uint32_t kL = (uint32_t) __builtin_amdgcn_readlane((int) other.x, (int) __builtin_ctzll(todo));
-								const unsigned long long same = __ballot(other.x == kL);
-								todo &= ~same;
-								if (__ballot(mine.x == kL) != 0ull) {
-									const uint32_t t_m = mine.x == kL ? mine.y : 0u;
-									for (unsigned long long mm = same; mm; mm &= mm - 1ull) {
-										const uint32_t t2 = (uint32_t) __builtin_amdgcn_readlane((int) ot, (int) __builtin_ctzll(mm));
-										v += t2 < t_m ? 1u : 0u;
-									}
+							// every hit of this chunk against every hit of the other one: the other chunk's lanes by ds_bpermute, rotating, eight trips'
+							// permutes in flight (round 5: through scalar registers, two v_readlane per trip)
+							for (uint32_t j0 = 0; j0 < 64u; j0 += 8u) {
+								uint32_t k2[8], t2[8];
+#pragma unroll
+								for (int u = 0; u < 8; ++u) {
+									const uint32_t src = ((uint32_t) lane + j0 + (uint32_t) u) & 63u;
+									k2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) other.x);
+									t2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) ot);
 								}
+#pragma unroll
+								for (int u = 0; u < 8; ++u) v += (k2[u] == mine.x && t2[u] < mine.y) ? 1u : 0u;
 							}
 						}
 						if (mine.x != 0xFFFFFFFFu) {
