@@ -329,9 +329,13 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				d[0] = src[0]; d[1] = src[1];  // the table is padded by 16 entries
 				return ((uint32_t) lo << 16) | sg;
 			};
-			uint32_t item = fetch((uint32_t) tid, cur);
+			// (round 6: TWO segments' loads in flight behind the one being voted -- with one, a thread waited a whole memory latency per
+			// 8 hits: 88 000 hits / 512 threads = 21 segments per thread in 25 us of sweep A = 1.2 us each)
+			CsU4 nx2[2];
+			uint32_t item = fetch((uint32_t) tid, cur), item_1 = fetch((uint32_t) tid + NT, nxt);
 			for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += NT) {
-				const uint32_t item_n = fetch(idx + NT, nxt);
+				const uint32_t item_n = item_1;
+				item_1 = fetch(idx + 2u * NT, nx2);
 				const int li = (int) (item >> 16);
 				const uint32_t sg = item & 0xFFFFu;
 				const uint32_t len = l_pref[li + 1] - l_pref[li];
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
 				const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
 				f(pos8, cn, correction, (li & 1) != 0, len);
-				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1];
+				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1]; nxt[0] = nx2[0]; nxt[1] = nx2[1];
 			}
 		};
 		auto insert = [&](uint32_t bin, bool rev) {

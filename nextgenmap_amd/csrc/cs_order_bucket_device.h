@@ -119,9 +119,11 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 				d[0] = src[0]; d[1] = src[1];  // the table is padded by 16 entries
 				return ((uint32_t) lo << 16) | sg;
 			};
-			uint32_t item = fetch((uint32_t) tid, cur);
+			CsU4 nx2[2];   // (two segments' loads in flight behind the one in hand, as in cs_heavy2_kernel)
+			uint32_t item = fetch((uint32_t) tid, cur), item_1 = fetch((uint32_t) tid + NT, nxt);
 			for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += NT) {
-				const uint32_t item_n = fetch(idx + NT, nxt);
+				const uint32_t item_n = item_1;
+				item_1 = fetch(idx + 2u * NT, nx2);
 				const int li = (int) (item >> 16);
 				const uint32_t sg = item & 0xFFFFu;
 				const uint32_t first = l_pref[li], len = l_pref[li + 1] - first;
@@ -130,7 +132,7 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 				const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
 				const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
 				f(pos8, cnt, (li & 1) ? 0x80000000u : 0u, correction, first + sg * kCsSeg);
-				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1];
+				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1]; nxt[0] = nx2[0]; nxt[1] = nx2[1];
 			}
 		};
 		auto bucket_of = [&](uint32_t bin) -> uint32_t { return (bin * 2654435761u) >> (32 - log2_nb); };

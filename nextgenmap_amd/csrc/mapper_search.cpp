@@ -82,6 +82,9 @@ const HeavyClass *heavy_classes() {
 		const long m0 = test_limit("heavy_max0", 0), m1 = test_limit("heavy_max1", 0);
 		if (m0 > 0) { cl[0].max_hits = (uint32_t) m0; cl[0].scratch_cap = std::min<uint32_t>(cl[0].scratch_cap, (uint32_t) m0); }
 		if (m1 > 0 && m1 >= (long) cl[0].max_hits) cl[1].max_hits = (uint32_t) m1;
+		const long c1c = test_limit("heavy_c1_log2c", 0), c1s = test_limit("heavy_c1_log2s", 0);   // (experiments: the middle class alone)
+		if (c1c > 0) cl[1].log2c = (int) std::min<long>(cl[1].log2c, std::max<long>(6, c1c));
+		if (c1s > 0) cl[1].log2s = (int) std::min<long>(cl[1].log2s, std::max<long>(6, c1s));
 		const long sc = test_limit("heavy_scratch", 0);
 		if (sc > 0) for (int c = 1; c < 3; ++c) cl[c].scratch_cap = std::min<uint32_t>(cl[c].scratch_cap, (uint32_t) sc << (c - 1));
 		return true; }();
