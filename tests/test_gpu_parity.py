@@ -145,7 +145,11 @@ def test_device_resident_path_and_large_batch_properties():
     assert got.min() >= 0 and got.max() <= 10 * 151
     out2 = torch.empty_like(out)
     perm = torch.randperm(n, device="cuda")
-    eng.score_device(0, n, ref[perm].contiguous(), qry[perm].contiguous(), out2, st)
+    ref2, qry2 = ref[perm].contiguous(), qry[perm].contiguous()
+    # torch's current stream is the null stream (handle 0), which ngm_hip_score_device reads as "the engine's own stream" -- a non-blocking one
+    # that does not wait for the gathers above (round 6: the full suite once compared scores of half-written inputs here)
+    torch.cuda.synchronize()
+    eng.score_device(0, n, ref2, qry2, out2, st)
     torch.cuda.synchronize()
     assert torch.equal(out2, out[perm])
     eng.close()
