@@ -227,7 +227,8 @@ inline size_t cs_heavy2_lds_bytes(int lists_cap, int q, int log2_counters, int l
 // twice, no scratch slice: 2.0 x the algorithmic bytes instead of 2.9 x.  The rows must then be twice as large (row 2 over all hits is
 // noisier than over the survivors): one workgroup of 1 024 threads per CU instead of two of 512, and although a read took 54 us
 // instead of 86, a CU finished fewer of them: candidate search 252 against 188 ms per step at 3.1 Gbp (profiles/r06_cs_heavy2_two_rows.patch,
-// profiles/r06_heavy_tail_two_rows_ab.txt).  The sweeps are latency chains, not traffic: reads in flight per CU decide.
+// profiles/r06_heavy_tail_two_rows_ab.txt).  The SQ counters taken afterwards say why: the kernel issues VALU instructions for 0.71 of its
+// cycles (~35 lane operations per index hit over the sweeps) -- it is instruction-bound, not traffic- or latency-bound.
 template <int NT>
 __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__restrict__ ctl, int cls, uint32_t *__restrict__ scratch, uint32_t scratch_cap,
 		uint32_t coarse_cap, uint32_t max_parts, uint32_t ent_cap, unsigned long long *__restrict__ diag) {   // ctl: the search's control block (cs_queue_device.h) -- the class's list length and work counter, the run's statistics   // diag (NGM_HIP_CS_PHASES): [0..6] 100 MHz ticks per phase of every 8th read, [8] reads sampled, [9] their hits, [10] settled without a second row, [11] survivors, [12] table passes of the reads that needed several, [13] reads sent into a second pass
