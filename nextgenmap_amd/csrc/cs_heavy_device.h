@@ -330,13 +330,10 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				d[0] = src[0]; d[1] = src[1];  // the table is padded by 16 entries
 				return ((uint32_t) lo << 16) | sg;
 			};
-			// (round 6: TWO segments' loads in flight behind the one being voted -- with one, a thread waited a whole memory latency per
-			// 8 hits: 88 000 hits / 512 threads = 21 segments per thread in 25 us of sweep A = 1.2 us each)
-			CsU4 nx2[2];
-			uint32_t item = fetch((uint32_t) tid, cur), item_1 = fetch((uint32_t) tid + NT, nxt);
+			// (round 6 tried TWO segments' loads in flight behind the one being voted: 2 % -- and eight more registers, which the sweeps need)
+			uint32_t item = fetch((uint32_t) tid, cur);
 			for (uint32_t idx = (uint32_t) tid; idx < n_items; idx += NT) {
-				const uint32_t item_n = item_1;
-				item_1 = fetch(idx + 2u * NT, nx2);
+				const uint32_t item_n = fetch(idx + NT, nxt);
 				const int li = (int) (item >> 16);
 				const uint32_t sg = item & 0xFFFFu;
 				const uint32_t len = l_pref[li + 1] - l_pref[li];
@@ -345,7 +342,7 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				const uint32_t correction = (li & 1) ? (uint32_t) (L - (p + k)) : (uint32_t) p;  // CS.cpp:140-142
 				const uint32_t pos8[8] = {cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w};
 				f(pos8, cn, correction, (li & 1) != 0, len);
-				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1]; nxt[0] = nx2[0]; nxt[1] = nx2[1];
+				item = item_n; cur[0] = nxt[0]; cur[1] = nxt[1];
 			}
 		};
 		auto insert = [&](uint32_t bin, bool rev) {
@@ -410,11 +407,11 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 				uint32_t bin[kCsSeg];
 #pragma unroll
 				for (int j = 0; j < kCsSeg; ++j) {
+					// (no branch per hit: a hit beyond the segment's end adds 0 -- the SQ counters have this kernel at 0.71 of the VALU issue slots
+					// with a scalar branch pair around every hit)
 					bin[j] = (pos8[j] - correction) >> A.bin_shift;
-					if ((uint32_t) j < cn) {
-						const uint32_t hc = (bin[j] * 0x9E3779B1u) >> (32 - log2c);
-						atomicAdd(&cnt[hc >> 1], 1u << ((hc & 1u) * 16u));
-					}
+					const uint32_t hc = (bin[j] * 0x9E3779B1u) >> (32 - log2c);
+					atomicAdd(&cnt[hc >> 1], (uint32_t) j < cn ? 1u << ((hc & 1u) * 16u) : 0u);
 				}
 				if (len <= n_short) {
 					// the segment's first probes in flight together (a returning LDS atomic per hit, one after the other, made this sweep three
@@ -487,22 +484,33 @@ __global__ __launch_bounds__(NT) void cs_heavy2_kernel(CsArgs A, uint32_t *__res
 			mark(2);
 			if (!failed && s_direct) {
 				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t) {
+					uint32_t bin[8], hc[8], cw[8];
 #pragma unroll
-					for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn) {
-						const uint32_t bin = (pos8[j] - correction) >> A.bin_shift;
-						if (counter_of((bin * 0x9E3779B1u) >> (32 - log2c)) >= T) insert(bin, rev);
+					for (int j = 0; j < kCsSeg; ++j) {   // (the eight counter words in flight together, as in sweep B)
+						bin[j] = (pos8[j] - correction) >> A.bin_shift;
+						hc[j] = (bin[j] * 0x9E3779B1u) >> (32 - log2c);
+						cw[j] = cnt[hc[j] >> 1];
 					}
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) if ((uint32_t) j < cn && ((cw[j] >> ((hc[j] & 1u) * 16u)) & 0xFFFFu) >= T) insert(bin[j], rev);
 				});
 			} else if (!failed) {
 				// sweep B: the survivors of row 1 -> scratch slice (one slot request per wave and trip)
 				sweep([&](const uint32_t (&pos8)[8], uint32_t cn, uint32_t correction, bool rev, uint32_t) {
 					uint32_t keep = 0, nk = 0;
 					uint32_t e[8];
+					uint32_t hc[8], cw[8];
 #pragma unroll
-					for (int j = 0; j < kCsSeg; ++j) {
+					for (int j = 0; j < kCsSeg; ++j) {   // the eight counter words in flight together (round 5: a branch and an LDS round trip per hit)
 						const uint32_t bin = (pos8[j] - correction) >> A.bin_shift;
 						e[j] = (bin & 0x3FFFFFFFu) | (rev ? 0x80000000u : 0u);
-						if ((uint32_t) j < cn && counter_of((bin * 0x9E3779B1u) >> (32 - log2c)) >= T) { keep |= 1u << j; ++nk; }
+						hc[j] = (bin * 0x9E3779B1u) >> (32 - log2c);
+						cw[j] = cnt[hc[j] >> 1];
+					}
+#pragma unroll
+					for (int j = 0; j < kCsSeg; ++j) {
+						const uint32_t k1 = ((uint32_t) j < cn && ((cw[j] >> ((hc[j] & 1u) * 16u)) & 0xFFFFu) >= T) ? 1u : 0u;
+						keep |= k1 << j; nk += k1;
 					}
 					// (lanes that left the loop do not take part: the prefix runs over the active ones)
 					const unsigned long long act = __ballot(true);
