@@ -643,7 +643,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			const size_t npairs = (size_t) n / 2;
 			if (m->d_pair_info.reserve(npairs + 1) || m->p_pair_info.reserve(npairs + 1)) { ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
 			if (choice_on_gpu) {
-				if (m->d_pair_out.reserve(2 * npairs + 2) || m->d_pair_top.reserve(npairs + 1) || m->d_pair_tied_n.reserve(4) || m->p_pair_tied_n.reserve(4) || m->d_pair_list.reserve(2 * npairs + 2)) {
+				if (m->d_pair_out.reserve(2 * npairs + 2) || m->d_pair_top.reserve(npairs + 1) || m->d_pair_tied_n.reserve(4) || m->p_pair_tied_n.reserve(4) || m->d_pair_list.reserve(3 * npairs + 2)) {
 					ngm::pipeline_set_error("out of memory (pair selection)"); return -12; }
 				MAP_HIP_TRY(hipMemsetAsync(m->d_pair_tied_n.p, 0, 16, m->st));   // [0] tied pairs, [1] small pairs, [2] large pairs
 			}
@@ -657,11 +657,19 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				// ones at out[npairs ..) (2^30 + ... in the numbering pair_simple_kernel puts into d_pair_info)
 				const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
 				const float cutoff = m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f;
-				hipLaunchKernelGGL((ngm::pair_choice_kernel<64, 64>), dim3((unsigned) std::min<size_t>(npairs, 8192)), dim3(64), 0, m->st, (const uint32_t *) m->d_pair_list.p, (const uint32_t *) counts,
-						m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff, m->d_pair_out.p, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs);
-				hipLaunchKernelGGL((ngm::pair_choice_kernel<ngm::kPairThreads, ngm::kPairCap>), dim3((unsigned) std::min<size_t>(npairs, 1024)), dim3(ngm::kPairThreads), 0, m->st,
+				uint32_t *const huge_list = m->d_pair_list.p + 2 * npairs, *const huge_count = m->d_pair_tied_n.p + 3;   // entries of the large pairs with more than kPairCap candidates above the cut-off
+				hipLaunchKernelGGL((ngm::pair_choice_kernel<64, 64>), dim3((unsigned) std::min<size_t>(npairs, 8192)), dim3(64), ngm::pair_choice_lds_bytes(64), m->st, (const uint32_t *) m->d_pair_list.p, (const uint32_t *) counts,
+						m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff, m->d_pair_out.p, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs,
+						(uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) nullptr);
+				hipLaunchKernelGGL((ngm::pair_choice_kernel<ngm::kPairThreads, ngm::kPairCap>), dim3((unsigned) std::min<size_t>(npairs, 1024)), dim3(ngm::kPairThreads), ngm::pair_choice_lds_bytes(ngm::kPairCap), m->st,
 						(const uint32_t *) (m->d_pair_list.p + npairs), (const uint32_t *) (counts + 1), m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff,
-						m->d_pair_out.p + npairs, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs);
+						m->d_pair_out.p + npairs, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs, huge_list, huge_count, (const uint32_t *) nullptr);
+				// ... and what outgrew those lists once more with kPairCapHuge of them (96 KB of LDS: one workgroup per CU; a few hundred pairs of repeat families per batch)
+				static const bool huge_attr = [] { (void) hipFuncSetAttribute((const void *) ngm::pair_choice_kernel<ngm::kPairThreads, ngm::kPairCapHuge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ngm::pair_choice_lds_bytes(ngm::kPairCapHuge)); return true; }();
+				(void) huge_attr;
+				hipLaunchKernelGGL((ngm::pair_choice_kernel<ngm::kPairThreads, ngm::kPairCapHuge>), dim3((unsigned) std::min<size_t>(npairs, 256)), dim3(ngm::kPairThreads), ngm::pair_choice_lds_bytes(ngm::kPairCapHuge), m->st,
+						(const uint32_t *) huge_list, (const uint32_t *) huge_count, m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff,
+						m->d_pair_out.p + npairs, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs, (uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) (m->d_pair_list.p + npairs));
 				MAP_HIP_TRY(hipGetLastError());
 				MAP_HIP_TRY(hipMemcpyAsync(m->p_pair_tied_n.p, m->d_pair_tied_n.p, 16, hipMemcpyDeviceToHost, m->st));
 			}

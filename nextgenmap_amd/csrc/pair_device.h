@@ -23,7 +23,8 @@
 
 namespace ngm {
 
-constexpr int kPairThreads = 256, kPairCap = 2048, kPairCombos = 64;
+constexpr int kPairThreads = 256, kPairCap = 2048, kPairCapHuge = 8192, kPairCombos = 64;
+inline size_t pair_choice_lds_bytes(int cap) { return (size_t) cap * 12; }   // per mate: locations (32-bit) and candidate indices (16-bit) of the candidates above the cut-off
 enum : int32_t { kPairFound = 1, kPairTied = 2, kPairDup = 4, kPairHost = 8 };
 
 // flags: kPair* | mq_a << 8 | mq_b << 16 | n_top << 24 (n_top <= 8: the listed best-scoring combinations; 15: more than 8; 0 with more than
@@ -38,22 +39,30 @@ __device__ __forceinline__ float pair_o2f(int o) { return __int_as_float(o ^ ((o
 // list[i] (PairOut::pair names it); persistent workgroups walk the list with the grid's stride.
 // NT threads per pair, at most CAP candidates above the cut-off per mate: <64, 64> (one wave) for the pairs whose mates have up to 64
 // candidates each -- nearly all of them --, <kPairThreads, kPairCap> for the others (pair_simple_kernel sorts them into the two lists).
+// Round 6: a pair with more than CAP candidates above the cut-off on one side used to go back to the host's walk (~1 000 pairs per 131 072 reads of the
+// bench's stress sub-leg, 100-400 ms of its pool per batch).  The kernel now hands such a pair to a list (`huge_list`: the pair's entry number) that a third
+// launch with CAP = kPairCapHuge works through (`indirect`: the list then holds entry numbers, the pairs are indirect[entry]) and writes into the same entries;
+// pairs of repeat families have far more than kPairCombos combinations inside the window, so that launch learns "found, tied, order decides" after a
+// few trips of its combination loop and stops.  The candidate lists live in dynamic LDS (pair_choice_lds_bytes).
 template <int NT, int CAP>
 __global__ __launch_bounds__(NT) void pair_choice_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count, const uint32_t *__restrict__ cand_base,
 		const uint32_t *__restrict__ cand_count, const float *__restrict__ scores, const uint32_t *__restrict__ pair_loc, const uint16_t *__restrict__ read_len, int min_d, int max_d,
-		float cutoff, PairOut *__restrict__ out, PairTop *__restrict__ tops, uint32_t *__restrict__ tied_count, uint32_t tied_cap) {
+		float cutoff, PairOut *__restrict__ out, PairTop *__restrict__ tops, uint32_t *__restrict__ tied_count, uint32_t tied_cap,
+		uint32_t *__restrict__ huge_list, uint32_t *__restrict__ huge_count, const uint32_t *__restrict__ indirect) {
 	constexpr int NW = NT / 64;
-	__shared__ uint32_t s_loc[2][CAP];
-	__shared__ uint16_t s_ix[2][CAP];
+	extern __shared__ __attribute__((aligned(16))) uint32_t pair_lds[];
+	uint32_t (*s_loc)[CAP] = reinterpret_cast<uint32_t (*)[CAP]>(pair_lds);
+	uint16_t (*s_ix)[CAP] = reinterpret_cast<uint16_t (*)[CAP]>(pair_lds + 2 * CAP);
 	__shared__ int s_red[3][NW];
 	__shared__ uint32_t s_n[2], s_ncombo;
 	__shared__ int s_top;   // bits of the largest positive pair score inside the window (0: none)
 	__shared__ float s_cps[kPairCombos];
 	__shared__ int s_cd[kPairCombos], s_ca[kPairCombos], s_cb[kPairCombos];
 	const uint32_t n_list = *list_count;
-	for (uint32_t item = blockIdx.x; item < n_list; item += gridDim.x) {
+	for (uint32_t item_l = blockIdx.x; item_l < n_list; item_l += gridDim.x) {
 	__syncthreads();   // (the previous pair's shared state is no longer read)
-	const int pi = (int) list[item];
+	const uint32_t item = indirect ? list[item_l] : item_l;   // the pair's entry in `out`
+	const int pi = (int) (indirect ? indirect[item] : list[item_l]);
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int rb = 2 * pi, ra = 2 * pi + 1;   // `a` = the mate whose scores arrive last in the reference (the odd read id): the outer loop of top1PE
 	const uint32_t cnt[2] = {cand_count[ra], cand_count[rb]}, base[2] = {cand_base[ra], cand_base[rb]};
@@ -103,9 +112,13 @@ __global__ __launch_bounds__(NT) void pair_choice_kernel(const uint32_t *__restr
 		__syncthreads();
 	}
 	const uint32_t na = s_n[0], nbb = s_n[1];
-	if (na > (uint32_t) CAP || nbb > (uint32_t) CAP) to_host = true;
+	const bool over_cap = !to_host && (na > (uint32_t) CAP || nbb > (uint32_t) CAP);
+	if (over_cap) to_host = true;
 	if (to_host) {
-		if (tid == 0) { po.flags = kPairHost | (mq[0] << 8) | (mq[1] << 16); out[item] = po; }
+		if (tid == 0) {
+			po.flags = kPairHost | (mq[0] << 8) | (mq[1] << 16); out[item] = po;
+			if (over_cap && huge_list) huge_list[atomicAdd(huge_count, 1u)] = item;   // (the launch with the larger lists overwrites the entry)
+		}
 		continue;
 	}
 	// every combination inside the insert-size window; the larger side across the lanes
