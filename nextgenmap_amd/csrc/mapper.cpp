@@ -665,9 +665,9 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 						(const uint32_t *) (m->d_pair_list.p + npairs), (const uint32_t *) (counts + 1), m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff,
 						m->d_pair_out.p + npairs, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs, huge_list, huge_count, (const uint32_t *) nullptr);
 				// ... and what outgrew those lists once more with kPairCapHuge of them (96 KB of LDS: one workgroup per CU; a few hundred pairs of repeat families per batch)
-				static const bool huge_attr = [] { (void) hipFuncSetAttribute((const void *) ngm::pair_choice_kernel<ngm::kPairThreads, ngm::kPairCapHuge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ngm::pair_choice_lds_bytes(ngm::kPairCapHuge)); return true; }();
+				static const bool huge_attr = [] { (void) hipFuncSetAttribute((const void *) ngm::pair_choice_kernel<1024, ngm::kPairCapHuge>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ngm::pair_choice_lds_bytes(ngm::kPairCapHuge)); return true; }();
 				(void) huge_attr;
-				hipLaunchKernelGGL((ngm::pair_choice_kernel<ngm::kPairThreads, ngm::kPairCapHuge>), dim3((unsigned) std::min<size_t>(npairs, 256)), dim3(ngm::kPairThreads), ngm::pair_choice_lds_bytes(ngm::kPairCapHuge), m->st,
+				hipLaunchKernelGGL((ngm::pair_choice_kernel<1024, ngm::kPairCapHuge>), dim3((unsigned) std::min<size_t>(npairs, 256)), dim3(1024), ngm::pair_choice_lds_bytes(ngm::kPairCapHuge), m->st,   // (one workgroup per CU either way: sixteen waves share a pair)
 						(const uint32_t *) huge_list, (const uint32_t *) huge_count, m->d_cand_base.p, m->d_cand_count.p, m->d_scores.p, m->d_out_loc.p, m->d_read_len.p, min_d, max_d, cutoff,
 						m->d_pair_out.p + npairs, m->d_pair_top.p, m->d_pair_tied_n.p, (uint32_t) npairs, (uint32_t *) nullptr, (uint32_t *) nullptr, (const uint32_t *) (m->d_pair_list.p + npairs));
 				MAP_HIP_TRY(hipGetLastError());
