@@ -317,8 +317,25 @@ static void sort_like_reference(uint32_t *v, uint32_t base, uint32_t cnt, const 
 		struct Rec { float s; uint32_t i; };
 		thread_local std::vector<Rec> recs;
 		keys.resize(cnt);
-		for (uint32_t x = 0; x < cnt; ++x) keys[x] = ((uint64_t) rank[base + x] << 32) | (uint64_t) (base + x);
-		std::sort(keys.begin(), keys.end());
+		uint32_t rank_or = 0;
+		for (uint32_t x = 0; x < cnt; ++x) { keys[x] = ((uint64_t) rank[base + x] << 32) | (uint64_t) (base + x); rank_or |= rank[base + x]; }
+		if (cnt < 256) std::sort(keys.begin(), keys.end());
+		else {
+			// ranks are 2 x a hit time + strand: 21-23 bits -- two or three stable passes of 11 bits (equal ranks, should there be any, keep the
+			// index order they were written in: what the integer sort of (rank, index) gives)
+			thread_local std::vector<uint64_t> tmp;
+			tmp.resize(cnt);
+			uint64_t *src = keys.data(), *dst = tmp.data();
+			for (int sh = 32; sh < 64 && (rank_or >> (sh - 32)) != 0u; sh += 11) {
+				uint32_t hist[2048] = {0};
+				for (uint32_t x = 0; x < cnt; ++x) ++hist[(src[x] >> sh) & 2047u];
+				uint32_t run = 0;
+				for (uint32_t h = 0; h < 2048; ++h) { const uint32_t c = hist[h]; hist[h] = run; run += c; }
+				for (uint32_t x = 0; x < cnt; ++x) dst[hist[(src[x] >> sh) & 2047u]++] = src[x];
+				std::swap(src, dst);
+			}
+			if (src != keys.data()) std::copy(src, src + cnt, keys.data());
+		}
 		bool distinct = true;
 		for (uint32_t x = 1; x < cnt && distinct; ++x) distinct = (keys[x] >> 32) != (keys[x - 1] >> 32);
 		if (distinct) {
@@ -349,6 +366,9 @@ extern "C++" {
 // arrays sorted like the reference sorts them, the MAPQs, the candidates at or above best * pair_score_cutoff, and -- f(pair score,
 // insert size, candidate of a, candidate of b) -- every combination inside the insert-size window in the order of the reference's
 // double loop.  `a` = the mate whose scores arrive last (the odd read id: "read"), `b` = its mate.
+// (NGM_HIP_HOST_TIMING: where pass 3's CPU time goes -- [0] ns in the two sorts, [1] ns in the rest of the walk, [2] candidates, [3] heads, [4] combinations looked at, [5] pairs)
+static std::atomic<bool> g_walk_probe{false};
+static std::atomic<uint64_t> g_walk_ns[6];
 template <typename F>
 static void walk_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
 		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *mq_a, int *mq_b, F &&f) {
@@ -364,44 +384,76 @@ static void walk_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a,
 	if (cnt_a > 32) big_a.resize(cnt_a);
 	if (cnt_b > 32) big_b.resize(cnt_b);
 	uint32_t *A = cnt_a > 32 ? big_a.data() : small_a, *B = cnt_b > 32 ? big_b.data() : small_b;
+	const bool tm = g_walk_probe.load(std::memory_order_relaxed);
+	const auto t_0 = tm ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
 	sort_like_reference(A, base_a, cnt_a, loc, sv, score, rank);
 	sort_like_reference(B, base_b, cnt_b, loc, sv, score, rank);
+	const auto t_1 = tm ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+	struct WalkProbe { bool on; std::chrono::steady_clock::time_point t1; uint64_t cnt, *na, *nb, *nv; ~WalkProbe() { if (!on) return;
+		g_walk_ns[1] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count(); g_walk_ns[2] += cnt; g_walk_ns[3] += *na + *nb; g_walk_ns[4] += *nv; g_walk_ns[5] += 1; } };
+	if (tm) g_walk_ns[0] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(t_1 - t_0).count();
 	*mq_a = mq_of(A, cnt_a); *mq_b = mq_of(B, cnt_b);
 	const float cutoff = m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f;
 	const float min_a = score[A[0]] * cutoff, min_b = score[B[0]] * cutoff;
 	size_t na = 1, nb = 1;
 	while (na < cnt_a && min_a <= score[A[na]]) ++na;
 	while (nb < cnt_b && min_b <= score[B[nb]]) ++nb;
+	uint64_t pna = na, pnb = nb, n_visits = 0;
+	WalkProbe probe{tm, t_1, (uint64_t) cnt_a + cnt_b, &pna, &pnb, &n_visits};
 	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
 	// Mates with hundreds of candidates each (repeat families of a GRCh38-like genome): CheckPairs walks all na x nb combinations,
 	// but only those inside the insert-size window do anything -- B's candidates sorted by position, per candidate of A the ones
 	// within max_d, visited in increasing j like the reference's inner loop: the same sequence of in-window pairs, so every
 	// order-dependent outcome (first best, the equal counter, the recorded combinations) is unchanged.
 	const bool windowed = na * nb > 1024 && max_d < (1 << 28);
-	std::vector<std::pair<uint32_t, uint32_t>> b_by_loc;
-	std::vector<uint32_t> js;
-	if (windowed) {
-		b_by_loc.resize(nb);
-		for (size_t j = 0; j < nb; ++j) b_by_loc[j] = {loc[B[j]], (uint32_t) j};
-		std::sort(b_by_loc.begin(), b_by_loc.end());
+	auto visit = [&](size_t i, size_t j) {
+		++n_visits;
+		const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
+		const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
+		if (cur > min_d && cur < max_d) f(score[A[i]] + score[B[j]], cur, (int) A[i], (int) B[j]);
+	};
+	if (!windowed) {
+		for (size_t i = 0; i < na; ++i) for (size_t j = 0; j < nb; ++j) visit(i, j);
+		return;
+	}
+	// Round 6 (the stress sub-leg of the bench: ~1 800 candidates above the cut-off per tied pair, 5 600 such pairs per batch): both heads
+	// sorted by location, ONE sweep with two pointers gives every candidate of A its run of B's candidates within max_d -- the window's
+	// bounds grow with the location -- and the double loop's order (i major, j ascending) comes from a bit per j: set for the run, read
+	// back lowest first.  (Round 5: a binary search and a sort of the run per candidate of A -- half of pass 3's CPU time; sorting all
+	// matches at once was tried and is slower: satellite arrays put hundreds of B's candidates into every window.)
+	thread_local std::vector<uint64_t> a_by_loc, b_by_loc, bits;
+	thread_local std::vector<uint32_t> run_lo, run_hi;
+	a_by_loc.resize(na); b_by_loc.resize(nb); run_lo.resize(na); run_hi.resize(na);
+	bits.assign((nb + 63) / 64, 0ull);
+	for (size_t i = 0; i < na; ++i) a_by_loc[i] = ((uint64_t) loc[A[i]] << 32) | (uint64_t) i;
+	for (size_t j = 0; j < nb; ++j) b_by_loc[j] = ((uint64_t) loc[B[j]] << 32) | (uint64_t) j;
+	std::sort(a_by_loc.begin(), a_by_loc.end());
+	std::sort(b_by_loc.begin(), b_by_loc.end());
+	size_t lo = 0, hi = 0;
+	for (size_t x = 0; x < na; ++x) {
+		const uint64_t l1w = a_by_loc[x] >> 32;
+		const uint64_t lo_loc = l1w > (uint64_t) max_d ? l1w - (uint64_t) max_d : 0u;
+		const uint64_t hi_loc = std::min<uint64_t>(l1w + (uint64_t) max_d, 0xFFFFFFFFull);
+		while (lo < nb && (b_by_loc[lo] >> 32) < lo_loc) ++lo;
+		if (hi < lo) hi = lo;
+		while (hi < nb && (b_by_loc[hi] >> 32) <= hi_loc) ++hi;
+		const size_t i = (size_t) (a_by_loc[x] & 0xFFFFFFFFull);
+		run_lo[i] = (uint32_t) lo; run_hi[i] = (uint32_t) hi;
 	}
 	for (size_t i = 0; i < na; ++i) {
-		size_t n_inner = nb;
-		if (windowed) {
-			const uint64_t l1w = loc[A[i]];
-			const uint32_t lo_loc = l1w > (uint64_t) max_d ? (uint32_t) (l1w - (uint64_t) max_d) : 0u;
-			const uint64_t hi64 = l1w + (uint64_t) max_d;
-			const uint32_t hi_loc = hi64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) hi64;
-			js.clear();
-			for (auto it = std::lower_bound(b_by_loc.begin(), b_by_loc.end(), std::make_pair(lo_loc, 0u)); it != b_by_loc.end() && it->first <= hi_loc; ++it) js.push_back(it->second);
-			std::sort(js.begin(), js.end());
-			n_inner = js.size();
+		const uint32_t r0 = run_lo[i], r1 = run_hi[i];
+		if (r1 - r0 == 1u) { visit(i, (size_t) (b_by_loc[r0] & 0xFFFFFFFFull)); continue; }
+		if (r1 == r0) continue;
+		uint32_t w_min = 0xFFFFFFFFu, w_max = 0;
+		for (uint32_t y = r0; y < r1; ++y) {
+			const uint32_t j = (uint32_t) b_by_loc[y], w = j >> 6;
+			bits[w] |= 1ull << (j & 63u);
+			w_min = std::min(w_min, w); w_max = std::max(w_max, w);
 		}
-		for (size_t jj = 0; jj < n_inner; ++jj) {
-			const size_t j = windowed ? js[jj] : jj;
-			const uint64_t l1 = loc[A[i]], l2 = loc[B[j]];
-			const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
-			if (cur > min_d && cur < max_d) f(score[A[i]] + score[B[j]], cur, (int) A[i], (int) B[j]);
+		for (uint32_t w = w_min; w <= w_max; ++w) {
+			uint64_t word = bits[w];
+			bits[w] = 0ull;
+			while (word) { visit(i, (size_t) w * 64u + (size_t) __builtin_ctzll(word)); word &= word - 1ull; }
 		}
 	}
 }
@@ -891,8 +943,16 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			std::vector<PairSeq> seqs(picked.size());
 			auto build_seq = [&](PairSeq &sq, int pi) {
 				const int rb = 2 * pi, ra = 2 * pi + 1;
+				// (only the combinations that reach the running maximum of the pair score are kept: eval_pair_seq does nothing at the others
+				// whatever the mean -- its `top` is the maximum so far, starting at 0 -- and a pair of two satellite-array mates has
+				// hundreds of thousands of them)
+				float top = 0.0f;
 				walk_pair(m, m->h_base[ra], m->h_count[ra], len_of(ra), m->h_base[rb], m->h_count[rb], len_of(rb), h_loc, h_sv, h_scores, h_rank_pe, &sq.mq_a, &sq.mq_b,
-						[&](float ps, int cur, int ia, int ib) { sq.ps.push_back(ps); sq.d.push_back(cur); sq.a.push_back(ia); sq.b.push_back(ib); });
+						[&](float ps, int cur, int ia, int ib) {
+							if (ps < top) return;
+							top = ps;
+							sq.ps.push_back(ps); sq.d.push_back(cur); sq.a.push_back(ia); sq.b.push_back(ib);
+						});
 			};
 			parallel_for((int) picked.size(), [&](int lo, int hi) { for (int x = lo; x < hi; ++x) { build_seq(seqs[x], tied[picked[x]].pi); tied[picked[x]].seq = x; } }, 8);
 			qlap(2);
@@ -960,6 +1020,12 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 			m->pair_dist_sum += carry_sum; m->pair_dist_count += carry_cnt;
 			pair_turn.release();
 			qlap(4);
+			if (host_timing) {
+				g_walk_probe = true;
+				const double pn = (double) std::max<uint64_t>(1, g_walk_ns[5].load());
+				fprintf(stderr, "[ngm-hip] pair walks so far: %.0f pairs; per pair: sorts %.1f us, rest of the walk %.1f us, %.0f candidates, %.0f above the cut-off, %.0f combinations looked at\n", pn,
+						g_walk_ns[0].load() / pn / 1e3, g_walk_ns[1].load() / pn / 1e3, g_walk_ns[2].load() / pn, g_walk_ns[3].load() / pn, g_walk_ns[4].load() / pn);
+			}
 			if (host_timing) fprintf(stderr, "[ngm-hip] pair selection: %zu tied pairs, %zu picked for the order replay + %zu single-end ties, %zu open in the turn, %zu of them late; %ld pairs walked on the host; "
 					"ms: pass 1 %.2f | order replay %.2f | pass 3 %.2f | turn: pass 2 %.2f, late + pass 4 %.2f\n", tied.size(), picked.size(), se_tied.size(), n_open, late.size(), (long) n_host_walk, tq[0], tq[1], tq[2], tq[3], tq[4]);
 		}
