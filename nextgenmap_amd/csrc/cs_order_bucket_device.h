@@ -22,12 +22,15 @@
 namespace ngm {
 
 constexpr int kCsOrderBucketThreads = 512;     // (two or three workgroups per CU: while one waits at a barrier the others sweep)
-constexpr int kCsOrderBucketLog2Max = 13;      // most buckets of a read (one LDS word each)
+constexpr int kCsOrderBucketLog2Max = 14;      // most buckets of a read (one LDS word each; the host lowers it when the LDS does not hold them beside the lists: CsArgs::log2_bits).
+// Round 5 had 2^13 buckets of ~8 hits; 2^14 of ~4 (stress sub-leg of the bench, 66 000 hits per replayed read: `v + tau` 416 -> 365 us per read, scatter 75 -> 80; with 2^15
+// 350 and 85-100, and 128 KB of LDS that the search kernels of the other instances then lack: profiles/r06_bucket_fill_ab.txt) -- the walk's trip count is the
+// longest bucket of a window, and in reads from repeats that is a bin with many hits of its own, not a crowded bucket
 constexpr uint32_t kCsOrderBucketMaxHits = 1u << 20;   // a hit's time and its v share a word (20 + 12 bits)
 constexpr uint32_t kCsOrderBucketMaxTau = 1u << 12;
 
-inline size_t cs_order_bucket_lds_bytes(int lists_cap, int q, size_t coarse_cap) {
-	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + 3 + cs_order_tau(lists_cap) + ((size_t) 1 << kCsOrderBucketLog2Max) + 1 + 4) * 4;
+inline size_t cs_order_bucket_lds_bytes(int lists_cap, int q, size_t coarse_cap, int log2_buckets) {
+	return ((size_t) lists_cap * 3 + 2 + (size_t) (q + 3) / 4 + (coarse_cap + 1) / 2 + 3 + cs_order_tau(lists_cap) + ((size_t) 1 << log2_buckets) + 1 + 4) * 4;
 }
 
 // info[2 * i + 1] of listed read i: 0 = order determined | 2 more hits than the slice (or than 2^20) | 4 more votes than tau holds | 6 item table
@@ -85,7 +88,8 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 		}
 		int log2_nb = 6;
 		const int log2_nb_max = min(kCsOrderBucketLog2Max, max(6, A.log2_bits));   // (A.log2_bits: the host's limit -- kCsOrderBucketLog2Max unless a test asks for crowded buckets)
-		while (log2_nb < log2_nb_max && (8u << log2_nb) < H) ++log2_nb;   // ~8 hits per bucket where the LDS allows it
+		const uint32_t fill = A.order_gcap ? A.order_gcap : 4u;   // hits per bucket aimed at
+		while (log2_nb < log2_nb_max && (fill << log2_nb) < H) ++log2_nb;
 		const uint32_t nb = 1u << log2_nb;
 		for (uint32_t b = tid; b <= nb; b += NT) bk[b] = 0;
 		for (uint32_t v = tid; v < n_tau; v += NT) tau[v] = 0xFFFFFFFFu;

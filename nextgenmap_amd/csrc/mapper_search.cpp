@@ -594,7 +594,9 @@ int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 	// leaves (bisulfite runs, a read with more hits than a slice) goes on to the replay with a table in global memory below.
 	static const bool buckets_on = getenv("NGM_HIP_ORDER_NO_BUCKETS") == nullptr;
 	const size_t bucket_coarse_cap = cs_heavy2_coarse_cap(m->order_args.lists_cap, m->order_args.max_kfreq);
-	const size_t bucket_lds = cs_order_bucket_lds_bytes(m->order_args.lists_cap, m->order_args.q, bucket_coarse_cap);
+	int bucket_log2 = (int) test_limit("order_buckets_log2", kCsOrderBucketLog2Max);   // (most buckets of a read: what the LDS holds beside the lists)
+	while (bucket_log2 > 13 && cs_order_bucket_lds_bytes(m->order_args.lists_cap, m->order_args.q, bucket_coarse_cap, bucket_log2) > (size_t) kLdsAttr) --bucket_log2;
+	const size_t bucket_lds = cs_order_bucket_lds_bytes(m->order_args.lists_cap, m->order_args.q, bucket_coarse_cap, std::max(bucket_log2, 6));
 	const bool buckets_fit = buckets_on && !m->order_args.bs && cs_order_tau(m->order_args.lists_cap) <= kCsOrderBucketMaxTau && bucket_lds <= (size_t) kLdsAttr;
 	if (!big.empty() && buckets_fit) {
 		const uint32_t nb = (uint32_t) big.size();
@@ -603,8 +605,8 @@ int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		for (uint32_t j = 0; j < nb; ++j) reads[j] = m->order_pending[big[j]];
 		CsArgs B = m->order_args;
 		B.order_info = nullptr; B.order_scratch = nullptr; B.order_max_hits = 0;
-		B.order_gcap = 0;
-		B.log2_bits = (int) test_limit("order_buckets_log2", kCsOrderBucketLog2Max);   // (most buckets of a read)
+		B.order_gcap = (uint32_t) test_limit("order_bucket_fill", 4);   // (cs_order_bucket_kernel reads it as the hits per bucket it aims at)
+		B.log2_bits = bucket_log2;
 		auto kern = cs_order_bucket_kernel<kCsOrderBucketThreads>;
 		if (bucket_lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bucket_lds);
 		// ONE workgroup per CU: its eight waves leave the CU's other wave slots and LDS to the search kernels of the other mapper instances,
