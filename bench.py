@@ -793,7 +793,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--personality", choices=["affine", "linear"], default="affine")
     ap.add_argument("--no-reference-rerun", action="store_true", help="skip the second -t N run of the reference program (its own run-to-run differences)")
-    ap.add_argument("--heavy-tail-workers", type=int, default=8, help="mapper instances per GPU of the heavy-tailed leg (round 5: its kernels are 0.65-0.8 of a step with four, the heavy reads take three host round trips per batch; measured 2.52 M reads/s with 4, 2.49 with 6, 2.70 with 8, 2.57 with 12)")
+    ap.add_argument("--heavy-tail-workers", type=int, default=4, help="mapper instances per GPU of the heavy-tailed leg (round 6, a search being one enqueue and pass 3 of the pair selection light: reads drawn uniformly 3.35 / 3.51 / 3.34 / 3.38 / 3.30 / 3.16 M reads/s with 2 / 3 / 4 / 5 / 8 / 12 instances, stress sub-leg 1.20 / 1.24 / 1.23 / 1.23 M with 4 / 6 / 8 / 12, ngm-hip on 10 M reads 2.14 / 2.47 / 2.61 / 2.19 / 2.27 M with 2 / 3 / 4 / 5 / 8; round 5 needed 8)")
     ap.add_argument("--workers", type=int, default=3, help="mapper instances (streams + host threads) per GPU (round 6, one box, 20 steps each: 2 / 3 / 4 instances 43.7 / 53.4 / 52.4 M reads/s -- a batch's host stages are 10-12 ms of its 20-24 ms, so two instances leave the GPU idle a third of the time)")
     ap.add_argument("--read-sets", type=int, default=4, help="distinct sets of reads-per-step reads the timed steps rotate through (step i maps set i mod this)")
     ap.add_argument("--read-len", type=int, default=150, help="read length (150: BASELINE config #2/#3; 250: config #5's shape)")

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 ap = argparse.ArgumentParser()
 ap.add_argument("--mbp", type=float, default=3100.0)
 ap.add_argument("--steps", type=int, default=8)
-ap.add_argument("--workers", type=int, default=8)
+ap.add_argument("--workers", type=int, default=4)
 ap.add_argument("--reads", type=int, default=1 << 20)
 ap.add_argument("--cpu-reads", type=int, default=400_000)
 ap.add_argument("--no-cpu-baseline", action="store_true")
