@@ -205,14 +205,16 @@ __device__ __forceinline__ void cs_order_bucket_body(const CsArgs &A, uint32_t n
 					const uint32_t bs = live ? bk[bkt] - p_c : (uint32_t) lane, be = live ? bk[bkt + 1u] - p_c : (uint32_t) lane;   // this lane's bucket inside the window
 					const uint32_t longest = (uint32_t) wave_reduce_max((int) (be - bs));
 					uint32_t v = 1;
+					// (no bound on the walk: a lane beyond the bucket's end -- the permute takes the lane number modulo 64, and fewer than 64 steps
+					// never come round to the own bucket again -- holds a hit of ANOTHER bucket, whose key differs, or nothing)
+					const uint32_t a0 = bs << 2;
 					for (uint32_t j0 = 0; j0 < longest; j0 += 8u) {
 						uint32_t k2[8], t2[8];
+						const uint32_t a1 = a0 + (j0 << 2);
 #pragma unroll
 						for (int u = 0; u < 8; ++u) {
-							const uint32_t at = bs + j0 + (uint32_t) u;
-							const uint32_t src = at < be ? at : (uint32_t) lane;   // (beyond the bucket: this lane itself, whose time is not below its own)
-							k2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) key);
-							t2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) t);
+							k2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (a1 + 4u * (uint32_t) u), (int) key);
+							t2[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (a1 + 4u * (uint32_t) u), (int) t);
 						}
 #pragma unroll
 						for (int u = 0; u < 8; ++u) v += (k2[u] == key && t2[u] < t) ? 1u : 0u;
