@@ -611,6 +611,7 @@ int candidate_order_finish(ngm_mapper *m, hipStream_t ost, uint64_t np) {
 		if (bucket_lds > 64 * 1024) (void) hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bucket_lds);
 		// ONE workgroup per CU: its eight waves leave the CU's other wave slots and LDS to the search kernels of the other mapper instances,
 		// which run at the same time (measured at 3.1 Gbp, four instances: 2.63 M reads/s with one, 2.54 M with the two that fit)
+		// (round 6, four instances, same box: reads drawn uniformly 3.49 / 3.48 M with one / two, stress sub-leg 1.31 / 1.24 M)
 		// elements of a workgroup's slice: the most hits a read of this run can have (a list per k-mer and strand, none longer than max_kfreq) --
 		// not the most of THIS list: every new maximum would be a hipFree + hipMalloc, two device-wide synchronisations, in the middle of the run
 		uint64_t cap = std::min<uint64_t>(kCsOrderBucketMaxHits, (((uint64_t) (B.lists_cap / 2) * (uint64_t) std::max(B.max_kfreq, 1)) + 63) & ~63ull);
