@@ -48,6 +48,7 @@ Q, C, READ_LEN, KMER = 152, 27, 150, 13
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # roofline.traffic: the committed PMC pass of this round's default workload, and the kernel instance that workload launches (mapper.cpp cs_canon_fn)
 PMC_TRAFFIC_FILE = "r06_mapping_pe_affine_pmc_traffic.json"
+HEAVY_CS_TRAFFIC_SEARCHES = 4   # mapper instances of the PMC passes (profiles/tools/heavy_leg_only.py): their step of 1 048 576 reads is this many searches
 HEAVY_CS_TRAFFIC_FILE = "r06_heavy_tail_%s_cs_traffic.json"   # per sub-leg (uniform / repeats): profiles/summarize_rocprof.py, from PMC passes of profiles/tools/heavy_leg_only.py --only ...
 CS_DEFAULT_KERNEL = "ngm::cs_canon_kernel<3, 6, 2, 1, 7, true>"
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -593,18 +594,32 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
                    "sw_score": (km[2], n_cand * (Q + Q + C + 4), "sw_*score*_kernel (BatchScore): B_score = q + (q + c) + 4 bytes per pair"),
                    "sw_align": (km[5] + km[6], n_aln * (Q + Q + C + 8 + 4 * (2 * Q + C + 1)), "sw_*align*_kernel + traceback (BatchAlign): B_align = q + (q + c) + 8 + 4 (2q + c + 1) bytes per pair")}
         dom = max(kernels, key=lambda k_: kernels[k_][0])
-        dom_ms, dom_bytes, dom_note = kernels[dom]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = traffic_source = None
-        if dom == "candidate_search":
-            fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", HEAVY_CS_TRAFFIC_FILE % ("uniform" if share == 0.0 else "repeats"))
-            try:
-                with open(fn) as f:
-                    tj = json.load(f)
-                traffic = int(tj["candidate_search_bytes_per_batch"]) * W   # (a step = W searches of R / W reads, as in the PMC pass)
-                traffic_source = "profiles/" + os.path.basename(fn) + " [candidate_search_bytes_per_batch x %d searches per step]" % W
-            except (OSError, ValueError, KeyError):
-                pass
+
+        def roof(name):
+            k_ms, k_bytes, k_note = kernels[name]
+            achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            traffic = traffic_source = None
+            if name == "candidate_search":
+                fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", HEAVY_CS_TRAFFIC_FILE % ("uniform" if share == 0.0 else "repeats"))
+                try:
+                    with open(fn) as f:
+                        tj = json.load(f)
+                    if R == 1 << 20:   # (the PMC pass's step: HEAVY_CS_TRAFFIC_SEARCHES searches of 1 048 576 reads in all -- the bytes do not depend on how a step is cut)
+                        traffic = int(tj["candidate_search_bytes_per_batch"]) * HEAVY_CS_TRAFFIC_SEARCHES
+                        traffic_source = "profiles/" + os.path.basename(fn) + " [candidate_search_bytes_per_batch x %d searches per step of the PMC pass]" % HEAVY_CS_TRAFFIC_SEARCHES
+                except (OSError, ValueError, KeyError):
+                    pass
+            return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "traffic_over_algorithmic": (traffic / k_bytes) if traffic and k_bytes else None,
+                    "kernel": name, "kernel_note": k_note, "kernel_ms_per_step": float(k_ms), "bytes_per_step": int(k_bytes)}
+        roofline = roof(dom)
+        roofline["note"] = ("the kernel group with the largest GPU time per step of THIS workload; achieved = its algorithmic bytes (SURVEY.md 8d) / its HIP-event "
+                            "time on the launch streams (summed over the mapper instances); traffic = HBM bytes per step of the same group from this round's committed "
+                            "rocprofv3 PMC passes of this sub-leg (FETCH_SIZE / WRITE_SIZE in separate passes, profiles/summarize_rocprof.py), per search x the "
+                            "searches of a step -- not measured in this run"
+                            + ("" if dom == "candidate_search" else "; the score kernels are VALU-bound (sw_gcells_per_s), candidate search is priced beside it under `candidate_search`"))
+        if dom != "candidate_search":
+            roofline["candidate_search"] = roof("candidate_search")
         nr = max(1, pc["reads"])
         ms_step = elapsed / steps * 1e3
         all_k = float(km[:7].sum())
@@ -621,13 +636,7 @@ def heavy_tail_leg(args, dev, local_rank, paired, affine, sens, workdir):
                "gpu_kernels_fraction_of_step": {"stage_kernels": all_k / ms_step, "with_order_replay": (all_k + km[8]) / ms_step},
                "sw_gcells_per_s": {"score_kernel": n_cand * READ_LEN * band / (km[2] * 1e-3) / 1e9 if km[2] > 0 else None,
                                    "align_kernel": n_aln * READ_LEN * band / (km[5] * 1e-3) / 1e9 if km[5] > 0 else None},
-               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                            "traffic_over_algorithmic": (traffic / dom_bytes) if traffic and dom_bytes else None,
-                            "kernel": dom, "kernel_note": dom_note, "kernel_ms_per_step": float(dom_ms), "bytes_per_step": int(dom_bytes),
-                            "note": "the kernel group with the largest GPU time per step of THIS workload; achieved = its algorithmic bytes (SURVEY.md 8d) / its HIP-event "
-                                    "time on the launch streams (summed over the mapper instances); traffic = HBM bytes per step of the same group from this round's committed "
-                                    "rocprofv3 PMC passes of this sub-leg (FETCH_SIZE / WRITE_SIZE in separate passes, profiles/summarize_rocprof.py), per search x the "
-                                    "searches of a step -- not measured in this run"},
+               "roofline": roofline,
                "accuracy": {"mapped": float(mapped.mean()), "within_band_of_truth": float(correct.mean()), "mapq_gt0": float((hits["mapq"] > 0).mean())},
                "setup_s": {"read_sets": t_reads}}
         if with_cpu:
