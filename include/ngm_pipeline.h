@@ -267,6 +267,15 @@ int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]);
  * table in global memory (cs_order_kernel<true>) -- bisulfite runs, a read with a bucket of more than 256 hits, NGM_HIP_ORDER_NO_BUCKETS */
 int ngm_mapper_order_table_reads(ngm_mapper *m, uint64_t *out);
 
+/* Host-only debug / test entry (no GPU needed): what pass 3 of the pair selection does per tied pair -- ScoreBuffer::top1PE's two sorts
+ * (src/ScoreBuffer.cpp:373-376: std::sort(sortLocationScore) on the candidate lists in CollectResultsStd's order, here given by `rank`),
+ * computeMQ (:34-49), and the CheckPairs double loop (:405-413, :463-502) over the candidates at or above best * cutoff, restricted to
+ * the insert-size window.  Candidates of mate a are entries [0, cnt_a) of loc / sv / score / rank, those of mate b [cnt_a, cnt_a + cnt_b).
+ * rank may be NULL (no candidate order: any deterministic order).  Returns 0, or a negative error code. */
+int ngm_debug_pair_walk(uint32_t cnt_a, int len_a, uint32_t cnt_b, int len_b, const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank,
+		float cutoff, int min_insert, int max_insert, uint32_t *out_a, uint32_t *out_b, int *mq_a, int *mq_b, uint64_t cap, float *combo_score, int *combo_dist, int *combo_a, int *combo_b,
+		uint64_t *n_combo);
+
 /* test hook: ScoreBuffer::top1SE + computeMQ (src/ScoreBuffer.cpp:228-277, :34-49) as the score stage runs it (select_top1_kernel) over
  * host arrays: read i owns candidates [base[i], base[i] + count[i]); out: winner (candidate index, 0xFFFFFFFF: none), MAPQ, number of
  * best-scoring candidates, best score.  tests/test_gpu_select.py compares it with the reference's sequential loop. */

@@ -370,7 +370,7 @@ extern "C++" {
 static std::atomic<bool> g_walk_probe{false};
 static std::atomic<uint64_t> g_walk_ns[6];
 template <typename F>
-static void walk_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
+static void walk_pair(const ngm_mapper_params &prm, uint32_t base_a, uint32_t cnt_a, int len_a, uint32_t base_b, uint32_t cnt_b, int len_b,
 		const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank, int *mq_a, int *mq_b, F &&f) {
 	auto mq_of = [&](const uint32_t *v, uint32_t cnt) {  // computeMQ(MappedRead*), ScoreBuffer.cpp:42-49
 		if (cnt <= 1) return 60;
@@ -393,14 +393,14 @@ static void walk_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a,
 		g_walk_ns[1] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count(); g_walk_ns[2] += cnt; g_walk_ns[3] += *na + *nb; g_walk_ns[4] += *nv; g_walk_ns[5] += 1; } };
 	if (tm) g_walk_ns[0] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(t_1 - t_0).count();
 	*mq_a = mq_of(A, cnt_a); *mq_b = mq_of(B, cnt_b);
-	const float cutoff = m->prm.pair_score_cutoff > 0 ? m->prm.pair_score_cutoff : 0.9f;
+	const float cutoff = prm.pair_score_cutoff > 0 ? prm.pair_score_cutoff : 0.9f;
 	const float min_a = score[A[0]] * cutoff, min_b = score[B[0]] * cutoff;
 	size_t na = 1, nb = 1;
 	while (na < cnt_a && min_a <= score[A[na]]) ++na;
 	while (nb < cnt_b && min_b <= score[B[nb]]) ++nb;
 	uint64_t pna = na, pnb = nb, n_visits = 0;
 	WalkProbe probe{tm, t_1, (uint64_t) cnt_a + cnt_b, &pna, &pnb, &n_visits};
-	const int min_d = m->prm.min_insert_size, max_d = m->prm.max_insert_size > 0 ? m->prm.max_insert_size : INT_MAX;
+	const int min_d = prm.min_insert_size, max_d = prm.max_insert_size > 0 ? prm.max_insert_size : INT_MAX;
 	// Mates with hundreds of candidates each (repeat families of a GRCh38-like genome): CheckPairs walks all na x nb combinations,
 	// but only those inside the insert-size window do anything -- B's candidates sorted by position, per candidate of A the ones
 	// within max_d, visited in increasing j like the reference's inner loop: the same sequence of in-window pairs, so every
@@ -412,7 +412,17 @@ static void walk_pair(ngm_mapper *m, uint32_t base_a, uint32_t cnt_a, int len_a,
 		const int cur = (int) ((l2 > l1) ? l2 - l1 + (uint64_t) len_b : l1 - l2 + (uint64_t) len_a);
 		if (cur > min_d && cur < max_d) f(score[A[i]] + score[B[j]], cur, (int) A[i], (int) B[j]);
 	};
-	if (!windowed) {
+	// (the reference's insert size is an `int` made from a 64-bit difference, ScoreBuffer.cpp:467-473: two locations at opposite ends of the
+	// 32-bit range come out as a small number.  No genome ngm-hip accepts puts candidates there, but the window by location would miss what
+	// the double loop counts: such lists take the double loop)
+	bool wraps = false;
+	if (windowed) {
+		uint32_t l_min = 0xFFFFFFFFu, l_max = 0;
+		for (size_t i = 0; i < na; ++i) { l_min = std::min(l_min, loc[A[i]]); l_max = std::max(l_max, loc[A[i]]); }
+		for (size_t j = 0; j < nb; ++j) { l_min = std::min(l_min, loc[B[j]]); l_max = std::max(l_max, loc[B[j]]); }
+		wraps = (uint64_t) (l_max - l_min) + (uint64_t) std::max(len_a, len_b) >= (1ull << 32);
+	}
+	if (!windowed || wraps) {
 		for (size_t i = 0; i < na; ++i) for (size_t j = 0; j < nb; ++j) visit(i, j);
 		return;
 	}
@@ -511,7 +521,7 @@ static void select_pair(ngm_mapper *m, const long dist_sum, const long dist_coun
 	float combo_s[64];  // pair score, insert size and candidates of every pair inside the insert-size window
 	int combo_d[64], combo_a[64], combo_b[64];
 	const int avg = (int) (dist_sum / std::max(1L, dist_count));
-	walk_pair(m, base_a, cnt_a, len_a, base_b, cnt_b, len_b, loc, sv, score, rank, mq_a, mq_b, [&](float ps, int cur, int ia, int ib) {
+	walk_pair(m->prm, base_a, cnt_a, len_a, base_b, cnt_b, len_b, loc, sv, score, rank, mq_a, mq_b, [&](float ps, int cur, int ia, int ib) {
 		if (n_combo < 64) { combo_s[n_combo] = ps; combo_d[n_combo] = cur; combo_a[n_combo] = ia; combo_b[n_combo] = ib; }
 		++n_combo;
 		bool take = false;
@@ -947,7 +957,7 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				// whatever the mean -- its `top` is the maximum so far, starting at 0 -- and a pair of two satellite-array mates has
 				// hundreds of thousands of them)
 				float top = 0.0f;
-				walk_pair(m, m->h_base[ra], m->h_count[ra], len_of(ra), m->h_base[rb], m->h_count[rb], len_of(rb), h_loc, h_sv, h_scores, h_rank_pe, &sq.mq_a, &sq.mq_b,
+				walk_pair(m->prm, m->h_base[ra], m->h_count[ra], len_of(ra), m->h_base[rb], m->h_count[rb], len_of(rb), h_loc, h_sv, h_scores, h_rank_pe, &sq.mq_a, &sq.mq_b,
 						[&](float ps, int cur, int ia, int ib) {
 							if (ps < top) return;
 							top = ps;
@@ -1469,6 +1479,28 @@ int ngm_mapper_path_counters(ngm_mapper *m, uint64_t out[8]) {
 	if (!m || !out) return -22;
 	out[0] = m->st_reads; out[1] = m->st_cands; out[2] = m->st_exact_lds; out[3] = m->st_exact_global;
 	out[4] = m->st_order_reads; out[5] = m->st_order_big; out[6] = m->st_order_unknown; out[7] = m->st_heavy;
+	return 0;
+}
+
+// Debug / test entry, host only (no GPU): the part of top1PE that pass 3 of the pair selection runs per tied pair -- both candidate lists
+// sorted as the reference sorts them (candidate order from `rank`, then std::sort by score), the MAPQs, and the in-window combinations of
+// the candidates above the cut-off in the order of the reference's double loop.  out_a / out_b: the sorted lists (indices into loc / sv /
+// score / rank; cnt_a and cnt_b entries); combo_*: at most `cap` combinations, *n_combo their number (all of them counted).
+// tests/test_pair_walk.py compares it with a restatement of libstdc++'s std::sort and the plain double loop.
+int ngm_debug_pair_walk(uint32_t cnt_a, int len_a, uint32_t cnt_b, int len_b, const uint32_t *loc, const uint32_t *sv, const float *score, const uint32_t *rank,
+		float cutoff, int min_insert, int max_insert, uint32_t *out_a, uint32_t *out_b, int *mq_a, int *mq_b, uint64_t cap, float *combo_score, int *combo_dist, int *combo_a, int *combo_b,
+		uint64_t *n_combo) {
+	if (!cnt_a || !cnt_b || !loc || !sv || !score || !out_a || !out_b || !mq_a || !mq_b || !n_combo) { ngm::pipeline_set_error("ngm_debug_pair_walk: bad arguments"); return -1; }
+	ngm_mapper_params prm{};
+	prm.pair_score_cutoff = cutoff; prm.min_insert_size = min_insert; prm.max_insert_size = max_insert;
+	sort_like_reference(out_a, 0, cnt_a, loc, sv, score, rank);
+	sort_like_reference(out_b, cnt_a, cnt_b, loc, sv, score, rank);
+	uint64_t n = 0;
+	walk_pair(prm, 0, cnt_a, len_a, cnt_a, cnt_b, len_b, loc, sv, score, rank, mq_a, mq_b, [&](float ps, int cur, int ia, int ib) {
+		if (n < cap && combo_score && combo_dist && combo_a && combo_b) { combo_score[n] = ps; combo_dist[n] = cur; combo_a[n] = ia; combo_b[n] = ib; }
+		++n;
+	});
+	*n_combo = n;
 	return 0;
 }
 
