@@ -276,6 +276,12 @@ int ngm_debug_pair_walk(uint32_t cnt_a, int len_a, uint32_t cnt_b, int len_b, co
 		float cutoff, int min_insert, int max_insert, uint32_t *out_a, uint32_t *out_b, int *mq_a, int *mq_b, uint64_t cap, float *combo_score, int *combo_dist, int *combo_a, int *combo_b,
 		uint64_t *n_combo);
 
+/* Host-only debug / test entry: the double loop of ScoreBuffer::top1PE over CheckPairs (src/ScoreBuffer.cpp:405-413, :463-502) at the running
+ * mean insert size `avg`, on a given sequence of in-window combinations (pair score, insert size, candidate of a, candidate of b) -- on all
+ * of them (out_all) and on the ones the product keeps for its sequential pass (out_kept: those that reach the running maximum of the pair
+ * score).  out[6] = {found, winner of a, winner of b, equal-score-and-insert-size count, insert size, combinations evaluated}. */
+int ngm_debug_pair_eval(uint64_t n, const float *pair_score, const int *dist, const int *ia, const int *ib, int avg, int out_all[6], int out_kept[6]);
+
 /* test hook: ScoreBuffer::top1SE + computeMQ (src/ScoreBuffer.cpp:228-277, :34-49) as the score stage runs it (select_top1_kernel) over
  * host arrays: read i owns candidates [base[i], base[i] + count[i]); out: winner (candidate index, 0xFFFFFFFF: none), MAPQ, number of
  * best-scoring candidates, best score.  tests/test_gpu_select.py compares it with the reference's sequential loop. */

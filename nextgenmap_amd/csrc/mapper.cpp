@@ -475,6 +475,18 @@ struct PairSeq {
 	std::vector<int> d, a, b;
 	int mq_a = 0, mq_b = 0;
 };
+// what build_seq hands walk_pair: a combination is kept unless eval_pair_seq passes over it whatever the running mean -- its `top` is the
+// maximum of the pair scores so far, starting at 0, and a combination below it takes neither branch (a pair of two satellite-array
+// mates has hundreds of thousands of those)
+struct PairSeqKeeper {
+	PairSeq &sq;
+	float top = 0.0f;
+	void operator()(float ps, int cur, int ia, int ib) {
+		if (ps < top) return;
+		top = ps;
+		sq.ps.push_back(ps); sq.d.push_back(cur); sq.a.push_back(ia); sq.b.push_back(ib);
+	}
+};
 struct PairOutcome { int wa, wb, mqa, mqb, equal, dist; bool found; };
 // the double loop of top1PE over CheckPairs (src/ScoreBuffer.cpp:405-413, :463-502) at running mean `avg`
 static PairOutcome eval_pair_seq(const PairSeq &q, int avg) {
@@ -956,13 +968,8 @@ static int map_impl(ngm_mapper *m, int n, const char *reads, const void *d_reads
 				// (only the combinations that reach the running maximum of the pair score are kept: eval_pair_seq does nothing at the others
 				// whatever the mean -- its `top` is the maximum so far, starting at 0 -- and a pair of two satellite-array mates has
 				// hundreds of thousands of them)
-				float top = 0.0f;
 				walk_pair(m->prm, m->h_base[ra], m->h_count[ra], len_of(ra), m->h_base[rb], m->h_count[rb], len_of(rb), h_loc, h_sv, h_scores, h_rank_pe, &sq.mq_a, &sq.mq_b,
-						[&](float ps, int cur, int ia, int ib) {
-							if (ps < top) return;
-							top = ps;
-							sq.ps.push_back(ps); sq.d.push_back(cur); sq.a.push_back(ia); sq.b.push_back(ib);
-						});
+						PairSeqKeeper{sq});
 			};
 			parallel_for((int) picked.size(), [&](int lo, int hi) { for (int x = lo; x < hi; ++x) { build_seq(seqs[x], tied[picked[x]].pi); tied[picked[x]].seq = x; } }, 8);
 			qlap(2);
@@ -1501,6 +1508,25 @@ int ngm_debug_pair_walk(uint32_t cnt_a, int len_a, uint32_t cnt_b, int len_b, co
 		++n;
 	});
 	*n_combo = n;
+	return 0;
+}
+
+// Debug / test entry, host only: the double loop of top1PE over CheckPairs at running mean `avg` (eval_pair_seq) on a given sequence of
+// in-window combinations -- once on all of them, once on what PairSeqKeeper keeps.  out[6]: found, winner of a, winner of b, pairs of
+// equal score and insert size, insert size, combinations evaluated.
+int ngm_debug_pair_eval(uint64_t n, const float *pair_score, const int *dist, const int *ia, const int *ib, int avg, int out_all[6], int out_kept[6]) {
+	if ((n && (!pair_score || !dist || !ia || !ib)) || !out_all || !out_kept) { ngm::pipeline_set_error("ngm_debug_pair_eval: bad arguments"); return -1; }
+	PairSeq all, kept;
+	PairSeqKeeper keep{kept};
+	for (uint64_t x = 0; x < n; ++x) {
+		all.ps.push_back(pair_score[x]); all.d.push_back(dist[x]); all.a.push_back(ia[x]); all.b.push_back(ib[x]);
+		keep(pair_score[x], dist[x], ia[x], ib[x]);
+	}
+	auto put = [](const PairSeq &q, int avg_, int *o) {
+		const PairOutcome r = eval_pair_seq(q, avg_);
+		o[0] = r.found ? 1 : 0; o[1] = r.wa; o[2] = r.wb; o[3] = r.equal; o[4] = r.dist; o[5] = (int) q.ps.size();
+	};
+	put(all, avg, out_all); put(kept, avg, out_kept);
 	return 0;
 }
 

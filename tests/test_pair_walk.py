@@ -291,3 +291,58 @@ def test_pair_walk_without_ranks_with_repeated_ranks_and_other_windows():
         rank = np.concatenate([order * 2, order * 2 + 1]).astype(np.uint32)
         heaps, _ = run_case(lib, n, n, loc, np.zeros(2 * n, np.uint32), score, rank, cutoff=0.999)
         assert heaps > 0 or shape != "pipe"   # (the organ pipe spends the depth limit: the heap sort is compared too)
+
+
+def check_pairs_loop(ps, d, a, b, avg):
+    """ScoreBuffer::top1PE's double loop over CheckPairs (src/ScoreBuffer.cpp:397-413, :475-498), on the combinations inside the insert-size
+    window in the loop's order; pairDistSum / pairDistCount = avg"""
+    top, distance, equal, t1, t2 = np.float32(0.0), 0, 0, -1, -1
+    for x in range(len(ps)):
+        s, cur = np.float32(ps[x]), int(d[x])
+        take = False
+        if s > top * np.float32(1.0):
+            top, distance, take = s, cur, True
+        elif s == top:
+            if abs(distance - avg) > abs(cur - avg):
+                top, distance, take = s, cur, True
+            elif abs(distance) == abs(cur):
+                equal += 1
+        if take:
+            t1, t2 = int(a[x]), int(b[x])
+    return [1, t1, t2, equal, distance] if top > 0 else [0, -1, -1, 0, 0]
+
+
+def test_pair_evaluation_on_all_and_on_the_kept_combinations():
+    """eval_pair_seq (the sequential pass's scan) against the reference's loop, on every combination and on the ones the product keeps --
+    those that reach the running maximum of the pair score: the others change nothing whatever the running mean"""
+    lib = _lib()
+    lib.ngm_debug_pair_eval.restype = C.c_int
+    lib.ngm_debug_pair_eval.argtypes = [C.c_uint64] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 2
+    rng = np.random.default_rng(20261001)
+    kept_total = all_total = 0
+    for case in range(400):
+        n = int(rng.choice([0, 1, 2, 7, 64, 500, 5000]))
+        kind = case % 5
+        if kind == 0:
+            ps = rng.choice([2800.0, 2790.0, 2785.0, 2700.0], n)                # a repeat family: a handful of pair scores
+        elif kind == 1:
+            ps = np.full(n, 2468.0)                                             # all equal
+        elif kind == 2:
+            ps = rng.choice([0.0, -5.0, -20.0], n)                              # nothing positive: no pair
+        elif kind == 3:
+            ps = np.sort(rng.integers(1, 3000, n)).astype(np.float64)           # a new maximum nearly every time
+        else:
+            ps = rng.integers(-10, 40, n).astype(np.float64)                    # around zero, many ties
+        d = rng.integers(1, 1000, n) if case % 2 else rng.choice([300, 350, 400], n)   # (few insert sizes: the equal-size counter counts)
+        ps = np.ascontiguousarray(ps, np.float32); d = np.ascontiguousarray(d, np.int32)
+        a = np.ascontiguousarray(rng.integers(0, 1 << 20, n), np.int32); b = np.ascontiguousarray(rng.integers(0, 1 << 20, n), np.int32)
+        for avg in (int(rng.integers(150, 600)), 350, 0):
+            out_all, out_kept = np.zeros(6, np.int32), np.zeros(6, np.int32)
+            rc = lib.ngm_debug_pair_eval(n, ps.ctypes.data, d.ctypes.data, a.ctypes.data, b.ctypes.data, avg, out_all.ctypes.data, out_kept.ctypes.data)
+            assert rc == 0, lib.ngm_pipeline_last_error()
+            want = check_pairs_loop(ps, d, a, b, avg)
+            assert out_all[:5].tolist() == want, (case, n, avg)
+            assert out_kept[:5].tolist() == want, (case, n, avg)
+            assert out_all[5] == n and out_kept[5] <= n
+            kept_total += int(out_kept[5]); all_total += n
+    assert 0 < kept_total < all_total   # (the filter does drop combinations in these cases)
